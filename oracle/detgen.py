@@ -1,0 +1,105 @@
+"""TEST INFRASTRUCTURE ONLY -- never imported by the product path (yolov5_amd/).
+
+Deterministic, platform-independent data generator (splitmix64 on numpy uint64) used to create
+the synthetic weights / images / predictions / targets that the golden fixtures were made from.
+Because the stream depends only on (seed, element index), the GPU box can regenerate the exact
+inputs without shipping them; only the (small) expected outputs are committed under tests/golden/.
+"""
+from __future__ import annotations
+
+import zlib
+
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        x = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+        z = x
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def key(name: str, seed: int = 0) -> int:
+    """Stable 64-bit stream key from a tensor name and a seed."""
+    return (zlib.crc32(name.encode()) | (seed << 32)) & 0xFFFFFFFFFFFFFFFF
+
+
+def uniform(shape, lo=0.0, hi=1.0, *, name="x", seed=0) -> np.ndarray:
+    """float32 array ~ U[lo, hi) with 24 random mantissa bits per element (exact in fp32)."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    with np.errstate(over="ignore"):
+        base = _splitmix64(np.array([key(name, seed)], dtype=np.uint64))[0]
+        idx = np.arange(n, dtype=np.uint64) * np.uint64(0xD1342543DE82EF95) + base
+    bits = _splitmix64(idx) >> np.uint64(40)  # 24 bits
+    u = bits.astype(np.float64) / float(1 << 24)
+    return (lo + (hi - lo) * u).astype(np.float32).reshape(shape)
+
+
+def integers(shape, lo, hi, *, name="i", seed=0) -> np.ndarray:
+    """int64 array ~ U{lo..hi-1}."""
+    u = uniform(shape, 0.0, 1.0, name=name, seed=seed).astype(np.float64)
+    return np.minimum((lo + np.floor(u * (hi - lo))).astype(np.int64), hi - 1)
+
+
+def fill_state_dict(sd: dict, seed: int = 0) -> dict:
+    """Deterministic replacement values for every tensor of a YOLOv5 state_dict (name -> shape kept).
+
+    conv weights ~ U(-b, b), b = sqrt(6 / fan_in)   (keeps SiLU activations O(1) through 60 layers)
+    bn.weight ~ U(0.8, 1.2); bn.bias, running_mean ~ U(-0.1, 0.1); running_var ~ U(0.8, 1.2)
+    conv bias (fused convs, Detect.m) ~ U(-0.1, 0.1) except Detect objectness/class logits which get a
+    wider U(-3, 1) so that a realistic fraction of rows passes the NMS confidence threshold.
+    Returns {name: np.ndarray}; integer buffers (num_batches_tracked) -> 0; `anchors` are left untouched.
+    """
+    out = {}
+    for name, t in sd.items():
+        shape = tuple(t.shape)
+        if name.endswith("num_batches_tracked"):
+            out[name] = np.zeros(shape, dtype=np.int64)
+        elif name.endswith("anchors") or name.endswith("anchor_grid"):
+            out[name] = None  # keep
+        elif name.endswith("running_var"):
+            out[name] = uniform(shape, 0.8, 1.2, name=name, seed=seed)
+        elif name.endswith("running_mean"):
+            out[name] = uniform(shape, -0.1, 0.1, name=name, seed=seed)
+        elif ".bn." in name and name.endswith("weight"):
+            out[name] = uniform(shape, 0.8, 1.2, name=name, seed=seed)
+        elif name.endswith("bias"):
+            if ".m." in name and ".bn." not in name and len(shape) == 1 and ".cv" not in name:
+                out[name] = uniform(shape, -3.0, 1.0, name=name, seed=seed)  # Detect head bias
+            else:
+                out[name] = uniform(shape, -0.1, 0.1, name=name, seed=seed)
+        elif name.endswith("weight") and len(shape) == 4:
+            fan_in = shape[1] * shape[2] * shape[3]
+            b = float(np.sqrt(6.0 / fan_in))
+            out[name] = uniform(shape, -b, b, name=name, seed=seed)
+        else:
+            out[name] = uniform(shape, -0.1, 0.1, name=name, seed=seed)
+    return out
+
+
+def synth_predictions(bs, n, no, *, obj_pow=8, seed=0, img=640.0) -> np.ndarray:
+    """Synthetic Detect output (bs, n, no) float32 as SURVEY 8d defines for the NMS benchmark.
+
+    xy ~ U(0,img); wh ~ U(4,104); obj = u**obj_pow; cls ~ U(0,1); extra (mask) columns ~ U(-1,1).
+    """
+    p = uniform((bs, n, no), 0.0, 1.0, name=f"pred{obj_pow}", seed=seed)
+    p[..., 0:2] *= img
+    p[..., 2:4] = 4.0 + 100.0 * p[..., 2:4]
+    p[..., 4] = p[..., 4] ** obj_pow
+    return p
+
+
+def synth_targets(bs, per_img, nc=80, *, seed=0) -> np.ndarray:
+    """Synthetic training targets (nt,6) float32 [img, cls, x, y, w, h]."""
+    nt = bs * per_img
+    t = np.zeros((nt, 6), dtype=np.float32)
+    t[:, 0] = np.repeat(np.arange(bs), per_img)
+    t[:, 1] = integers((nt,), 0, nc, name="tcls", seed=seed)
+    t[:, 2:4] = uniform((nt, 2), 0.1, 0.9, name="txy", seed=seed)
+    t[:, 4:6] = uniform((nt, 2), 0.02, 0.32, name="twh", seed=seed)
+    return t

@@ -1,0 +1,238 @@
+"""TEST INFRASTRUCTURE ONLY -- never imported by the product path (yolov5_amd/).
+
+Generates tests/golden/*.npz by running the UNMODIFIED reference (imported from /root/reference via
+oracle/ref_shim.py) on deterministic synthetic inputs (oracle/detgen.py).  Run in the build container:
+
+    python -m oracle.make_golden            # rewrites tests/golden/
+
+Inputs and weights are NOT stored: they are regenerated from (name, seed) by detgen on any machine.
+Only expected outputs (full when small, strided samples + float64 checksums when large) are committed.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import detgen, ref_shim
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def load_det_weights(model, seed=0):
+    """Overwrite every parameter/buffer of a reference model with detgen values (anchors kept)."""
+    sd = model.state_dict()
+    new = detgen.fill_state_dict(sd, seed)
+    for k, v in new.items():
+        if v is not None:
+            sd[k] = torch.from_numpy(v).to(sd[k].dtype)
+    model.load_state_dict(sd)
+    return model
+
+
+def summarize(t: np.ndarray, stride: int):
+    flat = t.reshape(-1, t.shape[-1]).astype(np.float64)
+    return {"rows": t.reshape(-1, t.shape[-1])[::stride].astype(np.float32),
+            "sum": np.array([flat.sum(), np.abs(flat).sum(), (flat * flat).sum()])}
+
+
+def gen_forward(ns, name, yaml_rel, hw, bs, seed, row_stride, seg=False):
+    torch.manual_seed(0)
+    Model = ns.yolo.SegmentationModel if seg else ns.yolo.DetectionModel
+    m = Model(os.path.join(ns.root, yaml_rel))
+    load_det_weights(m, seed)
+    m.eval()
+    x = torch.from_numpy(detgen.uniform((bs, 3, hw, hw), 0.0, 1.0, name="img", seed=seed))
+    out = {"nparams": np.array(sum(p.numel() for p in m.parameters()))}
+    with torch.no_grad():
+        y = m(x)
+        z_unfused = y[0].numpy()
+        raws = y[2] if seg else y[1]
+        m.fuse()
+        y2 = m(x)
+    z_fused = y2[0].numpy()
+    out["anchors"] = m.model[-1].anchors.numpy()
+    out["stride"] = m.model[-1].stride.numpy()
+    if row_stride == 1:
+        out["z_unfused"] = z_unfused
+        out["z_fused"] = z_fused
+        for i, r in enumerate(raws):
+            out[f"raw{i}"] = r.numpy()
+    else:
+        s = summarize(z_unfused, row_stride)
+        out["z_unfused_rows"], out["z_unfused_sum"] = s["rows"], s["sum"]
+        s = summarize(z_fused, row_stride)
+        out["z_fused_rows"], out["z_fused_sum"] = s["rows"], s["sum"]
+    out["row_stride"] = np.array(row_stride)
+    if seg:
+        proto = y2[1].numpy()
+        out["proto_sum"] = np.array([proto.astype(np.float64).sum(), np.abs(proto.astype(np.float64)).sum()])
+        out["proto_sample"] = proto[:, :, ::5, ::5]
+    # Detect grid / anchor_grid exactly as the reference cached them (yolo.py:117-128)
+    det = m.model[-1]
+    for i in range(det.nl):
+        out[f"grid{i}"] = det.grid[i][0, 0].numpy()
+        out[f"anchor_grid{i}"] = det.anchor_grid[i][0, :, 0, 0].numpy()
+    np.savez_compressed(os.path.join(OUT, f"fwd_{name}.npz"), **out)
+    print("fwd", name, z_fused.shape, float(np.abs(z_fused - z_unfused).max()))
+    return m
+
+
+def gen_fuse(ns):
+    from torch import nn
+
+    conv = nn.Conv2d(8, 16, 3, 1, 1, bias=False)
+    bn = nn.BatchNorm2d(16)
+    bn.eps = 1e-3
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(detgen.uniform((16, 8, 3, 3), -0.5, 0.5, name="fw")))
+        bn.weight.copy_(torch.from_numpy(detgen.uniform((16,), 0.5, 1.5, name="fg")))
+        bn.bias.copy_(torch.from_numpy(detgen.uniform((16,), -0.5, 0.5, name="fb")))
+        bn.running_mean.copy_(torch.from_numpy(detgen.uniform((16,), -0.5, 0.5, name="fm")))
+        bn.running_var.copy_(torch.from_numpy(detgen.uniform((16,), 0.5, 1.5, name="fv")))
+        f = ns.torch_utils.fuse_conv_and_bn(conv, bn)
+    np.savez_compressed(os.path.join(OUT, "fuse.npz"), w=f.weight.detach().numpy(), b=f.bias.detach().numpy())
+
+
+NMS_CASES = {
+    # name: (pred kwargs, nms kwargs)
+    "default": (dict(bs=2, n=3000, no=85, obj_pow=8, seed=1), dict(conf_thres=0.25, iou_thres=0.45, max_det=1000)),
+    "sparse": (dict(bs=3, n=2000, no=85, obj_pow=64, seed=2), dict(conf_thres=0.25, iou_thres=0.45, max_det=300)),
+    "val_multilabel": (dict(bs=2, n=600, no=15, obj_pow=2, seed=3),
+                       dict(conf_thres=0.001, iou_thres=0.6, multi_label=True, max_det=300)),
+    "agnostic": (dict(bs=2, n=1500, no=85, obj_pow=4, seed=4), dict(conf_thres=0.25, iou_thres=0.45, agnostic=True, max_det=300)),
+    "classes": (dict(bs=2, n=1500, no=85, obj_pow=4, seed=5), dict(conf_thres=0.25, iou_thres=0.45, classes=[0, 3, 17, 79], max_det=300)),
+    "maxdet": (dict(bs=2, n=4000, no=85, obj_pow=2, seed=6), dict(conf_thres=0.1, iou_thres=0.45, max_det=50)),
+    "masks": (dict(bs=2, n=1500, no=117, obj_pow=4, seed=7), dict(conf_thres=0.25, iou_thres=0.45, max_det=300, nm=32)),
+    "ties": (dict(bs=2, n=3000, no=85, obj_pow=2, seed=8), dict(conf_thres=0.25, iou_thres=0.45, max_det=1000)),
+    "empty": (dict(bs=2, n=500, no=85, obj_pow=64, seed=9), dict(conf_thres=0.999, iou_thres=0.45, max_det=300)),
+    "clustered": (dict(bs=2, n=3000, no=85, obj_pow=3, seed=10), dict(conf_thres=0.25, iou_thres=0.45, max_det=300)),
+    "clustered_agn": (dict(bs=2, n=3000, no=85, obj_pow=3, seed=10),
+                      dict(conf_thres=0.25, iou_thres=0.45, max_det=300, agnostic=True)),
+}
+
+
+def nms_case_pred(name):
+    kw, _ = NMS_CASES[name]
+    p = detgen.synth_predictions(kw["bs"], kw["n"], kw["no"], obj_pow=kw["obj_pow"], seed=kw["seed"])
+    if name == "ties":  # quantise obj and cls so that obj*cls products tie often (fp16-like behaviour)
+        p[..., 4:] = np.round(p[..., 4:] * 16) / 16
+    if name.startswith("clustered"):  # heavy overlap: boxes drawn around 12 centres so that NMS suppresses a lot
+        c = detgen.uniform((12, 2), 80, 560, name="centres", seed=kw["seed"])
+        idx = detgen.integers((kw["bs"], kw["n"]), 0, 12, name="cidx", seed=kw["seed"])
+        p[..., 0:2] = c[idx] + (p[..., 0:2] / 640.0 - 0.5) * 30.0
+        p[..., 2:4] = 60.0 + (p[..., 2:4] - 4.0) * 0.4
+    return p
+
+
+def gen_nms(ns):
+    out = {}
+    with ref_shim.oracle_nms_mode():
+        for name, (kw, nkw) in NMS_CASES.items():
+            p = torch.from_numpy(nms_case_pred(name))
+            res = ns.general.non_max_suppression(p.clone(), **nkw)
+            for i, r in enumerate(res):
+                out[f"{name}_{i}"] = r.numpy().astype(np.float32)
+            print("nms", name, [int(r.shape[0]) for r in res])
+    np.savez_compressed(os.path.join(OUT, "nms.npz"), **out)
+
+
+APPENDIX_A_TARGETS = np.array([[0, 5, .50, .50, .10, .20], [0, 7, .013, .98, .05, .05],
+                               [0, 1, .30625, .70, .40, .40]], dtype=np.float32)
+
+
+def loss_case(name):
+    """(p list as np arrays, targets np) for the named loss fixture."""
+    if name == "appendix_a":  # zero logits at 640^2, bs=1
+        p = [np.zeros((1, 3, s, s, 85), dtype=np.float32) for s in (80, 40, 20)]
+        return p, APPENDIX_A_TARGETS.copy()
+    if name == "synthetic":  # bs=4 at 256^2 -> grids 32/16/8, 8 targets per image + boundary cases
+        p = [detgen.uniform((4, 3, s, s, 85), -3.0, 3.0, name=f"p{s}", seed=11) for s in (32, 16, 8)]
+        t = detgen.synth_targets(4, 8, seed=11)
+        extra = np.array([[1, 2, 0.5, 0.5, 0.25, 0.25],       # exact integer grid coordinates on every level
+                          [2, 3, 0.015, 0.985, 0.06, 0.05],    # near borders: gxy>1 guards + clamp
+                          [3, 4, 0.999, 0.001, 0.10, 0.12],
+                          [0, 5, 0.515625, 0.484375, 0.3, 0.02],  # extreme aspect: fails anchor_t on some anchors
+                          [0, 6, 0.25, 0.75, 0.9, 0.9]], dtype=np.float32)
+        return p, np.concatenate((t, extra), 0)
+    if name == "no_targets":
+        p = [detgen.uniform((2, 3, s, s, 85), -3.0, 3.0, name=f"q{s}", seed=12) for s in (16, 8, 4)]
+        return p, np.zeros((0, 6), dtype=np.float32)
+    raise KeyError(name)
+
+
+def gen_loss(ns):
+    import yaml
+
+    torch.manual_seed(0)
+    m = ns.yolo.DetectionModel(os.path.join(ns.root, "models/yolov5s.yaml"))
+    with open(os.path.join(ns.root, "data/hyps/hyp.scratch-low.yaml")) as f:
+        m.hyp = yaml.safe_load(f)
+    cl = ns.loss.ComputeLoss(m)
+    out = {"anchors": m.model[-1].anchors.numpy()}
+    for name in ("appendix_a", "synthetic", "no_targets"):
+        pn, tn = loss_case(name)
+        p = [torch.from_numpy(a).clone().requires_grad_(True) for a in pn]
+        t = torch.from_numpy(tn)
+        tcls, tbox, indices, anch = cl.build_targets(p, t)
+        loss, items = cl(p, t)
+        loss.backward()
+        out[f"{name}_loss"] = loss.detach().numpy()
+        out[f"{name}_items"] = items.numpy()
+        for i in range(3):
+            out[f"{name}_idx{i}"] = torch.stack(indices[i]).numpy() if indices[i][0].numel() else np.zeros((4, 0), np.int64)
+            out[f"{name}_tbox{i}"] = tbox[i].numpy()
+            out[f"{name}_tcls{i}"] = tcls[i].numpy()
+            out[f"{name}_anch{i}"] = anch[i].numpy()
+            g = p[i].grad.numpy()
+            if g.size > 400000:
+                out[f"{name}_grad{i}_sum"] = np.array([g.astype(np.float64).sum(), np.abs(g.astype(np.float64)).sum()])
+                nz = np.argwhere(np.abs(g[..., :4]).sum(-1) > 0)[:64]
+                out[f"{name}_grad{i}_nzidx"] = nz
+                out[f"{name}_grad{i}_nzrows"] = g[tuple(nz.T)] if len(nz) else np.zeros((0, 85), np.float32)
+            else:
+                out[f"{name}_grad{i}"] = g
+        print("loss", name, loss.item(), items.tolist(), [int(ix[0].numel()) for ix in indices])
+    np.savez_compressed(os.path.join(OUT, "loss.npz"), **out)
+
+
+def gen_mask(ns):
+    protos = torch.from_numpy(detgen.uniform((32, 40, 40), -1.0, 1.0, name="protos", seed=13))
+    coef = torch.from_numpy(detgen.uniform((7, 32), -1.0, 1.0, name="coef", seed=13))
+    xy1 = detgen.uniform((7, 2), 0, 90, name="bx1", seed=13)
+    wh = detgen.uniform((7, 2), 8, 70, name="bwh", seed=13)
+    boxes = torch.from_numpy(np.concatenate((xy1, xy1 + wh), 1))
+    m0 = ns.seg_general.process_mask(protos, coef, boxes, (160, 160), upsample=False)
+    m1 = ns.seg_general.process_mask(protos, coef, boxes, (160, 160), upsample=True)
+    np.savez_compressed(os.path.join(OUT, "mask.npz"), m_noup=np.packbits(m0.numpy().astype(bool)),
+                        m_up=np.packbits(m1.numpy().astype(bool)), shape_noup=np.array(m0.shape), shape_up=np.array(m1.shape))
+    print("mask", m0.shape, m1.shape, float(m1.float().mean()))
+
+
+def gen_scale_boxes(ns):
+    b = detgen.uniform((20, 4), -20, 660, name="sb", seed=14)
+    o = ns.general.scale_boxes((640, 640), torch.from_numpy(b.copy()), (1080, 810)).numpy()
+    o2 = ns.general.scale_boxes((384, 640), torch.from_numpy(b.copy()), (720, 1280)).numpy()
+    np.savez_compressed(os.path.join(OUT, "scale_boxes.npz"), a=o, b=o2)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ns = ref_shim.load()
+    torch.set_num_threads(os.cpu_count() or 1)
+    gen_fuse(ns)
+    gen_forward(ns, "yolov5n_64", "models/yolov5n.yaml", 64, 2, 0, 1)
+    gen_forward(ns, "yolov5s_320", "models/yolov5s.yaml", 320, 2, 1, 41)
+    gen_forward(ns, "yolov5n-seg_64", "models/segment/yolov5n-seg.yaml", 64, 2, 2, 1, seg=True)
+    gen_nms(ns)
+    gen_loss(ns)
+    gen_mask(ns)
+    gen_scale_boxes(ns)
+    sizes = {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT))}
+    print(sizes, sum(sizes.values()))
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,555 @@
+"""TEST INFRASTRUCTURE ONLY -- never imported by the product path (yolov5_amd/).
+
+CPU restatement (torch-CPU fp32 for the floating-point layers, numpy for index/selection work) of
+the reference hot path named by BASELINE.json `north_star`:
+
+    forward (Conv/C3/SPPF/Upsample/Concat/Detect/Segment)  -> models/common.py, models/yolo.py
+    non_max_suppression                                     -> utils/general.py:658-767
+    ComputeLoss (+build_targets)                            -> utils/loss.py:101-247
+    process_mask / crop_mask                                -> utils/segment/general.py:10-51
+    scale_boxes                                             -> utils/general.py:613-626
+    fuse_conv_and_bn                                        -> utils/torch_utils.py:224-254
+
+Every function cites the reference file:line it follows.  The restatement is PINNED two ways:
+(1) `tests/test_oracle_vs_reference.py` runs it against the unmodified reference modules imported through
+`oracle/ref_shim.py` (only where /root/reference exists), and (2) `tests/test_oracle_golden.py` checks it
+against fixtures under tests/golden/ that `oracle/make_golden.py` produced from that same imported
+reference.  The third-party arithmetic underneath the reference (`ultralytics` bbox_iou/xywh2xyxy/..,
+`torchvision.ops.nms`) is absent from /root/reference and from this image -> that layer is
+"PARITY UNPINNED" (see oracle/thirdparty.py); its restatement follows the published upstream algorithm.
+
+Tie / order contracts (SURVEY 8c hazards): NMS sort is stable (equal scores keep the lower row first);
+`tobj[b,a,gj,gi] = iou` with duplicate indices is last-write-wins in build_targets row order.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------------------------------
+# model configs (models/yolov5{n,s,m,l,x}.yaml, models/segment/yolov5*-seg.yaml)
+# --------------------------------------------------------------------------------------------------
+_MULT = {"n": (0.33, 0.25), "s": (0.33, 0.50), "m": (0.67, 0.75), "l": (1.0, 1.0), "x": (1.33, 1.25)}
+_ANCHORS = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]
+
+
+def model_cfg(name: str = "yolov5s", nc: int = 80) -> dict:
+    """Dict equivalent of models/yolov5s.yaml:9-53 (and the -seg variants, models/segment/yolov5s-seg.yaml)."""
+    seg = name.endswith("-seg")
+    size = name.replace("-seg", "")[-1]
+    gd, gw = _MULT[size]
+    backbone = [
+        [-1, 1, "Conv", [64, 6, 2, 2]], [-1, 1, "Conv", [128, 3, 2]], [-1, 3, "C3", [128]],
+        [-1, 1, "Conv", [256, 3, 2]], [-1, 6, "C3", [256]], [-1, 1, "Conv", [512, 3, 2]],
+        [-1, 9, "C3", [512]], [-1, 1, "Conv", [1024, 3, 2]], [-1, 3, "C3", [1024]],
+        [-1, 1, "SPPF", [1024, 5]],
+    ]
+    head = [
+        [-1, 1, "Conv", [512, 1, 1]], [-1, 1, "nn.Upsample", [None, 2, "nearest"]],
+        [[-1, 6], 1, "Concat", [1]], [-1, 3, "C3", [512, False]],
+        [-1, 1, "Conv", [256, 1, 1]], [-1, 1, "nn.Upsample", [None, 2, "nearest"]],
+        [[-1, 4], 1, "Concat", [1]], [-1, 3, "C3", [256, False]],
+        [-1, 1, "Conv", [256, 3, 2]], [[-1, 14], 1, "Concat", [1]], [-1, 3, "C3", [512, False]],
+        [-1, 1, "Conv", [512, 3, 2]], [[-1, 10], 1, "Concat", [1]], [-1, 3, "C3", [1024, False]],
+        [[17, 20, 23], 1, "Segment" if seg else "Detect",
+         ["nc", "anchors", 32, 256] if seg else ["nc", "anchors"]],
+    ]
+    return {"nc": nc, "depth_multiple": gd, "width_multiple": gw, "anchors": [list(a) for a in _ANCHORS],
+            "backbone": backbone, "head": head}
+
+
+def _make_divisible(x, d):
+    return math.ceil(x / d) * d
+
+
+def parse_graph(cfg: dict, ch: int = 3):
+    """Layer list with resolved channels/repeats; follows models/yolo.py:375-458 (parse_model)."""
+    nc, gd, gw = cfg["nc"], cfg["depth_multiple"], cfg["width_multiple"]
+    anchors = cfg["anchors"]
+    na = len(anchors[0]) // 2
+    no = na * (nc + 5)
+    chs, layers, save = [ch], [], []
+    c2 = ch
+    for i, (f, n, m, args) in enumerate(cfg["backbone"] + cfg["head"]):
+        args = [nc if a == "nc" else anchors if a == "anchors" else a for a in args]
+        n = max(round(n * gd), 1) if n > 1 else n  # yolo.py:401
+        spec = {"i": i, "f": f, "type": m}
+        if m in ("Conv", "C3", "SPPF"):
+            c1, c2 = chs[f], args[0]
+            if c2 != no:
+                c2 = _make_divisible(c2 * gw, 8)  # yolo.py:422-423
+            if m == "Conv":
+                k = args[1] if len(args) > 1 else 1
+                s = args[2] if len(args) > 2 else 1
+                p = args[3] if len(args) > 3 else None
+                spec.update(c1=c1, c2=c2, k=k, s=s, p=k // 2 if p is None else p)
+            elif m == "C3":
+                spec.update(c1=c1, c2=c2, n=n, shortcut=args[1] if len(args) > 1 else True)
+            else:
+                spec.update(c1=c1, c2=c2, k=args[1] if len(args) > 1 else 5)
+        elif m == "Concat":
+            c2 = sum(chs[x] for x in f)
+        elif m in ("Detect", "Segment"):
+            spec.update(nc=args[0], anchors=args[1], ch=[chs[x] for x in f])
+            if m == "Segment":
+                spec.update(nm=args[2], npr=_make_divisible(args[3] * gw, 8))  # yolo.py:440-441
+        else:  # nn.Upsample
+            c2 = chs[f]
+        spec["c_out"] = c2
+        layers.append(spec)
+        save.extend(x % i for x in ([f] if isinstance(f, int) else f) if x != -1)
+        if i == 0:
+            chs = []
+        chs.append(c2)
+    return layers, sorted(save)
+
+
+# --------------------------------------------------------------------------------------------------
+# layers (models/common.py)
+# --------------------------------------------------------------------------------------------------
+BN_EPS = 1e-3  # set by ultralytics initialize_weights (models/yolo.py:259) -- restated, see thirdparty.py
+
+
+def fuse_conv_and_bn(w, gamma, beta, mean, var, eps=BN_EPS, conv_bias=None):
+    """utils/torch_utils.py:224-254: W' = diag(g/sqrt(eps+var)) W ; b' = W_bn b_conv + beta - g*mean/sqrt(var+eps)."""
+    co = w.shape[0]
+    w_bn = torch.diag(gamma.div(torch.sqrt(eps + var)))
+    wf = torch.mm(w_bn, w.reshape(co, -1)).view(w.shape)
+    b_conv = torch.zeros(co, dtype=w.dtype) if conv_bias is None else conv_bias
+    b_bn = beta - gamma.mul(mean).div(torch.sqrt(var + eps))
+    bf = torch.mm(w_bn, b_conv.reshape(-1, 1)).reshape(-1) + b_bn
+    return wf, bf
+
+
+def _conv(sd, p, x, k, s, pad, act=True):
+    """models/common.py:74-92 Conv.forward (conv->BN(eval)->SiLU) or forward_fuse (conv+bias->SiLU)."""
+    w = sd[p + ".conv.weight"]
+    if (p + ".bn.weight") in sd:
+        y = F.conv2d(x, w, None, s, pad)
+        y = F.batch_norm(y, sd[p + ".bn.running_mean"], sd[p + ".bn.running_var"], sd[p + ".bn.weight"],
+                         sd[p + ".bn.bias"], False, 0.0, BN_EPS)
+    else:
+        y = F.conv2d(x, w, sd[p + ".conv.bias"], s, pad)
+    return F.silu(y) if act else y
+
+
+def _bottleneck(sd, p, x, shortcut):
+    """models/common.py:164-181 (e=1.0 inside C3, common.py:242): x + cv2(cv1(x)) iff shortcut and c1==c2."""
+    y = _conv(sd, p + ".cv2", _conv(sd, p + ".cv1", x, 1, 1, 0), 3, 1, 1)
+    return x + y if shortcut else y
+
+
+def _c3(sd, p, x, n, shortcut):
+    """models/common.py:230-246: cv3(cat(m(cv1(x)), cv2(x)))."""
+    a = _conv(sd, p + ".cv1", x, 1, 1, 0)
+    for j in range(n):
+        a = _bottleneck(sd, f"{p}.m.{j}", a, shortcut)
+    b = _conv(sd, p + ".cv2", x, 1, 1, 0)
+    return _conv(sd, p + ".cv3", torch.cat((a, b), 1), 1, 1, 0)
+
+
+def _sppf(sd, p, x, k):
+    """models/common.py:318-340: cv2(cat(x, m(x), m(m(x)), m(m(m(x))))) with MaxPool2d(k,1,k//2)."""
+    x = _conv(sd, p + ".cv1", x, 1, 1, 0)
+    y1 = F.max_pool2d(x, k, 1, k // 2)
+    y2 = F.max_pool2d(y1, k, 1, k // 2)
+    y3 = F.max_pool2d(y2, k, 1, k // 2)
+    return _conv(sd, p + ".cv2", torch.cat((x, y1, y2, y3), 1), 1, 1, 0)
+
+
+def _proto(sd, p, x):
+    """models/common.py:1104-1117: cv3(cv2(upsample2x(cv1(x))))."""
+    y = _conv(sd, p + ".cv1", x, 3, 1, 1)
+    y = F.interpolate(y, scale_factor=2, mode="nearest")
+    return _conv(sd, p + ".cv3", _conv(sd, p + ".cv2", y, 3, 1, 1), 1, 1, 0)
+
+
+def make_grid(nx, ny, anchors_i, stride_i, na=3):
+    """models/yolo.py:117-128: grid = (ix-0.5, iy-0.5); anchor_grid = anchors(grid units)*stride."""
+    yv, xv = torch.meshgrid(torch.arange(ny, dtype=torch.float32), torch.arange(nx, dtype=torch.float32), indexing="ij")
+    grid = torch.stack((xv, yv), 2).expand(1, na, ny, nx, 2) - 0.5
+    anchor_grid = (anchors_i * stride_i).view(1, na, 1, 1, 2).expand(1, na, ny, nx, 2)
+    return grid, anchor_grid
+
+
+def detect_head(sd, p, xs, anchors, strides, nc, nm=0, training=False):
+    """models/yolo.py:91-115 Detect.forward. anchors: (nl,na,2) in GRID units (after yolo.py:254)."""
+    na = anchors.shape[1]
+    no = nc + 5 + nm
+    z, raw = [], []
+    for i, x in enumerate(xs):
+        x = F.conv2d(x, sd[f"{p}.m.{i}.weight"], sd[f"{p}.m.{i}.bias"])
+        bs, _, ny, nx = x.shape
+        x = x.view(bs, na, no, ny, nx).permute(0, 1, 3, 4, 2).contiguous()
+        raw.append(x)
+        if not training:
+            grid, ag = make_grid(nx, ny, anchors[i], strides[i], na)
+            if nm:  # Segment: mask coefficients are NOT sigmoided (yolo.py:104-108)
+                xy, wh, conf, mask = x.split((2, 2, nc + 1, nm), 4)
+                xy = (xy.sigmoid() * 2 + grid) * strides[i]
+                wh = (wh.sigmoid() * 2) ** 2 * ag
+                y = torch.cat((xy, wh, conf.sigmoid(), mask), 4)
+            else:
+                xy, wh, conf = x.sigmoid().split((2, 2, nc + 1), 4)
+                xy = (xy * 2 + grid) * strides[i]
+                wh = (wh * 2) ** 2 * ag
+                y = torch.cat((xy, wh, conf), 4)
+            z.append(y.view(bs, na * nx * ny, no))
+    return raw if training else (torch.cat(z, 1), raw)
+
+
+def model_strides(cfg):
+    """models/yolo.py:250-256 derives strides from a 256^2 probe; for these graphs it is 8/16/32 by construction."""
+    layers, _ = parse_graph(cfg)
+    det = layers[-1]
+    red = []
+    scale = {}
+    for L in layers[:-1]:
+        f = L["f"]
+        src = scale.get(L["i"] - 1, 1) if f == -1 else None
+        if L["type"] == "Conv":
+            scale[L["i"]] = (scale.get(L["i"] - 1, 1) if f == -1 else scale[f]) * L["s"]
+        elif L["type"] == "nn.Upsample":
+            scale[L["i"]] = scale[L["i"] - 1] // 2
+        elif L["type"] == "Concat":
+            scale[L["i"]] = scale[L["i"] - 1] if f[0] == -1 else scale[f[0]]
+        else:
+            scale[L["i"]] = src if f == -1 else scale[f]
+    for j in det["f"]:
+        red.append(float(scale[j]))
+    return torch.tensor(red)
+
+
+def model_anchors(cfg):
+    """Anchors in grid units: yaml pixels / stride (models/yolo.py:254)."""
+    a = torch.tensor(cfg["anchors"], dtype=torch.float32).view(len(cfg["anchors"]), -1, 2)
+    return a / model_strides(cfg).view(-1, 1, 1)
+
+
+def model_forward(cfg, sd, x, training=False):
+    """models/yolo.py:160-170 `_forward_once` over the parsed graph; returns what the reference returns:
+    training -> list of raw (bs,na,ny,nx,no); eval -> (z, raw) (+ proto for Segment: (z, proto, raw))."""
+    layers, save = parse_graph(cfg, x.shape[1])
+    y = []
+    strides = model_strides(cfg)
+    anchors = sd.get(f"model.{len(layers) - 1}.anchors", None)
+    if anchors is None:
+        anchors = model_anchors(cfg)
+    for L in layers:
+        f, i, t = L["f"], L["i"], L["type"]
+        if f != -1:
+            x = y[f] if isinstance(f, int) else [x if j == -1 else y[j] for j in f]
+        p = f"model.{i}"
+        if t == "Conv":
+            x = _conv(sd, p, x, L["k"], L["s"], L["p"])
+        elif t == "C3":
+            x = _c3(sd, p, x, L["n"], L["shortcut"])
+        elif t == "SPPF":
+            x = _sppf(sd, p, x, L["k"])
+        elif t == "nn.Upsample":
+            x = F.interpolate(x, scale_factor=2, mode="nearest")
+        elif t == "Concat":
+            x = torch.cat(x, 1)
+        elif t == "Detect":
+            x = detect_head(sd, p, list(x), anchors, strides, L["nc"], 0, training)
+        elif t == "Segment":
+            proto = _proto(sd, p + ".proto", x[0])
+            d = detect_head(sd, p, list(x), anchors, strides, L["nc"], L["nm"], training)
+            x = (d, proto) if training else (d[0], proto, d[1])  # yolo.py:148-150
+        y.append(x if i in save else None)
+    return x
+
+
+# --------------------------------------------------------------------------------------------------
+# NMS (utils/general.py:658-767) -- numpy, dtype-preserving
+# --------------------------------------------------------------------------------------------------
+def greedy_nms(boxes: np.ndarray, scores: np.ndarray, iou_thres: float) -> np.ndarray:
+    """torchvision.ops.nms semantics (call site general.py:750); see oracle/thirdparty.py:nms for the contract."""
+    n = boxes.shape[0]
+    if n == 0:
+        return np.zeros((0,), dtype=np.int64)
+    order = np.argsort(-scores.astype(np.float64), kind="stable")
+    b = boxes[order]
+    x1, y1, x2, y2 = b[:, 0], b[:, 1], b[:, 2], b[:, 3]
+    areas = (x2 - x1) * (y2 - y1)
+    sup = np.zeros(n, dtype=bool)
+    keep = []
+    zero, thr = b.dtype.type(0), b.dtype.type(iou_thres)
+    for i in range(n):
+        if sup[i]:
+            continue
+        keep.append(order[i])
+        if i + 1 < n:
+            w = np.maximum(zero, np.minimum(x2[i], x2[i + 1:]) - np.maximum(x1[i], x1[i + 1:]))
+            h = np.maximum(zero, np.minimum(y2[i], y2[i + 1:]) - np.maximum(y1[i], y1[i + 1:]))
+            inter = w * h
+            with np.errstate(divide="ignore", invalid="ignore"):
+                sup[i + 1:] |= inter / (areas[i] + areas[i + 1:] - inter) > thr
+    return np.asarray(keep, dtype=np.int64)
+
+
+def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False,
+                        multi_label=False, max_det=300, nm=0, max_nms=30000, max_wh=7680):
+    """utils/general.py:658-767 restated on numpy float32 (the reference's arithmetic dtype for fp32 input).
+
+    prediction (bs, n, 5+nc+nm) -> list of (k, 6+nm) float32 arrays [x1,y1,x2,y2,conf,cls,(mask..)].
+    The wall-clock `time_limit` break (general.py:692,763-765) is not restated (time dependent).
+    """
+    assert 0 <= conf_thres <= 1 and 0 <= iou_thres <= 1  # general.py:675-676
+    pred = np.asarray(prediction, dtype=np.float32)
+    bs = pred.shape[0]
+    nc = pred.shape[2] - nm - 5
+    mi = 5 + nc
+    multi_label = multi_label and nc > 1  # general.py:693
+    conf_t = np.float32(conf_thres)
+    out = [np.zeros((0, 6 + nm), dtype=np.float32) for _ in range(bs)]
+    for xi in range(bs):
+        x = pred[xi]
+        x = x[x[:, 4] > conf_t].copy()  # general.py:679,703
+        if not x.shape[0]:
+            continue
+        x[:, 5:] *= x[:, 4:5]  # general.py:719  (note: also scales the mask columns, as the reference does)
+        half = x[:, 2:4] / np.float32(2)
+        box = np.concatenate((x[:, :2] - half, x[:, :2] + half), 1)  # xywh2xyxy, general.py:722
+        mask = x[:, mi:]
+        if multi_label:  # general.py:726-728
+            i, j = np.nonzero(x[:, 5:mi] > conf_t)
+            x = np.concatenate((box[i], x[i, 5 + j, None], j[:, None].astype(np.float32), mask[i]), 1)
+        else:  # general.py:729-731 (max returns the FIRST maximal index)
+            j = x[:, 5:mi].argmax(1)
+            conf = x[np.arange(x.shape[0]), 5 + j]
+            x = np.concatenate((box, conf[:, None], j[:, None].astype(np.float32), mask), 1)[conf > conf_t]
+        if classes is not None:  # general.py:734-735
+            x = x[np.isin(x[:, 5], np.asarray(classes, dtype=np.float32))]
+        n = x.shape[0]
+        if not n:
+            continue
+        x = x[np.argsort(-x[:, 4].astype(np.float64), kind="stable")[:max_nms]]  # general.py:745 (stable contract)
+        c = x[:, 5:6] * np.float32(0 if agnostic else max_wh)  # general.py:748
+        keep = greedy_nms(x[:, :4] + c, x[:, 4], iou_thres)[:max_det]  # general.py:749-751
+        out[xi] = x[keep]
+    return out
+
+
+def scale_boxes(img1_shape, boxes, img0_shape, ratio_pad=None):
+    """utils/general.py:613-626 (+ clip_boxes): de-letterbox xyxy boxes in place (float32 numpy)."""
+    if ratio_pad is None:
+        gain = min(img1_shape[0] / img0_shape[0], img1_shape[1] / img0_shape[1])
+        pad = (img1_shape[1] - img0_shape[1] * gain) / 2, (img1_shape[0] - img0_shape[0] * gain) / 2
+    else:
+        gain, pad = ratio_pad[0][0], ratio_pad[1]
+    boxes[..., [0, 2]] -= np.float32(pad[0])
+    boxes[..., [1, 3]] -= np.float32(pad[1])
+    boxes[..., :4] /= np.float32(gain)
+    boxes[..., [0, 2]] = boxes[..., [0, 2]].clip(0, img0_shape[1])
+    boxes[..., [1, 3]] = boxes[..., [1, 3]].clip(0, img0_shape[0])
+    return boxes
+
+
+# --------------------------------------------------------------------------------------------------
+# ComputeLoss (utils/loss.py:101-247)
+# --------------------------------------------------------------------------------------------------
+HYP_SCRATCH_LOW = {"box": 0.05, "cls": 0.5, "cls_pw": 1.0, "obj": 1.0, "obj_pw": 1.0, "anchor_t": 4.0,
+                   "fl_gamma": 0.0, "label_smoothing": 0.0}  # data/hyps/hyp.scratch-low.yaml:17-24
+
+
+def build_targets(shapes, targets, anchors, anchor_t=4.0):
+    """utils/loss.py:185-247.  shapes: list of p[i].shape (bs,na,ny,nx,no); targets (nt,6) float32 torch;
+    anchors (nl,na,2) grid units.  Returns tcls, tbox, indices, anch exactly as the reference."""
+    na, nt = anchors.shape[1], targets.shape[0]
+    tcls, tbox, indices, anch = [], [], [], []
+    gain = torch.ones(7)
+    ai = torch.arange(na).float().view(na, 1).repeat(1, nt)
+    targets = torch.cat((targets.repeat(na, 1, 1), ai[..., None]), 2)
+    g = 0.5
+    off = torch.tensor([[0, 0], [1, 0], [0, 1], [-1, 0], [0, -1]]).float() * g
+    for i in range(len(shapes)):
+        a_i, shape = anchors[i], shapes[i]
+        gain[2:6] = torch.tensor(shape)[[3, 2, 3, 2]]
+        t = targets * gain
+        if nt:
+            r = t[..., 4:6] / a_i[:, None]
+            j = torch.max(r, 1 / r).max(2)[0] < anchor_t
+            t = t[j]
+            gxy = t[:, 2:4]
+            gxi = gain[[2, 3]] - gxy
+            j, k = ((gxy % 1 < g) & (gxy > 1)).T
+            l, m = ((gxi % 1 < g) & (gxi > 1)).T
+            j = torch.stack((torch.ones_like(j), j, k, l, m))
+            t = t.repeat((5, 1, 1))[j]
+            offsets = (torch.zeros_like(gxy)[None] + off[:, None])[j]
+        else:
+            t = targets[0]
+            offsets = 0
+        bc, gxy, gwh, a = t.chunk(4, 1)
+        a, (b, c) = a.long().view(-1), bc.long().T
+        gij = (gxy - offsets).long()
+        gi, gj = gij.T
+        indices.append((b, a, gj.clamp_(0, shape[2] - 1), gi.clamp_(0, shape[3] - 1)))
+        tbox.append(torch.cat((gxy - gij, gwh), 1))
+        anch.append(a_i[a])
+        tcls.append(c)
+    return tcls, tbox, indices, anch
+
+
+def bbox_ciou(box1, box2, eps=1e-7):
+    """ultralytics bbox_iou(xywh=True, CIoU=True) as called at utils/loss.py:153 (see thirdparty.py)."""
+    (x1, y1, w1, h1), (x2, y2, w2, h2) = box1.chunk(4, -1), box2.chunk(4, -1)
+    b1_x1, b1_x2, b1_y1, b1_y2 = x1 - w1 / 2, x1 + w1 / 2, y1 - h1 / 2, y1 + h1 / 2
+    b2_x1, b2_x2, b2_y1, b2_y2 = x2 - w2 / 2, x2 + w2 / 2, y2 - h2 / 2, y2 + h2 / 2
+    inter = (b1_x2.minimum(b2_x2) - b1_x1.maximum(b2_x1)).clamp(0) * (b1_y2.minimum(b2_y2) - b1_y1.maximum(b2_y1)).clamp(0)
+    union = w1 * h1 + w2 * h2 - inter + eps
+    iou = inter / union
+    cw = b1_x2.maximum(b2_x2) - b1_x1.minimum(b2_x1)
+    ch = b1_y2.maximum(b2_y2) - b1_y1.minimum(b2_y1)
+    c2 = cw.pow(2) + ch.pow(2) + eps
+    rho2 = ((b2_x1 + b2_x2 - b1_x1 - b1_x2).pow(2) + (b2_y1 + b2_y2 - b1_y1 - b1_y2).pow(2)) / 4
+    v = (4 / math.pi ** 2) * ((w2 / h2).atan() - (w1 / h1).atan()).pow(2)
+    with torch.no_grad():
+        alpha = v / (v - iou + (1 + eps))
+    return iou - (rho2 / c2 + v * alpha)
+
+
+def compute_loss(p, targets, anchors, hyp=None, nc=80, balance=(4.0, 1.0, 0.4)):
+    """utils/loss.py:134-183 (fl_gamma=0, gr=1, autobalance off, sort_obj_iou off).
+
+    p: list of (bs,na,ny,nx,no) tensors (may require grad); returns (loss[1], loss_items[3])."""
+    hyp = hyp or HYP_SCRATCH_LOW
+    cp, cn = 1.0 - 0.5 * hyp.get("label_smoothing", 0.0), 0.5 * hyp.get("label_smoothing", 0.0)
+    lcls, lbox, lobj = torch.zeros(1), torch.zeros(1), torch.zeros(1)
+    tcls, tbox, indices, anch = build_targets([pi.shape for pi in p], targets, anchors, hyp["anchor_t"])
+    pw_cls, pw_obj = torch.tensor([hyp["cls_pw"]]), torch.tensor([hyp["obj_pw"]])
+    for i, pi in enumerate(p):
+        b, a, gj, gi = indices[i]
+        tobj = torch.zeros(pi.shape[:4], dtype=pi.dtype)
+        n = b.shape[0]
+        if n:
+            pxy, pwh, _, pcls = pi[b, a, gj, gi].split((2, 2, 1, nc), 1)
+            pxy = pxy.sigmoid() * 2 - 0.5
+            pwh = (pwh.sigmoid() * 2) ** 2 * anch[i]
+            pbox = torch.cat((pxy, pwh), 1)
+            iou = bbox_ciou(pbox, tbox[i]).squeeze(-1)
+            lbox = lbox + (1.0 - iou).mean()
+            iou = iou.detach().clamp(0).type(tobj.dtype)
+            tobj[b, a, gj, gi] = iou  # duplicate indices: last write wins (SURVEY 8c hazard 3)
+            if nc > 1:
+                t = torch.full_like(pcls, cn)
+                t[range(n), tcls[i]] = cp
+                lcls = lcls + F.binary_cross_entropy_with_logits(pcls, t, pos_weight=pw_cls)
+        obji = F.binary_cross_entropy_with_logits(pi[..., 4], tobj, pos_weight=pw_obj)
+        lobj = lobj + obji * balance[i]
+    lbox = lbox * hyp["box"]
+    lobj = lobj * hyp["obj"]
+    lcls = lcls * hyp["cls"]
+    bs = p[0].shape[0]
+    return (lbox + lobj + lcls) * bs, torch.cat((lbox, lobj, lcls)).detach()
+
+
+# --------------------------------------------------------------------------------------------------
+# segmentation post-process (utils/segment/general.py:10-51)
+# --------------------------------------------------------------------------------------------------
+def crop_mask(masks, boxes):
+    """utils/segment/general.py:10-22: zero everything outside box (r>=x1 & r<x2 & c>=y1 & c<y2)."""
+    _n, h, w = masks.shape
+    x1, y1, x2, y2 = torch.chunk(boxes[:, :, None], 4, 1)
+    r = torch.arange(w, dtype=x1.dtype)[None, None, :]
+    c = torch.arange(h, dtype=x1.dtype)[None, :, None]
+    return masks * ((r >= x1) * (r < x2) * (c >= y1) * (c < y2))
+
+
+def process_mask(protos, masks_in, bboxes, shape, upsample=False):
+    """utils/segment/general.py:25-51: sigmoid(coef @ proto) -> crop to box/4 -> bilinear x4 -> >0.5."""
+    c, mh, mw = protos.shape
+    ih, iw = shape
+    masks = (masks_in @ protos.float().view(c, -1)).sigmoid().view(-1, mh, mw)
+    d = bboxes.clone()
+    d[:, 0] *= mw / iw
+    d[:, 2] *= mw / iw
+    d[:, 3] *= mh / ih
+    d[:, 1] *= mh / ih
+    masks = crop_mask(masks, d)
+    if upsample:
+        masks = F.interpolate(masks[None], shape, mode="bilinear", align_corners=False)[0]
+    return masks.gt_(0.5)
+
+
+# --------------------------------------------------------------------------------------------------
+# state-dict enumeration (names/shapes of the reference's unfused model) -- lets tests regenerate the
+# golden weights with oracle/detgen.py without the reference being present
+# --------------------------------------------------------------------------------------------------
+class _Shape:
+    def __init__(self, *shape):
+        self.shape = tuple(shape)
+
+
+def state_spec(cfg: dict, ch: int = 3) -> dict:
+    """Ordered {name: _Shape} of `DetectionModel(cfg).state_dict()` (unfused: conv.weight + bn.*)."""
+    layers, _ = parse_graph(cfg, ch)
+    spec = {}
+
+    def conv(p, c1, c2, k):
+        spec[p + ".conv.weight"] = _Shape(c2, c1, k, k)
+        spec[p + ".bn.weight"] = _Shape(c2)
+        spec[p + ".bn.bias"] = _Shape(c2)
+        spec[p + ".bn.running_mean"] = _Shape(c2)
+        spec[p + ".bn.running_var"] = _Shape(c2)
+        spec[p + ".bn.num_batches_tracked"] = _Shape()
+
+    for L in layers:
+        p, t = f"model.{L['i']}", L["type"]
+        if t == "Conv":
+            conv(p, L["c1"], L["c2"], L["k"])
+        elif t == "C3":
+            c_ = int(L["c2"] * 0.5)
+            conv(p + ".cv1", L["c1"], c_, 1)
+            conv(p + ".cv2", L["c1"], c_, 1)
+            conv(p + ".cv3", 2 * c_, L["c2"], 1)
+            for j in range(L["n"]):
+                conv(f"{p}.m.{j}.cv1", c_, c_, 1)
+                conv(f"{p}.m.{j}.cv2", c_, c_, 3)
+        elif t == "SPPF":
+            c_ = L["c1"] // 2
+            conv(p + ".cv1", L["c1"], c_, 1)
+            conv(p + ".cv2", c_ * 4, L["c2"], 1)
+        elif t in ("Detect", "Segment"):
+            nl = len(L["anchors"])
+            na = len(L["anchors"][0]) // 2
+            no = na * (L["nc"] + 5 + L.get("nm", 0))
+            spec[p + ".anchors"] = _Shape(nl, na, 2)
+            for j, c in enumerate(L["ch"]):
+                spec[f"{p}.m.{j}.weight"] = _Shape(no, c, 1, 1)
+                spec[f"{p}.m.{j}.bias"] = _Shape(no)
+            if t == "Segment":
+                conv(p + ".proto.cv1", L["ch"][0], L["npr"], 3)
+                conv(p + ".proto.cv2", L["npr"], L["npr"], 3)
+                conv(p + ".proto.cv3", L["npr"], L["nm"], 1)
+    return spec
+
+
+def det_state_dict(cfg: dict, seed: int = 0, fused: bool = False) -> dict:
+    """The deterministic weights the golden fixtures were generated with (torch fp32 tensors)."""
+    from . import detgen
+
+    spec = state_spec(cfg)
+    vals = detgen.fill_state_dict(spec, seed)
+    sd = {}
+    for k, v in vals.items():
+        if v is None:
+            sd[k] = model_anchors(cfg)
+        else:
+            sd[k] = torch.from_numpy(np.ascontiguousarray(v))
+    if fused:
+        out = {}
+        for k in list(sd):
+            if k.endswith(".conv.weight") and k.replace(".conv.weight", ".bn.weight") in sd:
+                p = k[: -len(".conv.weight")]
+                w, b = fuse_conv_and_bn(sd[k], sd[p + ".bn.weight"], sd[p + ".bn.bias"], sd[p + ".bn.running_mean"],
+                                        sd[p + ".bn.running_var"])
+                out[p + ".conv.weight"], out[p + ".conv.bias"] = w, b
+            elif ".bn." not in k:
+                out[k] = sd[k]
+        sd = out
+    return sd

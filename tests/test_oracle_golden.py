@@ -1,0 +1,147 @@
+"""CPU: the oracle restatement (oracle/yolo_oracle.py) reproduces the committed golden vectors that
+oracle/make_golden.py generated from the unmodified reference.  Travels to the GPU box (no /root/reference)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import detgen, yolo_oracle as yo
+from oracle.make_golden import NMS_CASES, loss_case, nms_case_pred
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _load(name):
+    return np.load(os.path.join(G, name))
+
+
+@pytest.mark.parametrize("name,model,hw,bs,seed", [("yolov5n_64", "yolov5n", 64, 2, 0), ("yolov5s_320", "yolov5s", 320, 2, 1),
+                                                   ("yolov5n-seg_64", "yolov5n-seg", 64, 2, 2)])
+def test_forward_matches_reference_golden(name, model, hw, bs, seed):
+    g = _load(f"fwd_{name}.npz")
+    cfg = yo.model_cfg(model)
+    x = torch.from_numpy(detgen.uniform((bs, 3, hw, hw), 0.0, 1.0, name="img", seed=seed))
+    assert np.array_equal(g["anchors"], yo.model_anchors(cfg).numpy())
+    assert np.array_equal(g["stride"], yo.model_strides(cfg).numpy())
+    for fused in (False, True):
+        sd = yo.det_state_dict(cfg, seed, fused=fused)
+        with torch.no_grad():
+            out = yo.model_forward(cfg, sd, x)
+        z = out[0].numpy()
+        key = "z_fused" if fused else "z_unfused"
+        rs = int(g["row_stride"])
+        if rs == 1:
+            np.testing.assert_allclose(z, g[key], rtol=2e-4, atol=2e-4)
+            if not fused:
+                raws = out[2] if "seg" in model else out[1]
+                for i, r in enumerate(raws):
+                    np.testing.assert_allclose(r.numpy(), g[f"raw{i}"], rtol=2e-4, atol=2e-4)
+        else:
+            np.testing.assert_allclose(z.reshape(-1, z.shape[-1])[::rs], g[key + "_rows"], rtol=2e-4, atol=5e-4)
+            s = z.astype(np.float64)
+            np.testing.assert_allclose([s.sum(), np.abs(s).sum(), (s * s).sum()], g[key + "_sum"], rtol=1e-5)
+        if "seg" in model and fused:
+            proto = out[1].numpy()
+            np.testing.assert_allclose(proto[:, :, ::5, ::5], g["proto_sample"], rtol=2e-4, atol=2e-4)
+
+
+def test_nparams_match():
+    g = _load("fwd_yolov5s_320.npz")
+    spec = yo.state_spec(yo.model_cfg("yolov5s"))
+    n = sum(int(np.prod(v.shape)) for k, v in spec.items()
+            if not k.endswith(("running_mean", "running_var", "num_batches_tracked", "anchors")))
+    assert n == int(g["nparams"]) == 7235389  # yolov5s params
+
+
+def test_detect_grid_bit_exact():
+    g = _load("fwd_yolov5n_64.npz")
+    cfg = yo.model_cfg("yolov5n")
+    anchors, strides = yo.model_anchors(cfg), yo.model_strides(cfg)
+    for i, s in enumerate((8, 4, 2)):
+        grid, ag = yo.make_grid(s, s, anchors[i], strides[i])
+        assert np.array_equal(grid[0, 0].numpy(), g[f"grid{i}"])
+        assert np.array_equal(ag[0, :, 0, 0].numpy(), g[f"anchor_grid{i}"])
+
+
+def test_fuse_conv_bn():
+    g = _load("fuse.npz")
+    w, b = yo.fuse_conv_and_bn(torch.from_numpy(detgen.uniform((16, 8, 3, 3), -0.5, 0.5, name="fw")),
+                               torch.from_numpy(detgen.uniform((16,), 0.5, 1.5, name="fg")),
+                               torch.from_numpy(detgen.uniform((16,), -0.5, 0.5, name="fb")),
+                               torch.from_numpy(detgen.uniform((16,), -0.5, 0.5, name="fm")),
+                               torch.from_numpy(detgen.uniform((16,), 0.5, 1.5, name="fv")))
+    np.testing.assert_allclose(w.numpy(), g["w"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(b.numpy(), g["b"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", list(NMS_CASES))
+def test_nms_bit_exact(name):
+    g = _load("nms.npz")
+    kw, nkw = NMS_CASES[name]
+    out = yo.non_max_suppression(nms_case_pred(name), **nkw)
+    for i, o in enumerate(out):
+        ref = g[f"{name}_{i}"]
+        assert o.shape == ref.shape, (name, i, o.shape, ref.shape)
+        assert np.array_equal(o, ref), (name, i)
+
+
+@pytest.mark.parametrize("name", ["appendix_a", "synthetic", "no_targets"])
+def test_loss_and_targets(name):
+    g = _load("loss.npz")
+    pn, tn = loss_case(name)
+    anchors = torch.from_numpy(g["anchors"])
+    assert np.array_equal(g["anchors"], yo.model_anchors(yo.model_cfg("yolov5s")).numpy())
+    p = [torch.from_numpy(a).clone().requires_grad_(True) for a in pn]
+    t = torch.from_numpy(tn)
+    tcls, tbox, indices, anch = yo.build_targets([q.shape for q in p], t, anchors)
+    for i in range(3):
+        idx = torch.stack(indices[i]).numpy() if indices[i][0].numel() else np.zeros((4, 0), np.int64)
+        assert np.array_equal(idx, g[f"{name}_idx{i}"])  # int64 indices: bit-exact
+        assert np.array_equal(tcls[i].numpy(), g[f"{name}_tcls{i}"])
+        assert np.array_equal(tbox[i].numpy(), g[f"{name}_tbox{i}"])
+        assert np.array_equal(anch[i].numpy(), g[f"{name}_anch{i}"])
+    loss, items = yo.compute_loss(p, t, anchors)
+    loss.backward()
+    np.testing.assert_allclose(loss.detach().numpy(), g[f"{name}_loss"], rtol=1e-6)
+    np.testing.assert_allclose(items.numpy(), g[f"{name}_items"], rtol=1e-6, atol=1e-8)
+    for i in range(3):
+        gr = p[i].grad.numpy()
+        if f"{name}_grad{i}" in g:
+            np.testing.assert_allclose(gr, g[f"{name}_grad{i}"], rtol=1e-5, atol=1e-9)
+        else:
+            s = gr.astype(np.float64)
+            np.testing.assert_allclose([s.sum(), np.abs(s).sum()], g[f"{name}_grad{i}_sum"], rtol=1e-6)
+            nz = g[f"{name}_grad{i}_nzidx"]
+            if len(nz):
+                np.testing.assert_allclose(gr[tuple(nz.T)], g[f"{name}_grad{i}_nzrows"], rtol=1e-5, atol=1e-9)
+
+
+def test_appendix_a_known_answer():
+    """lobj = ln2*(4+1+0.4)*hyp.obj, lcls = ln2*3*hyp.cls at zero logits (no third-party code)."""
+    pn, tn = loss_case("appendix_a")
+    anchors = yo.model_anchors(yo.model_cfg("yolov5s"))
+    _, items = yo.compute_loss([torch.from_numpy(a) for a in pn], torch.from_numpy(tn), anchors)
+    assert abs(items[1].item() - np.log(2) * 5.4) < 1e-5
+    assert abs(items[2].item() - np.log(2) * 1.5) < 1e-5
+    assert abs(items[0].item() - 0.09738069) < 1e-6
+
+
+def test_process_mask():
+    g = _load("mask.npz")
+    protos = torch.from_numpy(detgen.uniform((32, 40, 40), -1.0, 1.0, name="protos", seed=13))
+    coef = torch.from_numpy(detgen.uniform((7, 32), -1.0, 1.0, name="coef", seed=13))
+    xy1 = detgen.uniform((7, 2), 0, 90, name="bx1", seed=13)
+    wh = detgen.uniform((7, 2), 8, 70, name="bwh", seed=13)
+    boxes = torch.from_numpy(np.concatenate((xy1, xy1 + wh), 1))
+    for up, key in ((False, "noup"), (True, "up")):
+        m = yo.process_mask(protos, coef, boxes, (160, 160), upsample=up).numpy().astype(bool)
+        ref = np.unpackbits(g[f"m_{key}"])[: m.size].reshape(g[f"shape_{key}"]).astype(bool)
+        assert (m != ref).mean() < 1e-4
+
+
+def test_scale_boxes():
+    g = _load("scale_boxes.npz")
+    b = detgen.uniform((20, 4), -20, 660, name="sb", seed=14)
+    np.testing.assert_allclose(yo.scale_boxes((640, 640), b.copy(), (1080, 810)), g["a"], rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(yo.scale_boxes((384, 640), b.copy(), (720, 1280)), g["b"], rtol=1e-6, atol=1e-5)
