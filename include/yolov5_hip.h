@@ -1,0 +1,139 @@
+/* yolov5_hip.h -- C-ABI of libyolov5_hip.so, the MI355X (gfx950) kernel library behind the YOLOv5 hot path.
+ *
+ * The reference (ultralytics/yolov5, pure Python) has no FFI of its own: its "operator API" for this path is the
+ * set of Python callables named below.  Every entry point here is what a maintainer would bind (ctypes stub in
+ * INTEGRATION.md) to replace the third-party native op those callables reach today.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; all device memory is owned by the caller (PyTorch caching allocator);
+ *     the library never allocates per call (one 4 KiB zero page per process is created on first use).
+ *   - every launch goes to the `stream` argument (a hipStream_t passed as void*); no internal synchronisation.
+ *   - return 0 on success, <0 = y5_status; y5_last_error() gives the message of the last failure on this thread.
+ *   - activations are NHWC ("channels last"): element (b,h,w,c) at ((b*H+h)*W+w)*ld + c, `ld` >= C is the
+ *     pixel stride in elements so a tensor may be a channel slice of a wider buffer (concat-free writes).
+ */
+#ifndef YOLOV5_HIP_H
+#define YOLOV5_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { Y5_OK = 0, Y5_ERR_BAD_ARG = -1, Y5_ERR_UNSUPPORTED = -2, Y5_ERR_RUNTIME = -3, Y5_ERR_WORKSPACE = -4 } y5_status;
+typedef enum { Y5_F16 = 0, Y5_F32 = 1, Y5_U8 = 2 } y5_dtype;
+
+int y5_version(void);                /* 10000*major + 100*minor + patch */
+const char* y5_last_error(void);     /* thread-local message of the last non-zero return */
+
+/* ---------------------------------------------------------------------------------------------------------
+ * y5_conv2d_fwd -- fused convolution: y = act(conv(x, w) + bias) [+ residual], NHWC, MFMA implicit GEMM.
+ * Replaces: models/common.py:90-92 `Conv.forward_fuse` (nn.Conv2d + SiLU after utils/torch_utils.py:224-254
+ * BN folding), common.py:181 `Bottleneck` residual add, common.py:246/340/453 `torch.cat` (write into a channel
+ * slice via ldy), yolov5s.yaml:36,41 `nn.Upsample(None,2,'nearest')` (y_up2), models/yolo.py:95 Detect conv.
+ * w_packed: [Npad][Kpad] row-major, k = (kh, kw, c); Npad % 32 == 0, Kpad % (64/elemsize) == 0, zero padded.
+ * bias: fp32 [Npad].  residual/y_up2 may be NULL.  residual may alias y (in-place add).
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct {
+  int dtype;          /* Y5_F16 | Y5_F32 (storage type of x, w, y, residual; accumulation is always fp32) */
+  int B, H, W;        /* input batch / height / width */
+  int C1, ldx;        /* input channels, input pixel stride (elements); both multiples of 16 bytes */
+  int OH, OW;         /* output height / width (checked against H,W,k,s,p) */
+  int C2, ldy;        /* output channels (multiple of 4), output pixel stride */
+  int KH, KW, SH, SW, PH, PW;
+  int act;            /* 0 identity, 1 SiLU */
+  int Kpad, Npad;     /* packed filter dims */
+  int ldr;            /* residual pixel stride (if residual != NULL) */
+  int ld2;            /* y_up2 pixel stride (if y_up2 != NULL); y_up2 has spatial size 2*OH x 2*OW */
+  int tile_n;         /* 0 = auto, else 32/64/128/256 output channels per workgroup */
+} y5_conv_desc;
+
+int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w_packed, const float* bias,
+                  const void* residual, void* y, void* y_up2, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * y5_nchw_to_nhwc -- input contract (train.py:379, val.py:259-262, detect.py:206-210, common.py:926):
+ * NCHW {u8|f16|f32} -> NHWC {f16|f32} with channel padding to `ld` (pad channels written as 0) and a scale
+ * (1/255 for u8 images, 1 for already-normalised floats).
+ * ------------------------------------------------------------------------------------------------------- */
+int y5_nchw_to_nhwc(const void* src, int src_dtype, void* dst, int dst_dtype, int B, int C, int H, int W, int ld,
+                    float scale, void* stream);
+
+/* y5_nhwc_to_nchw -- export a NHWC slice as a contiguous NCHW tensor (API boundary: raw head outputs, Proto). */
+int y5_nhwc_to_nchw(const void* src, int dtype, void* dst, int B, int C, int H, int W, int ld, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * y5_sppf_pool -- models/common.py:331,338-340: y1 = m(x), y2 = m(y1), y3 = m(y2), m = MaxPool2d(k,1,k//2)
+ * (-inf padding), written as channel slices 1..3 of the same NHWC buffer whose slice 0 holds x:
+ * buf[..., 0:C] = x (input), buf[..., C:2C] = y1, [2C:3C] = y2, [3C:4C] = y3;  pixel stride ld >= 4C.
+ * ------------------------------------------------------------------------------------------------------- */
+int y5_sppf_pool(void* buf, int dtype, int B, int H, int W, int C, int ld, int k, void* stream);
+
+/* y5_upsample2x -- nn.Upsample(None,2,'nearest') into a channel slice (only used when the producer conv could
+ * not emit the replicated store itself). */
+int y5_upsample2x(const void* src, int dtype, void* dst, int B, int H, int W, int C, int lds, int ldd, void* stream);
+
+/* y5_copy_slice -- strided NHWC channel-slice copy (generic `Concat` fallback, common.py:453). */
+int y5_copy_slice(const void* src, int dtype, void* dst, int npix, int C, int lds, int ldd, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * y5_detect_decode -- models/yolo.py:96-115 (`Detect.forward`, eval branch) for one level:
+ * logits NHWC (B,ny,nx, na*no) [pixel stride ld] ->
+ *   z[b, row_off + a*ny*nx + iy*nx + ix, :]  (B, nrows_total, no)    xy=(2s-0.5+g)*stride, wh=(2s)^2*anchor_px,
+ *                                              conf/cls = sigmoid; the last `nm` columns are copied raw (Segment)
+ *   raw[b, a, iy, ix, :] (optional, may be NULL): the un-activated (bs,na,ny,nx,no) tensor the reference returns.
+ * anchors_px: na*2 floats = anchors (grid units) * stride, i.e. the reference's anchor_grid.
+ * ------------------------------------------------------------------------------------------------------- */
+int y5_detect_decode(const void* logits, int dtype, int B, int ny, int nx, int na, int no, int nm, int ld,
+                     float stride, const float* anchors_px, void* z, int z_dtype, long long nrows_total,
+                     long long row_off, void* raw, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * y5_nms_batched -- utils/general.py:658-767 `non_max_suppression` incl. torchvision.ops.nms (general.py:750).
+ * pred: (bs, n, no) f16|f32, no = 5 + nc + nm.  All arithmetic is fp32 on the fp32 value of each element.
+ * out:       (bs, max_det, 6+nm) fp32 rows [x1,y1,x2,y2,conf,cls,(mask..)] in descending-confidence order
+ * out_count: (bs) int32 number of valid rows per image
+ * flags: Y5_NMS_MULTI_LABEL | Y5_NMS_AGNOSTIC.  classes: optional device int32[nclasses] filter (general.py:734).
+ * Tie rule: equal confidences keep the lower candidate index first (stable sort contract).
+ * workspace: y5_nms_workspace_bytes(...) bytes, 256-byte aligned.
+ * ------------------------------------------------------------------------------------------------------- */
+enum { Y5_NMS_MULTI_LABEL = 1, Y5_NMS_AGNOSTIC = 2 };
+size_t y5_nms_workspace_bytes(int bs, int n, int no, int nm, int flags, int max_nms);
+int y5_nms_batched(const void* pred, int dtype, int bs, int n, int no, int nm, float conf_thres, float iou_thres,
+                   int max_det, int max_nms, float max_wh, int flags, const int* classes, int nclasses,
+                   float* out, int* out_count, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Execution plan: a recorded list of the calls above, replayed by ONE host call (and optionally through a
+ * captured hipGraph).  Replaces the Python module walk of models/yolo.py:160-170 `_forward_once`.
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct y5_plan y5_plan;
+y5_plan* y5_plan_create(void);
+void y5_plan_destroy(y5_plan*);
+int y5_plan_add_conv(y5_plan*, const y5_conv_desc* d, const void* x, const void* w_packed, const float* bias,
+                     const void* residual, void* y, void* y_up2);
+int y5_plan_add_nchw_to_nhwc(y5_plan*, const void* src, int src_dtype, void* dst, int dst_dtype, int B, int C, int H,
+                             int W, int ld, float scale);
+int y5_plan_add_sppf_pool(y5_plan*, void* buf, int dtype, int B, int H, int W, int C, int ld, int k);
+int y5_plan_add_upsample2x(y5_plan*, const void* src, int dtype, void* dst, int B, int H, int W, int C, int lds, int ldd);
+int y5_plan_add_copy_slice(y5_plan*, const void* src, int dtype, void* dst, int npix, int C, int lds, int ldd);
+int y5_plan_add_detect_decode(y5_plan*, const void* logits, int dtype, int B, int ny, int nx, int na, int no, int nm,
+                              int ld, float stride, const float* anchors_px, void* z, int z_dtype,
+                              long long nrows_total, long long row_off, void* raw);
+int y5_plan_add_nhwc_to_nchw(y5_plan*, const void* src, int dtype, void* dst, int B, int C, int H, int W, int ld);
+int y5_plan_size(const y5_plan*);
+int y5_plan_run(y5_plan*, void* stream);                 /* eager replay of every recorded op */
+int y5_plan_run_range(y5_plan*, int first, int last, void* stream);
+int y5_plan_capture(y5_plan*, void* stream);             /* capture the replay into a hipGraph (once) */
+int y5_plan_launch_graph(y5_plan*, void* stream);        /* hipGraphLaunch of the captured graph */
+
+/* Timing helper for bench/profiling: run ops [first,last) `iters` times on `stream` bracketed by hipEvents
+ * recorded on that same stream; returns total milliseconds in *ms. */
+int y5_plan_time_range(y5_plan*, int first, int last, int iters, void* stream, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLOV5_HIP_H */

@@ -1,0 +1,143 @@
+// TEST INFRASTRUCTURE ONLY.  A tiny single-threaded HIP *emulator* (fibers via ucontext) that lets the unmodified
+// kernel sources under yolov5_amd/csrc be compiled for the HOST and executed lane by lane in the GPU-less build
+// container, so indexing / tiling / barrier logic is checked against the oracle before GPU minutes are spent.
+// It shadows <hip/hip_runtime.h> ONLY when tests/hipemu/build.sh compiles liby5emu.so; the product library is
+// always built by hipcc against the real ROCm headers and never sees this file.
+#pragma once
+#include <ucontext.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct int2 { int x, y; };
+
+namespace emu {
+struct Lane;
+extern Lane* cur;
+extern dim3 g_blockIdx, g_blockDim, g_gridDim;
+dim3& lane_tid();
+int lane_id();
+void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& fn);
+void barrier_block();
+// wave collective: every live lane of the wave deposits `bytes` of payload; returns after all arrived.
+// out[l] points at lane l's payload (nullptr if lane l did not participate).
+void wave_exchange(const void* payload, int bytes, const void* out[64]);
+}  // namespace emu
+
+#define threadIdx (emu::lane_tid())
+#define blockIdx (emu::g_blockIdx)
+#define blockDim (emu::g_blockDim)
+#define gridDim (emu::g_gridDim)
+
+// ---- runtime API subset used by csrc/*.hip ---------------------------------------------------------
+typedef void* hipStream_t;
+typedef int hipError_t;
+typedef void* hipEvent_t;
+typedef void* hipGraph_t;
+typedef void* hipGraphExec_t;
+enum { hipSuccess = 0, hipErrorNotSupported = 801 };
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+enum { hipStreamCaptureModeThreadLocal = 1 };
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) & ~(size_t)255); return *p ? hipSuccess : 2; }
+inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
+inline hipError_t hipStreamBeginCapture(hipStream_t, int) { return hipErrorNotSupported; }
+inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = nullptr; return hipErrorNotSupported; }
+inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*, size_t) { return hipErrorNotSupported; }
+inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
+
+#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
+  emu::launch((grid), (block), (shmem), [&]() { kern(__VA_ARGS__); })
+
+// ---- device builtins ---------------------------------------------------------------------------------
+#define __syncthreads() emu::barrier_block()
+#define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_s_barrier() emu::barrier_block()
+inline float __expf(float x) { return expf(x); }
+inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+inline int atomicAdd(int* p, int v) { int o = *p; *p += v; return o; }
+
+inline void emu_glds(const void* g, void* l, int size) { memcpy((char*)l + (size_t)emu::lane_id() * size, g, size); }
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu_glds((const void*)(uintptr_t)(g), (void*)(uintptr_t)(l), (size))
+
+inline unsigned long long __ballot(int pred) {
+  const void* o[64];
+  unsigned char v = pred ? 1 : 0;
+  emu::wave_exchange(&v, 1, o);
+  unsigned long long m = 0;
+  for (int l = 0; l < 64; ++l) if (o[l] && *(const unsigned char*)o[l]) m |= 1ull << l;
+  return m;
+}
+template <typename T> inline T __shfl(T v, int src) {
+  const void* o[64];
+  emu::wave_exchange(&v, sizeof(T), o);
+  T r = v;
+  if (o[src & 63]) memcpy(&r, o[src & 63], sizeof(T));
+  return r;
+}
+
+typedef _Float16 emu_half8 __attribute__((ext_vector_type(8)));
+typedef float emu_float16 __attribute__((ext_vector_type(16)));
+// D = A(32x16) * B(16x32) + C ; lane l holds A[i=l&31][k=8*(l>>5)+e], B[k=8*(l>>5)+e][j=l&31];
+// D: col j = l&31, row i = (r&3) + 8*(r>>2) + 4*(l>>5)   (cdna_hip_programming.md section 3)
+inline emu_float16 emu_mfma_32x32x16_f16(emu_half8 a, emu_half8 b, emu_float16 c) {
+  struct P { emu_half8 a, b; } pl{a, b};
+  const void* o[64];
+  emu::wave_exchange(&pl, sizeof(P), o);
+  const int l = emu::lane_id();
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), j = l & 31;
+    float s = c[r];
+    for (int k = 0; k < 16; ++k) {
+      const P* pa = (const P*)o[i + 32 * (k >> 3)];
+      const P* pb = (const P*)o[j + 32 * (k >> 3)];
+      s += (float)pa->a[k & 7] * (float)pb->b[k & 7];
+    }
+    c[r] = s;
+  }
+  return c;
+}
+inline emu_float16 emu_mfma_32x32x2_f32(float a, float b, emu_float16 c) {
+  struct P { float a, b; } pl{a, b};
+  const void* o[64];
+  emu::wave_exchange(&pl, sizeof(P), o);
+  const int l = emu::lane_id();
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), j = l & 31;
+    float s = c[r];
+    for (int k = 0; k < 2; ++k) s = fmaf(((const P*)o[i + 32 * k])->a, ((const P*)o[j + 32 * k])->b, s);
+    c[r] = s;
+  }
+  return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu_mfma_32x32x16_f16((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu_mfma_32x32x2_f32((a), (b), (c))

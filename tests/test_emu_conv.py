@@ -1,0 +1,110 @@
+"""CPU (no GPU): the real conv kernel source, compiled for the host on the HIP emulator (tests/hipemu), against
+torch-CPU conv2d on tiny shapes -- checks tiling, im2col addressing, swizzle, tails, epilogue variants."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import detgen
+from tests.hipemu.emu import aligned, emu, ptr
+from yolov5_amd import _lib
+from yolov5_amd.packing import pack_conv_weight
+
+CASES = [
+    # B, H, W, C1, C2, k, s, p, act, residual, up2, tile_n, dtype
+    (1, 6, 7, 32, 32, 1, 1, 0, 1, False, False, 0, "f16"),
+    (2, 9, 8, 32, 64, 3, 1, 1, 1, True, False, 0, "f16"),
+    (1, 12, 12, 64, 48, 3, 2, 1, 1, False, False, 0, "f16"),     # C2 not multiple of 32 (Npad 64)
+    (1, 8, 8, 64, 128, 1, 1, 0, 0, False, True, 0, "f16"),       # 2x2 wave tiling + upsampled second store
+    (1, 5, 5, 16, 16, 3, 1, 1, 1, True, False, 0, "f16"),        # table mode (C1 % 32 != 0), in-place residual
+    (1, 8, 8, 40, 256, 1, 1, 0, 1, False, False, 256, "f16"),    # table mode 1x1, BN=256 tile
+    (1, 6, 6, 32, 32, 3, 1, 1, 1, True, False, 0, "f32"),
+    (1, 7, 5, 4, 32, 3, 2, 1, 1, False, False, 0, "f32"),        # f32 table mode (C1=4)
+    (1, 10, 10, 16, 128, 1, 1, 0, 0, False, False, 0, "f32"),
+]
+
+
+def run_conv(lib, x_nchw, w, b, k, s, p, act, residual, up2, tile_n, dt, ldx_extra=0, ldy_extra=0):
+    B, C1, H, W = x_nchw.shape
+    C2 = w.shape[0]
+    npdt = np.float16 if dt == "f16" else np.float32
+    tdt = torch.float16 if dt == "f16" else torch.float32
+    ldx, ldy = C1 + ldx_extra, C2 + ldy_extra
+    x = aligned((B, H, W, ldx), npdt, 7.0)
+    x[..., :C1] = x_nchw.permute(0, 2, 3, 1).numpy().astype(npdt)
+    wp, bp, K, Kpad, Npad = pack_conv_weight(w, b, tdt)
+    wp_a = aligned(wp.shape, npdt); wp_a[...] = wp.numpy()
+    bp_a = aligned(bp.shape, np.float32); bp_a[...] = bp.numpy()
+    OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    y = aligned((B, OH, OW, ldy), npdt, -3.0)
+    res = None
+    if residual:
+        y[..., :C2] = detgen.uniform((B, OH, OW, C2), -1, 1, name="res").astype(npdt)
+        res = y.copy()
+    y2 = aligned((B, 2 * OH, 2 * OW, C2), npdt, -5.0) if up2 else None
+    d = _lib.ConvDesc(dtype=_lib.Y5_F16 if dt == "f16" else _lib.Y5_F32, B=B, H=H, W=W, C1=C1, ldx=ldx, OH=OH, OW=OW,
+                      C2=C2, ldy=ldy, KH=k, KW=k, SH=s, SW=s, PH=p, PW=p, act=act, Kpad=Kpad, Npad=Npad, ldr=ldy,
+                      ld2=C2, tile_n=tile_n)
+    rc = lib.y5_conv2d_fwd(C.byref(d), ptr(x), ptr(wp_a), ptr(bp_a), ptr(y) if residual else None, ptr(y), ptr(y2), None)
+    assert rc == 0, lib.y5_last_error()
+    return y, y2, res
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_emulated_matches_torch(case):
+    B, H, W, C1, C2, k, s, p, act, residual, up2, tile_n, dt = case
+    lib = emu()
+    x = torch.from_numpy(detgen.uniform((B, C1, H, W), -1, 1, name="x"))
+    w = torch.from_numpy(detgen.uniform((C2, C1, k, k), -0.3, 0.3, name="w"))
+    b = torch.from_numpy(detgen.uniform((C2,), -0.5, 0.5, name="b"))
+    if dt == "f16":
+        x, w = x.half().float(), w.half().float()
+    y, y2, res = run_conv(lib, x, w, b, k, s, p, act, residual, up2, tile_n, dt, ldx_extra=8, ldy_extra=4)
+    ref = F.conv2d(x, w, b, s, p)
+    if act:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 3, 1).numpy()
+    if residual:
+        ref = ref + res[..., :C2].astype(np.float32)
+    tol = 2e-2 if dt == "f16" else 2e-5
+    np.testing.assert_allclose(y[..., :C2].astype(np.float32), ref, rtol=tol, atol=tol)
+    assert np.all(y[..., C2:] == (-3.0 if not residual else res[..., C2:]))  # neighbouring channels untouched
+    if up2:
+        up = np.repeat(np.repeat(y[..., :C2], 2, axis=1), 2, axis=2)
+        assert np.array_equal(up, y2)
+
+
+def test_conv_layer0_pair_view():
+    """Layer 0 (k6 s2 p2, C=3): NHWC4 input viewed as (H, W/2, 8), filter as (6, 3, 8), stride (2,1), pad (2,1)."""
+    lib = emu()
+    B, H, W = 1, 16, 16
+    x = torch.from_numpy(detgen.uniform((B, 3, H, W), 0, 1, name="x0")).half().float()
+    w = torch.from_numpy(detgen.uniform((32, 3, 6, 6), -0.2, 0.2, name="w0")).half().float()
+    b = torch.from_numpy(detgen.uniform((32,), -0.5, 0.5, name="b0"))
+    xn = aligned((B, H, W, 4), np.float16, 0.0)
+    xn[..., :3] = x.permute(0, 2, 3, 1).numpy().astype(np.float16)
+    w4 = torch.zeros((32, 4, 6, 6)); w4[:, :3] = w
+    # (C2, C, KH, KW) -> k order (kh, kw, c) with (kw, c) regrouped as (kw/2, 8)
+    wp, bp, K, Kpad, Npad = pack_conv_weight(w4, b, torch.float16)
+    assert K == 144 and Kpad == 160
+    wp_a = aligned(wp.shape, np.float16); wp_a[...] = wp.numpy()
+    bp_a = aligned(bp.shape, np.float32); bp_a[...] = bp.numpy()
+    OH = OW = 8
+    y = aligned((B, OH, OW, 32), np.float16)
+    d = _lib.ConvDesc(dtype=_lib.Y5_F16, B=B, H=H, W=W // 2, C1=8, ldx=8, OH=OH, OW=OW, C2=32, ldy=32, KH=6, KW=3, SH=2, SW=1,
+                      PH=2, PW=1, act=1, Kpad=Kpad, Npad=Npad, ldr=0, ld2=0, tile_n=0)
+    rc = lib.y5_conv2d_fwd(C.byref(d), ptr(xn), ptr(wp_a), ptr(bp_a), None, ptr(y), None, None)
+    assert rc == 0, lib.y5_last_error()
+    ref = F.silu(F.conv2d(x, w, b, 2, 2)).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(y.astype(np.float32), ref, rtol=2e-2, atol=2e-2)
+
+
+def test_conv_rejects_bad_args():
+    lib = emu()
+    d = _lib.ConvDesc(dtype=_lib.Y5_F16, B=1, H=4, W=4, C1=12, ldx=12, OH=4, OW=4, C2=32, ldy=32, KH=1, KW=1, SH=1, SW=1,
+                      PH=0, PW=0, act=1, Kpad=32, Npad=32)
+    a = aligned((64,), np.float16)
+    assert lib.y5_conv2d_fwd(C.byref(d), ptr(a), ptr(a), ptr(a), None, ptr(a), None, None) == -1
+    assert b"16 bytes" in lib.y5_last_error()

@@ -1,0 +1,127 @@
+"""CPU (no GPU): NMS / decode / pool / layout kernels run on the HIP emulator against the golden vectors and the
+oracle -- bit-exact selection order (integer/index work), fp tolerance for decode."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import detgen, yolo_oracle as yo
+from oracle.make_golden import NMS_CASES, nms_case_pred
+from tests.hipemu.emu import aligned, emu, ptr
+from yolov5_amd import _lib
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def run_nms(lib, pred, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, max_det=300,
+            nm=0, max_nms=30000, dtype=np.float32):
+    bs, n, no = pred.shape
+    p = aligned(pred.shape, dtype); p[...] = pred.astype(dtype)
+    flags = (_lib.NMS_MULTI_LABEL if multi_label else 0) | (_lib.NMS_AGNOSTIC if agnostic else 0)
+    wsb = lib.y5_nms_workspace_bytes(bs, n, no, nm, flags, max_nms)
+    ws = aligned((wsb,), np.uint8)
+    out = aligned((bs, max_det, 6 + nm), np.float32, -1.0)
+    cnt = aligned((bs,), np.int32, -1)
+    cls = None
+    if classes is not None:
+        cls = aligned((len(classes),), np.int32); cls[...] = classes
+    rc = lib.y5_nms_batched(ptr(p), _lib.Y5_F16 if dtype == np.float16 else _lib.Y5_F32, bs, n, no, nm, conf_thres, iou_thres,
+                            max_det, max_nms, 7680.0, flags, ptr(cls), 0 if cls is None else len(classes), ptr(out), ptr(cnt),
+                            ptr(ws), wsb, None)
+    assert rc == 0, lib.y5_last_error()
+    return [out[i, :cnt[i]].copy() for i in range(bs)]
+
+
+@pytest.mark.parametrize("name", list(NMS_CASES))
+def test_nms_emulated_bit_exact_vs_golden(name):
+    g = np.load(os.path.join(G, "nms.npz"))
+    kw, nkw = NMS_CASES[name]
+    res = run_nms(emu(), nms_case_pred(name), **nkw)
+    for i, r in enumerate(res):
+        ref = g[f"{name}_{i}"]
+        assert r.shape == ref.shape, (name, i, r.shape, ref.shape)
+        assert np.array_equal(r, ref), (name, i)
+
+
+def test_nms_fp16_input_equals_oracle_on_upcast():
+    """Contract for half predictions: identical to the fp32 path on pred.float() (NMS dtype note)."""
+    p = detgen.synth_predictions(2, 1500, 85, obj_pow=4, seed=21).astype(np.float16)
+    res = run_nms(emu(), p, conf_thres=0.25, iou_thres=0.45, max_det=300, dtype=np.float16)
+    ref = yo.non_max_suppression(p.astype(np.float32), 0.25, 0.45, max_det=300)
+    for r, o in zip(res, ref):
+        assert np.array_equal(r, o)
+
+
+def test_nms_large_candidate_set_global_sort_path():
+    """> 8192 candidates per image exercises the global-memory bitonic path and the max_nms truncation."""
+    p = detgen.synth_predictions(1, 12000, 9, obj_pow=1, seed=22)
+    kw = dict(conf_thres=0.01, iou_thres=0.5, multi_label=True, max_det=100, max_nms=9000)
+    res = run_nms(emu(), p, **kw)
+    ref = yo.non_max_suppression(p, **kw)
+    assert len(ref[0]) == 100 and np.array_equal(res[0], ref[0])
+
+
+def test_detect_decode_emulated():
+    lib = emu()
+    B, ny, nx, na, no = 2, 5, 7, 3, 85
+    logits = detgen.uniform((B, ny, nx, na * no), -4, 4, name="lg", seed=3)
+    ld = 256
+    lg = aligned((B, ny, nx, ld), np.float32, 9.0); lg[..., : na * no] = logits
+    anchors = np.array([[1.25, 1.625], [2.0, 3.75], [4.125, 2.875]], np.float32)
+    stride = 8.0
+    apx = (anchors * stride).astype(np.float32).reshape(-1)
+    nrows = na * ny * nx + 11
+    z = aligned((B, nrows, no), np.float32, -1.0)
+    raw = aligned((B, na, ny, nx, no), np.float32, -1.0)
+    rc = lib.y5_detect_decode(ptr(lg), _lib.Y5_F32, B, ny, nx, na, no, 0, ld, stride, apx.ctypes.data_as(C.POINTER(C.c_float)),
+                              ptr(z), _lib.Y5_F32, nrows, 11, ptr(raw), None)
+    assert rc == 0, lib.y5_last_error()
+    x = torch.from_numpy(logits).view(B, ny, nx, na, no).permute(0, 3, 1, 2, 4).contiguous()
+    assert np.array_equal(raw, x.numpy())
+    grid, ag = yo.make_grid(nx, ny, torch.from_numpy(anchors), stride)
+    s = x.sigmoid()
+    ref = torch.cat(((s[..., :2] * 2 + grid) * stride, (s[..., 2:4] * 2) ** 2 * ag, s[..., 4:]), 4).view(B, -1, no).numpy()
+    np.testing.assert_allclose(z[:, 11:], ref, rtol=1e-5, atol=1e-5)
+    assert np.all(z[:, :11] == -1.0)
+
+
+@pytest.mark.parametrize("dt", ["f16", "f32"])
+def test_sppf_pool_emulated(dt):
+    lib = emu()
+    npdt = np.float16 if dt == "f16" else np.float32
+    B, H, W, Cc = 2, 6, 5, 16
+    x = detgen.uniform((B, Cc, H, W), -2, 2, name="pool").astype(npdt)
+    buf = aligned((B, H, W, 4 * Cc), npdt, 0.0)
+    buf[..., :Cc] = x.transpose(0, 2, 3, 1)
+    rc = lib.y5_sppf_pool(ptr(buf), _lib.Y5_F16 if dt == "f16" else _lib.Y5_F32, B, H, W, Cc, 4 * Cc, 5, None)
+    assert rc == 0, lib.y5_last_error()
+    t = torch.from_numpy(x.astype(np.float32))
+    for i in range(1, 4):
+        t = torch.nn.functional.max_pool2d(t, 5, 1, 2)
+        assert np.array_equal(buf[..., i * Cc:(i + 1) * Cc].astype(np.float32), t.permute(0, 2, 3, 1).numpy())
+
+
+def test_layout_and_copy_kernels_emulated():
+    lib = emu()
+    B, Cc, H, W = 2, 3, 5, 6
+    img = (detgen.uniform((B, Cc, H, W), 0, 255.99, name="u8")).astype(np.uint8)
+    src = aligned(img.shape, np.uint8); src[...] = img
+    dst = aligned((B, H, W, 4), np.float16, 5.0)
+    assert lib.y5_nchw_to_nhwc(ptr(src), _lib.Y5_U8, ptr(dst), _lib.Y5_F16, B, Cc, H, W, 4, 1.0 / 255.0, None) == 0
+    ref = (img.astype(np.float32) * np.float32(1.0 / 255.0)).astype(np.float16).transpose(0, 2, 3, 1)
+    assert np.array_equal(dst[..., :3], ref) and np.all(dst[..., 3] == 0)
+    # nhwc slice -> nchw
+    a = aligned((B, H, W, 16), np.float32); a[...] = detgen.uniform(a.shape, -1, 1, name="a")
+    o = aligned((B, 8, H, W), np.float32)
+    assert lib.y5_nhwc_to_nchw(ptr(a[..., 4:]), _lib.Y5_F32, ptr(o), B, 8, H, W, 16, None) == 0
+    assert np.array_equal(o, a[..., 4:12].transpose(0, 3, 1, 2))
+    # upsample into a slice, copy slice
+    s = aligned((B, H, W, 8), np.float16); s[...] = detgen.uniform(s.shape, -1, 1, name="s")
+    d = aligned((B, 2 * H, 2 * W, 24), np.float16, 3.0)
+    assert lib.y5_upsample2x(ptr(s), _lib.Y5_F16, ptr(d[..., 8:]), B, H, W, 8, 8, 24, None) == 0
+    assert np.array_equal(d[..., 8:16], np.repeat(np.repeat(s, 2, 1), 2, 2)) and np.all(d[..., :8] == 3) and np.all(d[..., 16:] == 3)
+    e = aligned((B, H, W, 24), np.float16, 1.0)
+    assert lib.y5_copy_slice(ptr(s), _lib.Y5_F16, ptr(e[..., 16:]), B * H * W, 8, 8, 24, None) == 0
+    assert np.array_equal(e[..., 16:], s) and np.all(e[..., :16] == 1)

@@ -1,0 +1,107 @@
+"""ctypes binding of libyolov5_hip.so (C-ABI declared in include/yolov5_hip.h).
+
+The library is built in-tree by `make -C yolov5_amd/csrc` (or `__graft_entry__.build()`); it is NOT optional:
+`lib()` raises RuntimeError when it cannot be loaded -- there is no eager/PyTorch fallback for any op.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyolov5_hip.so")
+
+Y5_F16, Y5_F32, Y5_U8 = 0, 1, 2
+NMS_MULTI_LABEL, NMS_AGNOSTIC = 1, 2
+
+
+class ConvDesc(C.Structure):
+    """y5_conv_desc (include/yolov5_hip.h)."""
+
+    _fields_ = [(n, C.c_int) for n in (
+        "dtype", "B", "H", "W", "C1", "ldx", "OH", "OW", "C2", "ldy", "KH", "KW", "SH", "SW", "PH", "PW",
+        "act", "Kpad", "Npad", "ldr", "ld2", "tile_n")]
+
+
+EXPORTS = {
+    # name: (restype, argtypes)
+    "y5_version": (C.c_int, []),
+    "y5_last_error": (C.c_char_p, []),
+    "y5_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_void_p]),
+    "y5_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, C.c_float, C.c_void_p]),
+    "y5_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_void_p]),
+    "y5_sppf_pool": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "y5_upsample2x": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.c_void_p]),
+    "y5_copy_slice": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "y5_detect_decode": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_float, C.POINTER(C.c_float), C.c_void_p, C.c_int, C.c_longlong, C.c_longlong,
+                                   C.c_void_p, C.c_void_p]),
+    "y5_nms_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "y5_nms_batched": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                 C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_size_t, C.c_void_p]),
+    "y5_plan_create": (C.c_void_p, []),
+    "y5_plan_destroy": (None, [C.c_void_p]),
+    "y5_plan_add_conv": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]),
+    "y5_plan_add_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, C.c_int, C.c_float]),
+    "y5_plan_add_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.c_int]),
+    "y5_plan_add_sppf_pool": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_int]),
+    "y5_plan_add_upsample2x": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, C.c_int]),
+    "y5_plan_add_copy_slice": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                         C.c_int]),
+    "y5_plan_add_detect_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_float), C.c_void_p,
+                                            C.c_int, C.c_longlong, C.c_longlong, C.c_void_p]),
+    "y5_plan_size": (C.c_int, [C.c_void_p]),
+    "y5_plan_run": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "y5_plan_run_range": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "y5_plan_capture": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "y5_plan_launch_graph": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "y5_plan_time_range": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
+}
+
+
+def bind(cdll):
+    """Attach restype/argtypes for every symbol declared in include/yolov5_hip.h; fails loudly if one is missing."""
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(cdll, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return cdll
+
+
+_lib = None
+
+
+def lib():
+    """The loaded kernel library.  Raises RuntimeError (never falls back) if it is not built / not loadable."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError(
+                f"yolov5_amd: {LIB_PATH} not found -- build it with `make -C yolov5_amd/csrc` "
+                "(or __graft_entry__.build()). There is no CPU/PyTorch fallback for the HIP kernels.")
+        try:
+            _lib = bind(C.CDLL(LIB_PATH))
+        except OSError as e:  # e.g. libamdhip64 missing
+            raise RuntimeError(f"yolov5_amd: cannot load {LIB_PATH}: {e}") from e
+    return _lib
+
+
+def check(rc: int, handle=None):
+    """Translate a y5_status into a Python exception (message from y5_last_error())."""
+    if rc != 0:
+        h = handle or lib()
+        msg = h.y5_last_error().decode(errors="replace")
+        if rc == -1:
+            raise ValueError(f"yolov5_hip: {msg}")
+        raise RuntimeError(f"yolov5_hip (status {rc}): {msg}")

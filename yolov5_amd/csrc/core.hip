@@ -1,0 +1,199 @@
+// Library core: status/error reporting, the per-device zero page, and the execution plan
+// (recorded op list replayed by one host call, optionally through a captured hipGraph).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/yolov5_hip.h"
+#include "y5_host.h"
+
+namespace {
+thread_local std::string g_err;
+std::mutex g_zero_mu;
+void* g_zero[64] = {nullptr};
+}  // namespace
+
+int y5_fail(int code, const char* msg) {
+  g_err = msg ? msg : "unknown error";
+  return code;
+}
+
+int y5_check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return Y5_OK;
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return Y5_ERR_RUNTIME;
+}
+
+const void* y5_zero_page() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(g_zero_mu);
+  if (!g_zero[dev]) {
+    void* p = nullptr;
+    if (hipMalloc(&p, 4096) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 4096) != hipSuccess) return nullptr;
+    g_zero[dev] = p;
+  }
+  return g_zero[dev];
+}
+
+extern "C" int y5_version(void) { return 10000 * 0 + 100 * 1 + 0; }
+extern "C" const char* y5_last_error(void) { return g_err.c_str(); }
+
+// ---------------------------------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------------------------------
+enum OpKind { OP_CONV, OP_TO_NHWC, OP_SPPF, OP_UPS, OP_COPY, OP_DECODE, OP_TO_NCHW };
+
+struct Op {
+  OpKind kind;
+  y5_conv_desc conv;
+  const void* p0; const void* p1; const void* p2; const void* p3; void* q0; void* q1;
+  int i[12];
+  float f[2];
+  long long l[2];
+  float anchors[16];
+};
+
+struct y5_plan {
+  std::vector<Op> ops;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+
+extern "C" y5_plan* y5_plan_create(void) { return new y5_plan(); }
+extern "C" void y5_plan_destroy(y5_plan* p) {
+  if (!p) return;
+  if (p->exec) hipGraphExecDestroy(p->exec);
+  if (p->graph) hipGraphDestroy(p->graph);
+  delete p;
+}
+extern "C" int y5_plan_size(const y5_plan* p) { return p ? (int)p->ops.size() : 0; }
+
+extern "C" int y5_plan_add_conv(y5_plan* pl, const y5_conv_desc* d, const void* x, const void* w, const float* bias,
+                                const void* res, void* y, void* y2) {
+  if (!pl || !d) return y5_fail(Y5_ERR_BAD_ARG, "plan_add_conv: null");
+  Op o{}; o.kind = OP_CONV; o.conv = *d; o.p0 = x; o.p1 = w; o.p2 = bias; o.p3 = res; o.q0 = y; o.q1 = y2;
+  pl->ops.push_back(o);
+  return Y5_OK;
+}
+extern "C" int y5_plan_add_nchw_to_nhwc(y5_plan* pl, const void* src, int sdt, void* dst, int ddt, int B, int C, int H, int W,
+                                        int ld, float scale) {
+  if (!pl) return y5_fail(Y5_ERR_BAD_ARG, "plan: null");
+  Op o{}; o.kind = OP_TO_NHWC; o.p0 = src; o.q0 = dst;
+  o.i[0] = sdt; o.i[1] = ddt; o.i[2] = B; o.i[3] = C; o.i[4] = H; o.i[5] = W; o.i[6] = ld; o.f[0] = scale;
+  pl->ops.push_back(o);
+  return Y5_OK;
+}
+extern "C" int y5_plan_add_nhwc_to_nchw(y5_plan* pl, const void* src, int dt, void* dst, int B, int C, int H, int W, int ld) {
+  if (!pl) return y5_fail(Y5_ERR_BAD_ARG, "plan: null");
+  Op o{}; o.kind = OP_TO_NCHW; o.p0 = src; o.q0 = dst;
+  o.i[0] = dt; o.i[1] = B; o.i[2] = C; o.i[3] = H; o.i[4] = W; o.i[5] = ld;
+  pl->ops.push_back(o);
+  return Y5_OK;
+}
+extern "C" int y5_plan_add_sppf_pool(y5_plan* pl, void* buf, int dt, int B, int H, int W, int C, int ld, int k) {
+  if (!pl) return y5_fail(Y5_ERR_BAD_ARG, "plan: null");
+  Op o{}; o.kind = OP_SPPF; o.q0 = buf;
+  o.i[0] = dt; o.i[1] = B; o.i[2] = H; o.i[3] = W; o.i[4] = C; o.i[5] = ld; o.i[6] = k;
+  pl->ops.push_back(o);
+  return Y5_OK;
+}
+extern "C" int y5_plan_add_upsample2x(y5_plan* pl, const void* src, int dt, void* dst, int B, int H, int W, int C, int lds, int ldd) {
+  if (!pl) return y5_fail(Y5_ERR_BAD_ARG, "plan: null");
+  Op o{}; o.kind = OP_UPS; o.p0 = src; o.q0 = dst;
+  o.i[0] = dt; o.i[1] = B; o.i[2] = H; o.i[3] = W; o.i[4] = C; o.i[5] = lds; o.i[6] = ldd;
+  pl->ops.push_back(o);
+  return Y5_OK;
+}
+extern "C" int y5_plan_add_copy_slice(y5_plan* pl, const void* src, int dt, void* dst, int npix, int C, int lds, int ldd) {
+  if (!pl) return y5_fail(Y5_ERR_BAD_ARG, "plan: null");
+  Op o{}; o.kind = OP_COPY; o.p0 = src; o.q0 = dst;
+  o.i[0] = dt; o.i[1] = npix; o.i[2] = C; o.i[3] = lds; o.i[4] = ldd;
+  pl->ops.push_back(o);
+  return Y5_OK;
+}
+extern "C" int y5_plan_add_detect_decode(y5_plan* pl, const void* logits, int dt, int B, int ny, int nx, int na, int no, int nm, int ld,
+                                         float stride, const float* anchors_px, void* z, int zdt, long long nrows_total,
+                                         long long row_off, void* raw) {
+  if (!pl || !anchors_px || na > 8) return y5_fail(Y5_ERR_BAD_ARG, "plan: null / na");
+  Op o{}; o.kind = OP_DECODE; o.p0 = logits; o.q0 = z; o.q1 = raw;
+  o.i[0] = dt; o.i[1] = B; o.i[2] = ny; o.i[3] = nx; o.i[4] = na; o.i[5] = no; o.i[6] = nm; o.i[7] = ld; o.i[8] = zdt;
+  o.f[0] = stride; o.l[0] = nrows_total; o.l[1] = row_off;
+  for (int k = 0; k < na * 2; ++k) o.anchors[k] = anchors_px[k];
+  pl->ops.push_back(o);
+  return Y5_OK;
+}
+
+static int run_op(const Op& o, void* st) {
+  switch (o.kind) {
+    case OP_CONV: return y5_conv2d_fwd(&o.conv, o.p0, o.p1, (const float*)o.p2, o.p3, o.q0, o.q1, st);
+    case OP_TO_NHWC: return y5_nchw_to_nhwc(o.p0, o.i[0], o.q0, o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], o.i[6], o.f[0], st);
+    case OP_TO_NCHW: return y5_nhwc_to_nchw(o.p0, o.i[0], o.q0, o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], st);
+    case OP_SPPF: return y5_sppf_pool(o.q0, o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], o.i[6], st);
+    case OP_UPS: return y5_upsample2x(o.p0, o.i[0], o.q0, o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], o.i[6], st);
+    case OP_COPY: return y5_copy_slice(o.p0, o.i[0], o.q0, o.i[1], o.i[2], o.i[3], o.i[4], st);
+    case OP_DECODE:
+      return y5_detect_decode(o.p0, o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], o.i[6], o.i[7], o.f[0], o.anchors, o.q0, o.i[8],
+                              o.l[0], o.l[1], o.q1, st);
+  }
+  return y5_fail(Y5_ERR_BAD_ARG, "plan: unknown op");
+}
+
+extern "C" int y5_plan_run_range(y5_plan* pl, int first, int last, void* st) {
+  if (!pl || first < 0 || last > (int)pl->ops.size() || first > last) return y5_fail(Y5_ERR_BAD_ARG, "plan_run_range: bad range");
+  for (int k = first; k < last; ++k) {
+    const int rc = run_op(pl->ops[k], st);
+    if (rc) return rc;
+  }
+  return Y5_OK;
+}
+extern "C" int y5_plan_run(y5_plan* pl, void* st) { return y5_plan_run_range(pl, 0, pl ? (int)pl->ops.size() : 0, st); }
+
+extern "C" int y5_plan_capture(y5_plan* pl, void* st_) {
+  if (!pl) return y5_fail(Y5_ERR_BAD_ARG, "plan_capture: null");
+  hipStream_t st = static_cast<hipStream_t>(st_);
+  if (!y5_zero_page()) return y5_fail(Y5_ERR_RUNTIME, "plan_capture: zero page");
+  // one eager run first: performs the per-kernel one-time attribute setup outside of capture
+  int rc = y5_plan_run(pl, st_);
+  if (rc) return rc;
+  if (hipStreamSynchronize(st) != hipSuccess) return y5_fail(Y5_ERR_RUNTIME, "plan_capture: sync failed");
+  if (pl->exec) { hipGraphExecDestroy(pl->exec); pl->exec = nullptr; }
+  if (pl->graph) { hipGraphDestroy(pl->graph); pl->graph = nullptr; }
+  if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) return y5_fail(Y5_ERR_RUNTIME, "plan_capture: begin capture failed");
+  rc = y5_plan_run(pl, st_);
+  const hipError_t e = hipStreamEndCapture(st, &pl->graph);
+  if (rc) return rc;
+  if (e != hipSuccess || !pl->graph) return y5_fail(Y5_ERR_RUNTIME, "plan_capture: end capture failed");
+  if (hipGraphInstantiate(&pl->exec, pl->graph, nullptr, nullptr, 0) != hipSuccess) return y5_fail(Y5_ERR_RUNTIME, "plan_capture: instantiate failed");
+  return Y5_OK;
+}
+
+extern "C" int y5_plan_launch_graph(y5_plan* pl, void* st_) {
+  if (!pl || !pl->exec) return y5_fail(Y5_ERR_BAD_ARG, "plan_launch_graph: plan not captured");
+  if (hipGraphLaunch(pl->exec, static_cast<hipStream_t>(st_)) != hipSuccess) return y5_fail(Y5_ERR_RUNTIME, "plan_launch_graph: launch failed");
+  return Y5_OK;
+}
+
+extern "C" int y5_plan_time_range(y5_plan* pl, int first, int last, int iters, void* st_, float* ms) {
+  if (!pl || !ms || iters < 1) return y5_fail(Y5_ERR_BAD_ARG, "plan_time_range: bad args");
+  hipStream_t st = static_cast<hipStream_t>(st_);
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return y5_fail(Y5_ERR_RUNTIME, "event create failed");
+  int rc = y5_plan_run_range(pl, first, last, st_);  // warm-up
+  if (!rc) {
+    hipEventRecord(e0, st);
+    for (int it = 0; it < iters && !rc; ++it) rc = y5_plan_run_range(pl, first, last, st_);
+    hipEventRecord(e1, st);
+    if (hipEventSynchronize(e1) != hipSuccess) rc = y5_fail(Y5_ERR_RUNTIME, "event sync failed");
+    else hipEventElapsedTime(ms, e0, e1);
+  }
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  return rc;
+}

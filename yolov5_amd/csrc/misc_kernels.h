@@ -1,0 +1,148 @@
+// HBM-bound glue kernels of the YOLOv5 forward path (gfx950): layout conversion at the API boundary,
+// SPPF max-pool chain, nearest 2x upsample / channel-slice copies, Detect decode.
+// Every kernel moves 16 bytes per lane where the layout allows it and is launched with >> 256 workgroups.
+#pragma once
+#include "y5_common.h"
+
+// ---- element load/store helpers ---------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float y5_ld(const T* p) { return (float)*p; }
+template <> __device__ __forceinline__ float y5_ld<unsigned char>(const unsigned char* p) { return (float)*p; }
+
+// ---------------------------------------------------------------------------------------------------
+// NCHW (u8|f16|f32) -> NHWC (f16|f32), channels padded to ld with zeros, values scaled (train.py:379)
+// one thread per pixel: reads are coalesced per channel plane, the write is one ld-element vector
+// ---------------------------------------------------------------------------------------------------
+template <typename S, typename D>
+__global__ void y5_nchw_to_nhwc_kernel(const S* __restrict__ src, D* __restrict__ dst, int C, long long HW,
+                                       long long npix, int ld, float scale) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix) return;
+  const long long b = i / HW, r = i - b * HW;
+  const S* s = src + b * C * HW + r;
+  D* d = dst + i * ld;
+  for (int c = 0; c < ld; ++c) d[c] = c < C ? (D)(y5_ld<S>(s + (long long)c * HW) * scale) : (D)0.f;
+}
+
+// NHWC slice -> contiguous NCHW (API boundary only; one thread per output element, writes coalesced)
+template <typename T>
+__global__ void y5_nhwc_to_nchw_kernel(const T* __restrict__ src, T* __restrict__ dst, int C, long long HW,
+                                       long long total, int ld) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long long r = i % HW;
+  const long long bc = i / HW;
+  const long long c = bc % C, b = bc / C;
+  dst[i] = src[(b * HW + r) * ld + c];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// SPPF pooling chain (models/common.py:338-340).  One workgroup per (image, 16-byte channel group):
+// the H*W*16 B plane lives in LDS; three successive k x k stride-1 max pools (implicit -inf padding)
+// are written to channel slices 1..3 of the same NHWC buffer.
+// ---------------------------------------------------------------------------------------------------
+template <typename V>  // V = half8_t (8 channels) or float4_t (4 channels): 16 bytes
+__global__ void y5_sppf_pool_kernel(char* __restrict__ buf, int H, int W, int C_bytes, int ld_bytes, int k) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int HW = H * W;
+  V* p0 = reinterpret_cast<V*>(smem);
+  V* p1 = p0 + HW;
+  const int groups = C_bytes / 16;
+  const int b = blockIdx.x / groups, cg = blockIdx.x - b * groups;
+  char* base = buf + (size_t)b * HW * ld_bytes + (size_t)cg * 16;
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) p0[i] = *reinterpret_cast<const V*>(base + (size_t)i * ld_bytes);
+  __syncthreads();
+  const int r = k / 2;
+  V* in = p0;
+  V* out = p1;
+  for (int pass = 1; pass <= 3; ++pass) {
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+      const int y = i / W, x = i - y * W;
+      const int y0 = y - r < 0 ? 0 : y - r, y1 = y + r >= H ? H - 1 : y + r;
+      const int x0 = x - r < 0 ? 0 : x - r, x1 = x + r >= W ? W - 1 : x + r;
+      V m = in[y0 * W + x0];
+      for (int yy = y0; yy <= y1; ++yy)
+        for (int xx = x0; xx <= x1; ++xx) m = __builtin_elementwise_max(m, in[yy * W + xx]);
+      out[i] = m;
+      *reinterpret_cast<V*>(base + (size_t)i * ld_bytes + (size_t)pass * C_bytes) = m;
+    }
+    __syncthreads();
+    V* t = in; in = out; out = t;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// nearest 2x upsample into a channel slice; 16 B per lane.  dst pixel (b, y, x) <- src (b, y/2, x/2)
+// ---------------------------------------------------------------------------------------------------
+__global__ void y5_upsample2x_kernel(const char* __restrict__ src, char* __restrict__ dst, int H, int W, int vec_per_pix,
+                                     int lds_bytes, int ldd_bytes, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over dst vectors
+  if (i >= total) return;
+  const int v = (int)(i % vec_per_pix);
+  const long long pix = i / vec_per_pix;
+  const int W2 = 2 * W, H2 = 2 * H;
+  const int x = (int)(pix % W2);
+  const long long t = pix / W2;
+  const int y = (int)(t % H2);
+  const long long b = t / H2;
+  const long long sp = (b * H + (y >> 1)) * W + (x >> 1);
+  *reinterpret_cast<uint4_t*>(dst + pix * ldd_bytes + v * 16) =
+      *reinterpret_cast<const uint4_t*>(src + sp * lds_bytes + v * 16);
+}
+
+__global__ void y5_copy_slice_kernel(const char* __restrict__ src, char* __restrict__ dst, int vec_per_pix, int lds_bytes,
+                                     int ldd_bytes, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int v = (int)(i % vec_per_pix);
+  const long long pix = i / vec_per_pix;
+  *reinterpret_cast<uint4_t*>(dst + pix * ldd_bytes + v * 16) =
+      *reinterpret_cast<const uint4_t*>(src + pix * lds_bytes + v * 16);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Detect decode (models/yolo.py:96-115).  One thread per OUTPUT element (b, a, iy, ix, o), o fastest, so
+// that both the z row write and the logits read are contiguous across the wave.
+// Row index inside z is bit-exactly the reference's: row_off + a*ny*nx + iy*nx + ix.
+// ---------------------------------------------------------------------------------------------------
+struct Y5DecodeParams {
+  const void* logits;
+  void* z;
+  void* raw;
+  long long nrows_total, row_off, total;
+  int ny, nx, na, no, nm, ld;
+  float stride;
+  float anchors_px[16];  // na*2
+};
+
+template <typename T, typename Z>
+__global__ void y5_detect_decode_kernel(const Y5DecodeParams p) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.total) return;
+  const int o = (int)(i % p.no);
+  long long t = i / p.no;
+  const int npix = p.ny * p.nx;
+  const int pix = (int)(t % npix);
+  t /= npix;
+  const int a = (int)(t % p.na);
+  const long long b = t / p.na;
+  const T* lg = static_cast<const T*>(p.logits);
+  const float v = (float)lg[(b * npix + pix) * p.ld + a * p.no + o];
+  if (p.raw) static_cast<T*>(p.raw)[i] = (T)v;  // (bs,na,ny,nx,no) contiguous == index i
+  float r;
+  if (o >= p.no - p.nm) {
+    r = v;  // Segment mask coefficients are not activated (yolo.py:104-108)
+  } else {
+    const float s = y5_sigmoid(v);
+    if (o < 2) {
+      const int iy = pix / p.nx, ix = pix - iy * p.nx;
+      const float g = (float)(o == 0 ? ix : iy) - 0.5f;  // grid = (ix-0.5, iy-0.5), yolo.py:126
+      r = (s * 2.0f + g) * p.stride;                        // yolo.py:110
+    } else if (o < 4) {
+      const float w = s * 2.0f;
+      r = w * w * p.anchors_px[a * 2 + (o - 2)];  // yolo.py:111
+    } else {
+      r = s;
+    }
+  }
+  static_cast<Z*>(p.z)[(b * p.nrows_total + p.row_off + (long long)a * npix + pix) * p.no + o] = (Z)r;
+}

@@ -1,0 +1,74 @@
+// C-ABI launcher for batched NMS (nms_kernels.h).  Built with -ffp-contract=off (bit-exact selection).
+#include <hip/hip_runtime.h>
+
+#include "../../include/yolov5_hip.h"
+#include "nms_kernels.h"
+#include "y5_host.h"
+
+namespace {
+struct Layout { size_t off_count, off_keys, off_cls, total; long long cap, cap_pad; };
+Layout layout(int bs, int n, int no, int nm, int flags) {
+  Layout L{};
+  const int nc = no - 5 - nm;
+  L.cap = (flags & Y5_NMS_MULTI_LABEL) && nc > 1 ? (long long)n * nc : n;
+  long long p2 = 64;
+  while (p2 < L.cap) p2 <<= 1;
+  L.cap_pad = p2;
+  size_t o = 0;
+  L.off_count = o; o += ((size_t)bs * 4 + 255) & ~(size_t)255;
+  L.off_keys = o; o += ((size_t)bs * L.cap_pad * 8 + 255) & ~(size_t)255;
+  L.off_cls = o; o += ((size_t)bs * n + 255) & ~(size_t)255;
+  L.total = o;
+  return L;
+}
+}  // namespace
+
+extern "C" size_t y5_nms_workspace_bytes(int bs, int n, int no, int nm, int flags, int max_nms) {
+  (void)max_nms;
+  return layout(bs, n, no, nm, flags).total;
+}
+
+extern "C" int y5_nms_batched(const void* pred, int dt, int bs, int n, int no, int nm, float conf_thres, float iou_thres, int max_det,
+                              int max_nms, float max_wh, int flags, const int* classes, int nclasses, float* out, int* out_count,
+                              void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  const int nc = no - 5 - nm;
+  if (!pred || !out || !out_count || !ws || bs <= 0 || n <= 0 || nc < 1 || nc > 256 || nm < 0)
+    return y5_fail(Y5_ERR_BAD_ARG, "nms: bad args");
+  if (!(conf_thres >= 0.f && conf_thres <= 1.f)) return y5_fail(Y5_ERR_BAD_ARG, "nms: Invalid Confidence threshold, valid values are between 0.0 and 1.0");
+  if (!(iou_thres >= 0.f && iou_thres <= 1.f)) return y5_fail(Y5_ERR_BAD_ARG, "nms: Invalid IoU, valid values are between 0.0 and 1.0");
+  if (max_det < 1 || max_det > Y5_NMS_MAX_DET_CAP) return y5_fail(Y5_ERR_UNSUPPORTED, "nms: max_det out of range [1,4096]");
+  if (dt != Y5_F16 && dt != Y5_F32) return y5_fail(Y5_ERR_BAD_ARG, "nms: dtype");
+  if ((flags & Y5_NMS_MULTI_LABEL) && nc <= 1) flags &= ~Y5_NMS_MULTI_LABEL;  // general.py:693
+  const Layout L = layout(bs, n, no, nm, flags);
+  if (ws_bytes < L.total || ((uintptr_t)ws & 255)) return y5_fail(Y5_ERR_WORKSPACE, "nms: workspace too small or misaligned");
+
+  Y5NmsParams p{};
+  p.pred = pred; p.bs = bs; p.n = n; p.no = no; p.nc = nc; p.nm = nm;
+  p.conf_thres = conf_thres; p.iou_thres = iou_thres; p.max_wh = max_wh;
+  p.max_det = max_det; p.max_nms = max_nms; p.flags = flags;
+  p.classes = nclasses > 0 ? classes : nullptr; p.nclasses = nclasses;
+  p.out = out; p.out_count = out_count;
+  char* w = static_cast<char*>(ws);
+  p.count = reinterpret_cast<int*>(w + L.off_count);
+  p.keys = reinterpret_cast<unsigned long long*>(w + L.off_keys);
+  p.best_cls = reinterpret_cast<unsigned char*>(w + L.off_cls);
+  p.cap = L.cap; p.cap_pad = L.cap_pad;
+
+  if (hipMemsetAsync(p.count, 0, (size_t)bs * 4, st) != hipSuccess) return y5_fail(Y5_ERR_RUNTIME, "nms: memset failed");
+  const dim3 fg((unsigned)((n + 255) / 256), (unsigned)bs), fb(256);
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)y5_nms_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Y5_NMS_SORT_LDS_KEYS * 8);
+    hipFuncSetAttribute((const void*)y5_nms_greedy_kernel<half_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    hipFuncSetAttribute((const void*)y5_nms_greedy_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr = true;
+  }
+  const size_t greedy_lds = (size_t)max_det * 20 + 64;
+  if (dt == Y5_F16) hipLaunchKernelGGL((y5_nms_filter_kernel<half_t>), fg, fb, 0, st, p);
+  else hipLaunchKernelGGL((y5_nms_filter_kernel<float>), fg, fb, 0, st, p);
+  hipLaunchKernelGGL(y5_nms_sort_kernel, dim3((unsigned)bs), dim3(1024), Y5_NMS_SORT_LDS_KEYS * 8, st, p);
+  if (dt == Y5_F16) hipLaunchKernelGGL((y5_nms_greedy_kernel<half_t>), dim3((unsigned)bs), dim3(256), greedy_lds, st, p);
+  else hipLaunchKernelGGL((y5_nms_greedy_kernel<float>), dim3((unsigned)bs), dim3(256), greedy_lds, st, p);
+  return y5_check_launch("y5_nms_batched");
+}

@@ -1,0 +1,248 @@
+// Batched non_max_suppression for gfx950: candidate filter (wave-aggregated compaction), per-image bitonic
+// sort of 64-bit (confidence, index) keys in LDS, greedy IoU suppression with the kept boxes held in LDS.
+//
+// Follows utils/general.py:658-767 + torchvision.ops.nms (general.py:750); all arithmetic is IEEE fp32 without
+// FMA contraction (this translation unit is built with -ffp-contract=off) so that the SELECTION ORDER is
+// bit-exact with the CPU oracle:
+//   conf_j = obj * cls_j ; keep obj > conf_thres and conf > conf_thres            (general.py:679,719,731)
+//   box    = (cx - w/2, cy - h/2, cx + w/2, cy + h/2)                             (general.py:722)
+//   order  = conf descending, ties: lower candidate index first                   (general.py:745, stable)
+//   boxes += cls * max_wh unless agnostic                                         (general.py:748-749)
+//   greedy: keep i unless a kept j has inter/(area_i + area_j - inter) > iou_thres (torchvision nms)
+//   first max_det kept rows, in order                                             (general.py:751)
+#pragma once
+#include "y5_common.h"
+
+#define Y5_NMS_SORT_LDS_KEYS 8192   // keys sorted entirely in LDS (64 KiB)
+#define Y5_NMS_MAX_DET_CAP 4096
+
+struct Y5NmsParams {
+  const void* pred;
+  int bs, n, no, nc, nm;
+  float conf_thres, iou_thres, max_wh;
+  int max_det, max_nms, flags;
+  const int* classes;
+  int nclasses;
+  float* out;
+  int* out_count;
+  // workspace
+  int* count;                 // [bs]
+  unsigned long long* keys;   // [bs][cap_pad]
+  unsigned char* best_cls;    // [bs][n] (best-class mode)
+  long long cap, cap_pad;
+};
+
+template <typename T> __device__ __forceinline__ float y5_ldf(const T* p, long long i) { return (float)p[i]; }
+
+// ---- K1: filter + compaction -----------------------------------------------------------------------
+template <typename T>
+__global__ void y5_nms_filter_kernel(const Y5NmsParams p) {
+  const int b = blockIdx.y;
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= p.n) return;
+  const T* row = static_cast<const T*>(p.pred) + ((long long)b * p.n + r) * p.no;
+  const float obj = (float)row[4];
+  if (!(obj > p.conf_thres)) return;
+  unsigned long long* keys = p.keys + (long long)b * p.cap_pad;
+  if (p.flags & 1) {  // multi_label: every (row, class) with obj*cls > thres (general.py:726-728)
+    for (int j = 0; j < p.nc; ++j) {
+      const float conf = (float)row[5 + j] * obj;
+      if (conf > p.conf_thres) {
+        bool ok = true;
+        if (p.classes) {
+          ok = false;
+          for (int c = 0; c < p.nclasses; ++c) ok |= (p.classes[c] == j);
+        }
+        if (ok) {
+          const unsigned idx = (unsigned)r * (unsigned)p.nc + (unsigned)j;
+          const int slot = atomicAdd(p.count + b, 1);
+          keys[slot] = ((unsigned long long)__float_as_uint(conf) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+        }
+      }
+    }
+  } else {  // best class only: first maximal class (general.py:730)
+    float best = (float)row[5] * obj;
+    int bj = 0;
+    for (int j = 1; j < p.nc; ++j) {
+      const float conf = (float)row[5 + j] * obj;
+      if (conf > best) { best = conf; bj = j; }
+    }
+    if (best > p.conf_thres) {
+      bool ok = true;
+      if (p.classes) {
+        ok = false;
+        for (int c = 0; c < p.nclasses; ++c) ok |= (p.classes[c] == bj);
+      }
+      if (ok) {
+        p.best_cls[(long long)b * p.n + r] = (unsigned char)bj;
+        const int slot = atomicAdd(p.count + b, 1);
+        keys[slot] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)r);
+      }
+    }
+  }
+}
+
+// ---- K2: per-image bitonic sort, descending ----------------------------------------------------------
+__device__ __forceinline__ void y5_cmpswap_desc(unsigned long long& a, unsigned long long& b2, bool desc) {
+  if ((a < b2) == desc) { const unsigned long long t = a; a = b2; b2 = t; }
+}
+
+__global__ void y5_nms_sort_kernel(const Y5NmsParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* sk = reinterpret_cast<unsigned long long*>(smem);
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  unsigned long long* keys = p.keys + (long long)b * p.cap_pad;
+  long long n = p.count[b];
+  if (n > p.cap) n = p.cap;
+  if (n <= 1) return;
+  long long np2 = 64;
+  while (np2 < n) np2 <<= 1;
+  if (np2 <= Y5_NMS_SORT_LDS_KEYS) {
+    const int N = (int)np2;
+    for (int i = tid; i < N; i += nt) sk[i] = i < n ? keys[i] : 0ull;
+    __syncthreads();
+    for (int k = 2; k <= N; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = tid; t < N / 2; t += nt) {
+          const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          const int hi = lo | j;
+          const bool desc = (lo & k) == 0;
+          unsigned long long a = sk[lo], c = sk[hi];
+          if ((a < c) == desc) { sk[lo] = c; sk[hi] = a; }
+        }
+        __syncthreads();
+      }
+    }
+    for (int i = tid; i < n; i += nt) keys[i] = sk[i];
+  } else {
+    // large candidate sets (val-style thresholds): bitonic network over global memory; strides that fit a
+    // Y5_NMS_SORT_LDS_KEYS window are finished inside LDS
+    for (long long i = n + tid; i < np2; i += nt) keys[i] = 0ull;
+    __syncthreads();
+    const long long half = np2 >> 1;
+    constexpr int WIN = Y5_NMS_SORT_LDS_KEYS;
+    for (long long k = 2; k <= np2; k <<= 1) {
+      long long j = k >> 1;
+      for (; j >= WIN; j >>= 1) {
+        for (long long t = tid; t < half; t += nt) {
+          const long long lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          const long long hi = lo | j;
+          const bool desc = (lo & k) == 0;
+          const unsigned long long a = keys[lo], c = keys[hi];
+          if ((a < c) == desc) { keys[lo] = c; keys[hi] = a; }
+        }
+        __syncthreads();
+      }
+      // remaining strides j < WIN: independent inside aligned windows of WIN keys
+      for (long long w0 = 0; w0 < np2; w0 += WIN) {
+        for (int i = tid; i < WIN; i += nt) sk[i] = keys[w0 + i];
+        __syncthreads();
+        for (long long jj = j; jj > 0; jj >>= 1) {
+          for (int t = tid; t < WIN / 2; t += nt) {
+            const int lo = (int)(((t & ~(jj - 1)) << 1) | (t & (jj - 1)));
+            const int hi = lo | (int)jj;
+            const bool desc = ((w0 + lo) & k) == 0;
+            const unsigned long long a = sk[lo], c = sk[hi];
+            if ((a < c) == desc) { sk[lo] = c; sk[hi] = a; }
+          }
+          __syncthreads();
+        }
+        for (int i = tid; i < WIN; i += nt) keys[w0 + i] = sk[i];
+        __syncthreads();
+      }
+    }
+  }
+}
+
+// ---- K3: greedy suppression, kept boxes in LDS -------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256)
+void y5_nms_greedy_kernel(const Y5NmsParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* kept = reinterpret_cast<float*>(smem);                 // [max_det][5]: x1,y1,x2,y2 (class offset), area
+  unsigned long long* supmask = reinterpret_cast<unsigned long long*>(smem + (size_t)p.max_det * 20);  // [4]
+  int* s_nkept = reinterpret_cast<int*>(supmask + 4);
+
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned long long* keys = p.keys + (long long)b * p.cap_pad;
+  long long n = p.count[b];
+  if (n > p.cap) n = p.cap;
+  if (n > p.max_nms) n = p.max_nms;
+  const T* pred = static_cast<const T*>(p.pred) + (long long)b * p.n * p.no;
+  const int mi = 5 + p.nc;
+  const int ow = 6 + p.nm;
+  float* out = p.out + (long long)b * p.max_det * ow;
+  const float cmul = (p.flags & 2) ? 0.0f : p.max_wh;
+
+  if (tid == 0) *s_nkept = 0;
+  __syncthreads();
+  int nkept = 0;
+
+  for (long long base = 0; base < n && nkept < p.max_det; base += 64) {
+    const long long ci = base + lane;
+    const bool valid = ci < n;
+    float x1 = 0, y1 = 0, x2 = 0, y2 = 0, conf = 0, clsf = 0, bx1 = 0, by1 = 0, bx2 = 0, by2 = 0, area = 0;
+    long long rowi = 0;
+    if (valid) {
+      const unsigned long long key = keys[ci];
+      conf = __uint_as_float((unsigned)(key >> 32));
+      const unsigned idx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
+      int cls;
+      if (p.flags & 1) { rowi = idx / (unsigned)p.nc; cls = (int)(idx - (unsigned)rowi * (unsigned)p.nc); }
+      else { rowi = idx; cls = p.best_cls[(long long)b * p.n + rowi]; }
+      const T* row = pred + rowi * p.no;
+      const float cx = (float)row[0], cy = (float)row[1], w = (float)row[2], h = (float)row[3];
+      const float hw = w / 2.0f, hh = h / 2.0f;
+      x1 = cx - hw; y1 = cy - hh; x2 = cx + hw; y2 = cy + hh;
+      clsf = (float)cls;
+      const float c = clsf * cmul;
+      bx1 = x1 + c; by1 = y1 + c; bx2 = x2 + c; by2 = y2 + c;
+      area = (bx2 - bx1) * (by2 - by1);
+    }
+    // phase A: every wave tests the 64 candidates against a quarter of the kept list
+    bool sup = false;
+    for (int k = wave; k < nkept; k += 4) {
+      const float kx1 = kept[k * 5 + 0], ky1 = kept[k * 5 + 1], kx2 = kept[k * 5 + 2], ky2 = kept[k * 5 + 3];
+      const float ka = kept[k * 5 + 4];
+      const float iw = fmaxf(0.0f, fminf(kx2, bx2) - fmaxf(kx1, bx1));
+      const float ih = fmaxf(0.0f, fminf(ky2, by2) - fmaxf(ky1, by1));
+      const float inter = iw * ih;
+      sup |= (inter / (ka + area - inter)) > p.iou_thres;
+    }
+    const unsigned long long m = __ballot(sup);
+    if (lane == 0) supmask[wave] = m;
+    __syncthreads();
+    // phase B: wave 0 resolves the chunk serially over its surviving candidates
+    if (wave == 0) {
+      unsigned long long alive = __ballot(valid) & ~(supmask[0] | supmask[1] | supmask[2] | supmask[3]);
+      while (alive != 0ull && nkept < p.max_det) {
+        const int i = __builtin_ctzll(alive);
+        alive &= ~(1ull << i);
+        const float kx1 = __shfl(bx1, i), ky1 = __shfl(by1, i), kx2 = __shfl(bx2, i), ky2 = __shfl(by2, i);
+        const float ka = __shfl(area, i);
+        if (lane == i) {
+          kept[nkept * 5 + 0] = bx1; kept[nkept * 5 + 1] = by1; kept[nkept * 5 + 2] = bx2; kept[nkept * 5 + 3] = by2;
+          kept[nkept * 5 + 4] = area;
+          float* o = out + (long long)nkept * ow;
+          o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = conf; o[5] = clsf;
+          const T* row = pred + rowi * p.no;
+          const float obj = (float)row[4];
+          for (int q = 0; q < p.nm; ++q) o[6 + q] = (float)row[mi + q] * obj;  // general.py:719 scales masks too
+        }
+        ++nkept;
+        const float iw = fmaxf(0.0f, fminf(kx2, bx2) - fmaxf(kx1, bx1));
+        const float ih = fmaxf(0.0f, fminf(ky2, by2) - fmaxf(ky1, by1));
+        const float inter = iw * ih;
+        const bool s2 = lane > i && (inter / (ka + area - inter)) > p.iou_thres;
+        alive &= ~__ballot(s2);
+      }
+      if (lane == 0) *s_nkept = nkept;
+    }
+    __syncthreads();
+    nkept = *s_nkept;
+  }
+  if (tid == 0) p.out_count[b] = nkept;
+}

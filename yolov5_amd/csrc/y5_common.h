@@ -1,0 +1,34 @@
+// Shared device-side helpers for the yolov5_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef float float16_t __attribute__((ext_vector_type(16)));
+typedef uint32_t uint4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t uint2_t __attribute__((ext_vector_type(2)));
+
+#define Y5_WAVE 64
+
+// address-space casts for the LDS-DMA builtin (global -> LDS, 16 B per lane, lane-linear destination)
+#define Y5_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define Y5_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+__device__ __forceinline__ void y5_glds16(const void* gsrc, void* lds_wave_base) {
+  // LDS destination = wave-uniform base + lane*16 (hardware rule); global source is per lane.
+  __builtin_amdgcn_global_load_lds(Y5_GLB_PTR(gsrc), Y5_LDS_PTR(lds_wave_base), 16, 0, 0);
+}
+
+__device__ __forceinline__ float y5_sigmoid(float v) { return 1.0f / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float y5_silu(float v) { return v / (1.0f + __expf(-v)); }
+
+// XCD-aware bijective remap of a 1-D block id: blocks that land on the same XCD (bid % 8) get a
+// contiguous range of logical tile ids so that neighbouring tiles share that XCD's L2.
+__device__ __forceinline__ int y5_xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
