@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""Headline benchmark (BASELINE.json): images/sec at 640 px, yolov5s, bs=64 per GPU, fp16, synthetic data.
+
+One "step" = the whole inference hot path over one batch that is already resident in HBM:
+    NCHW fp16 batch -> HIP forward (backbone + PANet neck + Detect decode) -> HIP non_max_suppression.
+N GPUs: one process per GPU (torch.distributed, backend nccl = RCCL), every rank runs the same per-GPU batch
+(images are independent: weak scaling, no data-path collective -- DESIGN.md section "multi-GPU").
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (conv implicit-GEMM kernel,
+MFMA bound) and `cpu_baseline` (the CPU oracle = port of the reference path, timed on this box's host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def build_model(name, dev, half=True):
+    from yolov5_amd.yolo import DetectionModel
+
+    torch.manual_seed(0)
+    m = DetectionModel(name + ".yaml").eval().fuse()
+    m = m.half() if half else m.float()
+    return m.to(dev)
+
+
+def calibrate_objectness(model, x, frac=0.02, conf=0.25):
+    """Random-init weights give objectness ~0.007 everywhere (models/yolo.py:323 bias init), so NMS would see no
+    candidates.  Shift the Detect objectness biases so that ~`frac` of the 25200 rows/img pass conf_thres
+    (SURVEY 8d 'realistic' case, ~500 candidates per image)."""
+    import math
+
+    det = model.model[-1]
+    z = model(x)[0]
+    obj = z[..., 4].float().flatten()
+    k = max(int(obj.numel() * (1 - frac)), 1)
+    q = obj.kthvalue(k).values.clamp(1e-6, 1 - 1e-6)
+    shift = math.log(conf / (1 - conf)) - math.log(float(q) / (1 - float(q)))
+    with torch.no_grad():
+        for mi in det.m:
+            b = mi.bias.view(det.na, -1)
+            b[:, 4] += shift
+    model.invalidate_engine()
+
+
+def conv_flops(engine):
+    """Algorithmic FLOPs per conv launch: 2 * B*OH*OW * C2 * C1*kh*kw with the TRUE (unpadded) channel counts."""
+    out = []
+    B = engine.spec.B
+    for i, op in enumerate(engine.spec.ops):
+        if op["op"] != "conv":
+            continue
+        fl = 0
+        for m in op["mods"]:
+            cv = m.conv if hasattr(m, "conv") else m
+            fl += 2 * B * op["y"].H * op["y"].W * cv.out_channels * cv.in_channels * cv.kernel_size[0] * cv.kernel_size[1]
+        out.append((i, fl))
+    return out
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The oracle (CPU port of the reference forward + NMS, torch-CPU fp32, all host cores) on a bounded sample:
+    yolov5s fused, 8 images of 3x640x640, forward + NMS per iteration."""
+    from oracle import detgen, yolo_oracle as yo
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = yo.model_cfg("yolov5s")
+    sd = yo.det_state_dict(cfg, 0, fused=True)
+    bs = 8
+    x = torch.from_numpy(detgen.uniform((bs, 3, 640, 640), 0.0, 1.0, name="img", seed=0))
+    with torch.no_grad():
+        yo.model_forward(cfg, sd, x[:1])  # warm-up
+        t0 = time.time()
+        n = 0
+        while True:
+            z = yo.model_forward(cfg, sd, x)[0]
+            yo.non_max_suppression(z.numpy(), 0.25, 0.45, max_det=1000)
+            n += bs
+            if time.time() - t0 > seconds_budget or n >= 64:
+                break
+        dt = time.time() - t0
+    return {"value": round(n / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle/yolo_oracle.py forward+NMS, yolov5s fused fp32, {n} images of 3x640x640 (batches of {bs}), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--imgsz", type=int, default=640)
+    ap.add_argument("--model", default="yolov5s")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--op-table", default="", help="write the per-op timing table (JSON) to this path")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from yolov5_amd.general import non_max_suppression
+
+    model = build_model(a.model, dev)
+    model.model[-1].export = True  # AutoShape mode: return (z,) only (models/common.py:866)
+    g = torch.Generator(device="cpu").manual_seed(rank)
+    x = torch.rand((a.batch, 3, a.imgsz, a.imgsz), generator=g).half().to(dev)
+    calibrate_objectness(model, x)
+
+    def step():
+        z = model(x)[0]
+        return non_max_suppression(z, 0.25, 0.45, max_det=1000)
+
+    for _ in range(max(a.warmup, 1)):
+        det = step()
+    ncand = sum(int(d.shape[0]) for d in det) / len(det)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- per-kernel timing on the launch stream (HIP events inside y5_plan_time_range) -----------------
+    torch.cuda.synchronize(dev)
+    eng = next(iter(model._engines.values()))
+    t_f0 = time.perf_counter()
+    for _ in range(10):
+        model(x)
+    torch.cuda.synchronize(dev)
+    fwd_ms = (time.perf_counter() - t_f0) / 10 * 1e3
+    z = model(x)[0]
+    torch.cuda.synchronize(dev)
+    t_n0 = time.perf_counter()
+    for _ in range(10):
+        non_max_suppression(z, 0.25, 0.45, max_det=1000)
+    torch.cuda.synchronize(dev)
+    nms_ms = (time.perf_counter() - t_n0) / 10 * 1e3
+    ops = eng.time_ops(iters=10)
+    fl = dict(conv_flops(eng))
+    conv_ms = sum(ms for (i, (name, ms)) in enumerate(ops, start=1) if i in fl)
+    conv_fl = sum(fl.values())
+    other_ms = sum(ms for (i, (name, ms)) in enumerate(ops, start=1) if i not in fl)
+    achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    if a.op_table and rank == 0:
+        table = [{"op": name, "ms": round(ms, 5), "gflop": round(fl.get(i, 0) / 1e9, 3),
+                  "tflops": round(fl.get(i, 0) / (ms * 1e-3) / 1e12, 1) if ms > 0 and i in fl else None}
+                 for i, (name, ms) in enumerate(ops, start=1)]
+        with open(a.op_table, "w") as f:
+            json.dump(table, f, indent=1)
+
+    if rank == 0:
+        imgs = a.batch * world * a.steps
+        res = {
+            "metric": "images/sec at 640px (yolov5s bs=64), forward+NMS", "value": round(imgs / dt, 1), "unit": "images/sec",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"{a.model} inference bs={a.batch}/GPU 3x{a.imgsz}x{a.imgsz} fp16: HIP forward (backbone+neck+Detect) + HIP NMS "
+                                   "(conf 0.25, iou 0.45, max_det 1000); random-init weights, objectness bias calibrated to ~2% candidate rows",
+                       "global_batch": a.batch * world, "parallelism": f"replicas x{world} (images independent, no collective)"},
+            "forward_ms": round(fwd_ms, 4), "nms_ms": round(nms_ms, 4), "nms_us_per_img": round(nms_ms * 1e3 / a.batch, 2),
+            "forward_images_per_sec": round(a.batch / (fwd_ms * 1e-3), 1), "detections_per_img": round(ncand, 1),
+            "roofline": {"bound": "mfma", "kernel": "y5_conv_igemm_kernel (all conv launches of one forward)",
+                         "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "algorithmic_gflop_per_step": round(conv_fl / 1e9, 1), "conv_ms_per_step": round(conv_ms, 4),
+                         "launches_per_step": len(fl), "other_kernels_ms_per_step": round(other_ms, 4)},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

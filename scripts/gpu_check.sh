@@ -1,0 +1,24 @@
+#!/bin/bash
+# One gpurun call: GPU parity tests, smoke, bench, rocprofv3 kernel-trace summary.  Logs -> gpurun_out/.
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+WHAT="${1:-all}"
+if [ "$WHAT" = "all" ] || [ "$WHAT" = "test" ]; then
+  timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a gpurun_out/pytest_gpu.log
+  tail -25 gpurun_out/pytest_gpu.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" | tee -a gpurun_out/smoke.log
+  tail -3 gpurun_out/smoke.log
+fi
+if [ "$WHAT" = "all" ] || [ "$WHAT" = "bench" ]; then
+  timeout 600 python bench.py --op-table gpurun_out/op_table.json > gpurun_out/bench.log 2>&1; echo "bench rc=$?" | tee -a gpurun_out/bench.log
+  tail -5 gpurun_out/bench.log
+fi
+if [ "$WHAT" = "all" ] || [ "$WHAT" = "prof" ]; then
+  rm -rf gpurun_out/prof
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o r -- python "$OLDPWD/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof.log" 2>&1); echo "prof rc=$?"
+  find gpurun_out/prof -name "*stats*" | head; 
+  f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -30 "$f"
+  # keep the merged-back directory small: drop the raw per-dispatch trace, keep the summaries
+  find gpurun_out/prof -name "*kernel_trace.csv" -size +20M -delete
+fi

@@ -1,0 +1,70 @@
+"""CPU (no GPU): whole-model check of the planner + plan materialisation + kernels on the HIP emulator:
+yolov5n / yolov5n-seg at 64x64 against the golden vectors generated from the unmodified reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import detgen, yolo_oracle as yo
+from tests.hipemu.backend import EmuBackend
+from yolov5_amd.engine import Engine, build_plan_spec
+from yolov5_amd.yolo import DetectionModel, SegmentationModel
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def det_model(name, seed, fused):
+    M = SegmentationModel if "seg" in name else DetectionModel
+    m = M(name + ".yaml")
+    sd = yo.det_state_dict(yo.model_cfg(name), seed, fused=False)
+    m.load_state_dict(sd)
+    m.eval()
+    if fused:
+        m.fuse()
+    return m
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_yolov5n_fp32_matches_reference_golden(fused):
+    g = np.load(os.path.join(G, "fwd_yolov5n_64.npz"))
+    m = det_model("yolov5n", 0, fused)
+    x = torch.from_numpy(detgen.uniform((2, 3, 64, 64), 0.0, 1.0, name="img", seed=0))
+    eng = Engine(m, (2, 3, 64, 64), torch.float32, "cpu", want_raw=True, backend=EmuBackend())
+    out = eng(x)
+    ref = g["z_fused" if fused else "z_unfused"]
+    # north_star tolerance: fp32 boxes within 1e-4 (relative to the 64 px image here; values up to ~64)
+    np.testing.assert_allclose(out["z"], ref, rtol=1e-4, atol=1e-4)
+    for i in range(3):
+        np.testing.assert_allclose(out[f"raw{i}"], g[f"raw{i}"], rtol=1e-4, atol=2e-4)
+
+
+def test_yolov5n_fp16_close_to_reference():
+    g = np.load(os.path.join(G, "fwd_yolov5n_64.npz"))
+    m = det_model("yolov5n", 0, True).half()
+    x = torch.from_numpy(detgen.uniform((2, 3, 64, 64), 0.0, 1.0, name="img", seed=0)).half()
+    eng = Engine(m, (2, 3, 64, 64), torch.float16, "cpu", want_raw=False, backend=EmuBackend())
+    z = eng(x)["z"].astype(np.float32)
+    ref = g["z_fused"]
+    # check_amp-style tolerance (utils/general.py:410-435 uses atol=0.1 on boxes) -- fp16 storage between layers
+    assert np.abs(z - ref).max() < 0.5
+    assert np.abs(z[..., 4:] - ref[..., 4:]).max() < 2e-2
+
+
+def test_yolov5n_seg_fp32():
+    g = np.load(os.path.join(G, "fwd_yolov5n-seg_64.npz"))
+    m = det_model("yolov5n-seg", 2, True)
+    x = torch.from_numpy(detgen.uniform((2, 3, 64, 64), 0.0, 1.0, name="img", seed=2))
+    eng = Engine(m, (2, 3, 64, 64), torch.float32, "cpu", want_raw=False, backend=EmuBackend())
+    out = eng(x)
+    np.testing.assert_allclose(out["z"], g["z_fused"], rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(out["proto"][:, :, ::5, ::5], g["proto_sample"], rtol=1e-4, atol=1e-4)
+
+
+def test_plan_is_concat_free_for_shipped_models():
+    for name in ("yolov5s", "yolov5x", "yolov5s-seg"):
+        M = SegmentationModel if "seg" in name else DetectionModel
+        spec = build_plan_spec(M(name + ".yaml").eval(), 1, 3, 640, 640)
+        kinds = [o["op"] for o in spec.ops]
+        assert "copy" not in kinds and "upsample" not in kinds  # every concat / upsample is a fused store
+        assert kinds.count("sppf_pool") == 1 and kinds.count("decode") == 3

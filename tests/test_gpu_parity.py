@@ -1,0 +1,261 @@
+"""GPU (-m gpu): parity of the HIP path, called through the C-ABI, against the golden vectors (reference outputs)
+and the CPU oracle.  Tolerances: fp32 boxes/logits within 1e-4 relative (north_star); NMS selection bit-exact."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import detgen, yolo_oracle as yo
+from oracle.make_golden import NMS_CASES, nms_case_pred
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def test_native_library_is_loaded():
+    from yolov5_amd import _lib
+
+    lib = _lib.lib()
+    assert lib.y5_version() >= 100
+    maps = open("/proc/self/maps").read()
+    assert "libyolov5_hip.so" in maps
+
+
+# ---- conv kernel, direct C-ABI ----------------------------------------------------------------------------
+CONV_CASES = [
+    # B, H, W, C1, C2, k, s, p, act, residual, up2, tile_n, dtype
+    (2, 20, 20, 32, 32, 1, 1, 0, 1, False, False, 0, "f16"),
+    (2, 23, 17, 32, 64, 3, 1, 1, 1, True, False, 0, "f16"),
+    (2, 40, 40, 64, 128, 3, 2, 1, 1, False, False, 0, "f16"),
+    (2, 20, 20, 64, 128, 1, 1, 0, 0, False, True, 0, "f16"),
+    (1, 9, 9, 16, 16, 3, 1, 1, 1, True, False, 0, "f16"),
+    (1, 16, 16, 40, 256, 1, 1, 0, 1, False, False, 256, "f16"),
+    (2, 20, 20, 512, 256, 1, 1, 0, 1, False, False, 0, "f16"),
+    (2, 20, 20, 256, 512, 3, 1, 1, 1, False, False, 256, "f16"),
+    (2, 20, 20, 256, 255 + 1, 1, 1, 0, 0, False, False, 0, "f16"),
+    (2, 12, 12, 32, 32, 3, 1, 1, 1, True, False, 0, "f32"),
+    (1, 14, 10, 4, 32, 3, 2, 1, 1, False, False, 0, "f32"),
+    (2, 20, 20, 128, 128, 3, 1, 1, 1, False, False, 0, "f32"),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_matches_torch_fp32_reference(case, dev):
+    from yolov5_amd import _lib
+    from yolov5_amd.packing import pack_conv_weight
+
+    B, H, W, C1, C2, k, s, p, act, residual, up2, tile_n, dt = case
+    lib = _lib.lib()
+    tdt = torch.float16 if dt == "f16" else torch.float32
+    x = torch.from_numpy(detgen.uniform((B, C1, H, W), -1, 1, name="x"))
+    w = torch.from_numpy(detgen.uniform((C2, C1, k, k), -1, 1, name="w")) * (2.0 / (C1 * k * k)) ** 0.5
+    b = torch.from_numpy(detgen.uniform((C2,), -0.5, 0.5, name="b"))
+    if dt == "f16":
+        x, w = x.half().float(), w.half().float()
+    ldx, ldy = C1 + 8, C2 + 8
+    xd = torch.full((B, H, W, ldx), 7.0, dtype=tdt, device=dev)
+    xd[..., :C1] = x.permute(0, 2, 3, 1).to(dev, tdt)
+    wp, bp, K, Kpad, Npad = pack_conv_weight(w, b, tdt)
+    wp, bp = wp.to(dev), bp.to(dev)
+    OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    y = torch.full((B, OH, OW, ldy), -3.0, dtype=tdt, device=dev)
+    res = None
+    if residual:
+        y[..., :C2] = torch.from_numpy(detgen.uniform((B, OH, OW, C2), -1, 1, name="res")).to(dev, tdt)
+        res = y.clone()
+    y2 = torch.full((B, 2 * OH, 2 * OW, C2), -5.0, dtype=tdt, device=dev) if up2 else None
+    d = _lib.ConvDesc(dtype=_lib.Y5_F16 if dt == "f16" else _lib.Y5_F32, B=B, H=H, W=W, C1=C1, ldx=ldx, OH=OH, OW=OW, C2=C2,
+                      ldy=ldy, KH=k, KW=k, SH=s, SW=s, PH=p, PW=p, act=act, Kpad=Kpad, Npad=Npad, ldr=ldy, ld2=C2, tile_n=tile_n)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    rc = lib.y5_conv2d_fwd(C.byref(d), C.c_void_p(xd.data_ptr()), C.c_void_p(wp.data_ptr()), C.c_void_p(bp.data_ptr()),
+                           C.c_void_p(y.data_ptr()) if residual else None, C.c_void_p(y.data_ptr()),
+                           C.c_void_p(y2.data_ptr()) if up2 else None, st)
+    assert rc == 0, lib.y5_last_error()
+    torch.cuda.synchronize()
+    ref = F.conv2d(x, w, b, s, p)
+    if act:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 3, 1)
+    if residual:
+        ref = ref + res[..., :C2].float().cpu()
+    got = y[..., :C2].float().cpu()
+    tol = 1e-2 if dt == "f16" else 2e-5
+    torch.testing.assert_close(got, ref, rtol=tol, atol=tol)
+    pad = y[..., C2:].float().cpu()
+    assert torch.equal(pad, torch.full_like(pad, -3.0) if not residual else res[..., C2:].float().cpu())
+    if up2:
+        up = y[..., :C2].repeat_interleave(2, 1).repeat_interleave(2, 2)
+        assert torch.equal(up, y2)
+
+
+# ---- whole model ------------------------------------------------------------------------------------------
+def _det_model(name, seed):
+    from yolov5_amd.yolo import DetectionModel, SegmentationModel
+
+    M = SegmentationModel if "seg" in name else DetectionModel
+    m = M(name + ".yaml")
+    m.load_state_dict(yo.det_state_dict(yo.model_cfg(name), seed, fused=False))
+    return m.eval()
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_yolov5n_fp32_vs_reference_golden(fused, dev):
+    g = np.load(os.path.join(G, "fwd_yolov5n_64.npz"))
+    m = _det_model("yolov5n", 0)
+    if fused:
+        m.fuse()
+    m = m.to(dev)
+    x = torch.from_numpy(detgen.uniform((2, 3, 64, 64), 0.0, 1.0, name="img", seed=0)).to(dev)
+    z, raw = m(x)
+    np.testing.assert_allclose(z.cpu().numpy(), g["z_fused" if fused else "z_unfused"], rtol=1e-4, atol=1e-4)
+    for i in range(3):
+        assert raw[i].shape == g[f"raw{i}"].shape
+        np.testing.assert_allclose(raw[i].cpu().numpy(), g[f"raw{i}"], rtol=1e-4, atol=2e-4)
+    # Detect grid/anchor indexing bit-exact (yolo.py:117-128): xy of a zero-logit cell is (ix, iy)*stride exactly
+    det = m.model[-1]
+    for i, s in enumerate((8, 4, 2)):
+        grid, ag = det._make_grid(s, s, i)
+        assert np.array_equal(grid[0, 0].cpu().numpy(), g[f"grid{i}"])
+        assert np.array_equal(ag[0, :, 0, 0].cpu().numpy(), g[f"anchor_grid{i}"])
+
+
+def test_yolov5s_fp32_320_vs_reference_golden(dev):
+    g = np.load(os.path.join(G, "fwd_yolov5s_320.npz"))
+    m = _det_model("yolov5s", 1).fuse().to(dev)
+    x = torch.from_numpy(detgen.uniform((2, 3, 320, 320), 0.0, 1.0, name="img", seed=1)).to(dev)
+    z = m(x)[0].cpu().numpy()
+    rs = int(g["row_stride"])
+    np.testing.assert_allclose(z.reshape(-1, 85)[::rs], g["z_fused_rows"], rtol=1e-4, atol=5e-4)
+    s = z.astype(np.float64)
+    np.testing.assert_allclose([s.sum(), np.abs(s).sum(), (s * s).sum()], g["z_fused_sum"], rtol=1e-5)
+
+
+def test_yolov5n_seg_fp32_vs_reference_golden(dev):
+    g = np.load(os.path.join(G, "fwd_yolov5n-seg_64.npz"))
+    m = _det_model("yolov5n-seg", 2).fuse().to(dev)
+    x = torch.from_numpy(detgen.uniform((2, 3, 64, 64), 0.0, 1.0, name="img", seed=2)).to(dev)
+    z, proto, raw = m(x)
+    np.testing.assert_allclose(z.cpu().numpy(), g["z_fused"], rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(proto.cpu().numpy()[:, :, ::5, ::5], g["proto_sample"], rtol=1e-4, atol=1e-4)
+
+
+def test_yolov5s_fp16_640_vs_oracle(dev):
+    """BASELINE config C2 shape class (bs reduced to 2 so the CPU oracle finishes in seconds)."""
+    cfg = yo.model_cfg("yolov5s")
+    sd = yo.det_state_dict(cfg, 3, fused=True)
+    m = _det_model("yolov5s", 3).fuse().half().to(dev)
+    x = torch.from_numpy(detgen.uniform((2, 3, 640, 640), 0.0, 1.0, name="img", seed=3))
+    with torch.no_grad():
+        ref = yo.model_forward(cfg, sd, x.half().float())[0].numpy()
+    z = m(x.half().to(dev))[0].float().cpu().numpy()
+    assert z.shape == (2, 25200, 85)
+    err_box = np.abs(z[..., :4] - ref[..., :4]).max()
+    err_conf = np.abs(z[..., 4:] - ref[..., 4:]).max()
+    assert err_box < 1.0 and err_conf < 3e-2, (err_box, err_conf)  # check_amp-class tolerance (general.py:420: atol 0.1)
+    assert np.abs(z[..., :4] - ref[..., :4]).mean() < 0.05
+
+
+def test_uint8_input_scaling(dev):
+    m = _det_model("yolov5n", 0).fuse().to(dev)
+    img = (detgen.uniform((1, 3, 64, 64), 0, 255.99, name="u8img")).astype(np.uint8)
+    a = m(torch.from_numpy(img).to(dev))[0].clone()
+    b = m((torch.from_numpy(img).float() / 255).to(dev))[0]
+    torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
+
+
+def test_single_layer_forward_api(dev):
+    from yolov5_amd.common import C3, SPPF, Conv
+
+    torch.manual_seed(0)
+    for layer, ref_fn in ((Conv(16, 32, 3, 2), None), (C3(32, 32, 2), None), (SPPF(32, 32, 5), None)):
+        layer = layer.eval()
+        x = torch.rand(2, layer.conv.in_channels if hasattr(layer, "conv") else layer.cv1.conv.in_channels, 16, 16)
+        sd = {"model.0." + k: v for k, v in layer.state_dict().items()}
+        kind = type(layer).__name__
+        with torch.no_grad():
+            if kind == "Conv":
+                ref = yo._conv(sd, "model.0", x, 3, 2, 1)
+            elif kind == "C3":
+                ref = yo._c3(sd, "model.0", x, 2, True)
+            else:
+                ref = yo._sppf(sd, "model.0", x, 5)
+        got = layer.to(dev)(x.to(dev)).cpu()
+        torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
+
+
+# ---- NMS ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list(NMS_CASES))
+def test_nms_bit_exact_vs_reference_golden(name, dev):
+    from yolov5_amd.general import non_max_suppression
+
+    g = np.load(os.path.join(G, "nms.npz"))
+    kw, nkw = NMS_CASES[name]
+    res = non_max_suppression(torch.from_numpy(nms_case_pred(name)).to(dev), **nkw)
+    for i, r in enumerate(res):
+        ref = g[f"{name}_{i}"]
+        assert tuple(r.shape) == ref.shape, (name, i, r.shape, ref.shape)
+        assert np.array_equal(r.cpu().numpy(), ref), (name, i)
+
+
+def test_nms_full_size_properties_and_oracle_subset(dev):
+    """BASELINE size (64, 25200, 85): size-independent properties on every image + oracle equality on 3 images."""
+    from yolov5_amd.general import non_max_suppression
+
+    p = detgen.synth_predictions(64, 25200, 85, obj_pow=8, seed=31)
+    for dt in (torch.float32, torch.float16):
+        pd = torch.from_numpy(p).to(dev, dt)
+        out = non_max_suppression(pd, 0.25, 0.45, max_det=1000)
+        assert len(out) == 64
+        pf = pd.float().cpu().numpy()
+        for i in (0, 17, 63):
+            ref = yo.non_max_suppression(pf[i:i + 1], 0.25, 0.45, max_det=1000)[0]
+            assert np.array_equal(out[i].cpu().numpy(), ref), (dt, i)
+        for o in out:
+            o = o.cpu().numpy()
+            assert o.shape[0] <= 1000 and o.shape[1] == 6
+            assert np.all(np.diff(o[:, 4]) <= 0)  # descending confidence
+            assert np.all(o[:, 4] > 0.25)
+        # idempotence: feeding the kept boxes back (as obj=conf, one-hot cls) keeps all of them
+        o = out[5].cpu().numpy()
+        q = np.zeros((1, o.shape[0], 85), np.float32)
+        q[0, :, 0] = (o[:, 0] + o[:, 2]) / 2; q[0, :, 1] = (o[:, 1] + o[:, 3]) / 2
+        q[0, :, 2] = o[:, 2] - o[:, 0]; q[0, :, 3] = o[:, 3] - o[:, 1]
+        q[0, :, 4] = 1.0
+        q[0, np.arange(o.shape[0]), 5 + o[:, 5].astype(int)] = o[:, 4]
+        again = non_max_suppression(torch.from_numpy(q).to(dev), 0.25, 0.45, max_det=1000)[0]
+        assert again.shape[0] >= o.shape[0] - 2  # re-derived xyxy may move a box by 1 ulp
+
+
+def test_nms_val_settings_large_candidate_sets(dev):
+    from yolov5_amd.general import non_max_suppression
+
+    p = detgen.synth_predictions(2, 25200, 85, obj_pow=2, seed=33)
+    out = non_max_suppression(torch.from_numpy(p).to(dev), 0.001, 0.6, multi_label=False, max_det=300)
+    ref = yo.non_max_suppression(p, 0.001, 0.6, multi_label=False, max_det=300)
+    for o, r in zip(out, ref):
+        assert np.array_equal(o.cpu().numpy(), r)
+    p2 = detgen.synth_predictions(1, 6000, 25, obj_pow=1, seed=34)
+    out = non_max_suppression(torch.from_numpy(p2).to(dev), 0.001, 0.6, multi_label=True, max_det=300)
+    ref = yo.non_max_suppression(p2, 0.001, 0.6, multi_label=True, max_det=300)
+    assert np.array_equal(out[0].cpu().numpy(), ref[0])
+
+
+def test_autoshape_pipeline(dev):
+    from yolov5_amd.common import AutoShape
+
+    m = _det_model("yolov5n", 0).fuse().to(dev)
+    a = AutoShape(m)
+    a.conf = 0.001
+    im = (detgen.uniform((96, 128, 3), 0, 255.99, name="autoshape")).astype(np.uint8)
+    r = a([im, im[:, ::-1].copy()], size=64)
+    assert len(r) == 2 and r.xyxy[0].shape[1] == 6
+    assert float(r.xyxy[0][:, [0, 2]].max()) <= 128 and float(r.xyxy[0][:, [1, 3]].max()) <= 96

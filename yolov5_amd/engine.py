@@ -1,0 +1,472 @@
+"""Inference engine: turns a YOLOv5 module tree (yolov5_amd.yolo / yolov5_amd.common classes) into a static list
+of HIP kernel launches (`PlanSpec`), then materialises it on one MI355X as a C-side execution plan
+(include/yolov5_hip.h: y5_plan_*).  Replaces the Python layer walk of the reference's
+`BaseModel._forward_once` (models/yolo.py:160-170) for eval-mode forward.
+
+Design:
+  * activations are NHWC; every tensor is a channel slice (buffer, c_off, C) with pixel stride = buffer width, so
+    `torch.cat` never runs: producers write straight into their slice of the consumer's concat buffer
+    (C3 common.py:246, SPPF :340, Concat :453), and `nn.Upsample` is a second, 2x-replicated store of the producer.
+  * C3's cv1 and cv2 (same input) are one GEMM with N = 2*c_; Bottleneck's residual add is the conv epilogue.
+  * BN is folded into the conv at plan build (utils/torch_utils.py:224-254 semantics), bias + SiLU fused.
+  * one host call replays the whole forward (y5_plan_run_range) on the caller's current HIP stream.
+
+`build_plan_spec` is device independent (pure shape/graph logic, unit-tested on CPU); `Engine` needs a GPU and the
+built library and raises otherwise -- there is no CPU execution path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import torch
+from torch import nn
+
+from . import _lib
+from .packing import fuse_conv_bn_weights, pack_conv_weight
+
+
+@dataclass
+class Buf:
+    id: int
+    H: int
+    W: int
+    C: int
+    name: str = ""
+
+
+@dataclass(frozen=True)
+class TRef:
+    """Channel slice [c_off, c_off+C) of NHWC buffer `buf` (pixel stride = that buffer's C)."""
+    buf: int
+    c_off: int
+    C: int
+    H: int
+    W: int
+
+
+@dataclass
+class PlanSpec:
+    B: int
+    in_ch: int
+    in_hw: tuple
+    bufs: list = field(default_factory=list)
+    ops: list = field(default_factory=list)
+    outputs: dict = field(default_factory=dict)
+
+    def new_buf(self, H, W, C, name=""):
+        b = Buf(len(self.bufs), H, W, C, name)
+        self.bufs.append(b)
+        return TRef(b.id, 0, C, H, W)
+
+    def ld(self, t: TRef) -> int:
+        return self.bufs[t.buf].C
+
+
+def _slice(t: TRef, off: int, c: int) -> TRef:
+    assert 0 <= off and off + c <= t.C
+    return TRef(t.buf, t.c_off + off, c, t.H, t.W)
+
+
+def _conv_out_hw(h, w, k, s, p):
+    return (h + 2 * p[0] - k[0]) // s[0] + 1, (w + 2 * p[1] - k[1]) // s[1] + 1
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+class _Planner:
+    """Walks the module tree once and emits PlanSpec ops."""
+
+    def __init__(self, model, B, ch, H, W, want_raw=False):
+        from . import common, yolo
+
+        self.cm, self.yo = common, yolo
+        self.model = model
+        self.spec = PlanSpec(B, ch, (H, W))
+        self.want_raw = want_raw
+
+    # ---- leaf emitters ----------------------------------------------------------------------------
+    def conv(self, mods, x: TRef, dest: TRef | None = None, res: TRef | None = None, up2: TRef | None = None,
+             act=True, name="", view=None, c2_store=None):
+        """mods: list of Conv-like modules stacked along output channels (same input, same k/s/p)."""
+        m0 = mods[0]
+        cv = m0.conv if hasattr(m0, "conv") else m0
+        k, s, p = _pair(cv.kernel_size), _pair(cv.stride), _pair(cv.padding)
+        c2 = sum((m.conv if hasattr(m, "conv") else m).out_channels for m in mods)
+        oh, ow = _conv_out_hw(x.H, x.W, k, s, p)
+        cst = c2 if c2_store is None else c2_store
+        if dest is None:
+            dest = self.spec.new_buf(oh, ow, cst, name)
+        assert dest.C == cst and (dest.H, dest.W) == (oh, ow), (name, dest, cst, oh, ow)
+        self.spec.ops.append(dict(op="conv", mods=mods, x=x, y=dest, res=res, y2=up2, k=k, s=s, p=p, act=act,
+                                  c2=c2, c2_store=cst, name=name, view=view))
+        return dest
+
+    def bottleneck(self, m, x: TRef, dest: TRef, tmp: TRef):
+        """Bottleneck (common.py:164-181) with e=1.0; dest may alias x (in-place residual)."""
+        t = self.conv([m.cv1], x, tmp, name="b.cv1")
+        return self.conv([m.cv2], t, dest, res=x if m.add else None, name="b.cv2")
+
+    def c3(self, m, x: TRef, dest: TRef | None, up2=None, name="C3"):
+        c_ = m.cv1.conv.out_channels
+        cat = self.spec.new_buf(x.H, x.W, 2 * c_, name + ".cat")
+        self.conv([m.cv1, m.cv2], x, cat, name=name + ".cv1+cv2")  # one GEMM, N = 2*c_
+        a = _slice(cat, 0, c_)
+        if len(m.m):
+            tmp = self.spec.new_buf(x.H, x.W, c_, name + ".tmp")
+            for b in m.m:
+                self.bottleneck(b, a, a, tmp)
+        return self.conv([m.cv3], cat, dest, up2=up2, name=name + ".cv3")
+
+    def sppf(self, m, x: TRef, dest, up2=None, name="SPPF"):
+        c_ = m.cv1.conv.out_channels
+        k = m.m.kernel_size if isinstance(m.m.kernel_size, int) else m.m.kernel_size[0]
+        cat = self.spec.new_buf(x.H, x.W, 4 * c_, name + ".cat")
+        self.conv([m.cv1], x, _slice(cat, 0, c_), name=name + ".cv1")
+        self.spec.ops.append(dict(op="sppf_pool", buf=cat, C=c_, k=k))
+        return self.conv([m.cv2], cat, dest, up2=up2, name=name + ".cv2")
+
+    def proto(self, m, x: TRef):
+        """Proto (common.py:1104-1117): cv3(cv2(up2x(cv1(x)))); the upsample is cv1's replicated store."""
+        c_ = m.cv1.conv.out_channels
+        up = self.spec.new_buf(2 * x.H, 2 * x.W, c_, "proto.up")
+        self.conv([m.cv1], x, None, up2=up, name="proto.cv1")
+        t = self.conv([m.cv2], up, None, name="proto.cv2")
+        return self.conv([m.cv3], t, None, name="proto.cv3")
+
+    # ---- whole model ----------------------------------------------------------------------------------
+    def run(self):
+        cm, yo, spec = self.cm, self.yo, self.spec
+        layers = list(self.model.model)
+        n = len(layers)
+        H, W = spec.in_hw
+
+        def src_ids(i, m):
+            f = m.f
+            fl = [f] if isinstance(f, int) else list(f)
+            return [i - 1 if j == -1 else (j if j >= 0 else i + j) for j in fl]
+
+        # pass 1: shapes
+        shp = []
+        for i, m in enumerate(layers):
+            ins = [(spec.in_ch, H, W)] if i == 0 else [shp[j] for j in src_ids(i, m)]
+            c, h, w = ins[0]
+            if isinstance(m, cm.Conv):
+                cv = m.conv
+                oh, ow = _conv_out_hw(h, w, _pair(cv.kernel_size), _pair(cv.stride), _pair(cv.padding))
+                shp.append((cv.out_channels, oh, ow))
+            elif isinstance(m, cm.C3):
+                shp.append((m.cv3.conv.out_channels, h, w))
+            elif isinstance(m, cm.SPPF):
+                shp.append((m.cv2.conv.out_channels, h, w))
+            elif isinstance(m, nn.Upsample):
+                if float(m.scale_factor) != 2.0 or m.mode != "nearest":
+                    raise NotImplementedError("only nn.Upsample(scale_factor=2, mode='nearest') is supported")
+                shp.append((c, 2 * h, 2 * w))
+            elif isinstance(m, cm.Concat):
+                if m.d != 1:
+                    raise NotImplementedError("Concat along a dimension other than channels")
+                shp.append((sum(s[0] for s in ins), h, w))
+            elif isinstance(m, yo.Detect):
+                shp.append(None)
+            else:
+                raise NotImplementedError(f"layer {i}: {type(m).__name__} has no HIP implementation")
+
+        # pass 2: concat homes + fusable upsamples
+        consumers = {i: [] for i in range(n)}
+        for i, m in enumerate(layers):
+            if i:
+                for j in src_ids(i, m):
+                    consumers[j].append(i)
+        cat_bufs, home = {}, {}
+        for i, m in enumerate(layers):
+            if isinstance(m, cm.Concat):
+                c, h, w = shp[i]
+                cat_bufs[i] = spec.new_buf(h, w, c, f"cat{i}")
+                off = 0
+                for j in src_ids(i, m):
+                    if j not in home:
+                        home[j] = _slice(cat_bufs[i], off, shp[j][0])
+                    off += shp[j][0]
+        fused_up = {}  # producer layer -> upsample layer
+        for i, m in enumerate(layers):
+            if isinstance(m, nn.Upsample):
+                j = src_ids(i, m)[0]
+                if isinstance(layers[j], (cm.Conv, cm.C3, cm.SPPF)):
+                    fused_up[j] = i
+
+        # pass 3: emit
+        out = {}
+        x0 = spec.new_buf(H, W, 4 if spec.in_ch <= 4 else (spec.in_ch + 7) // 8 * 8, "input_nhwc")
+        spec.ops.append(dict(op="to_nhwc", dst=x0, C=spec.in_ch))
+        for i, m in enumerate(layers):
+            ins = [x0] if i == 0 else [out[j] for j in src_ids(i, m)]
+            dest = home.get(i)
+            up2 = None
+            if i in fused_up:
+                u = fused_up[i]
+                c, h, w = shp[u]
+                up2 = home.get(u) or spec.new_buf(h, w, c, f"up{u}")
+                out[u] = up2
+            if isinstance(m, cm.Conv):
+                view = None
+                if i == 0:
+                    view = "first"
+                out[i] = self.conv([m], ins[0], dest, up2=up2, name=f"{i}.Conv", view=view)
+            elif isinstance(m, cm.C3):
+                out[i] = self.c3(m, ins[0], dest, up2, name=f"{i}.C3")
+            elif isinstance(m, cm.SPPF):
+                out[i] = self.sppf(m, ins[0], dest, up2, name=f"{i}.SPPF")
+            elif isinstance(m, nn.Upsample):
+                if i not in out:
+                    c, h, w = shp[i]
+                    d = dest or spec.new_buf(h, w, c, f"up{i}")
+                    spec.ops.append(dict(op="upsample", src=ins[0], dst=d))
+                    out[i] = d
+            elif isinstance(m, cm.Concat):
+                buf = cat_bufs[i]
+                off = 0
+                for t in ins:
+                    want = _slice(buf, off, t.C)
+                    if t != want:
+                        spec.ops.append(dict(op="copy", src=t, dst=want))
+                    off += t.C
+                out[i] = buf
+            elif isinstance(m, yo.Detect):
+                self.detect(m, ins)
+        return spec
+
+    def detect(self, m, xs):
+        spec = self.spec
+        B = spec.B
+        no, na = m.no, m.na
+        nm = getattr(m, "nm", 0) if isinstance(m, self.yo.Segment) else 0
+        nrows = sum(na * x.H * x.W for x in xs)
+        spec.outputs["z"] = dict(shape=(B, nrows, no))
+        if isinstance(m, self.yo.Segment):
+            p = self.proto(m.proto, xs[0])
+            spec.ops.append(dict(op="to_nchw", src=p, out="proto"))
+            spec.outputs["proto"] = dict(shape=(B, p.C, p.H, p.W))
+        row_off = 0
+        for i, x in enumerate(xs):
+            npad = (na * no + 31) // 32 * 32
+            lg = self.conv([m.m[i]], x, None, act=False, name=f"detect.m{i}", c2_store=npad)
+            raw = None
+            if self.want_raw:
+                raw = f"raw{i}"
+                spec.outputs[raw] = dict(shape=(B, na, x.H, x.W, no))
+            spec.ops.append(dict(op="decode", x=lg, level=i, ny=x.H, nx=x.W, na=na, no=no, nm=nm, row_off=row_off,
+                                 nrows=nrows, raw=raw))
+            row_off += na * x.H * x.W
+
+
+def build_plan_spec(model, B, ch, H, W, want_raw=False) -> PlanSpec:
+    """Device-independent kernel schedule for `model` (a yolov5_amd.yolo.BaseModel) at input (B,ch,H,W)."""
+    return _Planner(model, B, ch, H, W, want_raw).run()
+
+
+# ----------------------------------------------------------------------------------------------------------
+def folded_weights(mods):
+    """Stack Conv-like modules along output channels; fold BN (eval statistics) when present. fp32 (w, b)."""
+    ws, bs = [], []
+    for m in mods:
+        if hasattr(m, "conv"):
+            cv = m.conv
+            if hasattr(m, "bn") and m.bn is not None:
+                bn = m.bn
+                w, b = fuse_conv_bn_weights(cv.weight.detach(), None if cv.bias is None else cv.bias.detach(), bn.weight.detach(),
+                                            bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
+            else:
+                w = cv.weight.detach().float()
+                b = torch.zeros(cv.out_channels, device=w.device) if cv.bias is None else cv.bias.detach().float()
+        else:  # bare nn.Conv2d (Detect.m[i])
+            w = m.weight.detach().float()
+            b = torch.zeros(m.out_channels, device=w.device) if m.bias is None else m.bias.detach().float()
+        ws.append(w)
+        bs.append(b)
+    return torch.cat(ws, 0), torch.cat(bs, 0)
+
+
+class _HipBackend:
+    """Device memory + stream provider of the Engine: PyTorch-ROCm caching allocator and current HIP stream.
+    (The Engine takes it as a parameter so that tests can drive the very same plan-materialisation code against
+    the host-compiled kernels of tests/hipemu; the product only ever constructs this GPU backend.)"""
+
+    def __init__(self, device):
+        if not torch.cuda.is_available() or torch.device(device).type != "cuda":
+            raise RuntimeError("yolov5_amd.Engine needs a ROCm GPU (MI355X); there is no CPU execution path")
+        self.lib = _lib.lib()
+        self.device = torch.device(device)
+
+    def empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def from_torch(self, t):
+        return t.to(self.device).contiguous()
+
+    def ptr(self, h):
+        return h.data_ptr()
+
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def input(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("yolov5_amd: input tensor must live on the GPU (no CPU path)")
+        code = {torch.float16: _lib.Y5_F16, torch.float32: _lib.Y5_F32, torch.uint8: _lib.Y5_U8}.get(x.dtype)
+        if code is None:
+            raise TypeError(f"unsupported input dtype {x.dtype}")
+        x = x.contiguous()
+        return x, x.data_ptr(), code
+
+
+class Engine:
+    """A materialised PlanSpec on one GPU.  `engine(x)` -> dict of output tensors (engine-owned buffers, valid
+    until the next call).  Raises RuntimeError without a GPU / without libyolov5_hip.so."""
+
+    def __init__(self, model, x_shape, dtype: torch.dtype, device, want_raw=False, backend=None, spec=None):
+        if dtype not in (torch.float16, torch.float32):
+            raise TypeError(f"Engine dtype must be float16 or float32, got {dtype}")
+        self.be = backend if backend is not None else _HipBackend(device)
+        self.lib = self.be.lib
+        self.dtype = dtype
+        self.dt = _lib.Y5_F16 if dtype == torch.float16 else _lib.Y5_F32
+        self.es = 2 if dtype == torch.float16 else 4
+        B, ch, H, W = x_shape
+        self.x_shape = tuple(x_shape)
+        self.spec = spec if spec is not None else build_plan_spec(model, B, ch, H, W, want_raw)
+        det = getattr(model, "model", [None])[-1] if model is not None else None
+        if det is not None and hasattr(det, "anchors"):
+            self.stride_t = [float(s) for s in det.stride]
+            self.anchors = det.anchors.detach().float().cpu()
+        self._keep = []  # device tensors referenced by raw pointers inside the C plan
+        self.bufs = [self.be.empty((B, b.H, b.W, b.C), dtype) for b in self.spec.bufs]
+        self.outputs = {}
+        for name, o in self.spec.outputs.items():
+            self.outputs[name] = self.be.empty(o["shape"], dtype)
+        self.plan = C.c_void_p(self.lib.y5_plan_create())
+        self.op_names = []
+        self._first_op = None
+        with torch.no_grad():
+            for op in self.spec.ops:
+                self._add(op)
+        self._graph = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "plan", None):
+                self.lib.y5_plan_destroy(self.plan)
+                self.plan = None
+        except Exception:
+            pass
+
+    # -- helpers ---------------------------------------------------------------------------------------------
+    def _ptr(self, t: TRef | None):
+        if t is None:
+            return None
+        return C.c_void_p(self.be.ptr(self.bufs[t.buf]) + t.c_off * self.es)
+
+    def _ld(self, t: TRef):
+        return self.spec.bufs[t.buf].C
+
+    def _add(self, op):
+        lib, B, kind = self.lib, self.spec.B, op["op"]
+        if kind == "to_nhwc":
+            d = op["dst"]
+            self._first_op = (d, op["C"])
+            rc = lib.y5_plan_add_nchw_to_nhwc(self.plan, None, self.dt, self._ptr(d), self.dt, B, op["C"], d.H, d.W, self._ld(d), 1.0)
+            self.op_names.append("to_nhwc")
+        elif kind == "conv":
+            rc = self._add_conv(op)
+        elif kind == "sppf_pool":
+            b = op["buf"]
+            rc = lib.y5_plan_add_sppf_pool(self.plan, self._ptr(b), self.dt, B, b.H, b.W, op["C"], self._ld(b), op["k"])
+            self.op_names.append("sppf_pool")
+        elif kind == "upsample":
+            s, d = op["src"], op["dst"]
+            rc = lib.y5_plan_add_upsample2x(self.plan, self._ptr(s), self.dt, self._ptr(d), B, s.H, s.W, s.C, self._ld(s), self._ld(d))
+            self.op_names.append("upsample2x")
+        elif kind == "copy":
+            s, d = op["src"], op["dst"]
+            rc = lib.y5_plan_add_copy_slice(self.plan, self._ptr(s), self.dt, self._ptr(d), B * s.H * s.W, s.C, self._ld(s), self._ld(d))
+            self.op_names.append("copy_slice")
+        elif kind == "decode":
+            x, i = op["x"], op["level"]
+            apx = (self.anchors[i] * self.stride_t[i]).reshape(-1).tolist()
+            arr = (C.c_float * len(apx))(*apx)
+            raw = self.outputs[op["raw"]] if op["raw"] else None
+            rc = lib.y5_plan_add_detect_decode(self.plan, self._ptr(x), self.dt, B, op["ny"], op["nx"], op["na"], op["no"], op["nm"],
+                                               self._ld(x), self.stride_t[i], arr, C.c_void_p(self.be.ptr(self.outputs["z"])), self.dt,
+                                               op["nrows"], op["row_off"], C.c_void_p(self.be.ptr(raw)) if raw is not None else None)
+            self.op_names.append(f"decode{i}")
+        elif kind == "to_nchw":
+            s = op["src"]
+            o = self.outputs[op["out"]]
+            rc = lib.y5_plan_add_nhwc_to_nchw(self.plan, self._ptr(s), self.dt, C.c_void_p(self.be.ptr(o)), B, s.C, s.H, s.W, self._ld(s))
+            self.op_names.append("to_nchw")
+        else:
+            raise ValueError(kind)
+        _lib.check(rc, lib)
+
+    def _add_conv(self, op):
+        x, y, res, y2 = op["x"], op["y"], op["res"], op["y2"]
+        w, b = folded_weights(op["mods"])
+        (kh, kw), (sh, sw), (ph, pw) = op["k"], op["s"], op["p"]
+        H, W, C1, ldx = x.H, x.W, x.C, self._ld(x)
+        if op["view"] == "first":
+            cin = w.shape[1]
+            wfull = torch.zeros((w.shape[0], C1, kh, kw), device=w.device)
+            wfull[:, :cin] = w
+            w = wfull
+            if self.dtype == torch.float16 and C1 == 4 and kw % 2 == 0 and sw % 2 == 0 and pw % 2 == 0 and W % 2 == 0:
+                # k6 s2 p2 stem: NHWC4 pixels pair up into 16-byte pieces -> conv over (H, W/2, 8), kernel (kh, kw/2)
+                W, C1, ldx, kw, sw, pw = W // 2, 8, 8, kw // 2, sw // 2, pw // 2
+                wp, bp, K, Kpad, Npad = pack_conv_weight(w, b, self.dtype)
+            else:
+                wp, bp, K, Kpad, Npad = pack_conv_weight(w, b, self.dtype)
+        else:
+            assert w.shape[1] == C1, (op["name"], w.shape, C1)
+            wp, bp, K, Kpad, Npad = pack_conv_weight(w, b, self.dtype)
+        if self.dtype == torch.float16 and C1 % 8:
+            raise NotImplementedError(f"conv {op['name']}: fp16 needs input channels in multiples of 8 (got {C1})")
+        wp, bp = self.be.from_torch(wp), self.be.from_torch(bp)
+        self._keep += [wp, bp]
+        c2s = op["c2_store"]
+        d = _lib.ConvDesc(dtype=self.dt, B=self.spec.B, H=H, W=W, C1=C1, ldx=ldx, OH=y.H, OW=y.W, C2=c2s, ldy=self._ld(y),
+                          KH=kh, KW=kw, SH=sh, SW=sw, PH=ph, PW=pw, act=1 if op["act"] else 0, Kpad=Kpad, Npad=Npad,
+                          ldr=self._ld(res) if res is not None else 0, ld2=self._ld(y2) if y2 is not None else 0, tile_n=0)
+        assert Npad >= c2s
+        self.op_names.append("conv:" + op["name"])
+        return self.lib.y5_plan_add_conv(self.plan, C.byref(d), self._ptr(x), C.c_void_p(self.be.ptr(wp)), C.c_void_p(self.be.ptr(bp)),
+                                         self._ptr(res), self._ptr(y), self._ptr(y2))
+
+    # -- execution ---------------------------------------------------------------------------------------------
+    def _stream(self):
+        return self.be.stream()
+
+    def __call__(self, x):
+        if tuple(x.shape) != self.x_shape:
+            raise ValueError(f"engine built for input {self.x_shape}, got {tuple(x.shape)}")
+        x, xptr, src_dt = self.be.input(x)
+        d, cin = self._first_op
+        st = self._stream()
+        B = self.spec.B
+        scale = 1.0 / 255.0 if src_dt == _lib.Y5_U8 else 1.0  # train.py:379 / detect.py:209: uint8 images -> 0..1
+        _lib.check(self.lib.y5_nchw_to_nhwc(C.c_void_p(xptr), src_dt, self._ptr(d), self.dt, B, cin, d.H, d.W, self._ld(d),
+                                            scale, st), self.lib)
+        n = self.lib.y5_plan_size(self.plan)
+        _lib.check(self.lib.y5_plan_run_range(self.plan, 1, n, st), self.lib)
+        return self.outputs
+
+    def time_ops(self, iters=20):
+        """Per-op HIP-event timing (ms per launch) on the current stream: [(name, ms)] -- used by bench.py."""
+        st = self._stream()
+        n = self.lib.y5_plan_size(self.plan)
+        res = []
+        ms = C.c_float(0)
+        for i in range(1, n):
+            _lib.check(self.lib.y5_plan_time_range(self.plan, i, i + 1, iters, st, C.byref(ms)), self.lib)
+            res.append((self.op_names[i], ms.value / iters))
+        return res

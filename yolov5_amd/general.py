@@ -1,0 +1,114 @@
+"""Post-processing entry points with the reference's names and signatures (utils/general.py):
+`non_max_suppression` :658-767 (HIP: y5_nms_batched), `scale_boxes` :613-626, `xyxy2xywh` :574-581, plus the
+un-vendored helpers the reference imports from `ultralytics.utils.ops` (xywh2xyxy, clip_boxes, make_divisible).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+import math
+
+import torch
+
+from . import _lib
+
+LOGGER = logging.getLogger("yolov5_amd")
+
+
+def make_divisible(x, divisor):
+    if isinstance(divisor, torch.Tensor):
+        divisor = int(divisor.max())
+    return math.ceil(x / divisor) * divisor
+
+
+def xyxy2xywh(x):
+    """utils/general.py:574-581."""
+    y = x.clone()
+    y[..., 0] = (x[..., 0] + x[..., 2]) / 2
+    y[..., 1] = (x[..., 1] + x[..., 3]) / 2
+    y[..., 2] = x[..., 2] - x[..., 0]
+    y[..., 3] = x[..., 3] - x[..., 1]
+    return y
+
+
+def xywh2xyxy(x):
+    y = x.clone()
+    y[..., :2] = x[..., :2] - x[..., 2:4] / 2
+    y[..., 2:4] = x[..., :2] + x[..., 2:4] / 2
+    return y
+
+
+def clip_boxes(boxes, shape):
+    boxes[..., 0].clamp_(0, shape[1])
+    boxes[..., 1].clamp_(0, shape[0])
+    boxes[..., 2].clamp_(0, shape[1])
+    boxes[..., 3].clamp_(0, shape[0])
+    return boxes
+
+
+def scale_boxes(img1_shape, boxes, img0_shape, ratio_pad=None):
+    """utils/general.py:613-626: de-letterbox xyxy boxes in place (n is at most max_det: host-side torch ops)."""
+    if ratio_pad is None:
+        gain = min(img1_shape[0] / img0_shape[0], img1_shape[1] / img0_shape[1])
+        pad = (img1_shape[1] - img0_shape[1] * gain) / 2, (img1_shape[0] - img0_shape[0] * gain) / 2
+    else:
+        gain = ratio_pad[0][0]
+        pad = ratio_pad[1]
+    boxes[..., [0, 2]] -= pad[0]
+    boxes[..., [1, 3]] -= pad[1]
+    boxes[..., :4] /= gain
+    clip_boxes(boxes, img0_shape)
+    return boxes
+
+
+_nms_ws = {}
+
+
+def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
+                        labels=(), max_det=300, nm=0):
+    """utils/general.py:658-767 on the GPU: one batched HIP kernel chain for all images (filter -> LDS bitonic sort
+    -> greedy IoU with kept boxes in LDS), ONE device->host sync (the per-image counts) instead of >= 3 per image.
+
+    Returns list of (k, 6+nm) fp32 tensors [x1, y1, x2, y2, conf, cls, (mask coefficients)] per image, rows in
+    descending confidence.  Deliberate differences from the reference, both documented in DESIGN.md:
+      * arithmetic is fp32 on the fp32 value of every element also for half inputs (the reference's half path
+        overflows the class offset cls*7680 for cls >= 9); output rows are always fp32;
+      * no wall-clock `time_limit` (general.py:692,763-765) -- results never depend on timing;
+      * ties in confidence are ordered by the lower candidate index (the reference's argsort is unstable).
+    """
+    assert 0 <= conf_thres <= 1, f"Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0"
+    assert 0 <= iou_thres <= 1, f"Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0"
+    if isinstance(prediction, (list, tuple)):  # model in validation mode: (inference_out, loss_out)
+        prediction = prediction[0]
+    if labels:
+        raise NotImplementedError("autolabelling `labels` (general.py:706-712) is not part of the hot path")
+    if not prediction.is_cuda:
+        raise RuntimeError("yolov5_amd.non_max_suppression needs a GPU tensor (no CPU path)")
+    if prediction.dtype not in (torch.float16, torch.float32):
+        prediction = prediction.float()
+    prediction = prediction.contiguous()
+    lib = _lib.lib()
+    bs, n, no = prediction.shape
+    nc = no - nm - 5
+    flags = (_lib.NMS_MULTI_LABEL if (multi_label and nc > 1) else 0) | (_lib.NMS_AGNOSTIC if agnostic else 0)
+    max_nms = 30000
+    dev = prediction.device
+    key = (bs, n, no, nm, flags, max_det, str(dev))
+    ws = _nms_ws.get(key)
+    if ws is None:
+        nbytes = lib.y5_nms_workspace_bytes(bs, n, no, nm, flags, max_nms)
+        _nms_ws.clear()
+        ws = _nms_ws[key] = (torch.empty(nbytes, dtype=torch.uint8, device=dev), nbytes)
+    out = torch.empty((bs, max_det, 6 + nm), dtype=torch.float32, device=dev)
+    cnt = torch.empty((bs,), dtype=torch.int32, device=dev)
+    cls_t = None
+    if classes is not None:
+        cls_t = torch.tensor(list(classes), dtype=torch.int32, device=dev)
+    dt = _lib.Y5_F16 if prediction.dtype == torch.float16 else _lib.Y5_F32
+    rc = lib.y5_nms_batched(C.c_void_p(prediction.data_ptr()), dt, bs, n, no, nm, float(conf_thres), float(iou_thres), int(max_det),
+                            max_nms, 7680.0, flags, C.c_void_p(cls_t.data_ptr()) if cls_t is not None else None,
+                            0 if cls_t is None else cls_t.numel(), C.c_void_p(out.data_ptr()), C.c_void_p(cnt.data_ptr()),
+                            C.c_void_p(ws[0].data_ptr()), ws[1], C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    _lib.check(rc, lib)
+    counts = cnt.tolist()  # the single D2H sync
+    return [out[i, :counts[i]] for i in range(bs)]
