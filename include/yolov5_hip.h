@@ -33,25 +33,35 @@ const char* y5_last_error(void);     /* thread-local message of the last non-zer
  * Replaces: models/common.py:90-92 `Conv.forward_fuse` (nn.Conv2d + SiLU after utils/torch_utils.py:224-254
  * BN folding), common.py:181 `Bottleneck` residual add, common.py:246/340/453 `torch.cat` (write into a channel
  * slice via ldy), yolov5s.yaml:36,41 `nn.Upsample(None,2,'nearest')` (y_up2), models/yolo.py:95 Detect conv.
- * w_packed: [Npad][Kpad] row-major, k = (kh, kw, c); Npad % 32 == 0, Kpad % (64/elemsize) == 0, zero padded.
- * bias: fp32 [Npad].  residual/y_up2 may be NULL.  residual may alias y (in-place add).
+ * w_packed: [Npad][Kpad] row-major, k = (kh, kw, c); Npad % 32 == 0, Kpad = K rounded up to 128 bytes, zero padded.
+ * bias: fp32 [Npad].  residual/y_up2 may be NULL.  residual may alias y (in-place add).  y may be NULL when only
+ * the upsampled copy y_up2 is wanted.
  * ------------------------------------------------------------------------------------------------------- */
 typedef struct {
   int dtype;          /* Y5_F16 | Y5_F32 (storage type of x, w, y, residual; accumulation is always fp32) */
   int B, H, W;        /* input batch / height / width */
   int C1, ldx;        /* input channels, input pixel stride (elements); both multiples of 16 bytes */
   int OH, OW;         /* output height / width (checked against H,W,k,s,p) */
-  int C2, ldy;        /* output channels (multiple of 4), output pixel stride */
+  int C2, ldy;        /* output channels, output pixel stride; both multiples of 16 bytes */
   int KH, KW, SH, SW, PH, PW;
   int act;            /* 0 identity, 1 SiLU */
   int Kpad, Npad;     /* packed filter dims */
   int ldr;            /* residual pixel stride (if residual != NULL) */
   int ld2;            /* y_up2 pixel stride (if y_up2 != NULL); y_up2 has spatial size 2*OH x 2*OW */
-  int tile_n;         /* 0 = auto, else 32/64/128/256 output channels per workgroup */
+  int cfg;            /* workgroup tile configuration id (y5_conv_cfg_info), -1 = built-in heuristic */
+  int max_blocks;     /* 0 = fill the GPU (CUs x occupancy) with persistent workgroups; >0 caps the grid (tests) */
 } y5_conv_desc;
+
+#define Y5_CONV_NUM_CFGS 14
+int y5_conv_num_cfgs(void);
+int y5_conv_cfg_info(int cfg, int* bm_pixels, int* bn_channels, int* k_bytes_per_stage);
 
 int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                   const void* residual, void* y, void* y_up2, void* stream);
+/* Same call timed with HIP events on `stream` (1 warm-up + `iters` launches); *ms = average per launch.
+ * Used by the engine's per-layer tile autotuner and by bench.py. */
+int y5_conv2d_time(const y5_conv_desc* d, const void* x, const void* w_packed, const float* bias,
+                   const void* residual, void* y, void* y_up2, int iters, void* stream, float* ms);
 
 /* ---------------------------------------------------------------------------------------------------------
  * y5_nchw_to_nhwc -- input contract (train.py:379, val.py:259-262, detect.py:206-210, common.py:926):

@@ -60,6 +60,9 @@ inline hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 2
 inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+enum { hipDeviceAttributeMultiprocessorCount = 63 };
+inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 3; return hipSuccess; }  // tiny "GPU": 3 CUs
+inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, const void*, int, size_t) { *n = 1; return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
@@ -81,10 +84,14 @@ inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorN
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_s_barrier() emu::barrier_block()
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+inline void emu_wave_barrier() { const void* o[64]; char c = 0; emu::wave_exchange(&c, 1, o); }
+#define __builtin_amdgcn_wave_barrier() emu_wave_barrier()
 inline float __expf(float x) { return expf(x); }
 inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 inline int atomicAdd(int* p, int v) { int o = *p; *p += v; return o; }
+inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 
 inline void emu_glds(const void* g, void* l, int size) { memcpy((char*)l + (size_t)emu::lane_id() * size, g, size); }
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu_glds((const void*)(uintptr_t)(g), (void*)(uintptr_t)(l), (size))

@@ -32,20 +32,22 @@ def test_native_library_is_loaded():
 
 # ---- conv kernel, direct C-ABI ----------------------------------------------------------------------------
 CONV_CASES = [
-    # B, H, W, C1, C2, k, s, p, act, residual, up2, tile_n, dtype
-    (2, 20, 20, 32, 32, 1, 1, 0, 1, False, False, 0, "f16"),
-    (2, 23, 17, 32, 64, 3, 1, 1, 1, True, False, 0, "f16"),
-    (2, 40, 40, 64, 128, 3, 2, 1, 1, False, False, 0, "f16"),
-    (2, 20, 20, 64, 128, 1, 1, 0, 0, False, True, 0, "f16"),
-    (1, 9, 9, 16, 16, 3, 1, 1, 1, True, False, 0, "f16"),
-    (1, 16, 16, 40, 256, 1, 1, 0, 1, False, False, 256, "f16"),
-    (2, 20, 20, 512, 256, 1, 1, 0, 1, False, False, 0, "f16"),
-    (2, 20, 20, 256, 512, 3, 1, 1, 1, False, False, 256, "f16"),
-    (2, 20, 20, 256, 255 + 1, 1, 1, 0, 0, False, False, 0, "f16"),
-    (2, 12, 12, 32, 32, 3, 1, 1, 1, True, False, 0, "f32"),
-    (1, 14, 10, 4, 32, 3, 2, 1, 1, False, False, 0, "f32"),
-    (2, 20, 20, 128, 128, 3, 1, 1, 1, False, False, 0, "f32"),
-]
+    # B, H, W, C1, C2, k, s, p, act, residual, up2, cfg, max_blocks, dtype
+    (2, 20, 20, 32, 32, 1, 1, 0, 1, False, False, -1, 0, "f16"),
+    (2, 23, 17, 32, 64, 3, 1, 1, 1, True, False, -1, 0, "f16"),
+    (2, 40, 40, 64, 128, 3, 2, 1, 1, False, False, -1, 0, "f16"),
+    (2, 20, 20, 64, 128, 1, 1, 0, 0, False, True, -1, 0, "f16"),
+    (1, 9, 9, 16, 16, 3, 1, 1, 1, True, False, -1, 0, "f16"),
+    (1, 16, 16, 40, 256, 1, 1, 0, 1, False, False, 3, 0, "f16"),
+    (2, 20, 20, 512, 256, 1, 1, 0, 1, False, False, -1, 0, "f16"),
+    (2, 20, 20, 256, 512, 3, 1, 1, 1, False, False, 9, 0, "f16"),
+    (2, 20, 20, 256, 256, 1, 1, 0, 0, False, False, -1, 0, "f16"),
+    (2, 12, 12, 32, 32, 3, 1, 1, 1, True, False, -1, 0, "f32"),
+    (1, 14, 10, 4, 32, 3, 2, 1, 1, False, False, -1, 0, "f32"),
+    (2, 20, 20, 128, 128, 3, 1, 1, 1, False, False, -1, 0, "f32"),
+    (4, 40, 40, 64, 64, 1, 1, 0, 1, False, False, 7, 5, "f16"),     # persistent: 50 one-chunk tiles on 5 workgroups
+    (3, 33, 31, 32, 96, 3, 1, 1, 1, True, True, 0, 8, "f16"),
+] + [(2, 21, 19, c1, 160, 3, 1, 1, 1, True, False, cfg, 3, "f16") for cfg in range(14) for c1 in (64, 48)]
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
@@ -53,7 +55,7 @@ def test_conv_matches_torch_fp32_reference(case, dev):
     from yolov5_amd import _lib
     from yolov5_amd.packing import pack_conv_weight
 
-    B, H, W, C1, C2, k, s, p, act, residual, up2, tile_n, dt = case
+    B, H, W, C1, C2, k, s, p, act, residual, up2, cfg, max_blocks, dt = case
     lib = _lib.lib()
     tdt = torch.float16 if dt == "f16" else torch.float32
     x = torch.from_numpy(detgen.uniform((B, C1, H, W), -1, 1, name="x"))
@@ -62,6 +64,7 @@ def test_conv_matches_torch_fp32_reference(case, dev):
     if dt == "f16":
         x, w = x.half().float(), w.half().float()
     ldx, ldy = C1 + 8, C2 + 8
+    assert cfg is not None and max_blocks is not None
     xd = torch.full((B, H, W, ldx), 7.0, dtype=tdt, device=dev)
     xd[..., :C1] = x.permute(0, 2, 3, 1).to(dev, tdt)
     wp, bp, K, Kpad, Npad = pack_conv_weight(w, b, tdt)
@@ -74,7 +77,7 @@ def test_conv_matches_torch_fp32_reference(case, dev):
         res = y.clone()
     y2 = torch.full((B, 2 * OH, 2 * OW, C2), -5.0, dtype=tdt, device=dev) if up2 else None
     d = _lib.ConvDesc(dtype=_lib.Y5_F16 if dt == "f16" else _lib.Y5_F32, B=B, H=H, W=W, C1=C1, ldx=ldx, OH=OH, OW=OW, C2=C2,
-                      ldy=ldy, KH=k, KW=k, SH=s, SW=s, PH=p, PW=p, act=act, Kpad=Kpad, Npad=Npad, ldr=ldy, ld2=C2, tile_n=tile_n)
+                      ldy=ldy, KH=k, KW=k, SH=s, SW=s, PH=p, PW=p, act=act, Kpad=Kpad, Npad=Npad, ldr=ldy, ld2=C2, cfg=cfg, max_blocks=max_blocks)
     st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     rc = lib.y5_conv2d_fwd(C.byref(d), C.c_void_p(xd.data_ptr()), C.c_void_p(wp.data_ptr()), C.c_void_p(bp.data_ptr()),
                            C.c_void_p(y.data_ptr()) if residual else None, C.c_void_p(y.data_ptr()),
@@ -88,7 +91,7 @@ def test_conv_matches_torch_fp32_reference(case, dev):
     if residual:
         ref = ref + res[..., :C2].float().cpu()
     got = y[..., :C2].float().cpu()
-    tol = 1e-2 if dt == "f16" else 2e-5
+    tol = 2e-2 if dt == "f16" else 2e-5
     torch.testing.assert_close(got, ref, rtol=tol, atol=tol)
     pad = y[..., C2:].float().cpu()
     assert torch.equal(pad, torch.full_like(pad, -3.0) if not residual else res[..., C2:].float().cpu())
@@ -177,6 +180,9 @@ def test_single_layer_forward_api(dev):
 
     torch.manual_seed(0)
     for layer, ref_fn in ((Conv(16, 32, 3, 2), None), (C3(32, 32, 2), None), (SPPF(32, 32, 5), None)):
+        from yolov5_amd.yolo import initialize_weights
+
+        initialize_weights(layer)  # BN eps=1e-3 as inside a DetectionModel (models/yolo.py:259)
         layer = layer.eval()
         x = torch.rand(2, layer.conv.in_channels if hasattr(layer, "conv") else layer.cv1.conv.in_channels, 16, 16)
         sd = {"model.0." + k: v for k, v in layer.state_dict().items()}

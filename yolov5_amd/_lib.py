@@ -20,7 +20,7 @@ class ConvDesc(C.Structure):
 
     _fields_ = [(n, C.c_int) for n in (
         "dtype", "B", "H", "W", "C1", "ldx", "OH", "OW", "C2", "ldy", "KH", "KW", "SH", "SW", "PH", "PW",
-        "act", "Kpad", "Npad", "ldr", "ld2", "tile_n")]
+        "act", "Kpad", "Npad", "ldr", "ld2", "cfg", "max_blocks")]
 
 
 EXPORTS = {
@@ -29,6 +29,10 @@ EXPORTS = {
     "y5_last_error": (C.c_char_p, []),
     "y5_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p]),
+    "y5_conv2d_time": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
+    "y5_conv_num_cfgs": (C.c_int, []),
+    "y5_conv_cfg_info": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "y5_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_int, C.c_float, C.c_void_p]),
     "y5_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

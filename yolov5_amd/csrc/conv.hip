@@ -1,4 +1,4 @@
-// Host-side launcher + C-ABI entry point for the implicit-GEMM convolution (see conv_igemm.h).
+// Host-side launcher + C-ABI entry points for the implicit-GEMM convolution (see conv_igemm.h).
 #include <hip/hip_runtime.h>
 
 #include "../../include/yolov5_hip.h"
@@ -7,56 +7,138 @@
 
 namespace {
 
-template <typename T, int WM, int WN, int TM, int TN, bool TABLE>
-int launch_cfg(const Y5ConvParams& p0, hipStream_t stream) {
-  using Tr = Y5Tr<T>;
+struct TileCfg { int wm, wn, tm, tn, rb; };
+// id -> workgroup tile (BM = wm*tm*32 pixels, BN = wn*tn*32 channels), LDS row bytes (K per stage = rb / elemsize)
+constexpr TileCfg kCfgs[Y5_CONV_NUM_CFGS] = {
+    {4, 1, 1, 1, 64},   //  0: 128 x  32, BK32
+    {4, 1, 1, 2, 64},   //  1: 128 x  64, BK32
+    {2, 2, 2, 2, 64},   //  2: 128 x 128, BK32
+    {2, 2, 2, 4, 64},   //  3: 128 x 256, BK32
+    {4, 1, 2, 1, 64},   //  4: 256 x  32, BK32
+    {4, 1, 2, 2, 64},   //  5: 256 x  64, BK32
+    {4, 1, 1, 1, 128},  //  6: 128 x  32, BK64
+    {4, 1, 1, 2, 128},  //  7: 128 x  64, BK64
+    {2, 2, 2, 2, 128},  //  8: 128 x 128, BK64
+    {2, 2, 2, 4, 128},  //  9: 128 x 256, BK64
+    {4, 1, 2, 2, 128},  // 10: 256 x  64, BK64
+    {2, 2, 1, 2, 128},  // 11:  64 x 128, BK64
+    {2, 2, 4, 2, 128},  // 12: 256 x 128, BK64
+    {4, 1, 2, 1, 128},  // 13: 256 x  32, BK64
+};
+
+int g_num_cu = 0;
+
+template <typename T, int WM, int WN, int TM, int TN, int RB, bool TABLE>
+int launch_cfg(const Y5ConvParams& p0, int max_blocks, hipStream_t stream) {
+  using Gm = Y5ConvGeom<T, RB>;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   Y5ConvParams p = p0;
   p.tilesM = (p.M + BM - 1) / BM;
   p.tilesN = (p.Npad + BN - 1) / BN;
-  p.nk = p.Kpad / Tr::BK;
-  size_t lds = 2 * (BM + BN) * Y5_CONV_ROWB;
+  p.nk = (p.K + Gm::BK - 1) / Gm::BK;
+  if (p.nk * Gm::BK > p.Kpad) return y5_fail(Y5_ERR_BAD_ARG, "conv: Kpad smaller than K rounded up to the tile config's K per stage");
+  int pieces = 0;
   if (TABLE) {
-    if (p.Kpad / Tr::EPP > Y5_CONV_MAXTAB) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: K too large for gather-table mode");
-    lds += (size_t)(p.Kpad / Tr::EPP) * 8;
+    pieces = p.Kpad / Gm::EPP;
+    if (pieces > Y5_CONV_MAXTAB) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: K too large for gather-table mode");
   }
-  auto kern = y5_conv_igemm_kernel<T, WM, WN, TM, TN, TABLE>;
+  const size_t lds = y5_conv_lds_bytes<T, WM, WN, TM, TN, RB>(pieces);
+  if (lds > 160 * 1024) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: tile configuration exceeds 160 KiB of LDS");
+  auto kern = y5_conv_igemm_kernel<T, WM, WN, TM, TN, RB, TABLE>;
   static bool attr_done = false;  // per instantiation
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  const long long nblk = (long long)p.tilesM * p.tilesN;
-  if (nblk <= 0 || nblk > 0x7fffffffLL) return y5_fail(Y5_ERR_BAD_ARG, "conv: grid out of range");
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(WM * WN * 64), lds, stream, p);
+  const long long ntiles = (long long)p.tilesM * p.tilesN;
+  if (ntiles <= 0 || ntiles > 0x7fffffffLL) return y5_fail(Y5_ERR_BAD_ARG, "conv: grid out of range");
+  // persistent grid: as many workgroups as stay resident (CUs x occupancy), each walking ntiles/G tiles
+  long long G = max_blocks;
+  if (G <= 0) {
+    if (!g_num_cu) {
+      int dev = 0, n = 0;
+      hipGetDevice(&dev);
+      hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+      g_num_cu = n > 0 ? n : 256;
+    }
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), WM * WN * 64, lds) != hipSuccess || occ < 1)
+      occ = 1;
+    G = (long long)g_num_cu * occ;
+  }
+  if (G > ntiles) G = ntiles;
+  if (G >= 8) G &= ~7LL;  // y5_xcd_remap of the virtual block id needs G % 8 == 0 when blocks own several tiles
+  hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(WM * WN * 64), lds, stream, p);
   return y5_check_launch("y5_conv2d_fwd");
 }
 
 template <typename T, bool TABLE>
-int launch_by_n(const Y5ConvParams& p, int tile_n, hipStream_t stream) {
-  switch (tile_n) {
-    case 32: return launch_cfg<T, 4, 1, 1, 1, TABLE>(p, stream);
-    case 64: return launch_cfg<T, 4, 1, 1, 2, TABLE>(p, stream);
-    case 128: return launch_cfg<T, 2, 2, 2, 2, TABLE>(p, stream);
-    case 256: return launch_cfg<T, 2, 2, 2, 4, TABLE>(p, stream);
+int launch_by_cfg(const Y5ConvParams& p, int cfg, int mb, hipStream_t s) {
+  if constexpr (sizeof(T) == 4) {
+    switch (cfg) {
+      case 0: return launch_cfg<T, 4, 1, 1, 1, 64, TABLE>(p, mb, s);
+      case 1: return launch_cfg<T, 4, 1, 1, 2, 64, TABLE>(p, mb, s);
+      case 2: return launch_cfg<T, 2, 2, 2, 2, 64, TABLE>(p, mb, s);
+      case 3: return launch_cfg<T, 2, 2, 2, 4, 64, TABLE>(p, mb, s);
+    }
+    return y5_fail(Y5_ERR_BAD_ARG, "conv: fp32 supports tile configs 0..3 only");
+  } else {
+    switch (cfg) {
+      case 0: return launch_cfg<T, 4, 1, 1, 1, 64, TABLE>(p, mb, s);
+      case 1: return launch_cfg<T, 4, 1, 1, 2, 64, TABLE>(p, mb, s);
+      case 2: return launch_cfg<T, 2, 2, 2, 2, 64, TABLE>(p, mb, s);
+      case 3: return launch_cfg<T, 2, 2, 2, 4, 64, TABLE>(p, mb, s);
+      case 4: return launch_cfg<T, 4, 1, 2, 1, 64, TABLE>(p, mb, s);
+      case 5: return launch_cfg<T, 4, 1, 2, 2, 64, TABLE>(p, mb, s);
+      case 6: return launch_cfg<T, 4, 1, 1, 1, 128, TABLE>(p, mb, s);
+      case 7: return launch_cfg<T, 4, 1, 1, 2, 128, TABLE>(p, mb, s);
+      case 8: return launch_cfg<T, 2, 2, 2, 2, 128, TABLE>(p, mb, s);
+      case 9: return launch_cfg<T, 2, 2, 2, 4, 128, TABLE>(p, mb, s);
+      case 10: return launch_cfg<T, 4, 1, 2, 2, 128, TABLE>(p, mb, s);
+      case 11: return launch_cfg<T, 2, 2, 1, 2, 128, TABLE>(p, mb, s);
+      case 12: return launch_cfg<T, 2, 2, 4, 2, 128, TABLE>(p, mb, s);
+      case 13: return launch_cfg<T, 4, 1, 2, 1, 128, TABLE>(p, mb, s);
+    }
+    return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown tile config");
   }
-  return y5_fail(Y5_ERR_BAD_ARG, "conv: tile_n must be 32/64/128/256");
+}
+
+int default_cfg(const y5_conv_desc* d) {
+  const int n = d->Npad;
+  if (d->dtype == Y5_F32) return n <= 32 ? 0 : n <= 64 ? 1 : 2;
+  const bool k64 = d->Kpad % 64 == 0 && d->C1 % 64 == 0;
+  if (n <= 32) return k64 ? 6 : 0;
+  if (n <= 64) return k64 ? 7 : 1;
+  return k64 ? 8 : 2;
 }
 
 }  // namespace
 
+extern "C" int y5_conv_num_cfgs(void) { return Y5_CONV_NUM_CFGS; }
+
+extern "C" int y5_conv_cfg_info(int cfg, int* bm, int* bn, int* bk_bytes) {
+  if (cfg < 0 || cfg >= Y5_CONV_NUM_CFGS) return y5_fail(Y5_ERR_BAD_ARG, "conv_cfg_info: bad id");
+  if (bm) *bm = kCfgs[cfg].wm * kCfgs[cfg].tm * 32;
+  if (bn) *bn = kCfgs[cfg].wn * kCfgs[cfg].tn * 32;
+  if (bk_bytes) *bk_bytes = kCfgs[cfg].rb;
+  return Y5_OK;
+}
+
 extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                              const void* residual, void* y, void* y_up2, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (!d || !x || !w_packed || !bias || !y) return y5_fail(Y5_ERR_BAD_ARG, "conv: null pointer");
+  if (!d || !x || !w_packed || !bias || (!y && !y_up2)) return y5_fail(Y5_ERR_BAD_ARG, "conv: null pointer");
   const int es = d->dtype == Y5_F16 ? 2 : d->dtype == Y5_F32 ? 4 : 0;
   if (!es) return y5_fail(Y5_ERR_BAD_ARG, "conv: dtype must be Y5_F16 or Y5_F32");
-  const int epp = 16 / es, bk = 64 / es;
+  const int epp = 16 / es;
+  int cfg = d->cfg < 0 ? default_cfg(d) : d->cfg;
+  if (cfg >= Y5_CONV_NUM_CFGS) return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown tile config");
+  const int bk = kCfgs[cfg].rb / es;
   if (d->C1 % epp || d->ldx % epp) return y5_fail(Y5_ERR_BAD_ARG, "conv: C1 and ldx must be multiples of 16 bytes");
-  if (d->C2 % 4 || d->ldy % 4 || (residual && d->ldr % 4) || (y_up2 && d->ld2 % 4))
-    return y5_fail(Y5_ERR_BAD_ARG, "conv: C2/ldy/ldr/ld2 must be multiples of 4");
-  if (d->Kpad % bk || d->Kpad < d->KH * d->KW * d->C1 || d->Npad % 32 || d->Npad < d->C2)
-    return y5_fail(Y5_ERR_BAD_ARG, "conv: bad packed filter dims (Kpad % BK, Npad % 32)");
+  if (d->C2 % epp || (y && d->ldy % epp) || (residual && d->ldr % epp) || (y_up2 && d->ld2 % epp))
+    return y5_fail(Y5_ERR_BAD_ARG, "conv: C2/ldy/ldr/ld2 must be multiples of 16 bytes");
+  if (d->Kpad % epp || d->Kpad < d->KH * d->KW * d->C1 || d->Npad % 32 || d->Npad < d->C2)
+    return y5_fail(Y5_ERR_BAD_ARG, "conv: bad packed filter dims (Kpad % 16 bytes, Kpad >= K, Npad % 32)");
   if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)bias | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)y_up2) & 15)
     return y5_fail(Y5_ERR_BAD_ARG, "conv: pointers must be 16-byte aligned");
   const int oh = (d->H + 2 * d->PH - d->KH) / d->SH + 1, ow = (d->W + 2 * d->PW - d->KW) / d->SW + 1;
@@ -75,10 +157,26 @@ extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w
   p.ldr = d->ldr; p.ld2 = d->ld2;
   p.M = d->B * oh * ow;
 
-  int tile_n = d->tile_n;
-  if (tile_n == 0) tile_n = d->Npad <= 32 ? 32 : d->Npad <= 64 ? 64 : 128;
   const bool table = (d->C1 % bk) != 0;
   if (d->dtype == Y5_F16)
-    return table ? launch_by_n<half_t, true>(p, tile_n, stream) : launch_by_n<half_t, false>(p, tile_n, stream);
-  return table ? launch_by_n<float, true>(p, tile_n, stream) : launch_by_n<float, false>(p, tile_n, stream);
+    return table ? launch_by_cfg<half_t, true>(p, cfg, d->max_blocks, stream) : launch_by_cfg<half_t, false>(p, cfg, d->max_blocks, stream);
+  return table ? launch_by_cfg<float, true>(p, cfg, d->max_blocks, stream) : launch_by_cfg<float, false>(p, cfg, d->max_blocks, stream);
+}
+
+extern "C" int y5_conv2d_time(const y5_conv_desc* d, const void* x, const void* w_packed, const float* bias, const void* residual,
+                              void* y, void* y_up2, int iters, void* stream_, float* ms) {
+  if (!ms || iters < 1) return y5_fail(Y5_ERR_BAD_ARG, "conv_time: bad args");
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  int rc = y5_conv2d_fwd(d, x, w_packed, bias, residual, y, y_up2, stream_);  // warm-up + validation
+  if (rc) return rc;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return y5_fail(Y5_ERR_RUNTIME, "event create failed");
+  hipEventRecord(e0, st);
+  for (int i = 0; i < iters && !rc; ++i) rc = y5_conv2d_fwd(d, x, w_packed, bias, residual, y, y_up2, stream_);
+  hipEventRecord(e1, st);
+  if (hipEventSynchronize(e1) != hipSuccess) rc = y5_fail(Y5_ERR_RUNTIME, "event sync failed");
+  else { hipEventElapsedTime(ms, e0, e1); *ms /= (float)iters; }
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  return rc;
 }

@@ -1,6 +1,8 @@
-// NHWC implicit-GEMM convolution for gfx950 (MI355X): MFMA 32x32 tiles, LDS-DMA staged input/filter
-// tiles (global_load_lds, 16 B/lane, XOR-swizzled on the SOURCE side), fused bias + SiLU + residual
-// epilogue written straight from the accumulator registers (no LDS transpose).
+// NHWC implicit-GEMM convolution for gfx950 (MI355X): MFMA 32x32 tiles, LDS-DMA staged input/filter tiles
+// (global_load_lds, 16 B/lane, XOR-swizzled on the SOURCE side), PERSISTENT workgroups that walk several output
+// tiles with the next tile's loads in flight while the previous tile's epilogue runs, and a fused
+// bias + SiLU + residual epilogue that is transposed through a per-wave LDS scratch so that every global
+// store (and the optional 2x-upsampled replica) is a 16-byte, row-contiguous access.
 //
 // Replaces, for the reference hot path, `Conv.forward_fuse` (models/common.py:90-92: act(conv(x)) with the
 // BN folded by utils/torch_utils.py:224-254), the residual add of `Bottleneck.forward` (common.py:181),
@@ -11,13 +13,13 @@
 // GEMM view (operands swapped so that one lane owns ONE output pixel and 4 consecutive channels):
 //     D[n][m] = sum_k  Wp[n][k] * A[m][k]      n = output channel, m = output pixel (b,oh,ow),
 //     k = (kh, kw, c) flattened, A gathered on the fly from x[b][oh*SH-PH+kh][ow*SW-PW+kw][c].
-// MFMA "A" operand = filter rows, "B" operand = activation rows; both are 64-byte LDS rows (32 halfs /
-// 16 floats of K) read with one ds_read_b128 per lane: lane l -> row (l & 31), 16-byte slot (l >> 5).
-// Any permutation of k inside a 64-byte row is legal as long as filter and activation use the same one.
+// MFMA "A" operand = filter rows, "B" operand = activation rows; both are RB-byte LDS rows (RB = 64 or 128:
+// BK = 32/64 halfs or 16 floats of K) read with ds_read_b128: lane l -> row (l & 31), 16-byte slot from (l >> 5).
+// Any permutation of k inside a row is legal as long as filter and activation use the same one.
 //
-// LDS row swizzle: 16-byte slot s of row r is stored at slot s ^ ((r >> 2) & 3).  With 64-byte rows the
-// four 16-lane groups of a ds_read_b128 then hit 16 distinct 16-byte bank slots (conflict free).  The LDS-DMA
-// destination must stay lane-linear, so the permutation is applied to the per-lane GLOBAL source address.
+// LDS row swizzle: 16-byte slot s of row r is stored at slot s ^ f(r), f(r) = (r>>2)&3 for 64-byte rows and
+// (r>>1)&7 for 128-byte rows; the four 16-lane groups of a ds_read_b128 then hit 16 distinct 16-byte bank slots.
+// The LDS-DMA destination must stay lane-linear, so the permutation is applied to the per-lane GLOBAL source.
 #pragma once
 #include "y5_common.h"
 
@@ -26,7 +28,7 @@ struct Y5ConvParams {
   const void* w;      // packed filter [Npad][Kpad], k = (kh,kw,c)
   const float* bias;  // [Npad] fp32
   const void* res;    // optional residual, same geometry as y (pixel stride ldr), may alias y
-  void* y;            // output NHWC slice, pixel stride ldy
+  void* y;            // output NHWC slice, pixel stride ldy (may be null when only y2 is wanted)
   void* y2;           // optional second destination: 2x nearest-upsampled copy (pixel stride ld2)
   const void* zero;   // >= 64 bytes of zeros in global memory (source for padding taps / tails)
   int B, H, W, C1, ldx;
@@ -39,38 +41,59 @@ struct Y5ConvParams {
   int tilesM, tilesN, nk;
 };
 
-template <typename T> struct Y5Tr;
-template <> struct Y5Tr<half_t> { static constexpr int EPP = 8, BK = 32; };
-template <> struct Y5Tr<float>  { static constexpr int EPP = 4, BK = 16; };
+#define Y5_CONV_MAXTAB 4096   // max k-pieces in TABLE mode (LDS: 8 B each)
 
-#define Y5_CONV_ROWB 64       // bytes per LDS row (= BK elements)
-#define Y5_CONV_MAXTAB 2048   // max k-pieces in TABLE mode (LDS: 8 B each)
+template <typename T, int RB> struct Y5ConvGeom {
+  static constexpr int EPP = 16 / (int)sizeof(T);        // elements per 16-byte piece
+  static constexpr int BK = RB / (int)sizeof(T);         // K elements per stage
+  static constexpr int NSLOT = RB / 16;                  // 16-byte slots per LDS row
+  static constexpr int ROWS_PER_INSTR = 1024 / RB;       // rows covered by one 64-lane LDS-DMA instruction
+  static constexpr int SCR_ROWB = 32 * (int)sizeof(T) + 16;  // epilogue scratch row: 32 channels + 16 B pad
+  static constexpr int SCR_BYTES = 32 * SCR_ROWB;        // per wave
+  __device__ static __forceinline__ int swz(int row) { return RB == 64 ? ((row >> 2) & 3) : ((row >> 1) & 7); }
+};
 
-template <typename T, int WM, int WN, int TM, int TN, bool TABLE>
-__global__ __launch_bounds__(WM * WN * 64)
+template <typename T, int WM, int WN, int TM, int TN, int RB>
+constexpr size_t y5_conv_lds_bytes(int table_pieces) {
+  return 2 * (size_t)(WM * TM * 32 + WN * TN * 32) * RB + (size_t)table_pieces * 8 +
+         (size_t)WM * WN * Y5ConvGeom<T, RB>::SCR_BYTES;
+}
+
+// minimum waves per SIMD requested from the register allocator (keeps the accumulators in the unified VGPR file
+// and the allocation under the occupancy steps of MI355X_MICROARCH.md "Register files")
+constexpr int y5_conv_min_waves(int tm, int tn) { return tm * tn <= 1 ? 5 : tm * tn <= 2 ? 4 : tm * tn <= 4 ? 3 : 2; }
+
+template <typename T, int WM, int WN, int TM, int TN, int RB, bool TABLE>
+__global__ __launch_bounds__(WM * WN * 64, y5_conv_min_waves(TM, TN))
 void y5_conv_igemm_kernel(const Y5ConvParams p) {
-  using Tr = Y5Tr<T>;
-  constexpr int EPP = Tr::EPP, BK = Tr::BK;
+  using Gm = Y5ConvGeom<T, RB>;
+  constexpr int EPP = Gm::EPP, BK = Gm::BK, NSLOT = Gm::NSLOT, RPI = Gm::ROWS_PER_INSTR;
   constexpr int NW = WM * WN;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int ACT_INSTR = BM / 16, WGT_INSTR = BN / 16;
+  constexpr int ACT_INSTR = BM / RPI, WGT_INSTR = BN / RPI;
   static_assert(ACT_INSTR % NW == 0, "activation tile must split evenly over the waves");
+  static_assert(sizeof(T) == 2 || RB == 64, "fp32 path uses 64-byte rows only");
   constexpr int ACT_PER_WAVE = ACT_INSTR / NW;
   constexpr int WGT_PER_WAVE = (WGT_INSTR + NW - 1) / NW;
-  constexpr int BUF_BYTES = (BM + BN) * Y5_CONV_ROWB;
+  constexpr int BUF_BYTES = (BM + BN) * RB;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // layout: [buf0: act BM rows | wgt BN rows][buf1: same][tap table (TABLE mode only)]
+  // layout: [buf0: act BM rows | wgt BN rows][buf1: same][tap table (TABLE mode)][per-wave epilogue scratch]
   int2* tab = reinterpret_cast<int2*>(smem + 2 * BUF_BYTES);
+  const int tab_bytes = TABLE ? (p.Kpad / EPP) * 8 : 0;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
+  char* scratch = smem + 2 * BUF_BYTES + tab_bytes + wave * Gm::SCR_BYTES;
 
-  const int tile = y5_xcd_remap(blockIdx.x, p.tilesM * p.tilesN);
-  const int tile_n = tile % p.tilesN, tile_m = tile / p.tilesN;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int G = gridDim.x;
+  const int bid = blockIdx.x;
+  const int ntiles = p.tilesM * p.tilesN;
+  const int nmine = (ntiles - bid + G - 1) / G;  // host guarantees G <= ntiles
+  const int nk = p.nk;
+  const int total = nmine * nk;
 
   const T* __restrict__ xg = static_cast<const T*>(p.x);
   const T* __restrict__ wg = static_cast<const T*>(p.w);
@@ -95,45 +118,54 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
     }
   }
 
-  // ---- per-lane loader state ---------------------------------------------------------------------
-  const int lrow = lane >> 2;   // row inside one 16-row LDS-DMA instruction
-  const int lslot = lane & 3;   // destination 16-byte slot
-  int a_base[ACT_PER_WAVE];     // element offset of (b, ih0, iw0, source slot) ; meaningless if !a_ok
-  int a_ih0[ACT_PER_WAVE], a_iw0[ACT_PER_WAVE];
-  int a_slot[ACT_PER_WAVE];
-#pragma unroll
-  for (int i = 0; i < ACT_PER_WAVE; ++i) {
-    const int row = (wave + i * NW) * 16 + lrow;  // row inside the activation tile
-    const int sslot = lslot ^ ((row >> 2) & 3);
-    const int m = m0 + row;
-    const int mm = m < p.M ? m : 0;
-    const int ohw = p.OH * p.OW;
-    const int b = mm / ohw;
-    const int r = mm - b * ohw;
-    const int oh = r / p.OW, ow = r - oh * p.OW;
-    const int ih0 = oh * p.SH - p.PH, iw0 = ow * p.SW - p.PW;
-    a_ih0[i] = m < p.M ? ih0 : -0x40000000;  // pixel rows past M: every tap reads zeros
-    a_iw0[i] = iw0;
-    a_base[i] = ((b * p.H + ih0) * p.W + iw0) * p.ldx + sslot * EPP;
-    a_slot[i] = sslot;
-  }
+  // ---- stage-side (loader) state: describes the tile whose K chunks are currently being staged ------------
+  const int lrow = lane / NSLOT;   // row inside one LDS-DMA instruction
+  const int lslot = lane % NSLOT;  // destination 16-byte slot
+  int a_base[ACT_PER_WAVE];        // element offset of (b, ih0, iw0) + source slot
+  int a_ih0[ACT_PER_WAVE], a_iw0[ACT_PER_WAVE], a_slot[ACT_PER_WAVE];
   const char* w_src[WGT_PER_WAVE];
   bool w_ok[WGT_PER_WAVE];
+  int u_kh = 0, u_kw = 0, u_c0 = 0;  // uniform tap walker (UNIFORM mode: C1 % BK == 0)
+  int s_t = 0, s_kc = 0;             // staged tile (index into this block's tile list) / K chunk
+
+  auto tile_coords = [&](int j, int& m0, int& n0) {
+    const int t = y5_xcd_remap(bid + j * G, ntiles);
+    const int tn = t % p.tilesN, tm = t / p.tilesN;
+    m0 = tm * BM;
+    n0 = tn * BN;
+  };
+
+  auto loader_setup = [&](int j) {
+    int m0, n0;
+    tile_coords(j, m0, n0);
 #pragma unroll
-  for (int i = 0; i < WGT_PER_WAVE; ++i) {
-    const int row = (wave + i * NW) * 16 + lrow;  // row inside the filter tile
-    const int sslot = lslot ^ ((row >> 2) & 3);
-    const int n = n0 + row;
-    w_ok[i] = (row < BN) && (n < p.Npad);
-    w_src[i] = reinterpret_cast<const char*>(wg + (size_t)(w_ok[i] ? n : 0) * p.Kpad + sslot * EPP);
-  }
+    for (int i = 0; i < ACT_PER_WAVE; ++i) {
+      const int row = (wave + i * NW) * RPI + lrow;  // row inside the activation tile
+      const int sslot = lslot ^ Gm::swz(row);
+      const int m = m0 + row;
+      const int mm = m < p.M ? m : 0;
+      const int ohw = p.OH * p.OW;
+      const int b = mm / ohw;
+      const int r = mm - b * ohw;
+      const int oh = r / p.OW, ow = r - oh * p.OW;
+      const int ih0 = oh * p.SH - p.PH, iw0 = ow * p.SW - p.PW;
+      a_ih0[i] = m < p.M ? ih0 : -0x40000000;  // pixel rows past M: every tap reads zeros
+      a_iw0[i] = iw0;
+      a_base[i] = ((b * p.H + ih0) * p.W + iw0) * p.ldx + sslot * EPP;
+      a_slot[i] = sslot;
+    }
+#pragma unroll
+    for (int i = 0; i < WGT_PER_WAVE; ++i) {
+      const int row = (wave + i * NW) * RPI + lrow;  // row inside the filter tile
+      const int sslot = lslot ^ Gm::swz(row);
+      const int n = n0 + row;
+      w_ok[i] = (row < BN) && (n < p.Npad);
+      w_src[i] = reinterpret_cast<const char*>(wg + (size_t)(w_ok[i] ? n : 0) * p.Kpad + sslot * EPP);
+    }
+    u_kh = 0; u_kw = 0; u_c0 = 0;
+  };
 
-  if constexpr (TABLE) __syncthreads();
-
-  // uniform tap walker (UNIFORM mode: C1 % BK == 0 so one BK chunk never straddles a filter tap)
-  int u_kh = 0, u_kw = 0, u_c0 = 0;
-
-  auto stage = [&](int kc, int buf) {
+  auto stage = [&](int buf) {
     char* lds = smem + buf * BUF_BYTES;
     int tap_off = 0;
     if constexpr (!TABLE) tap_off = (u_kh * p.W + u_kw) * p.ldx + u_c0;
@@ -141,7 +173,7 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
     for (int i = 0; i < ACT_PER_WAVE; ++i) {
       int off, ih, iw;
       if constexpr (TABLE) {
-        const int2 e = tab[kc * 4 + a_slot[i]];
+        const int2 e = tab[s_kc * NSLOT + a_slot[i]];
         off = a_base[i] - a_slot[i] * EPP + e.x;
         ih = a_ih0[i] + (e.y & 0xffff);
         iw = a_iw0[i] + (e.y >> 16);
@@ -158,153 +190,186 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
     for (int i = 0; i < WGT_PER_WAVE; ++i) {
       const int idx = wave + i * NW;
       if (idx < WGT_INSTR) {
-        const char* src = w_ok[i] ? w_src[i] + (size_t)kc * BK * sizeof(T) : zero;
-        y5_glds16(src, lds + BM * Y5_CONV_ROWB + idx * 1024);
+        const char* src = w_ok[i] ? w_src[i] + (size_t)s_kc * BK * sizeof(T) : zero;
+        y5_glds16(src, lds + BM * RB + idx * 1024);
       }
     }
-    if constexpr (!TABLE) {  // advance the uniform tap walker by one BK chunk
+    // advance to the next (tile, chunk)
+    if constexpr (!TABLE) {
       u_c0 += BK;
       if (u_c0 >= p.C1) {
         u_c0 = 0;
         if (++u_kw == p.KW) { u_kw = 0; ++u_kh; }
       }
     }
+    if (++s_kc == nk) {
+      s_kc = 0;
+      if (++s_t < nmine) loader_setup(s_t);
+    }
   };
 
   float16_t acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // fragment read offsets (bytes inside a buffer); lane -> row (lane&31), k-slot group g = lane>>5
   const int g = lane >> 5;
   const int frow = lane & 31;
   int a_rd[TM], w_rd[TN];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) a_rd[i] = (wm * TM * 32 + i * 32 + frow) * Y5_CONV_ROWB;
+  for (int i = 0; i < TM; ++i) a_rd[i] = (wm * TM * 32 + i * 32 + frow) * RB;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) w_rd[j] = BM * Y5_CONV_ROWB + (wn * TN * 32 + j * 32 + frow) * Y5_CONV_ROWB;
-  const int fsw = (frow >> 2) & 3;  // swizzle term of this lane's rows (tile bases are multiples of 32)
+  for (int j = 0; j < TN; ++j) w_rd[j] = BM * RB + (wn * TN * 32 + j * 32 + frow) * RB;
+  const int fsw = Gm::swz(frow);  // swizzle term of this lane's rows (tile bases are multiples of 32)
 
-  stage(0, 0);
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): LDS-DMA of the next tile has landed
+  // ---- epilogue of one finished tile: bias + act -> per-wave LDS transpose -> 16-byte coalesced stores -----
+  T* yg = static_cast<T*>(p.y);  // may alias p.res (in-place residual): no restrict
+  const T* rg = static_cast<const T*>(p.res);
+  T* y2g = static_cast<T*>(p.y2);
+  constexpr int SCR_ROWB = Gm::SCR_ROWB;
+  constexpr int CPV = 16 / (int)sizeof(T);           // channels per 16-byte vector
+  constexpr int VPR = 32 / CPV;                      // vectors per scratch row (4 for half, 8 for float)
+  constexpr int ROWS_PER_PASS = 64 / VPR;            // 16 (half) / 8 (float)
+  auto epilogue = [&](int m0, int n0) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int mt = m0 + wm * TM * 32 + i * 32;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int nt = n0 + wn * TN * 32 + j * 32;
+        // (1) registers -> scratch[pixel row = lane&31][channel]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int nl = q * 8 + g * 4;
+          float4_t bv = {0.f, 0.f, 0.f, 0.f};
+          if (nt + nl < p.Npad) bv = *reinterpret_cast<const float4_t*>(p.bias + nt + nl);
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float t = acc[i][j][q * 4 + e] + bv[e];
+            v[e] = p.act ? y5_silu(t) : t;
+          }
+          char* dst = scratch + frow * SCR_ROWB + nl * (int)sizeof(T);
+          if constexpr (sizeof(T) == 2) {
+            half4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
+            *reinterpret_cast<half4_t*>(dst) = o;
+          } else {
+            float4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = v[e];
+            *reinterpret_cast<float4_t*>(dst) = o;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // (2) scratch rows -> global, 16 B per lane, VPR lanes cover one pixel's 32 channels
+#pragma unroll
+        for (int ps = 0; ps < 32 / ROWS_PER_PASS; ++ps) {
+          const int row = ps * ROWS_PER_PASS + lane / VPR;
+          const int vs = lane % VPR;
+          const int m = mt + row;
+          const int n = nt + vs * CPV;
+          if (m < p.M && n < p.C2) {
+            uint4_t raw = *reinterpret_cast<const uint4_t*>(scratch + row * SCR_ROWB + vs * 16);
+            if (rg) {
+              const uint4_t rr = *reinterpret_cast<const uint4_t*>(rg + (size_t)m * p.ldr + n);
+              if constexpr (sizeof(T) == 2) {
+                half8_t a = __builtin_bit_cast(half8_t, raw), b = __builtin_bit_cast(half8_t, rr), c;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) c[e] = (half_t)((float)a[e] + (float)b[e]);
+                raw = __builtin_bit_cast(uint4_t, c);
+              } else {
+                float4_t a = __builtin_bit_cast(float4_t, raw), b = __builtin_bit_cast(float4_t, rr);
+                a += b;
+                raw = __builtin_bit_cast(uint4_t, a);
+              }
+            }
+            if (yg) *reinterpret_cast<uint4_t*>(yg + (size_t)m * p.ldy + n) = raw;
+            if (y2g) {
+              const int ohw = p.OH * p.OW;
+              const int b = m / ohw;
+              const int r = m - b * ohw;
+              const int oh = r / p.OW, ow = r - oh * p.OW;
+              const size_t row0 = ((size_t)b * 2 * p.OH + 2 * oh) * (2 * p.OW) + 2 * ow;
+              T* d0 = y2g + row0 * p.ld2 + n;
+              T* d1 = y2g + (row0 + 2 * p.OW) * p.ld2 + n;
+              *reinterpret_cast<uint4_t*>(d0) = raw;
+              *reinterpret_cast<uint4_t*>(d0 + p.ld2) = raw;
+              *reinterpret_cast<uint4_t*>(d1) = raw;
+              *reinterpret_cast<uint4_t*>(d1 + p.ld2) = raw;
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  };
+
+  if constexpr (TABLE) __syncthreads();
+  loader_setup(0);
+  stage(0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   __syncthreads();
 
-  const int nk = p.nk;
-  for (int kc = 0; kc < nk; ++kc) {
-    const int cur = kc & 1;
-    if (kc + 1 < nk) stage(kc + 1, cur ^ 1);
-    const char* lds = smem + cur * BUF_BYTES;
-    if constexpr (sizeof(T) == 2) {
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int so = ((ks * 2 + g) ^ fsw) * 16;
-        half8_t af[TM], wf[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const half8_t*>(lds + a_rd[i] + so);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const half8_t*>(lds + w_rd[j] + so);
+  int it = 0;
+  int pm0 = 0, pn0 = 0;  // coordinates of the tile whose results sit in acc
+  for (int ti = 0; ti < nmine; ++ti) {
+    for (int kc = 0; kc < nk; ++kc, ++it) {
+      const int cur = it & 1;
+      if (it + 1 < total) stage(cur ^ 1);  // next chunk (possibly of the next tile) flies during everything below
+      if (kc == 0) {
+        if (ti > 0) epilogue(pm0, pn0);
+        tile_coords(ti, pm0, pn0);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
       }
-    } else {
-      const int so0 = ((2 * g) ^ fsw) * 16, so1 = ((2 * g + 1) ^ fsw) * 16;
-      float4_t af[TM][2], wf[TN][2];
+      const char* lds = smem + cur * BUF_BYTES;
+      if constexpr (sizeof(T) == 2) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        af[i][0] = *reinterpret_cast<const float4_t*>(lds + a_rd[i] + so0);
-        af[i][1] = *reinterpret_cast<const float4_t*>(lds + a_rd[i] + so1);
-      }
+        for (int ks = 0; ks < RB / 32; ++ks) {
+          const int so = ((ks * 2 + g) ^ fsw) * 16;
+          half8_t af[TM], wf[TN];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        wf[j][0] = *reinterpret_cast<const float4_t*>(lds + w_rd[j] + so0);
-        wf[j][1] = *reinterpret_cast<const float4_t*>(lds + w_rd[j] + so1);
-      }
+          for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const half8_t*>(lds + a_rd[i] + so);
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
+          for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const half8_t*>(lds + w_rd[j] + so);
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[j][h][e], af[i][h][e], acc[i][j], 0, 0, 0);
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): LDS-DMA of the next tile has landed
-    __syncthreads();
-  }
-
-  // ---- epilogue: D[n][m]; lane owns pixel m = .. + (lane & 31) and channels 8*q + 4*(lane>>5) + {0..3}
-  T* yg = static_cast<T*>(p.y);  // may alias p.res (in-place residual): no restrict
-  const T* rg = static_cast<const T*>(p.res);
-  T* y2g = static_cast<T*>(p.y2);
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int m = m0 + wm * TM * 32 + i * 32 + frow;
-    if (m >= p.M) continue;
-    size_t up_off[4];
-    if (y2g) {
-      const int ohw = p.OH * p.OW;
-      const int b = m / ohw;
-      const int r = m - b * ohw;
-      const int oh = r / p.OW, ow = r - oh * p.OW;
-      const size_t row0 = ((size_t)b * 2 * p.OH + 2 * oh) * (2 * p.OW) + 2 * ow;
-      up_off[0] = row0 * p.ld2;
-      up_off[1] = (row0 + 1) * p.ld2;
-      up_off[2] = (row0 + 2 * p.OW) * p.ld2;
-      up_off[3] = (row0 + 2 * p.OW + 1) * p.ld2;
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn * TN * 32 + j * 32 + q * 8 + g * 4;
-        if (n >= p.C2) continue;
-        const float4_t bv = *reinterpret_cast<const float4_t*>(p.bias + n);
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float t = acc[i][j][q * 4 + e] + bv[e];
-          v[e] = p.act ? y5_silu(t) : t;
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
         }
-        if (rg) {
-          const T* rp = rg + (size_t)m * p.ldr + n;
-          if constexpr (sizeof(T) == 2) {
-            const half4_t rv = *reinterpret_cast<const half4_t*>(rp);
+      } else {
+        const int so0 = ((2 * g) ^ fsw) * 16, so1 = ((2 * g + 1) ^ fsw) * 16;
+        float4_t af[TM][2], wf[TN][2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
-          } else {
-            const float4_t rv = *reinterpret_cast<const float4_t*>(rp);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += rv[e];
-          }
+        for (int i = 0; i < TM; ++i) {
+          af[i][0] = *reinterpret_cast<const float4_t*>(lds + a_rd[i] + so0);
+          af[i][1] = *reinterpret_cast<const float4_t*>(lds + a_rd[i] + so1);
         }
-        if constexpr (sizeof(T) == 2) {
-          half4_t o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
-          *reinterpret_cast<half4_t*>(yg + (size_t)m * p.ldy + n) = o;
-          if (y2g) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) *reinterpret_cast<half4_t*>(y2g + up_off[u] + n) = o;
-          }
-        } else {
-          float4_t o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = v[e];
-          *reinterpret_cast<float4_t*>(yg + (size_t)m * p.ldy + n) = o;
-          if (y2g) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) *reinterpret_cast<float4_t*>(y2g + up_off[u] + n) = o;
-          }
+        for (int j = 0; j < TN; ++j) {
+          wf[j][0] = *reinterpret_cast<const float4_t*>(lds + w_rd[j] + so0);
+          wf[j][1] = *reinterpret_cast<const float4_t*>(lds + w_rd[j] + so1);
         }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[j][h][e], af[i][h][e], acc[i][j], 0, 0, 0);
       }
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the chunk staged above has landed
+      __syncthreads();
     }
   }
+  epilogue(pm0, pn0);
 }

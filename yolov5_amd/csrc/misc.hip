@@ -89,13 +89,27 @@ extern "C" int y5_detect_decode(const void* logits, int dt, int B, int ny, int n
   Y5DecodeParams p{};
   p.logits = logits; p.z = z; p.raw = raw;
   p.nrows_total = nrows_total; p.row_off = row_off;
-  p.total = (long long)B * na * ny * nx * no;
   p.ny = ny; p.nx = nx; p.na = na; p.no = no; p.nm = nm; p.ld = ld; p.stride = stride;
   for (int i = 0; i < na * 2; ++i) p.anchors_px[i] = anchors_px[i];
-  const dim3 g(nblocks(p.total, 256)), b(256);
-  if (dt == Y5_F16 && zdt == Y5_F16) hipLaunchKernelGGL((y5_detect_decode_kernel<half_t, half_t>), g, b, 0, st, p);
-  else if (dt == Y5_F16 && zdt == Y5_F32) hipLaunchKernelGGL((y5_detect_decode_kernel<half_t, float>), g, b, 0, st, p);
-  else if (dt == Y5_F32 && zdt == Y5_F32) hipLaunchKernelGGL((y5_detect_decode_kernel<float, float>), g, b, 0, st, p);
+  const int es = esize(dt);
+  if ((ld * es) % 16 || ((uintptr_t)logits & 15)) return y5_fail(Y5_ERR_BAD_ARG, "detect_decode: logits rows must be 16-byte aligned");
+  p.P = dt == Y5_F16 ? 64 : 32;
+  while (p.P > 2 && (size_t)p.P * ld * es > 96 * 1024) p.P >>= 1;
+  if ((long long)p.P * no >= 65536) return y5_fail(Y5_ERR_UNSUPPORTED, "detect_decode: no too large");
+  p.inv_no = (unsigned)((0x100000000ULL + (unsigned)no - 1) / (unsigned)no);
+  const size_t lds = (size_t)p.P * ld * es;
+  const int npix = ny * nx;
+  const dim3 g((unsigned)((npix + p.P - 1) / p.P), (unsigned)B), b(256);
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)y5_detect_decode_kernel<half_t, half_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    hipFuncSetAttribute((const void*)y5_detect_decode_kernel<half_t, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    hipFuncSetAttribute((const void*)y5_detect_decode_kernel<float, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr = true;
+  }
+  if (dt == Y5_F16 && zdt == Y5_F16) hipLaunchKernelGGL((y5_detect_decode_kernel<half_t, half_t>), g, b, lds, st, p);
+  else if (dt == Y5_F16 && zdt == Y5_F32) hipLaunchKernelGGL((y5_detect_decode_kernel<half_t, float>), g, b, lds, st, p);
+  else if (dt == Y5_F32 && zdt == Y5_F32) hipLaunchKernelGGL((y5_detect_decode_kernel<float, float>), g, b, lds, st, p);
   else return y5_fail(Y5_ERR_BAD_ARG, "detect_decode: dtype pair");
   return y5_check_launch("y5_detect_decode");
 }

@@ -100,49 +100,86 @@ __global__ void y5_copy_slice_kernel(const char* __restrict__ src, char* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Detect decode (models/yolo.py:96-115).  One thread per OUTPUT element (b, a, iy, ix, o), o fastest, so
-// that both the z row write and the logits read are contiguous across the wave.
-// Row index inside z is bit-exactly the reference's: row_off + a*ny*nx + iy*nx + ix.
+// Detect decode (models/yolo.py:96-115).  One workgroup per (image, tile of P pixels): the tile's logits
+// (P x ld, 16 B per lane, coalesced) are staged in LDS; then for every anchor the P*no output values, which are
+// CONTIGUOUS in z (rows a*ny*nx + pix .. of image b) and in the raw (bs,na,ny,nx,no) tensor, are produced two
+// per lane and written with 4-byte/8-byte stores.  Row index inside z is bit-exactly the reference's:
+// row_off + a*ny*nx + iy*nx + ix.
 // ---------------------------------------------------------------------------------------------------
 struct Y5DecodeParams {
   const void* logits;
   void* z;
   void* raw;
-  long long nrows_total, row_off, total;
-  int ny, nx, na, no, nm, ld;
+  long long nrows_total, row_off;
+  int ny, nx, na, no, nm, ld, P;
+  unsigned inv_no;  // ceil(2^32 / no): idx / no == umulhi(idx, inv_no) for idx < 2^16
   float stride;
   float anchors_px[16];  // na*2
 };
 
+template <typename T>
+__device__ __forceinline__ float y5_decode_one(const Y5DecodeParams& p, const T* tile, int pix0, int a, int e, float& rawv) {
+  const int pl = (int)__umulhi((unsigned)e, p.inv_no);  // pixel inside the tile
+  const int o = e - pl * p.no;
+  const float v = (float)tile[pl * p.ld + a * p.no + o];
+  rawv = v;
+  if (o >= p.no - p.nm) return v;  // Segment mask coefficients are not activated (yolo.py:104-108)
+  const float s = y5_sigmoid(v);
+  if (o < 2) {
+    const int pix = pix0 + pl;
+    const int iy = pix / p.nx, ix = pix - iy * p.nx;
+    const float g = (float)(o == 0 ? ix : iy) - 0.5f;  // grid = (ix-0.5, iy-0.5), yolo.py:126
+    return (s * 2.0f + g) * p.stride;                   // yolo.py:110
+  }
+  if (o < 4) {
+    const float w = s * 2.0f;
+    return w * w * p.anchors_px[a * 2 + (o - 2)];  // yolo.py:111
+  }
+  return s;
+}
+
 template <typename T, typename Z>
-__global__ void y5_detect_decode_kernel(const Y5DecodeParams p) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= p.total) return;
-  const int o = (int)(i % p.no);
-  long long t = i / p.no;
+__global__ __launch_bounds__(256)
+void y5_detect_decode_kernel(const Y5DecodeParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* tile = reinterpret_cast<T*>(smem);
   const int npix = p.ny * p.nx;
-  const int pix = (int)(t % npix);
-  t /= npix;
-  const int a = (int)(t % p.na);
-  const long long b = t / p.na;
-  const T* lg = static_cast<const T*>(p.logits);
-  const float v = (float)lg[(b * npix + pix) * p.ld + a * p.no + o];
-  if (p.raw) static_cast<T*>(p.raw)[i] = (T)v;  // (bs,na,ny,nx,no) contiguous == index i
-  float r;
-  if (o >= p.no - p.nm) {
-    r = v;  // Segment mask coefficients are not activated (yolo.py:104-108)
-  } else {
-    const float s = y5_sigmoid(v);
-    if (o < 2) {
-      const int iy = pix / p.nx, ix = pix - iy * p.nx;
-      const float g = (float)(o == 0 ? ix : iy) - 0.5f;  // grid = (ix-0.5, iy-0.5), yolo.py:126
-      r = (s * 2.0f + g) * p.stride;                        // yolo.py:110
-    } else if (o < 4) {
-      const float w = s * 2.0f;
-      r = w * w * p.anchors_px[a * 2 + (o - 2)];  // yolo.py:111
+  const int b = blockIdx.y;
+  const int pix0 = blockIdx.x * p.P;
+  const int np = npix - pix0 < p.P ? npix - pix0 : p.P;
+  // stage logits: np pixels x ld elements, contiguous in global memory
+  {
+    const uint4_t* src = reinterpret_cast<const uint4_t*>(static_cast<const T*>(p.logits) + ((long long)b * npix + pix0) * p.ld);
+    uint4_t* dst = reinterpret_cast<uint4_t*>(smem);
+    const int nvec = np * p.ld * (int)sizeof(T) / 16;
+    for (int i = threadIdx.x; i < nvec; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int ne = np * p.no;  // output elements per anchor for this tile
+  for (int a = 0; a < p.na; ++a) {
+    const long long zbase = ((long long)b * p.nrows_total + p.row_off + (long long)a * npix + pix0) * p.no;
+    const long long rbase = (((long long)b * p.na + a) * npix + pix0) * p.no;
+    Z* zp = static_cast<Z*>(p.z) + zbase;
+    T* rp = p.raw ? static_cast<T*>(p.raw) + rbase : nullptr;
+    const bool pair_ok = ((zbase | rbase | ne) & 1) == 0;
+    if (pair_ok) {
+      for (int e = threadIdx.x * 2; e < ne; e += blockDim.x * 2) {
+        float r0, r1;
+        const float v0 = y5_decode_one<T>(p, tile, pix0, a, e, r0);
+        const float v1 = y5_decode_one<T>(p, tile, pix0, a, e + 1, r1);
+        typedef Z Z2 __attribute__((ext_vector_type(2)));
+        typedef T T2 __attribute__((ext_vector_type(2)));
+        Z2 zo; zo[0] = (Z)v0; zo[1] = (Z)v1;
+        *reinterpret_cast<Z2*>(zp + e) = zo;
+        if (rp) { T2 ro; ro[0] = (T)r0; ro[1] = (T)r1; *reinterpret_cast<T2*>(rp + e) = ro; }
+      }
     } else {
-      r = s;
+      for (int e = threadIdx.x; e < ne; e += blockDim.x) {
+        float r0;
+        const float v0 = y5_decode_one<T>(p, tile, pix0, a, e, r0);
+        zp[e] = (Z)v0;
+        if (rp) rp[e] = (T)r0;
+      }
     }
   }
-  static_cast<Z*>(p.z)[(b * p.nrows_total + p.row_off + (long long)a * npix + pix) * p.no + o] = (Z)r;
 }

@@ -17,6 +17,7 @@ built library and raises otherwise -- there is no CPU execution path.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 
 import torch
@@ -289,16 +290,23 @@ def folded_weights(mods):
     return torch.cat(ws, 0), torch.cat(bs, 0)
 
 
+_TUNE_CACHE = {}  # conv descriptor (shape/dtype/strides) -> fastest tile configuration id, per process
+
+
 class _HipBackend:
     """Device memory + stream provider of the Engine: PyTorch-ROCm caching allocator and current HIP stream.
     (The Engine takes it as a parameter so that tests can drive the very same plan-materialisation code against
     the host-compiled kernels of tests/hipemu; the product only ever constructs this GPU backend.)"""
+
+    autotune = True  # time every workgroup-tile configuration per conv layer at plan build and keep the fastest
 
     def __init__(self, device):
         if not torch.cuda.is_available() or torch.device(device).type != "cuda":
             raise RuntimeError("yolov5_amd.Engine needs a ROCm GPU (MI355X); there is no CPU execution path")
         self.lib = _lib.lib()
         self.device = torch.device(device)
+        if os.environ.get("Y5_AUTOTUNE", "1") == "0":
+            self.autotune = False
 
     def empty(self, shape, dtype):
         return torch.empty(shape, dtype=dtype, device=self.device)
@@ -348,6 +356,7 @@ class Engine:
             self.outputs[name] = self.be.empty(o["shape"], dtype)
         self.plan = C.c_void_p(self.lib.y5_plan_create())
         self.op_names = []
+        self.conv_cfgs = []
         self._first_op = None
         with torch.no_grad():
             for op in self.spec.ops:
@@ -436,11 +445,41 @@ class Engine:
         c2s = op["c2_store"]
         d = _lib.ConvDesc(dtype=self.dt, B=self.spec.B, H=H, W=W, C1=C1, ldx=ldx, OH=y.H, OW=y.W, C2=c2s, ldy=self._ld(y),
                           KH=kh, KW=kw, SH=sh, SW=sw, PH=ph, PW=pw, act=1 if op["act"] else 0, Kpad=Kpad, Npad=Npad,
-                          ldr=self._ld(res) if res is not None else 0, ld2=self._ld(y2) if y2 is not None else 0, tile_n=0)
+                          ldr=self._ld(res) if res is not None else 0, ld2=self._ld(y2) if y2 is not None else 0, cfg=-1, max_blocks=0)
         assert Npad >= c2s
+        ptrs = (self._ptr(x), C.c_void_p(self.be.ptr(wp)), C.c_void_p(self.be.ptr(bp)), self._ptr(res), self._ptr(y), self._ptr(y2))
+        if getattr(self.be, "autotune", False):
+            d.cfg = self._autotune_conv(d, ptrs)
+        self.conv_cfgs.append(int(d.cfg))
         self.op_names.append("conv:" + op["name"])
         return self.lib.y5_plan_add_conv(self.plan, C.byref(d), self._ptr(x), C.c_void_p(self.be.ptr(wp)), C.c_void_p(self.be.ptr(bp)),
                                          self._ptr(res), self._ptr(y), self._ptr(y2))
+
+    def _autotune_conv(self, d, ptrs):
+        """Measure-don't-guess tile selection: HIP-event timing of each tile configuration on the real buffers."""
+        key = tuple(getattr(d, f) for f, _ in _lib.ConvDesc._fields_ if f not in ("cfg", "max_blocks")) + tuple(p is None or p.value is None for p in ptrs)
+        best = _TUNE_CACHE.get(key)
+        if best is not None:
+            return best
+        ncfg = self.lib.y5_conv_num_cfgs() if d.dtype == _lib.Y5_F16 else 4
+        st = self._stream()
+        ms = C.c_float(0)
+        best, best_ms = -1, float("inf")
+        bm, bn, kb = C.c_int(0), C.c_int(0), C.c_int(0)
+        for cfg in range(ncfg):
+            self.lib.y5_conv_cfg_info(cfg, C.byref(bm), C.byref(bn), C.byref(kb))
+            if bn.value >= 2 * d.Npad and bn.value > 32:
+                continue  # more than half of the tile's channels would be padding
+            d.cfg = cfg
+            rc = self.lib.y5_conv2d_time(C.byref(d), *ptrs, 5, st, C.byref(ms))
+            if rc != 0:
+                continue  # configuration not applicable to this shape (e.g. gather table too large)
+            if ms.value < best_ms:
+                best, best_ms = cfg, ms.value
+        if best < 0:
+            _lib.check(-2, self.lib)
+        _TUNE_CACHE[key] = best
+        return best
 
     # -- execution ---------------------------------------------------------------------------------------------
     def _stream(self):

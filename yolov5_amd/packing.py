@@ -16,7 +16,7 @@ def pack_conv_weight(w: torch.Tensor, bias, dtype: torch.dtype, c1_pad: int | No
     """
     c2, c1, kh, kw = w.shape
     c1p = c1 if c1_pad is None else c1_pad
-    bk = 64 // torch.empty((), dtype=dtype).element_size()
+    bk = 128 // torch.empty((), dtype=dtype).element_size()  # K padded to 128 bytes: valid for every tile config
     wk = torch.zeros((c2, kh, kw, c1p), dtype=torch.float32, device=w.device)
     wk[..., :c1] = w.detach().float().permute(0, 2, 3, 1)
     k = kh * kw * c1p
