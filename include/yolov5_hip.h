@@ -116,6 +116,48 @@ int y5_nms_batched(const void* pred, int dtype, int bs, int n, int no, int nm, f
                    float* out, int* out_count, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * y5_loss_forward / y5_loss_backward -- utils/loss.py:101-247 `ComputeLoss.__call__` + `build_targets`, including
+ * the un-vendored ultralytics `bbox_iou(CIoU=True)` / `smooth_bce` it calls (loss.py:6,117,153).
+ * p[i]: device pointer of level i's raw head output (bs, na, ny[i], nx[i], 5+nc), contiguous, dtype `dtype`.
+ * targets: device (nt, 6) fp32 rows [img, cls, x, y, w, h] (xywh normalised), nt may be 0.
+ * forward:  out4 (device, 4 floats) = [loss = (lbox+lobj+lcls)*bs, lbox, lobj, lcls]          (loss.py:178-183)
+ * backward: dp[i] = d(loss * *grad_scale)/dp[i], same shape and dtype as p[i]; grad_scale is a DEVICE scalar
+ *           (autograd grad_output, e.g. GradScaler scale x WORLD_SIZE) or NULL for 1.  Needs the workspace of the
+ *           matching y5_loss_forward call untouched.  No host synchronisation in either call.
+ * Contracts: duplicate (b,a,gj,gi) rows -> tobj takes the LAST row's iou (loss.py:163 on CPU); row gradients of
+ * duplicate cells are summed in ascending row order; fl_gamma = 0, gr = 1, autobalance off, sort_obj_iou off.
+ * anchors: [level * 16 + a * 2 + {0,1}] in grid units (Detect.anchors); balance: loss.py:125.
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct {
+  int dtype;
+  int nl, na, nc, bs;
+  int ny[5], nx[5];
+  float anchors[5 * 16];
+  float balance[5];
+  float hyp_box, hyp_obj, hyp_cls, cls_pw, obj_pw, anchor_t, cp, cn;
+} y5_loss_desc;
+size_t y5_loss_workspace_bytes(const y5_loss_desc* d, int nt);   /* 0 on invalid descriptor */
+int y5_loss_forward(const y5_loss_desc* d, const void* const* p, const float* targets, int nt, float* out4,
+                    void* workspace, size_t workspace_bytes, void* stream);
+int y5_loss_backward(const y5_loss_desc* d, const void* const* p, int nt, const float* grad_scale, void* const* dp,
+                     void* workspace, size_t workspace_bytes, void* stream);
+/* Byte offsets inside the workspace of level `level`'s build_targets result (loss.py:185-247), valid after
+ * y5_loss_forward: offs = {n (int32), b, a, gj, gi, tcls (int32[cap]), tbox (float[cap][4]), anch (float[cap][2]),
+ * iou (float[cap]), row_grad (float[cap][5+nc])}; *cap = 5*na*nt rows. */
+int y5_loss_targets_layout(const y5_loss_desc* d, int nt, int level, size_t offs[10], long long* cap);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * y5_process_mask -- utils/segment/general.py:25-51 `process_mask` (+ `crop_mask` :10-22) for ONE image:
+ * protos (c, mh, mw) f16|f32 contiguous; instance i has c fp32 coefficients at masks_in + i*ld_m and an xyxy box (input
+ * image pixels) at boxes + i*ld_b (both may point into the NMS output rows: ld = 6+nm).  out: (n, ih, iw) when
+ * upsample != 0 (bilinear, align_corners=False, then > 0.5) else (n, mh, mw); element type Y5_F32 (0.f/1.f, the
+ * reference's `masks.gt_(0.5)` result) or Y5_U8 (0/1).
+ * ------------------------------------------------------------------------------------------------------- */
+int y5_process_mask(const void* protos, int proto_dtype, int c, int mh, int mw, const float* masks_in, int ld_m,
+                    const float* boxes, int ld_b, int n, int ih, int iw, int upsample, void* out, int out_dtype,
+                    void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Execution plan: a recorded list of the calls above, replayed by ONE host call (and optionally through a
  * captured hipGraph).  Replaces the Python module walk of models/yolo.py:160-170 `_forward_once`.
  * ------------------------------------------------------------------------------------------------------- */

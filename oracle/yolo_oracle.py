@@ -434,7 +434,11 @@ def compute_loss(p, targets, anchors, hyp=None, nc=80, balance=(4.0, 1.0, 0.4)):
             iou = bbox_ciou(pbox, tbox[i]).squeeze(-1)
             lbox = lbox + (1.0 - iou).mean()
             iou = iou.detach().clamp(0).type(tobj.dtype)
-            tobj[b, a, gj, gi] = iou  # duplicate indices: last write wins (SURVEY 8c hazard 3)
+            # duplicate (b,a,gj,gi): CONTRACT = last write in build_targets row order wins (SURVEY 8c hazard 3).  torch's
+            # CPU index_put_ gives exactly that for small n but an unspecified winner for a few thousand rows (observed),
+            # and its CUDA kernel is unordered, so the contract is spelled out with numpy (documented: last value wins).
+            lin = ((b * pi.shape[1] + a) * pi.shape[2] + gj) * pi.shape[3] + gi
+            tobj.view(-1).numpy()[lin.numpy()] = iou.numpy()
             if nc > 1:
                 t = torch.full_like(pcls, cn)
                 t[range(n), tcls[i]] = cp

@@ -91,6 +91,8 @@ inline float __expf(float x) { return expf(x); }
 inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 inline int atomicAdd(int* p, int v) { int o = *p; *p += v; return o; }
+inline int atomicExch(int* p, int v) { int o = *p; *p = v; return o; }
+inline float atomicAdd(float* p, float v) { float o = *p; *p += v; return o; }
 inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 
 inline void emu_glds(const void* g, void* l, int size) { memcpy((char*)l + (size_t)emu::lane_id() * size, g, size); }

@@ -23,6 +23,15 @@ class ConvDesc(C.Structure):
         "act", "Kpad", "Npad", "ldr", "ld2", "cfg", "max_blocks")]
 
 
+class LossDesc(C.Structure):
+    """y5_loss_desc (include/yolov5_hip.h)."""
+
+    _fields_ = [("dtype", C.c_int), ("nl", C.c_int), ("na", C.c_int), ("nc", C.c_int), ("bs", C.c_int),
+                ("ny", C.c_int * 5), ("nx", C.c_int * 5), ("anchors", C.c_float * 80), ("balance", C.c_float * 5),
+                ("hyp_box", C.c_float), ("hyp_obj", C.c_float), ("hyp_cls", C.c_float), ("cls_pw", C.c_float),
+                ("obj_pw", C.c_float), ("anchor_t", C.c_float), ("cp", C.c_float), ("cn", C.c_float)]
+
+
 EXPORTS = {
     # name: (restype, argtypes)
     "y5_version": (C.c_int, []),
@@ -48,6 +57,14 @@ EXPORTS = {
     "y5_nms_batched": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                  C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_size_t, C.c_void_p]),
+    "y5_loss_workspace_bytes": (C.c_size_t, [C.POINTER(LossDesc), C.c_int]),
+    "y5_loss_forward": (C.c_int, [C.POINTER(LossDesc), C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_size_t, C.c_void_p]),
+    "y5_loss_backward": (C.c_int, [C.POINTER(LossDesc), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.POINTER(C.c_void_p),
+                                   C.c_void_p, C.c_size_t, C.c_void_p]),
+    "y5_loss_targets_layout": (C.c_int, [C.POINTER(LossDesc), C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_longlong)]),
+    "y5_process_mask": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "y5_plan_create": (C.c_void_p, []),
     "y5_plan_destroy": (None, [C.c_void_p]),
     "y5_plan_add_conv": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -1,0 +1,149 @@
+// process_mask / crop_mask (utils/segment/general.py:10-51) for gfx950 as ONE kernel per image:
+//   masks = sigmoid(coef (n,c) @ proto (c, mh*mw)) -> zero outside box * (mw/iw, mh/ih) -> bilinear upsample to
+//   (ih, iw) (align_corners=False) -> > 0.5
+// One workgroup per (instance, 64x64 output tile).  The (TS+2)^2 low-resolution mask values the tile's bilinear taps
+// can touch are computed once into LDS (c-term dot product against the prototype planes, coalesced along x), then
+// every lane produces 4 consecutive output pixels and stores them as one vector.  The kernel is HBM-write bound:
+// n*ih*iw output bytes (uint8) or 4x that (float32, the reference's return type).
+#include <hip/hip_runtime.h>
+
+#include "../../include/yolov5_hip.h"
+#include "y5_common.h"
+#include "y5_host.h"
+
+struct MaskParams {
+  const void* protos;   // (c, mh, mw)
+  const float* coef;    // row i at coef + i*ld_m, c values
+  const float* boxes;   // row i at boxes + i*ld_b: x1,y1,x2,y2 in input-image pixels
+  void* out;            // (n, oh, ow)
+  int c, mh, mw, ld_m, ld_b, n, ih, iw, oh, ow, upsample;
+  float sx, sy;         // mw/iw, mh/ih as fp32 (general.py:43-46)
+  float rw, rh;         // source-per-destination scale of the bilinear resize = mw/ow, mh/oh
+};
+
+static constexpr int TILE = 64;      // output tile edge
+static constexpr int MAXSRC = 68;    // low-res window edge upper bound for LDS (tile 64 at scale 1 + 2)
+
+template <typename TP, typename TO>
+__global__ __launch_bounds__(256)
+void y5_process_mask_kernel(const MaskParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* s_m = reinterpret_cast<float*>(smem);                 // [wh][ww] cropped sigmoid masks
+  float* s_coef = s_m + MAXSRC * MAXSRC;                       // [c]
+  const int inst = blockIdx.y;
+  const int tiles_x = (p.ow + TILE - 1) / TILE;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int X0 = tx * TILE, Y0 = ty * TILE;
+  const int tid = threadIdx.x;
+  // low-resolution window covering the bilinear taps of output rows [Y0, Y0+TILE) / cols [X0, X0+TILE)
+  int wx0, wy0, ww, wh;
+  if (p.upsample) {
+    const float fx0 = fmaxf(p.rw * ((float)X0 + 0.5f) - 0.5f, 0.f), fy0 = fmaxf(p.rh * ((float)Y0 + 0.5f) - 0.5f, 0.f);
+    const int Xl = (X0 + TILE < p.ow ? X0 + TILE : p.ow) - 1, Yl = (Y0 + TILE < p.oh ? Y0 + TILE : p.oh) - 1;
+    const float fx1 = fmaxf(p.rw * ((float)Xl + 0.5f) - 0.5f, 0.f), fy1 = fmaxf(p.rh * ((float)Yl + 0.5f) - 0.5f, 0.f);
+    wx0 = (int)fx0; wy0 = (int)fy0;
+    int wx1 = (int)fx1 + 1, wy1 = (int)fy1 + 1;
+    wx1 = wx1 > p.mw - 1 ? p.mw - 1 : wx1;
+    wy1 = wy1 > p.mh - 1 ? p.mh - 1 : wy1;
+    ww = wx1 - wx0 + 1; wh = wy1 - wy0 + 1;
+  } else {
+    wx0 = X0; wy0 = Y0;
+    ww = p.mw - X0 < TILE ? p.mw - X0 : TILE;
+    wh = p.mh - Y0 < TILE ? p.mh - Y0 : TILE;
+  }
+  const float* bx = p.boxes + (long long)inst * p.ld_b;
+  const float x1 = bx[0] * p.sx, y1 = bx[1] * p.sy, x2 = bx[2] * p.sx, y2 = bx[3] * p.sy;  // general.py:42-46
+  for (int i = tid; i < p.c; i += 256) s_coef[i] = p.coef[(long long)inst * p.ld_m + i];
+  __syncthreads();
+  const TP* P = static_cast<const TP*>(p.protos);
+  const long long plane = (long long)p.mh * p.mw;
+  for (int i = tid; i < ww * wh; i += 256) {
+    const int ly = i / ww, lx = i - ly * ww;
+    const int gy = wy0 + ly, gx = wx0 + lx;
+    const float r = (float)gx, cc = (float)gy;
+    float v = 0.f;
+    if (r >= x1 && r < x2 && cc >= y1 && cc < y2) {  // crop_mask, general.py:22
+      float s = 0.f;
+      const TP* q = P + (long long)gy * p.mw + gx;
+      for (int k = 0; k < p.c; ++k) s += s_coef[k] * (float)q[k * plane];
+      v = 1.0f / (1.0f + expf(-s));
+    }
+    s_m[i] = v;
+  }
+  __syncthreads();
+  TO* out = static_cast<TO*>(p.out) + (long long)inst * p.oh * p.ow;
+  typedef TO TO4 __attribute__((ext_vector_type(4)));
+  const bool vec_ok = (p.ow & 3) == 0;
+  for (int i = tid; i < TILE * (TILE / 4); i += 256) {
+    const int oy = i / (TILE / 4), ox4 = (i - oy * (TILE / 4)) * 4;
+    const int Y = Y0 + oy, X = X0 + ox4;
+    if (Y >= p.oh || X >= p.ow) continue;
+    TO r4[4];
+    float hl1 = 0.f;
+    int h1 = Y - wy0, h1p = 0;
+    if (p.upsample) {  // upsample_bilinear2d, align_corners=False (F.interpolate, general.py:50)
+      const float h1r = fmaxf(p.rh * ((float)Y + 0.5f) - 0.5f, 0.f);
+      const int hh = (int)h1r;
+      h1p = hh < p.mh - 1 ? 1 : 0;
+      hl1 = h1r - (float)hh;
+      h1 = hh - wy0;
+    }
+    const float hl0 = 1.0f - hl1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int Xe = X + e;
+      float val = 0.f;
+      if (Xe < p.ow) {
+        if (p.upsample) {
+          const float w1r = fmaxf(p.rw * ((float)Xe + 0.5f) - 0.5f, 0.f);
+          const int w1i = (int)w1r;
+          const int w1p = w1i < p.mw - 1 ? 1 : 0;
+          const float wl1 = w1r - (float)w1i, wl0 = 1.0f - wl1;
+          const int w1 = w1i - wx0;
+          const float v00 = s_m[h1 * ww + w1], v01 = s_m[h1 * ww + w1 + w1p];
+          const float v10 = s_m[(h1 + h1p) * ww + w1], v11 = s_m[(h1 + h1p) * ww + w1 + w1p];
+          val = hl0 * (wl0 * v00 + wl1 * v01) + hl1 * (wl0 * v10 + wl1 * v11);
+        } else {
+          val = s_m[h1 * ww + (Xe - wx0)];
+        }
+      }
+      r4[e] = (TO)(val > 0.5f ? 1 : 0);  // general.py:51 gt_(0.5)
+    }
+    TO* d = out + (long long)Y * p.ow + X;
+    if (vec_ok && X + 3 < p.ow) {
+      TO4 v4; v4[0] = r4[0]; v4[1] = r4[1]; v4[2] = r4[2]; v4[3] = r4[3];
+      *reinterpret_cast<TO4*>(d) = v4;
+    } else {
+      for (int e = 0; e < 4 && X + e < p.ow; ++e) d[e] = r4[e];
+    }
+  }
+}
+
+extern "C" int y5_process_mask(const void* protos, int proto_dtype, int c, int mh, int mw, const float* masks_in, int ld_m,
+                               const float* boxes, int ld_b, int n, int ih, int iw, int upsample, void* out, int out_dtype,
+                               void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (n == 0) return Y5_OK;
+  if (!protos || !masks_in || !boxes || !out || n < 0 || c < 1 || c > 256 || mh < 1 || mw < 1 || ih < 1 || iw < 1 || ld_m < c || ld_b < 4)
+    return y5_fail(Y5_ERR_BAD_ARG, "process_mask: bad args");
+  if (proto_dtype != Y5_F16 && proto_dtype != Y5_F32) return y5_fail(Y5_ERR_BAD_ARG, "process_mask: protos must be f16 or f32");
+  if (out_dtype != Y5_F32 && out_dtype != Y5_U8) return y5_fail(Y5_ERR_BAD_ARG, "process_mask: out dtype must be Y5_F32 or Y5_U8");
+  MaskParams p{};
+  p.protos = protos; p.coef = masks_in; p.boxes = boxes; p.out = out;
+  p.c = c; p.mh = mh; p.mw = mw; p.ld_m = ld_m; p.ld_b = ld_b; p.n = n; p.ih = ih; p.iw = iw; p.upsample = upsample ? 1 : 0;
+  p.oh = upsample ? ih : mh; p.ow = upsample ? iw : mw;
+  p.sx = (float)((double)mw / (double)iw); p.sy = (float)((double)mh / (double)ih);
+  p.rw = (float)mw / (float)p.ow; p.rh = (float)mh / (float)p.oh;
+  if (upsample && (p.rw > 1.0f || p.rh > 1.0f)) return y5_fail(Y5_ERR_UNSUPPORTED, "process_mask: only upsampling (ih >= mh, iw >= mw) is supported");
+  const int tiles = ((p.ow + TILE - 1) / TILE) * ((p.oh + TILE - 1) / TILE);
+  const dim3 grid((unsigned)tiles, (unsigned)n), block(256);
+  const size_t lds = (size_t)(MAXSRC * MAXSRC + 256) * 4;
+  if (proto_dtype == Y5_F16) {
+    if (out_dtype == Y5_F32) hipLaunchKernelGGL((y5_process_mask_kernel<half_t, float>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((y5_process_mask_kernel<half_t, unsigned char>), grid, block, lds, st, p);
+  } else {
+    if (out_dtype == Y5_F32) hipLaunchKernelGGL((y5_process_mask_kernel<float, float>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((y5_process_mask_kernel<float, unsigned char>), grid, block, lds, st, p);
+  }
+  return y5_check_launch("y5_process_mask");
+}
