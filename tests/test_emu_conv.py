@@ -27,6 +27,15 @@ CASES = [
     (3, 13, 11, 32, 96, 3, 1, 1, 1, True, True, 0, 2, "f16"),      # 4 M-tiles x 3 N-tiles of 128x32 on 2 blocks
     (2, 16, 16, 64, 64, 1, 1, 0, 1, False, False, 7, 3, "f16"),    # nk = 1: every iteration is a new tile
     (2, 12, 12, 32, 64, 3, 2, 1, 1, False, False, 1, 1, "f32"),    # single block walks all tiles
+    # streaming pointwise kernel (conv_pw.h): ring fill / steady state / drain, partial last workgroup tile, upsampled store
+    (7, 8, 16, 32, 32, 1, 1, 0, 1, False, False, 14, 1, "f16"),    # 32->32, 7 tiles per wave on one workgroup, S=4
+    (7, 8, 16, 64, 32, 1, 1, 0, 1, False, False, 15, 1, "f16"),
+    (7, 8, 16, 64, 64, 1, 1, 0, 1, False, False, 16, 1, "f16"),
+    (5, 4, 8, 64, 64, 1, 1, 0, 1, False, True, 17, 2, "f16"),      # 5 wave tiles: partial workgroup tile + up2
+    (5, 8, 16, 128, 64, 1, 1, 0, 1, False, False, 18, 1, "f16"),
+    (5, 8, 16, 128, 128, 1, 1, 0, 1, False, True, 19, 1, "f16"),
+    (3, 8, 16, 128, 120, 1, 1, 0, 1, False, False, 20, 2, "f16"),  # C2 not a multiple of 32 (Npad 128)
+    (6, 8, 16, 128, 64, 1, 1, 0, 1, False, False, 21, 1, "f16"),
 ] + [
     # every fp16 tile configuration on one shape with M, N tails and K = 9*64 (uniform) / 9*48 (table for BK64)
     (2, 9, 9, c1, 160, 3, 1, 1, 1, True, False, cfg, 2, "f16") for cfg in range(14) for c1 in (64, 48)

@@ -3,13 +3,15 @@
 
 #include "../../include/yolov5_hip.h"
 #include "conv_igemm.h"
+#include "conv_pw.h"
 #include "y5_host.h"
 
 namespace {
 
 struct TileCfg { int wm, wn, tm, tn, rb; };
 // id -> workgroup tile (BM = wm*tm*32 pixels, BN = wn*tn*32 channels), LDS row bytes (K per stage = rb / elemsize)
-constexpr TileCfg kCfgs[Y5_CONV_NUM_CFGS] = {
+constexpr int kNumIgemm = 14;
+constexpr TileCfg kCfgs[kNumIgemm] = {
     {4, 1, 1, 1, 64},   //  0: 128 x  32, BK32
     {4, 1, 1, 2, 64},   //  1: 128 x  64, BK32
     {2, 2, 2, 2, 64},   //  2: 128 x 128, BK32
@@ -103,6 +105,66 @@ int launch_by_cfg(const Y5ConvParams& p, int cfg, int mb, hipStream_t s) {
   }
 }
 
+// ---- streaming pointwise configurations (conv_pw.h): id = kNumIgemm + index ---------------------------------
+struct PwCfg { int kc, rb, nt, s; };
+constexpr int kNumPw = Y5_CONV_NUM_CFGS - kNumIgemm;
+constexpr PwCfg kPwCfgs[kNumPw] = {
+    {1, 64, 1, 4},   // 14:  32 ->  32, 4 stages
+    {1, 128, 1, 4},  // 15:  64 ->  32
+    {1, 128, 2, 4},  // 16:  64 ->  64
+    {1, 128, 2, 3},  // 17:  64 ->  64, 3 stages
+    {2, 128, 2, 3},  // 18: 128 ->  64
+    {2, 128, 4, 3},  // 19: 128 -> 128
+    {2, 128, 4, 2},  // 20: 128 -> 128, 2 stages
+    {2, 128, 2, 4},  // 21: 128 ->  64, 4 stages
+};
+
+template <int KC, int RB, int NT, int S>
+int launch_pw(const Y5ConvParams& p, int max_blocks, hipStream_t stream) {
+  const size_t lds = y5_conv_pw_lds_bytes<KC, RB, NT, S>();
+  if (lds > 160 * 1024) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: pointwise configuration exceeds 160 KiB of LDS");
+  const void* kern = p.y2 ? reinterpret_cast<const void*>(y5_conv_pw_kernel<KC, RB, NT, S, true>)
+                          : reinterpret_cast<const void*>(y5_conv_pw_kernel<KC, RB, NT, S, false>);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(y5_conv_pw_kernel<KC, RB, NT, S, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(y5_conv_pw_kernel<KC, RB, NT, S, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const long long nbt = ((long long)(p.M >> 5) + 3) >> 2;
+  long long G = max_blocks;
+  if (G <= 0) {
+    if (!g_num_cu) {
+      int dev = 0, n = 0;
+      hipGetDevice(&dev);
+      hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+      g_num_cu = n > 0 ? n : 256;
+    }
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, lds) != hipSuccess || occ < 1) occ = 1;
+    G = (long long)g_num_cu * occ;
+  }
+  if (G > nbt) G = nbt;
+  if (G >= 8) G &= ~7LL;
+  if (p.y2) hipLaunchKernelGGL((y5_conv_pw_kernel<KC, RB, NT, S, true>), dim3((unsigned)G), dim3(256), lds, stream, p);
+  else hipLaunchKernelGGL((y5_conv_pw_kernel<KC, RB, NT, S, false>), dim3((unsigned)G), dim3(256), lds, stream, p);
+  return y5_check_launch("y5_conv2d_fwd(pw)");
+}
+
+int launch_pw_by_cfg(const Y5ConvParams& p, int idx, int mb, hipStream_t s) {
+  switch (idx) {
+    case 0: return launch_pw<1, 64, 1, 4>(p, mb, s);
+    case 1: return launch_pw<1, 128, 1, 4>(p, mb, s);
+    case 2: return launch_pw<1, 128, 2, 4>(p, mb, s);
+    case 3: return launch_pw<1, 128, 2, 3>(p, mb, s);
+    case 4: return launch_pw<2, 128, 2, 3>(p, mb, s);
+    case 5: return launch_pw<2, 128, 4, 3>(p, mb, s);
+    case 6: return launch_pw<2, 128, 4, 2>(p, mb, s);
+    case 7: return launch_pw<2, 128, 2, 4>(p, mb, s);
+  }
+  return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown pointwise config");
+}
+
 int default_cfg(const y5_conv_desc* d) {
   const int n = d->Npad;
   if (d->dtype == Y5_F32) return n <= 32 ? 0 : n <= 64 ? 1 : 2;
@@ -118,6 +180,13 @@ extern "C" int y5_conv_num_cfgs(void) { return Y5_CONV_NUM_CFGS; }
 
 extern "C" int y5_conv_cfg_info(int cfg, int* bm, int* bn, int* bk_bytes) {
   if (cfg < 0 || cfg >= Y5_CONV_NUM_CFGS) return y5_fail(Y5_ERR_BAD_ARG, "conv_cfg_info: bad id");
+  if (cfg >= kNumIgemm) {
+    const PwCfg& c = kPwCfgs[cfg - kNumIgemm];
+    if (bm) *bm = 128;
+    if (bn) *bn = c.nt * 32;
+    if (bk_bytes) *bk_bytes = c.kc * c.rb;
+    return Y5_OK;
+  }
   if (bm) *bm = kCfgs[cfg].wm * kCfgs[cfg].tm * 32;
   if (bn) *bn = kCfgs[cfg].wn * kCfgs[cfg].tn * 32;
   if (bk_bytes) *bk_bytes = kCfgs[cfg].rb;
@@ -133,7 +202,8 @@ extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w
   const int epp = 16 / es;
   int cfg = d->cfg < 0 ? default_cfg(d) : d->cfg;
   if (cfg >= Y5_CONV_NUM_CFGS) return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown tile config");
-  const int bk = kCfgs[cfg].rb / es;
+  const bool pw = cfg >= kNumIgemm;
+  const int bk = pw ? 8 : kCfgs[cfg].rb / es;
   if (d->C1 % epp || d->ldx % epp) return y5_fail(Y5_ERR_BAD_ARG, "conv: C1 and ldx must be multiples of 16 bytes");
   if (d->C2 % epp || (y && d->ldy % epp) || (residual && d->ldr % epp) || (y_up2 && d->ld2 % epp))
     return y5_fail(Y5_ERR_BAD_ARG, "conv: C2/ldy/ldr/ld2 must be multiples of 16 bytes");
@@ -157,6 +227,13 @@ extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w
   p.ldr = d->ldr; p.ld2 = d->ld2;
   p.M = d->B * oh * ow;
 
+  if (pw) {
+    const PwCfg& c = kPwCfgs[cfg - kNumIgemm];
+    if (d->dtype != Y5_F16 || d->KH != 1 || d->KW != 1 || d->SH != 1 || d->SW != 1 || d->PH || d->PW || residual || !y || d->act != 1 ||
+        d->C1 != c.kc * c.rb / 2 || d->Npad != c.nt * 32 || (p.M & 31) || d->Kpad * 2 < c.kc * c.rb)
+      return y5_fail(Y5_ERR_UNSUPPORTED, "conv: pointwise configuration does not match this layer");
+    return launch_pw_by_cfg(p, cfg - kNumIgemm, d->max_blocks, stream);
+  }
   const bool table = (d->C1 % bk) != 0;
   if (d->dtype == Y5_F16)
     return table ? launch_by_cfg<half_t, true>(p, cfg, d->max_blocks, stream) : launch_by_cfg<half_t, false>(p, cfg, d->max_blocks, stream);

@@ -1,0 +1,191 @@
+// Pointwise (1x1, stride 1) convolution for the HBM-bound high-resolution layers of the YOLOv5 graph
+// (C3 cv1+cv2 / cv3 / Bottleneck.cv1 at P1..P3: AI 16..100 flop/B, far below the MFMA ridge).  Same math and the same
+// operand layouts as conv_igemm.h (D[n][m] = sum_k W[n][k] * A[m][k], mfma_f32_32x32x16_f16, XOR-swizzled LDS rows
+// filled by LDS-DMA), but organised as a STREAMING kernel:
+//   * the whole filter [Npad][K] and the bias live in LDS for the lifetime of the persistent workgroup;
+//   * every wave owns a private ring of S stages, one stage = 32 consecutive pixels x K channels, filled by its own
+//     global_load_lds instructions and retired with COUNTED s_waitcnt vmcnt(N) -- the queue is never drained in steady
+//     state, S-1 tiles of loads plus the previous tiles' stores stay in flight per wave;
+//   * waves never synchronise with each other after the prologue (no s_barrier in the loop);
+//   * the epilogue (bias + SiLU) is transposed through the stage buffer the tile just vacated and leaves as full-row
+//     16-byte stores (plus the optional 2x nearest-upsampled replica of nn.Upsample, yolov5s.yaml:36,41).
+// vmcnt bookkeeping (gfx9 family: loads and stores retire in issue order on one counter): with LP loads and SP stores
+// per tile, the operations issued after tile i's loads are (S-1) x (LP + SP) in steady state and (S-1) x LP + i x SP
+// while the ring is filling; when fewer than S-1 tiles remain the wave drains completely.
+#pragma once
+#include "conv_igemm.h"
+
+constexpr int y5_waitcnt_vm(int n) {  // s_waitcnt immediate: vmcnt(n), expcnt/lgkmcnt untouched (gfx9 encoding)
+  return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8);
+}
+template <int N> __device__ __forceinline__ void y5_wait_vm() {
+  __builtin_amdgcn_s_waitcnt(y5_waitcnt_vm(N < 63 ? N : 63));
+  asm volatile("" ::: "memory");
+}
+
+template <int KC, int RB, int NT, int S>
+constexpr size_t y5_conv_pw_lds_bytes() {
+  constexpr int NPAD = 32 * NT;
+  constexpr int STAGE_A = 32 * KC * RB, STAGE_O = 32 * NPAD * 2;
+  constexpr int STAGE = STAGE_A > STAGE_O ? STAGE_A : STAGE_O;
+  return (size_t)KC * NPAD * RB + (size_t)NPAD * 4 + (size_t)4 * S * STAGE;
+}
+
+template <int KC, int RB, int NT, int S, bool UP2>
+__global__ __launch_bounds__(256)
+void y5_conv_pw_kernel(const Y5ConvParams p) {
+  typedef half_t T;
+  constexpr int NPAD = 32 * NT;
+  constexpr int NSLOT = RB / 16;          // 16-byte slots per LDS row of a K chunk
+  constexpr int RPI = 1024 / RB;          // rows per LDS-DMA instruction
+  constexpr int QN = 32 / RPI;            // instructions per chunk of a 32-row tile
+  constexpr int STAGE_A = 32 * KC * RB, STAGE_O = 32 * NPAD * 2;
+  constexpr int STAGE = STAGE_A > STAGE_O ? STAGE_A : STAGE_O;
+  constexpr int W_BYTES = KC * NPAD * RB;
+  constexpr int LP = KC * QN;                               // loads per tile per wave
+  constexpr int SPR = NPAD / 8;                             // 16-byte slots per output row
+  constexpr int RPP = 64 / SPR;                             // output rows per store pass
+  constexpr int NPASS = 32 / RPP;
+  constexpr int SP = NPASS * (UP2 ? 5 : 1);                 // stores per tile per wave
+  constexpr int SWM = SPR >= 8 ? 7 : SPR - 1;               // scratch swizzle mask
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* wlds = smem;
+  float* blds = reinterpret_cast<float*>(smem + W_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* ring = smem + W_BYTES + NPAD * 4 + wave * (S * STAGE);
+
+  const T* __restrict__ xg = static_cast<const T*>(p.x);
+  const T* __restrict__ wg = static_cast<const T*>(p.w);
+  T* __restrict__ yg = static_cast<T*>(p.y);
+  T* __restrict__ y2g = static_cast<T*>(p.y2);
+
+  const int lrow = lane / NSLOT, lslot = lane % NSLOT;
+  // ---- prologue: filter + bias into LDS (all waves), once per workgroup -------------------------------
+  {
+    constexpr int WI = NPAD * RB / 1024;  // LDS-DMA instructions per filter chunk
+    for (int kc = 0; kc < KC; ++kc)
+      for (int idx = wave; idx < WI; idx += 4) {
+        const int row = idx * RPI + lrow;
+        const int sslot = lslot ^ Y5ConvGeom<T, RB>::swz(row);
+        y5_glds16(reinterpret_cast<const char*>(wg + (size_t)row * p.Kpad) + kc * RB + sslot * 16, wlds + kc * NPAD * RB + idx * 1024);
+      }
+    for (int i = tid; i < NPAD; i += 256) blds[i] = p.bias[i];
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+  }
+
+  // ---- tile schedule: workgroup tiles of 128 pixels, wave w takes rows [32w, 32w+32) --------------------
+  const int G = gridDim.x, bid = blockIdx.x;
+  const int nwt = p.M >> 5;                 // 32-pixel wave tiles (host guarantees M % 32 == 0)
+  const int nbt = (nwt + 3) >> 2;
+  const int nmine = (nbt - bid + G - 1) / G;
+  auto tile_m0 = [&](int j) { return (y5_xcd_remap(bid + j * G, nbt) * 4 + wave) * 32; };
+  int nw = nmine;                           // this wave's tile count (the last workgroup tile may be partial)
+  if (nw > 0 && tile_m0(nw - 1) >= p.M) --nw;
+
+  int aoff[QN];                             // per-lane byte offset of its 16-byte piece inside a tile, per instruction
+#pragma unroll
+  for (int q = 0; q < QN; ++q) {
+    const int row = q * RPI + lrow;
+    aoff[q] = row * p.ldx * (int)sizeof(T) + (lslot ^ Y5ConvGeom<T, RB>::swz(row)) * 16;
+  }
+  auto issue = [&](int j, int buf) {
+    const char* src = reinterpret_cast<const char*>(xg + (size_t)tile_m0(j) * p.ldx);
+    char* dst = ring + buf * STAGE;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+      for (int q = 0; q < QN; ++q) y5_glds16(src + aoff[q] + kc * RB, dst + kc * 32 * RB + q * 1024);
+  };
+
+  const int g = lane >> 5, frow = lane & 31;
+  const int fsw = Y5ConvGeom<T, RB>::swz(frow);
+  const int orow = lane / SPR, oslot = lane % SPR;
+
+  for (int s = 0; s < S; ++s)
+    if (s < nw) issue(s, s);
+
+  int buf = 0;
+  for (int i = 0; i < nw; ++i) {
+    // ---- retire tile i's loads ----
+    if (i + S - 1 >= nw) {
+      y5_wait_vm<0>();
+    } else if (i < S - 1) {
+      switch (i) {
+        case 0: y5_wait_vm<(S - 1) * LP>(); break;
+        case 1: y5_wait_vm<(S - 1) * LP + SP>(); break;
+        case 2: y5_wait_vm<(S - 1) * LP + 2 * SP>(); break;
+        default: y5_wait_vm<(S - 1) * LP>(); break;
+      }
+    } else {
+      y5_wait_vm<(S - 1) * (LP + SP)>();
+    }
+    __builtin_amdgcn_wave_barrier();  // (lock-step on hardware; orders the lanes of the host emulator)
+    char* st = ring + buf * STAGE;
+    // ---- MFMA ----
+    float16_t acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+      for (int ks = 0; ks < RB / 32; ++ks) {
+        const int so = ((ks * 2 + g) ^ fsw) * 16;
+        const half8_t af = *reinterpret_cast<const half8_t*>(st + kc * 32 * RB + frow * RB + so);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const half8_t wf = *reinterpret_cast<const half8_t*>(wlds + kc * NPAD * RB + (j * 32 + frow) * RB + so);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, af, acc[j], 0, 0, 0);
+        }
+      }
+    // ---- epilogue: bias + act -> scratch (the vacated stage) -> full-row stores ----
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4_t bv = *reinterpret_cast<const float4_t*>(blds + j * 32 + q * 8 + g * 4);
+        half4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = acc[j][q * 4 + e] + bv[e];
+          o[e] = (half_t)y5_silu(t);  // the host only routes act == SiLU layers here
+        }
+        const int slot = j * 4 + q;
+        *reinterpret_cast<half4_t*>(st + frow * (NPAD * 2) + ((slot ^ (frow & SWM)) * 16) + g * 8) = o;
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // lanes exchange data through the scratch: keep LDS writes before the reads
+    const int m0 = tile_m0(i);
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int row = ps * RPP + orow;
+      const uint4_t raw = *reinterpret_cast<const uint4_t*>(st + row * (NPAD * 2) + ((oslot ^ (row & SWM)) * 16));
+      const int m = m0 + row, n = oslot * 8;
+      if (n < p.C2) {
+        *reinterpret_cast<uint4_t*>(yg + (size_t)m * p.ldy + n) = raw;
+        if constexpr (UP2) {
+          const int ohw = p.OH * p.OW;
+          const int b = m / ohw;
+          const int r = m - b * ohw;
+          const int oh = r / p.OW, ow = r - oh * p.OW;
+          const size_t row0 = ((size_t)b * 2 * p.OH + 2 * oh) * (2 * p.OW) + 2 * ow;
+          T* d0 = y2g + row0 * p.ld2 + n;
+          T* d1 = y2g + (row0 + 2 * p.OW) * p.ld2 + n;
+          *reinterpret_cast<uint4_t*>(d0) = raw;
+          *reinterpret_cast<uint4_t*>(d0 + p.ld2) = raw;
+          *reinterpret_cast<uint4_t*>(d1) = raw;
+          *reinterpret_cast<uint4_t*>(d1 + p.ld2) = raw;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- refill the vacated stage with tile i+S ----
+    if (i + S < nw) issue(i + S, buf);
+    buf = buf + 1 == S ? 0 : buf + 1;
+  }
+}
