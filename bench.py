@@ -184,15 +184,23 @@ def main():
     nms_ms = (time.perf_counter() - t_n0) / 10 * 1e3
     ops = eng.time_ops(iters=10)
     fl = dict(conv_flops(eng))
-    conv_ms = sum(ms for (i, (name, ms)) in enumerate(ops, start=1) if i in fl)
-    conv_fl = sum(fl.values())
-    other_ms = sum(ms for (i, (name, ms)) in enumerate(ops, start=1) if i not in fl)
+    if eng._stem is not None:
+        fl[eng._stem] = fl[1]  # the fused NCHW stem op computes spec op 1 (0.Conv)
+    timed = list(zip(eng.timed_order, ops))  # (plan index, (name, ms)) in execution order
+    conv_ms = sum(ms for i, (name, ms) in timed if i in fl)
+    conv_fl = sum(fl[i] for i, _ in timed if i in fl)
+    other_ms = sum(ms for i, (name, ms) in timed if i not in fl)
     achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    nconv = sum(1 for i, _ in timed if i in fl)
     if a.op_table and rank == 0:
-        cfgs = iter(eng.conv_cfgs)
-        table = [{"op": name, "cfg": next(cfgs) if i in fl else None, "ms": round(ms, 5), "gflop": round(fl.get(i, 0) / 1e9, 3),
+        cfg_of = {}
+        ci = iter(eng.conv_cfgs)
+        for i, op in enumerate(eng.spec.ops):
+            if op["op"] == "conv":
+                cfg_of[i] = next(ci)
+        table = [{"op": name, "cfg": cfg_of.get(i), "ms": round(ms, 5), "gflop": round(fl.get(i, 0) / 1e9, 3),
                   "tflops": round(fl.get(i, 0) / (ms * 1e-3) / 1e12, 1) if ms > 0 and i in fl else None}
-                 for i, (name, ms) in enumerate(ops, start=1)]
+                 for i, (name, ms) in timed]
         with open(a.op_table, "w") as f:
             json.dump(table, f, indent=1)
 
@@ -207,11 +215,11 @@ def main():
                        "global_batch": a.batch * world, "parallelism": f"replicas x{world} (images independent, no collective)"},
             "forward_ms": round(fwd_ms, 4), "nms_ms": round(nms_ms, 4), "nms_us_per_img": round(nms_ms * 1e3 / a.batch, 2),
             "forward_images_per_sec": round(a.batch / (fwd_ms * 1e-3), 1), "detections_per_img": round(ncand, 1),
-            "roofline": {"bound": "mfma", "kernel": "y5_conv_igemm_kernel (all conv launches of one forward)",
+            "roofline": {"bound": "mfma", "kernel": "y5_conv_{igemm,pw,stem}_kernel (all conv launches of one forward)",
                          "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
                          "algorithmic_gflop_per_step": round(conv_fl / 1e9, 1), "conv_ms_per_step": round(conv_ms, 4),
-                         "launches_per_step": len(fl), "other_kernels_ms_per_step": round(other_ms, 4)},
+                         "launches_per_step": nconv, "other_kernels_ms_per_step": round(other_ms, 4)},
         }
         if not a.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline()

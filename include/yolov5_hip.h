@@ -64,6 +64,16 @@ int y5_conv2d_time(const y5_conv_desc* d, const void* x, const void* w_packed, c
                    const void* residual, void* y, void* y_up2, int iters, void* stream, float* ms);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * y5_conv_stem_fwd -- the backbone's first layer (models/yolov5s.yaml:17 `Conv [64, 6, 2, 2]`, common.py:74-92,
+ * BN folded + SiLU) computed DIRECTLY from the caller's NCHW fp16 batch (train.py:379 / detect.py:206-210 input
+ * contract): x (B, 3, H, W) fp16 contiguous -> y NHWC (B, H/2, W/2, C2) fp16 with pixel stride ldy.
+ * w_stem: [Npad][144] fp16, k = (c*6 + kh)*8 + kw with the kw = 6,7 taps zero; bias fp32 [Npad]; Npad = 32 or 64.
+ * Requires even H and W % 64 == 0 (else Y5_ERR_UNSUPPORTED: use y5_nchw_to_nhwc + y5_conv2d_fwd).
+ * ------------------------------------------------------------------------------------------------------- */
+int y5_conv_stem_fwd(const void* x_nchw, int B, int H, int W, const void* w_stem, const float* bias, int C2, int Npad,
+                     void* y, int ldy, int max_blocks, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * y5_nchw_to_nhwc -- input contract (train.py:379, val.py:259-262, detect.py:206-210, common.py:926):
  * NCHW {u8|f16|f32} -> NHWC {f16|f32} with channel padding to `ld` (pad channels written as 0) and a scale
  * (1/255 for u8 images, 1 for already-normalised floats).
@@ -166,6 +176,9 @@ y5_plan* y5_plan_create(void);
 void y5_plan_destroy(y5_plan*);
 int y5_plan_add_conv(y5_plan*, const y5_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                      const void* residual, void* y, void* y_up2);
+int y5_plan_add_conv_stem(y5_plan*, const void* x_nchw, int B, int H, int W, const void* w_stem, const float* bias, int C2,
+                          int Npad, void* y, int ldy);
+int y5_plan_set_input(y5_plan*, int op_index, const void* src);  /* re-point a stem / nchw_to_nhwc op at a new input batch */
 int y5_plan_add_nchw_to_nhwc(y5_plan*, const void* src, int src_dtype, void* dst, int dst_dtype, int B, int C, int H,
                              int W, int ld, float scale);
 int y5_plan_add_sppf_pool(y5_plan*, void* buf, int dtype, int B, int H, int W, int C, int ld, int k);

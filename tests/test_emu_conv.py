@@ -124,3 +124,25 @@ def test_conv_rejects_bad_args():
     a = aligned((64,), np.float16)
     assert lib.y5_conv2d_fwd(C.byref(d), ptr(a), ptr(a), ptr(a), None, ptr(a), None, None) == -1
     assert b"16 bytes" in lib.y5_last_error()
+
+
+@pytest.mark.parametrize("B,H,W,C2,max_blocks", [(1, 8, 64, 32, 1), (2, 12, 128, 16, 2), (1, 6, 64, 48, 1), (3, 4, 64, 64, 1)])
+def test_conv_stem_direct_nchw(B, H, W, C2, max_blocks):
+    """y5_conv_stem_fwd (conv_stem.h): k6 s2 p2 straight from the NCHW batch, all four borders, Npad 32 and 64."""
+    from yolov5_amd.packing import pack_stem_weight
+
+    lib = emu()
+    x = torch.from_numpy(detgen.uniform((B, 3, H, W), 0, 1, name="xs")).half()
+    w = torch.from_numpy(detgen.uniform((C2, 3, 6, 6), -0.3, 0.3, name="ws")).half().float()
+    b = torch.from_numpy(detgen.uniform((C2,), -0.5, 0.5, name="bs"))
+    wp, bp, npad = pack_stem_weight(w, b)
+    xa = aligned(x.shape, np.float16); xa[...] = x.numpy()
+    wa = aligned(wp.shape, np.float16); wa[...] = wp.numpy()
+    ba = aligned(bp.shape, np.float32); ba[...] = bp.numpy()
+    ldy = C2 + 8
+    y = aligned((B, H // 2, W // 2, ldy), np.float16, -3.0)
+    rc = lib.y5_conv_stem_fwd(ptr(xa), B, H, W, ptr(wa), ptr(ba), C2, npad, ptr(y), ldy, max_blocks, None)
+    assert rc == 0, lib.y5_last_error()
+    ref = F.silu(F.conv2d(x.float(), w, b, 2, 2)).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(y[..., :C2].astype(np.float32), ref, rtol=2e-2, atol=2e-2)
+    assert np.all(y[..., C2:] == -3.0)

@@ -45,6 +45,7 @@ def test_yolov5n_fp16_close_to_reference():
     x = torch.from_numpy(detgen.uniform((2, 3, 64, 64), 0.0, 1.0, name="img", seed=0)).half()
     eng = Engine(m, (2, 3, 64, 64), torch.float16, "cpu", want_raw=False, backend=EmuBackend())
     z = eng(x)["z"].astype(np.float32)
+    assert eng._stem is not None and eng._stem_active  # fp16 NCHW batch -> fused stem kernel (conv_stem.h), no repack pass
     ref = g["z_fused"]
     # check_amp-style tolerance (utils/general.py:410-435 uses atol=0.1 on boxes) -- fp16 storage between layers
     assert np.abs(z - ref).max() < 0.5

@@ -40,6 +40,8 @@ EXPORTS = {
                                 C.c_void_p, C.c_void_p]),
     "y5_conv2d_time": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
+    "y5_conv_stem_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                   C.c_int, C.c_int, C.c_void_p]),
     "y5_conv_num_cfgs": (C.c_int, []),
     "y5_conv_cfg_info": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "y5_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -69,6 +71,9 @@ EXPORTS = {
     "y5_plan_destroy": (None, [C.c_void_p]),
     "y5_plan_add_conv": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
+    "y5_plan_add_conv_stem": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_int]),
+    "y5_plan_set_input": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "y5_plan_add_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.c_int, C.c_int, C.c_float]),
     "y5_plan_add_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,

@@ -4,6 +4,7 @@
 #include "../../include/yolov5_hip.h"
 #include "conv_igemm.h"
 #include "conv_pw.h"
+#include "conv_stem.h"
 #include "y5_host.h"
 
 namespace {
@@ -256,4 +257,53 @@ extern "C" int y5_conv2d_time(const y5_conv_desc* d, const void* x, const void* 
   hipEventDestroy(e0);
   hipEventDestroy(e1);
   return rc;
+}
+
+// ---- stem (conv_stem.h) -----------------------------------------------------------------------------------
+namespace {
+template <int NT, int S>
+int launch_stem(const Y5StemParams& p, int max_blocks, hipStream_t stream) {
+  const size_t lds = y5_conv_stem_lds_bytes<NT, S>();
+  auto kern = y5_conv_stem_kernel<NT, S>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const long long nbt = ((long long)p.nwt + 3) >> 2;
+  long long G = max_blocks;
+  if (G <= 0) {
+    if (!g_num_cu) {
+      int dev = 0, n = 0;
+      hipGetDevice(&dev);
+      hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+      g_num_cu = n > 0 ? n : 256;
+    }
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), 256, lds) != hipSuccess || occ < 1) occ = 1;
+    G = (long long)g_num_cu * occ;
+  }
+  if (G > nbt) G = nbt;
+  if (G >= 8) G &= ~7LL;
+  hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(256), lds, stream, p);
+  return y5_check_launch("y5_conv_stem_fwd");
+}
+}  // namespace
+
+extern "C" int y5_conv_stem_fwd(const void* x_nchw, int B, int H, int W, const void* w_stem, const float* bias, int C2, int Npad,
+                                void* y, int ldy, int max_blocks, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (!x_nchw || !w_stem || !bias || !y) return y5_fail(Y5_ERR_BAD_ARG, "conv_stem: null pointer");
+  if (B < 1 || H < 2 || (H & 1) || W < 64 || (W & 63)) return y5_fail(Y5_ERR_UNSUPPORTED, "conv_stem: needs even H and W % 64 == 0");
+  if (C2 < 8 || (C2 & 7) || C2 > Npad || (Npad != 32 && Npad != 64) || (ldy & 7) || ldy < C2)
+    return y5_fail(Y5_ERR_UNSUPPORTED, "conv_stem: C2 must be a multiple of 8, <= 64 (Npad 32 or 64)");
+  if (((uintptr_t)x_nchw | (uintptr_t)w_stem | (uintptr_t)bias | (uintptr_t)y) & 15) return y5_fail(Y5_ERR_BAD_ARG, "conv_stem: pointers must be 16-byte aligned");
+  if ((long long)B * 3 * H * W >= 0x3fffffffLL) return y5_fail(Y5_ERR_UNSUPPORTED, "conv_stem: input exceeds 2^30 elements");
+  Y5StemParams p{};
+  p.x = x_nchw; p.w = w_stem; p.bias = bias; p.y = y; p.zero = y5_zero_page();
+  if (!p.zero) return y5_fail(Y5_ERR_RUNTIME, "conv_stem: zero page allocation failed");
+  p.B = B; p.H = H; p.W = W; p.OH = H / 2; p.OW = W / 2; p.C2 = C2; p.ldy = ldy;
+  p.tiles_per_row = p.OW / 32;
+  p.nwt = B * p.OH * p.tiles_per_row;
+  return Npad == 32 ? launch_stem<1, 4>(p, max_blocks, stream) : launch_stem<2, 3>(p, max_blocks, stream);
 }

@@ -48,7 +48,7 @@ extern "C" const char* y5_last_error(void) { return g_err.c_str(); }
 // ---------------------------------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------------------------------
-enum OpKind { OP_CONV, OP_TO_NHWC, OP_SPPF, OP_UPS, OP_COPY, OP_DECODE, OP_TO_NCHW };
+enum OpKind { OP_CONV, OP_TO_NHWC, OP_SPPF, OP_UPS, OP_COPY, OP_DECODE, OP_TO_NCHW, OP_STEM };
 
 struct Op {
   OpKind kind;
@@ -130,8 +130,24 @@ extern "C" int y5_plan_add_detect_decode(y5_plan* pl, const void* logits, int dt
   return Y5_OK;
 }
 
+extern "C" int y5_plan_add_conv_stem(y5_plan* pl, const void* x_nchw, int B, int H, int W, const void* w_stem, const float* bias,
+                                     int C2, int Npad, void* y, int ldy) {
+  if (!pl) return y5_fail(Y5_ERR_BAD_ARG, "plan: null");
+  Op o{}; o.kind = OP_STEM; o.p0 = x_nchw; o.p1 = w_stem; o.p2 = bias; o.q0 = y;
+  o.i[0] = B; o.i[1] = H; o.i[2] = W; o.i[3] = C2; o.i[4] = Npad; o.i[5] = ldy;
+  pl->ops.push_back(o);
+  return Y5_OK;
+}
+extern "C" int y5_plan_set_input(y5_plan* pl, int op, const void* src) {
+  if (!pl || op < 0 || op >= (int)pl->ops.size()) return y5_fail(Y5_ERR_BAD_ARG, "plan_set_input: bad op index");
+  if (pl->ops[op].kind != OP_STEM && pl->ops[op].kind != OP_TO_NHWC) return y5_fail(Y5_ERR_BAD_ARG, "plan_set_input: op does not read the model input");
+  pl->ops[op].p0 = src;
+  return Y5_OK;
+}
+
 static int run_op(const Op& o, void* st) {
   switch (o.kind) {
+    case OP_STEM: return y5_conv_stem_fwd(o.p0, o.i[0], o.i[1], o.i[2], o.p1, (const float*)o.p2, o.i[3], o.i[4], o.q0, o.i[5], 0, st);
     case OP_CONV: return y5_conv2d_fwd(&o.conv, o.p0, o.p1, (const float*)o.p2, o.p3, o.q0, o.q1, st);
     case OP_TO_NHWC: return y5_nchw_to_nhwc(o.p0, o.i[0], o.q0, o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], o.i[6], o.f[0], st);
     case OP_TO_NCHW: return y5_nhwc_to_nchw(o.p0, o.i[0], o.q0, o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], st);

@@ -24,7 +24,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from .packing import fuse_conv_bn_weights, pack_conv_weight
+from .packing import fuse_conv_bn_weights, pack_conv_weight, pack_stem_weight
 
 
 @dataclass
@@ -358,9 +358,17 @@ class Engine:
         self.op_names = []
         self.conv_cfgs = []
         self._first_op = None
+        self._stem = None      # plan index of the fused NCHW stem op (conv_stem.h), appended after the regular ops
+        self._stem_args = None
         with torch.no_grad():
             for op in self.spec.ops:
                 self._add(op)
+            if self._stem_args is not None:
+                wp, bp, c2, npad, y = self._stem_args
+                self._stem = self.lib.y5_plan_size(self.plan)
+                _lib.check(self.lib.y5_plan_add_conv_stem(self.plan, None, B, H, W, C.c_void_p(self.be.ptr(wp)), C.c_void_p(self.be.ptr(bp)),
+                                                          c2, npad, self._ptr(y), self._ld(y)), self.lib)
+                self.op_names.append(self.op_names[1] + "[stem,nchw]")
         self._graph = False
 
     def __del__(self):
@@ -426,6 +434,13 @@ class Engine:
         H, W, C1, ldx = x.H, x.W, x.C, self._ld(x)
         if op["view"] == "first":
             cin = w.shape[1]
+            if (self.dtype == torch.float16 and cin == 3 and (kh, kw, sh, sw, ph, pw) == (6, 6, 2, 2, 2, 2) and op["act"] and res is None
+                    and y2 is None and W % 64 == 0 and H % 2 == 0 and w.shape[0] <= 64 and w.shape[0] % 8 == 0
+                    and os.environ.get("Y5_STEM", "1") != "0"):
+                swp, sbp, snpad = pack_stem_weight(w, b)
+                swp, sbp = self.be.from_torch(swp), self.be.from_torch(sbp)
+                self._keep += [swp, sbp]
+                self._stem_args = (swp, sbp, int(w.shape[0]), snpad, y)
             wfull = torch.zeros((w.shape[0], C1, kh, kw), device=w.device)
             wfull[:, :cin] = w
             w = wfull
@@ -492,11 +507,19 @@ class Engine:
         d, cin = self._first_op
         st = self._stream()
         B = self.spec.B
+        n = self.lib.y5_plan_size(self.plan)
+        if self._stem is not None and src_dt == _lib.Y5_F16:
+            # fp16 NCHW batch: the stem conv reads it in place (no NHWC repack pass), then the plan continues at op 2
+            self._stem_active = True
+            _lib.check(self.lib.y5_plan_set_input(self.plan, self._stem, C.c_void_p(xptr)), self.lib)
+            _lib.check(self.lib.y5_plan_run_range(self.plan, self._stem, self._stem + 1, st), self.lib)
+            _lib.check(self.lib.y5_plan_run_range(self.plan, 2, self._stem, st), self.lib)
+            return self.outputs
+        self._stem_active = False
         scale = 1.0 / 255.0 if src_dt == _lib.Y5_U8 else 1.0  # train.py:379 / detect.py:209: uint8 images -> 0..1
         _lib.check(self.lib.y5_nchw_to_nhwc(C.c_void_p(xptr), src_dt, self._ptr(d), self.dt, B, cin, d.H, d.W, self._ld(d),
                                             scale, st), self.lib)
-        n = self.lib.y5_plan_size(self.plan)
-        _lib.check(self.lib.y5_plan_run_range(self.plan, 1, n, st), self.lib)
+        _lib.check(self.lib.y5_plan_run_range(self.plan, 1, n if self._stem is None else self._stem, st), self.lib)
         return self.outputs
 
     def time_ops(self, iters=20):
@@ -505,7 +528,12 @@ class Engine:
         n = self.lib.y5_plan_size(self.plan)
         res = []
         ms = C.c_float(0)
-        for i in range(1, n):
+        if self._stem is not None and getattr(self, "_stem_active", False):
+            order = [self._stem] + list(range(2, self._stem))   # as executed by __call__ for an fp16 batch
+        else:
+            order = list(range(1, n if self._stem is None else self._stem))
+        for i in order:
             _lib.check(self.lib.y5_plan_time_range(self.plan, i, i + 1, iters, st, C.byref(ms)), self.lib)
             res.append((self.op_names[i], ms.value / iters))
+        self.timed_order = order
         return res

@@ -38,3 +38,16 @@ def fuse_conv_bn_weights(w, conv_bias, bn_w, bn_b, bn_mean, bn_var, eps):
     b0 = torch.zeros_like(bn_mean, dtype=torch.float32) if conv_bias is None else conv_bias.float()
     bf = (b0 - bn_mean.float()) * scale + bn_b.float()
     return wf, bf
+
+
+def pack_stem_weight(w: torch.Tensor, bias):
+    """Stem filter (C2, 3, 6, 6) -> [Npad][144] fp16 for y5_conv_stem_fwd: k = (c*6 + kh)*8 + kw, taps kw = 6,7 zero."""
+    c2, c1, kh, kw = w.shape
+    assert (c1, kh, kw) == (3, 6, 6), w.shape
+    npad = round_up(c2, 32)
+    wk = torch.zeros((npad, 3, 6, 8), dtype=torch.float32, device=w.device)
+    wk[:c2, :, :, :6] = w.detach().float()
+    bp = torch.zeros((npad,), dtype=torch.float32, device=w.device)
+    if bias is not None:
+        bp[:c2] = bias.detach().float()
+    return wk.reshape(npad, 144).to(torch.float16).contiguous(), bp.contiguous(), npad
