@@ -88,6 +88,7 @@ inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorN
 inline void emu_wave_barrier() { const void* o[64]; char c = 0; emu::wave_exchange(&c, 1, o); }
 #define __builtin_amdgcn_wave_barrier() emu_wave_barrier()
 inline float __expf(float x) { return expf(x); }
+inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 inline int atomicAdd(int* p, int v) { int o = *p; *p += v; return o; }

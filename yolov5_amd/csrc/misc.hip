@@ -97,6 +97,7 @@ extern "C" int y5_detect_decode(const void* logits, int dt, int B, int ny, int n
   while (p.P > 2 && (size_t)p.P * ld * es > 96 * 1024) p.P >>= 1;
   if ((long long)p.P * no >= 65536) return y5_fail(Y5_ERR_UNSUPPORTED, "detect_decode: no too large");
   p.inv_no = (unsigned)((0x100000000ULL + (unsigned)no - 1) / (unsigned)no);
+  p.inv_nx = (unsigned)((0x100000000ULL + (unsigned)nx - 1) / (unsigned)nx);
   const size_t lds = (size_t)p.P * ld * es;
   const int npix = ny * nx;
   const dim3 g((unsigned)((npix + p.P - 1) / p.P), (unsigned)B), b(256);

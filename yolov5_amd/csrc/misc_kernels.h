@@ -113,6 +113,7 @@ struct Y5DecodeParams {
   long long nrows_total, row_off;
   int ny, nx, na, no, nm, ld, P;
   unsigned inv_no;  // ceil(2^32 / no): idx / no == umulhi(idx, inv_no) for idx < 2^16
+  unsigned inv_nx;  // ceil(2^32 / nx): pix / nx for pix < 2^16 (fast path only when ny*nx < 65536)
   float stride;
   float anchors_px[16];  // na*2
 };
@@ -162,6 +163,41 @@ void y5_detect_decode_kernel(const Y5DecodeParams p) {
     Z* zp = static_cast<Z*>(p.z) + zbase;
     T* rp = p.raw ? static_cast<T*>(p.raw) + rbase : nullptr;
     const bool pair_ok = ((zbase | rbase | ne) & 1) == 0;
+    if constexpr (sizeof(T) == 2 && sizeof(Z) == 2) {
+      if (((zbase | rbase | ne) & 7) == 0 && npix < 65536) {
+        // fast path: 8 consecutive outputs (16 bytes) per lane, branch-free decode.  a (hence the anchor) is uniform;
+        // the 8 elements touch at most two pixels, whose grid coordinates are formed once with umulhi.
+        const float aw = p.anchors_px[a * 2], ah = p.anchors_px[a * 2 + 1];
+        const int nact = p.no - p.nm;
+        for (int e0 = threadIdx.x * 8; e0 < ne; e0 += blockDim.x * 8) {
+          int pl = (int)__umulhi((unsigned)e0, p.inv_no);
+          int o = e0 - pl * p.no;
+          const int pixA = pix0 + pl;
+          const int iyA = (int)__umulhi((unsigned)pixA, p.inv_nx), ixA = pixA - iyA * p.nx;
+          const int ixB = ixA + 1 == p.nx ? 0 : ixA + 1, iyB = ixA + 1 == p.nx ? iyA + 1 : iyA;
+          float gx = (float)ixA - 0.5f, gy = (float)iyA - 0.5f;
+          const float gxB = (float)ixB - 0.5f, gyB = (float)iyB - 0.5f;
+          const T* src = tile + pl * p.ld + a * p.no;
+          half8_t zo, ro;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float v = (float)src[o];
+            const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+            const float s2 = s * 2.0f;
+            const float rxy = (s2 + (o == 0 ? gx : gy)) * p.stride;   // yolo.py:110
+            const float rwh = s2 * s2 * (o == 2 ? aw : ah);           // yolo.py:111
+            float r = o < 2 ? rxy : (o < 4 ? rwh : s);
+            r = o < nact ? r : v;                                     // Segment mask coefficients stay raw
+            zo[k] = (half_t)r;
+            ro[k] = (half_t)v;
+            if (++o == p.no) { o = 0; src += p.ld; gx = gxB; gy = gyB; }
+          }
+          *reinterpret_cast<half8_t*>(zp + e0) = zo;
+          if (rp) *reinterpret_cast<half8_t*>(rp + e0) = ro;
+        }
+        continue;
+      }
+    }
     if (pair_ok) {
       for (int e = threadIdx.x * 2; e < ne; e += blockDim.x * 2) {
         float r0, r1;
