@@ -96,6 +96,13 @@ inline int atomicExch(int* p, int v) { int o = *p; *p = v; return o; }
 inline float atomicAdd(float* p, float v) { float o = *p; *p += v; return o; }
 inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 
+struct __amdgpu_buffer_rsrc_t { const char* base; unsigned num_records; };
+inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, int, int n, int) { return {(const char*)p, (unsigned)n}; }
+inline void emu_bglds(__amdgpu_buffer_rsrc_t r, void* l, int size, unsigned voff) {
+  char* d = (char*)l + (size_t)emu::lane_id() * size;
+  if ((unsigned long long)voff + size > r.num_records) memset(d, 0, size); else memcpy(d, r.base + voff, size);
+}
+#define __builtin_amdgcn_raw_ptr_buffer_load_lds(r, l, size, voff, soff, ioff, aux) emu_bglds((r), (void*)(uintptr_t)(l), (size), (unsigned)(voff))
 inline void emu_glds(const void* g, void* l, int size) { memcpy((char*)l + (size_t)emu::lane_id() * size, g, size); }
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu_glds((const void*)(uintptr_t)(g), (void*)(uintptr_t)(l), (size))
 

@@ -38,7 +38,7 @@ CASES = [
     (6, 8, 16, 128, 64, 1, 1, 0, 1, False, False, 21, 1, "f16"),
 ] + [
     # every fp16 tile configuration on one shape with M, N tails and K = 9*64 (uniform) / 9*48 (table for BK64)
-    (2, 9, 9, c1, 160, 3, 1, 1, 1, True, False, cfg, 2, "f16") for cfg in range(14) for c1 in (64, 48)
+    (2, 9, 9, c1, 160, 3, 1, 1, 1, True, False, cfg, 2, "f16") for cfg in list(range(14)) + list(range(22, 30)) for c1 in (64, 48)
 ]
 
 

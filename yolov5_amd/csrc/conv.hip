@@ -12,6 +12,8 @@ namespace {
 struct TileCfg { int wm, wn, tm, tn, rb; };
 // id -> workgroup tile (BM = wm*tm*32 pixels, BN = wn*tn*32 channels), LDS row bytes (K per stage = rb / elemsize)
 constexpr int kNumIgemm = 14;
+constexpr int kRing0 = 22, kNumRing = 8;  // ids 22..29: tile shapes of ids {1,2,3,5,7,8,11,12} with a 3-stage ring
+constexpr int kRingBase[kNumRing] = {1, 2, 3, 5, 7, 8, 11, 12};
 constexpr TileCfg kCfgs[kNumIgemm] = {
     {4, 1, 1, 1, 64},   //  0: 128 x  32, BK32
     {4, 1, 1, 2, 64},   //  1: 128 x  64, BK32
@@ -31,7 +33,7 @@ constexpr TileCfg kCfgs[kNumIgemm] = {
 
 int g_num_cu = 0;
 
-template <typename T, int WM, int WN, int TM, int TN, int RB, bool TABLE>
+template <typename T, int WM, int WN, int TM, int TN, int RB, bool TABLE, int NS = 2>
 int launch_cfg(const Y5ConvParams& p0, int max_blocks, hipStream_t stream) {
   using Gm = Y5ConvGeom<T, RB>;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -45,9 +47,9 @@ int launch_cfg(const Y5ConvParams& p0, int max_blocks, hipStream_t stream) {
     pieces = p.Kpad / Gm::EPP;
     if (pieces > Y5_CONV_MAXTAB) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: K too large for gather-table mode");
   }
-  const size_t lds = y5_conv_lds_bytes<T, WM, WN, TM, TN, RB>(pieces);
+  const size_t lds = y5_conv_lds_bytes<T, WM, WN, TM, TN, RB, NS>(pieces);
   if (lds > 160 * 1024) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: tile configuration exceeds 160 KiB of LDS");
-  auto kern = y5_conv_igemm_kernel<T, WM, WN, TM, TN, RB, TABLE>;
+  auto kern = y5_conv_igemm_kernel<T, WM, WN, TM, TN, RB, TABLE, NS>;
   static bool attr_done = false;  // per instantiation
   if (!attr_done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -101,6 +103,15 @@ int launch_by_cfg(const Y5ConvParams& p, int cfg, int mb, hipStream_t s) {
       case 11: return launch_cfg<T, 2, 2, 1, 2, 128, TABLE>(p, mb, s);
       case 12: return launch_cfg<T, 2, 2, 4, 2, 128, TABLE>(p, mb, s);
       case 13: return launch_cfg<T, 4, 1, 2, 1, 128, TABLE>(p, mb, s);
+      // 3-stage LDS ring (counted vmcnt, one raw barrier per chunk): ids kRing0 + 0..7
+      case kRing0 + 0: return launch_cfg<T, 4, 1, 1, 2, 64, TABLE, 3>(p, mb, s);
+      case kRing0 + 1: return launch_cfg<T, 2, 2, 2, 2, 64, TABLE, 3>(p, mb, s);
+      case kRing0 + 2: return launch_cfg<T, 2, 2, 2, 4, 64, TABLE, 3>(p, mb, s);
+      case kRing0 + 3: return launch_cfg<T, 4, 1, 2, 2, 64, TABLE, 3>(p, mb, s);
+      case kRing0 + 4: return launch_cfg<T, 4, 1, 1, 2, 128, TABLE, 3>(p, mb, s);
+      case kRing0 + 5: return launch_cfg<T, 2, 2, 2, 2, 128, TABLE, 3>(p, mb, s);
+      case kRing0 + 6: return launch_cfg<T, 2, 2, 1, 2, 128, TABLE, 3>(p, mb, s);
+      case kRing0 + 7: return launch_cfg<T, 2, 2, 4, 2, 128, TABLE, 3>(p, mb, s);
     }
     return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown tile config");
   }
@@ -108,7 +119,7 @@ int launch_by_cfg(const Y5ConvParams& p, int cfg, int mb, hipStream_t s) {
 
 // ---- streaming pointwise configurations (conv_pw.h): id = kNumIgemm + index ---------------------------------
 struct PwCfg { int kc, rb, nt, s; };
-constexpr int kNumPw = Y5_CONV_NUM_CFGS - kNumIgemm;
+constexpr int kNumPw = 8;
 constexpr PwCfg kPwCfgs[kNumPw] = {
     {1, 64, 1, 4},   // 14:  32 ->  32, 4 stages
     {1, 128, 1, 4},  // 15:  64 ->  32
@@ -181,6 +192,7 @@ extern "C" int y5_conv_num_cfgs(void) { return Y5_CONV_NUM_CFGS; }
 
 extern "C" int y5_conv_cfg_info(int cfg, int* bm, int* bn, int* bk_bytes) {
   if (cfg < 0 || cfg >= Y5_CONV_NUM_CFGS) return y5_fail(Y5_ERR_BAD_ARG, "conv_cfg_info: bad id");
+  if (cfg >= kRing0) cfg = kRingBase[cfg - kRing0];
   if (cfg >= kNumIgemm) {
     const PwCfg& c = kPwCfgs[cfg - kNumIgemm];
     if (bm) *bm = 128;
@@ -203,8 +215,9 @@ extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w
   const int epp = 16 / es;
   int cfg = d->cfg < 0 ? default_cfg(d) : d->cfg;
   if (cfg >= Y5_CONV_NUM_CFGS) return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown tile config");
-  const bool pw = cfg >= kNumIgemm;
-  const int bk = pw ? 8 : kCfgs[cfg].rb / es;
+  const bool pw = cfg >= kNumIgemm && cfg < kRing0;
+  const int bk = pw ? 8 : kCfgs[cfg >= kRing0 ? kRingBase[cfg - kRing0] : cfg].rb / es;
+  if (cfg >= kRing0 && d->dtype != Y5_F16) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: ring configurations are fp16 only");
   if (d->C1 % epp || d->ldx % epp) return y5_fail(Y5_ERR_BAD_ARG, "conv: C1 and ldx must be multiples of 16 bytes");
   if (d->C2 % epp || (y && d->ldy % epp) || (residual && d->ldr % epp) || (y_up2 && d->ld2 % epp))
     return y5_fail(Y5_ERR_BAD_ARG, "conv: C2/ldy/ldr/ld2 must be multiples of 16 bytes");
@@ -214,8 +227,9 @@ extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w
     return y5_fail(Y5_ERR_BAD_ARG, "conv: pointers must be 16-byte aligned");
   const int oh = (d->H + 2 * d->PH - d->KH) / d->SH + 1, ow = (d->W + 2 * d->PW - d->KW) / d->SW + 1;
   if (oh != d->OH || ow != d->OW) return y5_fail(Y5_ERR_BAD_ARG, "conv: OH/OW inconsistent with H/W/k/s/p");
-  if ((long long)d->B * d->H * d->W * d->ldx >= 0x7fffffffLL || (long long)d->B * oh * ow >= 0x7fffffffLL)
-    return y5_fail(Y5_ERR_UNSUPPORTED, "conv: tensor exceeds 2^31 elements");
+  if ((long long)d->B * d->H * d->W * d->ldx * es >= 0x7fffffffLL || (long long)d->B * oh * ow >= 0x7fffffffLL ||
+      (long long)d->Npad * d->Kpad * es >= 0x7fffffffLL)
+    return y5_fail(Y5_ERR_UNSUPPORTED, "conv: tensor exceeds 2^31 bytes (32-bit buffer offsets)");
 
   Y5ConvParams p{};
   p.x = x; p.w = w_packed; p.bias = bias; p.res = residual; p.y = y; p.y2 = y_up2;
@@ -227,6 +241,8 @@ extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w
   p.act = d->act; p.Kpad = d->Kpad; p.Npad = d->Npad; p.K = d->KH * d->KW * d->C1;
   p.ldr = d->ldr; p.ld2 = d->ld2;
   p.M = d->B * oh * ow;
+  p.x_bytes = (unsigned)((((long long)d->B * d->H * d->W - 1) * d->ldx + d->C1) * es);
+  p.w_bytes = (unsigned)((long long)d->Npad * d->Kpad * es);
 
   if (pw) {
     const PwCfg& c = kPwCfgs[cfg - kNumIgemm];
@@ -235,7 +251,7 @@ extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w
       return y5_fail(Y5_ERR_UNSUPPORTED, "conv: pointwise configuration does not match this layer");
     return launch_pw_by_cfg(p, cfg - kNumIgemm, d->max_blocks, stream);
   }
-  const bool table = (d->C1 % bk) != 0;
+  const bool table = (d->C1 % bk) != 0 || d->KH * d->KW > 32;  // uniform mode keeps a 32-bit tap-validity mask per row
   if (d->dtype == Y5_F16)
     return table ? launch_by_cfg<half_t, true>(p, cfg, d->max_blocks, stream) : launch_by_cfg<half_t, false>(p, cfg, d->max_blocks, stream);
   return table ? launch_by_cfg<float, true>(p, cfg, d->max_blocks, stream) : launch_by_cfg<float, false>(p, cfg, d->max_blocks, stream);

@@ -23,6 +23,14 @@
 #pragma once
 #include "y5_common.h"
 
+constexpr int y5_waitcnt_vm(int n) {  // s_waitcnt immediate: vmcnt(n), expcnt/lgkmcnt untouched (gfx9 encoding)
+  return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8);
+}
+template <int N> __device__ __forceinline__ void y5_wait_vm() {
+  __builtin_amdgcn_s_waitcnt(y5_waitcnt_vm(N < 63 ? N : 63));
+  asm volatile("" ::: "memory");
+}
+
 struct Y5ConvParams {
   const void* x;      // input  NHWC, pixel stride ldx elements
   const void* w;      // packed filter [Npad][Kpad], k = (kh,kw,c)
@@ -30,7 +38,8 @@ struct Y5ConvParams {
   const void* res;    // optional residual, same geometry as y (pixel stride ldr), may alias y
   void* y;            // output NHWC slice, pixel stride ldy (may be null when only y2 is wanted)
   void* y2;           // optional second destination: 2x nearest-upsampled copy (pixel stride ld2)
-  const void* zero;   // >= 64 bytes of zeros in global memory (source for padding taps / tails)
+  const void* zero;   // >= 64 bytes of zeros in global memory (pointer-addressed kernels: padding taps / tails)
+  unsigned x_bytes, w_bytes;  // extents of x / w for the buffer resource descriptors (offsets beyond them read as zeros)
   int B, H, W, C1, ldx;
   int OH, OW, C2, ldy;
   int KH, KW, SH, SW, PH, PW;
@@ -53,17 +62,20 @@ template <typename T, int RB> struct Y5ConvGeom {
   __device__ static __forceinline__ int swz(int row) { return RB == 64 ? ((row >> 2) & 3) : ((row >> 1) & 7); }
 };
 
-template <typename T, int WM, int WN, int TM, int TN, int RB>
+template <typename T, int WM, int WN, int TM, int TN, int RB, int NS = 2>
 constexpr size_t y5_conv_lds_bytes(int table_pieces) {
-  return 2 * (size_t)(WM * TM * 32 + WN * TN * 32) * RB + (size_t)table_pieces * 8 +
-         (size_t)WM * WN * Y5ConvGeom<T, RB>::SCR_BYTES;
+  return NS * (size_t)(WM * TM * 32 + WN * TN * 32) * RB + (size_t)table_pieces * 8 +
+         (size_t)WM * WN * Y5ConvGeom<T, RB>::SCR_BYTES + (NS > 2 ? (size_t)WM * WN * 1024 : 0);
 }
 
 // minimum waves per SIMD requested from the register allocator (keeps the accumulators in the unified VGPR file
 // and the allocation under the occupancy steps of MI355X_MICROARCH.md "Register files")
 constexpr int y5_conv_min_waves(int tm, int tn) { return tm * tn <= 1 ? 5 : tm * tn <= 2 ? 4 : tm * tn <= 4 ? 3 : 2; }
 
-template <typename T, int WM, int WN, int TM, int TN, int RB, bool TABLE>
+// NS = number of LDS stages.  NS == 2: issue chunk i+1, compute chunk i, drain (vmcnt(0)) + barrier.  NS >= 3: a ring
+// with NS-1 chunks in flight, retired by COUNTED vmcnt (every wave issues the same number of LDS-DMA instructions per
+// chunk: filter instructions a wave does not own go to a 1 KiB per-wave dummy slot) and ONE raw s_barrier per chunk.
+template <typename T, int WM, int WN, int TM, int TN, int RB, bool TABLE, int NS = 2>
 __global__ __launch_bounds__(WM * WN * 64, y5_conv_min_waves(TM, TN))
 void y5_conv_igemm_kernel(const Y5ConvParams p) {
   using Gm = Y5ConvGeom<T, RB>;
@@ -78,15 +90,16 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
   constexpr int BUF_BYTES = (BM + BN) * RB;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // layout: [buf0: act BM rows | wgt BN rows][buf1: same][tap table (TABLE mode)][per-wave epilogue scratch]
-  int2* tab = reinterpret_cast<int2*>(smem + 2 * BUF_BYTES);
+  // layout: [buf0: act BM rows | wgt BN rows][buf1: same]..[tap table (TABLE mode)][per-wave epilogue scratch][dummy]
+  int2* tab = reinterpret_cast<int2*>(smem + NS * BUF_BYTES);
   const int tab_bytes = TABLE ? (p.Kpad / EPP) * 8 : 0;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  char* scratch = smem + 2 * BUF_BYTES + tab_bytes + wave * Gm::SCR_BYTES;
+  char* scratch = smem + NS * BUF_BYTES + tab_bytes + wave * Gm::SCR_BYTES;
+  char* dummy = smem + NS * BUF_BYTES + tab_bytes + NW * Gm::SCR_BYTES + wave * 1024;  // NS > 2 only
 
   const int G = gridDim.x;
   const int bid = blockIdx.x;
@@ -95,9 +108,9 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
   const int nk = p.nk;
   const int total = nmine * nk;
 
-  const T* __restrict__ xg = static_cast<const T*>(p.x);
-  const T* __restrict__ wg = static_cast<const T*>(p.w);
-  const char* zero = static_cast<const char*>(p.zero);
+  const y5_rsrc_t xrs = y5_make_rsrc(p.x, p.x_bytes);
+  const y5_rsrc_t wrs = y5_make_rsrc(p.w, p.w_bytes);
+  constexpr int ES = (int)sizeof(T);
 
   if constexpr (TABLE) {
     // per k-piece (EPP elements) gather table: {element offset relative to pixel (ih0,iw0), kh | kw<<16}
@@ -121,10 +134,10 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
   // ---- stage-side (loader) state: describes the tile whose K chunks are currently being staged ------------
   const int lrow = lane / NSLOT;   // row inside one LDS-DMA instruction
   const int lslot = lane % NSLOT;  // destination 16-byte slot
-  int a_base[ACT_PER_WAVE];        // element offset of (b, ih0, iw0) + source slot
-  int a_ih0[ACT_PER_WAVE], a_iw0[ACT_PER_WAVE], a_slot[ACT_PER_WAVE];
-  const char* w_src[WGT_PER_WAVE];
-  bool w_ok[WGT_PER_WAVE];
+  int a_base[ACT_PER_WAVE];        // BYTE offset of (b, ih0, iw0) + source slot (may be negative for padded origins)
+  int a_ih0[ACT_PER_WAVE], a_iw0[ACT_PER_WAVE], a_slot[ACT_PER_WAVE];  // TABLE mode
+  unsigned a_mask[ACT_PER_WAVE];   // UNIFORM mode: bit (kh*KW + kw) set <=> that tap of this row lies inside the image
+  unsigned w_off[WGT_PER_WAVE];    // byte offset of the filter row + source slot, Y5_OOB for rows beyond the tile / Npad
   int u_kh = 0, u_kw = 0, u_c0 = 0;  // uniform tap walker (UNIFORM mode: C1 % BK == 0)
   int s_t = 0, s_kc = 0;             // staged tile (index into this block's tile list) / K chunk
 
@@ -149,49 +162,60 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
       const int r = mm - b * ohw;
       const int oh = r / p.OW, ow = r - oh * p.OW;
       const int ih0 = oh * p.SH - p.PH, iw0 = ow * p.SW - p.PW;
-      a_ih0[i] = m < p.M ? ih0 : -0x40000000;  // pixel rows past M: every tap reads zeros
-      a_iw0[i] = iw0;
-      a_base[i] = ((b * p.H + ih0) * p.W + iw0) * p.ldx + sslot * EPP;
-      a_slot[i] = sslot;
+      a_base[i] = (((b * p.H + ih0) * p.W + iw0) * p.ldx + sslot * EPP) * ES;
+      if constexpr (TABLE) {
+        a_ih0[i] = m < p.M ? ih0 : -0x40000000;  // pixel rows past M: every tap reads zeros
+        a_iw0[i] = iw0;
+        a_slot[i] = sslot;
+      } else {
+        unsigned mk = 0;
+        if (m < p.M) {
+          unsigned bit = 1;
+          for (int kh = 0; kh < p.KH; ++kh)
+            for (int kw = 0; kw < p.KW; ++kw, bit <<= 1)
+              if ((unsigned)(ih0 + kh) < (unsigned)p.H && (unsigned)(iw0 + kw) < (unsigned)p.W) mk |= bit;
+        }
+        a_mask[i] = mk;
+      }
     }
 #pragma unroll
     for (int i = 0; i < WGT_PER_WAVE; ++i) {
       const int row = (wave + i * NW) * RPI + lrow;  // row inside the filter tile
       const int sslot = lslot ^ Gm::swz(row);
       const int n = n0 + row;
-      w_ok[i] = (row < BN) && (n < p.Npad);
-      w_src[i] = reinterpret_cast<const char*>(wg + (size_t)(w_ok[i] ? n : 0) * p.Kpad + sslot * EPP);
+      w_off[i] = (row < BN) && (n < p.Npad) ? (unsigned)((n * p.Kpad + sslot * EPP) * ES) : Y5_OOB;
     }
     u_kh = 0; u_kw = 0; u_c0 = 0;
   };
 
   auto stage = [&](int buf) {
     char* lds = smem + buf * BUF_BYTES;
-    int tap_off = 0;
-    if constexpr (!TABLE) tap_off = (u_kh * p.W + u_kw) * p.ldx + u_c0;
+    int tap_off = 0, tap_bit = 0;
+    if constexpr (!TABLE) {
+      tap_off = ((u_kh * p.W + u_kw) * p.ldx + u_c0) * ES;
+      tap_bit = u_kh * p.KW + u_kw;
+    }
 #pragma unroll
     for (int i = 0; i < ACT_PER_WAVE; ++i) {
-      int off, ih, iw;
+      unsigned voff;
       if constexpr (TABLE) {
         const int2 e = tab[s_kc * NSLOT + a_slot[i]];
-        off = a_base[i] - a_slot[i] * EPP + e.x;
-        ih = a_ih0[i] + (e.y & 0xffff);
-        iw = a_iw0[i] + (e.y >> 16);
+        const int ih = a_ih0[i] + (e.y & 0xffff), iw = a_iw0[i] + (e.y >> 16);
+        const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        voff = ok ? (unsigned)(a_base[i] + (e.x - a_slot[i] * EPP) * ES) : Y5_OOB;
       } else {
-        off = a_base[i] + tap_off;
-        ih = a_ih0[i] + u_kh;
-        iw = a_iw0[i] + u_kw;
+        voff = (a_mask[i] >> tap_bit) & 1u ? (unsigned)(a_base[i] + tap_off) : Y5_OOB;
       }
-      const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-      const char* src = ok ? reinterpret_cast<const char*>(xg + off) : zero;
-      y5_glds16(src, lds + (wave + i * NW) * 1024);
+      y5_bglds16(xrs, voff, lds + (wave + i * NW) * 1024);
     }
+    const unsigned kc_bytes = (unsigned)(s_kc * BK * ES);
 #pragma unroll
     for (int i = 0; i < WGT_PER_WAVE; ++i) {
       const int idx = wave + i * NW;
       if (idx < WGT_INSTR) {
-        const char* src = w_ok[i] ? w_src[i] + (size_t)s_kc * BK * sizeof(T) : zero;
-        y5_glds16(src, lds + BM * RB + idx * 1024);
+        y5_bglds16(wrs, w_off[i] == Y5_OOB ? Y5_OOB : w_off[i] + kc_bytes, lds + BM * RB + idx * 1024);
+      } else if (NS > 2) {
+        y5_bglds16(wrs, Y5_OOB, dummy);  // keeps the per-chunk LDS-DMA count identical in every wave (counted vmcnt)
       }
     }
     // advance to the next (tile, chunk)
@@ -308,67 +332,97 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
 
   if constexpr (TABLE) __syncthreads();
   loader_setup(0);
-  stage(0);
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-  __syncthreads();
+  constexpr int LPC = ACT_PER_WAVE + WGT_PER_WAVE;  // LDS-DMA instructions per chunk per wave (NS > 2: uniform)
 
-  int it = 0;
-  int pm0 = 0, pn0 = 0;  // coordinates of the tile whose results sit in acc
-  for (int ti = 0; ti < nmine; ++ti) {
-    for (int kc = 0; kc < nk; ++kc, ++it) {
-      const int cur = it & 1;
-      if (it + 1 < total) stage(cur ^ 1);  // next chunk (possibly of the next tile) flies during everything below
-      if (kc == 0) {
-        if (ti > 0) epilogue(pm0, pn0);
-        tile_coords(ti, pm0, pn0);
+  auto compute = [&](const char* lds) {
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int ks = 0; ks < RB / 32; ++ks) {
+        const int so = ((ks * 2 + g) ^ fsw) * 16;
+        half8_t af[TM], wf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const half8_t*>(lds + a_rd[i] + so);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const half8_t*>(lds + w_rd[j] + so);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
       }
-      const char* lds = smem + cur * BUF_BYTES;
-      if constexpr (sizeof(T) == 2) {
+    } else {
+      const int so0 = ((2 * g) ^ fsw) * 16, so1 = ((2 * g + 1) ^ fsw) * 16;
+      float4_t af[TM][2], wf[TN][2];
 #pragma unroll
-        for (int ks = 0; ks < RB / 32; ++ks) {
-          const int so = ((ks * 2 + g) ^ fsw) * 16;
-          half8_t af[TM], wf[TN];
+      for (int i = 0; i < TM; ++i) {
+        af[i][0] = *reinterpret_cast<const float4_t*>(lds + a_rd[i] + so0);
+        af[i][1] = *reinterpret_cast<const float4_t*>(lds + a_rd[i] + so1);
+      }
 #pragma unroll
-          for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const half8_t*>(lds + a_rd[i] + so);
+      for (int j = 0; j < TN; ++j) {
+        wf[j][0] = *reinterpret_cast<const float4_t*>(lds + w_rd[j] + so0);
+        wf[j][1] = *reinterpret_cast<const float4_t*>(lds + w_rd[j] + so1);
+      }
 #pragma unroll
-          for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const half8_t*>(lds + w_rd[j] + so);
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
-        }
-      } else {
-        const int so0 = ((2 * g) ^ fsw) * 16, so1 = ((2 * g + 1) ^ fsw) * 16;
-        float4_t af[TM][2], wf[TN][2];
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[j][h][e], af[i][h][e], acc[i][j], 0, 0, 0);
+    }
+  };
+  auto tile_begin = [&](int ti, int& pm0, int& pn0) {
+    if (ti > 0) epilogue(pm0, pn0);
+    tile_coords(ti, pm0, pn0);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          af[i][0] = *reinterpret_cast<const float4_t*>(lds + a_rd[i] + so0);
-          af[i][1] = *reinterpret_cast<const float4_t*>(lds + a_rd[i] + so1);
-        }
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          wf[j][0] = *reinterpret_cast<const float4_t*>(lds + w_rd[j] + so0);
-          wf[j][1] = *reinterpret_cast<const float4_t*>(lds + w_rd[j] + so1);
-        }
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-              for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[j][h][e], af[i][h][e], acc[i][j], 0, 0, 0);
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+
+  int pm0 = 0, pn0 = 0;  // coordinates of the tile whose results sit in acc
+  if constexpr (NS == 2) {
+    stage(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    __syncthreads();
+    int it = 0;
+    for (int ti = 0; ti < nmine; ++ti) {
+      for (int kc = 0; kc < nk; ++kc, ++it) {
+        const int cur = it & 1;
+        if (it + 1 < total) stage(cur ^ 1);  // next chunk (possibly of the next tile) flies during everything below
+        if (kc == 0) tile_begin(ti, pm0, pn0);
+        compute(smem + cur * BUF_BYTES);
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the chunk staged above has landed
+        __syncthreads();
       }
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the chunk staged above has landed
-      __syncthreads();
+    }
+  } else {
+    // ring: chunks it+1 .. it+NS-2 are in flight while chunk `it` is retired; chunk it+NS-1 is issued right after the barrier
+    // into the buffer chunk it-1 occupied (all waves have finished reading it: they are past this barrier).
+    for (int s0 = 0; s0 < NS - 1; ++s0)
+      if (s0 < total) stage(s0);
+    int it = 0, cur = 0, nxt = NS - 1;
+    for (int ti = 0; ti < nmine; ++ti) {
+      for (int kc = 0; kc < nk; ++kc, ++it) {
+        const int ahead = total - 1 - it < NS - 2 ? total - 1 - it : NS - 2;  // chunks issued after chunk `it`
+        switch (ahead) {
+          case 0: y5_wait_vm<0>(); break;
+          case 1: y5_wait_vm<LPC>(); break;
+          case 2: y5_wait_vm<2 * LPC>(); break;
+          default: y5_wait_vm<3 * LPC>(); break;
+        }
+        __builtin_amdgcn_s_barrier();
+        if (it + NS - 1 < total) stage(nxt);
+        if (kc == 0) tile_begin(ti, pm0, pn0);
+        compute(smem + cur * BUF_BYTES);
+        cur = cur + 1 == NS ? 0 : cur + 1;
+        nxt = nxt + 1 == NS ? 0 : nxt + 1;
+      }
     }
   }
   epilogue(pm0, pn0);

@@ -15,14 +15,6 @@
 #pragma once
 #include "conv_igemm.h"
 
-constexpr int y5_waitcnt_vm(int n) {  // s_waitcnt immediate: vmcnt(n), expcnt/lgkmcnt untouched (gfx9 encoding)
-  return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8);
-}
-template <int N> __device__ __forceinline__ void y5_wait_vm() {
-  __builtin_amdgcn_s_waitcnt(y5_waitcnt_vm(N < 63 ? N : 63));
-  asm volatile("" ::: "memory");
-}
-
 template <int KC, int RB, int NT, int S>
 constexpr size_t y5_conv_pw_lds_bytes() {
   constexpr int NPAD = 32 * NT;

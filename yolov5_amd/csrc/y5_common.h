@@ -21,8 +21,20 @@ __device__ __forceinline__ void y5_glds16(const void* gsrc, void* lds_wave_base)
   __builtin_amdgcn_global_load_lds(Y5_GLB_PTR(gsrc), Y5_LDS_PTR(lds_wave_base), 16, 0, 0);
 }
 
+// Buffer-addressed LDS-DMA (buffer_load_dwordx4 ... offen lds): 32-bit byte offsets against a scalar resource
+// descriptor; an offset beyond num_records is NOT fetched and lands as zeros -- padding taps, tile tails and the
+// "dummy" loads that keep vmcnt bookkeeping uniform cost no address arithmetic and no memory traffic.
+typedef __amdgpu_buffer_rsrc_t y5_rsrc_t;
+#define Y5_OOB 0xFFFFFFFFu
+__device__ __forceinline__ y5_rsrc_t y5_make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void y5_bglds16(y5_rsrc_t r, unsigned voff, void* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, Y5_LDS_PTR(lds_wave_base), 16, (int)voff, 0, 0, 0);
+}
+
 __device__ __forceinline__ float y5_sigmoid(float v) { return 1.0f / (1.0f + __expf(-v)); }
-__device__ __forceinline__ float y5_silu(float v) { return v / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float y5_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 // XCD-aware bijective remap of a 1-D block id: blocks that land on the same XCD (bid % 8) get a
 // contiguous range of logical tile ids so that neighbouring tiles share that XCD's L2.
