@@ -82,6 +82,8 @@ inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorN
 // ---- device builtins ---------------------------------------------------------------------------------
 #define __syncthreads() emu::barrier_block()
 #define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_amdgcn_readlane(v, l) __shfl((v), (l))
+inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_s_barrier() emu::barrier_block()
 #define __builtin_amdgcn_fence(order, scope) ((void)0)

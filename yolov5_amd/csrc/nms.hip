@@ -64,11 +64,11 @@ extern "C" int y5_nms_batched(const void* pred, int dt, int bs, int n, int no, i
     hipFuncSetAttribute((const void*)y5_nms_greedy_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     attr = true;
   }
-  const size_t greedy_lds = (size_t)max_det * 20 + 64;
+  const size_t greedy_lds = (size_t)max_det * 20 + 5 * 64 * 4 + 64 * 8 + Y5_NMS_GREEDY_WAVES * 8 + 16;
   if (dt == Y5_F16) hipLaunchKernelGGL((y5_nms_filter_kernel<half_t>), fg, fb, 0, st, p);
   else hipLaunchKernelGGL((y5_nms_filter_kernel<float>), fg, fb, 0, st, p);
   hipLaunchKernelGGL(y5_nms_sort_kernel, dim3((unsigned)bs), dim3(1024), Y5_NMS_SORT_LDS_KEYS * 8, st, p);
-  if (dt == Y5_F16) hipLaunchKernelGGL((y5_nms_greedy_kernel<half_t>), dim3((unsigned)bs), dim3(256), greedy_lds, st, p);
-  else hipLaunchKernelGGL((y5_nms_greedy_kernel<float>), dim3((unsigned)bs), dim3(256), greedy_lds, st, p);
+  if (dt == Y5_F16) hipLaunchKernelGGL((y5_nms_greedy_kernel<half_t>), dim3((unsigned)bs), dim3(64 * Y5_NMS_GREEDY_WAVES), greedy_lds, st, p);
+  else hipLaunchKernelGGL((y5_nms_greedy_kernel<float>), dim3((unsigned)bs), dim3(64 * Y5_NMS_GREEDY_WAVES), greedy_lds, st, p);
   return y5_check_launch("y5_nms_batched");
 }

@@ -156,13 +156,23 @@ __global__ void y5_nms_sort_kernel(const Y5NmsParams p) {
 }
 
 // ---- K3: greedy suppression, kept boxes in LDS -------------------------------------------------------
+// One workgroup of 16 waves per image walks the sorted candidates in chunks of 64:
+//   (0) wave 0 decodes the chunk (box, class offset, area) into LDS;
+//   (A) every wave tests the 64 candidates (lane = candidate) against a 1/16 slice of the kept list -> suppression ballots;
+//   (M) every wave also forms 4 rows of the chunk's 64x64 "i suppresses j > i" bit matrix (one ballot per row);
+//   (B) wave 0 resolves the chunk serially with scalar bit operations only (ctz / readlane / andn2), then appends the
+//       survivors to the kept list and writes their output rows in parallel.
+// Same decisions as torchvision.ops.nms: candidate i is kept iff no EARLIER KEPT candidate has IoU > thr with it.
+#define Y5_NMS_GREEDY_WAVES 16
 template <typename T>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(1024)
 void y5_nms_greedy_kernel(const Y5NmsParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* kept = reinterpret_cast<float*>(smem);                 // [max_det][5]: x1,y1,x2,y2 (class offset), area
-  unsigned long long* supmask = reinterpret_cast<unsigned long long*>(smem + (size_t)p.max_det * 20);  // [4]
-  int* s_nkept = reinterpret_cast<int*>(supmask + 4);
+  float* kept = reinterpret_cast<float*>(smem);                                   // [max_det][5]: x1,y1,x2,y2 (class offset), area
+  float* cand = kept + (size_t)p.max_det * 5;                                     // [5][64]
+  unsigned long long* matrix = reinterpret_cast<unsigned long long*>(cand + 5 * 64);  // [64]
+  unsigned long long* supmask = matrix + 64;                                      // [16]
+  int* s_nkept = reinterpret_cast<int*>(supmask + Y5_NMS_GREEDY_WAVES);
 
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -182,29 +192,37 @@ void y5_nms_greedy_kernel(const Y5NmsParams p) {
   int nkept = 0;
 
   for (long long base = 0; base < n && nkept < p.max_det; base += 64) {
-    const long long ci = base + lane;
-    const bool valid = ci < n;
-    float x1 = 0, y1 = 0, x2 = 0, y2 = 0, conf = 0, clsf = 0, bx1 = 0, by1 = 0, bx2 = 0, by2 = 0, area = 0;
+    // (0) decode the chunk
+    float x1 = 0, y1 = 0, x2 = 0, y2 = 0, conf = 0, clsf = 0;
     long long rowi = 0;
-    if (valid) {
-      const unsigned long long key = keys[ci];
-      conf = __uint_as_float((unsigned)(key >> 32));
-      const unsigned idx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
-      int cls;
-      if (p.flags & 1) { rowi = idx / (unsigned)p.nc; cls = (int)(idx - (unsigned)rowi * (unsigned)p.nc); }
-      else { rowi = idx; cls = p.best_cls[(long long)b * p.n + rowi]; }
-      const T* row = pred + rowi * p.no;
-      const float cx = (float)row[0], cy = (float)row[1], w = (float)row[2], h = (float)row[3];
-      const float hw = w / 2.0f, hh = h / 2.0f;
-      x1 = cx - hw; y1 = cy - hh; x2 = cx + hw; y2 = cy + hh;
-      clsf = (float)cls;
-      const float c = clsf * cmul;
-      bx1 = x1 + c; by1 = y1 + c; bx2 = x2 + c; by2 = y2 + c;
-      area = (bx2 - bx1) * (by2 - by1);
+    if (wave == 0) {
+      const long long ci = base + lane;
+      float bx1 = 0, by1 = 0, bx2 = 0, by2 = 0, area = 0;
+      if (ci < n) {
+        const unsigned long long key = keys[ci];
+        conf = __uint_as_float((unsigned)(key >> 32));
+        const unsigned idx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
+        int cls;
+        if (p.flags & 1) { rowi = idx / (unsigned)p.nc; cls = (int)(idx - (unsigned)rowi * (unsigned)p.nc); }
+        else { rowi = idx; cls = p.best_cls[(long long)b * p.n + rowi]; }
+        const T* row = pred + rowi * p.no;
+        const float cx = (float)row[0], cy = (float)row[1], w = (float)row[2], h = (float)row[3];
+        const float hw = w / 2.0f, hh = h / 2.0f;
+        x1 = cx - hw; y1 = cy - hh; x2 = cx + hw; y2 = cy + hh;
+        clsf = (float)cls;
+        const float c = clsf * cmul;
+        bx1 = x1 + c; by1 = y1 + c; bx2 = x2 + c; by2 = y2 + c;
+        area = (bx2 - bx1) * (by2 - by1);
+      }
+      cand[0 * 64 + lane] = bx1; cand[1 * 64 + lane] = by1; cand[2 * 64 + lane] = bx2; cand[3 * 64 + lane] = by2;
+      cand[4 * 64 + lane] = area;
     }
-    // phase A: every wave tests the 64 candidates against a quarter of the kept list
+    __syncthreads();
+    const bool valid = base + lane < n;
+    const float bx1 = cand[lane], by1 = cand[64 + lane], bx2 = cand[128 + lane], by2 = cand[192 + lane], area = cand[256 + lane];
+    // (A) against the kept list
     bool sup = false;
-    for (int k = wave; k < nkept; k += 4) {
+    for (int k = wave; k < nkept; k += Y5_NMS_GREEDY_WAVES) {
       const float kx1 = kept[k * 5 + 0], ky1 = kept[k * 5 + 1], kx2 = kept[k * 5 + 2], ky2 = kept[k * 5 + 3];
       const float ka = kept[k * 5 + 4];
       const float iw = fmaxf(0.0f, fminf(kx2, bx2) - fmaxf(kx1, bx1));
@@ -214,32 +232,48 @@ void y5_nms_greedy_kernel(const Y5NmsParams p) {
     }
     const unsigned long long m = __ballot(sup);
     if (lane == 0) supmask[wave] = m;
+    // (M) rows 4*wave .. 4*wave+3 of the intra-chunk matrix
+#pragma unroll
+    for (int q = 0; q < 64 / Y5_NMS_GREEDY_WAVES; ++q) {
+      const int i = wave * (64 / Y5_NMS_GREEDY_WAVES) + q;
+      const float kx1 = cand[i], ky1 = cand[64 + i], kx2 = cand[128 + i], ky2 = cand[192 + i], ka = cand[256 + i];
+      const float iw = fmaxf(0.0f, fminf(kx2, bx2) - fmaxf(kx1, bx1));
+      const float ih = fmaxf(0.0f, fminf(ky2, by2) - fmaxf(ky1, by1));
+      const float inter = iw * ih;
+      const bool s2 = lane > i && (inter / (ka + area - inter)) > p.iou_thres;
+      const unsigned long long mm = __ballot(s2);
+      if (lane == 0) matrix[i] = mm;
+    }
     __syncthreads();
-    // phase B: wave 0 resolves the chunk serially over its surviving candidates
+    // (B) serial resolution on wave 0: uniform bit arithmetic only
     if (wave == 0) {
-      unsigned long long alive = __ballot(valid) & ~(supmask[0] | supmask[1] | supmask[2] | supmask[3]);
-      while (alive != 0ull && nkept < p.max_det) {
+      unsigned long long dead = 0ull;
+      for (int w2 = 0; w2 < Y5_NMS_GREEDY_WAVES; ++w2) dead |= supmask[w2];
+      unsigned long long alive = __ballot(valid) & ~dead;
+      const unsigned long long mrow = matrix[lane];
+      const unsigned mlo = (unsigned)mrow, mhi = (unsigned)(mrow >> 32);
+      unsigned long long keepm = 0ull;
+      int cnt = nkept;
+      while (alive != 0ull && cnt < p.max_det) {
         const int i = __builtin_ctzll(alive);
+        keepm |= 1ull << i;
+        ++cnt;
+        const unsigned long long mi64 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)mhi, i) << 32) |
+                                        (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)mlo, i);
         alive &= ~(1ull << i);
-        const float kx1 = __shfl(bx1, i), ky1 = __shfl(by1, i), kx2 = __shfl(bx2, i), ky2 = __shfl(by2, i);
-        const float ka = __shfl(area, i);
-        if (lane == i) {
-          kept[nkept * 5 + 0] = bx1; kept[nkept * 5 + 1] = by1; kept[nkept * 5 + 2] = bx2; kept[nkept * 5 + 3] = by2;
-          kept[nkept * 5 + 4] = area;
-          float* o = out + (long long)nkept * ow;
-          o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = conf; o[5] = clsf;
-          const T* row = pred + rowi * p.no;
-          const float obj = (float)row[4];
-          for (int q = 0; q < p.nm; ++q) o[6 + q] = (float)row[mi + q] * obj;  // general.py:719 scales masks too
-        }
-        ++nkept;
-        const float iw = fmaxf(0.0f, fminf(kx2, bx2) - fmaxf(kx1, bx1));
-        const float ih = fmaxf(0.0f, fminf(ky2, by2) - fmaxf(ky1, by1));
-        const float inter = iw * ih;
-        const bool s2 = lane > i && (inter / (ka + area - inter)) > p.iou_thres;
-        alive &= ~__ballot(s2);
+        alive &= ~mi64;
       }
-      if (lane == 0) *s_nkept = nkept;
+      if ((keepm >> lane) & 1ull) {
+        const int slot = nkept + __popcll(keepm & ((1ull << lane) - 1ull));
+        kept[slot * 5 + 0] = bx1; kept[slot * 5 + 1] = by1; kept[slot * 5 + 2] = bx2; kept[slot * 5 + 3] = by2;
+        kept[slot * 5 + 4] = area;
+        float* o = out + (long long)slot * ow;
+        o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = conf; o[5] = clsf;
+        const T* row = pred + rowi * p.no;
+        const float obj = (float)row[4];
+        for (int q = 0; q < p.nm; ++q) o[6 + q] = (float)row[mi + q] * obj;  // general.py:719 scales masks too
+      }
+      if (lane == 0) *s_nkept = cnt;
     }
     __syncthreads();
     nkept = *s_nkept;
