@@ -52,8 +52,8 @@ typedef struct {
   int max_blocks;     /* 0 = fill the GPU (CUs x occupancy) with persistent workgroups; >0 caps the grid (tests) */
 } y5_conv_desc;
 
-#define Y5_CONV_NUM_CFGS 30   /* 0..13 implicit-GEMM tiles (2 LDS stages), 14..21 streaming pointwise (1x1 s1, fp16),
-                                22..29 implicit-GEMM tiles with a 3-stage LDS ring (fp16) */
+#define Y5_CONV_NUM_CFGS 35   /* 0..13 implicit-GEMM tiles (2 LDS stages), 14..21 streaming pointwise (1x1 s1, fp16),
+                                22..29 implicit-GEMM tiles with a 3-stage LDS ring (fp16), 30..34 streaming 3x3 (small C, fp16) */
 int y5_conv_num_cfgs(void);
 int y5_conv_cfg_info(int cfg, int* bm_pixels, int* bn_channels, int* k_bytes_per_stage);
 

@@ -36,6 +36,13 @@ CASES = [
     (5, 8, 16, 128, 128, 1, 1, 0, 1, False, True, 19, 1, "f16"),
     (3, 8, 16, 128, 120, 1, 1, 0, 1, False, False, 20, 2, "f16"),  # C2 not a multiple of 32 (Npad 128)
     (6, 8, 16, 128, 64, 1, 1, 0, 1, False, False, 21, 1, "f16"),
+    # streaming 3x3 kernel (conv_k3.h): borders on all sides, partial workgroup tile, residual (in place), stride 2
+    (2, 8, 16, 32, 32, 3, 1, 1, 1, True, False, 30, 1, "f16"),
+    (1, 12, 8, 32, 32, 3, 1, 1, 1, False, False, 33, 2, "f16"),
+    (2, 16, 32, 32, 64, 3, 2, 1, 1, False, False, 31, 1, "f16"),
+    (1, 24, 16, 32, 64, 3, 2, 1, 1, False, False, 34, 1, "f16"),
+    (3, 8, 8, 64, 64, 3, 1, 1, 1, True, False, 32, 1, "f16"),
+    (1, 4, 24, 64, 56, 3, 1, 1, 1, False, False, 32, 2, "f16"),
 ] + [
     # every fp16 tile configuration on one shape with M, N tails and K = 9*64 (uniform) / 9*48 (table for BK64)
     (2, 9, 9, c1, 160, 3, 1, 1, 1, True, False, cfg, 2, "f16") for cfg in list(range(14)) + list(range(22, 30)) for c1 in (64, 48)

@@ -58,6 +58,13 @@ CONV_CASES = [
     (16, 40, 40, 128, 128, 1, 1, 0, 1, False, True, 19, 8, "f16"),
     (64, 20, 20, 128, 120, 1, 1, 0, 1, False, False, 20, 0, "f16"),
     (5, 4, 8, 128, 64, 1, 1, 0, 1, False, False, 21, 1, "f16"),
+    # streaming 3x3 kernel (conv_k3.h, cfg 30..34)
+    (8, 40, 40, 32, 32, 3, 1, 1, 1, True, False, 30, 8, "f16"),
+    (8, 40, 40, 32, 32, 3, 1, 1, 1, False, False, 33, 0, "f16"),
+    (8, 80, 80, 32, 64, 3, 2, 1, 1, False, False, 31, 8, "f16"),
+    (4, 80, 80, 32, 64, 3, 2, 1, 1, False, False, 34, 0, "f16"),
+    (8, 40, 40, 64, 64, 3, 1, 1, 1, True, False, 32, 8, "f16"),
+    (2, 20, 24, 64, 56, 3, 1, 1, 1, False, False, 32, 0, "f16"),
 ]
 
 

@@ -5,6 +5,7 @@
 #include "conv_igemm.h"
 #include "conv_pw.h"
 #include "conv_stem.h"
+#include "conv_k3.h"
 #include "y5_host.h"
 
 namespace {
@@ -177,6 +178,61 @@ int launch_pw_by_cfg(const Y5ConvParams& p, int idx, int mb, hipStream_t s) {
   return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown pointwise config");
 }
 
+// ---- streaming 3x3 configurations (conv_k3.h): ids kK3_0 + index ------------------------------------------------
+struct K3Cfg { int c1, nt, sh, s; };
+constexpr int kK3_0 = 30, kNumK3 = 5;
+constexpr K3Cfg kK3Cfgs[kNumK3] = {
+    {32, 1, 1, 3},  // 30: 3x3 s1 32->32, 3 stages   (Bottleneck.cv2 @160)
+    {32, 2, 2, 2},  // 31: 3x3 s2 32->64, 2 stages   (Conv 1 @320->160)
+    {64, 2, 1, 2},  // 32: 3x3 s1 64->64, 2 stages   (Bottleneck.cv2 @80)
+    {32, 1, 1, 2},  // 33: 3x3 s1 32->32, 2 stages
+    {32, 2, 2, 3},  // 34: 3x3 s2 32->64, 3 stages
+};
+
+template <int C1, int NT, int SH, int S>
+int launch_k3(const Y5ConvParams& p, int max_blocks, hipStream_t stream) {
+  const size_t lds = y5_conv_k3_lds_bytes<C1, NT, SH, S>();
+  if (lds > 160 * 1024) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: 3x3 streaming configuration exceeds 160 KiB of LDS");
+  const void* kern = p.res ? reinterpret_cast<const void*>(y5_conv_k3_kernel<C1, NT, SH, S, true>)
+                           : reinterpret_cast<const void*>(y5_conv_k3_kernel<C1, NT, SH, S, false>);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(y5_conv_k3_kernel<C1, NT, SH, S, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(y5_conv_k3_kernel<C1, NT, SH, S, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const long long nwt = (long long)p.B * (p.OH / 4) * (p.OW / 8);
+  const long long nbt = (nwt + 3) >> 2;
+  long long G = max_blocks;
+  if (G <= 0) {
+    if (!g_num_cu) {
+      int dev = 0, n = 0;
+      hipGetDevice(&dev);
+      hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+      g_num_cu = n > 0 ? n : 256;
+    }
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, lds) != hipSuccess || occ < 1) occ = 1;
+    G = (long long)g_num_cu * occ;
+  }
+  if (G > nbt) G = nbt;
+  if (G >= 8) G &= ~7LL;
+  if (p.res) hipLaunchKernelGGL((y5_conv_k3_kernel<C1, NT, SH, S, true>), dim3((unsigned)G), dim3(256), lds, stream, p);
+  else hipLaunchKernelGGL((y5_conv_k3_kernel<C1, NT, SH, S, false>), dim3((unsigned)G), dim3(256), lds, stream, p);
+  return y5_check_launch("y5_conv2d_fwd(k3)");
+}
+
+int launch_k3_by_cfg(const Y5ConvParams& p, int idx, int mb, hipStream_t s) {
+  switch (idx) {
+    case 0: return launch_k3<32, 1, 1, 3>(p, mb, s);
+    case 1: return launch_k3<32, 2, 2, 2>(p, mb, s);
+    case 2: return launch_k3<64, 2, 1, 2>(p, mb, s);
+    case 3: return launch_k3<32, 1, 1, 2>(p, mb, s);
+    case 4: return launch_k3<32, 2, 2, 3>(p, mb, s);
+  }
+  return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown 3x3 streaming config");
+}
+
 int default_cfg(const y5_conv_desc* d) {
   const int n = d->Npad;
   if (d->dtype == Y5_F32) return n <= 32 ? 0 : n <= 64 ? 1 : 2;
@@ -192,6 +248,13 @@ extern "C" int y5_conv_num_cfgs(void) { return Y5_CONV_NUM_CFGS; }
 
 extern "C" int y5_conv_cfg_info(int cfg, int* bm, int* bn, int* bk_bytes) {
   if (cfg < 0 || cfg >= Y5_CONV_NUM_CFGS) return y5_fail(Y5_ERR_BAD_ARG, "conv_cfg_info: bad id");
+  if (cfg >= kK3_0) {
+    const K3Cfg& c = kK3Cfgs[cfg - kK3_0];
+    if (bm) *bm = 128;
+    if (bn) *bn = c.nt * 32;
+    if (bk_bytes) *bk_bytes = 9 * c.c1 * 2;
+    return Y5_OK;
+  }
   if (cfg >= kRing0) cfg = kRingBase[cfg - kRing0];
   if (cfg >= kNumIgemm) {
     const PwCfg& c = kPwCfgs[cfg - kNumIgemm];
@@ -216,7 +279,8 @@ extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w
   int cfg = d->cfg < 0 ? default_cfg(d) : d->cfg;
   if (cfg >= Y5_CONV_NUM_CFGS) return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown tile config");
   const bool pw = cfg >= kNumIgemm && cfg < kRing0;
-  const int bk = pw ? 8 : kCfgs[cfg >= kRing0 ? kRingBase[cfg - kRing0] : cfg].rb / es;
+  const bool k3 = cfg >= kK3_0;
+  const int bk = (pw || k3) ? 8 : kCfgs[cfg >= kRing0 ? kRingBase[cfg - kRing0] : cfg].rb / es;
   if (cfg >= kRing0 && d->dtype != Y5_F16) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: ring configurations are fp16 only");
   if (d->C1 % epp || d->ldx % epp) return y5_fail(Y5_ERR_BAD_ARG, "conv: C1 and ldx must be multiples of 16 bytes");
   if (d->C2 % epp || (y && d->ldy % epp) || (residual && d->ldr % epp) || (y_up2 && d->ld2 % epp))
@@ -244,6 +308,13 @@ extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w
   p.x_bytes = (unsigned)((((long long)d->B * d->H * d->W - 1) * d->ldx + d->C1) * es);
   p.w_bytes = (unsigned)((long long)d->Npad * d->Kpad * es);
 
+  if (k3) {
+    const K3Cfg& c = kK3Cfgs[cfg - kK3_0];
+    if (d->dtype != Y5_F16 || d->KH != 3 || d->KW != 3 || d->SH != c.sh || d->SW != c.sh || d->PH != 1 || d->PW != 1 || !y || y_up2 ||
+        d->act != 1 || d->C1 != c.c1 || d->Npad != c.nt * 32 || (oh & 3) || (ow & 7) || d->Kpad < 9 * c.c1 || d->H > 255 * 4 || d->W > 65535)
+      return y5_fail(Y5_ERR_UNSUPPORTED, "conv: 3x3 streaming configuration does not match this layer");
+    return launch_k3_by_cfg(p, cfg - kK3_0, d->max_blocks, stream);
+  }
   if (pw) {
     const PwCfg& c = kPwCfgs[cfg - kNumIgemm];
     if (d->dtype != Y5_F16 || d->KH != 1 || d->KW != 1 || d->SH != 1 || d->SW != 1 || d->PH || d->PW || residual || !y || d->act != 1 ||

@@ -1,0 +1,213 @@
+// 3x3 (pad 1, stride 1 or 2) convolution for the HBM-bound, small-channel layers of the YOLOv5 backbone
+// (Conv 1 `3x3 s2 32->64 @320`, Bottleneck.cv2 `3x3 32->32 @160`, `3x3 64->64 @80`: models/yolov5s.yaml:18-21,
+// models/common.py:164-181).  Streaming structure of conv_pw.h -- filter resident in LDS, wave-private rings of
+// LDS-DMA stages retired with counted vmcnt, no barriers in the loop -- applied to a spatial convolution:
+//   * a wave tile is a 4x8 block of output pixels; its receptive field ((3+3s) x (7s+3) input pixels, all C1
+//     channels) is staged ONCE per tile as whole pixels (C1*2 bytes each, 16-byte pieces XOR-swizzled on the source
+//     side), so every input element crosses L2->LDS 1.9x (s=1) instead of the 9x of an im2col stage;
+//   * the nine taps are nine different LDS row offsets of the same stage: the MFMA B-fragment of lane (pixel p, k-half g)
+//     for tap (kh,kw) is one ds_read_b128 at a per-lane address computed once per kernel;
+//   * padding taps / image borders come from buffer-addressed LDS-DMA with out-of-range offsets (zero fill);
+//   * the Bottleneck residual (common.py:181) is fetched with ordinary loads at tile start and added in the epilogue.
+#pragma once
+#include "conv_pw.h"
+
+template <int C1, int NT, int SH, int S>
+constexpr size_t y5_conv_k3_lds_bytes() {
+  constexpr int RH = 3 * SH + 3, RW = 7 * SH + 3, NSL = C1 / 8;
+  constexpr int NI = (RH * RW * NSL + 63) / 64;
+  return (size_t)NT * 32 * 9 * C1 * 2 + (size_t)NT * 32 * 4 + (size_t)4 * S * NI * 1024;
+}
+
+template <int C1, int NT, int SH, int S, bool RES>
+__global__ __launch_bounds__(256)
+void y5_conv_k3_kernel(const Y5ConvParams p) {
+  typedef half_t T;
+  constexpr int NPAD = 32 * NT;
+  constexpr int TR = 4, TC = 8;                       // wave tile: 4 x 8 output pixels
+  constexpr int RH = (TR - 1) * SH + 3, RW = (TC - 1) * SH + 3;  // receptive field in input pixels
+  constexpr int NSL = C1 / 8;                         // 16-byte slots per pixel
+  constexpr int ROWB = C1 * 2;                        // bytes per staged pixel
+  constexpr int NPIECE = RH * RW * NSL;
+  constexpr int NI = (NPIECE + 63) / 64;              // LDS-DMA instructions per tile
+  constexpr int STAGE = NI * 1024;
+  constexpr int K2 = 9 * C1 * 2;                      // bytes per filter row in LDS
+  constexpr int WSL = 9 * NSL;                        // 16-byte slots per filter row
+  constexpr int W_BYTES = NPAD * K2;
+  constexpr int KS = C1 / 16;                         // MFMA k-steps per tap
+  constexpr int SPR = NPAD / 8, RPP = 64 / SPR, NPASS = 32 / RPP;
+  constexpr int SWM = SPR >= 8 ? 7 : SPR - 1;
+  constexpr int LP = NI, SP = NPASS, RP = RES ? NPASS : 0;
+  static_assert(STAGE >= 32 * NPAD * 2, "epilogue scratch must fit in a stage");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* wlds = smem;
+  float* blds = reinterpret_cast<float*>(smem + W_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* ring = smem + W_BYTES + NPAD * 4 + wave * (S * STAGE);
+
+  const y5_rsrc_t xrs = y5_make_rsrc(p.x, p.x_bytes);
+  const y5_rsrc_t wrs = y5_make_rsrc(p.w, p.w_bytes);
+  T* __restrict__ yg = static_cast<T*>(p.y);
+  const T* rg = static_cast<const T*>(p.res);  // may alias y (in-place residual)
+
+  auto fsw = [](int q) { return C1 == 32 ? ((q >> 2) & 3) : ((q >> 1) & 7); };  // pixel-row swizzle (64 / 128-byte rows)
+
+  // ---- prologue: filter (swizzled per row like the activation rows) + bias into LDS ---------------------------
+  {
+    constexpr int WI = NPAD * WSL / 64;
+    for (int I = wave; I < WI; I += 4) {
+      const int pidx = I * 64 + lane;
+      const int n = pidx / WSL, ps = pidx - n * WSL;
+      const int src_slot = (ps & ~(NSL - 1)) | ((ps & (NSL - 1)) ^ fsw(n));
+      y5_bglds16(wrs, (unsigned)((n * p.Kpad) * 2 + src_slot * 16), wlds + I * 1024);
+    }
+    for (int i = tid; i < NPAD; i += 256) blds[i] = p.bias[i];
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+  }
+
+  // ---- per-lane constants -----------------------------------------------------------------------------------
+  // (a) the NI pieces this lane stages: pixel q = (r, cq) of the receptive field, channel slot cs
+  int pc_rel[NI];   // byte offset relative to the tile's (ih0, iw0) pixel, source-swizzled slot included
+  int pc_rc[NI];    // r | cq << 8 | valid << 16
+#pragma unroll
+  for (int I = 0; I < NI; ++I) {
+    const int idx = I * 64 + lane;
+    const int q = idx / NSL, cs = idx - q * NSL;
+    const int r = q / RW, cq = q - r * RW;
+    pc_rel[I] = ((r * p.W + cq) * p.ldx) * 2 + ((cs ^ fsw(q)) * 16);
+    pc_rc[I] = r | (cq << 8) | ((idx < NPIECE ? 1 : 0) << 16);
+  }
+  // (b) fragment read addresses: lane (pixel pl = lane & 31, k-half g), tap t, k-step ks
+  const int g = lane >> 5, pl = lane & 31;
+  const int q0 = ((pl >> 3) * SH) * RW + (pl & 7) * SH;
+  int rd[9][KS];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int q = q0 + (t / 3) * RW + (t % 3);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) rd[t][ks] = q * ROWB + (((ks * 2 + g) ^ fsw(q)) * 16);
+  }
+  int wsl[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) wsl[ks] = pl * K2 + (((ks * 2 + g) ^ fsw(pl)) * 16);
+  const int orow = lane / SPR, oslot = lane % SPR;
+
+  // ---- tile schedule ---------------------------------------------------------------------------------------------
+  const int tw = p.OW / TC, th = p.OH / TR;
+  const int nwt = p.B * th * tw;
+  const int G = gridDim.x, bid = blockIdx.x;
+  const int nbt = (nwt + 3) >> 2;
+  const int nmine = (nbt - bid + G - 1) / G;
+  auto tile_id = [&](int j) { return y5_xcd_remap(bid + j * G, nbt) * 4 + wave; };
+  int nw = nmine;
+  if (nw > 0 && tile_id(nw - 1) >= nwt) --nw;
+  auto tile_origin = [&](int j, int& b, int& oh0, int& ow0) {
+    const int t = tile_id(j);
+    const int tx = t % tw, r = t / tw;
+    const int ty = r % th;
+    b = r / th; oh0 = ty * TR; ow0 = tx * TC;
+  };
+
+  auto issue = [&](int j, int buf) {
+    int b, oh0, ow0;
+    tile_origin(j, b, oh0, ow0);
+    const int ih0 = oh0 * SH - 1, iw0 = ow0 * SH - 1;
+    const int base = ((b * p.H + ih0) * p.W + iw0) * p.ldx * 2;
+    const bool interior = ih0 >= 0 && ih0 + RH <= p.H && iw0 >= 0 && iw0 + RW <= p.W;  // wave-uniform
+    char* dst = ring + buf * STAGE;
+#pragma unroll
+    for (int I = 0; I < NI; ++I) {
+      bool ok = (pc_rc[I] >> 16) != 0;
+      if (!interior) {
+        const int ih = ih0 + (pc_rc[I] & 0xff), iw = iw0 + ((pc_rc[I] >> 8) & 0xff);
+        ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      }
+      y5_bglds16(xrs, ok ? (unsigned)(base + pc_rel[I]) : Y5_OOB, dst + I * 1024);
+    }
+  };
+
+  for (int s = 0; s < S; ++s)
+    if (s < nw) issue(s, s);
+
+  int buf = 0;
+  for (int i = 0; i < nw; ++i) {
+    constexpr int PER = LP + SP + RP;
+    if (i + S - 1 >= nw) {
+      y5_wait_vm<0>();
+    } else if (i < S - 1) {
+      switch (i) {
+        case 0: y5_wait_vm<(S - 1) * LP>(); break;
+        case 1: y5_wait_vm<(S - 1) * LP + (SP + RP)>(); break;
+        case 2: y5_wait_vm<(S - 1) * LP + 2 * (SP + RP)>(); break;
+        default: y5_wait_vm<(S - 1) * LP>(); break;
+      }
+    } else {
+      y5_wait_vm<(S - 1) * PER>();
+    }
+    __builtin_amdgcn_wave_barrier();
+    char* st = ring + buf * STAGE;
+    int b, oh0, ow0;
+    tile_origin(i, b, oh0, ow0);
+    // output pixel of this lane's store rows (row = ps*RPP + orow of the 32 tile pixels)
+    uint4_t resv[NPASS];
+    if constexpr (RES) {
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int row = ps * RPP + orow;
+        const size_t m = ((size_t)b * p.OH + oh0 + (row >> 3)) * p.OW + ow0 + (row & 7);
+        resv[ps] = *reinterpret_cast<const uint4_t*>(rg + m * p.ldr + oslot * 8);
+      }
+    }
+    float16_t acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const half8_t af = *reinterpret_cast<const half8_t*>(st + rd[t][ks]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const half8_t wf = *reinterpret_cast<const half8_t*>(wlds + j * 32 * K2 + t * NSL * 16 + wsl[ks]);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, af, acc[j], 0, 0, 0);
+        }
+      }
+    // epilogue: bias + SiLU -> scratch (vacated stage) -> (+ residual) -> 16-byte stores
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4_t bv = *reinterpret_cast<const float4_t*>(blds + j * 32 + q * 8 + g * 4);
+        half4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (half_t)y5_silu(acc[j][q * 4 + e] + bv[e]);
+        const int slot = j * 4 + q;
+        *reinterpret_cast<half4_t*>(st + pl * (NPAD * 2) + ((slot ^ (pl & SWM)) * 16) + g * 8) = o;
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int row = ps * RPP + orow;
+      uint4_t raw = *reinterpret_cast<const uint4_t*>(st + row * (NPAD * 2) + ((oslot ^ (row & SWM)) * 16));
+      if constexpr (RES) {
+        half8_t a = __builtin_bit_cast(half8_t, raw), r8 = __builtin_bit_cast(half8_t, resv[ps]), c;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) c[e] = (half_t)((float)a[e] + (float)r8[e]);
+        raw = __builtin_bit_cast(uint4_t, c);
+      }
+      const size_t m = ((size_t)b * p.OH + oh0 + (row >> 3)) * p.OW + ow0 + (row & 7);
+      const int n = oslot * 8;
+      if (n < p.C2) *reinterpret_cast<uint4_t*>(yg + m * p.ldy + n) = raw;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (i + S < nw) issue(i + S, buf);
+    buf = buf + 1 == S ? 0 : buf + 1;
+  }
+}

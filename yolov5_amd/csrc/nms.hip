@@ -6,8 +6,8 @@
 #include "y5_host.h"
 
 namespace {
-struct Layout { size_t off_count, off_keys, off_cls, total; long long cap, cap_pad; };
-Layout layout(int bs, int n, int no, int nm, int flags) {
+struct Layout { size_t off_count, off_keys, off_cls, off_gbox, total; long long cap, cap_pad, gcap; };
+Layout layout(int bs, int n, int no, int nm, int flags, int max_nms) {
   Layout L{};
   const int nc = no - 5 - nm;
   L.cap = (flags & Y5_NMS_MULTI_LABEL) && nc > 1 ? (long long)n * nc : n;
@@ -18,14 +18,16 @@ Layout layout(int bs, int n, int no, int nm, int flags) {
   L.off_count = o; o += ((size_t)bs * 4 + 255) & ~(size_t)255;
   L.off_keys = o; o += ((size_t)bs * L.cap_pad * 8 + 255) & ~(size_t)255;
   L.off_cls = o; o += ((size_t)bs * n + 255) & ~(size_t)255;
+  L.gcap = L.cap < max_nms ? L.cap : max_nms;
+  if (L.gcap < 64) L.gcap = 64;
+  L.off_gbox = o; o += ((size_t)bs * L.gcap * Y5_NMS_REC * 4 + 255) & ~(size_t)255;
   L.total = o;
   return L;
 }
 }  // namespace
 
 extern "C" size_t y5_nms_workspace_bytes(int bs, int n, int no, int nm, int flags, int max_nms) {
-  (void)max_nms;
-  return layout(bs, n, no, nm, flags).total;
+  return layout(bs, n, no, nm, flags, max_nms > 0 ? max_nms : 30000).total;
 }
 
 extern "C" int y5_nms_batched(const void* pred, int dt, int bs, int n, int no, int nm, float conf_thres, float iou_thres, int max_det,
@@ -40,7 +42,8 @@ extern "C" int y5_nms_batched(const void* pred, int dt, int bs, int n, int no, i
   if (max_det < 1 || max_det > Y5_NMS_MAX_DET_CAP) return y5_fail(Y5_ERR_UNSUPPORTED, "nms: max_det out of range [1,4096]");
   if (dt != Y5_F16 && dt != Y5_F32) return y5_fail(Y5_ERR_BAD_ARG, "nms: dtype");
   if ((flags & Y5_NMS_MULTI_LABEL) && nc <= 1) flags &= ~Y5_NMS_MULTI_LABEL;  // general.py:693
-  const Layout L = layout(bs, n, no, nm, flags);
+  if (max_nms < 1) return y5_fail(Y5_ERR_BAD_ARG, "nms: max_nms must be positive");
+  const Layout L = layout(bs, n, no, nm, flags, max_nms);
   if (ws_bytes < L.total || ((uintptr_t)ws & 255)) return y5_fail(Y5_ERR_WORKSPACE, "nms: workspace too small or misaligned");
 
   Y5NmsParams p{};
@@ -53,7 +56,8 @@ extern "C" int y5_nms_batched(const void* pred, int dt, int bs, int n, int no, i
   p.count = reinterpret_cast<int*>(w + L.off_count);
   p.keys = reinterpret_cast<unsigned long long*>(w + L.off_keys);
   p.best_cls = reinterpret_cast<unsigned char*>(w + L.off_cls);
-  p.cap = L.cap; p.cap_pad = L.cap_pad;
+  p.gbox = reinterpret_cast<float*>(w + L.off_gbox);
+  p.cap = L.cap; p.cap_pad = L.cap_pad; p.gcap = L.gcap;
 
   if (hipMemsetAsync(p.count, 0, (size_t)bs * 4, st) != hipSuccess) return y5_fail(Y5_ERR_RUNTIME, "nms: memset failed");
   const dim3 fg((unsigned)((n + 255) / 256), (unsigned)bs), fb(256);
@@ -64,10 +68,15 @@ extern "C" int y5_nms_batched(const void* pred, int dt, int bs, int n, int no, i
     hipFuncSetAttribute((const void*)y5_nms_greedy_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     attr = true;
   }
-  const size_t greedy_lds = (size_t)max_det * 20 + 5 * 64 * 4 + 64 * 8 + Y5_NMS_GREEDY_WAVES * 8 + 16;
+  const size_t greedy_lds = (size_t)max_det * 20 + 2 * Y5_NMS_REC * 64 * 4 + 64 * 8 + Y5_NMS_GREEDY_WAVES * 8 + 16;
   if (dt == Y5_F16) hipLaunchKernelGGL((y5_nms_filter_kernel<half_t>), fg, fb, 0, st, p);
   else hipLaunchKernelGGL((y5_nms_filter_kernel<float>), fg, fb, 0, st, p);
   hipLaunchKernelGGL(y5_nms_sort_kernel, dim3((unsigned)bs), dim3(1024), Y5_NMS_SORT_LDS_KEYS * 8, st, p);
+  {
+    const dim3 gg((unsigned)((L.gcap + 255) / 256), (unsigned)bs);
+    if (dt == Y5_F16) hipLaunchKernelGGL((y5_nms_gather_kernel<half_t>), gg, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((y5_nms_gather_kernel<float>), gg, dim3(256), 0, st, p);
+  }
   if (dt == Y5_F16) hipLaunchKernelGGL((y5_nms_greedy_kernel<half_t>), dim3((unsigned)bs), dim3(64 * Y5_NMS_GREEDY_WAVES), greedy_lds, st, p);
   else hipLaunchKernelGGL((y5_nms_greedy_kernel<float>), dim3((unsigned)bs), dim3(64 * Y5_NMS_GREEDY_WAVES), greedy_lds, st, p);
   return y5_check_launch("y5_nms_batched");

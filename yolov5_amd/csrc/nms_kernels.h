@@ -29,7 +29,8 @@ struct Y5NmsParams {
   int* count;                 // [bs]
   unsigned long long* keys;   // [bs][cap_pad]
   unsigned char* best_cls;    // [bs][n] (best-class mode)
-  long long cap, cap_pad;
+  float* gbox;                // [bs][gcap][12]: bx1,by1,bx2,by2,area, x1,y1,x2,y2,conf,cls, row index (as int bits)
+  long long cap, cap_pad, gcap;
 };
 
 template <typename T> __device__ __forceinline__ float y5_ldf(const T* p, long long i) { return (float)p[i]; }
@@ -155,9 +156,40 @@ __global__ void y5_nms_sort_kernel(const Y5NmsParams p) {
   }
 }
 
+// ---- K2b: gather -- sorted keys -> compact per-candidate records (fully parallel over the GPU) ---------------
+// Takes the dependent key -> row -> box load chain off the serial greedy walk: record ci of image b =
+// {class-offset box, area, output box, conf, cls, row}, 48 bytes, read back coalesced (and prefetched) by K3.
+#define Y5_NMS_REC 12
+template <typename T>
+__global__ void y5_nms_gather_kernel(const Y5NmsParams p) {
+  const int b = blockIdx.y;
+  const long long ci = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long n = p.count[b];
+  if (n > p.cap) n = p.cap;
+  if (n > p.max_nms) n = p.max_nms;
+  if (ci >= n) return;
+  const unsigned long long key = p.keys[(long long)b * p.cap_pad + ci];
+  const float conf = __uint_as_float((unsigned)(key >> 32));
+  const unsigned idx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
+  long long rowi;
+  int cls;
+  if (p.flags & 1) { rowi = idx / (unsigned)p.nc; cls = (int)(idx - (unsigned)rowi * (unsigned)p.nc); }
+  else { rowi = idx; cls = p.best_cls[(long long)b * p.n + rowi]; }
+  const T* row = static_cast<const T*>(p.pred) + ((long long)b * p.n + rowi) * p.no;
+  const float cx = (float)row[0], cy = (float)row[1], w = (float)row[2], h = (float)row[3];
+  const float hw = w / 2.0f, hh = h / 2.0f;
+  const float x1 = cx - hw, y1 = cy - hh, x2 = cx + hw, y2 = cy + hh;   // general.py:722 xywh2xyxy
+  const float clsf = (float)cls;
+  const float c = clsf * ((p.flags & 2) ? 0.0f : p.max_wh);             // general.py:748
+  const float bx1 = x1 + c, by1 = y1 + c, bx2 = x2 + c, by2 = y2 + c;
+  float* r = p.gbox + ((long long)b * p.gcap + ci) * Y5_NMS_REC;
+  r[0] = bx1; r[1] = by1; r[2] = bx2; r[3] = by2; r[4] = (bx2 - bx1) * (by2 - by1);
+  r[5] = x1; r[6] = y1; r[7] = x2; r[8] = y2; r[9] = conf; r[10] = clsf; r[11] = __uint_as_float((unsigned)rowi);
+}
+
 // ---- K3: greedy suppression, kept boxes in LDS -------------------------------------------------------
-// One workgroup of 16 waves per image walks the sorted candidates in chunks of 64:
-//   (0) wave 0 decodes the chunk (box, class offset, area) into LDS;
+// One workgroup of 16 waves per image walks the sorted candidates in chunks of 64 (records double-buffered in LDS:
+// wave 1 prefetches chunk c+1 from the compact array while chunk c is resolved):
 //   (A) every wave tests the 64 candidates (lane = candidate) against a 1/16 slice of the kept list -> suppression ballots;
 //   (M) every wave also forms 4 rows of the chunk's 64x64 "i suppresses j > i" bit matrix (one ballot per row);
 //   (B) wave 0 resolves the chunk serially with scalar bit operations only (ctz / readlane / andn2), then appends the
@@ -169,57 +201,42 @@ __global__ __launch_bounds__(1024)
 void y5_nms_greedy_kernel(const Y5NmsParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* kept = reinterpret_cast<float*>(smem);                                   // [max_det][5]: x1,y1,x2,y2 (class offset), area
-  float* cand = kept + (size_t)p.max_det * 5;                                     // [5][64]
-  unsigned long long* matrix = reinterpret_cast<unsigned long long*>(cand + 5 * 64);  // [64]
+  float* cand = kept + (size_t)p.max_det * 5;                                     // [2][12][64] (record fields x candidates)
+  unsigned long long* matrix = reinterpret_cast<unsigned long long*>(cand + 2 * Y5_NMS_REC * 64);  // [64]
   unsigned long long* supmask = matrix + 64;                                      // [16]
   int* s_nkept = reinterpret_cast<int*>(supmask + Y5_NMS_GREEDY_WAVES);
 
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const unsigned long long* keys = p.keys + (long long)b * p.cap_pad;
   long long n = p.count[b];
   if (n > p.cap) n = p.cap;
   if (n > p.max_nms) n = p.max_nms;
+  const float* gb = p.gbox + (long long)b * p.gcap * Y5_NMS_REC;
   const T* pred = static_cast<const T*>(p.pred) + (long long)b * p.n * p.no;
   const int mi = 5 + p.nc;
   const int ow = 6 + p.nm;
   float* out = p.out + (long long)b * p.max_det * ow;
-  const float cmul = (p.flags & 2) ? 0.0f : p.max_wh;
 
   if (tid == 0) *s_nkept = 0;
+  if (wave == 1 || Y5_NMS_GREEDY_WAVES == 1) {  // chunk 0 -> buffer 0
+    for (int f = 0; f < Y5_NMS_REC; ++f) cand[f * 64 + lane] = lane < n ? gb[(long long)lane * Y5_NMS_REC + f] : 0.f;
+  }
   __syncthreads();
-  int nkept = 0;
+  int nkept = 0, cb = 0;
 
-  for (long long base = 0; base < n && nkept < p.max_det; base += 64) {
-    // (0) decode the chunk
-    float x1 = 0, y1 = 0, x2 = 0, y2 = 0, conf = 0, clsf = 0;
-    long long rowi = 0;
-    if (wave == 0) {
-      const long long ci = base + lane;
-      float bx1 = 0, by1 = 0, bx2 = 0, by2 = 0, area = 0;
-      if (ci < n) {
-        const unsigned long long key = keys[ci];
-        conf = __uint_as_float((unsigned)(key >> 32));
-        const unsigned idx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
-        int cls;
-        if (p.flags & 1) { rowi = idx / (unsigned)p.nc; cls = (int)(idx - (unsigned)rowi * (unsigned)p.nc); }
-        else { rowi = idx; cls = p.best_cls[(long long)b * p.n + rowi]; }
-        const T* row = pred + rowi * p.no;
-        const float cx = (float)row[0], cy = (float)row[1], w = (float)row[2], h = (float)row[3];
-        const float hw = w / 2.0f, hh = h / 2.0f;
-        x1 = cx - hw; y1 = cy - hh; x2 = cx + hw; y2 = cy + hh;
-        clsf = (float)cls;
-        const float c = clsf * cmul;
-        bx1 = x1 + c; by1 = y1 + c; bx2 = x2 + c; by2 = y2 + c;
-        area = (bx2 - bx1) * (by2 - by1);
-      }
-      cand[0 * 64 + lane] = bx1; cand[1 * 64 + lane] = by1; cand[2 * 64 + lane] = bx2; cand[3 * 64 + lane] = by2;
-      cand[4 * 64 + lane] = area;
+  for (long long base = 0; base < n && nkept < p.max_det; base += 64, cb ^= 1) {
+    const float* cd = cand + cb * (Y5_NMS_REC * 64);
+    // prefetch: wave 1 pulls the next chunk's records into registers now, parks them in the other buffer below
+    float nxt[Y5_NMS_REC];
+    const bool do_pf = wave == 1 && base + 64 < n;
+    if (do_pf) {
+      const long long ci = base + 64 + lane;
+#pragma unroll
+      for (int f = 0; f < Y5_NMS_REC; ++f) nxt[f] = ci < n ? gb[ci * Y5_NMS_REC + f] : 0.f;
     }
-    __syncthreads();
     const bool valid = base + lane < n;
-    const float bx1 = cand[lane], by1 = cand[64 + lane], bx2 = cand[128 + lane], by2 = cand[192 + lane], area = cand[256 + lane];
+    const float bx1 = cd[lane], by1 = cd[64 + lane], bx2 = cd[128 + lane], by2 = cd[192 + lane], area = cd[256 + lane];
     // (A) against the kept list
     bool sup = false;
     for (int k = wave; k < nkept; k += Y5_NMS_GREEDY_WAVES) {
@@ -236,13 +253,18 @@ void y5_nms_greedy_kernel(const Y5NmsParams p) {
 #pragma unroll
     for (int q = 0; q < 64 / Y5_NMS_GREEDY_WAVES; ++q) {
       const int i = wave * (64 / Y5_NMS_GREEDY_WAVES) + q;
-      const float kx1 = cand[i], ky1 = cand[64 + i], kx2 = cand[128 + i], ky2 = cand[192 + i], ka = cand[256 + i];
+      const float kx1 = cd[i], ky1 = cd[64 + i], kx2 = cd[128 + i], ky2 = cd[192 + i], ka = cd[256 + i];
       const float iw = fmaxf(0.0f, fminf(kx2, bx2) - fmaxf(kx1, bx1));
       const float ih = fmaxf(0.0f, fminf(ky2, by2) - fmaxf(ky1, by1));
       const float inter = iw * ih;
       const bool s2 = lane > i && (inter / (ka + area - inter)) > p.iou_thres;
       const unsigned long long mm = __ballot(s2);
       if (lane == 0) matrix[i] = mm;
+    }
+    if (do_pf) {
+      float* cn = cand + (cb ^ 1) * (Y5_NMS_REC * 64);
+#pragma unroll
+      for (int f = 0; f < Y5_NMS_REC; ++f) cn[f * 64 + lane] = nxt[f];
     }
     __syncthreads();
     // (B) serial resolution on wave 0: uniform bit arithmetic only
@@ -268,10 +290,14 @@ void y5_nms_greedy_kernel(const Y5NmsParams p) {
         kept[slot * 5 + 0] = bx1; kept[slot * 5 + 1] = by1; kept[slot * 5 + 2] = bx2; kept[slot * 5 + 3] = by2;
         kept[slot * 5 + 4] = area;
         float* o = out + (long long)slot * ow;
-        o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = conf; o[5] = clsf;
-        const T* row = pred + rowi * p.no;
-        const float obj = (float)row[4];
-        for (int q = 0; q < p.nm; ++q) o[6 + q] = (float)row[mi + q] * obj;  // general.py:719 scales masks too
+        o[0] = cd[5 * 64 + lane]; o[1] = cd[6 * 64 + lane]; o[2] = cd[7 * 64 + lane]; o[3] = cd[8 * 64 + lane];
+        o[4] = cd[9 * 64 + lane]; o[5] = cd[10 * 64 + lane];
+        if (p.nm > 0) {
+          const long long rowi = (long long)__float_as_uint(cd[11 * 64 + lane]);
+          const T* row = pred + rowi * p.no;
+          const float obj = (float)row[4];
+          for (int q = 0; q < p.nm; ++q) o[6 + q] = (float)row[mi + q] * obj;  // general.py:719 scales masks too
+        }
       }
       if (lane == 0) *s_nkept = cnt;
     }
