@@ -127,6 +127,27 @@ int y5_nms_batched(const void* pred, int dtype, int bs, int n, int no, int nm, f
                    float* out, int* out_count, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Train-mode Conv block pieces (models/common.py:82-88 `Conv.forward` = SiLU(BatchNorm2d(conv(x))) with BATCH
+ * statistics; eps / momentum as set by initialize_weights, models/yolo.py:259).  z = raw conv output (y5_conv2d_fwd
+ * with act = 0 and zero bias), NHWC slice, npix = B*OH*OW pixels, C channels (C*elemsize % 16 == 0).
+ * y5_bn_silu_fwd: batch mean / biased variance per channel (deterministic two-level reduction) -> save_mean,
+ *   save_invstd = 1/sqrt(var+eps); running stats updated like torch (unbiased variance, momentum); then
+ *   y = [residual +] silu(gamma*(z-mean)*invstd + beta)   (residual = Bottleneck shortcut, common.py:181).
+ * y5_bn_silu_bwd: dy -> dz (gradient w.r.t. the conv output), dgamma, dbeta (fp32).
+ * y5_channel_sum: out[c] = sum over pixels of x[., c]  (bias gradient of Detect.m[i], models/yolo.py:95).
+ * workspace: y5_bn_workspace_bytes(C, npix) bytes, 16-byte aligned.
+ * ------------------------------------------------------------------------------------------------------- */
+size_t y5_bn_workspace_bytes(int C, long long npix);
+int y5_bn_silu_fwd(const void* z, int dtype, long long npix, int C, int ldz, const float* gamma, const float* beta, float eps,
+                   float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                   const void* residual, int ldr, void* y, int ldy, void* workspace, size_t workspace_bytes, void* stream);
+int y5_bn_silu_bwd(const void* dy, int ld_dy, const void* z, int ldz, int dtype, long long npix, int C, const float* gamma,
+                   const float* beta, const float* save_mean, const float* save_invstd, void* dz, int ld_dz, float* dgamma,
+                   float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+int y5_channel_sum(const void* x, int dtype, long long npix, int C, int ld, float* out, void* workspace, size_t workspace_bytes,
+                   void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * y5_loss_forward / y5_loss_backward -- utils/loss.py:101-247 `ComputeLoss.__call__` + `build_targets`, including
  * the un-vendored ultralytics `bbox_iou(CIoU=True)` / `smooth_bce` it calls (loss.py:6,117,153).
  * p[i]: device pointer of level i's raw head output (bs, na, ny[i], nx[i], 5+nc), contiguous, dtype `dtype`.

@@ -59,6 +59,13 @@ EXPORTS = {
     "y5_nms_batched": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                  C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_size_t, C.c_void_p]),
+    "y5_bn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_longlong]),
+    "y5_bn_silu_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                 C.c_size_t, C.c_void_p]),
+    "y5_bn_silu_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "y5_channel_sum": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "y5_loss_workspace_bytes": (C.c_size_t, [C.POINTER(LossDesc), C.c_int]),
     "y5_loss_forward": (C.c_int, [C.POINTER(LossDesc), C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_size_t, C.c_void_p]),

@@ -1,0 +1,181 @@
+// Train-mode BatchNorm + SiLU around the convolution (models/common.py:82-88 `Conv.forward`: act(bn(conv(x))), BN with
+// batch statistics, eps = 1e-3 / momentum = 0.03 from initialize_weights, models/yolo.py:259) and its backward.
+// All tensors are NHWC channel slices (pixel stride ld); C % 8 == 0 (fp16) / C % 4 == 0 (fp32): 16 bytes per lane.
+//
+//   y5_chan_reduce_kernel<MODE>   per-channel sums over all pixels, deterministic: per-block partials, fixed-order finish
+//       MODE 0  s0 = sum z            s1 = sum z^2                       (batch statistics)
+//       MODE 1  s0 = sum dv           s1 = sum dv * zhat                 (dbeta, dgamma;  dv = dy * silu'(gamma*zhat+beta))
+//       MODE 2  s0 = sum dz                                              (bias gradient of a bias-only conv: Detect.m[i])
+//   y5_bn_finish_kernel           partials -> mean / invstd (+ running stats update)   or   -> dgamma / dbeta
+//   y5_bn_silu_apply_kernel       y = [res +] silu(gamma * (z - mean) * invstd + beta)
+//   y5_bn_silu_bwd_apply_kernel   dz = gamma * invstd * (dv - dbeta/N - zhat * dgamma/N)
+#pragma once
+#include "y5_common.h"
+
+struct Y5BnParams {
+  const void* z;        // conv output (pre-BN), NHWC slice
+  const void* dy;       // gradient w.r.t. the block output (backward)
+  const void* res;      // optional residual added after the activation (forward apply)
+  void* out;            // y (forward apply) / dz (backward apply)
+  const float* gamma; const float* beta;
+  float* mean; float* invstd;           // [C] saved batch statistics
+  float* running_mean; float* running_var;  // optional, updated in place by the stats finish
+  float* partial;       // [nblk][2][C]
+  float* dgamma; float* dbeta;          // [C]
+  long long npix;
+  int C, ldz, ldy, ldr, ldo;
+  int nblk;
+  float eps, momentum;
+};
+
+template <typename T> struct Y5Vec;
+template <> struct Y5Vec<half_t> { typedef half8_t V; static constexpr int N = 8; };
+template <> struct Y5Vec<float> { typedef float4_t V; static constexpr int N = 4; };
+
+__device__ __forceinline__ float y5_silu_grad(float v) {  // d/dv [v * sigmoid(v)]
+  const float s = 1.0f / (1.0f + __expf(-v));
+  return s * (1.0f + v * (1.0f - s));
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256)
+void y5_chan_reduce_kernel(const Y5BnParams p) {
+  typedef typename Y5Vec<T>::V V;
+  constexpr int N = Y5Vec<T>::N;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* s_red = reinterpret_cast<float*>(smem);  // [rows][lanes_c][2*N]
+  const int lanes_c = p.C / N;
+  const int rows = 256 / lanes_c;
+  const int tid = threadIdx.x;
+  const int r = tid / lanes_c, cl = tid - r * lanes_c;
+  float a0[N], a1[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
+  if (r < rows) {
+    float mu[N], is[N], ga[N], be[N];
+    if constexpr (MODE == 1) {
+#pragma unroll
+      for (int e = 0; e < N; ++e) {
+        const int c = cl * N + e;
+        mu[e] = p.mean[c]; is[e] = p.invstd[c]; ga[e] = p.gamma[c]; be[e] = p.beta[c];
+      }
+    }
+    // pixels of this block: a contiguous range split evenly over the grid, rows of the block stride through it
+    const long long per = (p.npix + gridDim.x - 1) / gridDim.x;
+    const long long p0 = per * blockIdx.x, p1 = p0 + per < p.npix ? p0 + per : p.npix;
+    for (long long px = p0 + r; px < p1; px += rows) {
+      if constexpr (MODE == 0) {
+        const V zv = *reinterpret_cast<const V*>(static_cast<const T*>(p.z) + px * p.ldz + cl * N);
+#pragma unroll
+        for (int e = 0; e < N; ++e) { const float z = (float)zv[e]; a0[e] += z; a1[e] += z * z; }
+      } else if constexpr (MODE == 1) {
+        const V zv = *reinterpret_cast<const V*>(static_cast<const T*>(p.z) + px * p.ldz + cl * N);
+        const V gv = *reinterpret_cast<const V*>(static_cast<const T*>(p.dy) + px * p.ldy + cl * N);
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          const float zh = ((float)zv[e] - mu[e]) * is[e];
+          const float dv = (float)gv[e] * y5_silu_grad(ga[e] * zh + be[e]);
+          a0[e] += dv; a1[e] += dv * zh;
+        }
+      } else {
+        const V gv = *reinterpret_cast<const V*>(static_cast<const T*>(p.dy) + px * p.ldy + cl * N);
+#pragma unroll
+        for (int e = 0; e < N; ++e) a0[e] += (float)gv[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      s_red[(r * lanes_c + cl) * 2 * N + e] = a0[e];
+      s_red[(r * lanes_c + cl) * 2 * N + N + e] = a1[e];
+    }
+  }
+  __syncthreads();
+  // fixed-order sum over the block's rows: thread (cl, which, e) walks r = 0..rows-1
+  const int nout = lanes_c * 2 * N;
+  for (int o = tid; o < nout; o += 256) {
+    const int c2 = o / (2 * N), k = o - c2 * 2 * N;
+    float s = 0.f;
+    for (int rr = 0; rr < rows; ++rr) s += s_red[(rr * lanes_c + c2) * 2 * N + k];
+    const int which = k / N, e = k - which * N;
+    p.partial[((long long)blockIdx.x * 2 + which) * p.C + c2 * N + e] = s;
+  }
+}
+
+// MODE 0: batch statistics (+ running update, torch semantics: running_var uses the unbiased estimate)
+// MODE 1/2: plain sums -> dbeta (s0), dgamma (s1)
+template <int MODE>
+__global__ void y5_bn_finish_kernel(const Y5BnParams p) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= p.C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int b = 0; b < p.nblk; ++b) {
+    s0 += (double)p.partial[((long long)b * 2 + 0) * p.C + c];
+    s1 += (double)p.partial[((long long)b * 2 + 1) * p.C + c];
+  }
+  if constexpr (MODE == 0) {
+    const double n = (double)p.npix;
+    const double mean = s0 / n;
+    double var = s1 / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    p.mean[c] = (float)mean;
+    p.invstd[c] = (float)(1.0 / sqrt(var + (double)p.eps));
+    if (p.running_mean) p.running_mean[c] = (1.0f - p.momentum) * p.running_mean[c] + p.momentum * (float)mean;
+    if (p.running_var) p.running_var[c] = (1.0f - p.momentum) * p.running_var[c] + p.momentum * (float)(n > 1.0 ? var * n / (n - 1.0) : var);
+  } else {
+    if (p.dbeta) p.dbeta[c] = (float)s0;
+    if (p.dgamma) p.dgamma[c] = (float)s1;
+  }
+}
+
+template <typename T, bool RES>
+__global__ __launch_bounds__(256)
+void y5_bn_silu_apply_kernel(const Y5BnParams p) {
+  typedef typename Y5Vec<T>::V V;
+  constexpr int N = Y5Vec<T>::N;
+  const int lanes_c = p.C / N;
+  const long long total = p.npix * lanes_c;
+  for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long long)gridDim.x * 256) {
+    const long long px = v / lanes_c;
+    const int cl = (int)(v - px * lanes_c);
+    const V zv = *reinterpret_cast<const V*>(static_cast<const T*>(p.z) + px * p.ldz + cl * N);
+    V rv;
+    if constexpr (RES) rv = *reinterpret_cast<const V*>(static_cast<const T*>(p.res) + px * p.ldr + cl * N);
+    V o;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      const int c = cl * N + e;
+      const float sc = p.gamma[c] * p.invstd[c];
+      const float u = ((float)zv[e] - p.mean[c]) * sc + p.beta[c];
+      float y = u / (1.0f + __expf(-u));
+      if constexpr (RES) y += (float)rv[e];
+      o[e] = (T)y;
+    }
+    *reinterpret_cast<V*>(static_cast<T*>(p.out) + px * p.ldo + cl * N) = o;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256)
+void y5_bn_silu_bwd_apply_kernel(const Y5BnParams p) {
+  typedef typename Y5Vec<T>::V V;
+  constexpr int N = Y5Vec<T>::N;
+  const int lanes_c = p.C / N;
+  const long long total = p.npix * lanes_c;
+  const float inv_n = 1.0f / (float)p.npix;
+  for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long long)gridDim.x * 256) {
+    const long long px = v / lanes_c;
+    const int cl = (int)(v - px * lanes_c);
+    const V zv = *reinterpret_cast<const V*>(static_cast<const T*>(p.z) + px * p.ldz + cl * N);
+    const V gv = *reinterpret_cast<const V*>(static_cast<const T*>(p.dy) + px * p.ldy + cl * N);
+    V o;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      const int c = cl * N + e;
+      const float is = p.invstd[c], ga = p.gamma[c];
+      const float zh = ((float)zv[e] - p.mean[c]) * is;
+      const float dv = (float)gv[e] * y5_silu_grad(ga * zh + p.beta[c]);
+      o[e] = (T)(ga * is * (dv - p.dbeta[c] * inv_n - zh * p.dgamma[c] * inv_n));
+    }
+    *reinterpret_cast<V*>(static_cast<T*>(p.out) + px * p.ldo + cl * N) = o;
+  }
+}

@@ -161,11 +161,12 @@ void y5_conv_k3_kernel(const Y5ConvParams p) {
         resv[ps] = *reinterpret_cast<const uint4_t*>(rg + m * p.ldr + oslot * 8);
       }
     }
-    float16_t acc[NT];
+    // two accumulators per output tile (alternating k-steps): back-to-back MFMAs never wait on their own result
+    float16_t acc[NT], acc2[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; acc2[j][r] = 0.f; }
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -174,9 +175,12 @@ void y5_conv_k3_kernel(const Y5ConvParams p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const half8_t wf = *reinterpret_cast<const half8_t*>(wlds + j * 32 * K2 + t * NSL * 16 + wsl[ks]);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, af, acc[j], 0, 0, 0);
+          if ((t * KS + ks) & 1) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, af, acc2[j], 0, 0, 0);
+          else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, af, acc[j], 0, 0, 0);
         }
       }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] += acc2[j];
     // epilogue: bias + SiLU -> scratch (vacated stage) -> (+ residual) -> 16-byte stores
 #pragma unroll
     for (int j = 0; j < NT; ++j)

@@ -117,11 +117,13 @@ void y5_conv_pw_kernel(const Y5ConvParams p) {
     __builtin_amdgcn_wave_barrier();  // (lock-step on hardware; orders the lanes of the host emulator)
     char* st = ring + buf * STAGE;
     // ---- MFMA ----
-    float16_t acc[NT];
+    // NT <= 2: two accumulators per output tile (alternating k-steps) so that MFMAs never wait on their own result
+    constexpr bool DUAL = NT <= 2;
+    float16_t acc[NT], acc2[DUAL ? NT : 1];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; if (DUAL) acc2[j][r] = 0.f; }
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
@@ -131,9 +133,14 @@ void y5_conv_pw_kernel(const Y5ConvParams p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const half8_t wf = *reinterpret_cast<const half8_t*>(wlds + kc * NPAD * RB + (j * 32 + frow) * RB + so);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, af, acc[j], 0, 0, 0);
+          if (DUAL && (ks & 1)) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, af, acc2[j], 0, 0, 0);
+          else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, af, acc[j], 0, 0, 0);
         }
       }
+    if constexpr (DUAL) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] += acc2[j];
+    }
     // ---- epilogue: bias + act -> scratch (the vacated stage) -> full-row stores ----
 #pragma unroll
     for (int j = 0; j < NT; ++j)

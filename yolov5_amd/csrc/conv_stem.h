@@ -119,11 +119,12 @@ void y5_conv_stem_kernel(const Y5StemParams p) {
     }
     __builtin_amdgcn_wave_barrier();
     char* st = ring + buf * STAGE;
-    float16_t acc[NT];
+    // two accumulators per output tile (even / odd k-steps): back-to-back MFMAs never wait on their own result
+    float16_t acc[NT], acc2[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; acc2[j][r] = 0.f; }
 #pragma unroll
     for (int ks = 0; ks < 9; ++ks) {
       const uint32_t* src = reinterpret_cast<const uint32_t*>(st + (2 * ks + g) * 160 + 4 * frow + 12);
@@ -131,8 +132,13 @@ void y5_conv_stem_kernel(const Y5StemParams p) {
       raw[0] = src[0]; raw[1] = src[1]; raw[2] = src[2]; raw[3] = src[3];
       const half8_t af = __builtin_bit_cast(half8_t, raw);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j][ks], af, acc[j], 0, 0, 0);
+      for (int j = 0; j < NT; ++j) {
+        if (ks & 1) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j][ks], af, acc2[j], 0, 0, 0);
+        else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j][ks], af, acc[j], 0, 0, 0);
+      }
     }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] += acc2[j];
     // epilogue: bias + SiLU -> scratch (vacated stage) -> full-row 16-byte stores
 #pragma unroll
     for (int j = 0; j < NT; ++j)

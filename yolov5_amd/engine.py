@@ -486,7 +486,7 @@ class Engine:
             if bn.value >= 2 * d.Npad and bn.value > 32:
                 continue  # more than half of the tile's channels would be padding
             d.cfg = cfg
-            rc = self.lib.y5_conv2d_time(C.byref(d), *ptrs, 5, st, C.byref(ms))
+            rc = self.lib.y5_conv2d_time(C.byref(d), *ptrs, int(os.environ.get("Y5_AUTOTUNE_ITERS", "5")), st, C.byref(ms))
             if rc != 0:
                 continue  # configuration not applicable to this shape (e.g. gather table too large)
             if ms.value < best_ms:
