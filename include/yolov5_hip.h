@@ -50,6 +50,11 @@ typedef struct {
   int ld2;            /* y_up2 pixel stride (if y_up2 != NULL); y_up2 has spatial size 2*OH x 2*OW */
   int cfg;            /* workgroup tile configuration id (y5_conv_cfg_info), -1 = built-in heuristic */
   int max_blocks;     /* 0 = fill the GPU (CUs x occupancy) with persistent workgroups; >0 caps the grid (tests) */
+  /* Optional output placement (all zero = dense): output pixel (b, oh, ow) is stored at (b, oh*out_mul_h + out_off_h,
+   * ow*out_mul_w + out_off_w) of an out_H x out_W image with pixel stride ldy, and OH/OW are taken as given (taps that
+   * fall outside the input read zeros).  Used by the data-gradient of strided convolutions (one launch per output
+   * parity class); general implicit-GEMM configurations only. */
+  int out_mul_h, out_mul_w, out_off_h, out_off_w, out_H, out_W;
 } y5_conv_desc;
 
 #define Y5_CONV_NUM_CFGS 35   /* 0..13 implicit-GEMM tiles (2 LDS stages), 14..21 streaming pointwise (1x1 s1, fp16),
@@ -125,6 +130,15 @@ size_t y5_nms_workspace_bytes(int bs, int n, int no, int nm, int flags, int max_
 int y5_nms_batched(const void* pred, int dtype, int bs, int n, int no, int nm, float conf_thres, float iou_thres,
                    int max_det, int max_nms, float max_wh, int flags, const int* classes, int nclasses,
                    float* out, int* out_count, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * y5_conv2d_wgrad -- weight gradient of the convolution described by `d` (same descriptor as the forward call; act,
+ * cfg, ldy, ldr, ld2 ignored; max_blocks > 0 forces the number of pixel splits -- tests):
+ *   dw_packed[n][k] += sum_pixels dz[pixel][n] * im2col(x)[pixel][k]     fp32, layout [Npad][Kpad] of w_packed.
+ * The caller zero-fills dw_packed; accumulation uses fp32 atomics (split over the pixel range).  x, dz: fp16 NHWC
+ * slices (pixel strides d->ldx, ld_dz).  Replaces autograd's conv weight backward under train.py:410.
+ * ------------------------------------------------------------------------------------------------------- */
+int y5_conv2d_wgrad(const y5_conv_desc* d, const void* x, const void* dz, int ld_dz, float* dw_packed, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Train-mode Conv block pieces (models/common.py:82-88 `Conv.forward` = SiLU(BatchNorm2d(conv(x))) with BATCH

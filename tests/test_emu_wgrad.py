@@ -1,0 +1,57 @@
+"""CPU: y5_conv2d_wgrad (yolov5_amd/csrc/wgrad.hip) on the HIP emulator vs torch autograd's conv weight gradient."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import detgen
+from tests.hipemu.emu import aligned, emu, ptr
+from yolov5_amd import _lib
+from yolov5_amd.packing import round_up
+
+
+def run_wgrad(lib, x_nchw, dz_nchw, k, s, p, splits, ldx_extra=8, ldz_extra=8, aligned_fn=aligned, ptr_fn=ptr, stream=None):
+    B, C1, H, W = x_nchw.shape
+    C2 = dz_nchw.shape[1]
+    kh, kw = k; sh, sw = s; ph, pw = p
+    OH, OW = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
+    assert dz_nchw.shape[2:] == (OH, OW)
+    ldx, ldz = C1 + ldx_extra, C2 + ldz_extra
+    x = aligned_fn((B, H, W, ldx), np.float16, 5.0); x[..., :C1] = x_nchw.permute(0, 2, 3, 1).numpy()
+    dz = aligned_fn((B, OH, OW, ldz), np.float16, 5.0); dz[..., :C2] = dz_nchw.permute(0, 2, 3, 1).numpy()
+    K = kh * kw * C1
+    Kpad, Npad = round_up(K, 64), round_up(C2, 32)
+    dw = aligned_fn((Npad, Kpad), np.float32, 0.0)
+    d = _lib.ConvDesc(dtype=_lib.Y5_F16, B=B, H=H, W=W, C1=C1, ldx=ldx, OH=OH, OW=OW, C2=C2, ldy=ldz, KH=kh, KW=kw, SH=sh, SW=sw,
+                      PH=ph, PW=pw, act=0, Kpad=Kpad, Npad=Npad, ldr=0, ld2=0, cfg=-1, max_blocks=splits)
+    rc = lib.y5_conv2d_wgrad(C.byref(d), ptr_fn(x), ptr_fn(dz), ldz, ptr_fn(dw), stream)
+    assert rc == 0, lib.y5_last_error()
+    return dw, K, Kpad
+
+
+CASES = [
+    # B, H, W, C1, C2, k, s, p, splits
+    (2, 6, 7, 32, 32, (1, 1), (1, 1), (0, 0), 0),
+    (2, 9, 8, 32, 40, (3, 3), (1, 1), (1, 1), 3),     # C1=32: a 64-wide k tile spans two taps; C2 tail
+    (1, 12, 12, 64, 64, (3, 3), (2, 2), (1, 1), 2),
+    (2, 8, 8, 16, 72, (3, 3), (1, 1), (1, 1), 0),     # K = 144 -> 3 k tiles with a tail, two n tiles
+    (1, 16, 8, 8, 32, (6, 3), (2, 1), (2, 1), 0),     # the stem's paired-pixel view (NHWC4 x 2 = 8 channels)
+    (3, 5, 5, 128, 64, (1, 1), (1, 1), (0, 0), 4),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_emu_wgrad_matches_torch(case):
+    B, H, W, C1, C2, k, s, p, splits = case
+    lib = emu()
+    x = torch.from_numpy(detgen.uniform((B, C1, H, W), -1, 1, name="wx")).half()
+    OH, OW = (H + 2 * p[0] - k[0]) // s[0] + 1, (W + 2 * p[1] - k[1]) // s[1] + 1
+    dz = torch.from_numpy(detgen.uniform((B, C2, OH, OW), -1, 1, name="wdz")).half()
+    dw, K, Kpad = run_wgrad(lib, x, dz, k, s, p, splits)
+    w = torch.zeros((C2, C1, k[0], k[1]), requires_grad=True)
+    F.conv2d(x.float(), w, None, s, p).backward(dz.float())
+    ref = w.grad.permute(0, 2, 3, 1).reshape(C2, K).numpy()   # k = (kh, kw, c)
+    np.testing.assert_allclose(dw[:C2, :K], ref, rtol=2e-3, atol=2e-3)
+    assert np.all(dw[C2:] == 0) and np.all(dw[:, K:] == 0)

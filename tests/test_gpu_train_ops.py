@@ -1,0 +1,144 @@
+"""GPU parity of the training-path kernels through the C-ABI: train-mode BN+SiLU forward/backward, conv weight gradient
+(y5_conv2d_wgrad) and conv data gradient (forward kernel on transformed filters with output placement) vs torch-CPU
+autograd in fp32 on the same fp16-rounded inputs, at layer sizes of the yolov5s graph."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import detgen
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _st(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+@pytest.mark.parametrize("B,H,W,Cc,use_res", [(8, 40, 40, 64, False), (4, 80, 80, 32, True), (16, 20, 20, 256, False)])
+def test_bn_silu_fwd_bwd(B, H, W, Cc, use_res, dev):
+    from yolov5_amd import _lib
+
+    lib = _lib.lib()
+    npix, ld = B * H * W, Cc + 8
+    z = torch.from_numpy(detgen.uniform((B, H, W, Cc), -2, 3, name="gz")).half()
+    dy = torch.from_numpy(detgen.uniform((B, H, W, Cc), -1, 1, name="gdy")).half()
+    res = torch.from_numpy(detgen.uniform((B, H, W, Cc), -1, 1, name="gr")).half() if use_res else None
+    gamma = torch.from_numpy(detgen.uniform((Cc,), 0.5, 1.5, name="gg"))
+    beta = torch.from_numpy(detgen.uniform((Cc,), -0.5, 0.5, name="gb"))
+
+    def slab(t, fill):
+        a = torch.full((npix, ld), fill, dtype=torch.float16, device=dev)
+        if t is not None:
+            a[:, :Cc] = t.reshape(npix, Cc).to(dev)
+        return a
+
+    zd, dyd, rd = slab(z, 3.0), slab(dy, 0.0), slab(res, 0.0) if use_res else None
+    yd, dzd = slab(None, -7.0), slab(None, -9.0)
+    g, b = gamma.to(dev), beta.to(dev)
+    rm, rv = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
+    sm, si, dg, db = (torch.empty(Cc, device=dev) for _ in range(4))
+    nws = lib.y5_bn_workspace_bytes(Cc, npix)
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    _lib.check(lib.y5_bn_silu_fwd(_p(zd), _lib.Y5_F16, npix, Cc, ld, _p(g), _p(b), 1e-3, 0.03, _p(rm), _p(rv), _p(sm), _p(si), _p(rd), ld,
+                                  _p(yd), ld, _p(ws), nws, _st(dev)), lib)
+    _lib.check(lib.y5_bn_silu_bwd(_p(dyd), ld, _p(zd), ld, _lib.Y5_F16, npix, Cc, _p(g), _p(b), _p(sm), _p(si), _p(dzd), ld, _p(dg), _p(db),
+                                  _p(ws), nws, _st(dev)), lib)
+    torch.cuda.synchronize()
+    zt = z.float().permute(0, 3, 1, 2).requires_grad_(True)
+    gt, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    trm, trv = torch.zeros(Cc), torch.ones(Cc)
+    out = F.silu(F.batch_norm(zt, trm, trv, gt, bt, True, 0.03, 1e-3))
+    if use_res:
+        out = out + res.float().permute(0, 3, 1, 2)
+    out.backward(dy.float().permute(0, 3, 1, 2))
+    tol = dict(rtol=5e-3, atol=5e-3)
+    torch.testing.assert_close(yd[:, :Cc].float().cpu().reshape(B, H, W, Cc), out.detach().permute(0, 2, 3, 1), **tol)
+    torch.testing.assert_close(dzd[:, :Cc].float().cpu().reshape(B, H, W, Cc), zt.grad.permute(0, 2, 3, 1), **tol)
+    torch.testing.assert_close(dg.cpu(), gt.grad, rtol=1e-3, atol=2e-2)
+    torch.testing.assert_close(db.cpu(), bt.grad, rtol=1e-3, atol=2e-2)
+    torch.testing.assert_close(rm.cpu(), trm, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rv.cpu(), trv, rtol=1e-3, atol=1e-5)
+    assert torch.all(yd[:, Cc:] == -7.0) and torch.all(dzd[:, Cc:] == -9.0)
+
+
+WG = [
+    # B, H, W, C1, C2, k, s, p
+    (8, 40, 40, 64, 64, (3, 3), (1, 1), (1, 1)),
+    (4, 80, 80, 32, 64, (3, 3), (2, 2), (1, 1)),
+    (8, 20, 20, 256, 128, (1, 1), (1, 1), (0, 0)),
+    (2, 64, 32, 8, 32, (6, 3), (2, 1), (2, 1)),
+    (4, 20, 20, 128, 256, (3, 3), (2, 2), (1, 1)),
+]
+
+
+@pytest.mark.parametrize("case", WG)
+def test_conv_wgrad(case, dev):
+    from yolov5_amd import _lib
+    from yolov5_amd.packing import round_up
+
+    B, H, W, C1, C2, k, s, p = case
+    lib = _lib.lib()
+    OH, OW = (H + 2 * p[0] - k[0]) // s[0] + 1, (W + 2 * p[1] - k[1]) // s[1] + 1
+    x = torch.from_numpy(detgen.uniform((B, C1, H, W), -1, 1, name="gwx")).half()
+    dz = torch.from_numpy(detgen.uniform((B, C2, OH, OW), -1, 1, name="gwdz")).half() * 0.1
+    ldx, ldz = C1 + 8, C2 + 8
+    xd = torch.full((B, H, W, ldx), 5.0, dtype=torch.float16, device=dev); xd[..., :C1] = x.permute(0, 2, 3, 1).to(dev)
+    dzd = torch.full((B, OH, OW, ldz), 5.0, dtype=torch.float16, device=dev); dzd[..., :C2] = dz.permute(0, 2, 3, 1).to(dev)
+    K = k[0] * k[1] * C1
+    Kpad, Npad = round_up(K, 64), round_up(C2, 32)
+    dw = torch.zeros((Npad, Kpad), dtype=torch.float32, device=dev)
+    d = _lib.ConvDesc(dtype=_lib.Y5_F16, B=B, H=H, W=W, C1=C1, ldx=ldx, OH=OH, OW=OW, C2=C2, ldy=ldz, KH=k[0], KW=k[1], SH=s[0], SW=s[1],
+                      PH=p[0], PW=p[1], act=0, Kpad=Kpad, Npad=Npad, cfg=-1, max_blocks=0)
+    _lib.check(lib.y5_conv2d_wgrad(C.byref(d), _p(xd), _p(dzd), ldz, _p(dw), _st(dev)), lib)
+    torch.cuda.synchronize()
+    w = torch.zeros((C2, C1, k[0], k[1]), requires_grad=True)
+    F.conv2d(x.float(), w, None, s, p).backward(dz.float())
+    ref = w.grad.permute(0, 2, 3, 1).reshape(C2, K)
+    scale = float(ref.abs().max())
+    torch.testing.assert_close(dw[:C2, :K].cpu(), ref, rtol=2e-3, atol=2e-3 * scale)
+    assert torch.all(dw[C2:] == 0) and torch.all(dw[:, K:] == 0)
+
+
+DG = [(8, 40, 40, 64, 64, 3, 1, 1, True), (4, 80, 80, 32, 64, 3, 2, 1, False), (8, 20, 20, 256, 128, 1, 1, 0, False),
+      (4, 40, 40, 128, 256, 3, 2, 1, True)]
+
+
+@pytest.mark.parametrize("case", DG)
+def test_conv_dgrad(case, dev):
+    from yolov5_amd import _lib
+    from yolov5_amd.train_ops import ConvDgrad
+
+    B, H, W, C1, C2, k, s, p, acc = case
+    lib = _lib.lib()
+    OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    w = torch.from_numpy(detgen.uniform((C2, C1, k, k), -0.2, 0.2, name="gdw")).half().float()
+    dz = torch.from_numpy(detgen.uniform((B, C2, OH, OW), -1, 1, name="gddz")).half()
+    ldz, ldx = C2 + 8, C1 + 8
+    dzd = torch.full((B, OH, OW, ldz), 9.0, dtype=torch.float16, device=dev); dzd[..., :C2] = dz.permute(0, 2, 3, 1).to(dev)
+    dxd = torch.zeros((B, H, W, ldx), dtype=torch.float16, device=dev)
+    init = torch.from_numpy(detgen.uniform((B, H, W, C1), -1, 1, name="gdx0")).half()
+    if acc:
+        dxd[..., :C1] = init.to(dev)
+    op = ConvDgrad(lib, B, (H, W), (OH, OW), C1, C2, (k, k), (s, s), (p, p))
+    op.launch(w.to(dev), dzd.data_ptr(), ldz, dxd.data_ptr(), ldx, acc, _st(dev))
+    torch.cuda.synchronize()
+    x = torch.zeros((B, C1, H, W), requires_grad=True)
+    F.conv2d(x, w, None, s, p).backward(dz.float())
+    ref = x.grad.permute(0, 2, 3, 1)
+    if acc:
+        ref = ref + init.float()
+    torch.testing.assert_close(dxd[..., :C1].float().cpu(), ref, rtol=2e-2, atol=3e-2)
+    assert torch.all(dxd[..., C1:] == 0)

@@ -20,7 +20,8 @@ class ConvDesc(C.Structure):
 
     _fields_ = [(n, C.c_int) for n in (
         "dtype", "B", "H", "W", "C1", "ldx", "OH", "OW", "C2", "ldy", "KH", "KW", "SH", "SW", "PH", "PW",
-        "act", "Kpad", "Npad", "ldr", "ld2", "cfg", "max_blocks")]
+        "act", "Kpad", "Npad", "ldr", "ld2", "cfg", "max_blocks",
+        "out_mul_h", "out_mul_w", "out_off_h", "out_off_w", "out_H", "out_W")]
 
 
 class LossDesc(C.Structure):
@@ -59,6 +60,7 @@ EXPORTS = {
     "y5_nms_batched": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                  C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_size_t, C.c_void_p]),
+    "y5_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "y5_bn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_longlong]),
     "y5_bn_silu_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,

@@ -289,7 +289,11 @@ extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w
     return y5_fail(Y5_ERR_BAD_ARG, "conv: bad packed filter dims (Kpad % 16 bytes, Kpad >= K, Npad % 32)");
   if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)bias | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)y_up2) & 15)
     return y5_fail(Y5_ERR_BAD_ARG, "conv: pointers must be 16-byte aligned");
-  const int oh = (d->H + 2 * d->PH - d->KH) / d->SH + 1, ow = (d->W + 2 * d->PW - d->KW) / d->SW + 1;
+  const bool placed = d->out_mul_h != 0;
+  if (placed && (d->out_mul_w < 1 || d->out_mul_h < 1 || d->out_off_h < 0 || d->out_off_w < 0 || d->OH < 1 || d->OW < 1 ||
+                 (d->OH - 1) * d->out_mul_h + d->out_off_h >= d->out_H || (d->OW - 1) * d->out_mul_w + d->out_off_w >= d->out_W || y_up2))
+    return y5_fail(Y5_ERR_BAD_ARG, "conv: bad output placement");
+  const int oh = placed ? d->OH : (d->H + 2 * d->PH - d->KH) / d->SH + 1, ow = placed ? d->OW : (d->W + 2 * d->PW - d->KW) / d->SW + 1;
   if (oh != d->OH || ow != d->OW) return y5_fail(Y5_ERR_BAD_ARG, "conv: OH/OW inconsistent with H/W/k/s/p");
   if ((long long)d->B * d->H * d->W * d->ldx * es >= 0x7fffffffLL || (long long)d->B * oh * ow >= 0x7fffffffLL ||
       (long long)d->Npad * d->Kpad * es >= 0x7fffffffLL)
@@ -305,6 +309,8 @@ extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w
   p.act = d->act; p.Kpad = d->Kpad; p.Npad = d->Npad; p.K = d->KH * d->KW * d->C1;
   p.ldr = d->ldr; p.ld2 = d->ld2;
   p.M = d->B * oh * ow;
+  p.o_mul_h = d->out_mul_h; p.o_mul_w = d->out_mul_w; p.o_off_h = d->out_off_h; p.o_off_w = d->out_off_w; p.o_H = d->out_H; p.o_W = d->out_W;
+  if (placed && ((cfg >= kNumIgemm && cfg < kRing0) || cfg >= kK3_0)) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: output placement needs a general implicit-GEMM configuration");
   p.x_bytes = (unsigned)((((long long)d->B * d->H * d->W - 1) * d->ldx + d->C1) * es);
   p.w_bytes = (unsigned)((long long)d->Npad * d->Kpad * es);
 

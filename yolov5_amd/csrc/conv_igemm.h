@@ -40,6 +40,8 @@ struct Y5ConvParams {
   void* y2;           // optional second destination: 2x nearest-upsampled copy (pixel stride ld2)
   const void* zero;   // >= 64 bytes of zeros in global memory (pointer-addressed kernels: padding taps / tails)
   unsigned x_bytes, w_bytes;  // extents of x / w for the buffer resource descriptors (offsets beyond them read as zeros)
+  int o_mul_h, o_mul_w, o_off_h, o_off_w, o_H, o_W;  // o_mul_h != 0: output pixel (b,oh,ow) is stored at
+                                                       // (b, oh*o_mul_h + o_off_h, ow*o_mul_w + o_off_w) of an o_H x o_W image (dgrad parity classes)
   int B, H, W, C1, ldx;
   int OH, OW, C2, ldy;
   int KH, KW, SH, SW, PH, PW;
@@ -295,8 +297,16 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
           const int n = nt + vs * CPV;
           if (m < p.M && n < p.C2) {
             uint4_t raw = *reinterpret_cast<const uint4_t*>(scratch + row * SCR_ROWB + vs * 16);
+            size_t mo = (size_t)m;
+            if (p.o_mul_h) {
+              const int ohw = p.OH * p.OW;
+              const int b = m / ohw;
+              const int r = m - b * ohw;
+              const int oh = r / p.OW, ow = r - oh * p.OW;
+              mo = ((size_t)b * p.o_H + oh * p.o_mul_h + p.o_off_h) * p.o_W + ow * p.o_mul_w + p.o_off_w;
+            }
             if (rg) {
-              const uint4_t rr = *reinterpret_cast<const uint4_t*>(rg + (size_t)m * p.ldr + n);
+              const uint4_t rr = *reinterpret_cast<const uint4_t*>(rg + mo * p.ldr + n);
               if constexpr (sizeof(T) == 2) {
                 half8_t a = __builtin_bit_cast(half8_t, raw), b = __builtin_bit_cast(half8_t, rr), c;
 #pragma unroll
@@ -308,7 +318,7 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
                 raw = __builtin_bit_cast(uint4_t, a);
               }
             }
-            if (yg) *reinterpret_cast<uint4_t*>(yg + (size_t)m * p.ldy + n) = raw;
+            if (yg) *reinterpret_cast<uint4_t*>(yg + mo * p.ldy + n) = raw;
             if (y2g) {
               const int ohw = p.OH * p.OW;
               const int b = m / ohw;
