@@ -162,6 +162,21 @@ int y5_channel_sum(const void* x, int dtype, long long npix, int C, int ld, floa
                    void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Training-path glue (fp16 NHWC slices; ld = pixel stride in elements, multiples of 8):
+ * y5_nhwc_to_raw / y5_raw_to_nhwc -- models/yolo.py:96-98 `x[i].view(bs,na,no,ny,nx).permute(0,1,3,4,2)` and its
+ *   backward: logits (B, npix, ld >= na*no) <-> raw (B, na, npix, no) (padding channels of dlogits are zeroed).
+ * y5_upsample2x_bwd  -- backward of nn.Upsample(2,'nearest'): gsrc(b,h,w,:) (+)= sum of the 2x2 block of gup.
+ * y5_add_slice       -- dst (+)= src over npix pixels x C channels (Bottleneck shortcut / Concat fan-out gradients).
+ * y5_sppf_pool_bwd   -- backward of SPPF's three chained max-pools (common.py:338-340) in the [x|y1|y2|y3] buffers:
+ *   on entry grad holds the per-slice gradients left by cv2's data-gradient, on return grad[..., 0:C] = d/dx.
+ * ------------------------------------------------------------------------------------------------------- */
+int y5_nhwc_to_raw(const void* logits, void* raw, int B, int npix, int na, int no, int ld, void* stream);
+int y5_raw_to_nhwc(const void* draw, void* dlogits, int B, int npix, int na, int no, int ld, void* stream);
+int y5_upsample2x_bwd(const void* gup, void* gsrc, int B, int H, int W, int C, int ld_up, int ld_src, int accumulate, void* stream);
+int y5_add_slice(const void* src, void* dst, long long npix, int C, int lds, int ldd, int accumulate, void* stream);
+int y5_sppf_pool_bwd(const void* act, void* grad, int B, int H, int W, int C, int ld_act, int ld_grad, int k, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * y5_loss_forward / y5_loss_backward -- utils/loss.py:101-247 `ComputeLoss.__call__` + `build_targets`, including
  * the un-vendored ultralytics `bbox_iou(CIoU=True)` / `smooth_bce` it calls (loss.py:6,117,153).
  * p[i]: device pointer of level i's raw head output (bs, na, ny[i], nx[i], 5+nc), contiguous, dtype `dtype`.

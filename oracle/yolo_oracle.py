@@ -124,13 +124,19 @@ def fuse_conv_and_bn(w, gamma, beta, mean, var, eps=BN_EPS, conv_bias=None):
     return wf, bf
 
 
+BN_MOMENTUM = 0.03
+_BN_TRAIN = [False]  # set by model_forward(training=True, bn_batch_stats=True)
+
+
 def _conv(sd, p, x, k, s, pad, act=True):
     """models/common.py:74-92 Conv.forward (conv->BN(eval)->SiLU) or forward_fuse (conv+bias->SiLU)."""
     w = sd[p + ".conv.weight"]
     if (p + ".bn.weight") in sd:
         y = F.conv2d(x, w, None, s, pad)
+        # train.py runs the model in train() mode: BatchNorm2d uses batch statistics and updates the running ones in
+        # place (momentum 0.03 / eps 1e-3 from initialize_weights, models/yolo.py:259)
         y = F.batch_norm(y, sd[p + ".bn.running_mean"], sd[p + ".bn.running_var"], sd[p + ".bn.weight"],
-                         sd[p + ".bn.bias"], False, 0.0, BN_EPS)
+                         sd[p + ".bn.bias"], _BN_TRAIN[0], BN_MOMENTUM if _BN_TRAIN[0] else 0.0, BN_EPS)
     else:
         y = F.conv2d(x, w, sd[p + ".conv.bias"], s, pad)
     return F.silu(y) if act else y
@@ -229,9 +235,18 @@ def model_anchors(cfg):
     return a / model_strides(cfg).view(-1, 1, 1)
 
 
-def model_forward(cfg, sd, x, training=False):
+def model_forward(cfg, sd, x, training=False, bn_batch_stats=False):
     """models/yolo.py:160-170 `_forward_once` over the parsed graph; returns what the reference returns:
-    training -> list of raw (bs,na,ny,nx,no); eval -> (z, raw) (+ proto for Segment: (z, proto, raw))."""
+    training -> list of raw (bs,na,ny,nx,no); eval -> (z, raw) (+ proto for Segment: (z, proto, raw)).
+    bn_batch_stats=True reproduces model.train(): every BatchNorm uses (and updates) batch statistics."""
+    _BN_TRAIN[0] = bool(bn_batch_stats)
+    try:
+        return _model_forward(cfg, sd, x, training)
+    finally:
+        _BN_TRAIN[0] = False
+
+
+def _model_forward(cfg, sd, x, training=False):
     layers, save = parse_graph(cfg, x.shape[1])
     y = []
     strides = model_strides(cfg)

@@ -9,7 +9,7 @@ from yolov5_amd import _lib
 
 from .emu import aligned, emu
 
-_NP = {torch.float16: np.float16, torch.float32: np.float32}
+_NP = {torch.float16: np.float16, torch.float32: np.float32, torch.uint8: np.uint8}
 
 
 class EmuBackend:
@@ -26,6 +26,12 @@ class EmuBackend:
 
     def ptr(self, h):
         return h.ctypes.data
+
+    def to_torch(self, h):
+        return torch.from_numpy(np.array(h))
+
+    def zero_(self, h):
+        h[...] = 0
 
     def stream(self):
         return None

@@ -1,0 +1,63 @@
+"""CPU: the whole training plan (train-mode forward with batch-statistics BN, full backward to every parameter) run on
+the HIP emulator for yolov5n @128x128, against torch autograd over the CPU oracle (reference semantics of model.train(),
+models/common.py:82-88 + models/yolo.py:96-98)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import detgen, yolo_oracle as yo
+from tests.hipemu.backend import EmuBackend
+from yolov5_amd.train_engine import TrainEngine
+from yolov5_amd.yolo import DetectionModel
+
+
+def test_yolov5n_train_forward_backward_vs_oracle_autograd():
+    cfg = yo.model_cfg("yolov5n")
+    sd = yo.det_state_dict(cfg, 0, fused=False)
+    m = DetectionModel("yolov5n.yaml")
+    m.load_state_dict(sd)
+    m.train()
+    B = 2
+    x = torch.from_numpy(detgen.uniform((B, 3, 128, 128), 0.0, 1.0, name="img", seed=0))
+    eng = TrainEngine(m, (B, 3, 128, 128), "cpu", backend=EmuBackend())
+    p = [eng.be.to_torch(o).float() for o in eng.forward(x.half())]
+
+    # oracle: same weights as leaf tensors, train-mode BN
+    sdo = {k: v.clone() for k, v in sd.items()}
+    leaves = {}
+    for k, v in sdo.items():
+        if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var", "anchors")):
+            sdo[k] = v.clone().requires_grad_(True)
+            leaves[k] = sdo[k]
+    ref = yo.model_forward(cfg, sdo, x, training=True, bn_batch_stats=True)
+    for a, b in zip(p, ref):
+        assert a.shape == b.shape
+        scale = float(b.detach().abs().max())
+        # fp16 activations vs the fp32 oracle through 60 batch-normalised layers (the deepest have 32 samples per channel)
+        assert float((a - b.detach()).abs().max()) < 6e-2 * max(scale, 1.0)
+        assert float((a - b.detach()).abs().mean()) < 1e-2 * max(scale, 1.0)
+    # running statistics were updated like torch's (momentum 0.03)
+    for name, mod in m.named_modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            np.testing.assert_allclose(mod.running_mean.numpy(), sdo[name + ".running_mean"].numpy(), rtol=2e-2, atol=2e-3)
+            np.testing.assert_allclose(mod.running_var.numpy(), sdo[name + ".running_var"].numpy(), rtol=2e-2, atol=2e-3)
+            assert int(mod.num_batches_tracked) == 1
+    # backward with a fixed upstream gradient
+    rs = [torch.from_numpy(detgen.uniform(tuple(b.shape), -1, 1, name=f"up{i}", seed=3)) for i, b in enumerate(ref)]
+    sum((b * r).sum() for b, r in zip(ref, rs)).backward()
+    grads = eng.backward([r.half() for r in rs])
+    names = [n for n, _ in m.named_parameters()]
+    # fp16 activations + batch statistics over as few as 32 samples make individual elements noisy against the fp32
+    # oracle; direction and norm of every parameter gradient must agree (the kernels are unit-tested to 1e-3 each)
+    worst_cos, worst_rel = 1.0, 0.0
+    for n, g in zip(names, grads):
+        assert g is not None, n
+        rg = leaves[n].grad
+        assert rg is not None and g.shape == rg.shape, n
+        a, b = g.float().flatten().double(), rg.flatten().double()
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+        rel = float((a - b).norm() / (b.norm() + 1e-30))
+        worst_cos, worst_rel = min(worst_cos, cos), max(worst_rel, rel)
+        assert cos > 0.97 and rel < 0.25, (n, cos, rel)
+    print(f"\n[train-emu] {len(names)} parameter gradients: worst cosine {worst_cos:.4f}, worst relative L2 error {worst_rel:.4f}")
+    assert len(names) == len(list(m.parameters()))

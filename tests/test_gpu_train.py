@@ -1,0 +1,101 @@
+"""GPU: one training step through the reference-shaped API -- model.train(); pred = model(imgs);
+loss, items = ComputeLoss(model)(pred, targets); (loss * scale).backward()  (train.py:401-410) -- with every kernel on the
+MI355X, against torch autograd over the CPU oracle (fp32, train-mode BN)."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import detgen, yolo_oracle as yo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _model(name, dev):
+    from yolov5_amd.yolo import DetectionModel
+
+    cfg = yo.model_cfg(name)
+    sd = yo.det_state_dict(cfg, 0, fused=False)
+    m = DetectionModel(name + ".yaml")
+    m.load_state_dict(sd)
+    m.hyp = dict(yo.HYP_SCRATCH_LOW)
+    return m.to(dev).train(), cfg, sd
+
+
+def test_train_step_matches_oracle_autograd(dev):
+    from yolov5_amd.loss import ComputeLoss
+
+    m, cfg, sd = _model("yolov5n", dev)
+    B, S, SCALE = 8, 256, 4096.0
+    x = torch.from_numpy(detgen.uniform((B, 3, S, S), 0.0, 1.0, name="timg", seed=7))
+    t = torch.from_numpy(detgen.synth_targets(B, 6, seed=7))
+    compute_loss = ComputeLoss(m)
+    pred = m(x.half().to(dev))
+    assert isinstance(pred, list) and len(pred) == 3 and pred[0].shape == (B, 3, S // 8, S // 8, 85) and pred[0].requires_grad
+    loss, items = compute_loss(pred, t.to(dev))
+    (loss * SCALE).backward()
+    torch.cuda.synchronize()
+
+    sdo = {k: v.clone() for k, v in sd.items()}
+    leaves = {}
+    for k, v in sdo.items():
+        if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var", "anchors")):
+            sdo[k] = v.clone().requires_grad_(True)
+            leaves[k] = sdo[k]
+    ref = yo.model_forward(cfg, sdo, x, training=True, bn_batch_stats=True)
+    rloss, ritems = yo.compute_loss(ref, t, yo.model_anchors(cfg))
+    rloss.backward()
+    for a, b in zip(pred, ref):
+        d = (a.float().cpu() - b.detach()).abs()
+        assert float(d.max()) < 4e-2 * float(b.detach().abs().max()) and float(d.mean()) < 4e-3 * float(b.detach().abs().max())
+    np.testing.assert_allclose(loss.item(), rloss.item(), rtol=2e-2)
+    np.testing.assert_allclose(items.cpu().numpy(), ritems.numpy(), rtol=3e-2)
+    worst_cos, worst_rel = 1.0, 0.0
+    for n, p in m.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+        a, b = (p.grad.float().cpu().flatten() / SCALE).double(), leaves[n].grad.flatten().double()
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+        rel = float((a - b).norm() / (b.norm() + 1e-30))
+        worst_cos, worst_rel = min(worst_cos, cos), max(worst_rel, rel)
+        assert cos > 0.98 and rel < 0.2, (n, cos, rel)
+    for name, mod in m.named_modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            np.testing.assert_allclose(mod.running_mean.cpu().numpy(), sdo[name + ".running_mean"].numpy(), rtol=2e-2, atol=2e-3)
+    print(f"\n[train] yolov5n bs={B} {S}^2: loss {loss.item():.5f} vs oracle {rloss.item():.5f}; parameter gradients: worst cosine "
+          f"{worst_cos:.4f}, worst relative L2 error {worst_rel:.4f}")
+
+
+def test_train_step_yolov5s_bs64_timing(dev):
+    """BASELINE config 3 per-GPU shape (yolov5s, 64 x 3x640x640, 512 targets): forward + ComputeLoss + backward + SGD step."""
+    from yolov5_amd.loss import ComputeLoss
+
+    m, cfg, sd = _model("yolov5s", dev)
+    B = 64
+    x = torch.rand((B, 3, 640, 640), device=dev).half()
+    t = torch.from_numpy(detgen.synth_targets(B, 8, seed=1)).to(dev)
+    compute_loss = ComputeLoss(m)
+    opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.937, nesterov=True)
+    losses = []
+    for it in range(4):
+        if it == 1:
+            torch.cuda.synchronize()
+            t0 = time.time()
+        pred = m(x)
+        loss, items = compute_loss(pred, t)
+        opt.zero_grad(set_to_none=True)
+        (loss * 1024.0).backward()
+        for p in m.parameters():
+            p.grad.div_(1024.0)
+        opt.step()
+        losses.append(float(loss))
+    torch.cuda.synchronize()
+    ms = (time.time() - t0) / 3 * 1e3
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]  # the loss goes down on a fixed batch
+    print(f"\n[train] yolov5s bs=64 640^2: {ms:.1f} ms per step (fwd + ComputeLoss + bwd + SGD) = {B / ms * 1e3:.0f} img/s; losses {['%.3f' % l for l in losses]}")

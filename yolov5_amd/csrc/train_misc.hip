@@ -1,0 +1,189 @@
+// Small HBM-bound kernels of the training path (fp16 NHWC slices): head layout changes between the NHWC logits of the
+// Detect convolutions and the (bs, na, ny, nx, no) tensors ComputeLoss consumes (models/yolo.py:96-98 view+permute),
+// and the backward of nn.Upsample(2,'nearest'), of the Bottleneck shortcut / Concat fan-out (gradient accumulation)
+// and of SPPF's three chained MaxPool2d(k,1,k//2) (models/common.py:338-340).
+#include <hip/hip_runtime.h>
+
+#include "../../include/yolov5_hip.h"
+#include "y5_common.h"
+#include "y5_host.h"
+
+namespace {
+inline unsigned nblk(long long n, int per) { long long b = (n + per - 1) / per; return (unsigned)(b < 1 ? 1 : b); }
+}
+
+// logits (B, npix, ld) -> raw (B, na, npix, no): raw[b][a][pix][o] = logits[b][pix][a*no + o]
+__global__ void y5_nhwc_to_raw_kernel(const half_t* __restrict__ lg, half_t* __restrict__ raw, int npix, int na, int no, int ld, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over raw elements
+  if (i >= total) return;
+  const int o = (int)(i % no);
+  long long t = i / no;
+  const int pix = (int)(t % npix);
+  t /= npix;
+  const int a = (int)(t % na);
+  const long long b = t / na;
+  raw[i] = lg[(b * npix + pix) * ld + a * no + o];
+}
+// draw (B, na, npix, no) -> dlogits (B, npix, ld), channels >= na*no zero
+__global__ void y5_raw_to_nhwc_kernel(const half_t* __restrict__ draw, half_t* __restrict__ dlg, int npix, int na, int no, int ld, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over dlogits elements
+  if (i >= total) return;
+  const int n = (int)(i % ld);
+  const long long bp = i / ld;
+  half_t v = (half_t)0.f;
+  if (n < na * no) {
+    const int a = n / no, o = n - a * no;
+    const long long b = bp / npix;
+    const int pix = (int)(bp - b * npix);
+    v = draw[((b * na + a) * npix + pix) * no + o];
+  }
+  dlg[i] = v;
+}
+
+// dst(b,h,w,:) (+)= sum of the 2x2 block of src(b,2h..2h+1,2w..2w+1,:)
+__global__ void y5_upsample2x_bwd_kernel(const char* __restrict__ src, char* __restrict__ dst, int H, int W, int vpp, int lds_b, int ldd_b,
+                                         int acc, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over dst vectors
+  if (i >= total) return;
+  const int v = (int)(i % vpp);
+  const long long pix = i / vpp;
+  const int w = (int)(pix % W);
+  const long long t = pix / W;
+  const int h = (int)(t % H);
+  const long long b = t / H;
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0.f;
+  if (acc) {
+    const half8_t d = *reinterpret_cast<const half8_t*>(dst + pix * ldd_b + v * 16);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = (float)d[e];
+  }
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const long long sp = (b * 2 * H + 2 * h + dy) * (2 * W) + 2 * w + dx;
+      const half8_t q = *reinterpret_cast<const half8_t*>(src + sp * lds_b + v * 16);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += (float)q[e];
+    }
+  half8_t o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (half_t)s[e];
+  *reinterpret_cast<half8_t*>(dst + pix * ldd_b + v * 16) = o;
+}
+
+__global__ void y5_add_slice_kernel(const char* __restrict__ src, char* __restrict__ dst, int vpp, int lds_b, int ldd_b, int acc, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int v = (int)(i % vpp);
+  const long long pix = i / vpp;
+  half8_t q = *reinterpret_cast<const half8_t*>(src + pix * lds_b + v * 16);
+  if (acc) {
+    const half8_t d = *reinterpret_cast<const half8_t*>(dst + pix * ldd_b + v * 16);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) q[e] = (half_t)((float)q[e] + (float)d[e]);
+  }
+  *reinterpret_cast<half8_t*>(dst + pix * ldd_b + v * 16) = q;
+}
+
+// SPPF backward.  act: NHWC buffer [x | y1 | y2 | y3] (4*C channels), grad: same geometry holding d/d[x|y1|y2|y3] as left by
+// the consumer's data-gradient; on return grad[..., 0:C] holds the total gradient w.r.t. x (slices 1..3 are consumed).
+// One workgroup per (image, 8-channel group); fp32 accumulators in LDS; argmax = first maximum in (kh, kw) scan order
+// (torch's max_pool2d_with_indices tie rule).
+__global__ __launch_bounds__(256)
+void y5_sppf_pool_bwd_kernel(const char* __restrict__ act, char* __restrict__ grad, int H, int W, int C_bytes, int lda_b, int ldg_b, int k) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int HW = H * W;
+  half8_t* a_in = reinterpret_cast<half8_t*>(smem);                 // [HW] activation of the pool input
+  float* g_out = reinterpret_cast<float*>(a_in + HW);               // [HW][8] gradient of the pool output
+  float* g_in = g_out + (size_t)HW * 8;                             // [HW][8] gradient accumulated for the pool input
+  const int groups = C_bytes / 16;
+  const int b = blockIdx.x / groups, cg = blockIdx.x - b * groups;
+  const char* abase = act + (size_t)b * HW * lda_b + (size_t)cg * 16;
+  char* gbase = grad + (size_t)b * HW * ldg_b + (size_t)cg * 16;
+  const int r = k / 2;
+  // g_out <- d/dy3
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+    const half8_t q = *reinterpret_cast<const half8_t*>(gbase + (size_t)i * ldg_b + 3 * (size_t)C_bytes);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g_out[i * 8 + e] = (float)q[e];
+  }
+  for (int pass = 3; pass >= 1; --pass) {  // pool `pass`: input slice pass-1 -> output slice pass
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+      a_in[i] = *reinterpret_cast<const half8_t*>(abase + (size_t)i * lda_b + (size_t)(pass - 1) * C_bytes);
+      const half8_t q = *reinterpret_cast<const half8_t*>(gbase + (size_t)i * ldg_b + (size_t)(pass - 1) * C_bytes);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g_in[i * 8 + e] = (float)q[e];  // direct gradient of that slice (from cv2's data-gradient)
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+      const int y = i / W, x = i - y * W;
+      const int y0 = y - r < 0 ? 0 : y - r, y1 = y + r >= H ? H - 1 : y + r;
+      const int x0 = x - r < 0 ? 0 : x - r, x1 = x + r >= W ? W - 1 : x + r;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float best = (float)a_in[y0 * W + x0][e];
+        int bi = y0 * W + x0;
+        for (int yy = y0; yy <= y1; ++yy)
+          for (int xx = x0; xx <= x1; ++xx) {
+            const float v = (float)a_in[yy * W + xx][e];
+            if (v > best) { best = v; bi = yy * W + xx; }
+          }
+        atomicAdd(&g_in[bi * 8 + e], g_out[i * 8 + e]);
+      }
+    }
+    __syncthreads();
+    // the accumulated input gradient is the next pass's output gradient
+    for (int i = threadIdx.x; i < HW * 8; i += blockDim.x) g_out[i] = g_in[i];
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+    half8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)g_out[i * 8 + e];
+    *reinterpret_cast<half8_t*>(gbase + (size_t)i * ldg_b) = o;
+  }
+}
+
+extern "C" int y5_nhwc_to_raw(const void* logits, void* raw, int B, int npix, int na, int no, int ld, void* stream_) {
+  if (!logits || !raw || B < 1 || npix < 1 || na < 1 || no < 1 || ld < na * no) return y5_fail(Y5_ERR_BAD_ARG, "nhwc_to_raw: bad args");
+  const long long total = (long long)B * na * npix * no;
+  hipLaunchKernelGGL(y5_nhwc_to_raw_kernel, dim3(nblk(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream_), (const half_t*)logits,
+                     (half_t*)raw, npix, na, no, ld, total);
+  return y5_check_launch("y5_nhwc_to_raw");
+}
+extern "C" int y5_raw_to_nhwc(const void* draw, void* dlogits, int B, int npix, int na, int no, int ld, void* stream_) {
+  if (!draw || !dlogits || B < 1 || npix < 1 || na < 1 || no < 1 || ld < na * no) return y5_fail(Y5_ERR_BAD_ARG, "raw_to_nhwc: bad args");
+  const long long total = (long long)B * npix * ld;
+  hipLaunchKernelGGL(y5_raw_to_nhwc_kernel, dim3(nblk(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream_), (const half_t*)draw,
+                     (half_t*)dlogits, npix, na, no, ld, total);
+  return y5_check_launch("y5_raw_to_nhwc");
+}
+extern "C" int y5_upsample2x_bwd(const void* gup, void* gsrc, int B, int H, int W, int C, int ld_up, int ld_src, int accumulate, void* stream_) {
+  if (!gup || !gsrc || C % 8 || ld_up % 8 || ld_src % 8) return y5_fail(Y5_ERR_BAD_ARG, "upsample2x_bwd: bad args");
+  const int vpp = C / 8;
+  const long long total = (long long)B * H * W * vpp;
+  hipLaunchKernelGGL(y5_upsample2x_bwd_kernel, dim3(nblk(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream_), (const char*)gup,
+                     (char*)gsrc, H, W, vpp, ld_up * 2, ld_src * 2, accumulate, total);
+  return y5_check_launch("y5_upsample2x_bwd");
+}
+extern "C" int y5_add_slice(const void* src, void* dst, long long npix, int C, int lds, int ldd, int accumulate, void* stream_) {
+  if (!src || !dst || C % 8 || lds % 8 || ldd % 8) return y5_fail(Y5_ERR_BAD_ARG, "add_slice: bad args");
+  const int vpp = C / 8;
+  const long long total = npix * vpp;
+  hipLaunchKernelGGL(y5_add_slice_kernel, dim3(nblk(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream_), (const char*)src,
+                     (char*)dst, vpp, lds * 2, ldd * 2, accumulate, total);
+  return y5_check_launch("y5_add_slice");
+}
+extern "C" int y5_sppf_pool_bwd(const void* act, void* grad, int B, int H, int W, int C, int ld_act, int ld_grad, int k, void* stream_) {
+  if (!act || !grad || C % 8 || ld_act % 8 || ld_grad % 8 || ld_act < 4 * C || ld_grad < 4 * C || !(k & 1)) return y5_fail(Y5_ERR_BAD_ARG, "sppf_pool_bwd: bad args");
+  const size_t lds = (size_t)H * W * (16 + 32 + 32);
+  if (lds > 150 * 1024) return y5_fail(Y5_ERR_UNSUPPORTED, "sppf_pool_bwd: H*W plane does not fit in LDS");
+  static bool a = false;
+  if (!a) { hipFuncSetAttribute((const void*)y5_sppf_pool_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); a = true; }
+  hipLaunchKernelGGL(y5_sppf_pool_bwd_kernel, dim3((unsigned)(B * (C / 8))), dim3(256), lds, static_cast<hipStream_t>(stream_), (const char*)act,
+                     (char*)grad, H, W, C * 2, ld_act * 2, ld_grad * 2, k);
+  return y5_check_launch("y5_sppf_pool_bwd");
+}

@@ -317,6 +317,12 @@ class _HipBackend:
     def ptr(self, h):
         return h.data_ptr()
 
+    def to_torch(self, h):
+        return h
+
+    def zero_(self, h):
+        h.zero_()
+
     def stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 

@@ -1,0 +1,360 @@
+"""Training engine: train-mode forward (conv -> batch-stat BN -> SiLU, models/common.py:82-88) and the full backward of
+the YOLOv5 graph as HIP kernel launches, exposed to torch.autograd as ONE Function so that
+`pred = model(imgs); loss, _ = compute_loss(pred, targets); scaler.scale(loss).backward()` (train.py:401-410) works
+unchanged: autograd sees model parameters -> pred, the kernels do everything in between.
+
+Per Conv block, forward:  z = conv(x) [y5_conv2d_fwd, no bias/act] -> y = [res +] silu(bn_batch(z)) [y5_bn_silu_fwd]
+                backward: dz, dgamma, dbeta = y5_bn_silu_bwd(dy, z); dW = y5_conv2d_wgrad(x, dz); dx (+)= dgrad(dz, W)
+Concat is free (producers write channel slices of the consumer's buffer; the gradient buffer mirrors that layout),
+nn.Upsample / SPPF pools / Bottleneck shortcuts have their own small backward kernels (train_misc.hip).
+
+Differences from the inference plan (engine.py): no in-place residuals and C3's cv1/cv2 are separate launches, because
+backward needs every block input intact.  Compute dtype is fp16 with fp32 master weights (AMP semantics): filters are
+re-packed from the live fp32 parameters at every step.  There is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch import nn
+
+from . import _lib
+from .engine import TRef, _HipBackend, _Planner, _slice
+from .packing import pack_conv_weight
+from .train_ops import dgrad_subconvs
+
+
+class _TrainPlanner(_Planner):
+    """Same graph walk as the inference planner; C3 un-fused and without buffer aliasing."""
+
+    def c3(self, m, x: TRef, dest, up2=None, name="C3"):
+        c_ = m.cv1.conv.out_channels
+        n = len(m.m)
+        cat = self.spec.new_buf(x.H, x.W, 2 * c_, name + ".cat")
+        a = self.conv([m.cv1], x, _slice(cat, 0, c_) if n == 0 else None, name=name + ".cv1")
+        self.conv([m.cv2], x, _slice(cat, c_, c_), name=name + ".cv2")
+        for i, b in enumerate(m.m):
+            t = self.conv([b.cv1], a, None, name=f"{name}.m{i}.cv1")
+            a = self.conv([b.cv2], t, _slice(cat, 0, c_) if i == n - 1 else None, res=a if b.add else None, name=f"{name}.m{i}.cv2")
+        return self.conv([m.cv3], cat, dest, up2=up2, name=name + ".cv3")
+
+
+def _vp(v):
+    return C.c_void_p(v)
+
+
+class TrainEngine:
+    """Materialised training plan for one (batch, resolution) on one GPU."""
+
+    def __init__(self, model, x_shape, device, backend=None):
+        self.be = backend if backend is not None else _HipBackend(device)
+        self.lib = self.be.lib
+        self.model = model
+        B, ch, H, W = x_shape
+        self.x_shape = tuple(x_shape)
+        self.spec = _TrainPlanner(model, B, ch, H, W, want_raw=True).run()
+        if any(o["op"] in ("copy", "upsample") for o in self.spec.ops):
+            raise NotImplementedError("training plan: standalone Concat copy / Upsample ops are not supported")
+        f16 = torch.float16
+        self.bufs = [self.be.empty((B, b.H, b.W, b.C), f16) for b in self.spec.bufs]
+        self.gbufs = [self.be.empty((B, b.H, b.W, b.C), f16) for b in self.spec.bufs]
+        det = model.model[-1]
+        self.na, self.no = det.na, det.no
+        self.params = list(model.parameters())
+        self._pidx = {id(p): i for i, p in enumerate(self.params)}
+        self.raw = {}
+        self.convs = []
+        max_z, max_ws = 0, 0
+        for op in self.spec.ops:
+            if op["op"] == "conv":
+                m = op["mods"][0]
+                assert len(op["mods"]) == 1
+                cv = m.conv if hasattr(m, "conv") else m
+                has_bn = hasattr(m, "bn")
+                if hasattr(m, "conv") and not has_bn:
+                    raise NotImplementedError("training needs the un-fused model (Conv blocks with their BatchNorm); do not call fuse()")
+                y = op["y"]
+                st = dict(op=op, mod=m, cv=cv, has_bn=has_bn)
+                if has_bn:
+                    c2 = cv.out_channels
+                    st["z"] = self.be.empty((B, y.H, y.W, c2), f16)
+                    for k in ("mean", "invstd", "dgamma", "dbeta"):
+                        st[k] = self.be.empty((c2,), torch.float32)
+                    max_z = max(max_z, B * y.H * y.W * c2)
+                    max_ws = max(max_ws, self.lib.y5_bn_workspace_bytes(c2, B * y.H * y.W))
+                else:
+                    st["dbias"] = self.be.empty((op["c2_store"],), torch.float32)
+                    max_ws = max(max_ws, self.lib.y5_bn_workspace_bytes(op["c2_store"], B * y.H * y.W))
+                op["_st"] = st
+                self.convs.append(st)
+            elif op["op"] == "decode":
+                self.raw[op["level"]] = self.be.empty((B, op["na"], op["ny"], op["nx"], op["no"]), f16)
+        self.dz = self.be.empty((max(max_z, 8),), f16)
+        self.ws = self.be.empty((max(max_ws, 256),), torch.uint8)
+        self.ws_bytes = max(max_ws, 256)
+        self._keep = []
+
+    # ---- helpers ---------------------------------------------------------------------------------------------------
+    def _ptr(self, t: TRef, grad=False):
+        bufs = self.gbufs if grad else self.bufs
+        return self.be.ptr(bufs[t.buf]) + t.c_off * 2
+
+    def _ld(self, t: TRef):
+        return self.spec.bufs[t.buf].C
+
+    def _dev(self, t):
+        h = self.be.from_torch(t)
+        self._keep.append(h)
+        return h
+
+    def _geom(self, st):
+        """Forward geometry of a conv op (with the paired-pixel view of the 3-channel stem)."""
+        op, cv = st["op"], st["cv"]
+        x = op["x"]
+        (kh, kw), (sh, sw), (ph, pw) = op["k"], op["s"], op["p"]
+        H, W, C1, ldx = x.H, x.W, x.C, self._ld(x)
+        paired = op["view"] == "first" and C1 == 4 and kw % 2 == 0 and sw % 2 == 0 and pw % 2 == 0 and W % 2 == 0
+        if paired:
+            W, C1, ldx, kw, sw, pw = W // 2, 8, 8, kw // 2, sw // 2, pw // 2
+        return dict(H=H, W=W, C1=C1, ldx=ldx, k=(kh, kw), s=(sh, sw), p=(ph, pw), paired=paired)
+
+    def _packed_weight(self, st):
+        op, cv = st["op"], st["cv"]
+        w = cv.weight.detach().float()
+        x = op["x"]
+        if op["view"] == "first":
+            wf = torch.zeros((w.shape[0], x.C, w.shape[2], w.shape[3]), device=w.device)
+            wf[:, :w.shape[1]] = w
+            w = wf
+        b = None if st["has_bn"] or cv.bias is None else cv.bias.detach().float()
+        return pack_conv_weight(w, b, torch.float16)
+
+    # ---- forward ---------------------------------------------------------------------------------------------------
+    def forward(self, x):
+        lib, be, B = self.lib, self.be, self.spec.B
+        if tuple(x.shape) != self.x_shape:
+            raise ValueError(f"training engine built for input {self.x_shape}, got {tuple(x.shape)}")
+        stm = be.stream()
+        self._keep = []
+        x, xptr, src_dt = be.input(x)
+        for op in self.spec.ops:
+            kind = op["op"]
+            if kind == "to_nhwc":
+                d = op["dst"]
+                scale = 1.0 / 255.0 if src_dt == _lib.Y5_U8 else 1.0
+                _lib.check(lib.y5_nchw_to_nhwc(_vp(xptr), src_dt, _vp(self._ptr(d)), _lib.Y5_F16, B, op["C"], d.H, d.W, self._ld(d), scale, stm), lib)
+            elif kind == "conv":
+                self._fwd_conv(op["_st"], stm)
+            elif kind == "sppf_pool":
+                b = op["buf"]
+                _lib.check(lib.y5_sppf_pool(_vp(self._ptr(b)), _lib.Y5_F16, B, b.H, b.W, op["C"], self._ld(b), op["k"], stm), lib)
+            elif kind == "decode":
+                lg = op["x"]
+                _lib.check(lib.y5_nhwc_to_raw(_vp(self._ptr(lg)), _vp(be.ptr(self.raw[op["level"]])), B, op["ny"] * op["nx"], op["na"], op["no"],
+                                              self._ld(lg), stm), lib)
+            else:
+                raise NotImplementedError(kind)
+        return [self.raw[i] for i in sorted(self.raw)]
+
+    def _fwd_conv(self, st, stm):
+        lib, B = self.lib, self.spec.B
+        op, cv = st["op"], st["cv"]
+        x, y, res, y2 = op["x"], op["y"], op["res"], op["y2"]
+        g = self._geom(st)
+        wp, bp, K, Kpad, Npad = self._packed_weight(st)
+        st["Kpad"], st["Npad"], st["K"] = Kpad, Npad, K
+        wd, bd = self._dev(wp), self._dev(bp)
+        if st["has_bn"]:
+            c2 = cv.out_channels
+            out_ptr, ldo, c2s = self.be.ptr(st["z"]), c2, c2
+        else:
+            out_ptr, ldo, c2s = self._ptr(y), self._ld(y), op["c2_store"]
+        d = _lib.ConvDesc(dtype=_lib.Y5_F16, B=B, H=g["H"], W=g["W"], C1=g["C1"], ldx=g["ldx"], OH=y.H, OW=y.W, C2=c2s, ldy=ldo,
+                          KH=g["k"][0], KW=g["k"][1], SH=g["s"][0], SW=g["s"][1], PH=g["p"][0], PW=g["p"][1], act=0, Kpad=Kpad, Npad=Npad,
+                          ldr=0, ld2=0, cfg=-1, max_blocks=0)
+        st["desc"] = d
+        _lib.check(lib.y5_conv2d_fwd(C.byref(d), _vp(self._ptr(x)), _vp(self.be.ptr(wd)), _vp(self.be.ptr(bd)), None, _vp(out_ptr), None, stm), lib)
+        if st["has_bn"]:
+            bn = st["mod"].bn
+            npix = B * y.H * y.W
+            gam, bet = self._dev(bn.weight.detach().float()), self._dev(bn.bias.detach().float())
+            st["gamma"], st["beta"] = gam, bet
+            rm, rv = self._running(bn)
+            _lib.check(lib.y5_bn_silu_fwd(_vp(self.be.ptr(st["z"])), _lib.Y5_F16, npix, cv.out_channels, cv.out_channels, _vp(self.be.ptr(gam)),
+                                          _vp(self.be.ptr(bet)), float(bn.eps), float(bn.momentum if bn.momentum is not None else 0.1),
+                                          rm, rv, _vp(self.be.ptr(st["mean"])), _vp(self.be.ptr(st["invstd"])),
+                                          _vp(self._ptr(res)) if res is not None else None, self._ld(res) if res is not None else 0,
+                                          _vp(self._ptr(y)), self._ld(y), _vp(self.be.ptr(self.ws)), self.ws_bytes, stm), lib)
+            self._running_done(bn)
+        if y2 is not None:
+            _lib.check(lib.y5_upsample2x(_vp(self._ptr(y)), _lib.Y5_F16, _vp(self._ptr(y2)), B, y.H, y.W, y.C, self._ld(y), self._ld(y2), stm), lib)
+
+    def _running(self, bn):
+        """Device pointers of the BatchNorm running statistics (updated in place by the kernel)."""
+        if not bn.track_running_stats or bn.running_mean is None:
+            return None, None
+        if isinstance(self.be, _HipBackend):
+            return _vp(bn.running_mean.data_ptr()), _vp(bn.running_var.data_ptr())
+        rm, rv = self.be.from_torch(bn.running_mean.detach().float()), self.be.from_torch(bn.running_var.detach().float())
+        self._run_tmp = (rm, rv)
+        return _vp(self.be.ptr(rm)), _vp(self.be.ptr(rv))
+
+    def _running_done(self, bn):
+        if not bn.track_running_stats or bn.running_mean is None:
+            return
+        if not isinstance(self.be, _HipBackend):  # host-emulated backend: copy the updated statistics back
+            rm, rv = self._run_tmp
+            bn.running_mean.copy_(self.be.to_torch(rm))
+            bn.running_var.copy_(self.be.to_torch(rv))
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+
+    # ---- backward --------------------------------------------------------------------------------------------------
+    def backward(self, dps):
+        lib, be, B = self.lib, self.be, self.spec.B
+        stm = be.stream()
+        written = {}
+
+        def is_written(t: TRef):
+            iv = written.get(t.buf, [])
+            lo, hi = t.c_off, t.c_off + t.C
+            covered = any(a <= lo and hi <= b for a, b in iv)
+            if not covered and any(a < hi and lo < b for a, b in iv):
+                raise RuntimeError("training plan: partially written gradient slice")
+            return covered
+
+        def mark(t: TRef):
+            iv = written.setdefault(t.buf, [])
+            iv.append((t.c_off, t.c_off + t.C))
+            iv.sort()
+            merged = [iv[0]]
+            for a, b in iv[1:]:
+                if a <= merged[-1][1]:
+                    merged[-1] = (merged[-1][0], max(merged[-1][1], b))
+                else:
+                    merged.append((a, b))
+            written[t.buf] = merged
+
+        grads = [None] * len(self.params)
+        hold = []
+        for op in reversed(self.spec.ops):
+            kind = op["op"]
+            if kind == "decode":
+                lg = op["x"]
+                dp = dps[op["level"]]
+                dph, dpp, _ = be.input(dp)
+                hold.append(dph)
+                _lib.check(lib.y5_raw_to_nhwc(_vp(dpp), _vp(self._ptr(lg, True)), B, op["ny"] * op["nx"], op["na"], op["no"], self._ld(lg), stm), lib)
+                mark(lg)
+            elif kind == "sppf_pool":
+                b = op["buf"]
+                if not is_written(b):
+                    raise RuntimeError("training plan: SPPF gradient buffer not produced")
+                _lib.check(lib.y5_sppf_pool_bwd(_vp(self._ptr(b)), _vp(self._ptr(b, True)), B, b.H, b.W, op["C"], self._ld(b), self._ld(b), op["k"], stm), lib)
+            elif kind == "conv":
+                self._bwd_conv(op["_st"], stm, is_written, mark, grads, hold)
+            elif kind == "to_nhwc":
+                pass
+            else:
+                raise NotImplementedError(kind)
+        out = []
+        for p, g in zip(self.params, grads):
+            out.append(None if g is None else g.to(device=p.device, dtype=p.dtype))
+        return out
+
+    def _bwd_conv(self, st, stm, is_written, mark, grads, hold):
+        lib, be, B = self.lib, self.be, self.spec.B
+        op, cv, m = st["op"], st["cv"], st["mod"]
+        x, y, res, y2 = op["x"], op["y"], op["res"], op["y2"]
+        npix = B * y.H * y.W
+        if y2 is not None:
+            _lib.check(lib.y5_upsample2x_bwd(_vp(self._ptr(y2, True)), _vp(self._ptr(y, True)), B, y.H, y.W, y.C, self._ld(y2), self._ld(y),
+                                             1 if is_written(y) else 0, stm), lib)
+            mark(y)
+        if not is_written(y):
+            raise RuntimeError(f"training plan: gradient of {op['name']} output was never produced")
+        if st["has_bn"]:
+            c2 = cv.out_channels
+            if res is not None:
+                _lib.check(lib.y5_add_slice(_vp(self._ptr(y, True)), _vp(self._ptr(res, True)), npix, y.C, self._ld(y), self._ld(res),
+                                            1 if is_written(res) else 0, stm), lib)
+                mark(res)
+            _lib.check(lib.y5_bn_silu_bwd(_vp(self._ptr(y, True)), self._ld(y), _vp(be.ptr(st["z"])), c2, _lib.Y5_F16, npix, c2,
+                                          _vp(be.ptr(st["gamma"])), _vp(be.ptr(st["beta"])), _vp(be.ptr(st["mean"])), _vp(be.ptr(st["invstd"])),
+                                          _vp(be.ptr(self.dz)), c2, _vp(be.ptr(st["dgamma"])), _vp(be.ptr(st["dbeta"])),
+                                          _vp(be.ptr(self.ws)), self.ws_bytes, stm), lib)
+            dz_ptr, ld_dz, c2s = be.ptr(self.dz), c2, c2
+            grads[self._pidx[id(m.bn.weight)]] = be.to_torch(st["dgamma"]).clone()
+            grads[self._pidx[id(m.bn.bias)]] = be.to_torch(st["dbeta"]).clone()
+        else:
+            dz_ptr, ld_dz, c2s = self._ptr(y, True), self._ld(y), op["c2_store"]
+            _lib.check(lib.y5_channel_sum(_vp(dz_ptr), _lib.Y5_F16, npix, c2s, ld_dz, _vp(be.ptr(st["dbias"])), _vp(be.ptr(self.ws)), self.ws_bytes, stm), lib)
+            if cv.bias is not None:
+                grads[self._pidx[id(cv.bias)]] = be.to_torch(st["dbias"])[:cv.out_channels].clone()
+        # weight gradient
+        g = self._geom(st)
+        Kpad, Npad, K = st["Kpad"], st["Npad"], st["K"]
+        dw = be.empty((Npad, Kpad), torch.float32)
+        be.zero_(dw)
+        hold.append(dw)
+        d = _lib.ConvDesc(dtype=_lib.Y5_F16, B=B, H=g["H"], W=g["W"], C1=g["C1"], ldx=g["ldx"], OH=y.H, OW=y.W, C2=c2s, ldy=ld_dz,
+                          KH=g["k"][0], KW=g["k"][1], SH=g["s"][0], SW=g["s"][1], PH=g["p"][0], PW=g["p"][1], act=0, Kpad=Kpad, Npad=Npad,
+                          cfg=-1, max_blocks=0)
+        _lib.check(lib.y5_conv2d_wgrad(C.byref(d), _vp(self._ptr(x)), _vp(dz_ptr), ld_dz, _vp(be.ptr(dw)), stm), lib)
+        c2, c1, kh, kw = cv.weight.shape
+        dwt = be.to_torch(dw)[:c2, :K]
+        if op["view"] == "first":
+            gw = dwt.reshape(c2, kh, kw, x.C).permute(0, 3, 1, 2)[:, :c1]      # k = (kh, kw, c4) also in the paired-pixel view
+        else:
+            gw = dwt.reshape(c2, kh, kw, c1).permute(0, 3, 1, 2)
+        grads[self._pidx[id(cv.weight)]] = gw.contiguous().clone()
+        # data gradient
+        if op["view"] == "first":
+            return
+        w = cv.weight.detach().float()
+        if w.shape[0] < c2s:  # Detect: 255 real output channels in a 256-channel logits buffer
+            w = torch.cat((w, torch.zeros((c2s - w.shape[0],) + tuple(w.shape[1:]), device=w.device)), 0)
+        acc = is_written(x)
+        for sub in dgrad_subconvs(w, op["s"], op["p"], (x.H, x.W)):
+            if sub["empty"]:
+                raise NotImplementedError("dgrad: parity class without taps")
+            wp, bp, K2, Kpad2, Npad2 = pack_conv_weight(sub["w"], None, torch.float16)
+            wd, bd = be.from_torch(wp), be.from_torch(bp)
+            hold += [wd, bd]
+            dense = tuple(op["s"]) == (1, 1)
+            dd = _lib.ConvDesc(dtype=_lib.Y5_F16, B=B, H=y.H, W=y.W, C1=c2s, ldx=ld_dz, OH=sub["nh"], OW=sub["nw"], C2=x.C, ldy=self._ld(x),
+                               KH=sub["k"][0], KW=sub["k"][1], SH=1, SW=1, PH=sub["pad"][0], PW=sub["pad"][1], act=0, Kpad=Kpad2, Npad=Npad2,
+                               ldr=self._ld(x) if acc else 0, ld2=0, cfg=-1, max_blocks=0,
+                               out_mul_h=0 if dense else op["s"][0], out_mul_w=0 if dense else op["s"][1], out_off_h=sub["rh"],
+                               out_off_w=sub["rw"], out_H=0 if dense else x.H, out_W=0 if dense else x.W)
+            gx = _vp(self._ptr(x, True))
+            _lib.check(lib.y5_conv2d_fwd(C.byref(dd), _vp(dz_ptr), _vp(be.ptr(wd)), _vp(be.ptr(bd)), gx if acc else None, gx, None, stm), lib)
+        mark(x)
+
+
+class _TrainFn(torch.autograd.Function):
+    """parameters -> raw head outputs, with the HIP backward plan as the gradient."""
+
+    @staticmethod
+    def forward(ctx, eng, x, *params):
+        ctx.eng = eng
+        outs = eng.forward(x)
+        return tuple(eng.be.to_torch(o) for o in outs)
+
+    @staticmethod
+    def backward(ctx, *dps):
+        grads = ctx.eng.backward([d.contiguous() for d in dps])
+        return (None, None, *grads)
+
+
+def train_forward(model, x):
+    """Train-mode `BaseModel._forward_once` (models/yolo.py:160-170): list of (bs, na, ny, nx, no) fp16 tensors."""
+    key = (tuple(x.shape), str(x.device))
+    cache = model.__dict__.setdefault("_train_engines", {})
+    eng = cache.get(key)
+    if eng is None:
+        cache.clear()
+        eng = TrainEngine(model, tuple(x.shape), x.device)
+        cache[key] = eng
+    return list(_TrainFn.apply(eng, x, *eng.params))

@@ -3,8 +3,8 @@ BaseModel :153-212, DetectionModel :215-327, SegmentationModel :333, parse_model
 
 Eval-mode `forward` is one call into the HIP execution plan (yolov5_amd.engine); what it returns matches the
 reference: `(z[bs, N, no], [raw_i[bs, na, ny, nx, no]])`, `(z,)` when `Detect.export` is set (AutoShape), and
-`(z, proto, raw)` / `(z, proto)` for Segment.  Training-mode forward (raw maps + autograd) is not built yet
-(next rounds) and raises NotImplementedError.
+`(z, proto, raw)` / `(z, proto)` for Segment.  Training-mode forward returns the raw maps and is differentiable
+w.r.t. the parameters through the HIP backward plan of yolov5_amd/train_engine.py.
 """
 from __future__ import annotations
 
@@ -77,8 +77,9 @@ class BaseModel(nn.Module):
 
     def _forward_once(self, x, profile=False):
         if self.training:
-            raise NotImplementedError(
-                "yolov5_amd: training-mode forward/backward HIP kernels are not built yet; call model.eval()")
+            from .train_engine import train_forward
+
+            return train_forward(self, x)  # list of raw (bs, na, ny, nx, no) maps, differentiable w.r.t. the parameters
         det = self.model[-1]
         want_raw = not getattr(det, "export", False)
         key = (tuple(x.shape), next(self.parameters()).dtype, str(x.device), want_raw, self._weights_version())
