@@ -94,6 +94,7 @@ class TrainEngine:
         self.ws = self.be.empty((max(max_ws, 256),), torch.uint8)
         self.ws_bytes = max(max_ws, 256)
         self._keep = []
+        self.grad_sink = None   # HipDDP (torch_utils.py): receives every parameter gradient as soon as it is queued
 
     # ---- helpers ---------------------------------------------------------------------------------------------------
     def _ptr(self, t: TRef, grad=False):
@@ -238,6 +239,17 @@ class TrainEngine:
 
         grads = [None] * len(self.params)
         hold = []
+        sink = self.grad_sink
+        if sink is not None:
+            sink.begin()
+
+        class _G(list):  # grads[i] = t also reports t to the sink (bucketed all-reduce overlapped with the rest of backward)
+            def __setitem__(s2, i, t):
+                if sink is not None and t is not None:
+                    t = sink.grad_ready(i, t.to(device=self.params[i].device, dtype=torch.float32))
+                list.__setitem__(s2, i, t)
+
+        grads = _G(grads)
         for op in reversed(self.spec.ops):
             kind = op["op"]
             if kind == "decode":
@@ -258,6 +270,8 @@ class TrainEngine:
                 pass
             else:
                 raise NotImplementedError(kind)
+        if sink is not None:
+            sink.finish(grads)
         out = []
         for p, g in zip(self.params, grads):
             out.append(None if g is None else g.to(device=p.device, dtype=p.dtype))
@@ -357,4 +371,5 @@ def train_forward(model, x):
         cache.clear()
         eng = TrainEngine(model, tuple(x.shape), x.device)
         cache[key] = eng
+    eng.grad_sink = model.__dict__.get("_ddp_sink")
     return list(_TrainFn.apply(eng, x, *eng.params))
