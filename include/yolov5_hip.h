@@ -175,6 +175,17 @@ int y5_raw_to_nhwc(const void* draw, void* dlogits, int B, int npix, int na, int
 int y5_upsample2x_bwd(const void* gup, void* gsrc, int B, int H, int W, int C, int ld_up, int ld_src, int accumulate, void* stream);
 int y5_add_slice(const void* src, void* dst, long long npix, int C, int lds, int ldd, int accumulate, void* stream);
 int y5_sppf_pool_bwd(const void* act, void* grad, int B, int H, int W, int C, int ld_act, int ld_grad, int k, void* stream);
+/* Filter (re)packing on the device -- fp32 master weights (C2, C1, KH, KW) change at every optimizer step:
+ * y5_pack_conv_weight : -> fp16 [Npad][Kpad], k = (kh*KW + kw)*C1_view + c (C1_view >= C1: channel padding of the stem view)
+ * y5_pack_dgrad_weight: -> fp16 [Npad][Kpad] sub-filter of one data-gradient parity class, out[c1][(a*ntw + b)*C2_view + c2] =
+ *                          w[c2][c1][taps_h[a]][taps_w[b]]  (taps_* are HOST arrays, at most 8 entries)
+ * y5_unpack_conv_wgrad: fp32 [.][Kpad] weight gradient of y5_conv2d_wgrad -> (C2, C1, KH, KW) parameter layout
+ * y5_memset_zero      : hipMemsetAsync on the stream (zero-fill of the weight-gradient accumulators) */
+int y5_pack_conv_weight(const float* w, int C2, int C1, int KH, int KW, int C1_view, void* out_f16, int Kpad, int Npad, void* stream);
+int y5_pack_dgrad_weight(const float* w, int C2, int C1, int KH, int KW, const int* taps_h, int nth, const int* taps_w, int ntw,
+                         int C2_view, void* out_f16, int Kpad, int Npad, void* stream);
+int y5_unpack_conv_wgrad(const float* dw_packed, int Kpad, float* gw, int C2, int C1, int KH, int KW, int C1_view, void* stream);
+int y5_memset_zero(void* p, size_t bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * y5_loss_forward / y5_loss_backward -- utils/loss.py:101-247 `ComputeLoss.__call__` + `build_targets`, including

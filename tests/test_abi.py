@@ -53,5 +53,5 @@ def test_no_cpu_fallback_for_model_forward():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError, match="GPU"):
         m(torch.zeros(1, 3, 64, 64))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="GPU"):
         m.train()(torch.zeros(1, 3, 64, 64))

@@ -8,7 +8,7 @@
 namespace {
 int nblk_for(long long npix) {
   long long n = (npix + 63) / 64;
-  return (int)(n < 1 ? 1 : n > 1024 ? 1024 : n);
+  return (int)(n < 1 ? 1 : n > 512 ? 512 : n);
 }
 int check(int dt, long long npix, int C, const void* ws, size_t ws_bytes) {
   if (dt != Y5_F16 && dt != Y5_F32) return y5_fail(Y5_ERR_BAD_ARG, "bn: dtype must be Y5_F16 or Y5_F32");
@@ -44,7 +44,7 @@ extern "C" int y5_bn_silu_fwd(const void* z, int dt, long long npix, int C, int 
   p.running_mean = running_mean; p.running_var = running_var; p.partial = static_cast<float*>(ws);
   p.npix = npix; p.C = C; p.ldz = ldz; p.ldr = ldr; p.ldo = ldy; p.nblk = nblk_for(npix); p.eps = eps; p.momentum = momentum;
   reduce<0>(p, dt, st);
-  hipLaunchKernelGGL(y5_bn_finish_kernel<0>, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(y5_bn_finish_kernel<0>, dim3((unsigned)C), dim3(128), 2 * 128 * 8, st, p);
   const dim3 g(apply_grid(npix, C, dt));
   if (dt == Y5_F16) {
     if (residual) hipLaunchKernelGGL((y5_bn_silu_apply_kernel<half_t, true>), g, dim3(256), 0, st, p);
@@ -68,7 +68,7 @@ extern "C" int y5_bn_silu_bwd(const void* dy, int ld_dy, const void* z, int ldz,
   p.partial = static_cast<float*>(ws); p.dgamma = dgamma; p.dbeta = dbeta;
   p.npix = npix; p.C = C; p.ldz = ldz; p.ldy = ld_dy; p.ldo = ld_dz; p.nblk = nblk_for(npix);
   reduce<1>(p, dt, st);
-  hipLaunchKernelGGL(y5_bn_finish_kernel<1>, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(y5_bn_finish_kernel<1>, dim3((unsigned)C), dim3(128), 2 * 128 * 8, st, p);
   const dim3 g(apply_grid(npix, C, dt));
   if (dt == Y5_F16) hipLaunchKernelGGL((y5_bn_silu_bwd_apply_kernel<half_t>), g, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((y5_bn_silu_bwd_apply_kernel<float>), g, dim3(256), 0, st, p);
@@ -83,6 +83,6 @@ extern "C" int y5_channel_sum(const void* x, int dt, long long npix, int C, int 
   p.dy = x; p.partial = static_cast<float*>(ws); p.dbeta = out; p.dgamma = nullptr;
   p.npix = npix; p.C = C; p.ldy = ld; p.nblk = nblk_for(npix);
   reduce<2>(p, dt, st);
-  hipLaunchKernelGGL(y5_bn_finish_kernel<2>, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(y5_bn_finish_kernel<2>, dim3((unsigned)C), dim3(128), 2 * 128 * 8, st, p);
   return y5_check_launch("y5_channel_sum");
 }

@@ -101,17 +101,30 @@ void y5_chan_reduce_kernel(const Y5BnParams p) {
   }
 }
 
+// One workgroup per channel: 128 threads sum the per-block partials (strided, fp64), fixed-order tree in LDS.
 // MODE 0: batch statistics (+ running update, torch semantics: running_var uses the unbiased estimate)
 // MODE 1/2: plain sums -> dbeta (s0), dgamma (s1)
 template <int MODE>
-__global__ void y5_bn_finish_kernel(const Y5BnParams p) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= p.C) return;
+__global__ __launch_bounds__(128)
+void y5_bn_finish_kernel(const Y5BnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* s_red = reinterpret_cast<double*>(smem);  // [2][128]
+  const int c = blockIdx.x;
+  const int tid = threadIdx.x;
   double s0 = 0.0, s1 = 0.0;
-  for (int b = 0; b < p.nblk; ++b) {
+  for (int b = tid; b < p.nblk; b += 128) {
     s0 += (double)p.partial[((long long)b * 2 + 0) * p.C + c];
     s1 += (double)p.partial[((long long)b * 2 + 1) * p.C + c];
   }
+  s_red[tid] = s0;
+  s_red[128 + tid] = s1;
+  __syncthreads();
+  for (int d = 64; d > 0; d >>= 1) {
+    if (tid < d) { s_red[tid] += s_red[tid + d]; s_red[128 + tid] += s_red[128 + tid + d]; }
+    __syncthreads();
+  }
+  if (tid != 0) return;
+  s0 = s_red[0]; s1 = s_red[128];
   if constexpr (MODE == 0) {
     const double n = (double)p.npix;
     const double mean = s0 / n;

@@ -187,3 +187,84 @@ extern "C" int y5_sppf_pool_bwd(const void* act, void* grad, int B, int H, int W
                      (char*)grad, H, W, C * 2, ld_act * 2, ld_grad * 2, k);
   return y5_check_launch("y5_sppf_pool_bwd");
 }
+
+// ---- filter (re)packing on the device: fp32 master weights -> the fp16 layouts the kernels stream ---------------------
+// (replaces a dozen torch micro-ops per convolution per step; weights change at every optimizer step)
+// forward: out[n][k = (kh*KW + kw)*C1v + c] = w[n][c][kh][kw]   (c < C1, n < C2; everything else zero)
+__global__ void y5_pack_conv_weight_kernel(const float* __restrict__ w, half_t* __restrict__ out, int C2, int C1, int KH, int KW, int C1v,
+                                           int Kpad, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int k = (int)(i % Kpad);
+  const int n = (int)(i / Kpad);
+  float v = 0.f;
+  const int K = KH * KW * C1v;
+  if (n < C2 && k < K) {
+    const int c = k % C1v, t = k / C1v;
+    const int kh = t / KW, kw = t - kh * KW;
+    if (c < C1) v = w[((n * C1 + c) * KH + kh) * KW + kw];
+  }
+  out[i] = (half_t)v;
+}
+// data-gradient sub-filter of one parity class: out[n = c1][k = (a*NTW + b)*C2v + c2] = w[c2][c1][th[a]][tw[b]]
+struct Y5DgradTaps { int th[8], tw[8]; };
+__global__ void y5_pack_dgrad_weight_kernel(const float* __restrict__ w, half_t* __restrict__ out, int C2, int C1, int KH, int KW, int NTH,
+                                            int NTW, Y5DgradTaps taps, int C2v, int Kpad, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int k = (int)(i % Kpad);
+  const int n = (int)(i / Kpad);
+  float v = 0.f;
+  const int K = NTH * NTW * C2v;
+  if (n < C1 && k < K) {
+    const int c2 = k % C2v, t = k / C2v;
+    const int a = t / NTW, b = t - a * NTW;
+    if (c2 < C2) v = w[((c2 * C1 + n) * KH + taps.th[a]) * KW + taps.tw[b]];
+  }
+  out[i] = (half_t)v;
+}
+// weight gradient back to the parameter layout: gw[n][c][kh][kw] = dw[n][(kh*KW + kw)*C1v + c]
+__global__ void y5_unpack_conv_wgrad_kernel(const float* __restrict__ dw, float* __restrict__ gw, int C1, int KH, int KW, int C1v, int Kpad,
+                                            long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over gw elements
+  if (i >= total) return;
+  const int kw = (int)(i % KW);
+  long long t = i / KW;
+  const int kh = (int)(t % KH);
+  t /= KH;
+  const int c = (int)(t % C1);
+  const long long n = t / C1;
+  gw[i] = dw[n * Kpad + (kh * KW + kw) * C1v + c];
+}
+
+extern "C" int y5_pack_conv_weight(const float* w, int C2, int C1, int KH, int KW, int C1_view, void* out_f16, int Kpad, int Npad, void* stream_) {
+  if (!w || !out_f16 || C1_view < C1 || Kpad < KH * KW * C1_view || Npad < C2) return y5_fail(Y5_ERR_BAD_ARG, "pack_conv_weight: bad args");
+  const long long total = (long long)Npad * Kpad;
+  hipLaunchKernelGGL(y5_pack_conv_weight_kernel, dim3(nblk(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream_), w, (half_t*)out_f16, C2, C1,
+                     KH, KW, C1_view, Kpad, total);
+  return y5_check_launch("y5_pack_conv_weight");
+}
+extern "C" int y5_pack_dgrad_weight(const float* w, int C2, int C1, int KH, int KW, const int* taps_h, int nth, const int* taps_w, int ntw,
+                                    int C2_view, void* out_f16, int Kpad, int Npad, void* stream_) {
+  if (!w || !out_f16 || !taps_h || !taps_w || nth < 1 || nth > 8 || ntw < 1 || ntw > 8 || C2_view < C2 || Kpad < nth * ntw * C2_view || Npad < C1)
+    return y5_fail(Y5_ERR_BAD_ARG, "pack_dgrad_weight: bad args");
+  Y5DgradTaps t{};
+  for (int i = 0; i < nth; ++i) t.th[i] = taps_h[i];
+  for (int i = 0; i < ntw; ++i) t.tw[i] = taps_w[i];
+  const long long total = (long long)Npad * Kpad;
+  hipLaunchKernelGGL(y5_pack_dgrad_weight_kernel, dim3(nblk(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream_), w, (half_t*)out_f16, C2, C1,
+                     KH, KW, nth, ntw, t, C2_view, Kpad, total);
+  return y5_check_launch("y5_pack_dgrad_weight");
+}
+extern "C" int y5_unpack_conv_wgrad(const float* dw_packed, int Kpad, float* gw, int C2, int C1, int KH, int KW, int C1_view, void* stream_) {
+  if (!dw_packed || !gw || C1_view < C1 || Kpad < KH * KW * C1_view) return y5_fail(Y5_ERR_BAD_ARG, "unpack_conv_wgrad: bad args");
+  const long long total = (long long)C2 * C1 * KH * KW;
+  hipLaunchKernelGGL(y5_unpack_conv_wgrad_kernel, dim3(nblk(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream_), dw_packed, gw, C1, KH, KW,
+                     C1_view, Kpad, total);
+  return y5_check_launch("y5_unpack_conv_wgrad");
+}
+extern "C" int y5_memset_zero(void* p, size_t bytes, void* stream_) {
+  if (!p) return y5_fail(Y5_ERR_BAD_ARG, "memset_zero: null");
+  if (hipMemsetAsync(p, 0, bytes, static_cast<hipStream_t>(stream_)) != hipSuccess) return y5_fail(Y5_ERR_RUNTIME, "memset_zero failed");
+  return Y5_OK;
+}

@@ -293,6 +293,34 @@ def folded_weights(mods):
 _TUNE_CACHE = {}  # conv descriptor (shape/dtype/strides) -> fastest tile configuration id, per process
 
 
+def autotune_conv(lib, d, ptrs, st):
+    """Measure-don't-guess tile selection: HIP-event timing of every kernel configuration on the real buffers
+    (cached per descriptor for the life of the process).  ptrs = (x, w, bias, residual, y, y2) as c_void_p / None."""
+    key = tuple(getattr(d, f) for f, _ in _lib.ConvDesc._fields_ if f not in ("cfg", "max_blocks")) + tuple(p is None or p.value is None for p in ptrs)
+    best = _TUNE_CACHE.get(key)
+    if best is not None:
+        return best
+    ncfg = lib.y5_conv_num_cfgs() if d.dtype == _lib.Y5_F16 else 4
+    ms = C.c_float(0)
+    best, best_ms = -1, float("inf")
+    bm, bn, kb = C.c_int(0), C.c_int(0), C.c_int(0)
+    iters = int(os.environ.get("Y5_AUTOTUNE_ITERS", "5"))
+    for cfg in range(ncfg):
+        lib.y5_conv_cfg_info(cfg, C.byref(bm), C.byref(bn), C.byref(kb))
+        if bn.value >= 2 * d.Npad and bn.value > 32:
+            continue  # more than half of the tile's channels would be padding
+        d.cfg = cfg
+        rc = lib.y5_conv2d_time(C.byref(d), *ptrs, iters, st, C.byref(ms))
+        if rc != 0:
+            continue  # configuration not applicable to this shape
+        if ms.value < best_ms:
+            best, best_ms = cfg, ms.value
+    if best < 0:
+        _lib.check(-2, lib)
+    _TUNE_CACHE[key] = best
+    return best
+
+
 class _HipBackend:
     """Device memory + stream provider of the Engine: PyTorch-ROCm caching allocator and current HIP stream.
     (The Engine takes it as a parameter so that tests can drive the very same plan-materialisation code against
@@ -477,30 +505,7 @@ class Engine:
                                          self._ptr(res), self._ptr(y), self._ptr(y2))
 
     def _autotune_conv(self, d, ptrs):
-        """Measure-don't-guess tile selection: HIP-event timing of each tile configuration on the real buffers."""
-        key = tuple(getattr(d, f) for f, _ in _lib.ConvDesc._fields_ if f not in ("cfg", "max_blocks")) + tuple(p is None or p.value is None for p in ptrs)
-        best = _TUNE_CACHE.get(key)
-        if best is not None:
-            return best
-        ncfg = self.lib.y5_conv_num_cfgs() if d.dtype == _lib.Y5_F16 else 4
-        st = self._stream()
-        ms = C.c_float(0)
-        best, best_ms = -1, float("inf")
-        bm, bn, kb = C.c_int(0), C.c_int(0), C.c_int(0)
-        for cfg in range(ncfg):
-            self.lib.y5_conv_cfg_info(cfg, C.byref(bm), C.byref(bn), C.byref(kb))
-            if bn.value >= 2 * d.Npad and bn.value > 32:
-                continue  # more than half of the tile's channels would be padding
-            d.cfg = cfg
-            rc = self.lib.y5_conv2d_time(C.byref(d), *ptrs, int(os.environ.get("Y5_AUTOTUNE_ITERS", "5")), st, C.byref(ms))
-            if rc != 0:
-                continue  # configuration not applicable to this shape (e.g. gather table too large)
-            if ms.value < best_ms:
-                best, best_ms = cfg, ms.value
-        if best < 0:
-            _lib.check(-2, self.lib)
-        _TUNE_CACHE[key] = best
-        return best
+        return autotune_conv(self.lib, d, ptrs, self._stream())
 
     # -- execution ---------------------------------------------------------------------------------------------
     def _stream(self):
