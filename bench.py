@@ -112,6 +112,61 @@ def cpu_baseline(seconds_budget=20.0):
             "sample": f"oracle/yolo_oracle.py forward+NMS, yolov5s fused fp32, {n} images of 3x640x640 (batches of {bs}), {dt:.1f} s"}
 
 
+def train_probe(name, batch, imgsz, dev, world, steps=6, warmup=2):
+    """Secondary measurement (BASELINE config 3 per-GPU shape): training step = train-mode forward + ComputeLoss + backward
+    (+ bucketed RCCL gradient all-reduce when world > 1) + SGD, fp16 compute with fp32 master weights, synthetic data."""
+    from yolov5_amd.loss import ComputeLoss
+    from yolov5_amd.torch_utils import smart_DDP
+    from yolov5_amd.yolo import DetectionModel
+
+    torch.manual_seed(0)
+    m = DetectionModel(name + ".yaml").to(dev).train()
+    m.hyp = {"box": 0.05, "cls": 0.5, "cls_pw": 1.0, "obj": 1.0, "obj_pw": 1.0, "anchor_t": 4.0, "fl_gamma": 0.0, "label_smoothing": 0.0}
+    compute_loss = ComputeLoss(m)
+    model = smart_DDP(m) if world > 1 else m
+    opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.937, nesterov=True)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    x = torch.rand((batch, 3, imgsz, imgsz), generator=g).half().to(dev)
+    nt = batch * 8
+    t = torch.cat((torch.randint(0, batch, (nt, 1), generator=g).float(), torch.randint(0, 80, (nt, 1), generator=g).float(),
+                   torch.rand((nt, 2), generator=g) * 0.8 + 0.1, torch.rand((nt, 2), generator=g) * 0.3 + 0.02), 1).to(dev)
+    scale = 1024.0
+
+    def step():
+        pred = model(x)
+        loss, _ = compute_loss(pred, t)
+        if world > 1:
+            loss = loss * world  # train.py:404-405
+        opt.zero_grad(set_to_none=True)
+        (loss * scale).backward()
+        for p in m.parameters():
+            p.grad.div_(scale)
+        opt.step()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    del m, model, opt
+    torch.cuda.empty_cache()
+    return {"images_per_sec": round(batch * world * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps,
+            "workload": f"{name} train step, {batch} img/GPU 3x{imgsz}x{imgsz}, {nt} targets: forward(train BN) + ComputeLoss + backward"
+                        f"{' + RCCL all-reduce' if world > 1 else ''} + SGD; fp16 compute / fp32 masters", "loss": round(float(loss), 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,6 +176,7 @@ def main():
     ap.add_argument("--imgsz", type=int, default=640)
     ap.add_argument("--model", default="yolov5s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement")
     ap.add_argument("--op-table", default="", help="write the per-op timing table (JSON) to this path")
     a = ap.parse_args()
 
@@ -204,6 +260,14 @@ def main():
         with open(a.op_table, "w") as f:
             json.dump(table, f, indent=1)
 
+    train = None
+    if not a.no_train:
+        try:
+            del model, eng
+            torch.cuda.empty_cache()
+            train = train_probe(a.model, a.batch, a.imgsz, dev, world)
+        except Exception as e:  # the headline metric must not depend on the secondary probe
+            train = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         imgs = a.batch * world * a.steps
         res = {
@@ -221,6 +285,8 @@ def main():
                          "algorithmic_gflop_per_step": round(conv_fl / 1e9, 1), "conv_ms_per_step": round(conv_ms, 4),
                          "launches_per_step": nconv, "other_kernels_ms_per_step": round(other_ms, 4)},
         }
+        if train is not None:
+            res["train"] = train
         if not a.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))

@@ -16,7 +16,7 @@ if [ "$WHAT" = "all" ] || [ "$WHAT" = "bench" ]; then
 fi
 if [ "$WHAT" = "all" ] || [ "$WHAT" = "prof" ]; then
   rm -rf gpurun_out/prof
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o r -- python "$OLDPWD/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof.log" 2>&1); echo "prof rc=$?"
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o r -- python "$OLDPWD/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-train > "$OLDPWD/gpurun_out/prof.log" 2>&1); echo "prof rc=$?"
   find gpurun_out/prof -name "*stats*" | head; 
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -30 "$f"
   # keep the merged-back directory small: drop the raw per-dispatch trace, keep the summaries

@@ -9,7 +9,7 @@ for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   rm -rf gpurun_out/pmcb_$i
-  (cd /tmp && Y5_AUTOTUNE_ITERS=2 timeout 400 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d "$OLDPWD/gpurun_out/pmcb_$i" -o p -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OLDPWD/gpurun_out/pmcb_$i.log" 2>&1)
+  (cd /tmp && Y5_AUTOTUNE_ITERS=2 timeout 400 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d "$OLDPWD/gpurun_out/pmcb_$i" -o p -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-train > "$OLDPWD/gpurun_out/pmcb_$i.log" 2>&1)
   echo "pass $i rc=$?"
 done
 python - <<'PY'
