@@ -86,6 +86,8 @@ inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorN
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_s_barrier() emu::barrier_block()
+#define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
+#define __builtin_amdgcn_sched_barrier(a) ((void)0)
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 inline void emu_wave_barrier() { const void* o[64]; char c = 0; emu::wave_exchange(&c, 1, o); }
 #define __builtin_amdgcn_wave_barrier() emu_wave_barrier()

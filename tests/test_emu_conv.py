@@ -29,7 +29,7 @@ CASES = [
     (2, 12, 12, 32, 64, 3, 2, 1, 1, False, False, 1, 1, "f32"),    # single block walks all tiles
     # streaming pointwise kernel (conv_pw.h): ring fill / steady state / drain, partial last workgroup tile, upsampled store
     (7, 8, 16, 32, 32, 1, 1, 0, 1, False, False, 14, 1, "f16"),    # 32->32, 7 tiles per wave on one workgroup, S=4
-    (7, 8, 16, 64, 32, 1, 1, 0, 1, False, False, 15, 1, "f16"),
+    (7, 8, 16, 64, 32, 1, 1, 0, 0, False, False, 15, 1, "f16"),
     (7, 8, 16, 64, 64, 1, 1, 0, 1, False, False, 16, 1, "f16"),
     (5, 4, 8, 64, 64, 1, 1, 0, 1, False, True, 17, 2, "f16"),      # 5 wave tiles: partial workgroup tile + up2
     (5, 8, 16, 128, 64, 1, 1, 0, 1, False, False, 18, 1, "f16"),
@@ -38,7 +38,7 @@ CASES = [
     (6, 8, 16, 128, 64, 1, 1, 0, 1, False, False, 21, 1, "f16"),
     # streaming 3x3 kernel (conv_k3.h): borders on all sides, partial workgroup tile, residual (in place), stride 2
     (2, 8, 16, 32, 32, 3, 1, 1, 1, True, False, 30, 1, "f16"),
-    (1, 12, 8, 32, 32, 3, 1, 1, 1, False, False, 33, 2, "f16"),
+    (1, 12, 8, 32, 32, 3, 1, 1, 0, False, False, 33, 2, "f16"),
     (2, 16, 32, 32, 64, 3, 2, 1, 1, False, False, 31, 1, "f16"),
     (1, 24, 16, 32, 64, 3, 2, 1, 1, False, False, 34, 1, "f16"),
     (3, 8, 8, 64, 64, 3, 1, 1, 1, True, False, 32, 1, "f16"),

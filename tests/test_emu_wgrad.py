@@ -39,6 +39,8 @@ CASES = [
     (2, 8, 8, 16, 72, (3, 3), (1, 1), (1, 1), 0),     # K = 144 -> 3 k tiles with a tail, two n tiles
     (1, 16, 8, 8, 32, (6, 3), (2, 1), (2, 1), 0),     # the stem's paired-pixel view (NHWC4 x 2 = 8 channels)
     (3, 5, 5, 128, 64, (1, 1), (1, 1), (0, 0), 4),
+    (2, 6, 6, 32, 136, (3, 3), (1, 1), (1, 1), 2),    # 128 x 128 block tile (2 x 2 accumulators per wave), n tail
+    (2, 7, 5, 64, 128, (1, 1), (1, 1), (0, 0), 0),    # 128 x 64 block tile
 ]
 
 

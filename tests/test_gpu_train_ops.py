@@ -142,3 +142,26 @@ def test_conv_dgrad(case, dev):
         ref = ref + init.float()
     torch.testing.assert_close(dxd[..., :C1].float().cpu(), ref, rtol=2e-2, atol=3e-2)
     assert torch.all(dxd[..., C1:] == 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,npix,na,no,ld", [(8, 1024, 3, 85, 256), (3, 64, 3, 85, 256), (4, 400, 3, 85, 264), (2, 6400, 3, 117, 352),
+                                              (5, 100, 3, 8, 24)])
+def test_head_layout_roundtrip(B, npix, na, no, ld, dev):
+    """models/yolo.py:96-98 view/permute and its backward, against the torch permute (bit-exact: pure data movement)."""
+    from yolov5_amd import _lib
+
+    lib = _lib.lib()
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    lg = torch.from_numpy(detgen.uniform((B, npix, ld), -4, 4, name="hl")).half().to(dev)
+    raw = torch.full((B, na, npix, no), 9.0, dtype=torch.float16, device=dev)
+    _lib.check(lib.y5_nhwc_to_raw(C.c_void_p(lg.data_ptr()), C.c_void_p(raw.data_ptr()), B, npix, na, no, ld, st), lib)
+    ref = lg[..., : na * no].view(B, npix, na, no).permute(0, 2, 1, 3).contiguous()
+    assert torch.equal(raw, ref)
+    draw = torch.from_numpy(detgen.uniform((B, na, npix, no), -1, 1, name="hd")).half().to(dev)
+    dlg = torch.full((B, npix, ld), 5.0, dtype=torch.float16, device=dev)
+    _lib.check(lib.y5_raw_to_nhwc(C.c_void_p(draw.data_ptr()), C.c_void_p(dlg.data_ptr()), B, npix, na, no, ld, st), lib)
+    torch.cuda.synchronize()
+    want = torch.zeros_like(dlg)
+    want[..., : na * no] = draw.permute(0, 2, 1, 3).reshape(B, npix, na * no)
+    assert torch.equal(dlg, want)

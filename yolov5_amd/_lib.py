@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libyolov5_hip.so")
+LIB_PATH = os.environ.get("Y5_LIB_PATH") or os.path.join(_HERE, "libyolov5_hip.so")  # override: kernel experiments only
 
 Y5_F16, Y5_F32, Y5_U8 = 0, 1, 2
 NMS_MULTI_LABEL, NMS_AGNOSTIC = 1, 2

@@ -132,16 +132,14 @@ constexpr PwCfg kPwCfgs[kNumPw] = {
     {2, 128, 2, 4},  // 21: 128 ->  64, 4 stages
 };
 
-template <int KC, int RB, int NT, int S>
-int launch_pw(const Y5ConvParams& p, int max_blocks, hipStream_t stream) {
+template <int KC, int RB, int NT, int S, bool UP2, bool ACT>
+int launch_pw_v(const Y5ConvParams& p, int max_blocks, hipStream_t stream) {
   const size_t lds = y5_conv_pw_lds_bytes<KC, RB, NT, S>();
   if (lds > 160 * 1024) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: pointwise configuration exceeds 160 KiB of LDS");
-  const void* kern = p.y2 ? reinterpret_cast<const void*>(y5_conv_pw_kernel<KC, RB, NT, S, true>)
-                          : reinterpret_cast<const void*>(y5_conv_pw_kernel<KC, RB, NT, S, false>);
+  auto kern = y5_conv_pw_kernel<KC, RB, NT, S, UP2, ACT>;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(y5_conv_pw_kernel<KC, RB, NT, S, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(y5_conv_pw_kernel<KC, RB, NT, S, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   const long long nbt = ((long long)(p.M >> 5) + 3) >> 2;
@@ -154,14 +152,18 @@ int launch_pw(const Y5ConvParams& p, int max_blocks, hipStream_t stream) {
       g_num_cu = n > 0 ? n : 256;
     }
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, lds) != hipSuccess || occ < 1) occ = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), 256, lds) != hipSuccess || occ < 1) occ = 1;
     G = (long long)g_num_cu * occ;
   }
   if (G > nbt) G = nbt;
   if (G >= 8) G &= ~7LL;
-  if (p.y2) hipLaunchKernelGGL((y5_conv_pw_kernel<KC, RB, NT, S, true>), dim3((unsigned)G), dim3(256), lds, stream, p);
-  else hipLaunchKernelGGL((y5_conv_pw_kernel<KC, RB, NT, S, false>), dim3((unsigned)G), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(256), lds, stream, p);
   return y5_check_launch("y5_conv2d_fwd(pw)");
+}
+template <int KC, int RB, int NT, int S>
+int launch_pw(const Y5ConvParams& p, int mb, hipStream_t st) {
+  if (p.y2) return p.act ? launch_pw_v<KC, RB, NT, S, true, true>(p, mb, st) : launch_pw_v<KC, RB, NT, S, true, false>(p, mb, st);
+  return p.act ? launch_pw_v<KC, RB, NT, S, false, true>(p, mb, st) : launch_pw_v<KC, RB, NT, S, false, false>(p, mb, st);
 }
 
 int launch_pw_by_cfg(const Y5ConvParams& p, int idx, int mb, hipStream_t s) {
@@ -189,16 +191,14 @@ constexpr K3Cfg kK3Cfgs[kNumK3] = {
     {32, 2, 2, 3},  // 34: 3x3 s2 32->64, 3 stages
 };
 
-template <int C1, int NT, int SH, int S>
-int launch_k3(const Y5ConvParams& p, int max_blocks, hipStream_t stream) {
+template <int C1, int NT, int SH, int S, bool RES, bool ACT>
+int launch_k3_v(const Y5ConvParams& p, int max_blocks, hipStream_t stream) {
   const size_t lds = y5_conv_k3_lds_bytes<C1, NT, SH, S>();
   if (lds > 160 * 1024) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: 3x3 streaming configuration exceeds 160 KiB of LDS");
-  const void* kern = p.res ? reinterpret_cast<const void*>(y5_conv_k3_kernel<C1, NT, SH, S, true>)
-                           : reinterpret_cast<const void*>(y5_conv_k3_kernel<C1, NT, SH, S, false>);
+  auto kern = y5_conv_k3_kernel<C1, NT, SH, S, RES, ACT>;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(y5_conv_k3_kernel<C1, NT, SH, S, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(y5_conv_k3_kernel<C1, NT, SH, S, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   const long long nwt = (long long)p.B * (p.OH / 4) * (p.OW / 8);
@@ -212,14 +212,18 @@ int launch_k3(const Y5ConvParams& p, int max_blocks, hipStream_t stream) {
       g_num_cu = n > 0 ? n : 256;
     }
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, lds) != hipSuccess || occ < 1) occ = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), 256, lds) != hipSuccess || occ < 1) occ = 1;
     G = (long long)g_num_cu * occ;
   }
   if (G > nbt) G = nbt;
   if (G >= 8) G &= ~7LL;
-  if (p.res) hipLaunchKernelGGL((y5_conv_k3_kernel<C1, NT, SH, S, true>), dim3((unsigned)G), dim3(256), lds, stream, p);
-  else hipLaunchKernelGGL((y5_conv_k3_kernel<C1, NT, SH, S, false>), dim3((unsigned)G), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(256), lds, stream, p);
   return y5_check_launch("y5_conv2d_fwd(k3)");
+}
+template <int C1, int NT, int SH, int S>
+int launch_k3(const Y5ConvParams& p, int mb, hipStream_t st) {
+  if (p.res) return p.act ? launch_k3_v<C1, NT, SH, S, true, true>(p, mb, st) : launch_k3_v<C1, NT, SH, S, true, false>(p, mb, st);
+  return p.act ? launch_k3_v<C1, NT, SH, S, false, true>(p, mb, st) : launch_k3_v<C1, NT, SH, S, false, false>(p, mb, st);
 }
 
 int launch_k3_by_cfg(const Y5ConvParams& p, int idx, int mb, hipStream_t s) {
@@ -317,13 +321,13 @@ extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w
   if (k3) {
     const K3Cfg& c = kK3Cfgs[cfg - kK3_0];
     if (d->dtype != Y5_F16 || d->KH != 3 || d->KW != 3 || d->SH != c.sh || d->SW != c.sh || d->PH != 1 || d->PW != 1 || !y || y_up2 ||
-        d->act != 1 || d->C1 != c.c1 || d->Npad != c.nt * 32 || (oh & 3) || (ow & 7) || d->Kpad < 9 * c.c1 || d->H > 255 * 4 || d->W > 65535)
+        d->C1 != c.c1 || d->Npad != c.nt * 32 || (oh & 3) || (ow & 7) || d->Kpad < 9 * c.c1 || d->H > 255 * 4 || d->W > 65535)
       return y5_fail(Y5_ERR_UNSUPPORTED, "conv: 3x3 streaming configuration does not match this layer");
     return launch_k3_by_cfg(p, cfg - kK3_0, d->max_blocks, stream);
   }
   if (pw) {
     const PwCfg& c = kPwCfgs[cfg - kNumIgemm];
-    if (d->dtype != Y5_F16 || d->KH != 1 || d->KW != 1 || d->SH != 1 || d->SW != 1 || d->PH || d->PW || residual || !y || d->act != 1 ||
+    if (d->dtype != Y5_F16 || d->KH != 1 || d->KW != 1 || d->SH != 1 || d->SW != 1 || d->PH || d->PW || residual || !y ||
         d->C1 != c.kc * c.rb / 2 || d->Npad != c.nt * 32 || (p.M & 31) || d->Kpad * 2 < c.kc * c.rb)
       return y5_fail(Y5_ERR_UNSUPPORTED, "conv: pointwise configuration does not match this layer");
     return launch_pw_by_cfg(p, cfg - kNumIgemm, d->max_blocks, stream);

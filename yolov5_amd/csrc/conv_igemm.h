@@ -192,6 +192,12 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
 
   auto stage = [&](int buf) {
     char* lds = smem + buf * BUF_BYTES;
+#ifdef Y5_DBG_NOLOAD
+    if (s_t > 0 || s_kc > 0) {
+      if (++s_kc == nk) { s_kc = 0; if (++s_t < nmine) loader_setup(s_t); }
+      return;
+    }
+#endif
     int tap_off = 0, tap_bit = 0;
     if constexpr (!TABLE) {
       tap_off = ((u_kh * p.W + u_kw) * p.ldx + u_c0) * ES;
@@ -345,6 +351,10 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
   constexpr int LPC = ACT_PER_WAVE + WGT_PER_WAVE;  // LDS-DMA instructions per chunk per wave (NS > 2: uniform)
 
   auto compute = [&](const char* lds) {
+#ifdef Y5_DBG_NOMFMA
+    asm volatile("" :: "v"(lds));
+    return;
+#endif
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
       for (int ks = 0; ks < RB / 32; ++ks) {

@@ -19,7 +19,7 @@ constexpr size_t y5_conv_k3_lds_bytes() {
   return (size_t)NT * 32 * 9 * C1 * 2 + (size_t)NT * 32 * 4 + (size_t)4 * S * NI * 1024;
 }
 
-template <int C1, int NT, int SH, int S, bool RES>
+template <int C1, int NT, int SH, int S, bool RES, bool ACT = true>
 __global__ __launch_bounds__(256)
 void y5_conv_k3_kernel(const Y5ConvParams p) {
   typedef half_t T;
@@ -189,7 +189,7 @@ void y5_conv_k3_kernel(const Y5ConvParams p) {
         const float4_t bv = *reinterpret_cast<const float4_t*>(blds + j * 32 + q * 8 + g * 4);
         half4_t o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (half_t)y5_silu(acc[j][q * 4 + e] + bv[e]);
+        for (int e = 0; e < 4; ++e) { const float t = acc[j][q * 4 + e] + bv[e]; o[e] = (half_t)(ACT ? y5_silu(t) : t); }
         const int slot = j * 4 + q;
         *reinterpret_cast<half4_t*>(st + pl * (NPAD * 2) + ((slot ^ (pl & SWM)) * 16) + g * 8) = o;
       }

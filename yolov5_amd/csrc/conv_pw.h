@@ -23,7 +23,7 @@ constexpr size_t y5_conv_pw_lds_bytes() {
   return (size_t)KC * NPAD * RB + (size_t)NPAD * 4 + (size_t)4 * S * STAGE;
 }
 
-template <int KC, int RB, int NT, int S, bool UP2>
+template <int KC, int RB, int NT, int S, bool UP2, bool ACT = true>
 __global__ __launch_bounds__(256)
 void y5_conv_pw_kernel(const Y5ConvParams p) {
   typedef half_t T;
@@ -151,7 +151,7 @@ void y5_conv_pw_kernel(const Y5ConvParams p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float t = acc[j][q * 4 + e] + bv[e];
-          o[e] = (half_t)y5_silu(t);  // the host only routes act == SiLU layers here
+          o[e] = (half_t)(ACT ? y5_silu(t) : t);
         }
         const int slot = j * 4 + q;
         *reinterpret_cast<half4_t*>(st + frow * (NPAD * 2) + ((slot ^ (frow & SWM)) * 16) + g * 8) = o;

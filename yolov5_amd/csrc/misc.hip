@@ -84,7 +84,7 @@ extern "C" int y5_detect_decode(const void* logits, int dt, int B, int ny, int n
                                 const float* anchors_px, void* z, int zdt, long long nrows_total, long long row_off, void* raw,
                                 void* stream_) {
   hipStream_t st = static_cast<hipStream_t>(stream_);
-  if (!logits || !z || !anchors_px || na < 1 || na > 8 || ld < na * no || nm < 0 || nm > no - 5)
+  if (!logits || (!z && !raw) || !anchors_px || na < 1 || na > 8 || ld < na * no || nm < 0 || nm > no - 5)
     return y5_fail(Y5_ERR_BAD_ARG, "detect_decode: bad args");
   Y5DecodeParams p{};
   p.logits = logits; p.z = z; p.raw = raw;
@@ -113,4 +113,19 @@ extern "C" int y5_detect_decode(const void* logits, int dt, int B, int ny, int n
   else if (dt == Y5_F32 && zdt == Y5_F32) hipLaunchKernelGGL((y5_detect_decode_kernel<float, float>), g, b, lds, st, p);
   else return y5_fail(Y5_ERR_BAD_ARG, "detect_decode: dtype pair");
   return y5_check_launch("y5_detect_decode");
+}
+
+// tiled fp16 head-layout kernels used by the training path (train_misc.hip declares the simple per-element versions)
+extern "C" int y5_raw_to_nhwc_tiled(const void* draw, void* dlogits, int B, int npix, int na, int no, int ld, void* stream_) {
+  if (!draw || !dlogits || B < 1 || npix < 1 || na < 1 || no < 1 || ld < na * no || (ld & 7) || (((uintptr_t)draw | (uintptr_t)dlogits) & 15))
+    return y5_fail(Y5_ERR_BAD_ARG, "raw_to_nhwc: bad args");
+  int P = 64;
+  while (P > 2 && (size_t)P * ld * 2 > 96 * 1024) P >>= 1;
+  if ((long long)P * no >= 65536) return y5_fail(Y5_ERR_UNSUPPORTED, "raw_to_nhwc: no too large");
+  const unsigned inv_no = (unsigned)((0x100000000ULL + (unsigned)no - 1) / (unsigned)no);
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)y5_raw_to_nhwc_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
+  hipLaunchKernelGGL(y5_raw_to_nhwc_tiled_kernel, dim3((unsigned)((npix + P - 1) / P), (unsigned)B), dim3(256), (size_t)P * ld * 2,
+                     static_cast<hipStream_t>(stream_), (const half_t*)draw, (half_t*)dlogits, npix, na, no, ld, P, inv_no);
+  return y5_check_launch("y5_raw_to_nhwc");
 }

@@ -192,7 +192,7 @@ void y5_detect_decode_kernel(const Y5DecodeParams p) {
             ro[k] = (half_t)v;
             if (++o == p.no) { o = 0; src += p.ld; gx = gxB; gy = gyB; }
           }
-          *reinterpret_cast<half8_t*>(zp + e0) = zo;
+          if (p.z) *reinterpret_cast<half8_t*>(zp + e0) = zo;
           if (rp) *reinterpret_cast<half8_t*>(rp + e0) = ro;
         }
         continue;
@@ -206,16 +206,60 @@ void y5_detect_decode_kernel(const Y5DecodeParams p) {
         typedef Z Z2 __attribute__((ext_vector_type(2)));
         typedef T T2 __attribute__((ext_vector_type(2)));
         Z2 zo; zo[0] = (Z)v0; zo[1] = (Z)v1;
-        *reinterpret_cast<Z2*>(zp + e) = zo;
+        if (p.z) *reinterpret_cast<Z2*>(zp + e) = zo;
         if (rp) { T2 ro; ro[0] = (T)r0; ro[1] = (T)r1; *reinterpret_cast<T2*>(rp + e) = ro; }
       }
     } else {
       for (int e = threadIdx.x; e < ne; e += blockDim.x) {
         float r0;
         const float v0 = y5_decode_one<T>(p, tile, pix0, a, e, r0);
-        zp[e] = (Z)v0;
+        if (p.z) zp[e] = (Z)v0;
         if (rp) rp[e] = (T)r0;
       }
     }
   }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Backward of the head layout change (models/yolo.py:96-98): draw (B, na, ny*nx, no) -> dlogits NHWC (B, ny*nx, ld),
+// channels >= na*no zeroed.  One workgroup per (image, tile of P pixels): the na contiguous runs of P*no gradients are
+// read 16 bytes per lane and scattered into an LDS tile laid out like the logits rows, which then leaves as 16-byte rows.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void y5_raw_to_nhwc_tiled_kernel(const half_t* __restrict__ draw, half_t* __restrict__ dlg, int npix, int na, int no, int ld, int P,
+                                 unsigned inv_no) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* tile = reinterpret_cast<half_t*>(smem);
+  const int b = blockIdx.y;
+  const int pix0 = blockIdx.x * P;
+  const int np = npix - pix0 < P ? npix - pix0 : P;
+  for (int i = threadIdx.x; i < np * ld / 8; i += blockDim.x) reinterpret_cast<uint4_t*>(smem)[i] = uint4_t{0, 0, 0, 0};
+  __syncthreads();
+  const int ne = np * no;
+  for (int a = 0; a < na; ++a) {
+    const long long rbase = (((long long)b * na + a) * npix + pix0) * no;
+    const half_t* src = draw + rbase;
+    if (((rbase | ne) & 7) == 0) {
+      for (int e0 = threadIdx.x * 8; e0 < ne; e0 += blockDim.x * 8) {
+        const half8_t v = *reinterpret_cast<const half8_t*>(src + e0);
+        int pl = (int)__umulhi((unsigned)e0, inv_no);
+        int o = e0 - pl * no;
+        half_t* dst = tile + pl * ld + a * no;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          dst[o] = v[k];
+          if (++o == no) { o = 0; dst += ld; }
+        }
+      }
+    } else {
+      for (int e = threadIdx.x; e < ne; e += blockDim.x) {
+        const int pl = (int)__umulhi((unsigned)e, inv_no);
+        tile[pl * ld + a * no + (e - pl * no)] = src[e];
+      }
+    }
+  }
+  __syncthreads();
+  uint4_t* out = reinterpret_cast<uint4_t*>(dlg + ((long long)b * npix + pix0) * ld);
+  for (int i = threadIdx.x; i < np * ld / 8; i += blockDim.x) out[i] = reinterpret_cast<const uint4_t*>(smem)[i];
 }

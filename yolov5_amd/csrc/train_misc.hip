@@ -147,8 +147,14 @@ void y5_sppf_pool_bwd_kernel(const char* __restrict__ act, char* __restrict__ gr
   }
 }
 
+extern "C" int y5_raw_to_nhwc_tiled(const void* draw, void* dlogits, int B, int npix, int na, int no, int ld, void* stream_);
 extern "C" int y5_nhwc_to_raw(const void* logits, void* raw, int B, int npix, int na, int no, int ld, void* stream_) {
   if (!logits || !raw || B < 1 || npix < 1 || na < 1 || no < 1 || ld < na * no) return y5_fail(Y5_ERR_BAD_ARG, "nhwc_to_raw: bad args");
+  if ((ld & 7) == 0 && na <= 8 && (((uintptr_t)logits | (uintptr_t)raw) & 15) == 0) {
+    // LDS-tiled path of the inference decode kernel, raw output only (z = NULL): nx = npix, ny = 1 keeps the row math trivial
+    const float anchors[16] = {0};
+    return y5_detect_decode(logits, Y5_F16, B, 1, npix, na, no, 0, ld, 1.0f, anchors, nullptr, Y5_F16, (long long)na * npix, 0, raw, stream_);
+  }
   const long long total = (long long)B * na * npix * no;
   hipLaunchKernelGGL(y5_nhwc_to_raw_kernel, dim3(nblk(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream_), (const half_t*)logits,
                      (half_t*)raw, npix, na, no, ld, total);
@@ -156,6 +162,8 @@ extern "C" int y5_nhwc_to_raw(const void* logits, void* raw, int B, int npix, in
 }
 extern "C" int y5_raw_to_nhwc(const void* draw, void* dlogits, int B, int npix, int na, int no, int ld, void* stream_) {
   if (!draw || !dlogits || B < 1 || npix < 1 || na < 1 || no < 1 || ld < na * no) return y5_fail(Y5_ERR_BAD_ARG, "raw_to_nhwc: bad args");
+  if ((ld & 7) == 0 && (((uintptr_t)draw | (uintptr_t)dlogits) & 15) == 0 && (long long)64 * no < 65536)
+    return y5_raw_to_nhwc_tiled(draw, dlogits, B, npix, na, no, ld, stream_);
   const long long total = (long long)B * npix * ld;
   hipLaunchKernelGGL(y5_raw_to_nhwc_kernel, dim3(nblk(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream_), (const half_t*)draw,
                      (half_t*)dlogits, npix, na, no, ld, total);

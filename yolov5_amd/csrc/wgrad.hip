@@ -22,19 +22,22 @@ struct Y5WgradParams {
   int pix_per_split;  // multiple of 32
 };
 
+template <int TNB, int TKB>
 __global__ __launch_bounds__(256)
 void y5_conv_wgrad_kernel(const Y5WgradParams p) {
   typedef half_t T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // [buf][dz tile 32 x 128 B | x tile 32 x 128 B]
-  constexpr int TILE = 32 * 128, BUF = 2 * TILE;
+  constexpr int ZROW = 128 * TNB, XROW = 128 * TKB;            // bytes per staged pixel row (64*T channels)
+  constexpr int ZT = 32 * ZROW, XT = 32 * XROW, BUF = ZT + XT;
+  constexpr int ZI = ZT / 1024, XI = XT / 1024, NI = (ZI + XI) / 4;  // LDS-DMA instructions per chunk: dz, x, per wave
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bid = blockIdx.x;
   const int tk = bid % p.tiles_k;
   const int tn = (bid / p.tiles_k) % p.tiles_n;
   const int sp = bid / (p.tiles_k * p.tiles_n);
-  const int n0 = tn * 64, k0 = tk * 64;
+  const int n0 = tn * 64 * TNB, k0 = tk * 64 * TKB;
   const int m_begin = sp * p.pix_per_split;
   const int m_end = m_begin + p.pix_per_split < p.M ? m_begin + p.pix_per_split : p.M;
   if (m_begin >= m_end) return;
@@ -43,48 +46,66 @@ void y5_conv_wgrad_kernel(const Y5WgradParams p) {
   const y5_rsrc_t xrs = y5_make_rsrc(p.x, p.x_bytes);
   const y5_rsrc_t zrs = y5_make_rsrc(p.dz, p.dz_bytes);
 
-  // staging roles: 8 LDS-DMA instructions per chunk (4 dz + 4 x), 2 per wave; instruction I covers rows 8*(I&3) .. +7
-  const int lrow = lane >> 3, lslot = lane & 7;
-  // x piece of this lane: k = k0 + 8*lslot -> tap, channel
-  const int kx = k0 + 8 * lslot;
-  const bool kx_ok = kx < p.K;
-  const int tap = kx_ok ? kx / p.C1 : 0;
-  const int cx = kx - tap * p.C1;
-  const int kh = tap / p.KW, kw = tap - kh * p.KW;
-  const bool nz_ok = n0 + 8 * lslot < p.Npad && n0 + 8 * lslot < p.C2 + 7;  // dz columns beyond C2 are never used
+  // staging roles: ZI + XI LDS-DMA instructions per chunk (1 KiB each), NI per wave; a dz instruction covers 1024/ZROW
+  // pixel rows of 64*TNB channels, an x instruction 1024/XROW rows of 64*TKB gathered k columns
   const int ohw = p.OH * p.OW;
+  int i_isx[NI], i_row[NI], i_col8[NI], i_dst[NI];   // per instruction of this wave: kind, pixel row, 8-channel group, LDS offset
+  int x_kh[NI], x_kw[NI], x_c[NI];
+  bool i_ok[NI];
+#pragma unroll
+  for (int q = 0; q < NI; ++q) {
+    const int I = wave * NI + q;
+    const bool isx = I >= ZI;
+    const int J = isx ? I - ZI : I;
+    const int rowb = isx ? XROW : ZROW;
+    const int lpr = rowb / 16;                       // lanes per pixel row
+    const int r = J * (1024 / rowb) + lane / lpr;    // pixel row inside the chunk
+    const int s8 = lane % lpr;                       // 16-byte group inside the row
+    i_isx[q] = isx; i_row[q] = r; i_col8[q] = s8; i_dst[q] = (isx ? ZT : 0) + J * 1024;
+    if (isx) {
+      const int kx = k0 + 8 * s8;
+      i_ok[q] = kx < p.K;
+      const int tap = i_ok[q] ? kx / p.C1 : 0;
+      x_c[q] = kx - tap * p.C1;
+      x_kh[q] = tap / p.KW; x_kw[q] = tap - x_kh[q] * p.KW;
+    } else {
+      i_ok[q] = n0 + 8 * s8 < p.C2;
+      x_c[q] = x_kh[q] = x_kw[q] = 0;
+    }
+  }
 
   auto stage = [&](int ch, int buf) {
     char* base = smem + buf * BUF;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int I = wave * 2 + q;            // 0..7
-      const int r = (I & 3) * 8 + lrow;      // pixel row inside the chunk
-      const int m = m_begin + ch * 32 + r;
+    for (int q = 0; q < NI; ++q) {
+      const int m = m_begin + ch * 32 + i_row[q];
       unsigned voff = Y5_OOB;
-      if (I < 4) {                           // dz rows
-        if (m < m_end && nz_ok) voff = (unsigned)((m * p.ldz + n0 + 8 * lslot) * 2);
-        y5_bglds16(zrs, voff, base + (I & 3) * 1024);
-      } else {                               // gathered x rows
-        if (m < m_end && kx_ok) {
+      if (m < m_end && i_ok[q]) {
+        if (!i_isx[q]) {
+          voff = (unsigned)((m * p.ldz + n0 + 8 * i_col8[q]) * 2);
+        } else {
           const int b = m / ohw;
           const int rr = m - b * ohw;
           const int oh = rr / p.OW, ow = rr - oh * p.OW;
-          const int ih = oh * p.SH - p.PH + kh, iw = ow * p.SW - p.PW + kw;
+          const int ih = oh * p.SH - p.PH + x_kh[q], iw = ow * p.SW - p.PW + x_kw[q];
           if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
-            voff = (unsigned)((((b * p.H + ih) * p.W + iw) * p.ldx + cx) * 2);
+            voff = (unsigned)((((b * p.H + ih) * p.W + iw) * p.ldx + x_c[q]) * 2);
         }
-        y5_bglds16(xrs, voff, base + TILE + (I & 3) * 1024);
       }
+      y5_bglds16(i_isx[q] ? xrs : zrs, voff, base + i_dst[q]);
     }
   };
 
-  // MFMA roles: wave -> 32 x 32 sub-tile (wn, wk) of the 64 x 64 block tile
+  // MFMA roles: wave -> (32*TNB) x (32*TKB) sub-tile (wn, wk) of the block tile, TNB x TKB accumulators
   const int wn = wave >> 1, wk = wave & 1;
   const int fi = lane & 31, g = lane >> 5;
-  float16_t acc;
+  float16_t acc[TNB][TKB];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int a = 0; a < TNB; ++a)
+#pragma unroll
+    for (int b2 = 0; b2 < TKB; ++b2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b2][r] = 0.f;
 
   stage(0, 0);
   __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -92,30 +113,39 @@ void y5_conv_wgrad_kernel(const Y5WgradParams p) {
   for (int ch = 0; ch < nchunks; ++ch) {
     const int cur = ch & 1;
     if (ch + 1 < nchunks) stage(ch + 1, cur ^ 1);
-    const T* zt = reinterpret_cast<const T*>(smem + cur * BUF) + wn * 32 + fi;          // [p][64]: column n
-    const T* xt = reinterpret_cast<const T*>(smem + cur * BUF + TILE) + wk * 32 + fi;   // [p][64]: column k
+    const T* zt = reinterpret_cast<const T*>(smem + cur * BUF) + wn * 32 * TNB + fi;        // [p][64*TNB]: column n
+    const T* xt = reinterpret_cast<const T*>(smem + cur * BUF + ZT) + wk * 32 * TKB + fi;   // [p][64*TKB]: column k
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      half8_t af, bf;
+      half8_t af[TNB], bf[TKB];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int pr = ks * 16 + g * 8 + e;
-        af[e] = zt[pr * 64];
-        bf[e] = xt[pr * 64];
+#pragma unroll
+        for (int a = 0; a < TNB; ++a) af[a][e] = zt[pr * (64 * TNB) + a * 32];
+#pragma unroll
+        for (int b2 = 0; b2 < TKB; ++b2) bf[b2][e] = xt[pr * (64 * TKB) + b2 * 32];
       }
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < TNB; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < TKB; ++b2) acc[a][b2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b2], acc[a][b2], 0, 0, 0);
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
   }
   // D[i][j]: col j = lane & 31 (k), row i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (n)
-  const int kcol = k0 + wk * 32 + fi;
-  if (kcol < p.K) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-      if (n < p.C2) atomicAdd(p.dw + (size_t)n * p.Kpad + kcol, acc[r]);
-    }
+  for (int b2 = 0; b2 < TKB; ++b2) {
+    const int kcol = k0 + wk * 32 * TKB + b2 * 32 + fi;
+    if (kcol >= p.K) continue;
+#pragma unroll
+    for (int a = 0; a < TNB; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 32 * TNB + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        if (n < p.C2) atomicAdd(p.dw + (size_t)n * p.Kpad + kcol, acc[a][b2][r]);
+      }
   }
 }
 
@@ -137,8 +167,9 @@ extern "C" int y5_conv2d_wgrad(const y5_conv_desc* d, const void* x, const void*
   p.K = d->KH * d->KW * d->C1; p.Kpad = d->Kpad; p.Npad = d->Npad;
   if (p.Kpad < p.K || p.Npad < p.C2) return y5_fail(Y5_ERR_BAD_ARG, "wgrad: bad packed filter dims");
   p.M = d->B * oh * ow;
-  p.tiles_n = (d->C2 + 63) / 64;
-  p.tiles_k = (p.K + 63) / 64;
+  const int tnb = d->C2 >= 128 ? 2 : 1, tkb = p.K >= 128 ? 2 : 1;
+  p.tiles_n = (d->C2 + 64 * tnb - 1) / (64 * tnb);
+  p.tiles_k = (p.K + 64 * tkb - 1) / (64 * tkb);
   int ncu = 256;
   {
     int dev = 0, n = 0;
@@ -154,6 +185,10 @@ extern "C" int y5_conv2d_wgrad(const y5_conv_desc* d, const void* x, const void*
   p.splits = (p.M + p.pix_per_split - 1) / p.pix_per_split;
   const long long grid = (long long)tiles * p.splits;
   if (grid > 0x7fffffffLL) return y5_fail(Y5_ERR_UNSUPPORTED, "wgrad: grid too large");
-  hipLaunchKernelGGL(y5_conv_wgrad_kernel, dim3((unsigned)grid), dim3(256), 2 * 2 * 32 * 128, st, p);
+  const size_t lds = (size_t)2 * 32 * 128 * (tnb + tkb);
+  if (tnb == 2 && tkb == 2) hipLaunchKernelGGL((y5_conv_wgrad_kernel<2, 2>), dim3((unsigned)grid), dim3(256), lds, st, p);
+  else if (tnb == 2) hipLaunchKernelGGL((y5_conv_wgrad_kernel<2, 1>), dim3((unsigned)grid), dim3(256), lds, st, p);
+  else if (tkb == 2) hipLaunchKernelGGL((y5_conv_wgrad_kernel<1, 2>), dim3((unsigned)grid), dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((y5_conv_wgrad_kernel<1, 1>), dim3((unsigned)grid), dim3(256), lds, st, p);
   return y5_check_launch("y5_conv2d_wgrad");
 }

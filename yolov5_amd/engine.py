@@ -297,6 +297,7 @@ def autotune_conv(lib, d, ptrs, st):
     """Measure-don't-guess tile selection: HIP-event timing of every kernel configuration on the real buffers
     (cached per descriptor for the life of the process).  ptrs = (x, w, bias, residual, y, y2) as c_void_p / None."""
     key = tuple(getattr(d, f) for f, _ in _lib.ConvDesc._fields_ if f not in ("cfg", "max_blocks")) + tuple(p is None or p.value is None for p in ptrs)
+    _load_tune_cache()
     best = _TUNE_CACHE.get(key)
     if best is not None:
         return best
@@ -305,7 +306,14 @@ def autotune_conv(lib, d, ptrs, st):
     best, best_ms = -1, float("inf")
     bm, bn, kb = C.c_int(0), C.c_int(0), C.c_int(0)
     iters = int(os.environ.get("Y5_AUTOTUNE_ITERS", "5"))
+    skip = set()
+    for part in os.environ.get("Y5_AUTOTUNE_SKIP", "").split(","):  # e.g. "14-21,30-34": keep kernel families out of the race
+        if part:
+            lo, _, hi = part.partition("-")
+            skip.update(range(int(lo), int(hi or lo) + 1))
     for cfg in range(ncfg):
+        if cfg in skip:
+            continue
         lib.y5_conv_cfg_info(cfg, C.byref(bm), C.byref(bn), C.byref(kb))
         if bn.value >= 2 * d.Npad and bn.value > 32:
             continue  # more than half of the tile's channels would be padding
@@ -318,7 +326,41 @@ def autotune_conv(lib, d, ptrs, st):
     if best < 0:
         _lib.check(-2, lib)
     _TUNE_CACHE[key] = best
+    _save_tune_cache()
     return best
+
+
+_TUNE_FILE_STATE = {"loaded": False}
+
+
+def _load_tune_cache():
+    """Optional persistence of the per-layer tile choices (env Y5_TUNE_CACHE=<json path>): skips the timing launches of
+    later processes (plan build in production, clean rocprof traces)."""
+    path = os.environ.get("Y5_TUNE_CACHE")
+    if not path or _TUNE_FILE_STATE["loaded"]:
+        return
+    _TUNE_FILE_STATE["loaded"] = True
+    try:
+        import json
+
+        with open(path) as f:
+            for k, v in json.load(f).items():
+                _TUNE_CACHE[tuple(int(x) if x not in ("True", "False") else x == "True" for x in k.split(","))] = int(v)
+    except (OSError, ValueError):
+        pass
+
+
+def _save_tune_cache():
+    path = os.environ.get("Y5_TUNE_CACHE")
+    if not path:
+        return
+    try:
+        import json
+
+        with open(path, "w") as f:
+            json.dump({",".join(str(x) for x in k): v for k, v in _TUNE_CACHE.items()}, f)
+    except OSError:
+        pass
 
 
 class _HipBackend:
@@ -326,7 +368,8 @@ class _HipBackend:
     (The Engine takes it as a parameter so that tests can drive the very same plan-materialisation code against
     the host-compiled kernels of tests/hipemu; the product only ever constructs this GPU backend.)"""
 
-    autotune = True  # time every workgroup-tile configuration per conv layer at plan build and keep the fastest
+    # time every workgroup-tile configuration per conv layer at plan build and keep the fastest (Y5_AUTOTUNE=0: heuristic tiles)
+    autotune = os.environ.get("Y5_AUTOTUNE", "1") != "0"
 
     def __init__(self, device):
         if not torch.cuda.is_available() or torch.device(device).type != "cuda":
