@@ -31,6 +31,11 @@ LAYERS = [
     ("7.Conv 3x3s2 256->512 @40", 40, 256, 512, 3, 2, 512, 512, False),
     ("9.SPPF.cv2 1x1 1024->512 @20", 20, 1024, 512, 1, 1, 1024, 512, False),
     ("detect.m0 1x1 128->255 @80", 80, 128, 256, 1, 1, 128, 256, False),
+    ("8.b.cv2 3x3 256->256 @20 +res", 20, 256, 256, 3, 1, 256, 512, True),
+    ("21.Conv 3x3s2 256->256 @40", 40, 256, 256, 3, 2, 256, 512, False),
+    ("18.Conv 3x3s2 128->128 @80", 80, 128, 128, 3, 2, 128, 256, False),
+    ("8.cv3 1x1 512->512 @20", 20, 512, 512, 1, 1, 512, 512, False),
+    ("8.cv1+cv2 1x1 512->512 @20", 20, 512, 512, 1, 1, 512, 512, False),
 ]
 
 
@@ -47,7 +52,7 @@ def main():
     ncfg = lib.y5_conv_num_cfgs()
     res = []
     for name, H, C1, C2, k, s, ldx, ldy, resid in LAYERS:
-        if a.only and a.only not in name:
+        if a.only and not any(o in name for o in a.only.split(",")):
             continue
         B = a.batch
         p = k // 2

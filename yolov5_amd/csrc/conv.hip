@@ -15,6 +15,25 @@ struct TileCfg { int wm, wn, tm, tn, rb; };
 constexpr int kNumIgemm = 14;
 constexpr int kRing0 = 22, kNumRing = 8;  // ids 22..29: tile shapes of ids {1,2,3,5,7,8,11,12} with a 3-stage ring
 constexpr int kRingBase[kNumRing] = {1, 2, 3, 5, 7, 8, 11, 12};
+// ids 35..39: large tiles for the deep layers (K >= 576, N >= 128).  The general mainloop is bound by the L2->LDS bytes in
+// flight per CU, so these trade occupancy for bytes per flop: 256-row tiles, BK32 chunks, deeper rings, 8 waves where the
+// tile is 256 wide.  (wm, wn, tm, tn, rb, stages)
+struct BigCfg { int wm, wn, tm, tn, rb, ns; };
+constexpr int kBig0 = 35, kNumBig = 11;
+constexpr BigCfg kBigCfgs[kNumBig] = {
+    {2, 2, 4, 2, 64, 4},   // 35: 256 x 128, BK32, 4 stages, 4 waves
+    {4, 2, 2, 2, 64, 4},   // 36: 256 x 128, BK32, 4 stages, 8 waves
+    {2, 4, 4, 2, 64, 4},   // 37: 256 x 256, BK32, 4 stages, 8 waves
+    {2, 4, 4, 2, 64, 3},   // 38: 256 x 256, BK32, 3 stages, 8 waves
+    {2, 4, 4, 2, 128, 2},  // 39: 256 x 256, BK64, 2 stages, 8 waves
+    // producer / consumer (conv_igemm.h PROD): as many LDS-DMA waves again as MFMA waves
+    {2, 2, 4, 2, 128, 3},  // 40: 256 x 128, BK64, 3 stages, 4 + 4 waves
+    {2, 2, 4, 2, 64, 4},   // 41: 256 x 128, BK32, 4 stages, 4 + 4 waves
+    {2, 2, 2, 2, 128, 3},  // 42: 128 x 128, BK64, 3 stages, 4 + 4 waves
+    {2, 2, 2, 2, 64, 4},   // 43: 128 x 128, BK32, 4 stages, 4 + 4 waves
+    {2, 2, 2, 4, 64, 4},   // 44: 128 x 256, BK32, 4 stages, 4 + 4 waves
+    {4, 1, 1, 2, 128, 3},  // 45: 128 x  64, BK64, 3 stages, 4 + 4 waves
+};
 constexpr TileCfg kCfgs[kNumIgemm] = {
     {4, 1, 1, 1, 64},   //  0: 128 x  32, BK32
     {4, 1, 1, 2, 64},   //  1: 128 x  64, BK32
@@ -34,7 +53,7 @@ constexpr TileCfg kCfgs[kNumIgemm] = {
 
 int g_num_cu = 0;
 
-template <typename T, int WM, int WN, int TM, int TN, int RB, bool TABLE, int NS = 2>
+template <typename T, int WM, int WN, int TM, int TN, int RB, bool TABLE, int NS = 2, bool PROD = false>
 int launch_cfg(const Y5ConvParams& p0, int max_blocks, hipStream_t stream) {
   using Gm = Y5ConvGeom<T, RB>;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -50,7 +69,8 @@ int launch_cfg(const Y5ConvParams& p0, int max_blocks, hipStream_t stream) {
   }
   const size_t lds = y5_conv_lds_bytes<T, WM, WN, TM, TN, RB, NS>(pieces);
   if (lds > 160 * 1024) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: tile configuration exceeds 160 KiB of LDS");
-  auto kern = y5_conv_igemm_kernel<T, WM, WN, TM, TN, RB, TABLE, NS>;
+  auto kern = y5_conv_igemm_kernel<T, WM, WN, TM, TN, RB, TABLE, NS, PROD>;
+  constexpr int NTHREADS = WM * WN * 64 * (PROD ? 2 : 1);
   static bool attr_done = false;  // per instantiation
   if (!attr_done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -68,13 +88,13 @@ int launch_cfg(const Y5ConvParams& p0, int max_blocks, hipStream_t stream) {
       g_num_cu = n > 0 ? n : 256;
     }
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), WM * WN * 64, lds) != hipSuccess || occ < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), NTHREADS, lds) != hipSuccess || occ < 1)
       occ = 1;
     G = (long long)g_num_cu * occ;
   }
   if (G > ntiles) G = ntiles;
   if (G >= 8) G &= ~7LL;  // y5_xcd_remap of the virtual block id needs G % 8 == 0 when blocks own several tiles
-  hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(WM * WN * 64), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(NTHREADS), lds, stream, p);
   return y5_check_launch("y5_conv2d_fwd");
 }
 
@@ -113,6 +133,17 @@ int launch_by_cfg(const Y5ConvParams& p, int cfg, int mb, hipStream_t s) {
       case kRing0 + 5: return launch_cfg<T, 2, 2, 2, 2, 128, TABLE, 3>(p, mb, s);
       case kRing0 + 6: return launch_cfg<T, 2, 2, 1, 2, 128, TABLE, 3>(p, mb, s);
       case kRing0 + 7: return launch_cfg<T, 2, 2, 4, 2, 128, TABLE, 3>(p, mb, s);
+      case kBig0 + 0: return launch_cfg<T, 2, 2, 4, 2, 64, TABLE, 4>(p, mb, s);
+      case kBig0 + 1: return launch_cfg<T, 4, 2, 2, 2, 64, TABLE, 4>(p, mb, s);
+      case kBig0 + 2: return launch_cfg<T, 2, 4, 4, 2, 64, TABLE, 4>(p, mb, s);
+      case kBig0 + 3: return launch_cfg<T, 2, 4, 4, 2, 64, TABLE, 3>(p, mb, s);
+      case kBig0 + 4: return launch_cfg<T, 2, 4, 4, 2, 128, TABLE, 2>(p, mb, s);
+      case kBig0 + 5: return launch_cfg<T, 2, 2, 4, 2, 128, TABLE, 3, true>(p, mb, s);
+      case kBig0 + 6: return launch_cfg<T, 2, 2, 4, 2, 64, TABLE, 4, true>(p, mb, s);
+      case kBig0 + 7: return launch_cfg<T, 2, 2, 2, 2, 128, TABLE, 3, true>(p, mb, s);
+      case kBig0 + 8: return launch_cfg<T, 2, 2, 2, 2, 64, TABLE, 4, true>(p, mb, s);
+      case kBig0 + 9: return launch_cfg<T, 2, 2, 2, 4, 64, TABLE, 4, true>(p, mb, s);
+      case kBig0 + 10: return launch_cfg<T, 4, 1, 1, 2, 128, TABLE, 3, true>(p, mb, s);
     }
     return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown tile config");
   }
@@ -252,6 +283,13 @@ extern "C" int y5_conv_num_cfgs(void) { return Y5_CONV_NUM_CFGS; }
 
 extern "C" int y5_conv_cfg_info(int cfg, int* bm, int* bn, int* bk_bytes) {
   if (cfg < 0 || cfg >= Y5_CONV_NUM_CFGS) return y5_fail(Y5_ERR_BAD_ARG, "conv_cfg_info: bad id");
+  if (cfg >= kBig0) {
+    const BigCfg& c = kBigCfgs[cfg - kBig0];
+    if (bm) *bm = c.wm * c.tm * 32;
+    if (bn) *bn = c.wn * c.tn * 32;
+    if (bk_bytes) *bk_bytes = c.rb;
+    return Y5_OK;
+  }
   if (cfg >= kK3_0) {
     const K3Cfg& c = kK3Cfgs[cfg - kK3_0];
     if (bm) *bm = 128;
@@ -283,8 +321,9 @@ extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w
   int cfg = d->cfg < 0 ? default_cfg(d) : d->cfg;
   if (cfg >= Y5_CONV_NUM_CFGS) return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown tile config");
   const bool pw = cfg >= kNumIgemm && cfg < kRing0;
-  const bool k3 = cfg >= kK3_0;
-  const int bk = (pw || k3) ? 8 : kCfgs[cfg >= kRing0 ? kRingBase[cfg - kRing0] : cfg].rb / es;
+  const bool big = cfg >= kBig0;
+  const bool k3 = cfg >= kK3_0 && !big;
+  const int bk = (pw || k3) ? 8 : (big ? kBigCfgs[cfg - kBig0].rb : kCfgs[cfg >= kRing0 ? kRingBase[cfg - kRing0] : cfg].rb) / es;
   if (cfg >= kRing0 && d->dtype != Y5_F16) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: ring configurations are fp16 only");
   if (d->C1 % epp || d->ldx % epp) return y5_fail(Y5_ERR_BAD_ARG, "conv: C1 and ldx must be multiples of 16 bytes");
   if (d->C2 % epp || (y && d->ldy % epp) || (residual && d->ldr % epp) || (y_up2 && d->ld2 % epp))
@@ -314,7 +353,7 @@ extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w
   p.ldr = d->ldr; p.ld2 = d->ld2;
   p.M = d->B * oh * ow;
   p.o_mul_h = d->out_mul_h; p.o_mul_w = d->out_mul_w; p.o_off_h = d->out_off_h; p.o_off_w = d->out_off_w; p.o_H = d->out_H; p.o_W = d->out_W;
-  if (placed && ((cfg >= kNumIgemm && cfg < kRing0) || cfg >= kK3_0)) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: output placement needs a general implicit-GEMM configuration");
+  if (placed && (pw || k3)) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: output placement needs a general implicit-GEMM configuration");
   p.x_bytes = (unsigned)((((long long)d->B * d->H * d->W - 1) * d->ldx + d->C1) * es);
   p.w_bytes = (unsigned)((long long)d->Npad * d->Kpad * es);
 
@@ -404,3 +443,12 @@ extern "C" int y5_conv_stem_fwd(const void* x_nchw, int B, int H, int W, const v
   p.nwt = B * p.OH * p.tiles_per_row;
   return Npad == 32 ? launch_stem<1, 4>(p, max_blocks, stream) : launch_stem<2, 3>(p, max_blocks, stream);
 }
+
+#ifdef Y5_DBG_TIMING
+extern "C" int y5_dbg_read_timing(unsigned long long* out) {  // kernel-experiment builds only (not part of the ABI)
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(y5_dbg_timing), sizeof(unsigned long long) * 128) == hipSuccess ? 0 : -1;
+}
+extern "C" int y5_dbg_read_blocks(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(y5_dbg_blocks), sizeof(unsigned long long) * 4096) == hipSuccess ? 0 : -1;
+}
+#endif

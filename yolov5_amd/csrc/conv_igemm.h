@@ -23,13 +23,11 @@
 #pragma once
 #include "y5_common.h"
 
-constexpr int y5_waitcnt_vm(int n) {  // s_waitcnt immediate: vmcnt(n), expcnt/lgkmcnt untouched (gfx9 encoding)
-  return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8);
-}
-template <int N> __device__ __forceinline__ void y5_wait_vm() {
-  __builtin_amdgcn_s_waitcnt(y5_waitcnt_vm(N < 63 ? N : 63));
-  asm volatile("" ::: "memory");
-}
+
+#ifdef Y5_DBG_TIMING
+__device__ unsigned long long y5_dbg_timing[128];
+__device__ unsigned long long y5_dbg_blocks[4096];  // per workgroup: kernel entry, loop start, loop end, exit (s_memrealtime, 100 MHz)
+#endif
 
 struct Y5ConvParams {
   const void* x;      // input  NHWC, pixel stride ldx elements
@@ -77,9 +75,16 @@ constexpr int y5_conv_min_waves(int tm, int tn) { return tm * tn <= 1 ? 5 : tm *
 // NS = number of LDS stages.  NS == 2: issue chunk i+1, compute chunk i, drain (vmcnt(0)) + barrier.  NS >= 3: a ring
 // with NS-1 chunks in flight, retired by COUNTED vmcnt (every wave issues the same number of LDS-DMA instructions per
 // chunk: filter instructions a wave does not own go to a 1 KiB per-wave dummy slot) and ONE raw s_barrier per chunk.
-template <typename T, int WM, int WN, int TM, int TN, int RB, bool TABLE, int NS = 2>
-__global__ __launch_bounds__(WM * WN * 64, y5_conv_min_waves(TM, TN))
+//
+// PROD: producer / consumer specialisation.  One LDS-DMA instruction blocks its wave for 60-180 cycles at issue (the
+// vector-memory path takes 64 B/clk/CU), which in the plain kernel is time the wave's SIMD spends without MFMAs.  With
+// PROD the workgroup has 2 * WM * WN waves: the first WM * WN (consumers) only read fragments, multiply and run the
+// epilogue; the others (producers, one per SIMD beside a consumer) only issue the ring's LDS-DMA instructions, NS-1
+// chunks ahead, and retire them with counted vmcnt.  One raw s_barrier per chunk joins the two roles.
+template <typename T, int WM, int WN, int TM, int TN, int RB, bool TABLE, int NS = 2, bool PROD = false>
+__global__ __launch_bounds__(WM * WN * 64 * (PROD ? 2 : 1), y5_conv_min_waves(TM, TN))
 void y5_conv_igemm_kernel(const Y5ConvParams p) {
+  static_assert(!PROD || NS >= 3, "producer/consumer needs a ring");
   using Gm = Y5ConvGeom<T, RB>;
   constexpr int EPP = Gm::EPP, BK = Gm::BK, NSLOT = Gm::NSLOT, RPI = Gm::ROWS_PER_INSTR;
   constexpr int NW = WM * WN;
@@ -96,9 +101,14 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
   int2* tab = reinterpret_cast<int2*>(smem + NS * BUF_BYTES);
   const int tab_bytes = TABLE ? (p.Kpad / EPP) * 8 : 0;
 
+#ifdef Y5_DBG_TIMING
+  const unsigned long long r_entry = __builtin_amdgcn_s_memrealtime();
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = PROD && wave_id >= NW;
+  const int wave = producer ? wave_id - NW : wave_id;  // index inside the role: loader share / consumer sub-tile
   const int wm = wave / WN, wn = wave % WN;
   char* scratch = smem + NS * BUF_BYTES + tab_bytes + wave * Gm::SCR_BYTES;
   char* dummy = smem + NS * BUF_BYTES + tab_bytes + NW * Gm::SCR_BYTES + wave * 1024;  // NS > 2 only
@@ -117,7 +127,7 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
   if constexpr (TABLE) {
     // per k-piece (EPP elements) gather table: {element offset relative to pixel (ih0,iw0), kh | kw<<16}
     const int npieces = p.Kpad / EPP;
-    for (int q = tid; q < npieces; q += NW * 64) {
+    for (int q = tid; q < npieces; q += NW * 64 * (PROD ? 2 : 1)) {
       const int k = q * EPP;
       int2 e;
       if (k < p.K) {
@@ -190,21 +200,25 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
     u_kh = 0; u_kw = 0; u_c0 = 0;
   };
 
-  auto stage = [&](int buf) {
-    char* lds = smem + buf * BUF_BYTES;
-#ifdef Y5_DBG_NOLOAD
-    if (s_t > 0 || s_kc > 0) {
-      if (++s_kc == nk) { s_kc = 0; if (++s_t < nmine) loader_setup(s_t); }
-      return;
-    }
-#endif
-    int tap_off = 0, tap_bit = 0;
+  // One chunk = LPC LDS-DMA instructions per wave.  The vector-memory path moves 64 B/clk/CU, so a chunk's loads occupy it
+  // for about as long as its MFMAs occupy the matrix cores: stage() issues them back to back (used ahead of an epilogue),
+  // stage_begin/stage_load/stage_end let compute() spread them between the MFMAs of the chunk being multiplied.
+  constexpr int LPC = ACT_PER_WAVE + WGT_PER_WAVE;  // LDS-DMA instructions per chunk per wave (NS > 2: uniform)
+  char* st_lds = smem;
+  int st_tap_off = 0, st_tap_bit = 0;
+  unsigned st_kcb = 0;
+  auto stage_begin = [&](int buf) {
+    st_lds = smem + buf * BUF_BYTES;
     if constexpr (!TABLE) {
-      tap_off = ((u_kh * p.W + u_kw) * p.ldx + u_c0) * ES;
-      tap_bit = u_kh * p.KW + u_kw;
+      st_tap_off = ((u_kh * p.W + u_kw) * p.ldx + u_c0) * ES;
+      st_tap_bit = u_kh * p.KW + u_kw;
     }
-#pragma unroll
-    for (int i = 0; i < ACT_PER_WAVE; ++i) {
+    st_kcb = (unsigned)(s_kc * BK * ES);
+  };
+  auto stage_load = [&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    if constexpr (q < ACT_PER_WAVE) {
+      constexpr int i = q;
       unsigned voff;
       if constexpr (TABLE) {
         const int2 e = tab[s_kc * NSLOT + a_slot[i]];
@@ -212,21 +226,20 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
         const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
         voff = ok ? (unsigned)(a_base[i] + (e.x - a_slot[i] * EPP) * ES) : Y5_OOB;
       } else {
-        voff = (a_mask[i] >> tap_bit) & 1u ? (unsigned)(a_base[i] + tap_off) : Y5_OOB;
+        voff = (a_mask[i] >> st_tap_bit) & 1u ? (unsigned)(a_base[i] + st_tap_off) : Y5_OOB;
       }
-      y5_bglds16(xrs, voff, lds + (wave + i * NW) * 1024);
-    }
-    const unsigned kc_bytes = (unsigned)(s_kc * BK * ES);
-#pragma unroll
-    for (int i = 0; i < WGT_PER_WAVE; ++i) {
+      y5_bglds16(xrs, voff, st_lds + (wave + i * NW) * 1024);
+    } else {
+      constexpr int i = q - ACT_PER_WAVE;
       const int idx = wave + i * NW;
       if (idx < WGT_INSTR) {
-        y5_bglds16(wrs, w_off[i] == Y5_OOB ? Y5_OOB : w_off[i] + kc_bytes, lds + BM * RB + idx * 1024);
+        y5_bglds16(wrs, w_off[i] == Y5_OOB ? Y5_OOB : w_off[i] + st_kcb, st_lds + BM * RB + idx * 1024);
       } else if (NS > 2) {
         y5_bglds16(wrs, Y5_OOB, dummy);  // keeps the per-chunk LDS-DMA count identical in every wave (counted vmcnt)
       }
     }
-    // advance to the next (tile, chunk)
+  };
+  auto stage_end = [&]() {  // advance to the next (tile, chunk)
     if constexpr (!TABLE) {
       u_c0 += BK;
       if (u_c0 >= p.C1) {
@@ -238,6 +251,14 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
       s_kc = 0;
       if (++s_t < nmine) loader_setup(s_t);
     }
+  };
+  auto stage = [&](int buf) {
+#ifdef Y5_DBG_NOLOAD
+    if (s_t > 0 || s_kc > 0) { stage_end(); return; }
+#endif
+    stage_begin(buf);
+    y5_static_for<0, LPC>([&](auto qc) { stage_load(qc); });
+    stage_end();
   };
 
   float16_t acc[TM][TN];
@@ -347,30 +368,37 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
   };
 
   if constexpr (TABLE) __syncthreads();
-  loader_setup(0);
-  constexpr int LPC = ACT_PER_WAVE + WGT_PER_WAVE;  // LDS-DMA instructions per chunk per wave (NS > 2: uniform)
-
-  auto compute = [&](const char* lds) {
+  if (!PROD || producer) loader_setup(0);
+  // multiply the chunk in `lds`; with_loads: the next chunk's LDS-DMA instructions (stage_begin() already called) are issued
+  // between the k-steps, so that the vector-memory pipe and the matrix cores work at the same time
+  auto compute = [&](const char* lds, bool with_loads) {
 #ifdef Y5_DBG_NOMFMA
     asm volatile("" :: "v"(lds));
+    if (with_loads) y5_static_for<0, LPC>([&](auto qc) { stage_load(qc); });
     return;
 #endif
     if constexpr (sizeof(T) == 2) {
-#pragma unroll
-      for (int ks = 0; ks < RB / 32; ++ks) {
+      constexpr int KS = RB / 32, LPK = (LPC + KS - 1) / KS;
+      y5_static_for<0, KS>([&](auto ksc) {
+        constexpr int ks = decltype(ksc)::value;
         const int so = ((ks * 2 + g) ^ fsw) * 16;
         half8_t af[TM], wf[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const half8_t*>(lds + a_rd[i] + so);
 #pragma unroll
         for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const half8_t*>(lds + w_rd[j] + so);
+        if (with_loads) {
+          constexpr int Q0 = ks * LPK < LPC ? ks * LPK : LPC, Q1 = (ks + 1) * LPK < LPC ? (ks + 1) * LPK : LPC;
+          y5_static_for<Q0, Q1>([&](auto qc) { stage_load(qc); });
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
-      }
+      });
     } else {
+      if (with_loads) y5_static_for<0, LPC>([&](auto qc) { stage_load(qc); });
       const int so0 = ((2 * g) ^ fsw) * 16, so1 = ((2 * g + 1) ^ fsw) * 16;
       float4_t af[TM][2], wf[TN][2];
 #pragma unroll
@@ -406,21 +434,89 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
   };
 
   int pm0 = 0, pn0 = 0;  // coordinates of the tile whose results sit in acc
-  if constexpr (NS == 2) {
+#ifdef Y5_DBG_TIMING
+  unsigned long long r_start = 0, r_loop_end = 0;
+#endif
+  if constexpr (PROD) {
+    if (producer) {
+      for (int s0 = 0; s0 < NS - 1; ++s0)
+        if (s0 < total) stage(s0);
+      int nxt = NS - 1;
+      for (int it = 0; it < total; ++it) {
+        const int ahead = total - 1 - it < NS - 2 ? total - 1 - it : NS - 2;  // chunks issued after chunk `it`
+        switch (ahead) {
+          case 0: y5_wait_vm<0>(); break;
+          case 1: y5_wait_vm<LPC>(); break;
+          case 2: y5_wait_vm<2 * LPC>(); break;
+          default: y5_wait_vm<3 * LPC>(); break;
+        }
+        __builtin_amdgcn_s_barrier();  // chunk `it` is in LDS for the consumers; they are done with chunk it-1 (slot nxt)
+        if (it + NS - 1 < total) stage(nxt);
+        nxt = nxt + 1 == NS ? 0 : nxt + 1;
+      }
+      return;
+    }
+    int cur = 0;
+    for (int ti = 0; ti < nmine; ++ti) {
+      for (int kc = 0; kc < nk; ++kc) {
+        __builtin_amdgcn_s_barrier();
+        if (kc == 0) tile_begin(ti, pm0, pn0);
+        compute(smem + cur * BUF_BYTES, false);
+        cur = cur + 1 == NS ? 0 : cur + 1;
+      }
+    }
+  } else if constexpr (NS == 2) {
     stage(0);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     __syncthreads();
     int it = 0;
+#ifdef Y5_DBG_TIMING
+    unsigned long long d_stage = 0, d_comp = 0, d_wait = 0, d_bar = 0, d_epi = 0;
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+    r_start = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int ti = 0; ti < nmine; ++ti) {
       for (int kc = 0; kc < nk; ++kc, ++it) {
         const int cur = it & 1;
-        if (it + 1 < total) stage(cur ^ 1);  // next chunk (possibly of the next tile) flies during everything below
+#ifdef Y5_DBG_TIMING
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
+        // next chunk (possibly of the next tile): ahead of an epilogue all at once (it flies during the epilogue), otherwise
+        // spread over this chunk's k-steps
+        const bool more = it + 1 < total;
+        const bool spread = more && kc != 0;
+        if (more) { if (spread) stage_begin(cur ^ 1); else stage(cur ^ 1); }
+#ifdef Y5_DBG_TIMING
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
         if (kc == 0) tile_begin(ti, pm0, pn0);
-        compute(smem + cur * BUF_BYTES);
+#ifdef Y5_DBG_TIMING
+        const unsigned long long t1b = __builtin_amdgcn_s_memtime();
+#endif
+        compute(smem + cur * BUF_BYTES, spread);
+        if (spread) stage_end();
+#ifdef Y5_DBG_TIMING
+        const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+#endif
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the chunk staged above has landed
+#ifdef Y5_DBG_TIMING
+        const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+#endif
         __syncthreads();
+#ifdef Y5_DBG_TIMING
+        const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+        d_stage += t1 - t0; d_epi += t1b - t1; d_comp += t2 - t1b; d_wait += t3 - t2; d_bar += t4 - t3;
+#endif
       }
     }
+#ifdef Y5_DBG_TIMING
+    if (blockIdx.x == 0 && lane == 0) {
+      unsigned long long* o = y5_dbg_timing + wave * 8;
+      o[0] = d_stage; o[1] = d_epi; o[2] = d_comp; o[3] = d_wait; o[4] = d_bar; o[5] = __builtin_amdgcn_s_memtime() - t_start; o[6] = total; o[7] = nmine;
+      y5_dbg_timing[64 + wave] = __builtin_amdgcn_s_memrealtime() - r_start;
+    }
+    r_loop_end = __builtin_amdgcn_s_memrealtime();
+#endif
   } else {
     // ring: chunks it+1 .. it+NS-2 are in flight while chunk `it` is retired; chunk it+NS-1 is issued right after the barrier
     // into the buffer chunk it-1 occupied (all waves have finished reading it: they are past this barrier).
@@ -437,13 +533,24 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
           default: y5_wait_vm<3 * LPC>(); break;
         }
         __builtin_amdgcn_s_barrier();
-        if (it + NS - 1 < total) stage(nxt);
+        const bool more = it + NS - 1 < total;
+        const bool spread = more && kc != 0;
+        if (more) { if (spread) stage_begin(nxt); else stage(nxt); }
         if (kc == 0) tile_begin(ti, pm0, pn0);
-        compute(smem + cur * BUF_BYTES);
+        compute(smem + cur * BUF_BYTES, spread);
+        if (spread) stage_end();
         cur = cur + 1 == NS ? 0 : cur + 1;
         nxt = nxt + 1 == NS ? 0 : nxt + 1;
       }
     }
   }
   epilogue(pm0, pn0);
+#ifdef Y5_DBG_TIMING
+  if constexpr (NS == 2 && !PROD) {
+    if (tid == 0 && blockIdx.x < 1024) {
+      unsigned long long* o = y5_dbg_blocks + blockIdx.x * 4;
+      o[0] = r_entry; o[1] = r_start; o[2] = r_loop_end; o[3] = __builtin_amdgcn_s_memrealtime();
+    }
+  }
+#endif
 }

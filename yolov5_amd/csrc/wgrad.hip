@@ -5,8 +5,11 @@
 // MFMA operands need 8 consecutive PIXELS of one channel per lane -- a transposed read of the pixel-major NHWC tensors:
 // 32-pixel chunks of dz (64 output channels) and of the gathered x columns (64 k) are staged row-major in LDS by
 // buffer-addressed LDS-DMA (image borders / tails = zero fill) and the fragments are gathered with 16-bit LDS reads.
-// One workgroup = one 64 x 64 tile of dW and one slice of the pixel range (split-K over the grid).
-// v1 of this kernel is LDS-issue bound (16 ds_read_u16 per MFMA); DESIGN.md lists the ds_read_b64_tr_b16 upgrade.
+// One workgroup = one (64*TNB) x (64*TKB) tile of dW and one slice of the pixel range (split-K over the grid); every wave
+// keeps TNB x TKB accumulators.  The chunk loop is a latency problem (one 32-pixel chunk is 8-16 KiB per workgroup against
+// a ~2 us HBM round trip), so chunks travel through an S-stage LDS ring: S-1 chunks are in flight per workgroup, retired
+// with counted s_waitcnt vmcnt and ONE raw s_barrier per chunk, and the gather coordinates (b, oh, ow) of every staged
+// row advance incrementally (no integer division in the loop).
 #include <hip/hip_runtime.h>
 
 #include "../../include/yolov5_hip.h"
@@ -22,7 +25,7 @@ struct Y5WgradParams {
   int pix_per_split;  // multiple of 32
 };
 
-template <int TNB, int TKB>
+template <int TNB, int TKB, int S>
 __global__ __launch_bounds__(256)
 void y5_conv_wgrad_kernel(const Y5WgradParams p) {
   typedef half_t T;
@@ -49,9 +52,11 @@ void y5_conv_wgrad_kernel(const Y5WgradParams p) {
   // staging roles: ZI + XI LDS-DMA instructions per chunk (1 KiB each), NI per wave; a dz instruction covers 1024/ZROW
   // pixel rows of 64*TNB channels, an x instruction 1024/XROW rows of 64*TKB gathered k columns
   const int ohw = p.OH * p.OW;
-  int i_isx[NI], i_row[NI], i_col8[NI], i_dst[NI];   // per instruction of this wave: kind, pixel row, 8-channel group, LDS offset
-  int x_kh[NI], x_kw[NI], x_c[NI];
-  bool i_ok[NI];
+  const int q32 = 32 / p.OW, r32 = 32 - q32 * p.OW;   // a chunk advances every staged row by 32 pixels = q32 rows + r32 columns
+  bool i_isx[NI], i_ok[NI];
+  int i_dst[NI], i_m[NI];       // LDS offset; pixel index of the row staged next
+  int z_off[NI];                // dz: byte offset of the lane's 16 bytes inside a pixel row
+  int x_b[NI], x_oh[NI], x_ow[NI], x_dh[NI], x_dw[NI], x_c[NI];  // x: pixel coordinates, tap offset (kh - PH, kw - PW), channel
 #pragma unroll
   for (int q = 0; q < NI; ++q) {
     const int I = wave * NI + q;
@@ -61,38 +66,51 @@ void y5_conv_wgrad_kernel(const Y5WgradParams p) {
     const int lpr = rowb / 16;                       // lanes per pixel row
     const int r = J * (1024 / rowb) + lane / lpr;    // pixel row inside the chunk
     const int s8 = lane % lpr;                       // 16-byte group inside the row
-    i_isx[q] = isx; i_row[q] = r; i_col8[q] = s8; i_dst[q] = (isx ? ZT : 0) + J * 1024;
+    i_isx[q] = isx; i_dst[q] = (isx ? ZT : 0) + J * 1024; i_m[q] = m_begin + r;
+    z_off[q] = (n0 + 8 * s8) * 2;
+    x_b[q] = x_oh[q] = x_ow[q] = x_dh[q] = x_dw[q] = x_c[q] = 0;
     if (isx) {
       const int kx = k0 + 8 * s8;
       i_ok[q] = kx < p.K;
       const int tap = i_ok[q] ? kx / p.C1 : 0;
       x_c[q] = kx - tap * p.C1;
-      x_kh[q] = tap / p.KW; x_kw[q] = tap - x_kh[q] * p.KW;
+      const int kh = tap / p.KW;
+      x_dh[q] = kh - p.PH; x_dw[q] = tap - kh * p.KW - p.PW;
+      x_b[q] = i_m[q] / ohw;
+      const int rr = i_m[q] - x_b[q] * ohw;
+      x_oh[q] = rr / p.OW; x_ow[q] = rr - x_oh[q] * p.OW;
     } else {
       i_ok[q] = n0 + 8 * s8 < p.C2;
-      x_c[q] = x_kh[q] = x_kw[q] = 0;
     }
   }
 
-  auto stage = [&](int ch, int buf) {
+  // stage the next chunk of this wave's rows into ring slot `buf` and advance the rows by 32 pixels; rows past the end of
+  // the split are still issued (out-of-range offset = zero fill) so that every chunk costs exactly NI vmcnt slots
+  auto stage = [&](int buf) {
     char* base = smem + buf * BUF;
 #pragma unroll
     for (int q = 0; q < NI; ++q) {
-      const int m = m_begin + ch * 32 + i_row[q];
       unsigned voff = Y5_OOB;
-      if (m < m_end && i_ok[q]) {
+      if (i_m[q] < m_end && i_ok[q]) {
         if (!i_isx[q]) {
-          voff = (unsigned)((m * p.ldz + n0 + 8 * i_col8[q]) * 2);
+          voff = (unsigned)(i_m[q] * p.ldz * 2 + z_off[q]);
         } else {
-          const int b = m / ohw;
-          const int rr = m - b * ohw;
-          const int oh = rr / p.OW, ow = rr - oh * p.OW;
-          const int ih = oh * p.SH - p.PH + x_kh[q], iw = ow * p.SW - p.PW + x_kw[q];
+          const int ih = x_oh[q] * p.SH + x_dh[q], iw = x_ow[q] * p.SW + x_dw[q];
           if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
-            voff = (unsigned)((((b * p.H + ih) * p.W + iw) * p.ldx + x_c[q]) * 2);
+            voff = (unsigned)((((x_b[q] * p.H + ih) * p.W + iw) * p.ldx + x_c[q]) * 2);
         }
       }
+#ifndef Y5_WG_NOSTAGE
       y5_bglds16(i_isx[q] ? xrs : zrs, voff, base + i_dst[q]);
+#else
+      if (voff == 12345u) y5_bglds16(i_isx[q] ? xrs : zrs, voff, base + i_dst[q]);
+#endif
+      i_m[q] += 32;
+      if (i_isx[q]) {
+        x_ow[q] += r32; x_oh[q] += q32;
+        if (x_ow[q] >= p.OW) { x_ow[q] -= p.OW; ++x_oh[q]; }
+        while (x_oh[q] >= p.OH) { x_oh[q] -= p.OH; ++x_b[q]; }
+      }
     }
   };
 
@@ -107,17 +125,21 @@ void y5_conv_wgrad_kernel(const Y5WgradParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b2][r] = 0.f;
 
-  stage(0, 0);
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s) stage(s);
+  int cur = 0, nxt = S - 1;
   for (int ch = 0; ch < nchunks; ++ch) {
-    const int cur = ch & 1;
-    if (ch + 1 < nchunks) stage(ch + 1, cur ^ 1);
+    y5_wait_vm<(S - 2) * NI>();            // this wave's share of chunk ch has landed (S-2 younger chunks may still fly)
+    __builtin_amdgcn_s_barrier();          // ... and everybody's; all waves are done reading ring slot nxt (chunk ch-1)
+    stage(nxt);                            // chunk ch + S - 1
     const T* zt = reinterpret_cast<const T*>(smem + cur * BUF) + wn * 32 * TNB + fi;        // [p][64*TNB]: column n
     const T* xt = reinterpret_cast<const T*>(smem + cur * BUF + ZT) + wk * 32 * TKB + fi;   // [p][64*TKB]: column k
+    nxt = cur;
+    cur = cur + 1 == S ? 0 : cur + 1;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       half8_t af[TNB], bf[TKB];
+#ifndef Y5_WG_NOREAD
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int pr = ks * 16 + g * 8 + e;
@@ -126,14 +148,28 @@ void y5_conv_wgrad_kernel(const Y5WgradParams p) {
 #pragma unroll
         for (int b2 = 0; b2 < TKB; ++b2) bf[b2][e] = xt[pr * (64 * TKB) + b2 * 32];
       }
+#else
+#pragma unroll
+      for (int a = 0; a < TNB; ++a) af[a] = __builtin_bit_cast(half8_t, uint4_t{(uint32_t)ch, (uint32_t)lane, 3u, (uint32_t)a});
+#pragma unroll
+      for (int b2 = 0; b2 < TKB; ++b2) bf[b2] = __builtin_bit_cast(half8_t, uint4_t{(uint32_t)lane, (uint32_t)ch, 5u, (uint32_t)b2});
+#endif
+#ifndef Y5_WG_NOMFMA
 #pragma unroll
       for (int a = 0; a < TNB; ++a)
 #pragma unroll
         for (int b2 = 0; b2 < TKB; ++b2) acc[a][b2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b2], acc[a][b2], 0, 0, 0);
+#else
+#pragma unroll
+      for (int a = 0; a < TNB; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < TKB; ++b2)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[a][b2][e] += (float)af[a][e] * (float)bf[b2][e];
+#endif
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
   }
+  y5_wait_vm<0>();   // drain the zero-fill prefetches past the end of the split before the wave retires its LDS
   // D[i][j]: col j = lane & 31 (k), row i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (n)
 #pragma unroll
   for (int b2 = 0; b2 < TKB; ++b2) {
@@ -144,7 +180,11 @@ void y5_conv_wgrad_kernel(const Y5WgradParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wn * 32 * TNB + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+#ifndef Y5_WG_NOATOM
         if (n < p.C2) atomicAdd(p.dw + (size_t)n * p.Kpad + kcol, acc[a][b2][r]);
+#else
+        if (n < p.C2 && acc[a][b2][r] == 1.2345f) p.dw[(size_t)n * p.Kpad + kcol] = acc[a][b2][r];
+#endif
       }
   }
 }
@@ -185,10 +225,10 @@ extern "C" int y5_conv2d_wgrad(const y5_conv_desc* d, const void* x, const void*
   p.splits = (p.M + p.pix_per_split - 1) / p.pix_per_split;
   const long long grid = (long long)tiles * p.splits;
   if (grid > 0x7fffffffLL) return y5_fail(Y5_ERR_UNSUPPORTED, "wgrad: grid too large");
-  const size_t lds = (size_t)2 * 32 * 128 * (tnb + tkb);
-  if (tnb == 2 && tkb == 2) hipLaunchKernelGGL((y5_conv_wgrad_kernel<2, 2>), dim3((unsigned)grid), dim3(256), lds, st, p);
-  else if (tnb == 2) hipLaunchKernelGGL((y5_conv_wgrad_kernel<2, 1>), dim3((unsigned)grid), dim3(256), lds, st, p);
-  else if (tkb == 2) hipLaunchKernelGGL((y5_conv_wgrad_kernel<1, 2>), dim3((unsigned)grid), dim3(256), lds, st, p);
-  else hipLaunchKernelGGL((y5_conv_wgrad_kernel<1, 1>), dim3((unsigned)grid), dim3(256), lds, st, p);
+  // ring depth: as many 32-pixel chunks in flight as ~48 KiB of LDS per workgroup allows (3 workgroups per CU)
+  if (tnb == 2 && tkb == 2) hipLaunchKernelGGL((y5_conv_wgrad_kernel<2, 2, 3>), dim3((unsigned)grid), dim3(256), 3 * 16384, st, p);
+  else if (tnb == 2) hipLaunchKernelGGL((y5_conv_wgrad_kernel<2, 1, 4>), dim3((unsigned)grid), dim3(256), 4 * 12288, st, p);
+  else if (tkb == 2) hipLaunchKernelGGL((y5_conv_wgrad_kernel<1, 2, 4>), dim3((unsigned)grid), dim3(256), 4 * 12288, st, p);
+  else hipLaunchKernelGGL((y5_conv_wgrad_kernel<1, 1, 6>), dim3((unsigned)grid), dim3(256), 6 * 8192, st, p);
   return y5_check_launch("y5_conv2d_wgrad");
 }

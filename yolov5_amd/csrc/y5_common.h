@@ -1,5 +1,6 @@
 // Shared device-side helpers for the yolov5_amd HIP kernels (gfx950 / CDNA4 only).
 #pragma once
+#include <type_traits>
 #include <stdint.h>
 
 typedef _Float16 half_t;
@@ -43,4 +44,21 @@ __device__ __forceinline__ int y5_xcd_remap(int bid, int nwg) {
   const int xcd = bid & 7, idx = bid >> 3;
   const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + idx;
+}
+
+constexpr int y5_waitcnt_vm(int n) {  // s_waitcnt immediate: vmcnt(n), expcnt/lgkmcnt untouched (gfx9 encoding)
+  return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8);
+}
+template <int N> __device__ __forceinline__ void y5_wait_vm() {
+  __builtin_amdgcn_s_waitcnt(y5_waitcnt_vm(N < 63 ? N : 63));
+  asm volatile("" ::: "memory");
+}
+
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [B, E)
+template <int B, int E, typename F>
+__device__ __forceinline__ void y5_static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    y5_static_for<B + 1, E>(f);
+  }
 }
