@@ -25,6 +25,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MFMA_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+HBM_PEAK_GBS = 8000.0      # HBM3E, same table (about 6.3 TB/s is achievable in practice)
 
 
 def build_model(name, dev, half=True):
@@ -73,6 +74,27 @@ def conv_flops(engine):
     return out
 
 
+def conv_bytes(engine, esize=2):
+    """Algorithmic HBM bytes per conv launch (SURVEY.md 8(d) "per-layer unfused conv traffic"): input read once + output
+    written once (+ the residual read of a Bottleneck add) + filter read once, true channel counts, `esize` bytes/element.
+    The input of the NCHW stem is its 3-channel image.  yolov5s bs=64 640^2: 7.8 GB per forward."""
+    out = []
+    B = engine.spec.B
+    for i, op in enumerate(engine.spec.ops):
+        if op["op"] != "conv":
+            continue
+        x, y = op["x"], op["y"]
+        cin = sum((m.conv if hasattr(m, "conv") else m).in_channels for m in op["mods"][:1])
+        by = B * x.H * x.W * cin + B * y.H * y.W * sum((m.conv if hasattr(m, "conv") else m).out_channels for m in op["mods"])
+        if op.get("res") is not None:
+            by += B * y.H * y.W * y.C
+        for m in op["mods"]:
+            cv = m.conv if hasattr(m, "conv") else m
+            by += cv.out_channels * cv.in_channels * cv.kernel_size[0] * cv.kernel_size[1]
+        out.append((i, by * esize))
+    return out
+
+
 def usable_cores():
     """Host cores this process may really use: affinity mask and cgroup CPU quota, capped at 64 threads (oneDNN/OpenMP
     stop scaling -- and thrash -- far below the 256 logical CPUs the GPU box advertises)."""
@@ -116,7 +138,7 @@ def train_probe(name, batch, imgsz, dev, world, steps=6, warmup=2):
     """Secondary measurement (BASELINE config 3 per-GPU shape): training step = train-mode forward + ComputeLoss + backward
     (+ bucketed RCCL gradient all-reduce when world > 1) + SGD, fp16 compute with fp32 master weights, synthetic data."""
     from yolov5_amd.loss import ComputeLoss
-    from yolov5_amd.torch_utils import smart_DDP
+    from yolov5_amd.torch_utils import ModelEMA, smart_DDP, smart_optimizer
     from yolov5_amd.yolo import DetectionModel
 
     torch.manual_seed(0)
@@ -124,7 +146,8 @@ def train_probe(name, batch, imgsz, dev, world, steps=6, warmup=2):
     m.hyp = {"box": 0.05, "cls": 0.5, "cls_pw": 1.0, "obj": 1.0, "obj_pw": 1.0, "anchor_t": 4.0, "fl_gamma": 0.0, "label_smoothing": 0.0}
     compute_loss = ComputeLoss(m)
     model = smart_DDP(m) if world > 1 else m
-    opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.937, nesterov=True)
+    opt = smart_optimizer(m, "SGD", lr=0.01, momentum=0.937, decay=5e-4)  # HipSGD: 3 groups, fused multi-tensor step
+    ema = ModelEMA(m)
     g = torch.Generator(device="cpu").manual_seed(1)
     x = torch.rand((batch, 3, imgsz, imgsz), generator=g).half().to(dev)
     nt = batch * 8
@@ -139,9 +162,8 @@ def train_probe(name, batch, imgsz, dev, world, steps=6, warmup=2):
             loss = loss * world  # train.py:404-405
         opt.zero_grad(set_to_none=True)
         (loss * scale).backward()
-        for p in m.parameters():
-            p.grad.div_(scale)
-        opt.step()
+        # train.py:413-421 scaler.unscale_ + clip_grad_norm_(10.0) + optimizer step + ema.update, fused (csrc/optim.hip)
+        opt.step_fused(inv_scale=1.0 / scale, max_norm=10.0, ema=ema, model=m)
         return loss
 
     for _ in range(warmup):
@@ -247,6 +269,11 @@ def main():
     conv_fl = sum(fl[i] for i, _ in timed if i in fl)
     other_ms = sum(ms for i, (name, ms) in timed if i not in fl)
     achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    by = dict(conv_bytes(eng))
+    if eng._stem is not None:
+        by[eng._stem] = by[1]
+    conv_by = sum(by[i] for i, _ in timed if i in by)
+    achieved_bw = conv_by / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0  # GB/s
     nconv = sum(1 for i, _ in timed if i in fl)
     if a.op_table and rank == 0:
         cfg_of = {}
@@ -279,10 +306,16 @@ def main():
                        "global_batch": a.batch * world, "parallelism": f"replicas x{world} (images independent, no collective)"},
             "forward_ms": round(fwd_ms, 4), "nms_ms": round(nms_ms, 4), "nms_us_per_img": round(nms_ms * 1e3 / a.batch, 2),
             "forward_images_per_sec": round(a.batch / (fwd_ms * 1e-3), 1), "detections_per_img": round(ncand, 1),
-            "roofline": {"bound": "mfma", "kernel": "y5_conv_{igemm,pw,stem}_kernel (all conv launches of one forward)",
-                         "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                         "algorithmic_gflop_per_step": round(conv_fl / 1e9, 1), "conv_ms_per_step": round(conv_ms, 4),
+            # arithmetic intensity of the conv stack at this config = algorithmic flops / algorithmic bytes (135 flop/B for
+            # yolov5s bs=64 640^2) is below the ridge (2500 TF / 8 TB/s = 312 flop/B): the stack as a whole is HBM-bound;
+            # the MFMA view of the same launches is kept beside it
+            "roofline": {"bound": "hbm", "kernel": "y5_conv_{igemm,pw,k3,stem}_kernel (all conv launches of one forward)",
+                         "achieved": round(achieved_bw, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved_bw / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_gbytes_per_step": round(conv_by / 1e9, 3), "algorithmic_gflop_per_step": round(conv_fl / 1e9, 1),
+                         "arithmetic_intensity_flop_per_byte": round(conv_fl / conv_by, 1) if conv_by else None,
+                         "mfma_achieved_tflops": round(achieved, 2), "mfma_peak_tflops": MFMA_PEAK_TFLOPS,
+                         "mfma_frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "conv_ms_per_step": round(conv_ms, 4),
                          "launches_per_step": nconv, "other_kernels_ms_per_step": round(other_ms, 4)},
         }
         if train is not None:

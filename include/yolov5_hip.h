@@ -262,6 +262,36 @@ int y5_plan_launch_graph(y5_plan*, void* stream);        /* hipGraphLaunch of th
  * recorded on that same stream; returns total milliseconds in *ms. */
 int y5_plan_time_range(y5_plan*, int first, int last, int iters, void* stream, float* ms);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Fused optimizer step over all parameter tensors -- train.py:413-421 `scaler.unscale_(optimizer)`,
+ * `clip_grad_norm_(model.parameters(), max_norm=10.0)`, `scaler.step(optimizer)` with the SGD(momentum, nesterov) groups of
+ * utils/torch_utils.py:257-290 `smart_optimizer`, and `ema.update(model)` (utils/torch_utils.py:354-365).
+ * The caller keeps a DEVICE array of y5_mt_tensor rows; every pointer is fp32 device memory of n elements.
+ *   y5_mt_grad_norm : stats[0] = || grad * inv_scale ||_2 over all tensors (deterministic order), stats[1] = clip coefficient
+ *                     min(1, max_norm / (norm + 1e-6)) (1 if max_norm <= 0), stats[2] = 1.0 if any gradient is inf/nan
+ *   y5_mt_sgd_step  : d = grad * inv_scale * stats[1]; d += wd[group] * p; buf = momentum * buf + d (buffers start at zero, so
+ *                     the first step gives buf = d like torch's clone); d = nesterov ? d + momentum * buf : buf; p -= lr[group] * d;
+ *                     if (ema) ema = ema_decay * ema + (1 - ema_decay) * p.  stats == NULL: no clipping / no skip;
+ *                     stats[2] != 0: parameters and momentum are left untouched (GradScaler skips the step), the EMA still moves.
+ *                     mom == NULL for a tensor: plain SGD on it.
+ *   y5_mt_lerp      : ema = decay * ema + (1 - decay) * param over a table (ModelEMA over float buffers).
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct {
+  void* param;       /* fp32 [n], updated in place                    */
+  const void* grad;  /* fp32 [n]                                      */
+  void* mom;         /* fp32 [n] momentum buffer or NULL              */
+  void* ema;         /* fp32 [n] exponential moving average or NULL   */
+  long long n;
+  int group;         /* 0..3: index into lr4 / wd4                    */
+  int reserved;
+} y5_mt_tensor;
+size_t y5_mt_workspace_bytes(int ntensors, long long max_numel);
+int y5_mt_grad_norm(const y5_mt_tensor* table_dev, int ntensors, long long max_numel, float inv_scale, float max_norm,
+                    float* stats_dev /* 4 floats */, void* workspace, size_t workspace_bytes, void* stream);
+int y5_mt_sgd_step(const y5_mt_tensor* table_dev, int ntensors, long long max_numel, const float* lr4, const float* wd4, float momentum,
+                   int nesterov, float inv_scale, const float* stats_dev, float ema_decay, void* stream);
+int y5_mt_lerp(const y5_mt_tensor* table_dev, int ntensors, long long max_numel, float decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

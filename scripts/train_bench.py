@@ -28,7 +28,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl")
     from yolov5_amd.loss import ComputeLoss
-    from yolov5_amd.torch_utils import smart_DDP
+    from yolov5_amd.torch_utils import ModelEMA, smart_DDP, smart_optimizer
     from yolov5_amd.yolo import DetectionModel
 
     torch.manual_seed(0)
@@ -36,7 +36,8 @@ def main():
     m.hyp = {"box": 0.05, "cls": 0.5, "cls_pw": 1.0, "obj": 1.0, "obj_pw": 1.0, "anchor_t": 4.0, "fl_gamma": 0.0, "label_smoothing": 0.0}
     compute_loss = ComputeLoss(m)
     model = smart_DDP(m) if world > 1 else m
-    opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.937, nesterov=True)
+    opt = smart_optimizer(m, "SGD", lr=0.01, momentum=0.937, decay=5e-4)  # HipSGD: 3 groups, fused multi-tensor step
+    ema = ModelEMA(m)
     g = torch.Generator(device="cpu").manual_seed(rank)
     x = torch.rand((a.batch, 3, a.imgsz, a.imgsz), generator=g).half().to(dev)
     nt = a.batch * 8
@@ -51,9 +52,8 @@ def main():
             loss = loss * world  # train.py:404-405
         opt.zero_grad(set_to_none=True)
         (loss * scale).backward()
-        for p in m.parameters():
-            p.grad.div_(scale)
-        opt.step()
+        # train.py:413-421 scaler.unscale_ + clip_grad_norm_(10.0) + optimizer step + ema.update, fused (csrc/optim.hip)
+        opt.step_fused(inv_scale=1.0 / scale, max_norm=10.0, ema=ema, model=m)
         return loss
 
     for _ in range(a.warmup):

@@ -30,6 +30,9 @@ class EmuBackend:
     def to_torch(self, h):
         return torch.from_numpy(np.array(h))
 
+    def view_torch(self, h):
+        return torch.from_numpy(h)  # shares memory with the emulated device buffer
+
     def zero_(self, h):
         h[...] = 0
 

@@ -124,7 +124,10 @@ def test_train_step_yolov5s_bs64_timing(dev):
     x = torch.rand((B, 3, 640, 640), device=dev).half()
     t = torch.from_numpy(detgen.synth_targets(B, 8, seed=1)).to(dev)
     compute_loss = ComputeLoss(m)
-    opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.937, nesterov=True)
+    from yolov5_amd.torch_utils import ModelEMA, smart_optimizer
+
+    opt = smart_optimizer(m, "SGD", lr=0.01, momentum=0.937, decay=5e-4)
+    ema = ModelEMA(m)
     losses = []
     for it in range(4):
         if it == 1:
@@ -134,10 +137,13 @@ def test_train_step_yolov5s_bs64_timing(dev):
         loss, items = compute_loss(pred, t)
         opt.zero_grad(set_to_none=True)
         (loss * 1024.0).backward()
-        for p in m.parameters():
-            p.grad.div_(1024.0)
-        opt.step()
+        if it == 0:  # parameter gradients are views of the engine's flat arena: autograd adopted them without copies
+            eng = next(iter(m.__dict__["_train_engines"].values()))
+            lo = eng.gflat.data_ptr()
+            assert all(lo <= p.grad.data_ptr() < lo + eng.gtotal * 4 for p in m.parameters())
+        stats = opt.step_fused(inv_scale=1.0 / 1024.0, max_norm=10.0, ema=ema, model=m)
         losses.append(float(loss))
+        assert float(stats[2]) == 0.0
     torch.cuda.synchronize()
     ms = (time.time() - t0) / 3 * 1e3
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]  # the loss goes down on a fixed batch

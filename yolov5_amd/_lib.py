@@ -33,6 +33,12 @@ class LossDesc(C.Structure):
                 ("obj_pw", C.c_float), ("anchor_t", C.c_float), ("cp", C.c_float), ("cn", C.c_float)]
 
 
+class MtTensor(C.Structure):
+    """include/yolov5_hip.h: y5_mt_tensor (one row of the fused optimizer's device-resident tensor table)."""
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("mom", C.c_void_p), ("ema", C.c_void_p), ("n", C.c_longlong),
+                ("group", C.c_int), ("reserved", C.c_int)]
+
+
 EXPORTS = {
     # name: (restype, argtypes)
     "y5_version": (C.c_int, []),
@@ -70,6 +76,11 @@ EXPORTS = {
                                        C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "y5_unpack_conv_wgrad": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "y5_memset_zero": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "y5_mt_workspace_bytes": (C.c_size_t, [C.c_int, C.c_longlong]),
+    "y5_mt_grad_norm": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "y5_mt_sgd_step": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_int, C.c_float,
+                                 C.c_void_p, C.c_float, C.c_void_p]),
+    "y5_mt_lerp": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_void_p]),
     "y5_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "y5_bn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_longlong]),
     "y5_bn_silu_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float,

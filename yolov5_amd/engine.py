@@ -391,6 +391,10 @@ class _HipBackend:
     def to_torch(self, h):
         return h
 
+    def view_torch(self, h):
+        """torch tensor sharing the buffer's memory (device buffers ARE torch tensors here)."""
+        return h
+
     def zero_(self, h):
         h.zero_()
 

@@ -30,21 +30,18 @@ def de_parallel(model):
 
 
 class _Bucket:
-    def __init__(self, idxs, numels, device):
-        self.idxs = idxs
-        self.offsets = {}
-        off = 0
-        for i, n in zip(idxs, numels):
-            self.offsets[i] = (off, n)
-            off += n
-        self.flat = torch.zeros(off, dtype=torch.float32, device=device)
+    """A contiguous range [lo, hi) of the training engine's gradient arena and the parameters that live in it."""
+
+    def __init__(self, idxs, lo, hi):
+        self.idxs, self.lo, self.hi = idxs, lo, hi
         self.pending = len(idxs)
         self.work = None
 
 
 class HipDDP(nn.Module):
     """Data-parallel wrapper for yolov5_amd models (see module docstring).  bucket_cap_mb follows torch DDP's default
-    (25 MB: yolov5s = 28.9 MB of fp32 gradients -> 2 buckets; a ring all-reduce of one bucket is ~0.3 ms on one xGMI link)."""
+    (25 MB: yolov5s = 28.9 MB of fp32 gradients -> 2 buckets; a ring all-reduce of one bucket is ~0.3 ms on one xGMI link).
+    Buckets are ranges of the engine's flat gradient arena (train_engine.py): nothing is packed or copied."""
 
     def __init__(self, module, bucket_cap_mb=25.0, process_group=None):
         super().__init__()
@@ -56,19 +53,8 @@ class HipDDP(nn.Module):
             if self.world > 1:
                 for t in list(module.parameters()) + [b for b in module.buffers() if b.dtype.is_floating_point or b.dtype == torch.long]:
                     dist.broadcast(t.data, 0, group=process_group)
-        cap = int(bucket_cap_mb * 1024 * 1024 / 4)
-        self.buckets, cur, cur_n = [], [], 0
-        dev = self.params[0].device
-        for i in reversed(range(len(self.params))):  # gradients arrive in (roughly) reverse registration order
-            n = self.params[i].numel()
-            if cur and cur_n + n > cap:
-                self.buckets.append(_Bucket(cur, [self.params[j].numel() for j in cur], dev))
-                cur, cur_n = [], 0
-            cur.append(i)
-            cur_n += n
-        if cur:
-            self.buckets.append(_Bucket(cur, [self.params[j].numel() for j in cur], dev))
-        self.p2b = {i: b for b in self.buckets for i in b.idxs}
+        self.cap = int(bucket_cap_mb * 1024 * 1024 / 4)
+        self.buckets, self.p2b, self._eng, self._flat = [], {}, None, None
         module.__dict__["_ddp_sink"] = self
         for k in ("stride", "names", "hyp", "nc", "yaml"):
             if hasattr(module, k):
@@ -77,29 +63,43 @@ class HipDDP(nn.Module):
     def forward(self, *a, **k):
         return self.module(*a, **k)
 
+    def _attach(self, eng):
+        """Cut the engine's arena (gradients in production order) into buckets of at most `cap` floats."""
+        self._eng = eng
+        self._flat = eng.be.view_torch(eng.gflat)
+        order = sorted(eng.goff, key=eng.goff.get)
+        self.buckets, cur, lo = [], [], 0
+        for i in order:
+            n = self.params[i].numel()
+            end = eng.goff[i] + n
+            if cur and end - lo > self.cap:
+                self.buckets.append(_Bucket(cur, lo, eng.goff[i]))
+                cur, lo = [], eng.goff[i]
+            cur.append(i)
+        if cur:
+            self.buckets.append(_Bucket(cur, lo, eng.gtotal))
+        self.p2b = {i: b for b in self.buckets for i in b.idxs}
+
     # ---- gradient sink protocol (called by TrainEngine.backward) -------------------------------------------------------
-    def begin(self):
+    def begin(self, eng):
+        if eng is not self._eng:
+            self._attach(eng)
         for b in self.buckets:
             b.pending = len(b.idxs)
             b.work = None
 
     def _launch(self, b):
         if self.world > 1:
-            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-        else:
-            b.work = None
+            b.work = dist.all_reduce(self._flat[b.lo:b.hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         b.pending = -1
 
-    def grad_ready(self, idx, g):
-        """Gradient of parameter `idx` is queued on the compute stream: pack it; a full bucket goes on the wire at once."""
+    def grad_ready(self, idx):
+        """The kernels producing parameter `idx`'s gradient are queued on the compute stream; a complete bucket goes on the
+        wire at once (the collective is ordered after them by the process group's stream synchronisation)."""
         b = self.p2b[idx]
-        off, n = b.offsets[idx]
-        view = b.flat[off:off + n].view(self.params[idx].shape)
-        view.copy_(g)
         b.pending -= 1
         if b.pending == 0:
             self._launch(b)
-        return view
 
     def finish(self, grads):
         """All kernels of the backward plan are queued: launch stragglers, wait for the wire, average."""
@@ -107,14 +107,14 @@ class HipDDP(nn.Module):
             if b.pending > 0:  # parameters that received no gradient this step contribute zeros
                 for i in b.idxs:
                     if grads[i] is None:
-                        off, n = b.offsets[i]
-                        b.flat[off:off + n].zero_()
+                        o = self._eng.goff[i]
+                        self._flat[o:o + self.params[i].numel()].zero_()
                 self._launch(b)
         for b in self.buckets:
             if b.work is not None:
                 b.work.wait()
-            if self.world > 1:
-                b.flat.div_(self.world)
+        if self.world > 1:
+            self._flat.div_(self.world)
         return grads
 
 
@@ -152,12 +152,131 @@ def smart_optimizer(model, name="SGD", lr=0.01, momentum=0.937, decay=5e-4):
     elif name == "RMSProp":
         optimizer = torch.optim.RMSprop(g[2], lr=lr, momentum=momentum)
     elif name == "SGD":
-        optimizer = torch.optim.SGD(g[2], lr=lr, momentum=momentum, nesterov=True)
+        # same groups / hyper-parameters / state_dict layout as torch.optim.SGD; the step is one fused multi-tensor launch
+        optimizer = HipSGD(g[2], lr=lr, momentum=momentum, nesterov=True)
     else:
         raise NotImplementedError(f"Optimizer {name} not implemented.")
     optimizer.add_param_group({"params": g[0], "weight_decay": decay})
     optimizer.add_param_group({"params": g[1], "weight_decay": 0.0})
     return optimizer
+
+
+class HipSGD(torch.optim.Optimizer):
+    """SGD(momentum, nesterov, weight_decay) with torch.optim.SGD's constructor, param_groups and state (`momentum_buffer`), whose
+    step is the fused multi-tensor kernel of csrc/optim.hip.  `step()` = plain optimizer step (gradients as they are);
+    `step_fused(inv_scale, max_norm, ema, model)` folds train.py:413-421 into three launches: GradScaler unscale + inf check,
+    clip_grad_norm_, the update (skipped on device when a gradient is non-finite) and ModelEMA.update.
+    `lib` selects the kernel library (default: libyolov5_hip.so; the tests pass the host-compiled emulator for CPU tensors)."""
+
+    def __init__(self, params, lr=0.01, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False, lib=None):
+        if dampening != 0.0:
+            raise ValueError("HipSGD: dampening is not supported (the reference never sets it)")
+        if nesterov and momentum <= 0:
+            raise ValueError("Nesterov momentum requires a momentum")
+        super().__init__(params, dict(lr=lr, momentum=momentum, dampening=0.0, weight_decay=weight_decay, nesterov=nesterov))
+        self._lib = lib
+        self._cache = None
+
+    def _library(self):
+        if self._lib is None:
+            from . import _lib
+
+            self._lib = _lib.lib()
+        return self._lib
+
+    def _tables(self, ema_pairs):
+        """Device-resident y5_mt_tensor table (rebuilt only when a pointer changes: .grad tensors are views of the engine's
+        gradient arena and keep their address from step to step)."""
+        import ctypes as C
+
+        import numpy as np
+
+        from . import _lib
+
+        if len(self.param_groups) > 4:
+            raise ValueError("HipSGD: at most 4 parameter groups")
+        rows = []
+        for gi, g in enumerate(self.param_groups):
+            for p in g["params"]:
+                if p.grad is None:
+                    continue
+                if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
+                    raise TypeError("HipSGD: contiguous fp32 parameters and gradients only")
+                st = self.state[p]
+                if g["momentum"] != 0 and "momentum_buffer" not in st:
+                    st["momentum_buffer"] = torch.zeros_like(p)
+                mom = st.get("momentum_buffer")
+                e = ema_pairs.get(id(p)) if ema_pairs else None
+                rows.append((p.data_ptr(), p.grad.data_ptr(), mom.data_ptr() if mom is not None else 0, e.data_ptr() if e is not None else 0,
+                             p.numel(), gi))
+        key = tuple(rows)
+        if self._cache is None or self._cache[0] != key:
+            if not rows:
+                self._cache = (key, None, 0, 0, None, None)
+                return self._cache
+            dev = self.param_groups[0]["params"][0].device
+            arr = (_lib.MtTensor * len(rows))()
+            for r, (pp, gp, mp, ep, n, gi) in zip(arr, rows):
+                r.param, r.grad, r.mom, r.ema, r.n, r.group = pp, gp, mp or None, ep or None, n, gi
+            tab = torch.from_numpy(np.frombuffer(arr, dtype=np.uint8).copy()).to(dev)
+            max_n = max(r[4] for r in rows)
+            ws = torch.empty(self._library().y5_mt_workspace_bytes(len(rows), max_n), dtype=torch.uint8, device=dev)
+            stats = torch.zeros(4, dtype=torch.float32, device=dev)
+            self._cache = (key, tab, len(rows), max_n, ws, stats)
+        return self._cache
+
+    @staticmethod
+    def _stream(dev):
+        import ctypes as C
+
+        return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else None
+
+    @torch.no_grad()
+    def step_fused(self, inv_scale=1.0, max_norm=0.0, ema=None, model=None):
+        """One optimizer step; returns the device tensor [grad_norm, clip_coef, found_inf, -] when a norm pass ran, else None."""
+        import ctypes as C
+
+        from . import _lib
+
+        if self._lib is None and any(p.device.type != "cuda" for g in self.param_groups for p in g["params"]):
+            raise RuntimeError("HipSGD: parameters must live on the GPU (there is no CPU execution path)")
+        lib = self._library()
+        ema_pairs, d = None, 0.0
+        if ema is not None:
+            if model is None:
+                raise ValueError("step_fused(ema=...) needs the model the EMA tracks")
+            ema.updates += 1
+            d = float(ema.decay(ema.updates))
+            ema_pairs = ema.param_pairs(model)
+        key, tab, n, max_n, ws, stats = self._tables(ema_pairs)
+        if n == 0:
+            return None
+        dev = tab.device
+        st = self._stream(dev)
+        g0 = self.param_groups[0]
+        for g in self.param_groups:
+            if g["momentum"] != g0["momentum"] or g["nesterov"] != g0["nesterov"]:
+                raise ValueError("HipSGD: momentum / nesterov must be the same in every group")
+        lr4 = (C.c_float * 4)(*([float(g["lr"]) for g in self.param_groups] + [0.0] * (4 - len(self.param_groups))))
+        wd4 = (C.c_float * 4)(*([float(g["weight_decay"]) for g in self.param_groups] + [0.0] * (4 - len(self.param_groups))))
+        use_stats = max_norm > 0 or inv_scale != 1.0
+        if use_stats:
+            _lib.check(lib.y5_mt_grad_norm(C.c_void_p(tab.data_ptr()), n, max_n, float(inv_scale), float(max_norm), C.c_void_p(stats.data_ptr()),
+                                           C.c_void_p(ws.data_ptr()), ws.numel(), st), lib)
+        _lib.check(lib.y5_mt_sgd_step(C.c_void_p(tab.data_ptr()), n, max_n, lr4, wd4, float(g0["momentum"]), int(bool(g0["nesterov"])),
+                                      float(inv_scale), C.c_void_p(stats.data_ptr()) if use_stats else None, d, st), lib)
+        if ema is not None:
+            ema.lerp_rest(model, d, lib, st, skip=set(k[0] for k in key))
+        return stats if use_stats else None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self.step_fused()
+        return loss
 
 
 class ModelEMA:
@@ -171,6 +290,7 @@ class ModelEMA:
         self.decay = lambda x: decay * (1 - math.exp(-x / tau))
         for p in self.ema.parameters():
             p.requires_grad_(False)
+        self._pairs = None
 
     def update(self, model):
         self.updates += 1
@@ -180,3 +300,44 @@ class ModelEMA:
             if v.dtype.is_floating_point:
                 v *= d
                 v += (1 - d) * msd[k].detach()
+
+    # ---- fused path (HipSGD.step_fused): the parameter EMA rides in the optimizer kernel, the rest in one y5_mt_lerp launch ----
+    def _build_pairs(self, model):
+        m = de_parallel(model)
+        e_p, e_b = dict(self.ema.named_parameters()), dict(self.ema.named_buffers())
+        params = {id(p): e_p[k] for k, p in m.named_parameters() if p.dtype.is_floating_point}
+        rest = [(p, e_p[k]) for k, p in m.named_parameters() if p.dtype.is_floating_point]
+        rest += [(b, e_b[k]) for k, b in m.named_buffers() if b.dtype.is_floating_point and k in e_b]
+        self._pairs = (m, params, rest, {})
+        return self._pairs
+
+    def param_pairs(self, model):
+        """id(model parameter) -> EMA parameter tensor."""
+        pr = self._pairs if self._pairs is not None and self._pairs[0] is de_parallel(model) else self._build_pairs(model)
+        return pr[1]
+
+    def lerp_rest(self, model, d, lib, stream, skip=()):
+        """EMA of every float tensor of the state_dict that the optimizer kernel did not already update (buffers: BatchNorm
+        running statistics; parameters without a gradient)."""
+        import ctypes as C
+
+        import numpy as np
+
+        from . import _lib
+
+        pr = self._pairs if self._pairs is not None and self._pairs[0] is de_parallel(model) else self._build_pairs(model)
+        todo = [(s, e) for s, e in pr[2] if s.data_ptr() not in skip]
+        if not todo:
+            return
+        key = tuple((s.data_ptr(), e.data_ptr()) for s, e in todo)
+        tab = pr[3].get(key)
+        if tab is None:
+            pr[3].clear()
+            arr = (_lib.MtTensor * len(todo))()
+            for r, (s, e) in zip(arr, todo):
+                if s.dtype != torch.float32 or e.dtype != torch.float32 or not s.is_contiguous() or not e.is_contiguous():
+                    raise TypeError("ModelEMA fused update: contiguous fp32 tensors only")
+                r.param, r.grad, r.mom, r.ema, r.n, r.group = s.data_ptr(), None, None, e.data_ptr(), s.numel(), 0
+            tab = (torch.from_numpy(np.frombuffer(arr, dtype=np.uint8).copy()).to(todo[0][0].device), max(s.numel() for s, _ in todo))
+            pr[3][key] = tab
+        _lib.check(lib.y5_mt_lerp(C.c_void_p(tab[0].data_ptr()), len(todo), tab[1], float(d), stream), lib)

@@ -61,6 +61,17 @@ class TrainEngine:
         self.gbufs = [self.be.empty((B, b.H, b.W, b.C), f16) for b in self.spec.bufs]
         self.params = list(model.parameters())
         self._pidx = {id(p): i for i, p in enumerate(self.params)}
+        # flat fp32 gradient arena, laid out in the order the backward plan produces the gradients (reverse registration
+        # order): kernels write parameter gradients straight into it, HipDDP all-reduces contiguous ranges of it, the fused
+        # optimizer reads it -- no per-parameter copies.  Slots are padded to 64 floats (Detect's 255-channel bias
+        # gradient is produced 256 wide).
+        self.goff, off = {}, 0
+        for i in reversed(range(len(self.params))):
+            self.goff[i] = off
+            off += round_up(self.params[i].numel(), 64)
+        self.gtotal = off
+        self.gflat = self.be.empty((max(off, 64),), torch.float32)
+        self.be.zero_(self.gflat)
         self.raw = {}
         self.convs = []
         self._keep = []
@@ -79,7 +90,7 @@ class TrainEngine:
                 if has_bn:
                     c2 = cv.out_channels
                     st["z"] = self.be.empty((B, y.H, y.W, c2), f16)
-                    for k in ("mean", "invstd", "dgamma", "dbeta"):
+                    for k in ("mean", "invstd"):
                         st[k] = self.be.empty((c2,), torch.float32)
                     max_z = max(max_z, B * y.H * y.W * c2)
                     max_ws = max(max_ws, self.lib.y5_bn_workspace_bytes(c2, B * y.H * y.W))
@@ -102,6 +113,10 @@ class TrainEngine:
 
     def _ld(self, t: TRef):
         return self.spec.bufs[t.buf].C
+
+    def _gptr(self, param):
+        """Device address of a parameter's slot in the gradient arena."""
+        return self.be.ptr(self.gflat) + self.goff[self._pidx[id(param)]] * 4
 
     def _f32(self, t):
         """Device pointer of an fp32 parameter / buffer (the emulated backend gets a host copy that is kept alive)."""
@@ -163,6 +178,7 @@ class TrainEngine:
             raise ValueError(f"training engine built for input {self.x_shape}, got {tuple(x.shape)}")
         stm = be.stream()
         self._keep = []
+        self._nbt = []
         x, xptr, src_dt = be.input(x)
         for op in self.spec.ops:
             kind = op["op"]
@@ -181,6 +197,8 @@ class TrainEngine:
                                               self._ld(lg), stm), lib)
             else:
                 raise NotImplementedError(kind)
+        if self._nbt:
+            torch._foreach_add_(self._nbt, 1)  # BatchNorm2d.num_batches_tracked of every layer: one launch instead of 57
         return [self.raw[i] for i in sorted(self.raw)]
 
     def _fwd_conv(self, st, stm):
@@ -239,7 +257,7 @@ class TrainEngine:
             bn.running_mean.copy_(self.be.to_torch(rm))
             bn.running_var.copy_(self.be.to_torch(rv))
         if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += 1
+            self._nbt.append(bn.num_batches_tracked)
 
     # ---- backward --------------------------------------------------------------------------------------------------
     def backward(self, dps):
@@ -269,14 +287,14 @@ class TrainEngine:
 
         sink = self.grad_sink
         if sink is not None:
-            sink.begin()
+            sink.begin(self)
         params = self.params
 
-        class _G(list):  # grads[i] = t also reports t to the sink (bucketed all-reduce overlapped with the rest of backward)
+        class _G(list):  # grads[i] = True: the gradient's kernels are queued -> tell the sink (bucketed all-reduce overlaps the rest)
             def __setitem__(s2, i, t):
-                if sink is not None and t is not None:
-                    t = sink.grad_ready(i, t.to(device=params[i].device, dtype=torch.float32))
                 list.__setitem__(s2, i, t)
+                if sink is not None and t is not None:
+                    sink.grad_ready(i)
 
         grads = _G([None] * len(params))
         hold = []
@@ -301,7 +319,8 @@ class TrainEngine:
                 raise NotImplementedError(kind)
         if sink is not None:
             sink.finish(grads)
-        return [None if g is None else g.to(device=p.device, dtype=p.dtype) for p, g in zip(params, grads)]
+        flat = be.view_torch(self.gflat)  # (fresh view tensors: autograd's AccumulateGrad can adopt them without a copy)
+        return [None if g is None else flat[self.goff[i]:self.goff[i] + p.numel()].view(p.shape) for i, (p, g) in enumerate(zip(params, grads))]
 
     def _bwd_conv(self, st, stm, is_written, mark, grads, hold):
         lib, be, B = self.lib, self.be, self.spec.B
@@ -323,16 +342,17 @@ class TrainEngine:
                 mark(res)
             _lib.check(lib.y5_bn_silu_bwd(_vp(self._ptr(y, True)), self._ld(y), _vp(be.ptr(st["z"])), c2, _lib.Y5_F16, npix, c2,
                                           _vp(st["gamma"]), _vp(st["beta"]), _vp(be.ptr(st["mean"])), _vp(be.ptr(st["invstd"])),
-                                          _vp(be.ptr(self.dz)), c2, _vp(be.ptr(st["dgamma"])), _vp(be.ptr(st["dbeta"])),
+                                          _vp(be.ptr(self.dz)), c2, _vp(self._gptr(m.bn.weight)), _vp(self._gptr(m.bn.bias)),
                                           _vp(be.ptr(self.ws)), self.ws_bytes, stm), lib)
             dz_ptr, ld_dz = be.ptr(self.dz), c2
-            grads[self._pidx[id(m.bn.weight)]] = be.to_torch(st["dgamma"]).clone()
-            grads[self._pidx[id(m.bn.bias)]] = be.to_torch(st["dbeta"]).clone()
+            grads[self._pidx[id(m.bn.weight)]] = True
+            grads[self._pidx[id(m.bn.bias)]] = True
         else:
             dz_ptr, ld_dz = self._ptr(y, True), self._ld(y)
-            _lib.check(lib.y5_channel_sum(_vp(dz_ptr), _lib.Y5_F16, npix, c2s, ld_dz, _vp(be.ptr(st["dbias"])), _vp(be.ptr(self.ws)), self.ws_bytes, stm), lib)
+            dbias = self._gptr(cv.bias) if cv.bias is not None else be.ptr(st["dbias"])  # (arena slots are 64-float padded: c2s fits)
+            _lib.check(lib.y5_channel_sum(_vp(dz_ptr), _lib.Y5_F16, npix, c2s, ld_dz, _vp(dbias), _vp(be.ptr(self.ws)), self.ws_bytes, stm), lib)
             if cv.bias is not None:
-                grads[self._pidx[id(cv.bias)]] = be.to_torch(st["dbias"])[:c2].clone()
+                grads[self._pidx[id(cv.bias)]] = True
         # weight gradient: packed fp32 accumulator -> parameter layout
         g = self._geom(st)
         Kpad, Npad = st["Kpad"], st["Npad"]
@@ -341,9 +361,8 @@ class TrainEngine:
                           KH=g["k"][0], KW=g["k"][1], SH=g["s"][0], SW=g["s"][1], PH=g["p"][0], PW=g["p"][1], act=0, Kpad=Kpad, Npad=Npad,
                           cfg=-1, max_blocks=0)
         _lib.check(lib.y5_conv2d_wgrad(C.byref(d), _vp(self._ptr(x)), _vp(dz_ptr), ld_dz, _vp(be.ptr(st["dw"])), stm), lib)
-        gw = be.empty((c2, c1, kh, kw), torch.float32)
-        _lib.check(lib.y5_unpack_conv_wgrad(_vp(be.ptr(st["dw"])), Kpad, _vp(be.ptr(gw)), c2, c1, kh, kw, st["c1v"], stm), lib)
-        grads[self._pidx[id(cv.weight)]] = be.to_torch(gw)
+        _lib.check(lib.y5_unpack_conv_wgrad(_vp(be.ptr(st["dw"])), Kpad, _vp(self._gptr(cv.weight)), c2, c1, kh, kw, st["c1v"], stm), lib)
+        grads[self._pidx[id(cv.weight)]] = True
         # data gradient: one forward launch per parity class on the re-packed sub-filter
         if not st["subs"]:
             return
@@ -378,7 +397,20 @@ class _TrainFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *dps):
-        grads = ctx.eng.backward([d.contiguous() for d in dps])
+        eng = ctx.eng
+        # gradient accumulation (a second backward before zero_grad): .grad tensors that alias the arena would be overwritten
+        # by this pass before autograd adds to them -- give those their own storage first, and hand autograd copies
+        lo = eng.be.ptr(eng.gflat)
+        hi = lo + eng.gtotal * 4
+        accumulating = False
+        for p in eng.params:
+            if p.grad is not None:
+                accumulating = True
+                if lo <= p.grad.data_ptr() < hi:
+                    p.grad = p.grad.clone()
+        grads = eng.backward([d.contiguous() for d in dps])
+        if accumulating:
+            grads = [None if g is None else g.clone() for g in grads]
         return (None, None, *grads)
 
 
