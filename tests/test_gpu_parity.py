@@ -47,7 +47,7 @@ CONV_CASES = [
     (2, 20, 20, 128, 128, 3, 1, 1, 1, False, False, -1, 0, "f32"),
     (4, 40, 40, 64, 64, 1, 1, 0, 1, False, False, 7, 5, "f16"),     # persistent: 50 one-chunk tiles on 5 workgroups
     (3, 33, 31, 32, 96, 3, 1, 1, 1, True, True, 0, 8, "f16"),
-] + [(2, 21, 19, c1, 160, 3, 1, 1, 1, True, False, cfg, 3, "f16") for cfg in list(range(14)) + list(range(22, 30)) + list(range(35, 46)) for c1 in (64, 48)] + [
+] + [(2, 21, 19, c1, 160, 3, 1, 1, 1, True, False, cfg, 3, "f16") for cfg in list(range(14)) + list(range(22, 30)) + list(range(35, 50)) for c1 in (64, 48)] + [
     # streaming pointwise kernel (conv_pw.h, cfg 14..21): many tiles per wave so the counted-vmcnt ring reaches steady
     # state and drains; LDS-DMA races would show up here as wrong tiles (run on the real machine, not the emulator)
     (16, 40, 40, 32, 32, 1, 1, 0, 1, False, False, 14, 8, "f16"),
@@ -72,6 +72,11 @@ CONV_CASES = [
     (16, 40, 40, 128, 256, 3, 2, 1, 1, False, False, 43, 0, "f16"),
     (8, 20, 20, 512, 512, 1, 1, 0, 1, False, False, 44, 8, "f16"),
     (8, 42, 38, 64, 64, 3, 1, 1, 1, True, True, 45, 0, "f16"),
+    # high-occupancy variants with aliased epilogue scratch (cfg 46..49): several tiles per workgroup
+    (8, 40, 40, 128, 128, 3, 1, 1, 1, True, False, 46, 16, "f16"),
+    (8, 40, 40, 128, 120, 3, 1, 1, 1, False, False, 47, 0, "f16"),
+    (16, 40, 40, 128, 256, 3, 2, 1, 1, False, False, 48, 24, "f16"),
+    (8, 42, 38, 64, 64, 3, 1, 1, 1, True, True, 49, 8, "f16"),
     # streaming 3x3 kernel (conv_k3.h, cfg 30..34)
     (8, 40, 40, 32, 32, 3, 1, 1, 1, True, False, 30, 8, "f16"),
     (8, 40, 40, 32, 32, 3, 1, 1, 1, False, False, 33, 0, "f16"),

@@ -19,7 +19,7 @@ constexpr int kRingBase[kNumRing] = {1, 2, 3, 5, 7, 8, 11, 12};
 // flight per CU, so these trade occupancy for bytes per flop: 256-row tiles, BK32 chunks, deeper rings, 8 waves where the
 // tile is 256 wide.  (wm, wn, tm, tn, rb, stages)
 struct BigCfg { int wm, wn, tm, tn, rb, ns; };
-constexpr int kBig0 = 35, kNumBig = 11;
+constexpr int kBig0 = 35, kNumBig = 15;
 constexpr BigCfg kBigCfgs[kNumBig] = {
     {2, 2, 4, 2, 64, 4},   // 35: 256 x 128, BK32, 4 stages, 4 waves
     {4, 2, 2, 2, 64, 4},   // 36: 256 x 128, BK32, 4 stages, 8 waves
@@ -33,6 +33,11 @@ constexpr BigCfg kBigCfgs[kNumBig] = {
     {2, 2, 2, 2, 64, 4},   // 43: 128 x 128, BK32, 4 stages, 4 + 4 waves
     {2, 2, 2, 4, 64, 4},   // 44: 128 x 256, BK32, 4 stages, 4 + 4 waves
     {4, 1, 1, 2, 128, 3},  // 45: 128 x  64, BK64, 3 stages, 4 + 4 waves
+    // high-occupancy 2-stage variants (conv_igemm.h ALIAS): epilogue scratch inside the idle ring stage
+    {2, 2, 2, 2, 64, 2},   // 46: 128 x 128, BK32 (32 KB LDS, 4 workgroups per CU)
+    {4, 1, 1, 2, 64, 2},   // 47: 128 x  64, BK32 (24 KB LDS)
+    {4, 1, 1, 2, 128, 2},  // 48: 128 x  64, BK64 (48 KB LDS, 3 workgroups per CU)
+    {2, 2, 1, 2, 128, 2},  // 49:  64 x 128, BK64 (48 KB LDS)
 };
 constexpr TileCfg kCfgs[kNumIgemm] = {
     {4, 1, 1, 1, 64},   //  0: 128 x  32, BK32
@@ -53,7 +58,7 @@ constexpr TileCfg kCfgs[kNumIgemm] = {
 
 int g_num_cu = 0;
 
-template <typename T, int WM, int WN, int TM, int TN, int RB, bool TABLE, int NS = 2, bool PROD = false>
+template <typename T, int WM, int WN, int TM, int TN, int RB, bool TABLE, int NS = 2, bool PROD = false, bool ALIAS = false>
 int launch_cfg(const Y5ConvParams& p0, int max_blocks, hipStream_t stream) {
   using Gm = Y5ConvGeom<T, RB>;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -67,9 +72,9 @@ int launch_cfg(const Y5ConvParams& p0, int max_blocks, hipStream_t stream) {
     pieces = p.Kpad / Gm::EPP;
     if (pieces > Y5_CONV_MAXTAB) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: K too large for gather-table mode");
   }
-  const size_t lds = y5_conv_lds_bytes<T, WM, WN, TM, TN, RB, NS>(pieces);
+  const size_t lds = y5_conv_lds_bytes<T, WM, WN, TM, TN, RB, NS, ALIAS>(pieces);
   if (lds > 160 * 1024) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: tile configuration exceeds 160 KiB of LDS");
-  auto kern = y5_conv_igemm_kernel<T, WM, WN, TM, TN, RB, TABLE, NS, PROD>;
+  auto kern = y5_conv_igemm_kernel<T, WM, WN, TM, TN, RB, TABLE, NS, PROD, ALIAS>;
   constexpr int NTHREADS = WM * WN * 64 * (PROD ? 2 : 1);
   static bool attr_done = false;  // per instantiation
   if (!attr_done) {
@@ -144,6 +149,10 @@ int launch_by_cfg(const Y5ConvParams& p, int cfg, int mb, hipStream_t s) {
       case kBig0 + 8: return launch_cfg<T, 2, 2, 2, 2, 64, TABLE, 4, true>(p, mb, s);
       case kBig0 + 9: return launch_cfg<T, 2, 2, 2, 4, 64, TABLE, 4, true>(p, mb, s);
       case kBig0 + 10: return launch_cfg<T, 4, 1, 1, 2, 128, TABLE, 3, true>(p, mb, s);
+      case kBig0 + 11: return launch_cfg<T, 2, 2, 2, 2, 64, TABLE, 2, false, true>(p, mb, s);
+      case kBig0 + 12: return launch_cfg<T, 4, 1, 1, 2, 64, TABLE, 2, false, true>(p, mb, s);
+      case kBig0 + 13: return launch_cfg<T, 4, 1, 1, 2, 128, TABLE, 2, false, true>(p, mb, s);
+      case kBig0 + 14: return launch_cfg<T, 2, 2, 1, 2, 128, TABLE, 2, false, true>(p, mb, s);
     }
     return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown tile config");
   }

@@ -62,10 +62,10 @@ template <typename T, int RB> struct Y5ConvGeom {
   __device__ static __forceinline__ int swz(int row) { return RB == 64 ? ((row >> 2) & 3) : ((row >> 1) & 7); }
 };
 
-template <typename T, int WM, int WN, int TM, int TN, int RB, int NS = 2>
+template <typename T, int WM, int WN, int TM, int TN, int RB, int NS = 2, bool ALIAS = false>
 constexpr size_t y5_conv_lds_bytes(int table_pieces) {
   return NS * (size_t)(WM * TM * 32 + WN * TN * 32) * RB + (size_t)table_pieces * 8 +
-         (size_t)WM * WN * Y5ConvGeom<T, RB>::SCR_BYTES + (NS > 2 ? (size_t)WM * WN * 1024 : 0);
+         (ALIAS ? 0 : (size_t)WM * WN * Y5ConvGeom<T, RB>::SCR_BYTES) + (NS > 2 ? (size_t)WM * WN * 1024 : 0);
 }
 
 // minimum waves per SIMD requested from the register allocator (keeps the accumulators in the unified VGPR file
@@ -81,10 +81,17 @@ constexpr int y5_conv_min_waves(int tm, int tn) { return tm * tn <= 1 ? 5 : tm *
 // PROD the workgroup has 2 * WM * WN waves: the first WM * WN (consumers) only read fragments, multiply and run the
 // epilogue; the others (producers, one per SIMD beside a consumer) only issue the ring's LDS-DMA instructions, NS-1
 // chunks ahead, and retire them with counted vmcnt.  One raw s_barrier per chunk joins the two roles.
-template <typename T, int WM, int WN, int TM, int TN, int RB, bool TABLE, int NS = 2, bool PROD = false>
-__global__ __launch_bounds__(WM * WN * 64 * (PROD ? 2 : 1), y5_conv_min_waves(TM, TN))
+//
+// ALIAS (2-stage only): the epilogue's transposition scratch lives in the ring stage that is idle at a tile boundary instead
+// of in LDS of its own, and one more wave per SIMD is requested from the register allocator -- more workgroups per CU, so
+// that layers whose tile count is just above the resident-workgroup count finish in one round instead of two.  The
+// prefetch of the new tile's second chunk starts after the epilogue (one extra barrier per tile).
+template <typename T, int WM, int WN, int TM, int TN, int RB, bool TABLE, int NS = 2, bool PROD = false, bool ALIAS = false>
+__global__ __launch_bounds__(WM * WN * 64 * (PROD ? 2 : 1), y5_conv_min_waves(TM, TN) + (ALIAS ? 1 : 0))
 void y5_conv_igemm_kernel(const Y5ConvParams p) {
   static_assert(!PROD || NS >= 3, "producer/consumer needs a ring");
+  static_assert(!ALIAS || (NS == 2 && !PROD), "scratch aliasing is implemented for the 2-stage kernel");
+  static_assert(!ALIAS || (WM * TM * 32 + WN * TN * 32) * RB >= WM * WN * Y5ConvGeom<T, RB>::SCR_BYTES, "stage too small for the scratch");
   using Gm = Y5ConvGeom<T, RB>;
   constexpr int EPP = Gm::EPP, BK = Gm::BK, NSLOT = Gm::NSLOT, RPI = Gm::ROWS_PER_INSTR;
   constexpr int NW = WM * WN;
@@ -110,7 +117,7 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
   const bool producer = PROD && wave_id >= NW;
   const int wave = producer ? wave_id - NW : wave_id;  // index inside the role: loader share / consumer sub-tile
   const int wm = wave / WN, wn = wave % WN;
-  char* scratch = smem + NS * BUF_BYTES + tab_bytes + wave * Gm::SCR_BYTES;
+  char* scratch = smem + (ALIAS ? 0 : NS * BUF_BYTES + tab_bytes) + wave * Gm::SCR_BYTES;  // ALIAS: re-pointed at every tile boundary
   char* dummy = smem + NS * BUF_BYTES + tab_bytes + NW * Gm::SCR_BYTES + wave * 1024;  // NS > 2 only
 
   const int G = gridDim.x;
@@ -485,11 +492,18 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
         // spread over this chunk's k-steps
         const bool more = it + 1 < total;
         const bool spread = more && kc != 0;
+        if constexpr (ALIAS) {
+          if (kc == 0) {
+            scratch = smem + (cur ^ 1) * BUF_BYTES + wave * Gm::SCR_BYTES;  // stage cur^1 held the previous chunk: idle
+            tile_begin(ti, pm0, pn0);
+            if (ti > 0) __syncthreads();  // every wave is done with its scratch before the stage is refilled
+          }
+        }
         if (more) { if (spread) stage_begin(cur ^ 1); else stage(cur ^ 1); }
 #ifdef Y5_DBG_TIMING
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
 #endif
-        if (kc == 0) tile_begin(ti, pm0, pn0);
+        if (!ALIAS && kc == 0) tile_begin(ti, pm0, pn0);
 #ifdef Y5_DBG_TIMING
         const unsigned long long t1b = __builtin_amdgcn_s_memtime();
 #endif
@@ -544,6 +558,7 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
       }
     }
   }
+  if constexpr (ALIAS) scratch = smem + wave * Gm::SCR_BYTES;  // both stages are idle after the last barrier
   epilogue(pm0, pn0);
 #ifdef Y5_DBG_TIMING
   if constexpr (NS == 2 && !PROD) {
