@@ -204,6 +204,25 @@ def test_yolov5s_fp16_640_vs_oracle(dev):
     assert np.abs(z[..., :4] - ref[..., :4]).mean() < 0.05
 
 
+@pytest.mark.parametrize("shape", [(3, 3, 96, 160), (1, 3, 64, 224), (5, 3, 128, 192), (2, 3, 352, 608), (7, 3, 32, 32)])
+def test_rectangular_and_odd_batches_fp16_and_fp32(shape, dev):
+    """val.py / detect.py rectangular inference (sizes are multiples of the stride, not of 64; any batch size): every kernel
+    family has to take its general fallback somewhere in these shapes (stem needs W % 64 == 0, k3 needs OW % 8 == 0, ...)."""
+    cfg = yo.model_cfg("yolov5n")
+    sd = yo.det_state_dict(cfg, 5, fused=True)
+    x = torch.from_numpy(detgen.uniform(shape, 0.0, 1.0, name="rimg", seed=shape[2] + shape[3]))
+    with torch.no_grad():
+        ref32 = yo.model_forward(cfg, sd, x)[0].numpy()
+        ref16 = yo.model_forward(cfg, sd, x.half().float())[0].numpy()
+    m = _det_model("yolov5n", 5).fuse().to(dev)
+    z32 = m(x.to(dev))[0].cpu().numpy()
+    np.testing.assert_allclose(z32, ref32, rtol=1e-4, atol=2e-4)
+    m = m.half()
+    z16 = m(x.half().to(dev))[0].float().cpu().numpy()
+    assert z16.shape == ref16.shape
+    assert np.abs(z16[..., :4] - ref16[..., :4]).max() < 1.0 and np.abs(z16[..., 4:] - ref16[..., 4:]).max() < 3e-2
+
+
 def test_uint8_input_scaling(dev):
     m = _det_model("yolov5n", 0).fuse().to(dev)
     img = (detgen.uniform((1, 3, 64, 64), 0, 255.99, name="u8img")).astype(np.uint8)
