@@ -257,6 +257,7 @@ int y5_plan_size(const y5_plan*);
 int y5_plan_run(y5_plan*, void* stream);                 /* eager replay of every recorded op */
 int y5_plan_run_range(y5_plan*, int first, int last, void* stream);
 int y5_plan_capture(y5_plan*, void* stream);             /* capture the replay into a hipGraph (once) */
+int y5_plan_capture_range(y5_plan*, int first, int last, void* stream);  /* same for ops [first, last) */
 int y5_plan_launch_graph(y5_plan*, void* stream);        /* hipGraphLaunch of the captured graph */
 
 /* Timing helper for bench/profiling: run ops [first,last) `iters` times on `stream` bracketed by hipEvents

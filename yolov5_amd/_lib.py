@@ -121,6 +121,7 @@ EXPORTS = {
     "y5_plan_run": (C.c_int, [C.c_void_p, C.c_void_p]),
     "y5_plan_run_range": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "y5_plan_capture": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "y5_plan_capture_range": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "y5_plan_launch_graph": (C.c_int, [C.c_void_p, C.c_void_p]),
     "y5_plan_time_range": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
 }

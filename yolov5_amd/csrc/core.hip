@@ -171,24 +171,33 @@ extern "C" int y5_plan_run_range(y5_plan* pl, int first, int last, void* st) {
 }
 extern "C" int y5_plan_run(y5_plan* pl, void* st) { return y5_plan_run_range(pl, 0, pl ? (int)pl->ops.size() : 0, st); }
 
-extern "C" int y5_plan_capture(y5_plan* pl, void* st_) {
-  if (!pl) return y5_fail(Y5_ERR_BAD_ARG, "plan_capture: null");
+extern "C" int y5_plan_capture_range(y5_plan* pl, int first, int last, void* st_) {
+  if (!pl || first < 0 || last > (int)pl->ops.size() || first >= last) return y5_fail(Y5_ERR_BAD_ARG, "plan_capture: bad range");
   hipStream_t st = static_cast<hipStream_t>(st_);
   if (!y5_zero_page()) return y5_fail(Y5_ERR_RUNTIME, "plan_capture: zero page");
   // one eager run first: performs the per-kernel one-time attribute setup outside of capture
-  int rc = y5_plan_run(pl, st_);
+  int rc = y5_plan_run_range(pl, first, last, st_);
   if (rc) return rc;
   if (hipStreamSynchronize(st) != hipSuccess) return y5_fail(Y5_ERR_RUNTIME, "plan_capture: sync failed");
   if (pl->exec) { hipGraphExecDestroy(pl->exec); pl->exec = nullptr; }
   if (pl->graph) { hipGraphDestroy(pl->graph); pl->graph = nullptr; }
-  if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) return y5_fail(Y5_ERR_RUNTIME, "plan_capture: begin capture failed");
-  rc = y5_plan_run(pl, st_);
-  const hipError_t e = hipStreamEndCapture(st, &pl->graph);
+  // capture on a private stream (the caller's may be the legacy default stream, which cannot be captured); the graph itself
+  // is stream-agnostic and is launched on whatever stream y5_plan_launch_graph receives
+  hipStream_t cs = nullptr;
+  if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) return y5_fail(Y5_ERR_RUNTIME, "plan_capture: stream create failed");
+  if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    hipStreamDestroy(cs);
+    return y5_fail(Y5_ERR_RUNTIME, "plan_capture: begin capture failed");
+  }
+  rc = y5_plan_run_range(pl, first, last, cs);
+  const hipError_t e = hipStreamEndCapture(cs, &pl->graph);
+  hipStreamDestroy(cs);
   if (rc) return rc;
   if (e != hipSuccess || !pl->graph) return y5_fail(Y5_ERR_RUNTIME, "plan_capture: end capture failed");
   if (hipGraphInstantiate(&pl->exec, pl->graph, nullptr, nullptr, 0) != hipSuccess) return y5_fail(Y5_ERR_RUNTIME, "plan_capture: instantiate failed");
   return Y5_OK;
 }
+extern "C" int y5_plan_capture(y5_plan* pl, void* st_) { return y5_plan_capture_range(pl, 0, pl ? (int)pl->ops.size() : 0, st_); }
 
 extern "C" int y5_plan_launch_graph(y5_plan* pl, void* st_) {
   if (!pl || !pl->exec) return y5_fail(Y5_ERR_BAD_ARG, "plan_launch_graph: plan not captured");

@@ -451,6 +451,7 @@ class Engine:
                                                           c2, npad, self._ptr(y), self._ld(y)), self.lib)
                 self.op_names.append(self.op_names[1] + "[stem,nchw]")
         self._graph = False
+        self._use_graph = os.environ.get("Y5_GRAPH", "1") == "1" and isinstance(self.be, _HipBackend)
 
     def __del__(self):
         try:
@@ -571,7 +572,17 @@ class Engine:
             self._stem_active = True
             _lib.check(self.lib.y5_plan_set_input(self.plan, self._stem, C.c_void_p(xptr)), self.lib)
             _lib.check(self.lib.y5_plan_run_range(self.plan, self._stem, self._stem + 1, st), self.lib)
-            _lib.check(self.lib.y5_plan_run_range(self.plan, 2, self._stem, st), self.lib)
+            if self._use_graph:
+                # ops 2.. only touch plan-owned buffers: replayed as ONE hipGraph launch (captured on first use)
+                if not self._graph:
+                    if self.lib.y5_plan_capture_range(self.plan, 2, self._stem, st) == 0:
+                        self._graph = True
+                    else:  # capture refused by the runtime: same kernels, launched one by one
+                        self._use_graph = False
+            if self._use_graph:
+                _lib.check(self.lib.y5_plan_launch_graph(self.plan, st), self.lib)
+            else:
+                _lib.check(self.lib.y5_plan_run_range(self.plan, 2, self._stem, st), self.lib)
             return self.outputs
         self._stem_active = False
         scale = 1.0 / 255.0 if src_dt == _lib.Y5_U8 else 1.0  # train.py:379 / detect.py:209: uint8 images -> 0..1
