@@ -95,6 +95,24 @@ def conv_bytes(engine, esize=2):
     return out
 
 
+def pmc_traffic(a, conv_by):
+    """HBM bytes of the conv launches of one forward from the memory-side L2 counters.  They cannot be collected from inside this
+    process: scripts/pmc_forward.sh runs the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same forward and the
+    result is committed under profiles/pmc/ (FETCH_SIZE doubled: gfx950 correction of MI355X_MICROARCH.md "HBM").  Only
+    reported for the configuration it was measured on."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc", "r01_pmc_forward.json")
+    if not (a.model == "yolov5s" and a.batch == 64 and a.imgsz == 640 and os.path.isfile(path)):
+        return None
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        gb = float(d["conv_traffic_gb_per_forward"])
+    except (OSError, ValueError, KeyError):
+        return None
+    return {"gbytes_per_step": round(gb, 3), "vs_algorithmic": round(gb * 1e9 / conv_by, 3) if conv_by else None,
+            "source": "profiles/pmc/r01_pmc_forward.json (scripts/pmc_forward.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, FETCH x2)"}
+
+
 def usable_cores():
     """Host cores this process may really use: affinity mask and cgroup CPU quota, capped at 64 threads (oneDNN/OpenMP
     stop scaling -- and thrash -- far below the 256 logical CPUs the GPU box advertises)."""
@@ -311,7 +329,7 @@ def main():
             # the MFMA view of the same launches is kept beside it
             "roofline": {"bound": "hbm", "kernel": "y5_conv_{igemm,pw,k3,stem}_kernel (all conv launches of one forward)",
                          "achieved": round(achieved_bw, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved_bw / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved_bw / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(a, conv_by),
                          "algorithmic_gbytes_per_step": round(conv_by / 1e9, 3), "algorithmic_gflop_per_step": round(conv_fl / 1e9, 1),
                          "arithmetic_intensity_flop_per_byte": round(conv_fl / conv_by, 1) if conv_by else None,
                          "mfma_achieved_tflops": round(achieved, 2), "mfma_peak_tflops": MFMA_PEAK_TFLOPS,

@@ -8,7 +8,7 @@
 namespace {
 int nblk_for(long long npix) {
   long long n = (npix + 63) / 64;
-  return (int)(n < 1 ? 1 : n > 512 ? 512 : n);
+  return (int)(n < 1 ? 1 : n > 1024 ? 1024 : n);
 }
 int check(int dt, long long npix, int C, const void* ws, size_t ws_bytes) {
   if (dt != Y5_F16 && dt != Y5_F32) return y5_fail(Y5_ERR_BAD_ARG, "bn: dtype must be Y5_F16 or Y5_F32");

@@ -63,14 +63,13 @@ void y5_chan_reduce_kernel(const Y5BnParams p) {
     // pixels of this block: a contiguous range split evenly over the grid, rows of the block stride through it
     const long long per = (p.npix + gridDim.x - 1) / gridDim.x;
     const long long p0 = per * blockIdx.x, p1 = p0 + per < p.npix ? p0 + per : p.npix;
-    for (long long px = p0 + r; px < p1; px += rows) {
+    // U independent 16-byte loads per thread and iteration: the pass is a pure stream, its speed is the number of bytes in flight
+    constexpr int U = 4;
+    auto accumulate = [&](const V& zv, const V& gv) {
       if constexpr (MODE == 0) {
-        const V zv = *reinterpret_cast<const V*>(static_cast<const T*>(p.z) + px * p.ldz + cl * N);
 #pragma unroll
         for (int e = 0; e < N; ++e) { const float z = (float)zv[e]; a0[e] += z; a1[e] += z * z; }
       } else if constexpr (MODE == 1) {
-        const V zv = *reinterpret_cast<const V*>(static_cast<const T*>(p.z) + px * p.ldz + cl * N);
-        const V gv = *reinterpret_cast<const V*>(static_cast<const T*>(p.dy) + px * p.ldy + cl * N);
 #pragma unroll
         for (int e = 0; e < N; ++e) {
           const float zh = ((float)zv[e] - mu[e]) * is[e];
@@ -78,10 +77,29 @@ void y5_chan_reduce_kernel(const Y5BnParams p) {
           a0[e] += dv; a1[e] += dv * zh;
         }
       } else {
-        const V gv = *reinterpret_cast<const V*>(static_cast<const T*>(p.dy) + px * p.ldy + cl * N);
 #pragma unroll
         for (int e = 0; e < N; ++e) a0[e] += (float)gv[e];
       }
+    };
+    const T* zb = static_cast<const T*>(p.z);
+    const T* gb = static_cast<const T*>(p.dy);
+    long long px = p0 + r;
+    for (; px + (long long)(U - 1) * rows < p1; px += (long long)U * rows) {
+      V zv[U] = {}, gv[U] = {};
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long q = px + (long long)u * rows;
+        if constexpr (MODE != 2) zv[u] = *reinterpret_cast<const V*>(zb + q * p.ldz + cl * N);
+        if constexpr (MODE != 0) gv[u] = *reinterpret_cast<const V*>(gb + q * p.ldy + cl * N);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) accumulate(zv[u], gv[u]);
+    }
+    for (; px < p1; px += rows) {
+      V zv{}, gv{};
+      if constexpr (MODE != 2) zv = *reinterpret_cast<const V*>(zb + px * p.ldz + cl * N);
+      if constexpr (MODE != 0) gv = *reinterpret_cast<const V*>(gb + px * p.ldy + cl * N);
+      accumulate(zv, gv);
     }
 #pragma unroll
     for (int e = 0; e < N; ++e) {
