@@ -55,5 +55,42 @@ def main():
             print(f"{parts} plans of batch {64 // parts} on one stream: {t3:.3f} ms")
 
 
+
+def split_engine_check():
+    """The product's SplitEngine (one model, two sub-batch plans) timed the same way."""
+    from yolov5_amd.engine import SplitEngine
+
+    dev = torch.device("cuda:0")
+    x = torch.rand((64, 3, 640, 640), device=dev).half()
+    m = bench.build_model("yolov5s", dev)
+    with torch.no_grad():
+        se = SplitEngine(m, tuple(x.shape), torch.float16, dev, want_raw=True, parts=2)
+        print(f"SplitEngine(parts=2): {timeit(lambda: se(x)):.3f} ms")
+        # same two engines driven by hand
+        def run():
+            cur = torch.cuda.current_stream(dev)
+            for i, (eng, s) in enumerate(zip(se.engines, se.streams)):
+                s.wait_stream(cur)
+                with torch.cuda.stream(s):
+                    eng(x[i * 32:(i + 1) * 32])
+            for s in se.streams:
+                cur.wait_stream(s)
+        print(f"same engines, manual loop: {timeit(run):.3f} ms")
+        xs = [c.contiguous() for c in x.chunk(2)]
+        def run2():
+            cur = torch.cuda.current_stream(dev)
+            for eng, xx, s in zip(se.engines, xs, se.streams):
+                s.wait_stream(cur)
+                with torch.cuda.stream(s):
+                    eng(xx)
+            for s in se.streams:
+                cur.wait_stream(s)
+        print(f"same engines, pre-chunked inputs: {timeit(run2):.3f} ms")
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "split":
+    split_engine_check()
+    sys.exit(0)
+
 if __name__ == "__main__":
     main()

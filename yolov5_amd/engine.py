@@ -415,7 +415,7 @@ class Engine:
     """A materialised PlanSpec on one GPU.  `engine(x)` -> dict of output tensors (engine-owned buffers, valid
     until the next call).  Raises RuntimeError without a GPU / without libyolov5_hip.so."""
 
-    def __init__(self, model, x_shape, dtype: torch.dtype, device, want_raw=False, backend=None, spec=None):
+    def __init__(self, model, x_shape, dtype: torch.dtype, device, want_raw=False, backend=None, spec=None, outputs=None):
         if dtype not in (torch.float16, torch.float32):
             raise TypeError(f"Engine dtype must be float16 or float32, got {dtype}")
         self.be = backend if backend is not None else _HipBackend(device)
@@ -434,7 +434,13 @@ class Engine:
         self.bufs = [self.be.empty((B, b.H, b.W, b.C), dtype) for b in self.spec.bufs]
         self.outputs = {}
         for name, o in self.spec.outputs.items():
-            self.outputs[name] = self.be.empty(o["shape"], dtype)
+            if outputs is not None:  # caller-owned output buffers (SplitEngine: batch slices of one tensor)
+                t = outputs[name]
+                if tuple(t.shape) != tuple(o["shape"]) or t.dtype != dtype or not t.is_contiguous():
+                    raise ValueError(f"engine output {name}: expected contiguous {tuple(o['shape'])} {dtype}")
+                self.outputs[name] = t
+            else:
+                self.outputs[name] = self.be.empty(o["shape"], dtype)
         self.plan = C.c_void_p(self.lib.y5_plan_create())
         self.op_names = []
         self.conv_cfgs = []
@@ -606,3 +612,47 @@ class Engine:
             res.append((self.op_names[i], ms.value / iters))
         self.timed_order = order
         return res
+
+
+_SPLIT_STREAMS = {}
+
+
+class SplitEngine:
+    """The batch cut into `parts` equal sub-batches, each with its own plan on its own HIP stream, writing batch slices of
+    one set of output tensors.  Every layer is a persistent kernel whose prologue burst, last epilogue and tail round leave
+    most CUs idle for 10-25 % of its duration; with two independent plans in flight the hardware fills
+    those holes with the other plan's workgroups (yolov5s bs=64: 2.86 ms vs 3.04 ms).  Images are independent in eval mode
+    (BatchNorm is folded), so the result is the same function of the input."""
+
+    def __init__(self, model, x_shape, dtype, device, want_raw=False, parts=2):
+        B = x_shape[0]
+        if B % parts:
+            raise ValueError("SplitEngine: batch not divisible")
+        self.parts, self.x_shape, self.sub_b = parts, tuple(x_shape), B // parts
+        sub_shape = (self.sub_b,) + tuple(x_shape[1:])
+        spec = build_plan_spec(model, self.sub_b, x_shape[1], x_shape[2], x_shape[3], want_raw)
+        self.outputs = {name: torch.empty((B,) + tuple(o["shape"][1:]), dtype=dtype, device=device) for name, o in spec.outputs.items()}
+        self.engines = []
+        for i in range(parts):
+            views = {name: t[i * self.sub_b:(i + 1) * self.sub_b] for name, t in self.outputs.items()}
+            self.engines.append(Engine(model, sub_shape, dtype, device, want_raw=want_raw, spec=spec if i == 0 else None, outputs=views))
+        self.device = device
+        # HIP multiplexes streams onto a few hardware queues and two streams on one queue run one after the other (measured:
+        # 2.92 ms vs 3.55 ms for the same two plans depending on the pair the stream pool hands out, 3.27 ms once eight
+        # streams exist) -- so one fixed set of side streams per device is created once and shared by every SplitEngine
+        key = (str(device), parts)
+        if key not in _SPLIT_STREAMS:
+            _SPLIT_STREAMS[key] = [torch.cuda.Stream(device) for _ in range(parts)]
+        self.streams = _SPLIT_STREAMS[key]
+
+    def __call__(self, x):
+        if tuple(x.shape) != self.x_shape:
+            raise ValueError(f"engine built for input {self.x_shape}, got {tuple(x.shape)}")
+        cur = torch.cuda.current_stream(self.device)
+        for i, (eng, s) in enumerate(zip(self.engines, self.streams)):
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                eng(x[i * self.sub_b:(i + 1) * self.sub_b])
+        for s in self.streams:
+            cur.wait_stream(s)
+        return self.outputs

@@ -13,6 +13,8 @@ import math
 from copy import deepcopy
 from pathlib import Path
 
+import os
+
 import torch
 from torch import nn
 
@@ -85,10 +87,15 @@ class BaseModel(nn.Module):
         key = (tuple(x.shape), next(self.parameters()).dtype, str(x.device), want_raw, self._weights_version())
         eng = self._engines.get(key)
         if eng is None:
-            from .engine import Engine
+            from .engine import Engine, SplitEngine
 
             self._engines.clear()  # one live plan per model keeps HBM use bounded
-            eng = Engine(self, tuple(x.shape), next(self.parameters()).dtype, x.device, want_raw=want_raw)
+            parts = int(os.environ.get("Y5_SPLIT", "2"))
+            if x.is_cuda and parts > 1 and x.shape[0] >= 16 * parts and x.shape[0] % parts == 0:
+                # large batches: sub-batch plans on separate streams fill each other's kernel tails (engine.SplitEngine)
+                eng = SplitEngine(self, tuple(x.shape), next(self.parameters()).dtype, x.device, want_raw=want_raw, parts=parts)
+            else:
+                eng = Engine(self, tuple(x.shape), next(self.parameters()).dtype, x.device, want_raw=want_raw)
             self._engines[key] = eng
         out = eng(x)
         z = out["z"]
