@@ -188,6 +188,17 @@ int y5_pack_conv_weight(const float* w, int C2, int C1, int KH, int KW, int C1_v
 int y5_pack_dgrad_weight(const float* w, int C2, int C1, int KH, int KW, const int* taps_h, int nth, const int* taps_w, int ntw,
                          int C2_view, void* out_f16, int Kpad, int Npad, void* stream);
 int y5_unpack_conv_wgrad(const float* dw_packed, int Kpad, float* gw, int C2, int C1, int KH, int KW, int C1_view, void* stream);
+/* The same three transforms over many filters in ONE launch: `jobs_dev` is a DEVICE array of njobs descriptors, max_total the
+ * largest `total` among them.  kind 0 = y5_pack_conv_weight, 1 = y5_pack_dgrad_weight, 2 = y5_unpack_conv_wgrad (total = output
+ * elements: Npad*Kpad for the packs, C2*C1*KH*KW for the unpack). */
+typedef struct {
+  const void* src; void* dst;
+  long long total;
+  int kind, C2, C1, KH, KW, C1_view, C2_view, Kpad, Npad, nth, ntw;
+  int th[8], tw[8];
+  int reserved;
+} y5_filter_job;
+int y5_filter_jobs(const y5_filter_job* jobs_dev, int njobs, long long max_total, void* stream);
 int y5_memset_zero(void* p, size_t bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------

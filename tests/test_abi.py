@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_header_symbols_match_binding_table():
     hdr = open(os.path.join(ROOT, "include", "yolov5_hip.h")).read()
     declared = set(re.findall(r"\b(y5_[a-z0-9_]+)\s*\(", hdr))
-    declared -= {"y5_status", "y5_dtype", "y5_conv_desc", "y5_plan"}
+    declared -= {"y5_status", "y5_dtype", "y5_conv_desc", "y5_plan"}  # (types, not functions)
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
 
 

@@ -33,6 +33,13 @@ class LossDesc(C.Structure):
                 ("obj_pw", C.c_float), ("anchor_t", C.c_float), ("cp", C.c_float), ("cn", C.c_float)]
 
 
+class FilterJob(C.Structure):
+    """include/yolov5_hip.h: y5_filter_job (one filter re-pack / weight-gradient unpack of a multi-filter launch)."""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("total", C.c_longlong)] + \
+               [(n, C.c_int) for n in ("kind", "C2", "C1", "KH", "KW", "C1_view", "C2_view", "Kpad", "Npad", "nth", "ntw")] + \
+               [("th", C.c_int * 8), ("tw", C.c_int * 8), ("reserved", C.c_int)]
+
+
 class MtTensor(C.Structure):
     """include/yolov5_hip.h: y5_mt_tensor (one row of the fused optimizer's device-resident tensor table)."""
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("mom", C.c_void_p), ("ema", C.c_void_p), ("n", C.c_longlong),
@@ -76,6 +83,7 @@ EXPORTS = {
                                        C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "y5_unpack_conv_wgrad": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "y5_memset_zero": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "y5_filter_jobs": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_void_p]),
     "y5_mt_workspace_bytes": (C.c_size_t, [C.c_int, C.c_longlong]),
     "y5_mt_grad_norm": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "y5_mt_sgd_step": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_int, C.c_float,

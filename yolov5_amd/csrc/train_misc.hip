@@ -271,6 +271,57 @@ extern "C" int y5_unpack_conv_wgrad(const float* dw_packed, int Kpad, float* gw,
                      C1_view, Kpad, total);
   return y5_check_launch("y5_unpack_conv_wgrad");
 }
+// ---- the three transforms above over MANY filters in one launch (one job per filter, table in device memory) ---------------
+// grid = (chunks of MT_CH output elements, jobs); workgroups past a job's end exit at once.  A training step re-packs ~57
+// forward filters and ~77 data-gradient sub-filters and unpacks ~60 weight gradients: 3 launches instead of ~194.
+namespace { constexpr int MT_CH = 4096; }
+__global__ __launch_bounds__(256)
+void y5_filter_jobs_kernel(const y5_filter_job* __restrict__ jobs) {
+  const y5_filter_job j = jobs[blockIdx.y];
+  const long long base = (long long)blockIdx.x * MT_CH;
+  if (base >= j.total) return;
+  const long long end = base + MT_CH < j.total ? base + MT_CH : j.total;
+  for (long long i = base + threadIdx.x; i < end; i += 256) {
+    if (j.kind == 2) {  // packed fp32 dW -> (C2, C1, KH, KW)
+      const int kw = (int)(i % j.KW);
+      long long t = i / j.KW;
+      const int kh = (int)(t % j.KH);
+      t /= j.KH;
+      const int c = (int)(t % j.C1);
+      const long long n = t / j.C1;
+      static_cast<float*>(j.dst)[i] = static_cast<const float*>(j.src)[n * j.Kpad + (kh * j.KW + kw) * j.C1_view + c];
+      continue;
+    }
+    const float* w = static_cast<const float*>(j.src);
+    const int k = (int)(i % j.Kpad);
+    const int n = (int)(i / j.Kpad);
+    float v = 0.f;
+    if (j.kind == 0) {  // forward filter
+      const int K = j.KH * j.KW * j.C1_view;
+      if (n < j.C2 && k < K) {
+        const int c = k % j.C1_view, t = k / j.C1_view;
+        const int kh = t / j.KW, kw = t - kh * j.KW;
+        if (c < j.C1) v = w[((n * j.C1 + c) * j.KH + kh) * j.KW + kw];
+      }
+    } else {            // data-gradient sub-filter of one parity class
+      const int K = j.nth * j.ntw * j.C2_view;
+      if (n < j.C1 && k < K) {
+        const int c2 = k % j.C2_view, t = k / j.C2_view;
+        const int a = t / j.ntw, b = t - a * j.ntw;
+        if (c2 < j.C2) v = w[((c2 * j.C1 + n) * j.KH + j.th[a]) * j.KW + j.tw[b]];
+      }
+    }
+    static_cast<half_t*>(j.dst)[i] = (half_t)v;
+  }
+}
+
+extern "C" int y5_filter_jobs(const y5_filter_job* jobs_dev, int njobs, long long max_total, void* stream_) {
+  if (!jobs_dev || njobs < 1 || njobs > 65535 || max_total < 1) return y5_fail(Y5_ERR_BAD_ARG, "filter_jobs: bad args");
+  const long long chunks = (max_total + MT_CH - 1) / MT_CH;
+  if (chunks > 0x7fffffffLL) return y5_fail(Y5_ERR_UNSUPPORTED, "filter_jobs: filter too large");
+  hipLaunchKernelGGL(y5_filter_jobs_kernel, dim3((unsigned)chunks, (unsigned)njobs), dim3(256), 0, static_cast<hipStream_t>(stream_), jobs_dev);
+  return y5_check_launch("y5_filter_jobs");
+}
 extern "C" int y5_memset_zero(void* p, size_t bytes, void* stream_) {
   if (!p) return y5_fail(Y5_ERR_BAD_ARG, "memset_zero: null");
   if (hipMemsetAsync(p, 0, bytes, static_cast<hipStream_t>(stream_)) != hipSuccess) return y5_fail(Y5_ERR_RUNTIME, "memset_zero failed");

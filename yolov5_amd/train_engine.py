@@ -74,6 +74,7 @@ class TrainEngine:
         self.be.zero_(self.gflat)
         self.raw = {}
         self.convs = []
+        self._dw_total = 0
         self._keep = []
         self.grad_sink = None   # HipDDP (torch_utils.py): receives every parameter gradient as soon as it is queued
         max_z, max_ws = 0, 0
@@ -103,6 +104,7 @@ class TrainEngine:
             elif op["op"] == "decode":
                 self.raw[op["level"]] = self.be.empty((B, op["na"], op["ny"], op["nx"], op["no"]), f16)
         self.dz = self.be.empty((max(max_z, 8),), f16)
+        self.dwflat = self.be.empty((max(self._dw_total, 64),), torch.float32)  # packed fp32 dW accumulators of all convs
         self.ws = self.be.empty((max(max_ws, 256),), torch.uint8)
         self.ws_bytes = max(max_ws, 256)
 
@@ -151,7 +153,8 @@ class TrainEngine:
         st["wp"] = be.empty((st["Npad"], st["Kpad"]), torch.float16)
         st["bp"] = be.empty((st["Npad"],), torch.float32)
         be.zero_(st["bp"])
-        st["dw"] = be.empty((st["Npad"], st["Kpad"]), torch.float32)
+        st["dw_off"] = self._dw_total  # slot in the packed weight-gradient arena (one memset per backward pass)
+        self._dw_total += round_up(st["Npad"] * st["Kpad"], 64)
         st["c2s"] = c2 if st["has_bn"] else op["c2_store"]
         st["fcfg"] = -1
         subs = []
@@ -180,6 +183,7 @@ class TrainEngine:
         self._keep = []
         self._nbt = []
         x, xptr, src_dt = be.input(x)
+        self._run_jobs(0, stm)  # every forward filter: fp32 master weights -> packed fp16, one launch
         for op in self.spec.ops:
             kind = op["op"]
             if kind == "to_nhwc":
@@ -208,7 +212,6 @@ class TrainEngine:
         g = self._geom(st)
         c2, c1, kh, kw = cv.weight.shape
         Kpad, Npad = st["Kpad"], st["Npad"]
-        _lib.check(lib.y5_pack_conv_weight(_vp(self._f32(cv.weight)), c2, c1, kh, kw, st["c1v"], _vp(be.ptr(st["wp"])), Kpad, Npad, stm), lib)
         if not st["has_bn"] and cv.bias is not None:
             if isinstance(be, _HipBackend):
                 st["bp"][:c2].copy_(cv.bias.detach())
@@ -289,6 +292,8 @@ class TrainEngine:
         if sink is not None:
             sink.begin(self)
         params = self.params
+        _lib.check(lib.y5_memset_zero(_vp(be.ptr(self.dwflat)), self._dw_total * 4, stm), lib)  # every conv's dW accumulator at once
+        self._run_jobs(1, stm)  # every data-gradient sub-filter, one launch
 
         class _G(list):  # grads[i] = True: the gradient's kernels are queued -> tell the sink (bucketed all-reduce overlaps the rest)
             def __setitem__(s2, i, t):
@@ -298,6 +303,7 @@ class TrainEngine:
 
         grads = _G([None] * len(params))
         hold = []
+        self._unpack_later = []
         for op in reversed(self.spec.ops):
             kind = op["op"]
             if kind == "decode":
@@ -317,10 +323,51 @@ class TrainEngine:
                 pass
             else:
                 raise NotImplementedError(kind)
+        if self._unpack_later:
+            self._run_jobs(2, stm)  # packed fp32 dW of every conv -> parameter layout in the gradient arena, one launch
+            for i in self._unpack_later:
+                grads[i] = True
         if sink is not None:
             sink.finish(grads)
         flat = be.view_torch(self.gflat)  # (fresh view tensors: autograd's AccumulateGrad can adopt them without a copy)
         return [None if g is None else flat[self.goff[i]:self.goff[i] + p.numel()].view(p.shape) for i, (p, g) in enumerate(zip(params, grads))]
+
+    def _run_jobs(self, kind, stm):
+        """One y5_filter_jobs launch: kind 0 = pack every forward filter, 1 = pack every data-gradient sub-filter, 2 = unpack every
+        weight gradient.  The device-resident job table is rebuilt only when a pointer changed."""
+        import numpy as np
+
+        lib, be = self.lib, self.be
+        cache = self.__dict__.setdefault("_job_tables", {})
+        ent = cache.get(kind)
+        wkey = tuple(self._f32(st["cv"].weight) for st in self.convs)  # (all other pointers are engine-owned buffers)
+        if ent is None or ent[0] != wkey:
+            rows = []
+            for st, wptr in zip(self.convs, wkey):
+                cv = st["cv"]
+                c2, c1, kh, kw = cv.weight.shape
+                if kind == 0:
+                    rows.append((wptr, be.ptr(st["wp"]), st["Npad"] * st["Kpad"], 0, c2, c1, kh, kw, st["c1v"], 0, st["Kpad"], st["Npad"], 0, 0, (), ()))
+                elif kind == 2:
+                    rows.append((be.ptr(self.dwflat) + st["dw_off"] * 4, self._gptr(cv.weight), c2 * c1 * kh * kw, 2, c2, c1, kh, kw, st["c1v"], 0,
+                                 st["Kpad"], st["Npad"], 0, 0, (), ()))
+                else:
+                    for sub in st["subs"]:
+                        rows.append((wptr, be.ptr(sub["w"]), sub["Npad"] * sub["Kpad"], 1, c2, c1, kh, kw, 0, st["c2s"], sub["Kpad"], sub["Npad"],
+                                     sub["nth"], sub["ntw"], tuple(sub["th"]), tuple(sub["tw"])))
+            if not rows:
+                return
+            arr = (_lib.FilterJob * len(rows))()
+            for j, r in zip(arr, rows):
+                (j.src, j.dst, j.total, j.kind, j.C2, j.C1, j.KH, j.KW, j.C1_view, j.C2_view, j.Kpad, j.Npad, j.nth, j.ntw) = r[:14]
+                for q, v in enumerate(r[14]):
+                    j.th[q] = v
+                for q, v in enumerate(r[15]):
+                    j.tw[q] = v
+            tab = be.from_torch(torch.from_numpy(np.frombuffer(arr, dtype=np.uint8).copy()))
+            ent = (wkey, tab, len(rows), max(r[2] for r in rows))
+            cache[kind] = ent
+        _lib.check(lib.y5_filter_jobs(_vp(be.ptr(ent[1])), ent[2], ent[3], stm), lib)
 
     def _bwd_conv(self, st, stm, is_written, mark, grads, hold):
         lib, be, B = self.lib, self.be, self.spec.B
@@ -356,22 +403,22 @@ class TrainEngine:
         # weight gradient: packed fp32 accumulator -> parameter layout
         g = self._geom(st)
         Kpad, Npad = st["Kpad"], st["Npad"]
-        _lib.check(lib.y5_memset_zero(_vp(be.ptr(st["dw"])), Npad * Kpad * 4, stm), lib)
         d = _lib.ConvDesc(dtype=_lib.Y5_F16, B=B, H=g["H"], W=g["W"], C1=g["C1"], ldx=g["ldx"], OH=y.H, OW=y.W, C2=c2s, ldy=ld_dz,
                           KH=g["k"][0], KW=g["k"][1], SH=g["s"][0], SW=g["s"][1], PH=g["p"][0], PW=g["p"][1], act=0, Kpad=Kpad, Npad=Npad,
                           cfg=-1, max_blocks=0)
-        _lib.check(lib.y5_conv2d_wgrad(C.byref(d), _vp(self._ptr(x)), _vp(dz_ptr), ld_dz, _vp(be.ptr(st["dw"])), stm), lib)
-        _lib.check(lib.y5_unpack_conv_wgrad(_vp(be.ptr(st["dw"])), Kpad, _vp(self._gptr(cv.weight)), c2, c1, kh, kw, st["c1v"], stm), lib)
-        grads[self._pidx[id(cv.weight)]] = True
+        _lib.check(lib.y5_conv2d_wgrad(C.byref(d), _vp(self._ptr(x)), _vp(dz_ptr), ld_dz, _vp(be.ptr(self.dwflat) + st["dw_off"] * 4), stm), lib)
+        if self.grad_sink is not None:  # a gradient sink (HipDDP) wants every gradient as early as possible: unpack per layer
+            _lib.check(lib.y5_unpack_conv_wgrad(_vp(be.ptr(self.dwflat) + st["dw_off"] * 4), Kpad, _vp(self._gptr(cv.weight)), c2, c1, kh, kw,
+                                                st["c1v"], stm), lib)
+            grads[self._pidx[id(cv.weight)]] = True
+        else:
+            self._unpack_later.append(self._pidx[id(cv.weight)])
         # data gradient: one forward launch per parity class on the re-packed sub-filter
         if not st["subs"]:
             return
         acc = is_written(x)
-        wptr = self._f32(cv.weight)
         dense = tuple(op["s"]) == (1, 1)
         for sub in st["subs"]:
-            _lib.check(lib.y5_pack_dgrad_weight(_vp(wptr), c2, c1, kh, kw, sub["th"], sub["nth"], sub["tw"], sub["ntw"], c2s,
-                                                _vp(be.ptr(sub["w"])), sub["Kpad"], sub["Npad"], stm), lib)
             dd = _lib.ConvDesc(dtype=_lib.Y5_F16, B=B, H=y.H, W=y.W, C1=c2s, ldx=ld_dz, OH=sub["nh"], OW=sub["nw"], C2=x.C, ldy=self._ld(x),
                                KH=sub["nth"], KW=sub["ntw"], SH=1, SW=1, PH=sub["pad"][0], PW=sub["pad"][1], act=0, Kpad=sub["Kpad"],
                                Npad=sub["Npad"], ldr=self._ld(x) if acc else 0, ld2=0, cfg=sub["cfg"].get(acc, -1), max_blocks=0,
