@@ -102,7 +102,12 @@ class ComputeLoss:
         d = _lib.LossDesc()
         d.dtype = _lib.Y5_F16 if dt == torch.float16 else _lib.Y5_F32
         d.nl, d.na, d.nc, d.bs = self.nl, self.na, self.nc, int(p[0].shape[0])
-        anc = self.anchors.detach().float().cpu()
+        # host copy of the (static) anchors, refreshed only when the tensor was modified: a per-call .cpu() is a device->host
+        # copy on the compute stream, i.e. a full pipeline drain in the middle of every training step
+        ver = (self.anchors.data_ptr(), self.anchors._version)
+        if getattr(self, "_anc_host", None) is None or self._anc_host[0] != ver:
+            self._anc_host = (ver, self.anchors.detach().float().cpu())
+        anc = self._anc_host[1]
         for i, pi in enumerate(p):
             if pi.dtype != dt or not pi.is_cuda:
                 raise RuntimeError("ComputeLoss: every prediction level must be a GPU tensor of the same dtype (no CPU path)")
