@@ -295,6 +295,7 @@ def main():
     conv_by = sum(by[i] for i, _ in timed if i in by)
     achieved_bw = conv_by / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0  # GB/s
     nconv = sum(1 for i, _ in timed if i in fl)
+    images_per_plan = eng.spec.B
     if a.op_table and rank == 0:
         cfg_of = {}
         ci = iter(eng.conv_cfgs)
@@ -310,7 +311,7 @@ def main():
     train = None
     if not a.no_train:
         try:
-            del model, eng
+            del model, eng, eng_top
             torch.cuda.empty_cache()
             train = train_probe(a.model, a.batch, a.imgsz, dev, world)
         except Exception as e:  # the headline metric must not depend on the secondary probe
@@ -332,7 +333,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "y5_conv_{igemm,pw,k3,stem}_kernel (all conv launches of one forward)",
                          "achieved": round(achieved_bw, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_bw / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(a, conv_by * parts),
-                         "plans_per_step": parts, "images_per_plan": eng.spec.B,
+                         "plans_per_step": parts, "images_per_plan": images_per_plan,
                          "algorithmic_gbytes_per_step": round(conv_by * parts / 1e9, 3), "algorithmic_gflop_per_step": round(conv_fl * parts / 1e9, 1),
                          "arithmetic_intensity_flop_per_byte": round(conv_fl / conv_by, 1) if conv_by else None,
                          "mfma_achieved_tflops": round(achieved, 2), "mfma_peak_tflops": MFMA_PEAK_TFLOPS,

@@ -90,9 +90,10 @@ class BaseModel(nn.Module):
             from .engine import Engine, SplitEngine
 
             self._engines.clear()  # one live plan per model keeps HBM use bounded
-            parts = int(os.environ.get("Y5_SPLIT", "2"))
+            parts = int(os.environ.get("Y5_SPLIT", "1"))
             if x.is_cuda and parts > 1 and x.shape[0] >= 16 * parts and x.shape[0] % parts == 0:
-                # large batches: sub-batch plans on separate streams fill each other's kernel tails (engine.SplitEngine)
+                # opt-in (Y5_SPLIT=2): sub-batch plans on separate streams fill each other's kernel tails (engine.SplitEngine;
+                # +3 % images/s on yolov5s bs=64, but per-kernel figures then describe overlapped launches)
                 eng = SplitEngine(self, tuple(x.shape), next(self.parameters()).dtype, x.device, want_raw=want_raw, parts=parts)
             else:
                 eng = Engine(self, tuple(x.shape), next(self.parameters()).dtype, x.device, want_raw=want_raw)
