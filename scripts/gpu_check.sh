@@ -16,6 +16,9 @@ if [ "$WHAT" = "all" ] || [ "$WHAT" = "bench" ]; then
 fi
 if [ "$WHAT" = "all" ] || [ "$WHAT" = "prof" ]; then
   rm -rf gpurun_out/prof
+  # tile choices cached by a first plain run: the profiled run launches no autotune timing kernels
+  export Y5_TUNE_CACHE=/tmp/y5_tune_prof.json
+  timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train > /dev/null 2>&1
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o r -- python "$OLDPWD/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-train > "$OLDPWD/gpurun_out/prof.log" 2>&1); echo "prof rc=$?"
   find gpurun_out/prof -name "*stats*" | head; 
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -30 "$f"
