@@ -61,3 +61,59 @@ def test_yolov5n_train_forward_backward_vs_oracle_autograd():
         assert cos > 0.97 and rel < 0.25, (n, cos, rel)
     print(f"\n[train-emu] {len(names)} parameter gradients: worst cosine {worst_cos:.4f}, worst relative L2 error {worst_rel:.4f}")
     assert len(names) == len(list(m.parameters()))
+
+
+def test_filter_jobs_match_single_filter_entry_points():
+    """y5_filter_jobs (one launch over many filters) against y5_pack_conv_weight / y5_pack_dgrad_weight / y5_unpack_conv_wgrad."""
+    import ctypes as C
+
+    import numpy as np
+
+    from tests.hipemu.emu import aligned, emu
+    from yolov5_amd import _lib
+    from yolov5_amd.packing import round_up
+
+    lib = emu()
+    rng = np.random.default_rng(0)
+    shapes = [(40, 24, 3, 3, 24), (255, 64, 1, 1, 64), (16, 3, 6, 6, 4), (72, 48, 3, 3, 48)]
+    jobs, checks, keep = [], [], []
+    for c2, c1, kh, kw, c1v in shapes:
+        w = aligned((c2, c1, kh, kw), np.float32)
+        w[...] = rng.standard_normal(w.shape).astype(np.float32)
+        Kpad, Npad = round_up(kh * kw * c1v, 64), round_up(c2, 32)
+        # kind 0
+        ref = aligned((Npad, Kpad), np.float16, 7)
+        assert lib.y5_pack_conv_weight(C.c_void_p(w.ctypes.data), c2, c1, kh, kw, c1v, C.c_void_p(ref.ctypes.data), Kpad, Npad, None) == 0
+        out = aligned((Npad, Kpad), np.float16, 9)
+        jobs.append((w, out, Npad * Kpad, 0, c2, c1, kh, kw, c1v, 0, Kpad, Npad, 0, 0, (), ()))
+        checks.append((out, ref))
+        # kind 2 (unpack of a packed fp32 gradient)
+        dw = aligned((Npad, Kpad), np.float32)
+        dw[...] = rng.standard_normal(dw.shape).astype(np.float32)
+        gref = aligned((c2, c1, kh, kw), np.float32, 1)
+        assert lib.y5_unpack_conv_wgrad(C.c_void_p(dw.ctypes.data), Kpad, C.c_void_p(gref.ctypes.data), c2, c1, kh, kw, c1v, None) == 0
+        gout = aligned((c2, c1, kh, kw), np.float32, 2)
+        jobs.append((dw, gout, c2 * c1 * kh * kw, 2, c2, c1, kh, kw, c1v, 0, Kpad, Npad, 0, 0, (), ()))
+        checks.append((gout, gref))
+        # kind 1 (data-gradient sub-filter: taps (0, 2) x (1,) where they exist)
+        th, tw = ((0, 2), (1,)) if kh >= 3 else ((0,), (0,))
+        c2v = round_up(c2, 8)
+        Kp2, Np2 = round_up(len(th) * len(tw) * c2v, 64), round_up(c1, 32)
+        dref = aligned((Np2, Kp2), np.float16, 3)
+        assert lib.y5_pack_dgrad_weight(C.c_void_p(w.ctypes.data), c2, c1, kh, kw, (C.c_int * len(th))(*th), len(th), (C.c_int * len(tw))(*tw), len(tw),
+                                        c2v, C.c_void_p(dref.ctypes.data), Kp2, Np2, None) == 0
+        dout = aligned((Np2, Kp2), np.float16, 4)
+        jobs.append((w, dout, Np2 * Kp2, 1, c2, c1, kh, kw, 0, c2v, Kp2, Np2, len(th), len(tw), th, tw))
+        checks.append((dout, dref))
+        keep += [w, dw]
+    arr = (_lib.FilterJob * len(jobs))()
+    for j, r in zip(arr, jobs):
+        j.src, j.dst = r[0].ctypes.data, r[1].ctypes.data
+        (j.total, j.kind, j.C2, j.C1, j.KH, j.KW, j.C1_view, j.C2_view, j.Kpad, j.Npad, j.nth, j.ntw) = r[2:14]
+        for q, v in enumerate(r[14]):
+            j.th[q] = v
+        for q, v in enumerate(r[15]):
+            j.tw[q] = v
+    assert lib.y5_filter_jobs(C.byref(arr), len(jobs), max(r[2] for r in jobs), None) == 0, lib.y5_last_error()
+    for got, want in checks:
+        assert np.array_equal(got, want)
