@@ -218,6 +218,45 @@ def gen_scale_boxes(ns):
     np.savez_compressed(os.path.join(OUT, "scale_boxes.npz"), a=o, b=o2)
 
 
+def optim_grad(name, shape, step):
+    """Deterministic synthetic gradient of parameter `name` at optimizer step `step` (shared with tests/test_emu_optim.py)."""
+    return detgen.uniform(tuple(shape), -0.05, 0.05, name="g:" + name, seed=100 + step)
+
+
+def gen_optim(ns):
+    """utils/torch_utils.py:257-290 smart_optimizer + :343-369 ModelEMA of the REFERENCE on yolov5n, three steps of
+    (synthetic gradients -> GradScaler-style unscale -> clip_grad_norm_(10.0) -> optimizer.step() -> ema.update(model)),
+    train.py:413-421.  Stores strided samples + float64 checksums of every parameter / EMA tensor after step 3."""
+    torch.manual_seed(0)
+    m = ns.yolo.DetectionModel(os.path.join(ns.root, "models/yolov5n.yaml"))
+    load_det_weights(m, 0)
+    m.train()
+    opt = ns.torch_utils.smart_optimizer(m, "SGD", 0.01, 0.937, 5e-4)
+    ema = ns.torch_utils.ModelEMA(m, tau=4)   # short ramp so that three updates move the average visibly
+    out = {"group_sizes": np.array([len(g["params"]) for g in opt.param_groups]),
+           "group_decay": np.array([g["weight_decay"] for g in opt.param_groups]), "norms": []}
+    S = 512.0
+    for step in range(3):
+        for i, g in enumerate(opt.param_groups):
+            g["lr"] = 0.01 * (1.0 + 0.5 * i) / (1 + step)
+        for k, p in m.named_parameters():
+            p.grad = torch.from_numpy(optim_grad(k, p.shape, step)) * S
+        for p in m.parameters():                      # scaler.unscale_
+            p.grad.mul_(1.0 / S)
+        out["norms"].append(float(torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=10.0)))
+        opt.step()
+        ema.update(m)
+    out["norms"] = np.array(out["norms"])
+    esd = ema.ema.state_dict()
+    for k, p in m.state_dict().items():
+        if not p.dtype.is_floating_point:
+            continue
+        a, e = p.detach().numpy().ravel(), esd[k].detach().float().numpy().ravel()
+        out["p:" + k] = np.concatenate([a[::97], [a.astype(np.float64).sum()]]).astype(np.float64)
+        out["e:" + k] = np.concatenate([e[::97], [e.astype(np.float64).sum()]]).astype(np.float64)
+    np.savez_compressed(os.path.join(OUT, "optim.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = ref_shim.load()
@@ -230,6 +269,7 @@ def main():
     gen_loss(ns)
     gen_mask(ns)
     gen_scale_boxes(ns)
+    gen_optim(ns)
     sizes = {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT))}
     print(sizes, sum(sizes.values()))
 
