@@ -217,6 +217,8 @@ def main():
     ap.add_argument("--model", default="yolov5s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement")
+    ap.add_argument("--train", action="store_true", help="run the training-step probe also under torchrun (N > 1: adds the RCCL gradient "
+                    "all-reduce; by default the multi-GPU run measures the headline inference metric only, scripts/train_bench.py is the DDP entry)")
     ap.add_argument("--op-table", default="", help="write the per-op timing table (JSON) to this path")
     a = ap.parse_args()
 
@@ -309,7 +311,7 @@ def main():
             json.dump(table, f, indent=1)
 
     train = None
-    if not a.no_train:
+    if not a.no_train and (world == 1 or a.train):
         try:
             del model, eng, eng_top
             torch.cuda.empty_cache()
