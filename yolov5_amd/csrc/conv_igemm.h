@@ -155,7 +155,7 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
   const int lslot = lane % NSLOT;  // destination 16-byte slot
   int a_base[ACT_PER_WAVE];        // BYTE offset of (b, ih0, iw0) + source slot (may be negative for padded origins)
   int a_ih0[ACT_PER_WAVE], a_iw0[ACT_PER_WAVE], a_slot[ACT_PER_WAVE];  // TABLE mode
-  unsigned a_mask[ACT_PER_WAVE];   // UNIFORM mode: bit (kh*KW + kw) set <=> that tap of this row lies inside the image
+  unsigned a_mask[ACT_PER_WAVE];   // UNIFORM mode: bit (kh*KW + kw) CLEAR <=> that tap of this row lies inside the image
   unsigned w_off[WGT_PER_WAVE];    // byte offset of the filter row + source slot, Y5_OOB for rows beyond the tile / Npad
   int u_kh = 0, u_kw = 0, u_c0 = 0;  // uniform tap walker (UNIFORM mode: C1 % BK == 0)
   int s_t = 0, s_kc = 0;             // staged tile (index into this block's tile list) / K chunk
@@ -194,7 +194,7 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
             for (int kw = 0; kw < p.KW; ++kw, bit <<= 1)
               if ((unsigned)(ih0 + kh) < (unsigned)p.H && (unsigned)(iw0 + kw) < (unsigned)p.W) mk |= bit;
         }
-        a_mask[i] = mk;
+        a_mask[i] = ~mk;  // stored inverted: bit set <=> tap outside the image
       }
     }
 #pragma unroll
@@ -202,7 +202,9 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
       const int row = (wave + i * NW) * RPI + lrow;  // row inside the filter tile
       const int sslot = lslot ^ Gm::swz(row);
       const int n = n0 + row;
-      w_off[i] = (row < BN) && (n < p.Npad) ? (unsigned)((n * p.Kpad + sslot * EPP) * ES) : Y5_OOB;
+      // invalid rows carry bit 31: every offset >= 2^31 is past the buffer's range (tensors are < 2^31 bytes) and reads as zero, so
+      // the per-chunk K offset can be added without a test
+      w_off[i] = (row < BN) && (n < p.Npad) ? (unsigned)((n * p.Kpad + sslot * EPP) * ES) : 0x80000000u;
     }
     u_kh = 0; u_kw = 0; u_c0 = 0;
   };
@@ -233,14 +235,15 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
         const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
         voff = ok ? (unsigned)(a_base[i] + (e.x - a_slot[i] * EPP) * ES) : Y5_OOB;
       } else {
-        voff = (a_mask[i] >> st_tap_bit) & 1u ? (unsigned)(a_base[i] + st_tap_off) : Y5_OOB;
+        // outside-the-image taps get bit 31 (= out of range = zero fill): shift, shift-or, add -- no compare / select
+        voff = (unsigned)(a_base[i] + st_tap_off) | ((a_mask[i] >> st_tap_bit) << 31);
       }
       y5_bglds16(xrs, voff, st_lds + (wave + i * NW) * 1024);
     } else {
       constexpr int i = q - ACT_PER_WAVE;
       const int idx = wave + i * NW;
-      if (idx < WGT_INSTR) {
-        y5_bglds16(wrs, w_off[i] == Y5_OOB ? Y5_OOB : w_off[i] + st_kcb, st_lds + BM * RB + idx * 1024);
+      if (WGT_INSTR % NW == 0 || idx < WGT_INSTR) {
+        y5_bglds16(wrs, w_off[i] + st_kcb, st_lds + BM * RB + idx * 1024);
       } else if (NS > 2) {
         y5_bglds16(wrs, Y5_OOB, dummy);  // keeps the per-chunk LDS-DMA count identical in every wave (counted vmcnt)
       }
@@ -296,15 +299,18 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
       for (int j = 0; j < TN; ++j) {
         const int nt = n0 + wn * TN * 32 + j * 32;
         // (1) registers -> scratch[pixel row = lane&31][channel]
+        // bias through the SCALAR cache (nt is wave-uniform; eight consecutive values per s_load, the lane picks its half): a
+        // vector load here would sit behind the next tile's in-flight LDS-DMA in the in-order vmcnt queue and stall the epilogue
+        // for a full memory round trip
+        const float* pb = p.bias + (nt < p.Npad ? nt : 0);
+        const float keep = nt < p.Npad ? 1.0f : 0.0f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int nl = q * 8 + g * 4;
-          float4_t bv = {0.f, 0.f, 0.f, 0.f};
-          if (nt + nl < p.Npad) bv = *reinterpret_cast<const float4_t*>(p.bias + nt + nl);
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float t = acc[i][j][q * 4 + e] + bv[e];
+            const float t = acc[i][j][q * 4 + e] + (g ? pb[q * 8 + 4 + e] : pb[q * 8 + e]) * keep;
             v[e] = p.act ? y5_silu(t) : t;
           }
           char* dst = scratch + frow * SCR_ROWB + nl * (int)sizeof(T);
