@@ -415,7 +415,7 @@ class Engine:
     """A materialised PlanSpec on one GPU.  `engine(x)` -> dict of output tensors (engine-owned buffers, valid
     until the next call).  Raises RuntimeError without a GPU / without libyolov5_hip.so."""
 
-    def __init__(self, model, x_shape, dtype: torch.dtype, device, want_raw=False, backend=None, spec=None, outputs=None):
+    def __init__(self, model, x_shape, dtype: torch.dtype, device, want_raw=False, backend=None, spec=None, outputs=None, raw_views=None):
         if dtype not in (torch.float16, torch.float32):
             raise TypeError(f"Engine dtype must be float16 or float32, got {dtype}")
         self.be = backend if backend is not None else _HipBackend(device)
@@ -432,8 +432,16 @@ class Engine:
             self.anchors = det.anchors.detach().float().cpu()
         self._keep = []  # device tensors referenced by raw pointers inside the C plan
         self.bufs = [self.be.empty((B, b.H, b.W, b.C), dtype) for b in self.spec.bufs]
+        # The raw (bs, na, ny, nx, no) head tensors of eval mode (models/yolo.py:96-98) are the Detect convs' NHWC outputs seen
+        # through another index order: on the GPU they are returned as strided VIEWS of those plan buffers instead of being
+        # written a second time by the decode kernel (274 MB per 64 images at 640^2).  Same shape and values; not contiguous;
+        # valid until the next forward like every other output.
+        self.raw_views = (isinstance(self.be, _HipBackend) and outputs is None and os.environ.get("Y5_RAW_VIEW", "1") != "0") \
+            if raw_views is None else raw_views
         self.outputs = {}
         for name, o in self.spec.outputs.items():
+            if self.raw_views and name.startswith("raw"):
+                continue  # filled in by the decode op below
             if outputs is not None:  # caller-owned output buffers (SplitEngine: batch slices of one tensor)
                 t = outputs[name]
                 if tuple(t.shape) != tuple(o["shape"]) or t.dtype != dtype or not t.is_contiguous():
@@ -501,7 +509,12 @@ class Engine:
             x, i = op["x"], op["level"]
             apx = (self.anchors[i] * self.stride_t[i]).reshape(-1).tolist()
             arr = (C.c_float * len(apx))(*apx)
-            raw = self.outputs[op["raw"]] if op["raw"] else None
+            raw = None
+            if op["raw"] and self.raw_views:
+                t = self.be.view_torch(self.bufs[x.buf])  # (B, ny, nx, ld) logits, channel a*no + o
+                self.outputs[op["raw"]] = t[..., x.c_off:x.c_off + op["na"] * op["no"]].unflatten(-1, (op["na"], op["no"])).permute(0, 3, 1, 2, 4)
+            elif op["raw"]:
+                raw = self.outputs[op["raw"]]
             rc = lib.y5_plan_add_detect_decode(self.plan, self._ptr(x), self.dt, B, op["ny"], op["nx"], op["na"], op["no"], op["nm"],
                                                self._ld(x), self.stride_t[i], arr, C.c_void_p(self.be.ptr(self.outputs["z"])), self.dt,
                                                op["nrows"], op["row_off"], C.c_void_p(self.be.ptr(raw)) if raw is not None else None)
@@ -635,7 +648,8 @@ class SplitEngine:
         self.engines = []
         for i in range(parts):
             views = {name: t[i * self.sub_b:(i + 1) * self.sub_b] for name, t in self.outputs.items()}
-            self.engines.append(Engine(model, sub_shape, dtype, device, want_raw=want_raw, spec=spec if i == 0 else None, outputs=views))
+            self.engines.append(Engine(model, sub_shape, dtype, device, want_raw=want_raw, spec=spec if i == 0 else None, outputs=views,
+                                       raw_views=False))
         self.device = device
         # HIP multiplexes streams onto a few hardware queues and two streams on one queue run one after the other (measured:
         # 2.92 ms vs 3.55 ms for the same two plans depending on the pair the stream pool hands out, 3.27 ms once eight
