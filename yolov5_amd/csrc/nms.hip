@@ -69,8 +69,22 @@ extern "C" int y5_nms_batched(const void* pred, int dt, int bs, int n, int no, i
     attr = true;
   }
   const size_t greedy_lds = (size_t)max_det * 20 + 2 * Y5_NMS_REC * 64 * 4 + 64 * 8 + Y5_NMS_GREEDY_WAVES * 8 + 16;
-  if (dt == Y5_F16) hipLaunchKernelGGL((y5_nms_filter_kernel<half_t>), fg, fb, 0, st, p);
-  else hipLaunchKernelGGL((y5_nms_filter_kernel<float>), fg, fb, 0, st, p);
+  {
+    // rows per workgroup of the LDS-staged filter: as many as fit 64 KiB (multiple of 64); unstaged fallback for very wide rows
+    const int es = dt == Y5_F16 ? 2 : 4;
+    int rows = (int)(65536 / ((long long)no * es)) / 64 * 64;
+    if (rows > 256) rows = 256;
+    if (rows >= 64) {
+      const dim3 sg((unsigned)((n + rows - 1) / rows), (unsigned)bs);
+      const size_t lds = (size_t)rows * no * es;
+      if (dt == Y5_F16) hipLaunchKernelGGL((y5_nms_filter_kernel<half_t, true>), sg, dim3(rows), lds, st, p);
+      else hipLaunchKernelGGL((y5_nms_filter_kernel<float, true>), sg, dim3(rows), lds, st, p);
+    } else if (dt == Y5_F16) {
+      hipLaunchKernelGGL((y5_nms_filter_kernel<half_t, false>), fg, fb, 0, st, p);
+    } else {
+      hipLaunchKernelGGL((y5_nms_filter_kernel<float, false>), fg, fb, 0, st, p);
+    }
+  }
   hipLaunchKernelGGL(y5_nms_sort_kernel, dim3((unsigned)bs), dim3(1024), Y5_NMS_SORT_LDS_KEYS * 8, st, p);
   {
     const dim3 gg((unsigned)((L.gcap + 255) / 256), (unsigned)bs);

@@ -36,12 +36,37 @@ struct Y5NmsParams {
 template <typename T> __device__ __forceinline__ float y5_ldf(const T* p, long long i) { return (float)p[i]; }
 
 // ---- K1: filter + compaction -----------------------------------------------------------------------
-template <typename T>
+// STAGED: the workgroup's blockDim.x consecutive prediction rows (one contiguous block of memory) are first copied into LDS
+// with full-width coalesced loads -- a thread reading "its" 170-byte row straight from HBM touches every 64-byte sector of
+// the tensor at a few bytes per request; the candidate logic below is identical in both variants.
+template <typename T, bool STAGED>
 __global__ void y5_nms_filter_kernel(const Y5NmsParams p) {
   const int b = blockIdx.y;
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= p.n) return;
-  const T* row = static_cast<const T*>(p.pred) + ((long long)b * p.n + r) * p.no;
+  const T* row;
+  if constexpr (STAGED) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* tile = reinterpret_cast<T*>(smem);
+    const long long r0 = (long long)blockIdx.x * blockDim.x;
+    const long long rows = p.n - r0 < (long long)blockDim.x ? p.n - r0 : (long long)blockDim.x;
+    const T* src = static_cast<const T*>(p.pred) + ((long long)b * p.n + r0) * p.no;
+    const int total = (int)(rows * p.no);
+    constexpr int V = 16 / (int)sizeof(T);
+    int done = 0;
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+      const int nv = total / V;
+      for (int i = threadIdx.x; i < nv; i += blockDim.x)
+        reinterpret_cast<uint4_t*>(tile)[i] = reinterpret_cast<const uint4_t*>(src)[i];
+      done = nv * V;
+    }
+    for (int i = done + threadIdx.x; i < total; i += blockDim.x) tile[i] = src[i];
+    __syncthreads();
+    if (r >= p.n) return;
+    row = tile + (long long)threadIdx.x * p.no;
+  } else {
+    if (r >= p.n) return;
+    row = static_cast<const T*>(p.pred) + ((long long)b * p.n + r) * p.no;
+  }
   const float obj = (float)row[4];
   if (!(obj > p.conf_thres)) return;
   unsigned long long* keys = p.keys + (long long)b * p.cap_pad;
