@@ -87,11 +87,11 @@ def test_detect_decode_emulated():
     assert np.all(z[:, :11] == -1.0)
 
 
-@pytest.mark.parametrize("dt", ["f16", "f32"])
-def test_sppf_pool_emulated(dt):
+@pytest.mark.parametrize("dt,Cc", [("f16", 16), ("f32", 16), ("f16", 128), ("f32", 64)])   # 128 x f16 / 64 x f32: 128-byte channel groups
+def test_sppf_pool_emulated(dt, Cc):
     lib = emu()
     npdt = np.float16 if dt == "f16" else np.float32
-    B, H, W, Cc = 2, 6, 5, 16
+    B, H, W = 2, 6, 5
     x = detgen.uniform((B, Cc, H, W), -2, 2, name="pool").astype(npdt)
     buf = aligned((B, H, W, 4 * Cc), npdt, 0.0)
     buf[..., :Cc] = x.transpose(0, 2, 3, 1)
@@ -101,6 +101,27 @@ def test_sppf_pool_emulated(dt):
     for i in range(1, 4):
         t = torch.nn.functional.max_pool2d(t, 5, 1, 2)
         assert np.array_equal(buf[..., i * Cc:(i + 1) * Cc].astype(np.float32), t.permute(0, 2, 3, 1).numpy())
+
+
+@pytest.mark.parametrize("Cc", [8, 32, 64])   # 32 / 64: four 16-byte groups per workgroup
+def test_sppf_pool_bwd_emulated(Cc):
+    """y5_sppf_pool_bwd against torch autograd through three chained max_pool2d(5, 1, 2) (models/common.py:338-340)."""
+    lib = emu()
+    B, H, W = 2, 7, 6
+    x = torch.from_numpy(detgen.uniform((B, Cc, H, W), -2, 2, name="pbx")).half().float().requires_grad_(True)
+    y1 = torch.nn.functional.max_pool2d(x, 5, 1, 2)
+    y2 = torch.nn.functional.max_pool2d(y1, 5, 1, 2)
+    y3 = torch.nn.functional.max_pool2d(y2, 5, 1, 2)
+    gs = [torch.from_numpy(detgen.uniform((B, Cc, H, W), -1, 1, name=f"pbg{i}")).half().float() for i in range(4)]
+    (x * gs[0] + y1 * gs[1] + y2 * gs[2] + y3 * gs[3]).sum().backward()
+    act = aligned((B, H, W, 4 * Cc), np.float16, 0.0)
+    grad = aligned((B, H, W, 4 * Cc), np.float16, 0.0)
+    for i, t in enumerate((x, y1, y2, y3)):
+        act[..., i * Cc:(i + 1) * Cc] = t.detach().permute(0, 2, 3, 1).numpy()
+        grad[..., i * Cc:(i + 1) * Cc] = gs[i].permute(0, 2, 3, 1).numpy()
+    rc = lib.y5_sppf_pool_bwd(ptr(act), ptr(grad), B, H, W, Cc, 4 * Cc, 4 * Cc, 5, None)
+    assert rc == 0, lib.y5_last_error()
+    np.testing.assert_allclose(grad[..., :Cc].astype(np.float32), x.grad.permute(0, 2, 3, 1).numpy(), rtol=2e-3, atol=2e-3)
 
 
 def test_layout_and_copy_kernels_emulated():

@@ -1,6 +1,8 @@
 // C-ABI launchers for the HBM-bound glue kernels (misc_kernels.h).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../../include/yolov5_hip.h"
 #include "misc_kernels.h"
 #include "y5_host.h"
@@ -43,18 +45,36 @@ extern "C" int y5_sppf_pool(void* buf, int dt, int B, int H, int W, int C, int l
   hipStream_t st = static_cast<hipStream_t>(stream_);
   const int es = esize(dt);
   if (!buf || es < 2 || (C * es) % 16 || (ld * es) % 16 || ld < 4 * C || !(k & 1)) return y5_fail(Y5_ERR_BAD_ARG, "sppf_pool: bad args");
-  const size_t lds = (size_t)H * W * 16 * 2;
+  // channel-group width: measured at the yolov5s shape (20x20, 256 of 1024 channels, bs 64): 16 B 52 us, 32 B 49.5, 64 B 49.9,
+  // 128 B 76 (one workgroup per CU) -- the kernel is bound by its LDS window loops, not by the strided rows.  Y5_SPPF_GV overrides.
+  int gv = 2;
+  if (const char* e = getenv("Y5_SPPF_GV")) gv = atoi(e);
+  if (gv != 1 && gv != 2 && gv != 4 && gv != 8) gv = 2;
+  while (gv > 1 && ((C * es) % (16 * gv) != 0 || (size_t)H * W * 16 * gv * 2 > 150 * 1024)) gv >>= 1;
+  const size_t lds = (size_t)H * W * 16 * gv * 2;
   if (lds > 150 * 1024) return y5_fail(Y5_ERR_UNSUPPORTED, "sppf_pool: H*W plane does not fit in LDS");
-  const dim3 g((unsigned)(B * (C * es / 16))), b(256);
-  if (dt == Y5_F16) {
-    static bool a = false;
-    if (!a) { hipFuncSetAttribute((const void*)y5_sppf_pool_kernel<half8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); a = true; }
-    hipLaunchKernelGGL((y5_sppf_pool_kernel<half8_t>), g, b, lds, st, (char*)buf, H, W, C * es, ld * es, k);
-  } else {
-    static bool a = false;
-    if (!a) { hipFuncSetAttribute((const void*)y5_sppf_pool_kernel<float4_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); a = true; }
-    hipLaunchKernelGGL((y5_sppf_pool_kernel<float4_t>), g, b, lds, st, (char*)buf, H, W, C * es, ld * es, k);
+  const dim3 g((unsigned)(B * (C * es / (16 * gv)))), b(256);
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)y5_sppf_pool_kernel<half8_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute((const void*)y5_sppf_pool_kernel<half8_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute((const void*)y5_sppf_pool_kernel<half8_t, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute((const void*)y5_sppf_pool_kernel<half8_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute((const void*)y5_sppf_pool_kernel<float4_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute((const void*)y5_sppf_pool_kernel<float4_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute((const void*)y5_sppf_pool_kernel<float4_t, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute((const void*)y5_sppf_pool_kernel<float4_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr = true;
   }
+#define Y5_SPPF_LAUNCH(V, G) hipLaunchKernelGGL((y5_sppf_pool_kernel<V, G>), g, b, lds, st, (char*)buf, H, W, C * es, ld * es, k)
+  if (dt == Y5_F16) {
+    switch (gv) { case 8: Y5_SPPF_LAUNCH(half8_t, 8); break; case 4: Y5_SPPF_LAUNCH(half8_t, 4); break; case 2: Y5_SPPF_LAUNCH(half8_t, 2); break;
+                  default: Y5_SPPF_LAUNCH(half8_t, 1); }
+  } else {
+    switch (gv) { case 8: Y5_SPPF_LAUNCH(float4_t, 8); break; case 4: Y5_SPPF_LAUNCH(float4_t, 4); break; case 2: Y5_SPPF_LAUNCH(float4_t, 2); break;
+                  default: Y5_SPPF_LAUNCH(float4_t, 1); }
+  }
+#undef Y5_SPPF_LAUNCH
   return y5_check_launch("y5_sppf_pool");
 }
 

@@ -92,58 +92,73 @@ __global__ void y5_add_slice_kernel(const char* __restrict__ src, char* __restri
 // the consumer's data-gradient; on return grad[..., 0:C] holds the total gradient w.r.t. x (slices 1..3 are consumed).
 // One workgroup per (image, 8-channel group); fp32 accumulators in LDS; argmax = first maximum in (kh, kw) scan order
 // (torch's max_pool2d_with_indices tie rule).
+// GV = 16-byte channel groups (8 channels each) a workgroup owns: 4 = 64 contiguous bytes per pixel (half a cache line per access
+// instead of 16 bytes out of every 2 KiB row), 1 when the H*W planes of four groups do not fit LDS.
+template <int GV>
 __global__ __launch_bounds__(256)
 void y5_sppf_pool_bwd_kernel(const char* __restrict__ act, char* __restrict__ grad, int H, int W, int C_bytes, int lda_b, int ldg_b, int k) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int HW = H * W;
-  half8_t* a_in = reinterpret_cast<half8_t*>(smem);                 // [HW] activation of the pool input
-  float* g_out = reinterpret_cast<float*>(a_in + HW);               // [HW][8] gradient of the pool output
-  float* g_in = g_out + (size_t)HW * 8;                             // [HW][8] gradient accumulated for the pool input
-  const int groups = C_bytes / 16;
+  const int n = HW * GV;                                               // vector index v = pixel * GV + group-in-workgroup
+  half8_t* a_in = reinterpret_cast<half8_t*>(smem);                 // [n] activation of the pool input
+  float* g_out = reinterpret_cast<float*>(a_in + n);                // [n][8] gradient of the pool output
+  float* g_in = g_out + (size_t)n * 8;                              // [n][8] gradient accumulated for the pool input
+  const int groups = C_bytes / (16 * GV);
   const int b = blockIdx.x / groups, cg = blockIdx.x - b * groups;
-  const char* abase = act + (size_t)b * HW * lda_b + (size_t)cg * 16;
-  char* gbase = grad + (size_t)b * HW * ldg_b + (size_t)cg * 16;
+  const char* abase = act + (size_t)b * HW * lda_b + (size_t)cg * 16 * GV;
+  char* gbase = grad + (size_t)b * HW * ldg_b + (size_t)cg * 16 * GV;
   const int r = k / 2;
   // g_out <- d/dy3
-  for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-    const half8_t q = *reinterpret_cast<const half8_t*>(gbase + (size_t)i * ldg_b + 3 * (size_t)C_bytes);
+  for (int v = threadIdx.x; v < n; v += blockDim.x) {
+    const half8_t q = *reinterpret_cast<const half8_t*>(gbase + (size_t)(v / GV) * ldg_b + 3 * (size_t)C_bytes + (v % GV) * 16);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) g_out[i * 8 + e] = (float)q[e];
+    for (int e = 0; e < 8; ++e) g_out[v * 8 + e] = (float)q[e];
   }
   for (int pass = 3; pass >= 1; --pass) {  // pool `pass`: input slice pass-1 -> output slice pass
-    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-      a_in[i] = *reinterpret_cast<const half8_t*>(abase + (size_t)i * lda_b + (size_t)(pass - 1) * C_bytes);
-      const half8_t q = *reinterpret_cast<const half8_t*>(gbase + (size_t)i * ldg_b + (size_t)(pass - 1) * C_bytes);
+    for (int v = threadIdx.x; v < n; v += blockDim.x) {
+      const size_t po = (size_t)(pass - 1) * C_bytes + (v % GV) * 16;
+      a_in[v] = *reinterpret_cast<const half8_t*>(abase + (size_t)(v / GV) * lda_b + po);
+      const half8_t q = *reinterpret_cast<const half8_t*>(gbase + (size_t)(v / GV) * ldg_b + po);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) g_in[i * 8 + e] = (float)q[e];  // direct gradient of that slice (from cv2's data-gradient)
+      for (int e = 0; e < 8; ++e) g_in[v * 8 + e] = (float)q[e];  // direct gradient of that slice (from cv2's data-gradient)
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+    for (int v = threadIdx.x; v < n; v += blockDim.x) {
+      const int i = v / GV, gl = v % GV;
       const int y = i / W, x = i - y * W;
       const int y0 = y - r < 0 ? 0 : y - r, y1 = y + r >= H ? H - 1 : y + r;
       const int x0 = x - r < 0 ? 0 : x - r, x1 = x + r >= W ? W - 1 : x + r;
+      // one LDS read per window position, eight running (maximum, position) pairs; strict > keeps the FIRST maximum in scan order
+      float best[8];
+      int bi[8];
+      {
+        const half8_t q = a_in[(y0 * W + x0) * GV + gl];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float best = (float)a_in[y0 * W + x0][e];
-        int bi = y0 * W + x0;
-        for (int yy = y0; yy <= y1; ++yy)
-          for (int xx = x0; xx <= x1; ++xx) {
-            const float v = (float)a_in[yy * W + xx][e];
-            if (v > best) { best = v; bi = yy * W + xx; }
-          }
-        atomicAdd(&g_in[bi * 8 + e], g_out[i * 8 + e]);
+        for (int e = 0; e < 8; ++e) { best[e] = (float)q[e]; bi[e] = y0 * W + x0; }
       }
+      for (int yy = y0; yy <= y1; ++yy)
+        for (int xx = x0; xx <= x1; ++xx) {
+          const int pos = yy * W + xx;
+          const half8_t q = a_in[pos * GV + gl];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float t = (float)q[e];
+            if (t > best[e]) { best[e] = t; bi[e] = pos; }
+          }
+        }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) atomicAdd(&g_in[(bi[e] * GV + gl) * 8 + e], g_out[v * 8 + e]);
     }
     __syncthreads();
     // the accumulated input gradient is the next pass's output gradient
-    for (int i = threadIdx.x; i < HW * 8; i += blockDim.x) g_out[i] = g_in[i];
+    for (int q = threadIdx.x; q < n * 8; q += blockDim.x) g_out[q] = g_in[q];
     __syncthreads();
   }
-  for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+  for (int v = threadIdx.x; v < n; v += blockDim.x) {
     half8_t o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (half_t)g_out[i * 8 + e];
-    *reinterpret_cast<half8_t*>(gbase + (size_t)i * ldg_b) = o;
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)g_out[v * 8 + e];
+    *reinterpret_cast<half8_t*>(gbase + (size_t)(v / GV) * ldg_b + (v % GV) * 16) = o;
   }
 }
 
@@ -187,12 +202,20 @@ extern "C" int y5_add_slice(const void* src, void* dst, long long npix, int C, i
 }
 extern "C" int y5_sppf_pool_bwd(const void* act, void* grad, int B, int H, int W, int C, int ld_act, int ld_grad, int k, void* stream_) {
   if (!act || !grad || C % 8 || ld_act % 8 || ld_grad % 8 || ld_act < 4 * C || ld_grad < 4 * C || !(k & 1)) return y5_fail(Y5_ERR_BAD_ARG, "sppf_pool_bwd: bad args");
-  const size_t lds = (size_t)H * W * (16 + 32 + 32);
+  const int gv = (C % 32 == 0 && (size_t)H * W * 4 * (16 + 32 + 32) <= 150 * 1024) ? 4 : 1;
+  const size_t lds = (size_t)H * W * gv * (16 + 32 + 32);
   if (lds > 150 * 1024) return y5_fail(Y5_ERR_UNSUPPORTED, "sppf_pool_bwd: H*W plane does not fit in LDS");
   static bool a = false;
-  if (!a) { hipFuncSetAttribute((const void*)y5_sppf_pool_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); a = true; }
-  hipLaunchKernelGGL(y5_sppf_pool_bwd_kernel, dim3((unsigned)(B * (C / 8))), dim3(256), lds, static_cast<hipStream_t>(stream_), (const char*)act,
-                     (char*)grad, H, W, C * 2, ld_act * 2, ld_grad * 2, k);
+  if (!a) {
+    hipFuncSetAttribute((const void*)y5_sppf_pool_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute((const void*)y5_sppf_pool_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    a = true;
+  }
+  const dim3 g((unsigned)(B * (C / (8 * gv))));
+  if (gv == 4) hipLaunchKernelGGL(y5_sppf_pool_bwd_kernel<4>, g, dim3(256), lds, static_cast<hipStream_t>(stream_), (const char*)act, (char*)grad, H, W,
+                                  C * 2, ld_act * 2, ld_grad * 2, k);
+  else hipLaunchKernelGGL(y5_sppf_pool_bwd_kernel<1>, g, dim3(256), lds, static_cast<hipStream_t>(stream_), (const char*)act, (char*)grad, H, W, C * 2,
+                          ld_act * 2, ld_grad * 2, k);
   return y5_check_launch("y5_sppf_pool_bwd");
 }
 
