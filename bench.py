@@ -204,7 +204,7 @@ def train_probe(name, batch, imgsz, dev, world, steps=6, warmup=2):
     torch.cuda.empty_cache()
     return {"images_per_sec": round(batch * world * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps,
             "workload": f"{name} train step, {batch} img/GPU 3x{imgsz}x{imgsz}, {nt} targets: forward(train BN) + ComputeLoss + backward"
-                        f"{' + RCCL all-reduce' if world > 1 else ''} + SGD; fp16 compute / fp32 masters", "loss": round(float(loss), 4)}
+                        f"{' + RCCL all-reduce' if world > 1 else ''} + SGD; fp16 compute / fp32 masters", "loss": round(float(loss.detach()), 4)}
 
 
 def main():

@@ -70,7 +70,7 @@ def main():
     dt = time.perf_counter() - t0
     if rank == 0:
         print(json.dumps({"metric": "training images/sec (yolov5s, 64 img/GPU, 640px, fp16 AMP-style)", "value": round(a.batch * world * a.steps / dt, 1),
-                          "unit": "images/sec", "n_gpus": world, "ms_per_step": round(dt / a.steps * 1e3, 2), "loss": round(float(loss), 4)}))
+                          "unit": "images/sec", "n_gpus": world, "ms_per_step": round(dt / a.steps * 1e3, 2), "loss": round(float(loss.detach()), 4)}))
     if world > 1:
         dist.destroy_process_group()
 

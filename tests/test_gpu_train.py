@@ -142,7 +142,7 @@ def test_train_step_yolov5s_bs64_timing(dev):
             lo = eng.gflat.data_ptr()
             assert all(lo <= p.grad.data_ptr() < lo + eng.gtotal * 4 for p in m.parameters())
         stats = opt.step_fused(inv_scale=1.0 / 1024.0, max_norm=10.0, ema=ema, model=m)
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
         assert float(stats[2]) == 0.0
     torch.cuda.synchronize()
     ms = (time.time() - t0) / 3 * 1e3
