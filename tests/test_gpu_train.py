@@ -80,7 +80,7 @@ def test_train_step_matches_oracle_autograd(dev):
 
     sdo, leaves, ref, rloss, ritems = _oracle_grads(cfg, sd, x, t, 0)
     for a, b in zip(pred, ref):
-        d = (a.float().cpu() - b.detach()).abs()
+        d = (a.detach().float().cpu() - b.detach()).abs()
         assert float(d.max()) < 4e-2 * float(b.detach().abs().max()) and float(d.mean()) < 4e-3 * float(b.detach().abs().max())
     np.testing.assert_allclose(loss.item(), rloss.item(), rtol=2e-2)
     np.testing.assert_allclose(items.cpu().numpy(), ritems.numpy(), rtol=3e-2)
