@@ -47,7 +47,7 @@ CONV_CASES = [
     (2, 20, 20, 128, 128, 3, 1, 1, 1, False, False, -1, 0, "f32"),
     (4, 40, 40, 64, 64, 1, 1, 0, 1, False, False, 7, 5, "f16"),     # persistent: 50 one-chunk tiles on 5 workgroups
     (3, 33, 31, 32, 96, 3, 1, 1, 1, True, True, 0, 8, "f16"),
-] + [(2, 21, 19, c1, 160, 3, 1, 1, 1, True, False, cfg, 3, "f16") for cfg in list(range(14)) + list(range(22, 30)) + list(range(35, 54)) for c1 in (64, 48)] + [
+] + [(2, 21, 19, c1, 160, 3, 1, 1, 1, True, False, cfg, 3, "f16") for cfg in list(range(14)) + list(range(22, 30)) + list(range(35, 56)) for c1 in (64, 48)] + [
     # streaming pointwise kernel (conv_pw.h, cfg 14..21): many tiles per wave so the counted-vmcnt ring reaches steady
     # state and drains; LDS-DMA races would show up here as wrong tiles (run on the real machine, not the emulator)
     (16, 40, 40, 32, 32, 1, 1, 0, 1, False, False, 14, 8, "f16"),

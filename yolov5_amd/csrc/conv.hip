@@ -19,7 +19,7 @@ constexpr int kRingBase[kNumRing] = {1, 2, 3, 5, 7, 8, 11, 12};
 // flight per CU, so these trade occupancy for bytes per flop: 256-row tiles, BK32 chunks, deeper rings, 8 waves where the
 // tile is 256 wide.  (wm, wn, tm, tn, rb, stages)
 struct BigCfg { int wm, wn, tm, tn, rb, ns; };
-constexpr int kBig0 = 35, kNumBig = 19;
+constexpr int kBig0 = 35, kNumBig = 21;
 constexpr BigCfg kBigCfgs[kNumBig] = {
     {2, 2, 4, 2, 64, 4},   // 35: 256 x 128, BK32, 4 stages, 4 waves
     {4, 2, 2, 2, 64, 4},   // 36: 256 x 128, BK32, 4 stages, 8 waves
@@ -43,6 +43,8 @@ constexpr BigCfg kBigCfgs[kNumBig] = {
     {4, 1, 1, 5, 128, 2},  // 51: 128 x 160, BK64
     {2, 2, 2, 3, 64, 2},   // 52: 128 x 192, BK32
     {4, 1, 1, 3, 128, 2},  // 53: 128 x  96, BK64
+    {4, 2, 2, 5, 64, 2},   // 54: 256 x 320, BK32, 8 waves
+    {4, 2, 2, 3, 64, 2},   // 55: 256 x 192, BK32, 8 waves
 };
 constexpr TileCfg kCfgs[kNumIgemm] = {
     {4, 1, 1, 1, 64},   //  0: 128 x  32, BK32
@@ -162,6 +164,8 @@ int launch_by_cfg(const Y5ConvParams& p, int cfg, int mb, hipStream_t s) {
       case kBig0 + 16: return launch_cfg<T, 4, 1, 1, 5, 128, TABLE, 2>(p, mb, s);
       case kBig0 + 17: return launch_cfg<T, 2, 2, 2, 3, 64, TABLE, 2>(p, mb, s);
       case kBig0 + 18: return launch_cfg<T, 4, 1, 1, 3, 128, TABLE, 2>(p, mb, s);
+      case kBig0 + 19: return launch_cfg<T, 4, 2, 2, 5, 64, TABLE, 2>(p, mb, s);
+      case kBig0 + 20: return launch_cfg<T, 4, 2, 2, 3, 64, TABLE, 2>(p, mb, s);
     }
     return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown tile config");
   }
