@@ -29,10 +29,10 @@ HBM_PEAK_GBS = 8000.0      # HBM3E, same table (about 6.3 TB/s is achievable in 
 
 
 def build_model(name, dev, half=True):
-    from yolov5_amd.yolo import DetectionModel
+    from yolov5_amd.yolo import DetectionModel, SegmentationModel
 
     torch.manual_seed(0)
-    m = DetectionModel(name + ".yaml").eval().fuse()
+    m = (SegmentationModel if name.endswith("-seg") else DetectionModel)(name + ".yaml").eval().fuse()
     m = m.half() if half else m.float()
     return m.to(dev)
 
@@ -48,14 +48,15 @@ def calibrate_head(model, x, obj_frac=0.04, conf=0.25):
     z = model(x)[0].float()
     obj = z[..., 4].flatten()
     q = obj.kthvalue(max(int(obj.numel() * (1 - obj_frac)), 1)).values.clamp(1e-6, 1 - 1e-6)
-    cls = z[..., 5:].max(-1).values.flatten()
+    nc = det.nc
+    cls = z[..., 5:5 + nc].max(-1).values.flatten()  # (a Segment head carries raw mask coefficients after the classes)
     qc = cls.median().clamp(1e-6, 1 - 1e-6)
     logit = lambda v: math.log(float(v) / (1 - float(v)))  # noqa: E731
     with torch.no_grad():
         for mi in det.m:
             b = mi.bias.view(det.na, -1)
             b[:, 4] += logit(0.5) - logit(q)
-            b[:, 5:] += logit(0.7) - logit(qc)
+            b[:, 5:5 + nc] += logit(0.7) - logit(qc)
     model.invalidate_engine()
 
 
@@ -236,13 +237,14 @@ def main():
 
     model = build_model(a.model, dev)
     model.model[-1].export = True  # AutoShape mode: return (z,) only (models/common.py:866)
+    nm = getattr(model.model[-1], "nm", 0)  # Segment head (C5: yolov5s-seg): 32 mask coefficients ride through NMS
     g = torch.Generator(device="cpu").manual_seed(rank)
     x = torch.rand((a.batch, 3, a.imgsz, a.imgsz), generator=g).half().to(dev)
     calibrate_head(model, x)
 
     def step():
         z = model(x)[0]
-        return non_max_suppression(z, 0.25, 0.45, max_det=1000)
+        return non_max_suppression(z, 0.25, 0.45, max_det=1000, nm=nm)
 
     for _ in range(max(a.warmup, 1)):
         det = step()
@@ -279,7 +281,7 @@ def main():
     torch.cuda.synchronize(dev)
     t_n0 = time.perf_counter()
     for _ in range(10):
-        non_max_suppression(z, 0.25, 0.45, max_det=1000)
+        non_max_suppression(z, 0.25, 0.45, max_det=1000, nm=nm)
     torch.cuda.synchronize(dev)
     nms_ms = (time.perf_counter() - t_n0) / 10 * 1e3
     ops = eng.time_ops(iters=10)
