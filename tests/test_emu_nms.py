@@ -87,6 +87,34 @@ def test_detect_decode_emulated():
     assert np.all(z[:, :11] == -1.0)
 
 
+@pytest.mark.parametrize("ny,nx,no,nm,row_off", [(8, 8, 85, 0, 0), (4, 16, 85, 0, 192), (8, 8, 117, 32, 0), (8, 4, 13, 0, 64)])
+def test_detect_decode_fp16_paths_agree(ny, nx, no, nm, row_off):
+    """fp16 decode: the z-only path (box outputs pre-computed in the LDS tile, sigmoid-only element loop) against the general
+    branch-free path (taken when the raw tensor is requested) and against the unaligned fallbacks: bit-identical z."""
+    lib = emu()
+    B, na, ld = 2, 3, 352 if no > 85 else 256
+    lg = aligned((B, ny, nx, ld), np.float16, 1.0)
+    lg[..., : na * no] = detgen.uniform((B, ny, nx, na * no), -5, 5, name="lgh", seed=ny * nx + no).astype(np.float16)
+    apx = (C.c_float * 6)(10, 13, 16, 30, 33, 23)
+    nrows = row_off + na * ny * nx
+    outs = []
+    for with_raw in (False, True):
+        z = aligned((B, nrows, no), np.float16, -1.0)
+        raw = aligned((B, na, ny, nx, no), np.float16, -1.0)
+        rc = lib.y5_detect_decode(ptr(lg), _lib.Y5_F16, B, ny, nx, na, no, nm, ld, 8.0, apx, ptr(z), _lib.Y5_F16, nrows, row_off,
+                                  ptr(raw) if with_raw else None, None)
+        assert rc == 0, lib.y5_last_error()
+        outs.append(z.copy())
+    assert np.array_equal(outs[0].view(np.uint16), outs[1].view(np.uint16))
+    # and against the float formulas (models/yolo.py:104-113)
+    x = torch.from_numpy(lg[..., : na * no].astype(np.float32)).view(B, ny, nx, na, no).permute(0, 3, 1, 2, 4)
+    grid, ag = yo.make_grid(nx, ny, torch.tensor([[10 / 8, 13 / 8], [16 / 8, 30 / 8], [33 / 8, 23 / 8]]), 8.0)
+    sg = x.sigmoid()
+    nact = no - nm
+    ref = torch.cat(((sg[..., :2] * 2 + grid) * 8.0, (sg[..., 2:4] * 2) ** 2 * ag, sg[..., 4:nact], x[..., nact:]), 4).reshape(B, -1, no).numpy()
+    np.testing.assert_allclose(outs[0][:, row_off:].astype(np.float32), ref, rtol=3e-3, atol=3e-3)
+
+
 @pytest.mark.parametrize("dt,Cc", [("f16", 16), ("f32", 16), ("f16", 128), ("f32", 64)])   # 128 x f16 / 64 x f32: 128-byte channel groups
 def test_sppf_pool_emulated(dt, Cc):
     lib = emu()

@@ -161,6 +161,36 @@ void y5_detect_decode_kernel(const Y5DecodeParams p) {
   }
   __syncthreads();
   const int ne = np * p.no;  // output elements per anchor for this tile
+  // z-only fast path (the engine returns the raw tensors as views, export mode has none): the four box outputs of every
+  // (pixel, anchor) row are computed FIRST and written back over their logits in the LDS tile (exact formulas of the general path,
+  // already rounded to fp16); the element loop below then only needs a sigmoid per element and a pass-through select for o < 4
+  // -- 12 instead of 38 VALU instructions per output.
+  bool light = false;
+  if constexpr (sizeof(T) == 2 && sizeof(Z) == 2) {
+    light = p.z != nullptr && p.raw == nullptr && npix < 65536 && (ne & 7) == 0;
+    for (int a = 0; a < p.na; ++a) {
+      const long long zbase = ((long long)b * p.nrows_total + p.row_off + (long long)a * npix + pix0) * p.no;
+      light = light && (zbase & 7) == 0;
+    }
+    if (light) {
+      for (int rix = threadIdx.x; rix < np * p.na; rix += blockDim.x) {
+        const int a = rix / np, pl = rix - a * np;
+        const int pix = pix0 + pl;
+        const int iy = (int)__umulhi((unsigned)pix, p.inv_nx), ix = pix - iy * p.nx;
+        T* q = tile + pl * p.ld + a * p.no;
+        const float gx = (float)ix - 0.5f, gy = (float)iy - 0.5f;
+        const float aw = p.anchors_px[a * 2], ah = p.anchors_px[a * 2 + 1];
+        float s2[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) s2[o] = __builtin_amdgcn_rcpf(1.0f + __expf(-(float)q[o])) * 2.0f;
+        q[0] = (T)((s2[0] + gx) * p.stride);   // yolo.py:110
+        q[1] = (T)((s2[1] + gy) * p.stride);
+        q[2] = (T)(s2[2] * s2[2] * aw);         // yolo.py:111
+        q[3] = (T)(s2[3] * s2[3] * ah);
+      }
+      __syncthreads();
+    }
+  }
   for (int a = 0; a < p.na; ++a) {
     const long long zbase = ((long long)b * p.nrows_total + p.row_off + (long long)a * npix + pix0) * p.no;
     const long long rbase = (((long long)b * p.na + a) * npix + pix0) * p.no;
@@ -168,6 +198,24 @@ void y5_detect_decode_kernel(const Y5DecodeParams p) {
     T* rp = p.raw ? static_cast<T*>(p.raw) + rbase : nullptr;
     const bool pair_ok = ((zbase | rbase | ne) & 1) == 0;
     if constexpr (sizeof(T) == 2 && sizeof(Z) == 2) {
+      if (light) {
+        const int nact = p.no - p.nm;
+        for (int e0 = threadIdx.x * 8; e0 < ne; e0 += blockDim.x * 8) {
+          const int pl = (int)__umulhi((unsigned)e0, p.inv_no);
+          int o = e0 - pl * p.no;
+          const T* src = tile + pl * p.ld + a * p.no;
+          half8_t zo;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float v = (float)src[o];
+            const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+            zo[k] = (half_t)((o < 4 || o >= nact) ? v : s);  // box outputs are final already; Segment mask coefficients stay raw
+            if (++o == p.no) { o = 0; src += p.ld; }
+          }
+          *reinterpret_cast<half8_t*>(zp + e0) = zo;
+        }
+        continue;
+      }
       if (((zbase | rbase | ne) & 7) == 0 && npix < 65536) {
         // fast path: 8 consecutive outputs (16 bytes) per lane, branch-free decode.  a (hence the anchor) is uniform;
         // the 8 elements touch at most two pixels, whose grid coordinates are formed once with umulhi.
