@@ -245,6 +245,26 @@ int y5_process_mask(const void* protos, int proto_dtype, int c, int mh, int mw, 
                     void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * y5_val_match -- val.py:296-307 for every image of a batch in one launch: de-letterbox the predictions and the labels
+ * (`scale_boxes` with ratio_pad, utils/general.py:613-626) and `process_batch` (utils/metrics.py:224-265, box branch;
+ * `box_iou` of ultralytics.utils.metrics, call site utils/metrics.py:252).
+ * det:       (bs, max_det, ld_det) fp32 rows [x1,y1,x2,y2,conf,cls,...] as y5_nms_batched writes them; det_count (bs)
+ *            int32 valid rows per image (NULL: max_det rows everywhere); max_det <= 1024.
+ * labels:    (nlabels, ld_lab) fp32 rows; column img_col holds the image index (img_col < 0: all rows belong to image 0),
+ *            cls_col the class, box_col..box_col+3 the box: centre-x, centre-y, w, h when xywh != 0 (val.py:274 targets in
+ *            letterboxed pixels), x1,y1,x2,y2 otherwise (process_batch's own labels layout).
+ * scale:     optional (bs, 5) fp32 [gain, pad_x, pad_y, h0, w0] = shapes[si][1][0][0], shapes[si][1][1], shapes[si][0]
+ *            (val.py:283,298); NULL: boxes are compared as given.
+ * iouv:      (niou) fp32 thresholds, niou <= 32.
+ * correct:   (bs, max_det, niou) uint8 0/1; rows past det_count are written as 0.
+ * predn:     optional (bs, max_det, 4) fp32 native-space boxes (val.py:297-298) for save_json / save_txt.
+ * Tie rule: a detection whose best IoU is shared by two labels of its class takes the later label row.
+ * ------------------------------------------------------------------------------------------------------- */
+int y5_val_match(const float* det, int ld_det, int max_det, const int* det_count, int bs, const float* labels, int ld_lab,
+                 int nlabels, int img_col, int cls_col, int box_col, int xywh, const float* scale, const float* iouv, int niou,
+                 unsigned char* correct, float* predn, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Execution plan: a recorded list of the calls above, replayed by ONE host call (and optionally through a
  * captured hipGraph).  Replaces the Python module walk of models/yolo.py:160-170 `_forward_once`.
  * ------------------------------------------------------------------------------------------------------- */

@@ -257,6 +257,91 @@ def gen_optim(ns):
     np.savez_compressed(os.path.join(OUT, "optim.npz"), **out)
 
 
+METRIC_CASES = {  # name: (images, labels per image, detections per label, false positives per image, classes, jitter px, seed)
+    "sparse": dict(bs=3, nl=6, per=2, nfp=20, nc=5, jit=6.0, seed=21),
+    "crowd": dict(bs=2, nl=40, per=5, nfp=60, nc=3, jit=10.0, seed=22),
+    "full": dict(bs=4, nl=30, per=8, nfp=60, nc=80, jit=4.0, seed=23),
+    "nolabel": dict(bs=2, nl=0, per=0, nfp=15, nc=4, jit=1.0, seed=24),
+    "dups": dict(bs=2, nl=5, per=3, nfp=4, nc=2, jit=0.0, seed=25),  # jitter 0: exact duplicates, IoU ties
+}
+METRIC_SHAPES = [((480, 640), ((0.8, 0.8), (0.0, 64.0))), ((1080, 810), ((0.5925926, 0.5925926), (80.0, 0.0))),
+                 ((300, 400), ((1.6, 1.6), (0.0, 80.0))), ((640, 640), ((1.0, 1.0), (0.0, 0.0)))]  # shapes[si] = (shape0, ratio_pad)
+
+
+def metrics_case(name, max_det=300):
+    """Synthetic validation batch: targets (M,6) [img, cls, cx, cy, w, h] in letterboxed 640x640 pixels (val.py:274) and
+    NMS-shaped output rows (bs, max_det, 6) + counts: jittered copies of the labels (some with a wrong class) plus random
+    false positives, ordered by descending confidence like non_max_suppression's output."""
+    kw = METRIC_CASES[name]
+    bs, nl, per, nfp, nc, seed = kw["bs"], kw["nl"], kw["per"], kw["nfp"], kw["nc"], kw["seed"]
+    t = detgen.synth_targets(bs, nl, nc, seed=seed) if nl else np.zeros((0, 6), np.float32)
+    if name == "crowd":  # heavy overlap between labels: centres squeezed into a band
+        t[:, 2:4] = 0.4 + 0.2 * t[:, 2:4]
+    t[:, 2:] *= np.float32(640)
+    det = np.zeros((bs, max_det, 6), np.float32)
+    cnt = np.zeros((bs,), np.int32)
+    for si in range(bs):
+        lab = t[t[:, 0] == si]
+        rows = []
+        if nl:
+            j = detgen.uniform((nl, per, 4), -1.0, 1.0, name=f"jit{si}", seed=seed) * np.float32(kw["jit"])
+            flip = detgen.uniform((nl, per), 0, 1, name=f"flip{si}", seed=seed) < 0.15
+            for l in range(nl):
+                for k in range(per):
+                    cx, cy, w, h = lab[l, 2:6] + j[l, k] * np.array([1, 1, 0.5, 0.5], np.float32)
+                    c = (lab[l, 1] + 1) % nc if flip[l, k] else lab[l, 1]
+                    rows.append([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2, 0.0, c])
+        fp = detgen.uniform((nfp, 4), 0, 1, name=f"fp{si}", seed=seed)
+        fc = detgen.integers((nfp,), 0, nc, name=f"fpc{si}", seed=seed)
+        for k in range(nfp):
+            cx, cy, w, h = fp[k, 0] * 640, fp[k, 1] * 640, 8 + fp[k, 2] * 120, 8 + fp[k, 3] * 120
+            rows.append([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2, 0.0, float(fc[k])])
+        rows = np.array(rows, np.float32).reshape(-1, 6)
+        conf = detgen.uniform((rows.shape[0],), 0.001, 1.0, name=f"conf{si}", seed=seed)
+        rows[:, 4] = conf
+        rows = rows[np.argsort(-conf, kind="stable")][:max_det]
+        det[si, :rows.shape[0]] = rows
+        cnt[si] = rows.shape[0]
+    shapes = [METRIC_SHAPES[(si + seed) % len(METRIC_SHAPES)] for si in range(bs)]
+    return det, cnt, t, shapes
+
+
+def gen_metrics(ns):
+    """val.py:282-307 + utils/metrics.py ap_per_class run by the reference's own functions on metrics_case batches."""
+    out = {}
+    iouv = torch.linspace(0.5, 0.95, 10)  # val.py:222
+    stats = []
+    for name in METRIC_CASES:
+        det, cnt, t, shapes = metrics_case(name)
+        targets = torch.from_numpy(t)
+        for si in range(det.shape[0]):
+            pred = torch.from_numpy(det[si, :cnt[si]].copy())
+            labels = targets[targets[:, 0] == si, 1:]
+            shape, ratio_pad = shapes[si]
+            # direct process_batch on the letterboxed-space boxes (no de-letterbox)
+            lab_xyxy = torch.cat((labels[:, 0:1], ns.general.xywh2xyxy(labels[:, 1:5])), 1)
+            c0 = ns.metrics.process_batch(pred, lab_xyxy, iouv) if labels.shape[0] else torch.zeros(pred.shape[0], 10, dtype=torch.bool)
+            # val.py:296-307
+            predn = pred.clone()
+            ns.general.scale_boxes((640, 640), predn[:, :4], shape, ratio_pad)
+            correct = torch.zeros(pred.shape[0], 10, dtype=torch.bool)
+            if labels.shape[0]:
+                tbox = ns.general.xywh2xyxy(labels[:, 1:5])
+                ns.general.scale_boxes((640, 640), tbox, shape, ratio_pad)
+                correct = ns.metrics.process_batch(predn, torch.cat((labels[:, 0:1], tbox), 1), iouv)
+            out[f"{name}_{si}_direct"] = np.packbits(c0.numpy())
+            out[f"{name}_{si}_correct"] = np.packbits(correct.numpy())
+            out[f"{name}_{si}_predn"] = predn[:, :4].numpy()
+            stats.append((correct.numpy(), pred[:, 4].numpy(), pred[:, 5].numpy(), labels[:, 0].numpy()))
+            print("metrics", name, si, int(pred.shape[0]), int(labels.shape[0]), correct.sum(0).tolist())
+    tp, conf, pcls, tcls = (np.concatenate(x, 0) for x in zip(*stats))
+    res = ns.metrics.ap_per_class(tp, conf, pcls, tcls, plot=False, names={})
+    for k, v in zip(("tp", "fp", "p", "r", "f1", "ap", "cls"), res):
+        out["ap_" + k] = np.asarray(v)
+    print("ap_per_class", res[5].mean(0)[[0, -1]], res[5].shape)
+    np.savez_compressed(os.path.join(OUT, "metrics.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = ref_shim.load()
@@ -270,6 +355,7 @@ def main():
     gen_mask(ns)
     gen_scale_boxes(ns)
     gen_optim(ns)
+    gen_metrics(ns)
     sizes = {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT))}
     print(sizes, sum(sizes.values()))
 

@@ -144,6 +144,9 @@ def load():
     met.bbox_iou = tp.bbox_iou
     met.box_iou = tp.box_iou
     met.smooth_bce = tp.smooth_bce
+    met.smooth = tp.smooth
+    met.mask_iou = None  # mask branch of process_batch: not on the path
+    met.plot_mc_curve = met.plot_pr_curve = lambda *a, **k: None
 
     tu = sys.modules["ultralytics.utils.torch_utils"]
     tu.initialize_weights = tp.initialize_weights
@@ -181,6 +184,7 @@ def load():
         import utils.loss as ref_loss  # noqa
         import utils.torch_utils as ref_torch_utils  # noqa
         import utils.segment.general as ref_seg_general  # noqa
+        import utils.metrics as ref_metrics  # noqa
     finally:
         os.chdir(cwd)
 
@@ -203,6 +207,7 @@ def load():
         loss=ref_loss,
         torch_utils=ref_torch_utils,
         seg_general=ref_seg_general,
+        metrics=ref_metrics,
         root=REFERENCE_ROOT,
     )
     _loaded = ns

@@ -106,6 +106,17 @@ def box_iou(box1, box2, eps=1e-7):
     return inter / ((a2 - a1).prod(2) + (b2 - b1).prod(2) - inter + eps)
 
 
+def smooth(y, f=0.05):
+    """ultralytics.utils.metrics.smooth; call site utils/metrics.py:91.  Box filter of fraction f over y with edge padding:
+    nf = odd number of taps closest to 2*f*len(y); y is extended by nf//2 copies of its first / last value, then averaged."""
+    import numpy as np
+
+    nf = round(len(y) * f * 2) // 2 + 1
+    pad = np.ones(nf // 2)
+    yp = np.concatenate((pad * y[0], y, pad * y[-1]), 0)
+    return np.convolve(yp, np.ones(nf) / nf, mode="valid")
+
+
 def initialize_weights(model):
     """ultralytics.utils.torch_utils.initialize_weights; call site models/yolo.py:259.
 

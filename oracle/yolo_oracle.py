@@ -8,6 +8,7 @@ the reference hot path named by BASELINE.json `north_star`:
     ComputeLoss (+build_targets)                            -> utils/loss.py:101-247
     process_mask / crop_mask                                -> utils/segment/general.py:10-51
     scale_boxes                                             -> utils/general.py:613-626
+    process_batch / ap_per_class (validation metrics)       -> utils/metrics.py:25-126,224-265, val.py:296-307
     fuse_conv_and_bn                                        -> utils/torch_utils.py:224-254
 
 Every function cites the reference file:line it follows.  The restatement is PINNED two ways:
@@ -362,6 +363,101 @@ def scale_boxes(img1_shape, boxes, img0_shape, ratio_pad=None):
     boxes[..., [0, 2]] = boxes[..., [0, 2]].clip(0, img0_shape[1])
     boxes[..., [1, 3]] = boxes[..., [1, 3]].clip(0, img0_shape[0])
     return boxes
+
+
+# --------------------------------------------------------------------------------------------------
+# validation metrics (utils/metrics.py:25-126,224-265; val.py:296-307)
+# --------------------------------------------------------------------------------------------------
+def box_iou_np(box1, box2, eps=1e-7):
+    """ultralytics.utils.metrics.box_iou (call site utils/metrics.py:252), float32 numpy, same operation order."""
+    box1 = np.asarray(box1, np.float32)
+    box2 = np.asarray(box2, np.float32)
+    a1, a2 = box1[:, None, :2], box1[:, None, 2:4]
+    b1, b2 = box2[None, :, :2], box2[None, :, 2:4]
+    wh = np.clip(np.minimum(a2, b2) - np.maximum(a1, b1), 0, None).astype(np.float32)
+    inter = wh[..., 0] * wh[..., 1]
+    area1 = (a2 - a1)[..., 0] * (a2 - a1)[..., 1]
+    area2 = (b2 - b1)[..., 0] * (b2 - b1)[..., 1]
+    return inter / (area1 + area2 - inter + np.float32(eps))
+
+
+def process_batch(detections, labels, iouv):
+    """utils/metrics.py:224-265 (box branch): (N,6) [x1,y1,x2,y2,conf,cls] x (M,5) [cls,x1,y1,x2,y2] -> bool (N, niou).
+    The sort at :260 is made STABLE (the reference's numpy argsort()[::-1] is stable only for short lists): equal IoUs keep
+    the later (label-major, detection-minor) pair first after the reversal."""
+    detections = np.asarray(detections, np.float32)
+    labels = np.asarray(labels, np.float32)
+    iouv = np.asarray(iouv, np.float32)
+    correct = np.zeros((detections.shape[0], iouv.shape[0]), dtype=bool)
+    if not detections.shape[0] or not labels.shape[0]:
+        return correct
+    iou = box_iou_np(labels[:, 1:], detections[:, :4])  # :252
+    correct_class = labels[:, 0:1] == detections[:, 5]  # :255
+    for i in range(len(iouv)):
+        li, di = np.nonzero((iou >= iouv[i]) & correct_class)  # :257
+        if li.shape[0]:
+            matches = np.stack([li.astype(np.float64), di.astype(np.float64), iou[li, di].astype(np.float64)], 1)  # :259
+            if li.shape[0] > 1:
+                matches = matches[np.argsort(matches[:, 2], kind="stable")[::-1]]  # :260
+                matches = matches[np.unique(matches[:, 1], return_index=True)[1]]  # :261
+                matches = matches[np.unique(matches[:, 0], return_index=True)[1]]  # :263
+            correct[matches[:, 1].astype(int), i] = True  # :264
+    return correct
+
+
+def val_match_image(pred, targets_px, im_shape, shape0, ratio_pad, iouv):
+    """val.py:296-307 for one image: pred (n,6+) NMS rows, targets_px (m,5) [cls, cx, cy, w, h] in letterboxed pixels
+    (val.py:274) -> (correct (n,niou) bool, predn boxes (n,4))."""
+    predn = np.array(pred[:, :6], np.float32, copy=True)
+    scale_boxes(im_shape, predn[:, :4], shape0, ratio_pad)  # :298
+    t = np.asarray(targets_px, np.float32)
+    half = t[:, 3:5] / np.float32(2)
+    tbox = np.concatenate([t[:, 1:3] - half, t[:, 1:3] + half], 1).astype(np.float32)  # xywh2xyxy, :303
+    scale_boxes(im_shape, tbox, shape0, ratio_pad)  # :304
+    labelsn = np.concatenate([t[:, 0:1], tbox], 1)  # :305
+    return process_batch(predn, labelsn, iouv), predn[:, :4]
+
+
+def compute_ap(recall, precision):
+    """utils/metrics.py:98-126, method 'interp': 101-point interpolated area under the precision envelope."""
+    mrec = np.concatenate(([0.0], recall, [1.0]))
+    mpre = np.concatenate(([1.0], precision, [0.0]))
+    mpre = np.flip(np.maximum.accumulate(np.flip(mpre)))  # :113
+    x = np.linspace(0, 1, 101)  # :118
+    y = np.interp(x, mrec, mpre)
+    ap = float(np.sum((y[1:] + y[:-1]) * np.diff(x) / 2.0))  # np.trapz / np.trapezoid, :119
+    return ap, mpre, mrec
+
+
+def ap_per_class(tp, conf, pred_cls, target_cls, eps=1e-16):
+    """utils/metrics.py:25-95 without the plots -> tp, fp, p, r, f1, ap (nc, niou), unique classes."""
+    from .thirdparty import smooth
+
+    order = np.argsort(-conf)  # :46
+    tp, conf, pred_cls = tp[order], conf[order], pred_cls[order]
+    unique_classes, nt = np.unique(target_cls, return_counts=True)  # :50
+    nc = unique_classes.shape[0]
+    px = np.linspace(0, 1, 1000)
+    ap, p, r = np.zeros((nc, tp.shape[1])), np.zeros((nc, 1000)), np.zeros((nc, 1000))
+    for ci, c in enumerate(unique_classes):
+        sel = pred_cls == c
+        n_l, n_p = nt[ci], sel.sum()
+        if n_p == 0 or n_l == 0:  # :60
+            continue
+        fpc = (1 - tp[sel]).cumsum(0)  # :64
+        tpc = tp[sel].cumsum(0)
+        recall = tpc / (n_l + eps)  # :68
+        r[ci] = np.interp(-px, -conf[sel], recall[:, 0], left=0)  # :69
+        precision = tpc / (tpc + fpc)  # :72
+        p[ci] = np.interp(-px, -conf[sel], precision[:, 0], left=1)  # :73
+        for j in range(tp.shape[1]):
+            ap[ci, j] = compute_ap(recall[:, j], precision[:, j])[0]  # :77
+    f1 = 2 * p * r / (p + r + eps)  # :82
+    i = smooth(f1.mean(0), 0.1).argmax()  # :91
+    p, r, f1 = p[:, i], r[:, i], f1[:, i]
+    tpn = (r * nt).round()  # :93
+    fpn = (tpn / (p + eps) - tpn).round()  # :94
+    return tpn, fpn, p, r, f1, ap, unique_classes.astype(int)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -53,3 +53,29 @@ def test_nms_matches_live_reference(ns):
     out = yo.non_max_suppression(pred, 0.25, 0.45, max_det=300)
     for r, o in zip(ref, out):
         assert np.array_equal(r.numpy(), o)
+
+
+def test_process_batch_and_ap_match_live_reference(ns):
+    """utils/metrics.py process_batch / ap_per_class (unmodified) vs the oracle restatement on a batch that is not in the fixtures."""
+    rng = np.random.default_rng(77)
+    iouv = torch.linspace(0.5, 0.95, 10)
+    stats = []
+    for _ in range(4):
+        m = int(rng.integers(1, 25))
+        lab = np.zeros((m, 5), np.float32)
+        lab[:, 0] = rng.integers(0, 4, m)
+        xy = rng.uniform(0, 500, (m, 2)); wh = rng.uniform(10, 140, (m, 2))
+        lab[:, 1:3], lab[:, 3:5] = xy, xy + wh
+        pick = rng.integers(0, m, 90)
+        det = np.zeros((90, 6), np.float32)
+        det[:, :4] = lab[pick, 1:] + rng.normal(0, 5, (90, 4))
+        det[:, 4] = np.sort(rng.uniform(0, 1, 90))[::-1]
+        det[:, 5] = np.where(rng.uniform(0, 1, 90) < 0.8, lab[pick, 0], rng.integers(0, 4, 90))
+        ref = ns.metrics.process_batch(torch.from_numpy(det), torch.from_numpy(lab), iouv).numpy()
+        assert np.array_equal(yo.process_batch(det, lab, iouv.numpy()), ref)
+        stats.append((ref, det[:, 4], det[:, 5], lab[:, 0]))
+    tp, conf, pcls, tcls = (np.concatenate(x, 0) for x in zip(*stats))
+    r = ns.metrics.ap_per_class(tp, conf, pcls, tcls, plot=False, names={})
+    o = yo.ap_per_class(tp, conf, pcls, tcls)
+    for a, b in zip(r, o):
+        np.testing.assert_allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), rtol=0, atol=1e-12)

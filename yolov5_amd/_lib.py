@@ -105,6 +105,8 @@ EXPORTS = {
     "y5_loss_targets_layout": (C.c_int, [C.POINTER(LossDesc), C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_longlong)]),
     "y5_process_mask": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "y5_val_match": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                               C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "y5_plan_create": (C.c_void_p, []),
     "y5_plan_destroy": (None, [C.c_void_p]),
     "y5_plan_add_conv": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

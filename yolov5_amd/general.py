@@ -65,12 +65,13 @@ _nms_ws = {}
 
 
 def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
-                        labels=(), max_det=300, nm=0):
+                        labels=(), max_det=300, nm=0, padded=False):
     """utils/general.py:658-767 on the GPU: one batched HIP kernel chain for all images (filter -> LDS bitonic sort
     -> greedy IoU with kept boxes in LDS), ONE device->host sync (the per-image counts) instead of >= 3 per image.
 
     Returns list of (k, 6+nm) fp32 tensors [x1, y1, x2, y2, conf, cls, (mask coefficients)] per image, rows in
-    descending confidence.  Deliberate differences from the reference, both documented in DESIGN.md:
+    descending confidence; with padded=True the device buffers themselves, (out (bs, max_det, 6+nm), counts (bs) int32),
+    without any host sync (input of metrics.match_batch / ValStats).  Deliberate differences from the reference, both documented in DESIGN.md:
       * arithmetic is fp32 on the fp32 value of every element also for half inputs (the reference's half path
         overflows the class offset cls*7680 for cls >= 9); output rows are always fp32;
       * no wall-clock `time_limit` (general.py:692,763-765) -- results never depend on timing;
@@ -110,5 +111,7 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
                             0 if cls_t is None else cls_t.numel(), C.c_void_p(out.data_ptr()), C.c_void_p(cnt.data_ptr()),
                             C.c_void_p(ws[0].data_ptr()), ws[1], C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     _lib.check(rc, lib)
+    if padded:
+        return out, cnt
     counts = cnt.tolist()  # the single D2H sync
     return [out[i, :counts[i]] for i in range(bs)]
