@@ -245,6 +245,26 @@ int y5_process_mask(const void* protos, int proto_dtype, int c, int mh, int mw, 
                     void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * y5_letterbox_batch -- the image pre-processing chain for a batch in one launch:
+ *   utils/augmentations.py:85-115 `letterbox` (cv2.resize INTER_LINEAR + cv2.copyMakeBorder with `pad_value`),
+ *   utils/dataloaders.py LoadImages / detect.py:205 `im.transpose((2,0,1))[::-1]` (HWC->CHW, BGR->RGB when swap_rb),
+ *   detect.py:208-209 / val.py:261-262 / models/common.py:926 `.half() / 255` (div255).
+ * jobs_dev: device array of B jobs.  src: u8 HWC 3-channel image, h0 x w0 pixels, `stride` bytes per row; nw x nh is
+ *   letterbox's `new_unpad` (== w0 x h0: no resize), (top, left) its border; the host mirror
+ *   yolov5_amd/augmentations.py:letterbox_geometry computes them with the reference's rounding rules.
+ * dst: (B, 3, H, W) when dst_chw != 0 else (B, H, W, 3); dtype Y5_U8 (the reference's letterbox output), Y5_F16 or Y5_F32.
+ * The resize restates OpenCV's 8-bit INTER_LINEAR (11-bit fixed point, exact 2x down-scale -> 2x2 area mean); cv2 is a
+ * third-party dependency of the reference that is absent from this image: that layer is parity-unpinned.
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct y5_letterbox_job {
+  const void* src;
+  int h0, w0, stride;
+  int nw, nh, top, left;
+} y5_letterbox_job;
+int y5_letterbox_batch(const y5_letterbox_job* jobs_dev, int B, int H, int W, int pad_value, int swap_rb, void* dst, int dst_dtype,
+                       int dst_chw, int div255, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * y5_val_match -- val.py:296-307 for every image of a batch in one launch: de-letterbox the predictions and the labels
  * (`scale_boxes` with ratio_pad, utils/general.py:613-626) and `process_batch` (utils/metrics.py:224-265, box branch;
  * `box_iou` of ultralytics.utils.metrics, call site utils/metrics.py:252).

@@ -342,6 +342,47 @@ def gen_metrics(ns):
     np.savez_compressed(os.path.join(OUT, "metrics.npz"), **out)
 
 
+LETTERBOX_CASES = {  # name: ((h0, w0), kwargs of letterbox)
+    "up": ((75, 100), dict(new_shape=128, auto=False)),
+    "down": ((300, 200), dict(new_shape=128, auto=False)),
+    "half": ((256, 192), dict(new_shape=128, auto=False)),  # exact 2x down-scale: cv2 re-routes INTER_LINEAR to INTER_AREA
+    "pad_only": ((96, 128), dict(new_shape=128, auto=False)),
+    "auto": ((90, 150), dict(new_shape=(96, 160), auto=True, stride=32)),
+    "fill": ((60, 110), dict(new_shape=128, auto=False, scaleFill=True)),
+    "noscaleup": ((50, 70), dict(new_shape=128, auto=False, scaleup=False)),
+}
+LETTERBOX_GEOMETRY = [((h, w), dict(new_shape=ns_, auto=a, scaleFill=f, scaleup=u, stride=st))
+                      for (h, w) in [(480, 640), (1080, 810), (375, 500), (333, 500), (1280, 960), (427, 640), (640, 640), (17, 1000), (720, 1280)]
+                      for ns_ in [640, (384, 640), 1280, 320]
+                      for (a, f, u, st) in [(False, False, True, 32), (True, False, True, 32), (False, True, True, 32), (True, False, False, 64)]]
+
+
+def letterbox_image(name):
+    (h, w), _ = LETTERBOX_CASES[name]
+    return detgen.integers((h, w, 3), 0, 256, name="lb_" + name, seed=51).astype(np.uint8)
+
+
+def gen_letterbox(ns):
+    """utils/augmentations.py letterbox (unmodified) on top of the restated cv2.resize / copyMakeBorder (oracle/thirdparty.py):
+    pins the geometry and the padding; the resize arithmetic itself stays parity-unpinned."""
+    out = {}
+    for name, (_, kw) in LETTERBOX_CASES.items():
+        im, ratio, pad = ns.augmentations.letterbox(letterbox_image(name), **kw)
+        out[name] = im
+        out[name + "_meta"] = np.array([ratio[0], ratio[1], pad[0], pad[1]], np.float64)
+        print("letterbox", name, im.shape, ratio, pad)
+    geo = []
+    for (h, w), kw in LETTERBOX_GEOMETRY:
+        im, ratio, pad = ns.augmentations.letterbox(np.zeros((h, w, 3), np.uint8), **kw)
+        top = int(np.argmax((im[:, im.shape[1] // 2, 0] != 114))) if (im[:, :, 0] != 114).any() else -1
+        left = int(np.argmax((im[im.shape[0] // 2, :, 0] != 114))) if (im[:, :, 0] != 114).any() else -1
+        rows = int((im[:, im.shape[1] // 2, 0] != 114).sum())
+        cols = int((im[im.shape[0] // 2, :, 0] != 114).sum())
+        geo.append([im.shape[0], im.shape[1], ratio[0], ratio[1], pad[0], pad[1], top, left, rows, cols])
+    out["geometry"] = np.array(geo, np.float64)
+    np.savez_compressed(os.path.join(OUT, "letterbox.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = ref_shim.load()
@@ -356,6 +397,7 @@ def main():
     gen_scale_boxes(ns)
     gen_optim(ns)
     gen_metrics(ns)
+    gen_letterbox(ns)
     sizes = {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT))}
     print(sizes, sum(sizes.values()))
 

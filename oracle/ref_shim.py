@@ -75,6 +75,9 @@ def load():
     sys.modules["ultralytics"].__version__ = "8.4.118"
     sys.modules["cv2"].__version__ = "4.6.0"
     sys.modules["cv2"].setNumThreads = lambda *_a, **_k: None
+    sys.modules["cv2"].INTER_LINEAR, sys.modules["cv2"].BORDER_CONSTANT = 1, 0
+    sys.modules["cv2"].resize = tp.cv2_resize  # restated, parity unpinned (oracle/thirdparty.py)
+    sys.modules["cv2"].copyMakeBorder = tp.cv2_copy_make_border
     sys.modules["torchvision"].__version__ = "0.19.0"
 
     # --- real implementations for the symbols the hot path touches -------------------
@@ -145,6 +148,7 @@ def load():
     met.box_iou = tp.box_iou
     met.smooth_bce = tp.smooth_bce
     met.smooth = tp.smooth
+    met.bbox_ioa = None  # copy-paste augmentation: not on the path
     met.mask_iou = None  # mask branch of process_batch: not on the path
     met.plot_mc_curve = met.plot_pr_curve = lambda *a, **k: None
 
@@ -185,6 +189,7 @@ def load():
         import utils.torch_utils as ref_torch_utils  # noqa
         import utils.segment.general as ref_seg_general  # noqa
         import utils.metrics as ref_metrics  # noqa
+        import utils.augmentations as ref_aug  # noqa
     finally:
         os.chdir(cwd)
 
@@ -208,6 +213,7 @@ def load():
         torch_utils=ref_torch_utils,
         seg_general=ref_seg_general,
         metrics=ref_metrics,
+        augmentations=ref_aug,
         root=REFERENCE_ROOT,
     )
     _loaded = ns

@@ -117,6 +117,65 @@ def smooth(y, f=0.05):
     return np.convolve(yp, np.ones(nf) / nf, mode="valid")
 
 
+def cv2_resize(src, dsize, dst=None, fx=0, fy=0, interpolation=1):
+    """cv2.resize(im, (w, h), interpolation=cv2.INTER_LINEAR) for 8-bit images; call site utils/augmentations.py:110.
+    PARITY UNPINNED (opencv-python is absent): restates OpenCV's published algorithm, modules/imgproc/src/resize.cpp --
+      scale = 1 / (dsize / ssize) in double;  an exact 2x down-scale in x and y is re-routed to INTER_AREA whose fast path
+      is the rounded mean of the 2x2 block;  otherwise for every destination index d: f = float((d + 0.5) * scale - 0.5),
+      s = floor(f), f -= s; along x  s < 0 -> (0, 0)  and  s >= w - 1 -> (w - 1, 0); along y the two rows are clamped to the
+      image and f is kept; weights = short(rint(w * 2048)) (half to even); horizontal pass h = S[s] * a0 + S[s + 1] * a1 in
+      int32, vertical pass out = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2."""
+    import numpy as np
+
+    assert interpolation == 1 and src.dtype == np.uint8, "only INTER_LINEAR on uint8 is restated"
+    squeeze = src.ndim == 2
+    s3 = src[:, :, None] if squeeze else src
+    sh, sw = s3.shape[:2]
+    dw, dh = int(dsize[0]), int(dsize[1])
+    scale_x, scale_y = 1.0 / (dw / sw), 1.0 / (dh / sh)
+    eps = np.finfo(np.float64).eps
+    if abs(scale_x - 2.0) < eps and abs(scale_y - 2.0) < eps:
+        a = s3.astype(np.int32)
+        out = (a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2
+        out = out.astype(np.uint8)
+        return out[:, :, 0] if squeeze else out
+
+    def taps(n_dst, scale, n_src, zero_outside):
+        d = np.arange(n_dst, dtype=np.float64)
+        f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = f - s.astype(np.float32)
+        if zero_outside:
+            lo, hi = s < 0, s >= n_src - 1
+            f[lo] = 0.0; s[lo] = 0
+            f[hi] = 0.0; s[hi] = n_src - 1
+        w0 = np.rint((np.float32(1.0) - f) * np.float32(2048.0)).astype(np.int32)
+        w1 = np.rint(f * np.float32(2048.0)).astype(np.int32)
+        return np.clip(s, 0, n_src - 1), np.clip(s + 1, 0, n_src - 1), w0, w1
+
+    x0, x1, a0, a1 = taps(dw, scale_x, sw, True)
+    y0, y1, b0, b1 = taps(dh, scale_y, sh, False)
+    a = s3.astype(np.int32)
+    h = a[:, x0] * a0[None, :, None] + a[:, x1] * a1[None, :, None]  # (sh, dw, c)
+    out = (((b0[:, None, None] * (h[y0] >> 4)) >> 16) + ((b1[:, None, None] * (h[y1] >> 4)) >> 16) + 2) >> 2
+    out = out.astype(np.uint8)
+    return out[:, :, 0] if squeeze else out
+
+
+def cv2_copy_make_border(src, top, bottom, left, right, borderType=0, value=0):
+    """cv2.copyMakeBorder(..., cv2.BORDER_CONSTANT, value=color); call site utils/augmentations.py:113."""
+    import numpy as np
+
+    assert borderType == 0
+    h, w = src.shape[:2]
+    val = np.asarray(value, dtype=src.dtype)
+    val = val[: src.shape[2]] if (src.ndim == 3 and val.ndim) else val
+    out = np.empty((h + top + bottom, w + left + right) + src.shape[2:], dtype=src.dtype)
+    out[...] = val
+    out[top:top + h, left:left + w] = src
+    return out
+
+
 def initialize_weights(model):
     """ultralytics.utils.torch_utils.initialize_weights; call site models/yolo.py:259.
 

@@ -14,6 +14,7 @@ if [ "$WHAT" = "all" ] || [ "$WHAT" = "bench" ]; then
   timeout 600 python bench.py --op-table gpurun_out/op_table.json > gpurun_out/bench.log 2>&1; echo "bench rc=$?" | tee -a gpurun_out/bench.log
   tail -5 gpurun_out/bench.log
   timeout 300 python scripts/metrics_bench.py > gpurun_out/metrics_bench.log 2>&1; tail -2 gpurun_out/metrics_bench.log
+  timeout 300 python scripts/letterbox_bench.py > gpurun_out/letterbox_bench.log 2>&1; tail -2 gpurun_out/letterbox_bench.log
 fi
 if [ "$WHAT" = "all" ] || [ "$WHAT" = "prof" ]; then
   rm -rf gpurun_out/prof

@@ -40,6 +40,11 @@ class FilterJob(C.Structure):
                [("th", C.c_int * 8), ("tw", C.c_int * 8), ("reserved", C.c_int)]
 
 
+class LetterboxJob(C.Structure):
+    """include/yolov5_hip.h: y5_letterbox_job (one image of a y5_letterbox_batch launch)."""
+    _fields_ = [("src", C.c_void_p)] + [(n, C.c_int) for n in ("h0", "w0", "stride", "nw", "nh", "top", "left")]
+
+
 class MtTensor(C.Structure):
     """include/yolov5_hip.h: y5_mt_tensor (one row of the fused optimizer's device-resident tensor table)."""
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("mom", C.c_void_p), ("ema", C.c_void_p), ("n", C.c_longlong),
@@ -105,6 +110,7 @@ EXPORTS = {
     "y5_loss_targets_layout": (C.c_int, [C.POINTER(LossDesc), C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_longlong)]),
     "y5_process_mask": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "y5_letterbox_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "y5_val_match": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "y5_plan_create": (C.c_void_p, []),

@@ -210,39 +210,6 @@ class Detections:
         print(self.__str__())
 
 
-def letterbox_np(im: np.ndarray, new_shape=(640, 640), color=(114, 114, 114), auto=True, scaleFill=False, scaleup=True,
-                 stride=32):
-    """utils/augmentations.py:85-115 geometry (ratio / padding rules identical); the resize itself uses PIL
-    bilinear instead of cv2.INTER_LINEAR (cv2 is not a dependency) -- parity is defined on the post-letterbox
-    tensor."""
-    from PIL import Image
-
-    shape = im.shape[:2]
-    if isinstance(new_shape, int):
-        new_shape = (new_shape, new_shape)
-    r = min(new_shape[0] / shape[0], new_shape[1] / shape[1])
-    if not scaleup:
-        r = min(r, 1.0)
-    ratio = r, r
-    new_unpad = int(round(shape[1] * r)), int(round(shape[0] * r))
-    dw, dh = new_shape[1] - new_unpad[0], new_shape[0] - new_unpad[1]
-    if auto:
-        dw, dh = np.mod(dw, stride), np.mod(dh, stride)
-    elif scaleFill:
-        dw, dh = 0.0, 0.0
-        new_unpad = (new_shape[1], new_shape[0])
-        ratio = new_shape[1] / shape[1], new_shape[0] / shape[0]
-    dw /= 2
-    dh /= 2
-    if shape[::-1] != new_unpad:
-        im = np.asarray(Image.fromarray(im).resize(new_unpad, Image.BILINEAR))
-    top, bottom = int(round(dh - 0.1)), int(round(dh + 0.1))
-    left, right = int(round(dw - 0.1)), int(round(dw + 0.1))
-    out = np.full((im.shape[0] + top + bottom, im.shape[1] + left + right, im.shape[2]), color, dtype=im.dtype)
-    out[top:top + im.shape[0], left:left + im.shape[1]] = im
-    return out, ratio, (dw, dh)
-
-
 class AutoShape(nn.Module):
     """Input-robust wrapper (models/common.py:843-948): numpy/PIL/tensor -> letterbox -> model -> NMS -> scale_boxes."""
 
@@ -269,6 +236,7 @@ class AutoShape(nn.Module):
 
     @torch.no_grad()
     def forward(self, ims, size=640, augment=False, profile=False):
+        from .augmentations import letterbox_batch
         from .general import make_divisible, non_max_suppression, scale_boxes
 
         if isinstance(size, int):
@@ -293,9 +261,10 @@ class AutoShape(nn.Module):
             ims[i] = im if im.data.contiguous else np.ascontiguousarray(im)
         stride = int(max(self.stride)) if hasattr(self.stride, "__len__") or torch.is_tensor(self.stride) else int(self.stride)
         shape1 = [make_divisible(x, stride) for x in np.array(shape1).max(0)]
-        x = [letterbox_np(im, shape1, auto=False)[0] for im in ims]
-        x = np.ascontiguousarray(np.array(x).transpose((0, 3, 1, 2)))  # BHWC -> BCHW
-        x = torch.from_numpy(x).to(p.device)  # uint8: the /255 scaling is fused into the layout kernel
+        # common.py:922-926 (letterbox each image, stack, BHWC -> BCHW, to device, /255) as ONE launch over the raw uint8
+        # images: only the un-padded source pixels cross PCIe (augmentations.letterbox_batch -> y5_letterbox_batch)
+        raw = [torch.from_numpy(np.array(im, dtype=np.uint8, order="C")).to(p.device) for im in ims]
+        x, _ = letterbox_batch(raw, tuple(shape1), auto=False, dtype=p.dtype if p.dtype in (torch.float16, torch.float32) else torch.float32)
         y = self.model(x)
         y = non_max_suppression(y if self.dmb else y[0], self.conf, self.iou, self.classes, self.agnostic, self.multi_label,
                                 max_det=self.max_det)

@@ -1,0 +1,168 @@
+// Input pre-processing on the device -- for a whole batch in one launch:
+//     letterbox(im, new_shape, auto=False)            utils/augmentations.py:85-115: cv2.resize(INTER_LINEAR) + 114 border
+//     im.transpose((2, 0, 1))[::-1]                   HWC -> CHW, BGR -> RGB (utils/dataloaders.py LoadImages, detect.py:205)
+//     im.half() / 255                                 detect.py:208-209, val.py:261-262, models/common.py:926
+// The geometry (ratio, new_unpad, top/left) is computed by the host mirror of `letterbox` and arrives per image in a job
+// table; this kernel does the pixel work.  cv2 is a third-party dependency of the reference (opencv-python, absent here):
+// the resize restates OpenCV's published 8-bit INTER_LINEAR algorithm (modules/imgproc/src/resize.cpp):
+//   * scale = 1 / (dst / src) in double; source position f = (float)((d + 0.5) * scale - 0.5), s = floor(f), f -= s;
+//     horizontally s < 0 -> (s, f) = (0, 0) and s >= w - 1 -> (w - 1, 0); vertically rows are clamped, f kept;
+//   * weights are 11-bit fixed point: short(rint(w * 2048)) (round half to even);
+//   * horizontal pass in int32: h = S[s] * a0 + S[s + 1] * a1; vertical pass
+//     out = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+//   * an exact 2x down-scale in both directions is re-routed to INTER_AREA: out = (p00 + p01 + p10 + p11 + 2) >> 2.
+// HBM-bound byte work: one lane produces 8 consecutive output pixels of one row (3 channels) and stores 16 bytes per
+// channel plane (fp16 CHW) -- reads are gathers from at most two source rows that stay in L2.
+#include <hip/hip_runtime.h>
+
+#include "../../include/yolov5_hip.h"
+#include "y5_common.h"
+#include "y5_host.h"
+
+namespace {
+constexpr int PX = 8;  // output pixels per lane
+
+struct LbParams {
+  const y5_letterbox_job* jobs;
+  void* dst;
+  int B, H, W, pad, swap_rb, dst_dtype, chw, div255;
+};
+
+struct Axis { int s0, s1, w0, w1; };  // two taps and their 11-bit weights
+
+__device__ inline int rint_short(float v) {  // saturate_cast<short>(float): round half to even
+  const int i = (int)rintf(v);
+  return i < -32768 ? -32768 : (i > 32767 ? 32767 : i);
+}
+
+__device__ inline Axis axis_x(int d, double scale, int n) {
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  int s = (int)floorf(f);
+  f -= (float)s;
+  if (s < 0) { s = 0; f = 0.f; }
+  if (s >= n - 1) { s = n - 1; f = 0.f; }
+  Axis a;
+  a.s0 = s; a.s1 = s + 1 < n ? s + 1 : n - 1;
+  a.w0 = rint_short((1.f - f) * 2048.f); a.w1 = rint_short(f * 2048.f);
+  return a;
+}
+
+__device__ inline Axis axis_y(int d, double scale, int n) {
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  const int s = (int)floorf(f);
+  f -= (float)s;
+  Axis a;
+  a.s0 = s < 0 ? 0 : (s < n ? s : n - 1);
+  a.s1 = s + 1 < 0 ? 0 : (s + 1 < n ? s + 1 : n - 1);
+  a.w0 = rint_short((1.f - f) * 2048.f); a.w1 = rint_short(f * 2048.f);
+  return a;
+}
+
+__device__ inline bool is_int_scale(double scale, int k) { return fabs(scale - (double)k) < 2.220446049250313e-16 && (int)rint(scale) == k; }
+}  // namespace
+
+__global__ __launch_bounds__(256)
+void y5_letterbox_kernel(const LbParams p) {
+  const int b = blockIdx.y;
+  const int nxg = (p.W + PX - 1) / PX;  // lanes per output row
+  const int id = blockIdx.x * 256 + threadIdx.x;
+  const int y = id / nxg;
+  if (y >= p.H) return;
+  const int x0 = (id - y * nxg) * PX;
+  const y5_letterbox_job j = p.jobs[b];
+  const unsigned char* src = static_cast<const unsigned char*>(j.src);
+  const int yy = y - j.top;
+  const bool row_in = yy >= 0 && yy < j.nh;
+  const bool resize = j.nw != j.w0 || j.nh != j.h0;
+  const double sx = 1.0 / ((double)j.nw / (double)j.w0), sy = 1.0 / ((double)j.nh / (double)j.h0);
+  const bool area2 = resize && is_int_scale(sx, 2) && is_int_scale(sy, 2);
+  Axis ay{};
+  if (row_in && resize && !area2) ay = axis_y(yy, sy, j.h0);
+  unsigned char v[3][PX];
+#pragma unroll
+  for (int i = 0; i < PX; ++i) {
+    const int xx = x0 + i - j.left;
+    int c0 = p.pad, c1 = p.pad, c2 = p.pad;
+    if (row_in && xx >= 0 && xx < j.nw) {
+      if (!resize) {
+        const unsigned char* s = src + (size_t)yy * j.stride + xx * 3;
+        c0 = s[0]; c1 = s[1]; c2 = s[2];
+      } else if (area2) {
+        const unsigned char* s = src + (size_t)(2 * yy) * j.stride + (2 * xx) * 3;
+        const unsigned char* t = s + j.stride;
+        c0 = (s[0] + s[3] + t[0] + t[3] + 2) >> 2;
+        c1 = (s[1] + s[4] + t[1] + t[4] + 2) >> 2;
+        c2 = (s[2] + s[5] + t[2] + t[5] + 2) >> 2;
+      } else {
+        const Axis ax = axis_x(xx, sx, j.w0);
+        const unsigned char* r0 = src + (size_t)ay.s0 * j.stride;
+        const unsigned char* r1 = src + (size_t)ay.s1 * j.stride;
+        int o[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int h0 = r0[ax.s0 * 3 + c] * ax.w0 + r0[ax.s1 * 3 + c] * ax.w1;
+          const int h1 = r1[ax.s0 * 3 + c] * ax.w0 + r1[ax.s1 * 3 + c] * ax.w1;
+          o[c] = (((ay.w0 * (h0 >> 4)) >> 16) + ((ay.w1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        }
+        c0 = o[0]; c1 = o[1]; c2 = o[2];
+      }
+    }
+    v[0][i] = (unsigned char)(p.swap_rb ? c2 : c0);
+    v[1][i] = (unsigned char)c1;
+    v[2][i] = (unsigned char)(p.swap_rb ? c0 : c2);
+  }
+  const int nvalid = p.W - x0 < PX ? p.W - x0 : PX;
+  const size_t plane = (size_t)p.H * p.W;
+  if (p.dst_dtype == Y5_U8) {
+    unsigned char* d = static_cast<unsigned char*>(p.dst) + (size_t)b * 3 * plane;
+    for (int i = 0; i < nvalid; ++i)
+      for (int c = 0; c < 3; ++c) {
+        const size_t o = p.chw ? (size_t)c * plane + (size_t)y * p.W + x0 + i : ((size_t)y * p.W + x0 + i) * 3 + c;
+        d[o] = v[c][i];
+      }
+  } else if (p.dst_dtype == Y5_F16) {
+    _Float16* d = static_cast<_Float16*>(p.dst) + (size_t)b * 3 * plane;
+    for (int c = 0; c < 3; ++c) {
+      _Float16 h[PX];
+#pragma unroll
+      for (int i = 0; i < PX; ++i) {
+        // `.half() / 255`: the division is carried out in fp32 on the half value (exact for 0..255) and rounded once
+        const float f = (float)v[c][i];
+        h[i] = (_Float16)(p.div255 ? f / 255.0f : f);
+      }
+      if (p.chw && nvalid == PX && (p.W & 7) == 0) {
+        half8_t hv;
+        for (int i = 0; i < PX; ++i) hv[i] = h[i];
+        *reinterpret_cast<half8_t*>(d + (size_t)c * plane + (size_t)y * p.W + x0) = hv;
+      } else {
+        for (int i = 0; i < nvalid; ++i) {
+          const size_t o = p.chw ? (size_t)c * plane + (size_t)y * p.W + x0 + i : ((size_t)y * p.W + x0 + i) * 3 + c;
+          d[o] = h[i];
+        }
+      }
+    }
+  } else {
+    float* d = static_cast<float*>(p.dst) + (size_t)b * 3 * plane;
+    for (int i = 0; i < nvalid; ++i)
+      for (int c = 0; c < 3; ++c) {
+        const size_t o = p.chw ? (size_t)c * plane + (size_t)y * p.W + x0 + i : ((size_t)y * p.W + x0 + i) * 3 + c;
+        const float f = (float)v[c][i];
+        d[o] = p.div255 ? f / 255.0f : f;
+      }
+  }
+}
+
+extern "C" int y5_letterbox_batch(const y5_letterbox_job* jobs_dev, int B, int H, int W, int pad_value, int swap_rb, void* dst, int dst_dtype,
+                                  int dst_chw, int div255, void* stream_) {
+  if (!jobs_dev || !dst) return y5_fail(Y5_ERR_BAD_ARG, "letterbox_batch: null pointer");
+  if (B < 1 || B > 65535 || H < 1 || W < 1 || pad_value < 0 || pad_value > 255)
+    return y5_fail(Y5_ERR_BAD_ARG, "letterbox_batch: need 1 <= B <= 65535, H, W >= 1, 0 <= pad_value <= 255");
+  if (dst_dtype != Y5_U8 && dst_dtype != Y5_F16 && dst_dtype != Y5_F32) return y5_fail(Y5_ERR_BAD_ARG, "letterbox_batch: dst dtype must be u8, f16 or f32");
+  LbParams p{};
+  p.jobs = jobs_dev; p.dst = dst; p.B = B; p.H = H; p.W = W; p.pad = pad_value; p.swap_rb = swap_rb; p.dst_dtype = dst_dtype;
+  p.chw = dst_chw; p.div255 = div255;
+  const long long lanes = (long long)H * ((W + PX - 1) / PX);
+  if (lanes > 0x7fffffffLL) return y5_fail(Y5_ERR_UNSUPPORTED, "letterbox_batch: output too large");
+  hipLaunchKernelGGL(y5_letterbox_kernel, dim3((unsigned)((lanes + 255) / 256), B), dim3(256), 0, static_cast<hipStream_t>(stream_), p);
+  return y5_check_launch("y5_letterbox_batch");
+}
