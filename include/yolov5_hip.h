@@ -285,6 +285,14 @@ int y5_val_match(const float* det, int ld_det, int max_det, const int* det_count
                  unsigned char* correct, float* predn, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * y5_scale_boxes_batch -- utils/general.py:613-626 `scale_boxes` (+ `clip_boxes` :629-640) applied IN PLACE to columns 0..3 of
+ * the first det_count[i] rows of every image of the padded NMS output (call sites detect.py:248 with do_round,
+ * models/common.py:941, val.py:298): x = clamp((x - pad) / gain, 0, w0|h0).  scale: (bs, 5) fp32 [gain, pad_x, pad_y, h0, w0].
+ * ------------------------------------------------------------------------------------------------------- */
+int y5_scale_boxes_batch(float* det, int ld_det, int max_det, const int* det_count, int bs, const float* scale, int do_round,
+                         void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Execution plan: a recorded list of the calls above, replayed by ONE host call (and optionally through a
  * captured hipGraph).  Replaces the Python module walk of models/yolo.py:160-170 `_forward_once`.
  * ------------------------------------------------------------------------------------------------------- */

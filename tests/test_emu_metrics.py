@@ -160,3 +160,29 @@ def test_host_smooth_compute_ap_fitness():
     pre = np.cos(rec) * 0.9
     assert abs(ym.compute_ap(rec, pre)[0] - yo.compute_ap(rec, pre)[0]) < 1e-15
     assert np.allclose(ym.fitness(np.array([[0.5, 0.6, 0.7, 0.8, 9.0]])), [0.79])
+
+
+def test_emu_scale_boxes_batch_vs_reference_golden():
+    """tests/golden/scale_boxes.npz: the reference's scale_boxes on 20 boxes, (640,640)->(1080,810) and (384,640)->(720,1280)."""
+    from oracle import detgen
+
+    S = np.load(os.path.join(os.path.dirname(__file__), "golden", "scale_boxes.npz"))
+    b = detgen.uniform((20, 4), -20, 660, name="sb", seed=14)
+    lib = emu()
+    det = aligned((2, 32, 7), np.float32, 5.0)
+    det[:, :20, :4] = b
+    cnt = aligned((2,), np.int32); cnt[...] = [20, 20]
+    rows = []
+    for img1, img0 in (((640, 640), (1080, 810)), ((384, 640), (720, 1280))):
+        gain = min(img1[0] / img0[0], img1[1] / img0[1])
+        rows.append([gain, (img1[1] - img0[1] * gain) / 2, (img1[0] - img0[0] * gain) / 2, img0[0], img0[1]])
+    sc = aligned((2, 5), np.float32); sc[...] = np.array(rows, np.float32)
+    rnd = det.copy()
+    assert lib.y5_scale_boxes_batch(ptr(det), 7, 32, ptr(cnt), 2, ptr(sc), 0, None) == 0, lib.y5_last_error()
+    assert np.array_equal(det[0, :20, :4], S["a"]) and np.array_equal(det[1, :20, :4], S["b"])
+    assert (det[:, 20:] == 5.0).all() and (det[:, :, 4:] == 5.0).all()  # rows past the count and other columns untouched
+    rnd_buf = aligned(rnd.shape, np.float32); rnd_buf[...] = rnd
+    assert lib.y5_scale_boxes_batch(ptr(rnd_buf), 7, 32, ptr(cnt), 2, ptr(sc), 1, None) == 0
+    import torch
+    assert np.array_equal(rnd_buf[0, :20, :4], torch.from_numpy(S["a"]).round().numpy())  # detect.py:248
+    assert lib.y5_scale_boxes_batch(None, 7, 32, ptr(cnt), 2, ptr(sc), 0, None) != 0

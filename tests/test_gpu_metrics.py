@@ -97,3 +97,20 @@ def test_metrics_need_gpu():
         process_batch(torch.zeros(3, 6), torch.zeros(2, 5), torch.linspace(0.5, 0.95, 10))
     with pytest.raises(RuntimeError):
         match_batch(torch.zeros(1, 3, 6), torch.zeros(1, dtype=torch.int32), torch.zeros(0, 6), None, torch.linspace(0.5, 0.95, 10))
+
+
+def test_scale_boxes_batch_vs_reference_golden(dev):
+    from yolov5_amd.general import scale_boxes_batch
+
+    S = np.load(os.path.join(os.path.dirname(__file__), "golden", "scale_boxes.npz"))
+    b = detgen.uniform((20, 4), -20, 660, name="sb", seed=14)
+    out = torch.full((1, 32, 6), 5.0, device=dev)
+    out[0, :20, :4] = torch.from_numpy(b).to(dev)
+    cnt = torch.tensor([20], dtype=torch.int32, device=dev)
+    a = scale_boxes_batch((640, 640), out.clone(), cnt, [(1080, 810)])
+    assert np.array_equal(a[0, :20, :4].cpu().numpy(), S["a"]) and bool((a[0, 20:] == 5.0).all()) and bool((a[0, :, 4:] == 5.0).all())
+    bb = scale_boxes_batch((384, 640), out.clone(), cnt, [(720, 1280)], round_=True)
+    assert np.array_equal(bb[0, :20, :4].cpu().numpy(), torch.from_numpy(S["b"]).round().numpy())
+    # explicit ratio_pad (val.py:298)
+    c = scale_boxes_batch((640, 640), out.clone(), cnt, [(1080, 810)], ratio_pads=[((640 / 1080, 640 / 1080), (80.0, 0.0))])
+    assert np.array_equal(c[0, :20, :4].cpu().numpy(), S["a"])

@@ -237,7 +237,7 @@ class AutoShape(nn.Module):
     @torch.no_grad()
     def forward(self, ims, size=640, augment=False, profile=False):
         from .augmentations import letterbox_batch
-        from .general import make_divisible, non_max_suppression, scale_boxes
+        from .general import make_divisible, non_max_suppression, scale_boxes_batch
 
         if isinstance(size, int):
             size = (size, size)
@@ -266,8 +266,9 @@ class AutoShape(nn.Module):
         raw = [torch.from_numpy(np.array(im, dtype=np.uint8, order="C")).to(p.device) for im in ims]
         x, _ = letterbox_batch(raw, tuple(shape1), auto=False, dtype=p.dtype if p.dtype in (torch.float16, torch.float32) else torch.float32)
         y = self.model(x)
-        y = non_max_suppression(y if self.dmb else y[0], self.conf, self.iou, self.classes, self.agnostic, self.multi_label,
-                                max_det=self.max_det)
-        for i in range(n):
-            scale_boxes(shape1, y[i][:, :4], shape0[i])
+        out, cnt = non_max_suppression(y if self.dmb else y[0], self.conf, self.iou, self.classes, self.agnostic, self.multi_label,
+                                       max_det=self.max_det, padded=True)
+        scale_boxes_batch(shape1, out, cnt, shape0)  # common.py:940-941 for all images in one launch
+        counts = cnt.tolist()  # the one device->host sync of the call
+        y = [out[i, :counts[i]] for i in range(n)]
         return Detections(ims, y, files, (0, 0, 0), self.names, x.shape)

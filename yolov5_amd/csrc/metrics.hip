@@ -144,6 +144,30 @@ void y5_val_match_kernel(const MatchParams p) {
   }
 }
 
+// scale_boxes (utils/general.py:613-626) in place on the padded NMS rows of every image: detect.py:248, models/common.py:941
+__global__ __launch_bounds__(256)
+void y5_scale_boxes_kernel(float* __restrict__ det, int ld, int max_det, const int* __restrict__ count, const float* __restrict__ scale, int do_round) {
+  const int si = blockIdx.y;
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  int n = count ? count[si] : max_det;
+  n = n > max_det ? max_det : n;
+  if (d >= n) return;
+  float* r = det + ((size_t)si * max_det + d) * ld;
+  float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
+  de_letterbox(x1, y1, x2, y2, scale + (size_t)si * 5);
+  if (do_round) { x1 = rintf(x1); y1 = rintf(y1); x2 = rintf(x2); y2 = rintf(y2); }  // torch.round: half to even (detect.py:248)
+  r[0] = x1; r[1] = y1; r[2] = x2; r[3] = y2;
+}
+
+extern "C" int y5_scale_boxes_batch(float* det, int ld_det, int max_det, const int* det_count, int bs, const float* scale, int do_round,
+                                    void* stream_) {
+  if (!det || !scale) return y5_fail(Y5_ERR_BAD_ARG, "scale_boxes_batch: null pointer");
+  if (bs < 1 || bs > 65535 || max_det < 1 || ld_det < 4) return y5_fail(Y5_ERR_BAD_ARG, "scale_boxes_batch: need 1 <= bs <= 65535, max_det >= 1, ld_det >= 4");
+  hipLaunchKernelGGL(y5_scale_boxes_kernel, dim3((max_det + 255) / 256, bs), dim3(256), 0, static_cast<hipStream_t>(stream_), det, ld_det, max_det,
+                     det_count, scale, do_round);
+  return y5_check_launch("y5_scale_boxes_batch");
+}
+
 extern "C" int y5_val_match(const float* det, int ld_det, int max_det, const int* det_count, int bs, const float* labels, int ld_lab,
                             int nlabels, int img_col, int cls_col, int box_col, int xywh, const float* scale, const float* iouv, int niou,
                             unsigned char* correct, float* predn, void* stream_) {

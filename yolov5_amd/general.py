@@ -61,6 +61,30 @@ def scale_boxes(img1_shape, boxes, img0_shape, ratio_pad=None):
     return boxes
 
 
+def scale_boxes_batch(img1_shape, out, counts, img0_shapes, ratio_pads=None, round_=False):
+    """`scale_boxes` (utils/general.py:613-626) for every image of a padded NMS result in one launch, in place: out (bs, max_det,
+    6+nm) fp32 / counts (bs) int32 as returned by non_max_suppression(..., padded=True); img0_shapes[i] = (h0, w0);
+    ratio_pads[i] = ((gain, gain), (pad_x, pad_y)) or None (computed from the shapes, :615-617).  round_: detect.py:248."""
+    if not out.is_cuda or out.dtype != torch.float32 or not out.is_contiguous():
+        raise RuntimeError("scale_boxes_batch needs the contiguous fp32 GPU buffer of non_max_suppression(..., padded=True)")
+    bs, max_det, ld = out.shape
+    rows = []
+    for i, s0 in enumerate(img0_shapes):
+        rp = ratio_pads[i] if ratio_pads is not None else None
+        if rp is None:
+            gain = min(img1_shape[0] / s0[0], img1_shape[1] / s0[1])
+            pad = (img1_shape[1] - s0[1] * gain) / 2, (img1_shape[0] - s0[0] * gain) / 2
+        else:
+            gain, pad = rp[0][0], rp[1]
+        rows.append([gain, pad[0], pad[1], s0[0], s0[1]])
+    sc = torch.tensor(rows, dtype=torch.float32).to(out.device)
+    lib = _lib.lib()
+    rc = lib.y5_scale_boxes_batch(C.c_void_p(out.data_ptr()), ld, max_det, C.c_void_p(counts.data_ptr()) if counts is not None else None, bs,
+                                  C.c_void_p(sc.data_ptr()), int(round_), C.c_void_p(torch.cuda.current_stream(out.device).cuda_stream))
+    _lib.check(rc, lib)
+    return out
+
+
 _nms_ws = {}
 
 
