@@ -208,6 +208,42 @@ def train_probe(name, batch, imgsz, dev, world, steps=6, warmup=2):
                         f"{' + RCCL all-reduce' if world > 1 else ''} + SGD; fp16 compute / fp32 masters", "loss": round(float(loss.detach()), 4)}
 
 
+def pipeline_probe(model, batch, dev, nm, iters=10):
+    """Secondary measurement: detect.py / val.py around the hot path, everything on the device -- `batch` uint8 1280x720 BGR frames
+    resident in HBM -> letterbox + CHW + RGB + /255 (one launch) -> forward -> NMS (padded result, no host sync) -> scale_boxes of
+    all images (one launch) -> validation matching against synthetic labels (one launch) -> the counts' D2H copy."""
+    from yolov5_amd.augmentations import letterbox_batch
+    from yolov5_amd.general import non_max_suppression, scale_boxes_batch
+    from yolov5_amd.metrics import match_batch
+
+    g = torch.Generator(device="cpu").manual_seed(7)
+    frames = [torch.randint(0, 256, (720, 1280, 3), generator=g, dtype=torch.uint8).to(dev) for _ in range(4)]
+    ims = [frames[i % 4] for i in range(batch)]
+    nt = batch * 7
+    targets = torch.cat((torch.randint(0, batch, (nt, 1), generator=g).float(), torch.randint(0, 80, (nt, 1), generator=g).float(),
+                         torch.rand((nt, 2), generator=g) * 500 + 70, torch.rand((nt, 2), generator=g) * 150 + 20), 1).to(dev)
+    iouv = torch.linspace(0.5, 0.95, 10, device=dev)
+
+    def step():
+        x, shapes = letterbox_batch(ims, 640, auto=False, dtype=torch.float16, swap_rb=True)
+        out, cnt = non_max_suppression(model(x)[0], 0.25, 0.45, max_det=300, nm=nm, padded=True)
+        correct = match_batch(out, cnt, targets, shapes, iouv)
+        scale_boxes_batch((640, 640), out, cnt, [s[0] for s in shapes], [s[1] for s in shapes])
+        return cnt.tolist(), correct
+
+    for _ in range(3):
+        counts, _ = step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    return {"images_per_sec": round(batch / ms * 1e3, 1), "ms_per_batch": round(ms, 4), "detections_per_img": round(sum(counts) / batch, 1),
+            "workload": f"{batch} uint8 1280x720 frames in HBM -> letterbox/CHW/RGB//255 -> forward -> NMS (max_det 300) -> val matching "
+                        "(10 IoU thresholds) -> scale_boxes; one host sync per batch"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -312,6 +348,14 @@ def main():
         with open(a.op_table, "w") as f:
             json.dump(table, f, indent=1)
 
+    # ---- secondary: the detect.py pipeline around the hot path (SURVEY 8(f) rank 1 + 3 rows) ---------------------------------
+    pipeline = None
+    if world == 1 and a.imgsz == 640 and not a.no_train:
+        try:
+            pipeline = pipeline_probe(model, a.batch, dev, nm)
+        except Exception as e:  # the headline metric must not depend on the secondary probe
+            pipeline = {"error": f"{type(e).__name__}: {e}"}
+
     train = None
     if not a.no_train and (world == 1 or a.train):
         try:
@@ -346,6 +390,8 @@ def main():
                          "conv_ms_per_step": round(conv_ms * parts, 4), "launches_per_step": nconv * parts,
                          "other_kernels_ms_per_step": round(other_ms * parts, 4)},
         }
+        if pipeline is not None:
+            res["pipeline"] = pipeline
         if train is not None:
             res["train"] = train
         if not a.no_cpu_baseline and world == 1:
