@@ -304,6 +304,11 @@ int y5_plan_add_conv(y5_plan*, const y5_conv_desc* d, const void* x, const void*
 int y5_plan_add_conv_stem(y5_plan*, const void* x_nchw, int B, int H, int W, const void* w_stem, const float* bias, int C2,
                           int Npad, void* y, int ldy);
 int y5_plan_set_input(y5_plan*, int op_index, const void* src);  /* re-point a stem / nchw_to_nhwc op at a new input batch */
+/* Side branch: consecutive ops marked branch = 1 run on a plan-owned second stream, forked behind the main op that precedes them in the
+ * list and joined at the end of the executed range (in a captured graph: fork / join edges).  The caller guarantees that their inputs are
+ * complete at the fork point and that no later op of the range reads their outputs (the Detect heads of the lower pyramid levels,
+ * models/yolo.py:83-108, which only the final output depends on). */
+int y5_plan_set_branch(y5_plan*, int op_index, int branch);
 int y5_plan_add_nchw_to_nhwc(y5_plan*, const void* src, int src_dtype, void* dst, int dst_dtype, int B, int C, int H,
                              int W, int ld, float scale);
 int y5_plan_add_sppf_pool(y5_plan*, void* buf, int dtype, int B, int H, int W, int C, int ld, int k);

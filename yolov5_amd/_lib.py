@@ -121,6 +121,7 @@ EXPORTS = {
     "y5_plan_add_conv_stem": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                         C.c_void_p, C.c_int]),
     "y5_plan_set_input": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "y5_plan_set_branch": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "y5_plan_add_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.c_int, C.c_int, C.c_float]),
     "y5_plan_add_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,

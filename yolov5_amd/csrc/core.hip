@@ -58,12 +58,15 @@ struct Op {
   float f[2];
   long long l[2];
   float anchors[16];
+  int branch;  // 0: the caller's stream; 1: the plan's side stream (forked after the preceding main op, joined at the end of the range)
 };
 
 struct y5_plan {
   std::vector<Op> ops;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
+  hipStream_t side = nullptr;        // side-branch stream (y5_plan_set_branch), created on first use
+  std::vector<hipEvent_t> events;    // fork / join markers, one per fork point of a run + one join
 };
 
 extern "C" y5_plan* y5_plan_create(void) { return new y5_plan(); }
@@ -71,6 +74,8 @@ extern "C" void y5_plan_destroy(y5_plan* p) {
   if (!p) return;
   if (p->exec) hipGraphExecDestroy(p->exec);
   if (p->graph) hipGraphDestroy(p->graph);
+  for (hipEvent_t e : p->events) hipEventDestroy(e);
+  if (p->side) hipStreamDestroy(p->side);
   delete p;
 }
 extern "C" int y5_plan_size(const y5_plan* p) { return p ? (int)p->ops.size() : 0; }
@@ -161,11 +166,49 @@ static int run_op(const Op& o, void* st) {
   return y5_fail(Y5_ERR_BAD_ARG, "plan: unknown op");
 }
 
-extern "C" int y5_plan_run_range(y5_plan* pl, int first, int last, void* st) {
+extern "C" int y5_plan_set_branch(y5_plan* pl, int op, int branch) {
+  if (!pl || op < 0 || op >= (int)pl->ops.size() || branch < 0 || branch > 1) return y5_fail(Y5_ERR_BAD_ARG, "plan_set_branch: bad op index / branch");
+  pl->ops[op].branch = branch;
+  return Y5_OK;
+}
+
+static hipEvent_t plan_event(y5_plan* pl, size_t idx) {
+  while (pl->events.size() <= idx) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    pl->events.push_back(e);
+  }
+  return pl->events[idx];
+}
+
+// Ops run in list order on `st`; a run of consecutive branch-1 ops is forked onto the plan's side stream behind the main op that
+// precedes it (event record / wait) and main continues with the ops after the run; the side stream is joined back into `st` at
+// the end of the range.  The host (engine.py) marks only ops whose inputs are complete at the fork point and whose outputs no
+// later op of the range reads.  Under stream capture the same calls become the fork / join edges of the graph.
+extern "C" int y5_plan_run_range(y5_plan* pl, int first, int last, void* st_) {
   if (!pl || first < 0 || last > (int)pl->ops.size() || first > last) return y5_fail(Y5_ERR_BAD_ARG, "plan_run_range: bad range");
+  hipStream_t st = static_cast<hipStream_t>(st_);
+  size_t nev = 0;
+  bool used_side = false;
   for (int k = first; k < last; ++k) {
-    const int rc = run_op(pl->ops[k], st);
-    if (rc) return rc;
+    const Op& o = pl->ops[k];
+    if (o.branch == 1) {
+      if (!pl->side && hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking) != hipSuccess) return y5_fail(Y5_ERR_RUNTIME, "plan: side stream create failed");
+      if (k == first || pl->ops[k - 1].branch == 0) {
+        hipEvent_t e = plan_event(pl, nev++);
+        if (!e || hipEventRecord(e, st) != hipSuccess || hipStreamWaitEvent(pl->side, e, 0) != hipSuccess) return y5_fail(Y5_ERR_RUNTIME, "plan: fork failed");
+      }
+      used_side = true;
+      const int rc = run_op(o, pl->side);
+      if (rc) return rc;
+    } else {
+      const int rc = run_op(o, st_);
+      if (rc) return rc;
+    }
+  }
+  if (used_side) {
+    hipEvent_t e = plan_event(pl, nev++);
+    if (!e || hipEventRecord(e, pl->side) != hipSuccess || hipStreamWaitEvent(st, e, 0) != hipSuccess) return y5_fail(Y5_ERR_RUNTIME, "plan: join failed");
   }
   return Y5_OK;
 }

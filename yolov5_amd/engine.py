@@ -237,7 +237,53 @@ class _Planner:
                 out[i] = buf
             elif isinstance(m, yo.Detect):
                 self.detect(m, ins)
+        if os.environ.get("Y5_HEAD_BRANCH", "1") != "0":
+            self._schedule_heads()
         return spec
+
+    def _schedule_heads(self):
+        """The Detect convolution + decode of every pyramid level but the last (and the Segment prototype branch) depend only on
+        one feature map and feed nothing but the final output (models/yolo.py:83-108,141-149 run them after the whole neck only
+        because Detect is the last module).  They are moved right behind the op that completes their input and marked `side`: the
+        plan runs them on its second stream (y5_plan_set_branch) -- HBM-bound head work overlapped with the tail of the neck."""
+        ops = self.spec.ops
+        groups = {}  # group key -> op indices (in order); keys: "proto", 0, 1, ... (pyramid level)
+        for j, op in enumerate(ops):
+            if "head" in op:
+                groups.setdefault(op["head"], []).append(j)
+        levels = [k for k in groups if k != "proto"]
+        if len(levels) < 2:
+            return
+        last = max(levels)
+        head_ops = {j for idx in groups.values() for j in idx}
+
+        def writes(op, t):
+            outs = [op.get(k) for k in ("y", "y2", "dst", "buf")]
+            return any(hasattr(o, "buf") and o.buf == t.buf and o.c_off < t.c_off + t.C and t.c_off < o.c_off + o.C for o in outs)
+
+        moved, after = set(), {}
+        for key, idx in groups.items():
+            if key == last:
+                continue
+            x = ops[idx[0]]["x"] if "x" in ops[idx[0]] else None
+            if x is None:
+                continue
+            prod = max((p for p in range(idx[0]) if p not in head_ops and writes(ops[p], x)), default=None)
+            if prod is None:
+                continue
+            after.setdefault(prod, []).extend(idx)
+            moved.update(idx)
+        if not moved:
+            return
+        new = []
+        for j, op in enumerate(ops):
+            if j in moved:
+                continue
+            new.append(op)
+            for k in after.get(j, ()):
+                ops[k]["side"] = True
+                new.append(ops[k])
+        self.spec.ops[:] = new
 
     def detect(self, m, xs):
         spec = self.spec
@@ -247,12 +293,16 @@ class _Planner:
         nrows = sum(na * x.H * x.W for x in xs)
         spec.outputs["z"] = dict(shape=(B, nrows, no))
         if isinstance(m, self.yo.Segment):
+            n0 = len(spec.ops)
             p = self.proto(m.proto, xs[0])
             spec.ops.append(dict(op="to_nchw", src=p, out="proto"))
             spec.outputs["proto"] = dict(shape=(B, p.C, p.H, p.W))
+            for op in spec.ops[n0:]:
+                op["head"] = "proto"
         row_off = 0
         for i, x in enumerate(xs):
             npad = (na * no + 31) // 32 * 32
+            n0 = len(spec.ops)
             lg = self.conv([m.m[i]], x, None, act=False, name=f"detect.m{i}", c2_store=npad)
             raw = None
             if self.want_raw:
@@ -260,6 +310,8 @@ class _Planner:
                 spec.outputs[raw] = dict(shape=(B, na, x.H, x.W, no))
             spec.ops.append(dict(op="decode", x=lg, level=i, ny=x.H, nx=x.W, na=na, no=no, nm=nm, row_off=row_off,
                                  nrows=nrows, raw=raw))
+            for op in spec.ops[n0:]:
+                op["head"] = i
             row_off += na * x.H * x.W
 
 
@@ -458,6 +510,8 @@ class Engine:
         with torch.no_grad():
             for op in self.spec.ops:
                 self._add(op)
+                if op.get("side"):
+                    _lib.check(self.lib.y5_plan_set_branch(self.plan, self.lib.y5_plan_size(self.plan) - 1, 1), self.lib)
             if self._stem_args is not None:
                 wp, bp, c2, npad, y = self._stem_args
                 self._stem = self.lib.y5_plan_size(self.plan)
