@@ -69,3 +69,28 @@ def test_plan_is_concat_free_for_shipped_models():
         kinds = [o["op"] for o in spec.ops]
         assert "copy" not in kinds and "upsample" not in kinds  # every concat / upsample is a fused store
         assert kinds.count("sppf_pool") == 1 and kinds.count("decode") == 3
+
+
+def test_head_side_branch_schedule(monkeypatch):
+    """engine._Planner._schedule_heads: the Detect heads of the lower pyramid levels (and the Segment proto branch) sit right behind
+    the op that completes their input and are marked for the plan's side stream; same ops, same results as the single-stream order."""
+    for name, M in (("yolov5n", DetectionModel), ("yolov5n-seg", SegmentationModel)):
+        m = det_model(name, 0, True)
+        monkeypatch.setenv("Y5_HEAD_BRANCH", "0")
+        flat = build_plan_spec(m, 2, 3, 64, 64)
+        monkeypatch.setenv("Y5_HEAD_BRANCH", "1")
+        br = build_plan_spec(m, 2, 3, 64, 64)
+        key = lambda o: (o["op"], o.get("name"), o.get("level"))  # noqa: E731
+        assert sorted(map(key, flat.ops), key=str) == sorted(map(key, br.ops), key=str)
+        assert not any(o.get("side") for o in flat.ops)
+        side = [i for i, o in enumerate(br.ops) if o.get("side")]
+        assert side and all(br.ops[i]["head"] != 2 for i in side)  # the last level stays on the main stream
+        for i in side:
+            if not br.ops[i - 1].get("side"):  # fork point: the previous op wrote this op's input
+                prev, x = br.ops[i - 1], br.ops[i]["x"]
+                assert prev["y"].buf == x.buf
+        x = torch.from_numpy(detgen.uniform((2, 3, 64, 64), 0.0, 1.0, name="img", seed=0))
+        a = Engine(m, (2, 3, 64, 64), torch.float32, "cpu", backend=EmuBackend(), spec=flat)(x)
+        b = Engine(m, (2, 3, 64, 64), torch.float32, "cpu", backend=EmuBackend(), spec=br)(x)
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (name, k)
