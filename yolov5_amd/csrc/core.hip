@@ -67,6 +67,7 @@ struct y5_plan {
   hipGraphExec_t exec = nullptr;
   hipStream_t side = nullptr;        // side-branch stream (y5_plan_set_branch), created on first use
   std::vector<hipEvent_t> events;    // fork / join markers, one per fork point of a run + one join
+  bool flat = false;                 // run every op on the caller's stream (per-op timing: no fork / join latency in the figure)
 };
 
 extern "C" y5_plan* y5_plan_create(void) { return new y5_plan(); }
@@ -192,7 +193,7 @@ extern "C" int y5_plan_run_range(y5_plan* pl, int first, int last, void* st_) {
   bool used_side = false;
   for (int k = first; k < last; ++k) {
     const Op& o = pl->ops[k];
-    if (o.branch == 1) {
+    if (o.branch == 1 && !pl->flat) {
       if (!pl->side && hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking) != hipSuccess) return y5_fail(Y5_ERR_RUNTIME, "plan: side stream create failed");
       if (k == first || pl->ops[k - 1].branch == 0) {
         hipEvent_t e = plan_event(pl, nev++);
@@ -253,6 +254,7 @@ extern "C" int y5_plan_time_range(y5_plan* pl, int first, int last, int iters, v
   hipStream_t st = static_cast<hipStream_t>(st_);
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return y5_fail(Y5_ERR_RUNTIME, "event create failed");
+  pl->flat = true;  // kernels timed on `st` itself
   int rc = y5_plan_run_range(pl, first, last, st_);  // warm-up
   if (!rc) {
     hipEventRecord(e0, st);
@@ -261,6 +263,7 @@ extern "C" int y5_plan_time_range(y5_plan* pl, int first, int last, int iters, v
     if (hipEventSynchronize(e1) != hipSuccess) rc = y5_fail(Y5_ERR_RUNTIME, "event sync failed");
     else hipEventElapsedTime(ms, e0, e1);
   }
+  pl->flat = false;
   hipEventDestroy(e0);
   hipEventDestroy(e1);
   return rc;
