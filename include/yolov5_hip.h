@@ -57,12 +57,13 @@ typedef struct {
   int out_mul_h, out_mul_w, out_off_h, out_off_w, out_H, out_W;
 } y5_conv_desc;
 
-#define Y5_CONV_NUM_CFGS 56   /* 0..13 implicit-GEMM tiles (2 LDS stages), 14..21 streaming pointwise (1x1 s1, fp16),
+#define Y5_CONV_NUM_CFGS 57   /* 0..13 implicit-GEMM tiles (2 LDS stages), 14..21 streaming pointwise (1x1 s1, fp16),
                                 22..29 implicit-GEMM tiles with a 3-stage LDS ring (fp16), 30..34 streaming 3x3 (small C, fp16),
                                 35..39 256-row implicit-GEMM tiles with 2-4 stage rings, 4 or 8 waves (fp16, deep layers),
                                 40..45 producer/consumer implicit GEMM: 4 MFMA waves + 4 LDS-DMA waves per workgroup (fp16),
                                 46..49 high-occupancy 2-stage tiles (epilogue scratch inside the idle ring stage, fp16),
-                                50..55 tiles 320 / 160 / 192 / 96 channels wide (yolov5x / yolov5m channel counts, fp16) */
+                                50..55 tiles 320 / 160 / 192 / 96 channels wide (yolov5x / yolov5m channel counts, fp16),
+                                56 streaming pointwise 128 -> 256 channels, epilogue in two channel groups (P3 Detect head, fp16) */
 int y5_conv_num_cfgs(void);
 int y5_conv_cfg_info(int cfg, int* bm_pixels, int* bn_channels, int* k_bytes_per_stage);
 

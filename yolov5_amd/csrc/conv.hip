@@ -173,7 +173,8 @@ int launch_by_cfg(const Y5ConvParams& p, int cfg, int mb, hipStream_t s) {
 
 // ---- streaming pointwise configurations (conv_pw.h): id = kNumIgemm + index ---------------------------------
 struct PwCfg { int kc, rb, nt, s; };
-constexpr int kNumPw = 8;
+constexpr int kNumPw = 9;
+constexpr int kPw2_0 = 56;  // pointwise configurations added after the id space was laid out: ids 56.. = kPwCfgs[8..]
 constexpr PwCfg kPwCfgs[kNumPw] = {
     {1, 64, 1, 4},   // 14:  32 ->  32, 4 stages
     {1, 128, 1, 4},  // 15:  64 ->  32
@@ -183,13 +184,14 @@ constexpr PwCfg kPwCfgs[kNumPw] = {
     {2, 128, 4, 3},  // 19: 128 -> 128
     {2, 128, 4, 2},  // 20: 128 -> 128, 2 stages
     {2, 128, 2, 4},  // 21: 128 ->  64, 4 stages
+    {2, 128, 8, 2},  // 56: 128 -> 256 (the P3 Detect head), epilogue in two channel groups
 };
 
-template <int KC, int RB, int NT, int S, bool UP2, bool ACT>
+template <int KC, int RB, int NT, int S, bool UP2, bool ACT, int OS = 1>
 int launch_pw_v(const Y5ConvParams& p, int max_blocks, hipStream_t stream) {
-  const size_t lds = y5_conv_pw_lds_bytes<KC, RB, NT, S>();
+  const size_t lds = y5_conv_pw_lds_bytes<KC, RB, NT, S, OS>();
   if (lds > 160 * 1024) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: pointwise configuration exceeds 160 KiB of LDS");
-  auto kern = y5_conv_pw_kernel<KC, RB, NT, S, UP2, ACT>;
+  auto kern = y5_conv_pw_kernel<KC, RB, NT, S, UP2, ACT, OS>;
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -213,10 +215,14 @@ int launch_pw_v(const Y5ConvParams& p, int max_blocks, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(256), lds, stream, p);
   return y5_check_launch("y5_conv2d_fwd(pw)");
 }
-template <int KC, int RB, int NT, int S>
+template <int KC, int RB, int NT, int S, int OS = 1>
 int launch_pw(const Y5ConvParams& p, int mb, hipStream_t st) {
-  if (p.y2) return p.act ? launch_pw_v<KC, RB, NT, S, true, true>(p, mb, st) : launch_pw_v<KC, RB, NT, S, true, false>(p, mb, st);
-  return p.act ? launch_pw_v<KC, RB, NT, S, false, true>(p, mb, st) : launch_pw_v<KC, RB, NT, S, false, false>(p, mb, st);
+  if constexpr (OS == 1) {
+    if (p.y2) return p.act ? launch_pw_v<KC, RB, NT, S, true, true>(p, mb, st) : launch_pw_v<KC, RB, NT, S, true, false>(p, mb, st);
+  } else {
+    if (p.y2) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: split-epilogue pointwise configuration has no upsampled replica");
+  }
+  return p.act ? launch_pw_v<KC, RB, NT, S, false, true, OS>(p, mb, st) : launch_pw_v<KC, RB, NT, S, false, false, OS>(p, mb, st);
 }
 
 int launch_pw_by_cfg(const Y5ConvParams& p, int idx, int mb, hipStream_t s) {
@@ -229,6 +235,7 @@ int launch_pw_by_cfg(const Y5ConvParams& p, int idx, int mb, hipStream_t s) {
     case 5: return launch_pw<2, 128, 4, 3>(p, mb, s);
     case 6: return launch_pw<2, 128, 4, 2>(p, mb, s);
     case 7: return launch_pw<2, 128, 2, 4>(p, mb, s);
+    case 8: return launch_pw<2, 128, 8, 2, 2>(p, mb, s);
   }
   return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown pointwise config");
 }
@@ -305,6 +312,13 @@ extern "C" int y5_conv_num_cfgs(void) { return Y5_CONV_NUM_CFGS; }
 
 extern "C" int y5_conv_cfg_info(int cfg, int* bm, int* bn, int* bk_bytes) {
   if (cfg < 0 || cfg >= Y5_CONV_NUM_CFGS) return y5_fail(Y5_ERR_BAD_ARG, "conv_cfg_info: bad id");
+  if (cfg >= kPw2_0) {
+    const PwCfg& c = kPwCfgs[8 + cfg - kPw2_0];
+    if (bm) *bm = 128;
+    if (bn) *bn = c.nt * 32;
+    if (bk_bytes) *bk_bytes = c.kc * c.rb;
+    return Y5_OK;
+  }
   if (cfg >= kBig0) {
     const BigCfg& c = kBigCfgs[cfg - kBig0];
     if (bm) *bm = c.wm * c.tm * 32;
@@ -342,9 +356,10 @@ extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w
   const int epp = 16 / es;
   int cfg = d->cfg < 0 ? default_cfg(d) : d->cfg;
   if (cfg >= Y5_CONV_NUM_CFGS) return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown tile config");
-  const bool pw = cfg >= kNumIgemm && cfg < kRing0;
-  const bool big = cfg >= kBig0;
-  const bool k3 = cfg >= kK3_0 && !big;
+  const bool pw = (cfg >= kNumIgemm && cfg < kRing0) || cfg >= kPw2_0;
+  const int pwi = cfg >= kPw2_0 ? 8 + cfg - kPw2_0 : cfg - kNumIgemm;
+  const bool big = cfg >= kBig0 && cfg < kPw2_0;
+  const bool k3 = cfg >= kK3_0 && cfg < kBig0;
   const int bk = (pw || k3) ? 8 : (big ? kBigCfgs[cfg - kBig0].rb : kCfgs[cfg >= kRing0 ? kRingBase[cfg - kRing0] : cfg].rb) / es;
   if (cfg >= kRing0 && d->dtype != Y5_F16) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: ring configurations are fp16 only");
   if (d->C1 % epp || d->ldx % epp) return y5_fail(Y5_ERR_BAD_ARG, "conv: C1 and ldx must be multiples of 16 bytes");
@@ -387,11 +402,11 @@ extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w
     return launch_k3_by_cfg(p, cfg - kK3_0, d->max_blocks, stream);
   }
   if (pw) {
-    const PwCfg& c = kPwCfgs[cfg - kNumIgemm];
+    const PwCfg& c = kPwCfgs[pwi];
     if (d->dtype != Y5_F16 || d->KH != 1 || d->KW != 1 || d->SH != 1 || d->SW != 1 || d->PH || d->PW || residual || !y ||
         d->C1 != c.kc * c.rb / 2 || d->Npad != c.nt * 32 || (p.M & 31) || d->Kpad * 2 < c.kc * c.rb)
       return y5_fail(Y5_ERR_UNSUPPORTED, "conv: pointwise configuration does not match this layer");
-    return launch_pw_by_cfg(p, cfg - kNumIgemm, d->max_blocks, stream);
+    return launch_pw_by_cfg(p, pwi, d->max_blocks, stream);
   }
   const bool table = (d->C1 % bk) != 0 || d->KH * d->KW > 32;  // uniform mode keeps a 32-bit tap-validity mask per row
   if (d->dtype == Y5_F16)

@@ -15,30 +15,34 @@
 #pragma once
 #include "conv_igemm.h"
 
-template <int KC, int RB, int NT, int S>
+template <int KC, int RB, int NT, int S, int OS = 1>
 constexpr size_t y5_conv_pw_lds_bytes() {
   constexpr int NPAD = 32 * NT;
-  constexpr int STAGE_A = 32 * KC * RB, STAGE_O = 32 * NPAD * 2;
+  constexpr int STAGE_A = 32 * KC * RB, STAGE_O = 32 * NPAD * 2 / OS;
   constexpr int STAGE = STAGE_A > STAGE_O ? STAGE_A : STAGE_O;
   return (size_t)KC * NPAD * RB + (size_t)NPAD * 4 + (size_t)4 * S * STAGE;
 }
 
-template <int KC, int RB, int NT, int S, bool UP2, bool ACT = true>
+// OS > 1 (wide outputs, e.g. the 255-channel Detect heads): the epilogue leaves in OS channel groups of NT/OS sub-tiles each, so
+// that the transposition scratch is not larger than an input stage and filter + rings still fit the 160 KB of LDS.
+template <int KC, int RB, int NT, int S, bool UP2, bool ACT = true, int OS = 1>
 __global__ __launch_bounds__(256)
 void y5_conv_pw_kernel(const Y5ConvParams p) {
   typedef half_t T;
+  static_assert(NT % OS == 0, "output split must divide the channel sub-tiles");
   constexpr int NPAD = 32 * NT;
+  constexpr int NTH = NT / OS, NPH = 32 * NTH;  // channel sub-tiles / channels per epilogue group
   constexpr int NSLOT = RB / 16;          // 16-byte slots per LDS row of a K chunk
   constexpr int RPI = 1024 / RB;          // rows per LDS-DMA instruction
   constexpr int QN = 32 / RPI;            // instructions per chunk of a 32-row tile
-  constexpr int STAGE_A = 32 * KC * RB, STAGE_O = 32 * NPAD * 2;
+  constexpr int STAGE_A = 32 * KC * RB, STAGE_O = 32 * NPH * 2;
   constexpr int STAGE = STAGE_A > STAGE_O ? STAGE_A : STAGE_O;
   constexpr int W_BYTES = KC * NPAD * RB;
   constexpr int LP = KC * QN;                               // loads per tile per wave
-  constexpr int SPR = NPAD / 8;                             // 16-byte slots per output row
+  constexpr int SPR = NPH / 8;                              // 16-byte slots per output row (of one epilogue group)
   constexpr int RPP = 64 / SPR;                             // output rows per store pass
   constexpr int NPASS = 32 / RPP;
-  constexpr int SP = NPASS * (UP2 ? 5 : 1);                 // stores per tile per wave
+  constexpr int SP = NPASS * OS * (UP2 ? 5 : 1);            // stores per tile per wave
   constexpr int SWM = SPR >= 8 ? 7 : SPR - 1;               // scratch swizzle mask
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -141,48 +145,51 @@ void y5_conv_pw_kernel(const Y5ConvParams p) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[j] += acc2[j];
     }
-    // ---- epilogue: bias + act -> scratch (the vacated stage) -> full-row stores ----
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4_t bv = *reinterpret_cast<const float4_t*>(blds + j * 32 + q * 8 + g * 4);
-        half4_t o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float t = acc[j][q * 4 + e] + bv[e];
-          o[e] = (half_t)(ACT ? y5_silu(t) : t);
-        }
-        const int slot = j * 4 + q;
-        *reinterpret_cast<half4_t*>(st + frow * (NPAD * 2) + ((slot ^ (frow & SWM)) * 16) + g * 8) = o;
-      }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();  // lanes exchange data through the scratch: keep LDS writes before the reads
+    // ---- epilogue: bias + act -> scratch (the vacated stage) -> full-row stores, one channel group at a time ----
     const int m0 = tile_m0(i);
 #pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-      const int row = ps * RPP + orow;
-      const uint4_t raw = *reinterpret_cast<const uint4_t*>(st + row * (NPAD * 2) + ((oslot ^ (row & SWM)) * 16));
-      const int m = m0 + row, n = oslot * 8;
-      if (n < p.C2) {
-        *reinterpret_cast<uint4_t*>(yg + (size_t)m * p.ldy + n) = raw;
-        if constexpr (UP2) {
-          const int ohw = p.OH * p.OW;
-          const int b = m / ohw;
-          const int r = m - b * ohw;
-          const int oh = r / p.OW, ow = r - oh * p.OW;
-          const size_t row0 = ((size_t)b * 2 * p.OH + 2 * oh) * (2 * p.OW) + 2 * ow;
-          T* d0 = y2g + row0 * p.ld2 + n;
-          T* d1 = y2g + (row0 + 2 * p.OW) * p.ld2 + n;
-          *reinterpret_cast<uint4_t*>(d0) = raw;
-          *reinterpret_cast<uint4_t*>(d0 + p.ld2) = raw;
-          *reinterpret_cast<uint4_t*>(d1) = raw;
-          *reinterpret_cast<uint4_t*>(d1 + p.ld2) = raw;
+    for (int h = 0; h < OS; ++h) {
+#pragma unroll
+      for (int j = 0; j < NTH; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4_t bv = *reinterpret_cast<const float4_t*>(blds + (h * NTH + j) * 32 + q * 8 + g * 4);
+          half4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float t = acc[h * NTH + j][q * 4 + e] + bv[e];
+            o[e] = (half_t)(ACT ? y5_silu(t) : t);
+          }
+          const int slot = j * 4 + q;
+          *reinterpret_cast<half4_t*>(st + frow * (NPH * 2) + ((slot ^ (frow & SWM)) * 16) + g * 8) = o;
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();  // lanes exchange data through the scratch: keep LDS writes before the reads
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int row = ps * RPP + orow;
+        const uint4_t raw = *reinterpret_cast<const uint4_t*>(st + row * (NPH * 2) + ((oslot ^ (row & SWM)) * 16));
+        const int m = m0 + row, n = h * NPH + oslot * 8;
+        if (n < p.C2) {
+          *reinterpret_cast<uint4_t*>(yg + (size_t)m * p.ldy + n) = raw;
+          if constexpr (UP2) {
+            const int ohw = p.OH * p.OW;
+            const int b = m / ohw;
+            const int r = m - b * ohw;
+            const int oh = r / p.OW, ow = r - oh * p.OW;
+            const size_t row0 = ((size_t)b * 2 * p.OH + 2 * oh) * (2 * p.OW) + 2 * ow;
+            T* d0 = y2g + row0 * p.ld2 + n;
+            T* d1 = y2g + (row0 + 2 * p.OW) * p.ld2 + n;
+            *reinterpret_cast<uint4_t*>(d0) = raw;
+            *reinterpret_cast<uint4_t*>(d0 + p.ld2) = raw;
+            *reinterpret_cast<uint4_t*>(d1) = raw;
+            *reinterpret_cast<uint4_t*>(d1 + p.ld2) = raw;
+          }
         }
       }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();  // the scratch is rewritten by the next group / refilled by the next tile's loads
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
     // ---- refill the vacated stage with tile i+S ----
     if (i + S < nw) issue(i + S, buf);
     buf = buf + 1 == S ? 0 : buf + 1;
