@@ -122,6 +122,16 @@ int y5_detect_decode(const void* logits, int dtype, int B, int ny, int nx, int n
                      long long row_off, void* raw, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * y5_detect_head_fwd -- one pyramid level of `Detect.forward` in export / z-only mode (models/yolo.py:83-108 with
+ * models/common.py:866): the 1x1 convolution `self.m[i]` (descriptor `d`: fp16, C1 = 128, 3 x 85 output channels stored as
+ * Npad = 256, act = 0) and the decode of y5_detect_decode in one pass -- the logits are never written.  z rows as in
+ * y5_detect_decode (fp16); ny*nx % 32 == 0, nrows_total / row_off / ny*nx multiples of 8.  Bit-identical to the two-call form.
+ * Y5_ERR_UNSUPPORTED for any other shape (callers keep y5_conv2d_fwd + y5_detect_decode).
+ * ------------------------------------------------------------------------------------------------------- */
+int y5_detect_head_fwd(const y5_conv_desc* d, const void* x, const void* w_packed, const float* bias, int ny, int nx, float stride,
+                       const float* anchors_px, void* z, long long nrows_total, long long row_off, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * y5_nms_batched -- utils/general.py:658-767 `non_max_suppression` incl. torchvision.ops.nms (general.py:750).
  * pred: (bs, n, no) f16|f32, no = 5 + nc + nm.  All arithmetic is fp32 on the fp32 value of each element.
  * out:       (bs, max_det, 6+nm) fp32 rows [x1,y1,x2,y2,conf,cls,(mask..)] in descending-confidence order
@@ -302,6 +312,9 @@ y5_plan* y5_plan_create(void);
 void y5_plan_destroy(y5_plan*);
 int y5_plan_add_conv(y5_plan*, const y5_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                      const void* residual, void* y, void* y_up2);
+int y5_plan_add_detect_head(y5_plan*, const y5_conv_desc* d, const void* x, const void* w_packed, const float* bias, int ny, int nx,
+                            float stride, const float* anchors_px, void* z, long long nrows_total, long long row_off);
+int y5_plan_add_nop(y5_plan*);  /* placeholder op: keeps the op numbering of the conv + decode form next to a fused head */
 int y5_plan_add_conv_stem(y5_plan*, const void* x_nchw, int B, int H, int W, const void* w_stem, const float* bias, int C2,
                           int Npad, void* y, int ldy);
 int y5_plan_set_input(y5_plan*, int op_index, const void* src);  /* re-point a stem / nchw_to_nhwc op at a new input batch */

@@ -120,6 +120,11 @@ EXPORTS = {
                                    C.c_void_p, C.c_void_p]),
     "y5_plan_add_conv_stem": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                         C.c_void_p, C.c_int]),
+    "y5_detect_head_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_float),
+                                     C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p]),
+    "y5_plan_add_detect_head": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
+                                          C.POINTER(C.c_float), C.c_void_p, C.c_longlong, C.c_longlong]),
+    "y5_plan_add_nop": (C.c_int, [C.c_void_p]),
     "y5_plan_set_input": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "y5_plan_set_branch": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "y5_plan_add_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,

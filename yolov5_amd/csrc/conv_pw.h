@@ -25,9 +25,19 @@ constexpr size_t y5_conv_pw_lds_bytes() {
 
 // OS > 1 (wide outputs, e.g. the 255-channel Detect heads): the epilogue leaves in OS channel groups of NT/OS sub-tiles each, so
 // that the transposition scratch is not larger than an input stage and filter + rings still fit the 160 KB of LDS.
-template <int KC, int RB, int NT, int S, bool UP2, bool ACT = true, int OS = 1>
-__global__ __launch_bounds__(256)
-void y5_conv_pw_kernel(const Y5ConvParams p) {
+// Parameters of the fused Detect-head epilogue (DEC): the tile's logits never reach HBM; they are decoded
+// (models/yolo.py:102-111, same arithmetic as y5_detect_decode_kernel's z-only path) and leave as the z rows of the three anchors.
+struct Y5HeadParams {
+  void* z;                 // (B, nrows_total, 85) fp16
+  long long nrows_total, row_off;
+  int npix, nx;            // pixels per image (multiple of 32), grid width
+  unsigned inv_nx;         // ceil(2^32 / nx)
+  float stride;
+  float anchors_px[6];     // 3 anchors x (w, h) in pixels
+};
+
+template <int KC, int RB, int NT, int S, bool UP2, bool ACT, int OS, bool DEC>
+__device__ __forceinline__ void y5_conv_pw_body(const Y5ConvParams& p, const Y5HeadParams* hp) {
   typedef half_t T;
   static_assert(NT % OS == 0, "output split must divide the channel sub-tiles");
   constexpr int NPAD = 32 * NT;
@@ -42,7 +52,7 @@ void y5_conv_pw_kernel(const Y5ConvParams p) {
   constexpr int SPR = NPH / 8;                              // 16-byte slots per output row (of one epilogue group)
   constexpr int RPP = 64 / SPR;                             // output rows per store pass
   constexpr int NPASS = 32 / RPP;
-  constexpr int SP = NPASS * OS * (UP2 ? 5 : 1);            // stores per tile per wave
+  constexpr int SP = DEC ? 3 * ((32 * 85 / 8 + 63) / 64) : NPASS * OS * (UP2 ? 5 : 1);  // stores per tile per wave
   constexpr int SWM = SPR >= 8 ? 7 : SPR - 1;               // scratch swizzle mask
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -147,6 +157,67 @@ void y5_conv_pw_kernel(const Y5ConvParams p) {
     }
     // ---- epilogue: bias + act -> scratch (the vacated stage) -> full-row stores, one channel group at a time ----
     const int m0 = tile_m0(i);
+    if constexpr (DEC) {
+      // Fused Detect head (3 anchors x 85 outputs = channels 0..254 of the 256-channel tile).  Per anchor a: every lane drops the
+      // values of its pixel (frow) whose channel lies in [85a, 85a + 85) into the scratch at [pixel][o] -- the fp16-rounded logit
+      // for the four box outputs, sigmoid(logit) otherwise -- lanes 0..31 then turn the four box logits of their pixel into
+      // xy / wh exactly as the decode kernel does, and the 32 x 85 halfs leave as 340 16-byte stores into the anchor's z rows.
+      constexpr int NO = 85;
+      static_assert(NT == 8 && STAGE >= 32 * NO * 2, "fused head: 256-channel tile, scratch of 32 x 85 halfs");
+      const Y5HeadParams& hd = *hp;
+      const int bimg = m0 / hd.npix;
+      const int pix0 = m0 - bimg * hd.npix;
+      half_t* sc = reinterpret_cast<half_t*>(st);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          if (j * 32 + 31 < NO * a || j * 32 >= NO * a + NO) continue;  // sub-tile outside this anchor's channels
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int n0 = j * 32 + q * 8;  // this lane's channels: n0 + g*4 + e
+            if (n0 + 7 < NO * a || n0 >= NO * a + NO) continue;
+            const float4_t bv = *reinterpret_cast<const float4_t*>(blds + j * 32 + q * 8 + g * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int o = n0 + g * 4 + e - NO * a;
+              const half_t v16 = (half_t)(acc[j][q * 4 + e] + bv[e]);   // the logit as the unfused path stores it
+              const float v = (float)v16;
+              const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+              const half_t val = o < 4 ? v16 : (half_t)sg;
+              if (o >= 0 && o < NO) sc[frow * NO + o] = val;
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 32) {
+          const int pix = pix0 + lane;
+          const int iy = (int)__umulhi((unsigned)pix, hd.inv_nx), ix = pix - iy * hd.nx;
+          half_t* qv = sc + lane * NO;
+          const float gx = (float)ix - 0.5f, gy = (float)iy - 0.5f;
+          const float aw = hd.anchors_px[a * 2], ah = hd.anchors_px[a * 2 + 1];
+          float s2[4];
+#pragma unroll
+          for (int o = 0; o < 4; ++o) s2[o] = __builtin_amdgcn_rcpf(1.0f + __expf(-(float)qv[o])) * 2.0f;
+          qv[0] = (half_t)((s2[0] + gx) * hd.stride);   // yolo.py:110
+          qv[1] = (half_t)((s2[1] + gy) * hd.stride);
+          qv[2] = (half_t)(s2[2] * s2[2] * aw);         // yolo.py:111
+          qv[3] = (half_t)(s2[3] * s2[3] * ah);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        half_t* zrow = static_cast<half_t*>(hd.z) + ((long long)bimg * hd.nrows_total + hd.row_off + (long long)a * hd.npix + pix0) * NO;
+        constexpr int NV = 32 * NO / 8;  // 16-byte vectors per anchor block
+#pragma unroll
+        for (int it = 0; it < (NV + 63) / 64; ++it) {
+          const int v = it * 64 + lane;
+          if (v < NV) *reinterpret_cast<uint4_t*>(zrow + v * 8) = *reinterpret_cast<const uint4_t*>(sc + v * 8);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // the scratch is rewritten by the next anchor / refilled by the next tile's loads
+      }
+    } else
 #pragma unroll
     for (int h = 0; h < OS; ++h) {
 #pragma unroll
@@ -194,4 +265,17 @@ void y5_conv_pw_kernel(const Y5ConvParams p) {
     if (i + S < nw) issue(i + S, buf);
     buf = buf + 1 == S ? 0 : buf + 1;
   }
+}
+
+template <int KC, int RB, int NT, int S, bool UP2, bool ACT = true, int OS = 1>
+__global__ __launch_bounds__(256)
+void y5_conv_pw_kernel(const Y5ConvParams p) {
+  y5_conv_pw_body<KC, RB, NT, S, UP2, ACT, OS, false>(p, nullptr);
+}
+
+// 1x1 Detect convolution (128 -> 3 x 85 channels) + Detect decode in one pass (export / z-only mode)
+template <int KC, int RB, int NT, int S, int OS>
+__global__ __launch_bounds__(256)
+void y5_conv_pw_head_kernel(const Y5ConvParams p, const Y5HeadParams h) {
+  y5_conv_pw_body<KC, RB, NT, S, false, false, OS, true>(p, &h);
 }

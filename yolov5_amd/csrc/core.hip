@@ -48,7 +48,7 @@ extern "C" const char* y5_last_error(void) { return g_err.c_str(); }
 // ---------------------------------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------------------------------
-enum OpKind { OP_CONV, OP_TO_NHWC, OP_SPPF, OP_UPS, OP_COPY, OP_DECODE, OP_TO_NCHW, OP_STEM };
+enum OpKind { OP_CONV, OP_TO_NHWC, OP_SPPF, OP_UPS, OP_COPY, OP_DECODE, OP_TO_NCHW, OP_STEM, OP_HEAD, OP_NOP };
 
 struct Op {
   OpKind kind;
@@ -136,6 +136,24 @@ extern "C" int y5_plan_add_detect_decode(y5_plan* pl, const void* logits, int dt
   return Y5_OK;
 }
 
+// fused Detect head (head.hip): the convolution `d` + the decode of one level; y5_plan_add_nop keeps the op numbering of the
+// two-op form (convolution, decode) so that a plan built either way has the same indices
+extern "C" int y5_plan_add_detect_head(y5_plan* pl, const y5_conv_desc* d, const void* x, const void* w, const float* bias, int ny, int nx,
+                                       float stride, const float* anchors_px, void* z, long long nrows_total, long long row_off) {
+  if (!pl || !d || !anchors_px) return y5_fail(Y5_ERR_BAD_ARG, "plan_add_detect_head: null");
+  Op o{}; o.kind = OP_HEAD; o.conv = *d; o.p0 = x; o.p1 = w; o.p2 = bias; o.q0 = z;
+  o.i[0] = ny; o.i[1] = nx; o.f[0] = stride; o.l[0] = nrows_total; o.l[1] = row_off;
+  for (int k = 0; k < 6; ++k) o.anchors[k] = anchors_px[k];
+  pl->ops.push_back(o);
+  return Y5_OK;
+}
+extern "C" int y5_plan_add_nop(y5_plan* pl) {
+  if (!pl) return y5_fail(Y5_ERR_BAD_ARG, "plan: null");
+  Op o{}; o.kind = OP_NOP;
+  pl->ops.push_back(o);
+  return Y5_OK;
+}
+
 extern "C" int y5_plan_add_conv_stem(y5_plan* pl, const void* x_nchw, int B, int H, int W, const void* w_stem, const float* bias,
                                      int C2, int Npad, void* y, int ldy) {
   if (!pl) return y5_fail(Y5_ERR_BAD_ARG, "plan: null");
@@ -160,6 +178,9 @@ static int run_op(const Op& o, void* st) {
     case OP_SPPF: return y5_sppf_pool(o.q0, o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], o.i[6], st);
     case OP_UPS: return y5_upsample2x(o.p0, o.i[0], o.q0, o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], o.i[6], st);
     case OP_COPY: return y5_copy_slice(o.p0, o.i[0], o.q0, o.i[1], o.i[2], o.i[3], o.i[4], st);
+    case OP_HEAD:
+      return y5_detect_head_fwd(&o.conv, o.p0, o.p1, (const float*)o.p2, o.i[0], o.i[1], o.f[0], o.anchors, o.q0, o.l[0], o.l[1], st);
+    case OP_NOP: return Y5_OK;
     case OP_DECODE:
       return y5_detect_decode(o.p0, o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], o.i[6], o.i[7], o.f[0], o.anchors, o.q0, o.i[8],
                               o.l[0], o.l[1], o.q1, st);

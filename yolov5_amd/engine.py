@@ -508,7 +508,9 @@ class Engine:
         self._stem = None      # plan index of the fused NCHW stem op (conv_stem.h), appended after the regular ops
         self._stem_args = None
         with torch.no_grad():
-            for op in self.spec.ops:
+            self._fused_heads = set()
+            for k, op in enumerate(self.spec.ops):
+                self._cur = k
                 self._add(op)
                 if op.get("side"):
                     _lib.check(self.lib.y5_plan_set_branch(self.plan, self.lib.y5_plan_size(self.plan) - 1, 1), self.lib)
@@ -559,6 +561,9 @@ class Engine:
             s, d = op["src"], op["dst"]
             rc = lib.y5_plan_add_copy_slice(self.plan, self._ptr(s), self.dt, self._ptr(d), B * s.H * s.W, s.C, self._ld(s), self._ld(d))
             self.op_names.append("copy_slice")
+        elif kind == "decode" and op["level"] in self._fused_heads:
+            rc = lib.y5_plan_add_nop(self.plan)  # decoded inside the level's convolution (y5_plan_add_detect_head)
+            self.op_names.append(f"decode{op['level']}(fused)")
         elif kind == "decode":
             x, i = op["x"], op["level"]
             apx = (self.anchors[i] * self.stride_t[i]).reshape(-1).tolist()
@@ -620,10 +625,59 @@ class Engine:
         ptrs = (self._ptr(x), C.c_void_p(self.be.ptr(wp)), C.c_void_p(self.be.ptr(bp)), self._ptr(res), self._ptr(y), self._ptr(y2))
         if getattr(self.be, "autotune", False):
             d.cfg = self._autotune_conv(d, ptrs)
+        head = self._fused_head_args(op, d, ptrs)
+        if head is not None:
+            self._fused_heads.add(head["level"])
+            self.conv_cfgs.append(56)
+            self.op_names.append("conv+decode:" + op["name"])
+            return self.lib.y5_plan_add_detect_head(self.plan, C.byref(d), ptrs[0], ptrs[1], ptrs[2], *head["args"])
         self.conv_cfgs.append(int(d.cfg))
         self.op_names.append("conv:" + op["name"])
         return self.lib.y5_plan_add_conv(self.plan, C.byref(d), self._ptr(x), C.c_void_p(self.be.ptr(wp)), C.c_void_p(self.be.ptr(bp)),
                                          self._ptr(res), self._ptr(y), self._ptr(y2))
+
+    def _fused_head_args(self, op, d, ptrs):
+        """Detect convolution of one level + its decode as ONE launch (csrc/head.hip) when only `z` is wanted (export mode: no raw
+        tensors) and the shape fits the kernel.  Y5_FUSED_HEAD = 0: never, 1: whenever the library accepts the shape, auto (default):
+        both forms are timed on the real buffers at plan build, like the tile autotuner, and the faster one is kept."""
+        mode = os.environ.get("Y5_FUSED_HEAD", "auto")
+        if mode == "0" or not op["name"].startswith("detect.m") or self.dt != _lib.Y5_F16 or self._cur + 1 >= len(self.spec.ops):
+            return None
+        dec = self.spec.ops[self._cur + 1]
+        if dec["op"] != "decode" or dec["raw"] or dec["na"] != 3 or dec["no"] != 85 or dec["nm"] or "z" not in self.outputs:
+            return None
+        if mode != "1" and not getattr(self.be, "autotune", False):
+            return None
+        lvl = dec["level"]
+        apx = (self.anchors[lvl] * self.stride_t[lvl]).reshape(-1).tolist()
+        arr = (C.c_float * 6)(*apx)
+        zp = C.c_void_p(self.be.ptr(self.outputs["z"]))
+        args = (dec["ny"], dec["nx"], self.stride_t[lvl], arr, zp, dec["nrows"], dec["row_off"])
+        lib, st = self.lib, self._stream()
+        fused = C.c_void_p(lib.y5_plan_create())
+        try:
+            if lib.y5_plan_add_detect_head(fused, C.byref(d), ptrs[0], ptrs[1], ptrs[2], *args) != 0:
+                return None
+            ms_f = C.c_float(0)
+            if lib.y5_plan_time_range(fused, 0, 1, 1 if mode == "1" else 10, st, C.byref(ms_f)) != 0:
+                return None  # shape not supported by the fused kernel
+            if mode != "1":
+                two = C.c_void_p(lib.y5_plan_create())
+                try:
+                    x = dec["x"]
+                    _lib.check(lib.y5_plan_add_conv(two, C.byref(d), *ptrs), lib)
+                    _lib.check(lib.y5_plan_add_detect_decode(two, self._ptr(x), self.dt, self.spec.B, dec["ny"], dec["nx"], 3, 85, 0, self._ld(x),
+                                                             self.stride_t[lvl], arr, zp, self.dt, dec["nrows"], dec["row_off"], None), lib)
+                    ms_t = C.c_float(0)
+                    _lib.check(lib.y5_plan_time_range(two, 0, 2, 10, st, C.byref(ms_t)), lib)
+                finally:
+                    lib.y5_plan_destroy(two)
+                if not ms_f.value < ms_t.value:
+                    return None
+        finally:
+            lib.y5_plan_destroy(fused)
+        self._keep.append(arr)
+        return dict(level=lvl, args=args)
 
     def _autotune_conv(self, d, ptrs):
         return autotune_conv(self.lib, d, ptrs, self._stream())
