@@ -323,6 +323,7 @@ int y5_plan_set_input(y5_plan*, int op_index, const void* src);  /* re-point a s
  * complete at the fork point and that no later op of the range reads their outputs (the Detect heads of the lower pyramid levels,
  * models/yolo.py:83-108, which only the final output depends on). */
 int y5_plan_set_branch(y5_plan*, int op_index, int branch);
+int y5_plan_set_anchors(y5_plan*, int op_index, const float* anchors_px, int n);  /* decode / fused-head op: new anchor sizes (px) */
 int y5_plan_add_nchw_to_nhwc(y5_plan*, const void* src, int src_dtype, void* dst, int dst_dtype, int B, int C, int H,
                              int W, int ld, float scale);
 int y5_plan_add_sppf_pool(y5_plan*, void* buf, int dtype, int B, int H, int W, int C, int ld, int k);
@@ -342,6 +343,15 @@ int y5_plan_launch_graph(y5_plan*, void* stream);        /* hipGraphLaunch of th
 /* Timing helper for bench/profiling: run ops [first,last) `iters` times on `stream` bracketed by hipEvents
  * recorded on that same stream; returns total milliseconds in *ms. */
 int y5_plan_time_range(y5_plan*, int first, int last, int iters, void* stream, float* ms);
+/* In-situ per-op timing: ops [first,last) run once per pass in plan order on `stream` with a hipEvent between consecutive ops
+ * (every op sees the inputs / cache state its predecessor left); ms_per_op[k - first] = median over `iters` passes.  Side-branch
+ * ops run on `stream` too.  Synchronises. */
+int y5_plan_profile_range(y5_plan*, int first, int last, int iters, void* stream, float* ms_per_op);
+/* Fresh outputs per call (the reference returns new tensors, models/yolo.py:115): re-point every op output of [first,last) that equals
+ * old_ptr at new_ptr; y5_plan_select_graph(key) picks the graph captured under that binding key (1 = found, 0 = capture needed: the
+ * next y5_plan_capture_range is stored under `key`; up to 8 graphs per plan, least recently selected evicted). */
+int y5_plan_rebind_output(y5_plan*, int first, int last, const void* old_ptr, void* new_ptr);
+int y5_plan_select_graph(y5_plan*, unsigned long long key);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Fused optimizer step over all parameter tensors -- train.py:413-421 `scaler.unscale_(optimizer)`,

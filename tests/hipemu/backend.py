@@ -36,6 +36,9 @@ class EmuBackend:
     def zero_(self, h):
         h[...] = 0
 
+    def assign(self, h, t):
+        h[...] = t.detach().cpu().numpy()
+
     def stream(self):
         return None
 
@@ -45,3 +48,57 @@ class EmuBackend:
         a = aligned(x.shape, x.dtype)
         a[...] = x
         return a, a.ctypes.data, code
+
+
+class TorchEmuBackend:
+    """Same role, buffers are torch CPU tensors (64-byte aligned by torch's allocator): what the `_lib.use_test_library` seam installs so
+    that `model(x)`, ComputeLoss, HipSGD, the train / detect loops ... run unchanged on CPU tensors against the host-compiled kernels."""
+
+    direct = True
+
+    def __init__(self):
+        self.lib = emu()
+
+    def empty(self, shape, dtype):
+        n = int(np.prod(shape)) if len(shape) else 1
+        es = torch.empty((), dtype=dtype).element_size()
+        raw = torch.zeros(n * es + 256, dtype=torch.uint8)
+        off = (-raw.data_ptr()) % 256          # the C-ABI wants 256-byte aligned workspaces / 16-byte aligned tensors
+        return raw[off:off + n * es].view(dtype).reshape(tuple(shape))
+
+    def from_torch(self, t):
+        return t.detach().cpu().contiguous().clone()
+
+    def ptr(self, h):
+        return h.data_ptr()
+
+    def to_torch(self, h):
+        return h
+
+    def view_torch(self, h):
+        return h
+
+    def zero_(self, h):
+        h.zero_()
+
+    def assign(self, h, t):
+        h.copy_(t)
+
+    def stream(self):
+        return None
+
+    def input(self, x):
+        code = {torch.float16: _lib.Y5_F16, torch.float32: _lib.Y5_F32, torch.uint8: _lib.Y5_U8}.get(x.dtype)
+        if code is None:
+            raise TypeError(f"unsupported input dtype {x.dtype}")
+        x = x.contiguous()
+        return x, x.data_ptr(), code
+
+
+def install():
+    """Route the whole yolov5_amd Python layer to the host-compiled kernels for CPU tensors (tests only)."""
+    _lib.use_test_library(emu(), TorchEmuBackend)
+
+
+def uninstall():
+    _lib.use_test_library(None, None)

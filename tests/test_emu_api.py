@@ -1,0 +1,142 @@
+"""CPU: the Python API layer end to end on the host-compiled kernels (tests/hipemu through the `_lib.use_test_library` seam):
+model(x) semantics the reference guarantees (fresh result tensors, live weights after a training step, deepcopy / pickle after a
+forward), the plan cache, and the guards of the training engine.  References: models/yolo.py:160-170 (forward on live weights),
+utils/torch_utils.py:343-365 (ModelEMA deep-copies the model), train.py:469-488 (checkpoint = deepcopy + torch.save)."""
+import copy
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import detgen, yolo_oracle as yo
+from tests.hipemu import backend as emu_backend
+from yolov5_amd import _state
+from yolov5_amd.loss import ComputeLoss
+from yolov5_amd.torch_utils import ModelEMA, smart_optimizer
+from yolov5_amd.yolo import DetectionModel
+
+
+@pytest.fixture(autouse=True)
+def _seam():
+    emu_backend.install()
+    yield
+    emu_backend.uninstall()
+
+
+def _model(seed=0):
+    m = DetectionModel("yolov5n.yaml")
+    m.load_state_dict(yo.det_state_dict(yo.model_cfg("yolov5n"), seed, fused=False))
+    m.hyp = dict(yo.HYP_SCRATCH_LOW)
+    return m
+
+
+def _img(seed, B=1, S=64):
+    return torch.from_numpy(detgen.uniform((B, 3, S, S), 0.0, 1.0, name="img", seed=seed))
+
+
+def test_forward_returns_fresh_tensors():
+    m = _model().eval()
+    a, b = _img(0), _img(1)
+    za, raw_a = m(a)
+    za_copy = za.clone()
+    zb, _ = m(b)
+    assert za.data_ptr() != zb.data_ptr()
+    assert torch.equal(za, za_copy)          # the second forward did not overwrite the first result (reference semantics)
+    assert not torch.equal(za, zb)
+    # and against the oracle
+    ref = yo.model_forward(yo.model_cfg("yolov5n"), yo.det_state_dict(yo.model_cfg("yolov5n"), 0, fused=False), a)[0]
+    np.testing.assert_allclose(za.numpy(), ref.numpy(), rtol=1e-4, atol=2e-4)
+
+
+def test_eval_after_train_step_uses_live_weights():
+    """HipSGD.step_fused, the fused EMA and the train-mode BatchNorm kernel write through raw pointers; the cached
+    eval plan must re-pack its filters (running statistics included) instead of replaying stale ones -- for `model` and `ema.ema`."""
+    m = _model()
+    x = _img(0)
+    m.eval()
+    z0 = m(x)[0].clone()
+    ema = ModelEMA(m)                       # deepcopy after a forward (engine caches must not be copied)
+    e0 = ema.ema(x)[0].clone()
+    np.testing.assert_allclose(e0.numpy(), z0.numpy(), rtol=1e-5, atol=1e-5)
+    opt = smart_optimizer(m, "SGD", lr=0.05, momentum=0.937, decay=5e-4)
+    loss_fn = ComputeLoss(m)
+    tg = torch.tensor([[0, 3, 0.5, 0.5, 0.3, 0.4], [0, 7, 0.3, 0.6, 0.2, 0.2]], dtype=torch.float32)
+    m.train()
+    epoch0 = _state.weights_epoch
+    for _ in range(2):
+        pred = m(x.half())
+        loss, _items = loss_fn(pred, tg)
+        loss.backward()
+        opt.step_fused(inv_scale=1.0, max_norm=10.0, ema=ema, model=m)
+        opt.zero_grad()
+    assert _state.weights_epoch > epoch0
+    m.eval()
+    z1 = m(x)[0].clone()                    # same cached plan, refreshed filters
+    assert float((z1 - z0).abs().max()) > 1e-4, "eval output did not move after two optimizer steps"
+    m.invalidate_engine()
+    z1_fresh = m(x)[0]
+    assert torch.equal(z1, z1_fresh)        # refreshed plan == plan built from scratch on the new weights
+    e1 = ema.ema(x)[0].clone()
+    assert float((e1 - e0).abs().max()) > 0
+    ema.ema.invalidate_engine()
+    assert torch.equal(e1, ema.ema(x)[0])
+    # BatchNorm running statistics moved too and are part of the refreshed fold
+    bn = next(mod for mod in m.modules() if isinstance(mod, torch.nn.BatchNorm2d))
+    assert int(bn.num_batches_tracked) == 2
+
+
+def test_deepcopy_and_pickle_after_forward():
+    m = _model().eval()
+    x = _img(2)
+    m(x)
+    m.train()
+    m(x.half())                              # training engine cached as well (and the BatchNorm running statistics moved)
+    m.eval()
+    z = m(x)[0]
+    c = copy.deepcopy(m)
+    assert "_engine_cache" not in c.__dict__ and "_train_engines" not in c.__dict__
+    assert torch.equal(c(x)[0], z)
+    buf = io.BytesIO()
+    torch.save({"model": copy.deepcopy(m).half(), "ema": None}, buf)   # train.py:469-472
+    buf.seek(0)
+    ck = torch.load(buf, weights_only=False)
+    zz = ck["model"].float().eval()(x)[0]
+    assert float((zz - z).abs().max()) < 0.1   # weights went through fp16
+
+
+def test_backward_of_a_stale_training_forward_raises():
+    m = _model().train()
+    x = _img(3).half()
+    p1 = m(x)
+    p2 = m(x)                                 # overwrites the engine-owned activations p1's backward would read
+    with pytest.raises(RuntimeError, match="no longer the model's latest"):
+        sum(p.float().sum() for p in p1).backward()
+    sum(p.float().sum() for p in p2).backward()   # the latest forward is fine
+    assert all(p.grad is not None for p in m.parameters())
+
+
+def test_plan_cache_keeps_several_shapes(monkeypatch):
+    monkeypatch.setenv("Y5_PLAN_CACHE", "2")
+    m = _model().eval()
+    outs = {}
+    for s in (64, 96, 64, 128, 64):
+        outs.setdefault(s, []).append(m(_img(4, S=s))[0])
+        assert len(m._engines) <= 2
+    assert torch.equal(outs[64][0], outs[64][1]) and torch.equal(outs[64][0], outs[64][2])
+    assert [k[0][2] for k in m._engines] == [128, 64]   # least recently used shape (96) was dropped
+
+
+def test_loss_targets_out_of_range():
+    m = _model().train()
+    loss_fn = ComputeLoss(m)
+    p = [torch.zeros(1, 3, s, s, 85) for s in (8, 4, 2)]
+    good = torch.tensor([[0, 3, 0.5, 0.5, 0.3, 0.4]])
+    bad = torch.tensor([[0, 3, 0.5, 0.5, 0.3, 0.4], [5, 3, 0.5, 0.5, 0.3, 0.4], [0, 99, 0.5, 0.5, 0.3, 0.4]])
+    l_good = loss_fn(p, good)[0]
+    l_bad = loss_fn(p, bad)[0]                 # rows outside the batch / class list are dropped, nothing is addressed out of range
+    assert torch.equal(l_good, l_bad)
+    loss_fn.check_targets = True
+    with pytest.raises(IndexError):
+        loss_fn(p, bad)

@@ -127,6 +127,7 @@ EXPORTS = {
     "y5_plan_add_nop": (C.c_int, [C.c_void_p]),
     "y5_plan_set_input": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "y5_plan_set_branch": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "y5_plan_set_anchors": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int]),
     "y5_plan_add_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.c_int, C.c_int, C.c_float]),
     "y5_plan_add_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
@@ -147,6 +148,9 @@ EXPORTS = {
     "y5_plan_capture_range": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "y5_plan_launch_graph": (C.c_int, [C.c_void_p, C.c_void_p]),
     "y5_plan_time_range": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
+    "y5_plan_profile_range": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
+    "y5_plan_rebind_output": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "y5_plan_select_graph": (C.c_int, [C.c_void_p, C.c_ulonglong]),
 }
 
 
@@ -160,11 +164,50 @@ def bind(cdll):
 
 
 _lib = None
+# TEST SEAM (tests/hipemu only): a host build of the SAME kernel sources (tests/hipemu/build.sh) bound with bind().  When set, the
+# Python layer accepts CPU tensors and hands their host pointers to that library, so `-m "not gpu"` tests can drive the real
+# wrappers / engines / loops end to end.  The product never sets it: without it every entry point refuses non-GPU tensors.
+_test_lib = None
+_test_backend = None  # engine backend factory that goes with it (tests.hipemu.backend.EmuBackend)
+
+
+def use_test_library(handle, backend_factory=None):
+    global _test_lib, _test_backend
+    _test_lib, _test_backend = handle, backend_factory
+
+
+def accepts(t) -> bool:
+    """True when tensor `t` can be handed to the kernels: a GPU tensor (product), or any tensor under the test seam."""
+    return bool(t.is_cuda) or (_test_lib is not None and t.device.type == "cpu")
+
+
+def stream(device):
+    """Current HIP stream of `device` as the void* the C-ABI takes (None for the host-emulated test library)."""
+    import torch
+
+    device = torch.device(device)
+    if device.type != "cuda":
+        if _test_lib is None:
+            raise RuntimeError("yolov5_amd: tensors must live on the GPU (there is no CPU execution path)")
+        return None
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def workspace(nbytes, device):
+    """uint8 scratch tensor whose address is 256-byte aligned, as the C-ABI asks of every workspace (the GPU caching allocator
+    aligns to 512 B already; host tensors of the test seam are 64-byte aligned, hence the slack)."""
+    import torch
+
+    t = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
+    off = (-t.data_ptr()) % 256
+    return t[off:off + int(nbytes)]
 
 
 def lib():
     """The loaded kernel library.  Raises RuntimeError (never falls back) if it is not built / not loadable."""
     global _lib
+    if _test_lib is not None:
+        return _test_lib
     if _lib is None:
         if not os.path.isfile(LIB_PATH):
             raise RuntimeError(

@@ -1,0 +1,15 @@
+"""Process-wide bookkeeping shared by the engines.
+
+`weights_epoch` counts events that change model weights or BatchNorm running statistics WITHOUT going through torch's
+tensor version counters: the fused optimizer / EMA kernels (csrc/optim.hip) and the train-mode BatchNorm kernel
+(csrc/bn_kernels.h) write through raw device pointers.  Every cached eval plan remembers the epoch its packed filters were
+built from; `BaseModel._forward_once` re-packs them (Engine.refresh_weights) when the epoch moved -- the reference always
+runs on the live parameters (models/yolo.py:160-170), so must we.
+"""
+weights_epoch = 0
+
+
+def bump_weights_epoch():
+    global weights_epoch
+    weights_epoch += 1
+    return weights_epoch

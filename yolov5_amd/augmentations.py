@@ -51,7 +51,7 @@ def _pad_value(color):
 
 
 def _check_image(im):
-    if not (torch.is_tensor(im) and im.is_cuda):
+    if not (torch.is_tensor(im) and _lib.accepts(im)):
         raise RuntimeError("yolov5_amd.augmentations.letterbox needs uint8 HWC GPU tensors (no CPU path)")
     if im.dtype != torch.uint8 or im.ndim != 3 or im.shape[2] != 3:
         raise ValueError(f"letterbox: expected uint8 (h, w, 3), got {im.dtype} {tuple(im.shape)}")
@@ -68,7 +68,7 @@ def _launch(ims, geos, H, W, pad, swap_rb, out, chw, div255):
     code = {torch.uint8: _lib.Y5_U8, torch.float16: _lib.Y5_F16, torch.float32: _lib.Y5_F32}[out.dtype]
     lib = _lib.lib()
     rc = lib.y5_letterbox_batch(C.c_void_p(table.data_ptr()), len(ims), H, W, pad, int(swap_rb), C.c_void_p(out.data_ptr()), code, int(chw),
-                                int(div255), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+                                int(div255), _lib.stream(dev))
     _lib.check(rc, lib)
     return out  # `table` may be released here: the caching allocator re-uses it in stream order, after the launch
 

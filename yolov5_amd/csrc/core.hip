@@ -61,10 +61,14 @@ struct Op {
   int branch;  // 0: the caller's stream; 1: the plan's side stream (forked after the preceding main op, joined at the end of the range)
 };
 
+struct GraphEntry { unsigned long long key; hipGraph_t graph; hipGraphExec_t exec; unsigned long long used; };
+
 struct y5_plan {
   std::vector<Op> ops;
-  hipGraph_t graph = nullptr;
+  hipGraph_t graph = nullptr;        // the SELECTED graph (one entry of `cache`, or the only graph of a plan that never rebinds)
   hipGraphExec_t exec = nullptr;
+  std::vector<GraphEntry> cache;     // captured graphs by binding key (y5_plan_select_graph): outputs re-pointed per call keep their graphs
+  unsigned long long cur_key = 0, tick = 0;
   hipStream_t side = nullptr;        // side-branch stream (y5_plan_set_branch), created on first use
   std::vector<hipEvent_t> events;    // fork / join markers, one per fork point of a run + one join
   bool flat = false;                 // run every op on the caller's stream (per-op timing: no fork / join latency in the figure)
@@ -73,8 +77,10 @@ struct y5_plan {
 extern "C" y5_plan* y5_plan_create(void) { return new y5_plan(); }
 extern "C" void y5_plan_destroy(y5_plan* p) {
   if (!p) return;
-  if (p->exec) hipGraphExecDestroy(p->exec);
-  if (p->graph) hipGraphDestroy(p->graph);
+  for (GraphEntry& g : p->cache) {  // (p->graph / p->exec alias one entry)
+    if (g.exec) hipGraphExecDestroy(g.exec);
+    if (g.graph) hipGraphDestroy(g.graph);
+  }
   for (hipEvent_t e : p->events) hipEventDestroy(e);
   if (p->side) hipStreamDestroy(p->side);
   delete p;
@@ -169,6 +175,47 @@ extern "C" int y5_plan_set_input(y5_plan* pl, int op, const void* src) {
   return Y5_OK;
 }
 
+// Re-point every output pointer of ops [first, last) that equals `old_ptr` at `new_ptr` (the Detect decode / fused head / to_nchw
+// destinations: the model returns a FRESH z / proto tensor per call like the reference, models/yolo.py:115, without a copy).
+extern "C" int y5_plan_rebind_output(y5_plan* pl, int first, int last, const void* old_ptr, void* new_ptr) {
+  if (!pl || first < 0 || last > (int)pl->ops.size() || first > last || !old_ptr || !new_ptr) return y5_fail(Y5_ERR_BAD_ARG, "plan_rebind_output: bad args");
+  int n = 0;
+  for (int k = first; k < last; ++k) {
+    Op& o = pl->ops[k];
+    if (o.q0 == old_ptr) { o.q0 = new_ptr; ++n; }
+    if (o.q1 == old_ptr) { o.q1 = new_ptr; ++n; }
+  }
+  if (!n) return y5_fail(Y5_ERR_BAD_ARG, "plan_rebind_output: no op writes that pointer");
+  return Y5_OK;
+}
+
+// Graph cache: select the captured graph recorded under `key` (the caller's hash of the current output bindings).  Returns 1 when
+// such a graph exists (y5_plan_launch_graph replays it), 0 when not (capture again: it is stored under `key`), < 0 on error.
+// At most Y5_GRAPH_CACHE graphs are kept per plan; the least recently selected one is dropped.
+#define Y5_GRAPH_CACHE 8
+extern "C" int y5_plan_select_graph(y5_plan* pl, unsigned long long key) {
+  if (!pl) return y5_fail(Y5_ERR_BAD_ARG, "plan_select_graph: null");
+  pl->cur_key = key;
+  for (GraphEntry& g : pl->cache)
+    if (g.key == key) {
+      g.used = ++pl->tick;
+      pl->graph = g.graph; pl->exec = g.exec;
+      return 1;
+    }
+  pl->graph = nullptr; pl->exec = nullptr;
+  return 0;
+}
+
+// New anchor sizes (pixels) for a Detect decode / fused head op: Detect.anchors is a buffer the EMA interpolates like any other
+// (utils/torch_utils.py:361-365), so a refreshed plan must pick it up together with the filters.
+extern "C" int y5_plan_set_anchors(y5_plan* pl, int op, const float* anchors_px, int n) {
+  if (!pl || op < 0 || op >= (int)pl->ops.size() || !anchors_px || n < 1 || n > 16) return y5_fail(Y5_ERR_BAD_ARG, "plan_set_anchors: bad args");
+  Op& o = pl->ops[op];
+  if (o.kind != OP_DECODE && o.kind != OP_HEAD) return y5_fail(Y5_ERR_BAD_ARG, "plan_set_anchors: op has no anchors");
+  for (int k = 0; k < n; ++k) o.anchors[k] = anchors_px[k];
+  return Y5_OK;
+}
+
 static int run_op(const Op& o, void* st) {
   switch (o.kind) {
     case OP_STEM: return y5_conv_stem_fwd(o.p0, o.i[0], o.i[1], o.i[2], o.p1, (const float*)o.p2, o.i[3], o.i[4], o.q0, o.i[5], 0, st);
@@ -244,8 +291,14 @@ extern "C" int y5_plan_capture_range(y5_plan* pl, int first, int last, void* st_
   int rc = y5_plan_run_range(pl, first, last, st_);
   if (rc) return rc;
   if (hipStreamSynchronize(st) != hipSuccess) return y5_fail(Y5_ERR_RUNTIME, "plan_capture: sync failed");
-  if (pl->exec) { hipGraphExecDestroy(pl->exec); pl->exec = nullptr; }
-  if (pl->graph) { hipGraphDestroy(pl->graph); pl->graph = nullptr; }
+  for (size_t k = 0; k < pl->cache.size(); ++k)
+    if (pl->cache[k].key == pl->cur_key) {  // re-capture under the same key: drop the stale entry
+      if (pl->cache[k].exec) hipGraphExecDestroy(pl->cache[k].exec);
+      if (pl->cache[k].graph) hipGraphDestroy(pl->cache[k].graph);
+      pl->cache.erase(pl->cache.begin() + k);
+      break;
+    }
+  pl->exec = nullptr; pl->graph = nullptr;  // aliases of cache entries
   // capture on a private stream (the caller's may be the legacy default stream, which cannot be captured); the graph itself
   // is stream-agnostic and is launched on whatever stream y5_plan_launch_graph receives
   hipStream_t cs = nullptr;
@@ -258,8 +311,24 @@ extern "C" int y5_plan_capture_range(y5_plan* pl, int first, int last, void* st_
   const hipError_t e = hipStreamEndCapture(cs, &pl->graph);
   hipStreamDestroy(cs);
   if (rc) return rc;
-  if (e != hipSuccess || !pl->graph) return y5_fail(Y5_ERR_RUNTIME, "plan_capture: end capture failed");
-  if (hipGraphInstantiate(&pl->exec, pl->graph, nullptr, nullptr, 0) != hipSuccess) return y5_fail(Y5_ERR_RUNTIME, "plan_capture: instantiate failed");
+  if (e != hipSuccess || !pl->graph) {
+    pl->graph = nullptr;
+    return y5_fail(Y5_ERR_RUNTIME, "plan_capture: end capture failed");
+  }
+  if (hipGraphInstantiate(&pl->exec, pl->graph, nullptr, nullptr, 0) != hipSuccess) {
+    hipGraphDestroy(pl->graph);
+    pl->graph = nullptr; pl->exec = nullptr;
+    return y5_fail(Y5_ERR_RUNTIME, "plan_capture: instantiate failed");
+  }
+  if (pl->cache.size() >= Y5_GRAPH_CACHE) {
+    size_t lru = 0;
+    for (size_t k = 1; k < pl->cache.size(); ++k)
+      if (pl->cache[k].used < pl->cache[lru].used) lru = k;
+    if (pl->cache[lru].exec) hipGraphExecDestroy(pl->cache[lru].exec);
+    if (pl->cache[lru].graph) hipGraphDestroy(pl->cache[lru].graph);
+    pl->cache.erase(pl->cache.begin() + lru);
+  }
+  pl->cache.push_back({pl->cur_key, pl->graph, pl->exec, ++pl->tick});
   return Y5_OK;
 }
 extern "C" int y5_plan_capture(y5_plan* pl, void* st_) { return y5_plan_capture_range(pl, 0, pl ? (int)pl->ops.size() : 0, st_); }
@@ -287,5 +356,45 @@ extern "C" int y5_plan_time_range(y5_plan* pl, int first, int last, int iters, v
   pl->flat = false;
   hipEventDestroy(e0);
   hipEventDestroy(e1);
+  return rc;
+}
+
+// In-situ per-op timing: ONE eager pass over ops [first, last) on `st` with a HIP event between consecutive ops, repeated `iters`
+// times; ms_out[k - first] = median over the passes of op k's event-to-event time.  Unlike y5_plan_time_range (back-to-back
+// launches of one op on warm buffers) every op here runs in its real position: inputs produced by the previous op, caches in the
+// state the previous layer left them.  Side-branch ops run on `st` too (serialised), so the figures add up to a single-stream
+// forward.  Synchronises the stream.
+extern "C" int y5_plan_profile_range(y5_plan* pl, int first, int last, int iters, void* st_, float* ms_out) {
+  if (!pl || !ms_out || iters < 1 || first < 0 || last > (int)pl->ops.size() || first >= last) return y5_fail(Y5_ERR_BAD_ARG, "plan_profile_range: bad args");
+  hipStream_t st = static_cast<hipStream_t>(st_);
+  const int n = last - first;
+  std::vector<hipEvent_t> ev(n + 1, nullptr);
+  for (int k = 0; k <= n; ++k)
+    if (hipEventCreate(&ev[k]) != hipSuccess) return y5_fail(Y5_ERR_RUNTIME, "plan_profile_range: event create failed");
+  std::vector<std::vector<float>> samples(n);
+  int rc = Y5_OK;
+  pl->flat = true;
+  rc = y5_plan_run_range(pl, first, last, st_);  // warm-up pass
+  for (int it = 0; it < iters && !rc; ++it) {
+    hipEventRecord(ev[0], st);
+    for (int k = 0; k < n && !rc; ++k) {
+      rc = run_op(pl->ops[first + k], st_);
+      hipEventRecord(ev[k + 1], st);
+    }
+    if (!rc && hipEventSynchronize(ev[n]) != hipSuccess) rc = y5_fail(Y5_ERR_RUNTIME, "plan_profile_range: sync failed");
+    for (int k = 0; k < n && !rc; ++k) {
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
+      samples[k].push_back(ms);
+    }
+  }
+  pl->flat = false;
+  for (int k = 0; k < n && !rc; ++k) {
+    std::vector<float>& v = samples[k];
+    for (size_t a = 1; a < v.size(); ++a)  // insertion sort (iters is small)
+      for (size_t b = a; b > 0 && v[b] < v[b - 1]; --b) { const float t = v[b]; v[b] = v[b - 1]; v[b - 1] = t; }
+    ms_out[k] = v[v.size() / 2];
+  }
+  for (hipEvent_t e : ev) hipEventDestroy(e);
   return rc;
 }

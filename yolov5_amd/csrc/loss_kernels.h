@@ -90,10 +90,15 @@ __device__ __forceinline__ Y5Cand y5_loss_candidate(const Y5LossParams& p, const
   else if (o == 2) { ok = ok && ((gy - floorf(gy)) < 0.5f) && (gy > 1.0f); oy = 0.5f; }  // k
   else if (o == 3) { const float gi = fnx - gx; ok = ok && ((gi - floorf(gi)) < 0.5f) && (gi > 1.0f); ox = -0.5f; }  // l
   else if (o == 4) { const float gi = fny - gy; ok = ok && ((gi - floorf(gi)) < 0.5f) && (gi > 1.0f); oy = -0.5f; }  // m
+  // image index / class outside the batch / class list: the reference raises IndexError at loss.py:145,163 (device assert on a
+  // GPU).  Such rows are dropped here so that no kernel of the chain can address outside p / dp (ComputeLoss.check_targets
+  // raises the reference's error on the host when asked to validate).
+  const int tb = (int)tg[0], tc = (int)tg[1];
+  ok = ok && tb >= 0 && tb < p.bs && tc >= 0 && tc < p.nc;
   r.ok = ok;
   if (!ok) return r;
-  r.b = (int)tg[0];
-  r.cls = (int)tg[1];
+  r.b = tb;
+  r.cls = tc;
   r.a = a;
   int gi = (int)(gx - ox), gj = (int)(gy - oy);                                          // loss.py:238 (.long() truncates)
   gi = gi < 0 ? 0 : gi > L.nx - 1 ? L.nx - 1 : gi;                                       // loss.py:242 clamp_ (in place: tbox

@@ -415,10 +415,19 @@ def _save_tune_cache():
         pass
 
 
+def default_backend(device):
+    """The GPU backend -- or, under the test seam of _lib.use_test_library, the host-emulation backend that goes with it."""
+    if _lib._test_backend is not None and torch.device(device).type == "cpu":
+        return _lib._test_backend()
+    return _HipBackend(device)
+
+
 class _HipBackend:
     """Device memory + stream provider of the Engine: PyTorch-ROCm caching allocator and current HIP stream.
     (The Engine takes it as a parameter so that tests can drive the very same plan-materialisation code against
     the host-compiled kernels of tests/hipemu; the product only ever constructs this GPU backend.)"""
+
+    direct = True  # buffers ARE torch tensors: parameters / outputs are used in place through data_ptr()
 
     # time every workgroup-tile configuration per conv layer at plan build and keep the fastest (Y5_AUTOTUNE=0: heuristic tiles)
     autotune = os.environ.get("Y5_AUTOTUNE", "1") != "0"
@@ -450,6 +459,9 @@ class _HipBackend:
     def zero_(self, h):
         h.zero_()
 
+    def assign(self, h, t):
+        h.copy_(t)
+
     def stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
@@ -470,7 +482,7 @@ class Engine:
     def __init__(self, model, x_shape, dtype: torch.dtype, device, want_raw=False, backend=None, spec=None, outputs=None, raw_views=None):
         if dtype not in (torch.float16, torch.float32):
             raise TypeError(f"Engine dtype must be float16 or float32, got {dtype}")
-        self.be = backend if backend is not None else _HipBackend(device)
+        self.be = backend if backend is not None else default_backend(device)
         self.lib = self.be.lib
         self.dtype = dtype
         self.dt = _lib.Y5_F16 if dtype == torch.float16 else _lib.Y5_F32
@@ -479,16 +491,19 @@ class Engine:
         self.x_shape = tuple(x_shape)
         self.spec = spec if spec is not None else build_plan_spec(model, B, ch, H, W, want_raw)
         det = getattr(model, "model", [None])[-1] if model is not None else None
-        if det is not None and hasattr(det, "anchors"):
+        self._det = det if det is not None and hasattr(det, "anchors") else None
+        self._anchor_ops = []  # (plan op index, pyramid level) of every op that holds anchor sizes
+        if self._det is not None:
             self.stride_t = [float(s) for s in det.stride]
-            self.anchors = det.anchors.detach().float().cpu()
+            self.anchors = det.anchors.detach().float().cpu().clone()
         self._keep = []  # device tensors referenced by raw pointers inside the C plan
+        self._conv_bufs = []  # (op, packed filter, bias, stem filter, stem bias) of every conv op -> refresh_weights()
         self.bufs = [self.be.empty((B, b.H, b.W, b.C), dtype) for b in self.spec.bufs]
         # The raw (bs, na, ny, nx, no) head tensors of eval mode (models/yolo.py:96-98) are the Detect convs' NHWC outputs seen
         # through another index order: on the GPU they are returned as strided VIEWS of those plan buffers instead of being
         # written a second time by the decode kernel (274 MB per 64 images at 640^2).  Same shape and values; not contiguous;
         # valid until the next forward like every other output.
-        self.raw_views = (isinstance(self.be, _HipBackend) and outputs is None and os.environ.get("Y5_RAW_VIEW", "1") != "0") \
+        self.raw_views = (getattr(self.be, "direct", False) and outputs is None and os.environ.get("Y5_RAW_VIEW", "1") != "0") \
             if raw_views is None else raw_views
         self.outputs = {}
         for name, o in self.spec.outputs.items():
@@ -522,6 +537,12 @@ class Engine:
                 self.op_names.append(self.op_names[1] + "[stem,nchw]")
         self._graph = False
         self._use_graph = os.environ.get("Y5_GRAPH", "1") == "1" and isinstance(self.be, _HipBackend)
+        # Fresh z / proto (/ raw copies) per call, as the reference returns new tensors from every forward (models/yolo.py:115):
+        # the plan's output pointers are re-pointed at newly allocated tensors (no copy) and captured graphs are cached per
+        # binding -- in a steady loop the caching allocator hands the same blocks back and the same graph replays.  The strided
+        # raw VIEWS of eval mode stay views of plan buffers (valid until the next forward; see DetectionModel.forward).
+        self.fresh_outputs = outputs is None and os.environ.get("Y5_FRESH_OUTPUTS", "1") != "0"
+        self._bound = {k: self.be.ptr(v) for k, v in self.outputs.items() if not (self.raw_views and k.startswith("raw"))}
 
     def __del__(self):
         try:
@@ -574,6 +595,7 @@ class Engine:
                 self.outputs[op["raw"]] = t[..., x.c_off:x.c_off + op["na"] * op["no"]].unflatten(-1, (op["na"], op["no"])).permute(0, 3, 1, 2, 4)
             elif op["raw"]:
                 raw = self.outputs[op["raw"]]
+            self._anchor_ops.append((lib.y5_plan_size(self.plan), i))
             rc = lib.y5_plan_add_detect_decode(self.plan, self._ptr(x), self.dt, B, op["ny"], op["nx"], op["na"], op["no"], op["nm"],
                                                self._ld(x), self.stride_t[i], arr, C.c_void_p(self.be.ptr(self.outputs["z"])), self.dt,
                                                op["nrows"], op["row_off"], C.c_void_p(self.be.ptr(raw)) if raw is not None else None)
@@ -587,36 +609,68 @@ class Engine:
             raise ValueError(kind)
         _lib.check(rc, lib)
 
-    def _add_conv(self, op):
-        x, y, res, y2 = op["x"], op["y"], op["res"], op["y2"]
+    def _conv_weights(self, op):
+        """Packed filter / bias of one conv op from the LIVE module parameters (BN folded with the current running statistics):
+        (view geometry, main pack, stem pack or None).  Called at plan build and again by refresh_weights()."""
+        x, res, y2 = op["x"], op["res"], op["y2"]
         w, b = folded_weights(op["mods"])
         (kh, kw), (sh, sw), (ph, pw) = op["k"], op["s"], op["p"]
         H, W, C1, ldx = x.H, x.W, x.C, self._ld(x)
+        stem = None
         if op["view"] == "first":
             cin = w.shape[1]
             if (self.dtype == torch.float16 and cin == 3 and (kh, kw, sh, sw, ph, pw) == (6, 6, 2, 2, 2, 2) and op["act"] and res is None
                     and y2 is None and W % 64 == 0 and H % 2 == 0 and w.shape[0] <= 64 and w.shape[0] % 8 == 0
                     and os.environ.get("Y5_STEM", "1") != "0"):
-                swp, sbp, snpad = pack_stem_weight(w, b)
-                swp, sbp = self.be.from_torch(swp), self.be.from_torch(sbp)
-                self._keep += [swp, sbp]
-                self._stem_args = (swp, sbp, int(w.shape[0]), snpad, y)
+                stem = pack_stem_weight(w, b) + (int(w.shape[0]),)
             wfull = torch.zeros((w.shape[0], C1, kh, kw), device=w.device)
             wfull[:, :cin] = w
             w = wfull
             if self.dtype == torch.float16 and C1 == 4 and kw % 2 == 0 and sw % 2 == 0 and pw % 2 == 0 and W % 2 == 0:
                 # k6 s2 p2 stem: NHWC4 pixels pair up into 16-byte pieces -> conv over (H, W/2, 8), kernel (kh, kw/2)
                 W, C1, ldx, kw, sw, pw = W // 2, 8, 8, kw // 2, sw // 2, pw // 2
-                wp, bp, K, Kpad, Npad = pack_conv_weight(w, b, self.dtype)
-            else:
-                wp, bp, K, Kpad, Npad = pack_conv_weight(w, b, self.dtype)
         else:
             assert w.shape[1] == C1, (op["name"], w.shape, C1)
-            wp, bp, K, Kpad, Npad = pack_conv_weight(w, b, self.dtype)
+        main = pack_conv_weight(w, b, self.dtype)
+        return (H, W, C1, ldx, kh, kw, sh, sw, ph, pw), main, stem
+
+    def refresh_weights(self):
+        """Re-pack every filter / bias from the live parameters into the plan's EXISTING device buffers (same shapes, same
+        pointers: captured graphs stay valid).  Needed whenever weights or BatchNorm running statistics changed behind torch's
+        version counters -- the fused optimizer, the fused EMA and the train-mode BatchNorm kernel write through raw pointers
+        (yolo.BaseModel tracks that with `_state.weights_epoch`)."""
+        with torch.no_grad():
+            for op, wp, bp, swp, sbp in self._conv_bufs:
+                _, main, stem = self._conv_weights(op)
+                self.be.assign(wp, main[0])
+                self.be.assign(bp, main[1])
+                if swp is not None:
+                    self.be.assign(swp, stem[0])
+                    self.be.assign(sbp, stem[1])
+            new_anchors = self._det.anchors.detach().float().cpu().clone() if self._det is not None else None
+            if new_anchors is not None and self._anchor_ops and not torch.equal(new_anchors, self.anchors):
+                self.anchors = new_anchors
+                for idx, lvl in self._anchor_ops:
+                    apx = (self.anchors[lvl] * self.stride_t[lvl]).reshape(-1).tolist()
+                    _lib.check(self.lib.y5_plan_set_anchors(self.plan, idx, (C.c_float * len(apx))(*apx), len(apx)), self.lib)
+                # graph kernel nodes hold their arguments by value: graphs captured so far carry the old anchors
+                self._graph = False
+                self._graph_gen = getattr(self, "_graph_gen", 0) + 1
+
+    def _add_conv(self, op):
+        x, y, res, y2 = op["x"], op["y"], op["res"], op["y2"]
+        (H, W, C1, ldx, kh, kw, sh, sw, ph, pw), (wp, bp, K, Kpad, Npad), stem = self._conv_weights(op)
+        swp = sbp = None
+        if stem is not None:
+            swp, sbp, snpad, sc2 = stem
+            swp, sbp = self.be.from_torch(swp), self.be.from_torch(sbp)
+            self._keep += [swp, sbp]
+            self._stem_args = (swp, sbp, sc2, snpad, y)
         if self.dtype == torch.float16 and C1 % 8:
             raise NotImplementedError(f"conv {op['name']}: fp16 needs input channels in multiples of 8 (got {C1})")
         wp, bp = self.be.from_torch(wp), self.be.from_torch(bp)
         self._keep += [wp, bp]
+        self._conv_bufs.append((op, wp, bp, swp, sbp))
         c2s = op["c2_store"]
         d = _lib.ConvDesc(dtype=self.dt, B=self.spec.B, H=H, W=W, C1=C1, ldx=ldx, OH=y.H, OW=y.W, C2=c2s, ldy=self._ld(y),
                           KH=kh, KW=kw, SH=sh, SW=sw, PH=ph, PW=pw, act=1 if op["act"] else 0, Kpad=Kpad, Npad=Npad,
@@ -628,6 +682,7 @@ class Engine:
         head = self._fused_head_args(op, d, ptrs)
         if head is not None:
             self._fused_heads.add(head["level"])
+            self._anchor_ops.append((self.lib.y5_plan_size(self.plan), head["level"]))
             self.conv_cfgs.append(56)
             self.op_names.append("conv+decode:" + op["name"])
             return self.lib.y5_plan_add_detect_head(self.plan, C.byref(d), ptrs[0], ptrs[1], ptrs[2], *head["args"])
@@ -686,7 +741,8 @@ class Engine:
     def _stream(self):
         return self.be.stream()
 
-    def __call__(self, x):
+    def __call__(self, x, outputs=None):
+        """outputs: optional caller-owned destination tensors {name: contiguous tensor of the plan's output shape} for this call."""
         if tuple(x.shape) != self.x_shape:
             raise ValueError(f"engine built for input {self.x_shape}, got {tuple(x.shape)}")
         x, xptr, src_dt = self.be.input(x)
@@ -694,13 +750,16 @@ class Engine:
         st = self._stream()
         B = self.spec.B
         n = self.lib.y5_plan_size(self.plan)
+        if self.fresh_outputs or outputs is not None:
+            self._rebind_fresh(n, outputs)
         if self._stem is not None and src_dt == _lib.Y5_F16:
             # fp16 NCHW batch: the stem conv reads it in place (no NHWC repack pass), then the plan continues at op 2
             self._stem_active = True
             _lib.check(self.lib.y5_plan_set_input(self.plan, self._stem, C.c_void_p(xptr)), self.lib)
             _lib.check(self.lib.y5_plan_run_range(self.plan, self._stem, self._stem + 1, st), self.lib)
             if self._use_graph:
-                # ops 2.. only touch plan-owned buffers: replayed as ONE hipGraph launch (captured on first use)
+                # ops 2.. only touch plan-owned buffers and the bound outputs: replayed as ONE hipGraph launch (captured on first
+                # use of every output binding)
                 if not self._graph:
                     if self.lib.y5_plan_capture_range(self.plan, 2, self._stem, st) == 0:
                         self._graph = True
@@ -717,6 +776,42 @@ class Engine:
                                             scale, st), self.lib)
         _lib.check(self.lib.y5_plan_run_range(self.plan, 1, n if self._stem is None else self._stem, st), self.lib)
         return self.outputs
+
+    def _rebind_fresh(self, n, outputs=None):
+        """Point the plan at newly allocated (or caller-provided) output tensors and select the graph captured for that binding."""
+        changed = False
+        for name, old in list(self._bound.items()):
+            if outputs is not None:
+                t = outputs[name]
+                if tuple(t.shape) != tuple(self.spec.outputs[name]["shape"]) or not t.is_contiguous():
+                    raise ValueError(f"engine output {name}: expected contiguous {tuple(self.spec.outputs[name]['shape'])}")
+            else:
+                t = self.be.empty(self.spec.outputs[name]["shape"], self.dtype)
+            new = self.be.ptr(t)
+            self.outputs[name] = t
+            if new != old:
+                _lib.check(self.lib.y5_plan_rebind_output(self.plan, 0, n, C.c_void_p(old), C.c_void_p(new)), self.lib)
+                self._bound[name] = new
+                changed = True
+        if changed or not self._graph:
+            key = hash((getattr(self, "_graph_gen", 0),) + tuple(sorted(self._bound.items()))) & 0xFFFFFFFFFFFFFFFF
+            self._graph = self.lib.y5_plan_select_graph(self.plan, key) == 1
+
+    def profile_ops(self, iters=5):
+        """In-situ per-op HIP-event timing: [(name, ms)] in execution order, every op timed in its real position of one eager
+        forward (median of `iters` passes) -- what bench.py's roofline is computed from.  Call after at least one forward."""
+        st = self._stream()
+        n = self.lib.y5_plan_size(self.plan)
+        res = []
+        if self._stem is not None and getattr(self, "_stem_active", False):
+            ranges = [(self._stem, self._stem + 1), (2, self._stem)]
+        else:
+            ranges = [(1, n if self._stem is None else self._stem)]
+        for lo, hi in ranges:
+            buf = (C.c_float * (hi - lo))()
+            _lib.check(self.lib.y5_plan_profile_range(self.plan, lo, hi, iters, st, buf), self.lib)
+            res += [(self.op_names[lo + k], float(buf[k])) for k in range(hi - lo)]
+        return res
 
     def time_ops(self, iters=20):
         """Per-op HIP-event timing (ms per launch) on the current stream: [(name, ms)] -- used by bench.py."""
@@ -752,7 +847,9 @@ class SplitEngine:
         self.parts, self.x_shape, self.sub_b = parts, tuple(x_shape), B // parts
         sub_shape = (self.sub_b,) + tuple(x_shape[1:])
         spec = build_plan_spec(model, self.sub_b, x_shape[1], x_shape[2], x_shape[3], want_raw)
-        self.outputs = {name: torch.empty((B,) + tuple(o["shape"][1:]), dtype=dtype, device=device) for name, o in spec.outputs.items()}
+        self._out_shapes = {name: (B,) + tuple(o["shape"][1:]) for name, o in spec.outputs.items()}
+        self.dtype = dtype
+        self.outputs = {name: torch.empty(shp, dtype=dtype, device=device) for name, shp in self._out_shapes.items()}
         self.engines = []
         for i in range(parts):
             views = {name: t[i * self.sub_b:(i + 1) * self.sub_b] for name, t in self.outputs.items()}
@@ -771,10 +868,17 @@ class SplitEngine:
         if tuple(x.shape) != self.x_shape:
             raise ValueError(f"engine built for input {self.x_shape}, got {tuple(x.shape)}")
         cur = torch.cuda.current_stream(self.device)
+        if os.environ.get("Y5_FRESH_OUTPUTS", "1") != "0":  # new result tensors per call (see Engine.fresh_outputs)
+            self.outputs = {name: torch.empty(shp, dtype=self.dtype, device=self.device) for name, shp in self._out_shapes.items()}
         for i, (eng, s) in enumerate(zip(self.engines, self.streams)):
             s.wait_stream(cur)
+            views = {name: t[i * self.sub_b:(i + 1) * self.sub_b] for name, t in self.outputs.items()}
             with torch.cuda.stream(s):
-                eng(x[i * self.sub_b:(i + 1) * self.sub_b])
+                eng(x[i * self.sub_b:(i + 1) * self.sub_b], outputs=views)
         for s in self.streams:
             cur.wait_stream(s)
         return self.outputs
+
+    def refresh_weights(self):
+        for eng in self.engines:
+            eng.refresh_weights()

@@ -84,7 +84,7 @@ class _SingleEngine(Engine):
 def run_single(layer, x, kind):
     if layer.training:
         raise NotImplementedError("yolov5_amd: training-mode layer forward is not built yet; call .eval()")
-    if not x.is_cuda:
+    if not _lib.accepts(x):
         raise RuntimeError("yolov5_amd: input tensor must live on the GPU (no CPU path)")
     dtype = next(layer.parameters()).dtype
     key = (kind, tuple(x.shape), dtype, str(x.device), sum(p._version for p in layer.parameters()))

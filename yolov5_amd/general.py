@@ -65,7 +65,7 @@ def scale_boxes_batch(img1_shape, out, counts, img0_shapes, ratio_pads=None, rou
     """`scale_boxes` (utils/general.py:613-626) for every image of a padded NMS result in one launch, in place: out (bs, max_det,
     6+nm) fp32 / counts (bs) int32 as returned by non_max_suppression(..., padded=True); img0_shapes[i] = (h0, w0);
     ratio_pads[i] = ((gain, gain), (pad_x, pad_y)) or None (computed from the shapes, :615-617).  round_: detect.py:248."""
-    if not out.is_cuda or out.dtype != torch.float32 or not out.is_contiguous():
+    if not _lib.accepts(out) or out.dtype != torch.float32 or not out.is_contiguous():
         raise RuntimeError("scale_boxes_batch needs the contiguous fp32 GPU buffer of non_max_suppression(..., padded=True)")
     bs, max_det, ld = out.shape
     rows = []
@@ -80,7 +80,7 @@ def scale_boxes_batch(img1_shape, out, counts, img0_shapes, ratio_pads=None, rou
     sc = torch.tensor(rows, dtype=torch.float32).to(out.device)
     lib = _lib.lib()
     rc = lib.y5_scale_boxes_batch(C.c_void_p(out.data_ptr()), ld, max_det, C.c_void_p(counts.data_ptr()) if counts is not None else None, bs,
-                                  C.c_void_p(sc.data_ptr()), int(round_), C.c_void_p(torch.cuda.current_stream(out.device).cuda_stream))
+                                  C.c_void_p(sc.data_ptr()), int(round_), _lib.stream(out.device))
     _lib.check(rc, lib)
     return out
 
@@ -107,7 +107,7 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
         prediction = prediction[0]
     if labels:
         raise NotImplementedError("autolabelling `labels` (general.py:706-712) is not part of the hot path")
-    if not prediction.is_cuda:
+    if not _lib.accepts(prediction):
         raise RuntimeError("yolov5_amd.non_max_suppression needs a GPU tensor (no CPU path)")
     if prediction.dtype not in (torch.float16, torch.float32):
         prediction = prediction.float()
@@ -123,7 +123,7 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     if ws is None:
         nbytes = lib.y5_nms_workspace_bytes(bs, n, no, nm, flags, max_nms)
         _nms_ws.clear()
-        ws = _nms_ws[key] = (torch.empty(nbytes, dtype=torch.uint8, device=dev), nbytes)
+        ws = _nms_ws[key] = (_lib.workspace(nbytes, dev), nbytes)
     out = torch.empty((bs, max_det, 6 + nm), dtype=torch.float32, device=dev)
     cnt = torch.empty((bs,), dtype=torch.int32, device=dev)
     cls_t = None
@@ -133,7 +133,7 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     rc = lib.y5_nms_batched(C.c_void_p(prediction.data_ptr()), dt, bs, n, no, nm, float(conf_thres), float(iou_thres), int(max_det),
                             max_nms, 7680.0, flags, C.c_void_p(cls_t.data_ptr()) if cls_t is not None else None,
                             0 if cls_t is None else cls_t.numel(), C.c_void_p(out.data_ptr()), C.c_void_p(cnt.data_ptr()),
-                            C.c_void_p(ws[0].data_ptr()), ws[1], C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+                            C.c_void_p(ws[0].data_ptr()), ws[1], _lib.stream(dev))
     _lib.check(rc, lib)
     if padded:
         return out, cnt

@@ -11,6 +11,7 @@ Unsupported options raise: focal loss (`fl_gamma > 0`, loss.py:120-122), `autoba
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -43,9 +44,9 @@ class _LossFn(torch.autograd.Function):
         nbytes = lib.y5_loss_workspace_bytes(C.byref(d), nt)
         if nbytes == 0:
             _lib.check(-1, lib)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ws = _lib.workspace(nbytes, dev)
         out = torch.empty(4, dtype=torch.float32, device=dev)
-        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        st = _lib.stream(dev)
         p = [pi.contiguous() for pi in p]
         rc = lib.y5_loss_forward(C.byref(d), _void_pp(p), C.c_void_p(targets.data_ptr()) if nt else None, nt,
                                  C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()), nbytes, st)
@@ -63,7 +64,7 @@ class _LossFn(torch.autograd.Function):
         dev = p[0].device
         gs = g_loss.detach().to(torch.float32).reshape(-1)[:1].contiguous()
         dp = [torch.empty_like(pi) for pi in p]
-        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        st = _lib.stream(dev)
         rc = lib.y5_loss_backward(C.byref(ctx.d), _void_pp(p), ctx.nt, C.c_void_p(gs.data_ptr()), _void_pp(dp),
                                   C.c_void_p(ctx.ws.data_ptr()), ctx.nbytes, st)
         _lib.check(rc, lib)
@@ -74,6 +75,9 @@ class ComputeLoss:
     """utils/loss.py:101-183."""
 
     sort_obj_iou = False
+    # True (or env Y5_CHECK_TARGETS=1): validate targets[:, 0] < batch size and targets[:, 1] < nc on the host and raise IndexError
+    # like the reference's indexing does (one device->host sync per call); the kernels themselves drop such rows (memory safe).
+    check_targets = False
 
     def __init__(self, model, autobalance=False):
         if autobalance:
@@ -109,7 +113,7 @@ class ComputeLoss:
             self._anc_host = (ver, self.anchors.detach().float().cpu())
         anc = self._anc_host[1]
         for i, pi in enumerate(p):
-            if pi.dtype != dt or not pi.is_cuda:
+            if pi.dtype != dt or not _lib.accepts(pi):
                 raise RuntimeError("ComputeLoss: every prediction level must be a GPU tensor of the same dtype (no CPU path)")
             if pi.dim() != 5 or pi.shape[1] != self.na or pi.shape[4] != 5 + self.nc:
                 raise ValueError(f"ComputeLoss: level {i} has shape {tuple(pi.shape)}, expected (bs,{self.na},ny,nx,{5 + self.nc})")
@@ -128,6 +132,13 @@ class ComputeLoss:
         if len(p) != self.nl:
             raise ValueError(f"ComputeLoss: expected {self.nl} prediction levels, got {len(p)}")
         targets = targets.to(device=p[0].device, dtype=torch.float32).contiguous()
+        if (self.check_targets or os.environ.get("Y5_CHECK_TARGETS") == "1") and targets.numel():
+            lo = targets[:, :2].min(0).values.tolist()
+            hi = targets[:, :2].max(0).values.tolist()
+            if lo[0] < 0 or hi[0] >= p[0].shape[0]:
+                raise IndexError(f"ComputeLoss: target image index {int(hi[0] if hi[0] >= p[0].shape[0] else lo[0])} is out of bounds for batch size {p[0].shape[0]}")
+            if lo[1] < 0 or hi[1] >= self.nc:
+                raise IndexError(f"ComputeLoss: target class {int(hi[1] if hi[1] >= self.nc else lo[1])} is out of bounds for nc={self.nc}")
         return _LossFn.apply(self, targets, *p)
 
     def build_targets(self, p, targets):

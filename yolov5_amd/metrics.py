@@ -23,7 +23,7 @@ def _p(t):
 
 
 def _need_gpu(t, what):
-    if not t.is_cuda:
+    if not _lib.accepts(t):
         raise RuntimeError(f"yolov5_amd.metrics.{what} needs GPU tensors (no CPU path)")
 
 
@@ -43,7 +43,7 @@ def process_batch(detections, labels, iouv):
     correct = torch.empty((1, n, niou), dtype=torch.uint8, device=det.device)
     lib = _lib.lib()
     rc = lib.y5_val_match(_p(det), det.shape[1], n, None, 1, _p(lab) if lab.numel() else None, 5, lab.shape[0], -1, 0, 1, 0, None, _p(iv), niou,
-                          _p(correct), None, C.c_void_p(torch.cuda.current_stream(det.device).cuda_stream))
+                          _p(correct), None, _lib.stream(det.device))
     _lib.check(rc, lib)
     return correct[0].bool()
 
@@ -72,7 +72,7 @@ def match_batch(out, counts, targets, shapes, iouv, predn=False):
     cn = counts.to(device=dev, dtype=torch.int32) if counts is not None else None
     lib = _lib.lib()
     rc = lib.y5_val_match(_p(out), ld, max_det, _p(cn), bs, _p(tg) if tg.numel() else None, 6, tg.shape[0], 0, 1, 2, 1, _p(sc), _p(iv), niou,
-                          _p(correct), _p(pn), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+                          _p(correct), _p(pn), _lib.stream(dev))
     _lib.check(rc, lib)
     return (correct, pn) if predn else correct
 

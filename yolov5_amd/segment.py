@@ -14,7 +14,7 @@ def process_mask(protos, masks_in, bboxes, shape, upsample=False, out_dtype=torc
     Returns (n, ih, iw) if upsample else (n, mh, mw), values 0/1.  `out_dtype`: torch.float32 (what the reference's
     `masks.gt_(0.5)` returns) or torch.bool / torch.uint8 (4x fewer HBM bytes).  masks_in / bboxes may be column
     views of the NMS output rows (`det[:, 6:]`, `det[:, :4]`): they are read in place through their row stride."""
-    if not protos.is_cuda:
+    if not _lib.accepts(protos):
         raise RuntimeError("yolov5_amd.process_mask needs GPU tensors (no CPU path)")
     lib = _lib.lib()
     c, mh, mw = protos.shape
@@ -39,6 +39,6 @@ def process_mask(protos, masks_in, bboxes, shape, upsample=False, out_dtype=torc
     rc = lib.y5_process_mask(C.c_void_p(protos.data_ptr()), _lib.Y5_F16 if protos.dtype == torch.float16 else _lib.Y5_F32,
                              c, mh, mw, C.c_void_p(masks_in.data_ptr()), ld_m, C.c_void_p(bboxes.data_ptr()), ld_b, n, ih, iw,
                              1 if upsample else 0, C.c_void_p(out.data_ptr()), _lib.Y5_U8 if u8 else _lib.Y5_F32,
-                             C.c_void_p(torch.cuda.current_stream(protos.device).cuda_stream))
+                             _lib.stream(protos.device))
     _lib.check(rc, lib)
     return out.view(torch.bool) if out_dtype == torch.bool else out

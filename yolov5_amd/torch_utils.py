@@ -20,6 +20,8 @@ import torch
 import torch.distributed as dist
 from torch import nn
 
+from . import _state
+
 
 def is_parallel(model):
     return type(model).__name__ in ("DataParallel", "DistributedDataParallel", "HipDDP")
@@ -133,8 +135,9 @@ def torch_distributed_zero_first(local_rank: int):
         dist.barrier()
 
 
-def smart_optimizer(model, name="SGD", lr=0.01, momentum=0.937, decay=5e-4):
-    """utils/torch_utils.py:257-290: 3 parameter groups -- biases (no decay), BatchNorm weights (no decay), other weights (decay)."""
+def smart_optimizer(model, name="Adam", lr=0.001, momentum=0.9, decay=1e-5):
+    """utils/torch_utils.py:257-290 (same defaults; train.py:227 passes every argument): 3 parameter groups -- biases (no decay),
+    BatchNorm weights (no decay), other weights (decay).  name="SGD" returns the fused HipSGD."""
     g = [], [], []
     bn = tuple(v for k, v in nn.__dict__.items() if "Norm" in k)
     for v in model.modules():
@@ -220,7 +223,7 @@ class HipSGD(torch.optim.Optimizer):
                 r.param, r.grad, r.mom, r.ema, r.n, r.group = pp, gp, mp or None, ep or None, n, gi
             tab = torch.from_numpy(np.frombuffer(arr, dtype=np.uint8).copy()).to(dev)
             max_n = max(r[4] for r in rows)
-            ws = torch.empty(self._library().y5_mt_workspace_bytes(len(rows), max_n), dtype=torch.uint8, device=dev)
+            ws = _lib.workspace(self._library().y5_mt_workspace_bytes(len(rows), max_n), dev)
             stats = torch.zeros(4, dtype=torch.float32, device=dev)
             self._cache = (key, tab, len(rows), max_n, ws, stats)
         return self._cache
@@ -238,7 +241,7 @@ class HipSGD(torch.optim.Optimizer):
 
         from . import _lib
 
-        if self._lib is None and any(p.device.type != "cuda" for g in self.param_groups for p in g["params"]):
+        if self._lib is None and any(not _lib.accepts(p) for g in self.param_groups for p in g["params"]):
             raise RuntimeError("HipSGD: parameters must live on the GPU (there is no CPU execution path)")
         lib = self._library()
         ema_pairs, d = None, 0.0
@@ -267,6 +270,7 @@ class HipSGD(torch.optim.Optimizer):
                                       float(inv_scale), C.c_void_p(stats.data_ptr()) if use_stats else None, d, st), lib)
         if ema is not None:
             ema.lerp_rest(model, d, lib, st, skip=set(k[0] for k in key))
+        _state.bump_weights_epoch()  # parameters (and the EMA's) were written through raw pointers: cached eval plans re-pack
         return stats if use_stats else None
 
     @torch.no_grad()
@@ -283,9 +287,7 @@ class ModelEMA:
     """utils/torch_utils.py:343-375: EMA of parameters AND buffers, fp32, decay ramp 1 - exp(-updates / tau)."""
 
     def __init__(self, model, decay=0.9999, tau=2000, updates=0):
-        self.ema = deepcopy(de_parallel(model)).eval()
-        self.ema.__dict__.pop("_train_engines", None)
-        self.ema.__dict__.pop("_ddp_sink", None)
+        self.ema = deepcopy(de_parallel(model)).eval()  # (BaseModel.__getstate__ leaves the engine caches / DDP sink behind)
         self.updates = updates
         self.decay = lambda x: decay * (1 - math.exp(-x / tau))
         for p in self.ema.parameters():
@@ -341,3 +343,4 @@ class ModelEMA:
             tab = (torch.from_numpy(np.frombuffer(arr, dtype=np.uint8).copy()).to(todo[0][0].device), max(s.numel() for s, _ in todo))
             pr[3][key] = tab
         _lib.check(lib.y5_mt_lerp(C.c_void_p(tab[0].data_ptr()), len(todo), tab[1], float(d), stream), lib)
+        _state.bump_weights_epoch()

@@ -19,8 +19,8 @@ import ctypes as C
 
 import torch
 
-from . import _lib
-from .engine import TRef, _HipBackend, _Planner, _slice, autotune_conv
+from . import _lib, _state
+from .engine import TRef, _Planner, _slice, autotune_conv, default_backend
 from .packing import round_up
 from .train_ops import _axis_classes
 
@@ -48,7 +48,7 @@ class TrainEngine:
     """Materialised training plan for one (batch, resolution) on one GPU."""
 
     def __init__(self, model, x_shape, device, backend=None):
-        self.be = backend if backend is not None else _HipBackend(device)
+        self.be = backend if backend is not None else default_backend(device)
         self.lib = self.be.lib
         self.model = model
         B, ch, H, W = x_shape
@@ -102,7 +102,7 @@ class TrainEngine:
                 op["_st"] = st
                 self.convs.append(st)
             elif op["op"] == "decode":
-                self.raw[op["level"]] = self.be.empty((B, op["na"], op["ny"], op["nx"], op["no"]), f16)
+                self.raw[op["level"]] = None  # allocated per forward: the caller owns the returned maps (models/yolo.py:98)
         self.dz = self.be.empty((max(max_z, 8),), f16)
         self.dwflat = self.be.empty((max(self._dw_total, 64),), torch.float32)  # packed fp32 dW accumulators of all convs
         self.ws = self.be.empty((max(max_ws, 256),), torch.uint8)
@@ -122,7 +122,7 @@ class TrainEngine:
 
     def _f32(self, t):
         """Device pointer of an fp32 parameter / buffer (the emulated backend gets a host copy that is kept alive)."""
-        if isinstance(self.be, _HipBackend):
+        if getattr(self.be, "direct", False):
             if t.dtype != torch.float32 or not t.is_contiguous():
                 raise TypeError("training expects contiguous fp32 master parameters")
             return t.data_ptr()
@@ -182,6 +182,8 @@ class TrainEngine:
         stm = be.stream()
         self._keep = []
         self._nbt = []
+        self._fwd_seq = getattr(self, "_fwd_seq", 0) + 1  # backward checks that its saved activations are still this forward's
+        _state.bump_weights_epoch()  # BatchNorm running statistics are updated through raw pointers below
         x, xptr, src_dt = be.input(x)
         self._run_jobs(0, stm)  # every forward filter: fp32 master weights -> packed fp16, one launch
         for op in self.spec.ops:
@@ -197,6 +199,7 @@ class TrainEngine:
                 _lib.check(lib.y5_sppf_pool(_vp(self._ptr(b)), _lib.Y5_F16, B, b.H, b.W, op["C"], self._ld(b), op["k"], stm), lib)
             elif kind == "decode":
                 lg = op["x"]
+                self.raw[op["level"]] = be.empty((B, op["na"], op["ny"], op["nx"], op["no"]), torch.float16)
                 _lib.check(lib.y5_nhwc_to_raw(_vp(self._ptr(lg)), _vp(be.ptr(self.raw[op["level"]])), B, op["ny"] * op["nx"], op["na"], op["no"],
                                               self._ld(lg), stm), lib)
             else:
@@ -213,7 +216,7 @@ class TrainEngine:
         c2, c1, kh, kw = cv.weight.shape
         Kpad, Npad = st["Kpad"], st["Npad"]
         if not st["has_bn"] and cv.bias is not None:
-            if isinstance(be, _HipBackend):
+            if getattr(be, "direct", False):
                 st["bp"][:c2].copy_(cv.bias.detach())
             else:
                 st["bp"][:c2] = cv.bias.detach().float().numpy()
@@ -246,7 +249,7 @@ class TrainEngine:
         """Device pointers of the BatchNorm running statistics (updated in place by the kernel)."""
         if not bn.track_running_stats or bn.running_mean is None:
             return None, None
-        if isinstance(self.be, _HipBackend):
+        if getattr(self.be, "direct", False):
             return _vp(bn.running_mean.data_ptr()), _vp(bn.running_var.data_ptr())
         rm, rv = self.be.from_torch(bn.running_mean.detach().float()), self.be.from_torch(bn.running_var.detach().float())
         self._run_tmp = (rm, rv)
@@ -255,7 +258,7 @@ class TrainEngine:
     def _running_done(self, bn):
         if not bn.track_running_stats or bn.running_mean is None:
             return
-        if not isinstance(self.be, _HipBackend):  # host-emulated backend: copy the updated statistics back
+        if not getattr(self.be, "direct", False):  # host-emulated (numpy) backend: copy the updated statistics back
             rm, rv = self._run_tmp
             bn.running_mean.copy_(self.be.to_torch(rm))
             bn.running_var.copy_(self.be.to_torch(rv))
@@ -440,11 +443,17 @@ class _TrainFn(torch.autograd.Function):
     def forward(ctx, eng, x, *params):
         ctx.eng = eng
         outs = eng.forward(x)
+        ctx.seq = eng._fwd_seq
         return tuple(eng.be.to_torch(o) for o in outs)
 
     @staticmethod
     def backward(ctx, *dps):
         eng = ctx.eng
+        if ctx.seq != eng._fwd_seq:
+            # activations, BatchNorm statistics and the raw head maps live in engine-owned buffers that the later forward overwrote
+            # (the reference would keep one autograd graph per forward alive; one training plan holds exactly one)
+            raise RuntimeError("yolov5_amd: backward() of a training forward that is no longer the model's latest one -- "
+                               "call backward before the next train-mode forward at this input shape")
         # gradient accumulation (a second backward before zero_grad): .grad tensors that alias the arena would be overwritten
         # by this pass before autograd adds to them -- give those their own storage first, and hand autograd copies
         lo = eng.be.ptr(eng.gflat)

@@ -8,16 +8,16 @@ w.r.t. the parameters through the HIP backward plan of yolov5_amd/train_engine.p
 """
 from __future__ import annotations
 
-import contextlib
 import math
+import os
+from collections import OrderedDict
 from copy import deepcopy
 from pathlib import Path
-
-import os
 
 import torch
 from torch import nn
 
+from . import _state
 from .cfg import load_cfg
 from .common import C3, SPPF, Bottleneck, Concat, Conv, Proto
 from .general import LOGGER, make_divisible
@@ -84,20 +84,31 @@ class BaseModel(nn.Module):
             return train_forward(self, x)  # list of raw (bs, na, ny, nx, no) maps, differentiable w.r.t. the parameters
         det = self.model[-1]
         want_raw = not getattr(det, "export", False)
-        key = (tuple(x.shape), next(self.parameters()).dtype, str(x.device), want_raw, self._weights_version())
-        eng = self._engines.get(key)
+        key = (tuple(x.shape), next(self.parameters()).dtype, str(x.device), want_raw)
+        cache = self._engines
+        eng = cache.get(key)
+        stamp = (_state.weights_epoch, self._weights_version())
         if eng is None:
             from .engine import Engine, SplitEngine
 
-            self._engines.clear()  # one live plan per model keeps HBM use bounded
             parts = int(os.environ.get("Y5_SPLIT", "1"))
             if x.is_cuda and parts > 1 and x.shape[0] >= 16 * parts and x.shape[0] % parts == 0:
                 # opt-in (Y5_SPLIT=2): sub-batch plans on separate streams fill each other's kernel tails (engine.SplitEngine;
                 # +3 % images/s on yolov5s bs=64, but per-kernel figures then describe overlapped launches)
-                eng = SplitEngine(self, tuple(x.shape), next(self.parameters()).dtype, x.device, want_raw=want_raw, parts=parts)
+                eng = SplitEngine(self, tuple(x.shape), key[1], x.device, want_raw=want_raw, parts=parts)
             else:
-                eng = Engine(self, tuple(x.shape), next(self.parameters()).dtype, x.device, want_raw=want_raw)
-            self._engines[key] = eng
+                eng = Engine(self, tuple(x.shape), key[1], x.device, want_raw=want_raw)
+            eng._stamp = stamp
+            cache[key] = eng
+            # a few live plans per model (rectangular validation batches, val.py rect=True, alternate between shapes); the least
+            # recently used one is dropped -- a yolov5s bs=64 640^2 plan holds 2.6 GB of the 288 GB
+            while len(cache) > max(1, int(os.environ.get("Y5_PLAN_CACHE", "4"))):
+                cache.popitem(last=False)
+        else:
+            cache.move_to_end(key)
+            if eng._stamp != stamp:  # weights / BN statistics changed since the filters were packed: re-pack, keep plan + graphs
+                eng.refresh_weights()
+                eng._stamp = stamp
         out = eng(x)
         z = out["z"]
         raw = [out[f"raw{i}"] for i in range(det.nl)] if want_raw else None
@@ -109,15 +120,30 @@ class BaseModel(nn.Module):
     def _engines(self):
         e = self.__dict__.get("_engine_cache")
         if e is None:
-            e = self.__dict__["_engine_cache"] = {}
+            e = self.__dict__["_engine_cache"] = OrderedDict()
         return e
 
     def _weights_version(self):
-        return sum(p._version for p in self.parameters())
+        """Sum of torch's in-place version counters over parameters and buffers (tensor list cached until the module tree changes:
+        fuse() / _apply() call invalidate_engine).  Catches load_state_dict / optimizer.step / user edits made through torch;
+        raw-pointer writers bump _state.weights_epoch instead."""
+        ts = self.__dict__.get("_ver_tensors")
+        if ts is None:
+            ts = self.__dict__["_ver_tensors"] = list(self.parameters()) + list(self.buffers())
+        return sum(t._version for t in ts)
 
     def invalidate_engine(self):
-        """Drop the cached plan (call after mutating weights in place outside of the optimizer)."""
+        """Drop the cached plans (module tree / dtype / device changed)."""
         self._engines.clear()
+        self.__dict__.pop("_ver_tensors", None)
+
+    def __getstate__(self):
+        """deepcopy / pickle (ModelEMA, train.py:469-488 checkpoints): engines hold ctypes handles and device plans -- they are
+        per-process caches, not model state."""
+        st = self.__dict__.copy()
+        for k in ("_engine_cache", "_train_engines", "_ddp_sink", "_ver_tensors"):
+            st.pop(k, None)
+        return st
 
     def fuse(self):
         """Fold BN into conv in every Conv block (models/yolo.py:186-195, utils/torch_utils.py:224-254)."""
