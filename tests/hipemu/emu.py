@@ -15,7 +15,12 @@ _emu = None
 def emu():
     global _emu
     if _emu is None:
-        out = subprocess.run([os.path.join(HERE, "build.sh")], capture_output=True, text=True)
+        import fcntl
+
+        os.makedirs(os.path.join(HERE, "_build"), exist_ok=True)
+        with open(os.path.join(HERE, "_build", ".lock"), "w") as lk:  # xdist workers: one (incremental) build at a time
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            out = subprocess.run([os.path.join(HERE, "build.sh")], capture_output=True, text=True)
         if out.returncode != 0:
             raise RuntimeError("hipemu build failed:\n" + out.stdout + out.stderr)
         _emu = _lib.bind(C.CDLL(os.path.join(HERE, "_build", "liby5emu.so")))
