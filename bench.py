@@ -6,8 +6,17 @@ One "step" = the whole inference hot path over one batch that is already residen
 N GPUs: one process per GPU (torch.distributed, backend nccl = RCCL), every rank runs the same per-GPU batch
 (images are independent: weak scaling, no data-path collective -- DESIGN.md section "multi-GPU").
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (conv implicit-GEMM kernel,
-MFMA bound) and `cpu_baseline` (the CPU oracle = port of the reference path, timed on this box's host cores).
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes itself under torch.distributed.run
+(one rank per GPU, 127.0.0.1 rendezvous); under a launcher it reads RANK / LOCAL_RANK / WORLD_SIZE as usual.  At N > 1 the line
+also carries the DDP TRAINING step (`train`: the only path with a collective -- bucketed RCCL all-reduce of the gradient arena
+overlapped with backward, train.py:404-405 semantics) with `rccl_ranks` and the all-reduce bytes per step.
+
+Protocol: >= 10 warm-up + >= 50 timed steps; `value` = images of the K timed steps / wall time between two
+barrier + synchronize fences (max over ranks); per-step device-event times give median / p10 / p90 beside it.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (all conv launches of one forward, durations
+measured IN SITU: one HIP event between consecutive plan ops of a real forward) and `cpu_baseline` (the CPU oracle = port of
+the reference path, timed on this box's host cores BEFORE the GPU work starts).
 """
 from __future__ import annotations
 
@@ -101,9 +110,12 @@ def pmc_traffic(a, conv_by):
     process: scripts/pmc_forward.sh runs the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same forward and the
     result is committed under profiles/pmc/ (FETCH_SIZE doubled: gfx950 correction of MI355X_MICROARCH.md "HBM").  Only
     reported for the configuration it was measured on."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc", "r01_pmc_forward.json")
-    if not (a.model == "yolov5s" and a.batch == 64 and a.imgsz == 640 and os.path.isfile(path)):
+    import glob
+
+    cands = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc", "r*_pmc_forward.json")))
+    if not (a.model == "yolov5s" and a.batch == 64 and a.imgsz == 640 and cands):
         return None
+    path = cands[-1]  # newest round
     try:
         with open(path) as f:
             d = json.load(f)
@@ -111,7 +123,7 @@ def pmc_traffic(a, conv_by):
     except (OSError, ValueError, KeyError):
         return None
     return {"gbytes_per_step": round(gb, 3), "vs_algorithmic": round(gb * 1e9 / conv_by, 3) if conv_by else None,
-            "source": "profiles/pmc/r01_pmc_forward.json (scripts/pmc_forward.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, FETCH x2)"}
+            "source": f"profiles/pmc/{os.path.basename(path)} (scripts/pmc_forward.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, FETCH x2)"}
 
 
 def usable_cores():
@@ -127,7 +139,7 @@ def usable_cores():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(seconds_budget=20.0):
+def cpu_baseline(seconds_budget=10.0):
     """The oracle (CPU port of the reference forward + NMS, torch-CPU fp32, all host cores) on a bounded sample:
     yolov5s fused, 8 images of 3x640x640, forward + NMS per iteration."""
     from oracle import detgen, yolo_oracle as yo
@@ -153,9 +165,33 @@ def cpu_baseline(seconds_budget=20.0):
             "sample": f"oracle/yolo_oracle.py forward+NMS, yolov5s fused fp32, {n} images of 3x640x640 (batches of {bs}), {dt:.1f} s"}
 
 
-def train_probe(name, batch, imgsz, dev, world, steps=6, warmup=2):
-    """Secondary measurement (BASELINE config 3 per-GPU shape): training step = train-mode forward + ComputeLoss + backward
-    (+ bucketed RCCL gradient all-reduce when world > 1) + SGD, fp16 compute with fp32 master weights, synthetic data."""
+def _pct(v, q):
+    v = sorted(v)
+    return v[min(len(v) - 1, max(0, int(round(q * (len(v) - 1)))))]
+
+
+def event_times(fn, iters, dev):
+    """Per-iteration device time (ms) of `fn` from HIP events on torch's current stream (the stream every yolov5_amd launch uses)."""
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+    evs[0].record()
+    for i in range(iters):
+        fn()
+        evs[i + 1].record()
+    torch.cuda.synchronize(dev)
+    return [evs[i].elapsed_time(evs[i + 1]) for i in range(iters)]
+
+
+def stats(ms):
+    return {"median": round(_pct(ms, 0.5), 4), "p10": round(_pct(ms, 0.1), 4), "p90": round(_pct(ms, 0.9), 4), "n": len(ms)}
+
+
+TRAIN_GFLOP_PER_IMG = {"yolov5s": 49.3}  # SURVEY 8d: forward + data gradient + weight gradient = 3 x 16.43 GFLOP at 640^2
+
+
+def train_probe(name, batch, imgsz, dev, world, steps=20, warmup=5):
+    """BASELINE config 3 per-GPU shape: one training step = train-mode forward (batch-statistics BN) + ComputeLoss + backward
+    (+ bucketed RCCL gradient all-reduce overlapped with backward when world > 1, loss * WORLD_SIZE as train.py:404-405) +
+    unscale / clip / SGD-Nesterov / EMA (fused), fp16 compute with fp32 master weights, synthetic data."""
     from yolov5_amd.loss import ComputeLoss
     from yolov5_amd.torch_utils import ModelEMA, smart_DDP, smart_optimizer
     from yolov5_amd.yolo import DetectionModel
@@ -167,7 +203,7 @@ def train_probe(name, batch, imgsz, dev, world, steps=6, warmup=2):
     model = smart_DDP(m) if world > 1 else m
     opt = smart_optimizer(m, "SGD", lr=0.01, momentum=0.937, decay=5e-4)  # HipSGD: 3 groups, fused multi-tensor step
     ema = ModelEMA(m)
-    g = torch.Generator(device="cpu").manual_seed(1)
+    g = torch.Generator(device="cpu").manual_seed(1 + int(os.environ.get("RANK", 0)))
     x = torch.rand((batch, 3, imgsz, imgsz), generator=g).half().to(dev)
     nt = batch * 8
     t = torch.cat((torch.randint(0, batch, (nt, 1), generator=g).float(), torch.randint(0, 80, (nt, 1), generator=g).float(),
@@ -190,22 +226,43 @@ def train_probe(name, batch, imgsz, dev, world, steps=6, warmup=2):
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
+        torch.cuda.synchronize(dev)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(steps):
+    evs[0].record()
+    for i in range(steps):
         loss = step()
+        evs[i + 1].record()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
+        torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    per = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
     if world > 1:
         tt = torch.tensor([dt], device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    ar_bytes = nbuckets = None
+    if world > 1:
+        ar_bytes = sum((b.hi - b.lo) * 4 for b in model.buckets)
+        nbuckets = len(model.buckets)
     del m, model, opt
     torch.cuda.empty_cache()
-    return {"images_per_sec": round(batch * world * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps,
-            "workload": f"{name} train step, {batch} img/GPU 3x{imgsz}x{imgsz}, {nt} targets: forward(train BN) + ComputeLoss + backward"
-                        f"{' + RCCL all-reduce' if world > 1 else ''} + SGD; fp16 compute / fp32 masters", "loss": round(float(loss.detach()), 4)}
+    ips = batch * world * steps / dt
+    out = {"images_per_sec": round(ips, 1), "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps, "warmup": warmup,
+           "step_ms": stats(per), "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+           "allreduce_bytes_per_step": ar_bytes, "allreduce_buckets": nbuckets,
+           "workload": f"{name} train step, {batch} img/GPU 3x{imgsz}x{imgsz}, {nt} targets: forward(train BN) + ComputeLoss + backward"
+                       f"{' + RCCL all-reduce (overlapped)' if world > 1 else ''} + clip + SGD + EMA; fp16 compute / fp32 masters",
+           "loss": round(float(loss.detach()), 4)}
+    gf = TRAIN_GFLOP_PER_IMG.get(name)
+    if gf and imgsz == 640:
+        tf = ips / world * gf / 1e3  # per GPU
+        out["roofline"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
+                           "traffic": None, "algorithmic_gflop_per_img": gf,
+                           "note": "whole training step (all kernels + host), per GPU: 3 x forward conv FLOPs / step time"}
+    return out
 
 
 def pipeline_probe(model, batch, dev, nm, iters=10):
@@ -244,30 +301,58 @@ def pipeline_probe(model, batch, dev, nm, iters=10):
                         "(10 IoU thresholds) -> scale_boxes; one host sync per batch"}
 
 
+def respawn_under_torchrun(n):
+    """`bench.py --gpus N` outside a launcher: become `python -m torch.distributed.run --nproc-per-node N bench.py ...`."""
+    import socket
+
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.stdout.flush()
+    os.execve(sys.executable, cmd, env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--imgsz", type=int, default=640)
     ap.add_argument("--model", default="yolov5s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement")
-    ap.add_argument("--train", action="store_true", help="run the training-step probe also under torchrun (N > 1: adds the RCCL gradient "
-                    "all-reduce; by default the multi-GPU run measures the headline inference metric only, scripts/train_bench.py is the DDP entry)")
-    ap.add_argument("--op-table", default="", help="write the per-op timing table (JSON) to this path")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step measurement")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the detect/val pipeline measurement")
+    ap.add_argument("--train", action="store_true", help="(kept for compatibility: the training step is measured at every N unless --no-train)")
+    ap.add_argument("--op-table", default="", help="write the per-op timing table (JSON: in-situ and isolated ms, %% of bound) to this path")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        respawn_under_torchrun(a.gpus)
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != a.gpus and rank == 0:
+        print(f"[bench] --gpus {a.gpus} but the launcher started {world} rank(s): reporting n_gpus={world}", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+
+    # ---- CPU baseline first: the GPU is idle while the host cores run the oracle, the rest of the run is GPU work ------------
+    cpu = None
+    if not a.no_cpu_baseline and world == 1:
+        cpu = cpu_baseline()
+        torch.set_num_threads(min(8, usable_cores()))
+
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from yolov5_amd.general import non_max_suppression
 
@@ -293,48 +378,53 @@ def main():
             torch.cuda.synchronize(dev)
 
     fence()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    evs[0].record()
+    for i in range(a.steps):
         step()
+        evs[i + 1].record()
     fence()
     dt = time.perf_counter() - t0
+    step_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(a.steps)]
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # ---- per-kernel timing on the launch stream (HIP events inside y5_plan_time_range) -----------------
+    # ---- forward / NMS alone: device events, >= 50 iterations ------------------------------------------------------------------
     torch.cuda.synchronize(dev)
     eng_top = next(iter(model._engines.values()))
     parts = getattr(eng_top, "parts", 1)  # SplitEngine: `parts` sub-batch plans on separate streams; per-kernel figures come from one of them
     eng = eng_top.engines[0] if parts > 1 else eng_top
-    t_f0 = time.perf_counter()
-    for _ in range(10):
-        model(x)
-    torch.cuda.synchronize(dev)
-    fwd_ms = (time.perf_counter() - t_f0) / 10 * 1e3
+    n_it = max(50, a.steps)
+    fwd = event_times(lambda: model(x), n_it, dev)
     z = model(x)[0]
+    nms = event_times(lambda: non_max_suppression(z, 0.25, 0.45, max_det=1000, nm=nm), n_it, dev)
+    fwd_ms, nms_ms = _pct(fwd, 0.5), _pct(nms, 0.5)
+
+    # ---- per-kernel timing: IN SITU (one eager forward, a HIP event between consecutive ops, median of 9 passes) is what the
+    # roofline uses; the isolated figure (10 back-to-back launches of one op on warm buffers) is printed beside it ---------------
+    model(x)
     torch.cuda.synchronize(dev)
-    t_n0 = time.perf_counter()
-    for _ in range(10):
-        non_max_suppression(z, 0.25, 0.45, max_det=1000, nm=nm)
-    torch.cuda.synchronize(dev)
-    nms_ms = (time.perf_counter() - t_n0) / 10 * 1e3
+    insitu = eng.profile_ops(iters=9)
     ops = eng.time_ops(iters=10)
     fl = dict(conv_flops(eng))
     if eng._stem is not None:
         fl[eng._stem] = fl[1]  # the fused NCHW stem op computes spec op 1 (0.Conv)
-    timed = list(zip(eng.timed_order, ops))  # (plan index, (name, ms)) in execution order
-    conv_ms = sum(ms for i, (name, ms) in timed if i in fl)
-    conv_fl = sum(fl[i] for i, _ in timed if i in fl)
-    other_ms = sum(ms for i, (name, ms) in timed if i not in fl)
-    achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     by = dict(conv_bytes(eng))
     if eng._stem is not None:
         by[eng._stem] = by[1]
-    conv_by = sum(by[i] for i, _ in timed if i in by)
+    timed = list(zip(eng.timed_order, ops, insitu))  # (plan index, (name, isolated ms), (name, in-situ ms)) in execution order
+    assert all(o[0] == s[0] for _, o, s in timed)
+    conv_ms = sum(s[1] for i, o, s in timed if i in fl)
+    conv_ms_iso = sum(o[1] for i, o, s in timed if i in fl)
+    conv_fl = sum(fl[i] for i, _, _ in timed if i in fl)
+    other_ms = sum(s[1] for i, o, s in timed if i not in fl)
+    achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    conv_by = sum(by[i] for i, _, _ in timed if i in by)
     achieved_bw = conv_by / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0  # GB/s
-    nconv = sum(1 for i, _ in timed if i in fl)
+    nconv = sum(1 for i, _, _ in timed if i in fl)
     images_per_plan = eng.spec.B
     if a.op_table and rank == 0:
         cfg_of = {}
@@ -342,27 +432,36 @@ def main():
         for i, op in enumerate(eng.spec.ops):
             if op["op"] == "conv":
                 cfg_of[i] = next(ci)
-        table = [{"op": name, "cfg": cfg_of.get(i), "ms": round(ms, 5), "gflop": round(fl.get(i, 0) / 1e9, 3),
-                  "tflops": round(fl.get(i, 0) / (ms * 1e-3) / 1e12, 1) if ms > 0 and i in fl else None}
-                 for i, (name, ms) in timed]
+        table = []
+        for i, (name, iso), (_, ms) in timed:
+            row = {"op": name, "cfg": cfg_of.get(i), "ms": round(ms, 5), "ms_isolated": round(iso, 5), "gflop": round(fl.get(i, 0) / 1e9, 3)}
+            if i in fl and ms > 0:
+                t_hbm = by[i] / (HBM_PEAK_GBS * 1e9) * 1e3
+                t_mfma = fl[i] / (MFMA_PEAK_TFLOPS * 1e12) * 1e3
+                row.update(tflops=round(fl[i] / (ms * 1e-3) / 1e12, 1), gbytes_per_s=round(by[i] / (ms * 1e-3) / 1e9, 1),
+                           bound="hbm" if t_hbm >= t_mfma else "mfma", bound_ms=round(max(t_hbm, t_mfma), 5),
+                           pct_of_bound=round(100.0 * max(t_hbm, t_mfma) / ms, 1))
+            table.append(row)
         with open(a.op_table, "w") as f:
             json.dump(table, f, indent=1)
 
     # ---- secondary: the detect.py pipeline around the hot path (SURVEY 8(f) rank 1 + 3 rows) ---------------------------------
     pipeline = None
-    if world == 1 and a.imgsz == 640 and not a.no_train:
+    if world == 1 and a.imgsz == 640 and not a.no_pipeline:
         try:
             pipeline = pipeline_probe(model, a.batch, dev, nm)
         except Exception as e:  # the headline metric must not depend on the secondary probe
             pipeline = {"error": f"{type(e).__name__}: {e}"}
 
     train = None
-    if not a.no_train and (world == 1 or a.train):
+    if not a.no_train:
         try:
             del model, eng, eng_top
             torch.cuda.empty_cache()
             train = train_probe(a.model, a.batch, a.imgsz, dev, world)
         except Exception as e:  # the headline metric must not depend on the secondary probe
+            if world > 1:
+                raise  # (a rank that fails alone would leave the others in a collective)
             train = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         imgs = a.batch * world * a.steps
@@ -372,32 +471,36 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{a.model} inference bs={a.batch}/GPU 3x{a.imgsz}x{a.imgsz} fp16: HIP forward (backbone+neck+Detect) + HIP NMS "
                                    "(conf 0.25, iou 0.45, max_det 1000); random-init weights, Detect biases calibrated to a realistic NMS load",
-                       "global_batch": a.batch * world, "parallelism": f"replicas x{world} (images independent, no collective)"},
-            "forward_ms": round(fwd_ms, 4), "nms_ms": round(nms_ms, 4), "nms_us_per_img": round(nms_ms * 1e3 / a.batch, 2),
+                       "global_batch": a.batch * world, "parallelism": f"replicas x{world} (images independent, no data-path collective); "
+                                                                       "the DDP training step with its RCCL all-reduce is the `train` object"},
+            "step_ms": stats(step_ms), "forward_ms": round(fwd_ms, 4), "forward_ms_stats": stats(fwd), "nms_ms": round(nms_ms, 4),
+            "nms_ms_stats": stats(nms), "nms_us_per_img": round(nms_ms * 1e3 / a.batch, 2),
             "forward_images_per_sec": round(a.batch / (fwd_ms * 1e-3), 1), "detections_per_img": round(ncand, 1),
-            # arithmetic intensity of the conv stack at this config = algorithmic flops / algorithmic bytes (135 flop/B for
+            # arithmetic intensity of the conv stack at this config = algorithmic flops / algorithmic bytes (144 flop/B for
             # yolov5s bs=64 640^2) is below the ridge (2500 TF / 8 TB/s = 312 flop/B): the stack as a whole is HBM-bound;
             # the MFMA view of the same launches is kept beside it
             "roofline": {"bound": "hbm", "kernel": "y5_conv_{igemm,pw,k3,stem}_kernel (all conv launches of one forward)",
                          "achieved": round(achieved_bw, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_bw / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(a, conv_by * parts),
+                         "timing": "in situ: HIP event between consecutive ops of one eager forward on the launch stream, median of 9 passes "
+                                   "(event-to-event: includes the dispatch gap of each launch)",
                          "plans_per_step": parts, "images_per_plan": images_per_plan,
                          "algorithmic_gbytes_per_step": round(conv_by * parts / 1e9, 3), "algorithmic_gflop_per_step": round(conv_fl * parts / 1e9, 1),
                          "arithmetic_intensity_flop_per_byte": round(conv_fl / conv_by, 1) if conv_by else None,
                          "mfma_achieved_tflops": round(achieved, 2), "mfma_peak_tflops": MFMA_PEAK_TFLOPS,
                          "mfma_frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-                         # durations are per launch in isolation (HIP events); with plans_per_step > 1 the plans overlap in time
-                         "conv_ms_per_step": round(conv_ms * parts, 4), "launches_per_step": nconv * parts,
-                         "other_kernels_ms_per_step": round(other_ms * parts, 4)},
+                         "conv_ms_per_step": round(conv_ms * parts, 4), "conv_ms_per_step_isolated": round(conv_ms_iso * parts, 4),
+                         "launches_per_step": nconv * parts, "other_kernels_ms_per_step": round(other_ms * parts, 4)},
         }
         if pipeline is not None:
             res["pipeline"] = pipeline
         if train is not None:
             res["train"] = train
-        if not a.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline()
+        if cpu is not None:
+            res["cpu_baseline"] = cpu
         print(json.dumps(res))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

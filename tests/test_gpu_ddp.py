@@ -1,0 +1,67 @@
+"""GPU: HipDDP (yolov5_amd/torch_utils.py, reference seam utils/torch_utils.py:61-70 `smart_DDP`, train.py:404-405) over RCCL.
+A world_size-1 `nccl` process group on the one GPU this box has: every bucket of the gradient arena goes through a real RCCL
+all-reduce (launch -> work.wait() -> arena), overlapped with the rest of the backward plan exactly as at N = 8; with one rank the
+mean over ranks is the identity, so the reduced arena must be bit-identical to the single-process gradients."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+from oracle import detgen, yolo_oracle as yo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pg():
+    assert torch.cuda.is_available()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    yield
+    dist.destroy_process_group()
+
+
+def test_hipddp_buckets_over_rccl_world1(pg):
+    from yolov5_amd.loss import ComputeLoss
+    from yolov5_amd.torch_utils import HipDDP, smart_DDP
+    from yolov5_amd.yolo import DetectionModel
+
+    dev = torch.device("cuda:0")
+    m = DetectionModel("yolov5s.yaml")
+    m.load_state_dict(yo.det_state_dict(yo.model_cfg("yolov5s"), 0, fused=False))
+    m.hyp = dict(yo.HYP_SCRATCH_LOW)
+    m = m.to(dev).train()
+    B, S = 8, 256
+    x = torch.from_numpy(detgen.uniform((B, 3, S, S), 0.0, 1.0, name="ddp", seed=3)).half().to(dev)
+    t = torch.from_numpy(detgen.synth_targets(B, 6, seed=3)).to(dev)
+    loss_fn = ComputeLoss(m)
+
+    def grads(model):
+        for p in m.parameters():
+            p.grad = None
+        loss, _ = loss_fn(model(x), t)
+        (loss * dist.get_world_size() * 1024.0).backward()   # train.py:404-405: loss *= WORLD_SIZE
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in m.parameters()]
+
+    local = grads(m)
+    ddp = smart_DDP(m)
+    assert isinstance(ddp, HipDDP) and ddp.avg_in_collective and dist.get_backend() == "nccl"
+    red = grads(ddp)
+    assert len(ddp.buckets) >= 4, len(ddp.buckets)                    # yolov5s: 28.9 MB of fp32 gradients in 6 MB buckets
+    assert all(b.work is not None for b in ddp.buckets)               # every bucket really went through RCCL
+    assert sum(b.hi - b.lo for b in ddp.buckets) == ddp._eng.gtotal   # the buckets tile the whole arena
+    # the first bucket is complete (and on the wire) long before the last gradient of the plan is produced
+    order = sorted(ddp._eng.goff, key=ddp._eng.goff.get)
+    assert ddp.buckets[0].idxs == order[:len(ddp.buckets[0].idxs)]
+    for a, b in zip(local, red):
+        assert torch.equal(a, b)                                      # AVG over one rank = identity, bit for bit
+    # and a second step re-uses the buckets (same arena, same ranges)
+    red2 = grads(ddp)
+    for a, b in zip(local, red2):
+        assert torch.equal(a, b)

@@ -41,15 +41,18 @@ class _Bucket:
 
 
 class HipDDP(nn.Module):
-    """Data-parallel wrapper for yolov5_amd models (see module docstring).  bucket_cap_mb follows torch DDP's default
-    (25 MB: yolov5s = 28.9 MB of fp32 gradients -> 2 buckets; a ring all-reduce of one bucket is ~0.3 ms on one xGMI link).
-    Buckets are ranges of the engine's flat gradient arena (train_engine.py): nothing is packed or copied."""
+    """Data-parallel wrapper for yolov5_amd models (see module docstring).  Buckets are ranges of the engine's flat gradient
+    arena (train_engine.py): nothing is packed or copied.  bucket_cap_mb = 6: yolov5s' 28.9 MB of fp32 gradients make 5 buckets,
+    so the first all-reduce is on the wire after the head + last C3 of the backward plan instead of after half of it (torch DDP's
+    25 MB default would give 2); a 6 MB ring all-reduce is ~70 us on one xGMI link, still far above the per-collective latency.
+    The mean over ranks is ReduceOp.AVG inside the collective on RCCL (`nccl`), a per-bucket division after the wait elsewhere."""
 
-    def __init__(self, module, bucket_cap_mb=25.0, process_group=None):
+    def __init__(self, module, bucket_cap_mb=6.0, process_group=None):
         super().__init__()
         self.module = module
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.avg_in_collective = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         self.params = list(module.parameters())
         with torch.no_grad():
             if self.world > 1:
@@ -91,8 +94,9 @@ class HipDDP(nn.Module):
             b.work = None
 
     def _launch(self, b):
-        if self.world > 1:
-            b.work = dist.all_reduce(self._flat[b.lo:b.hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        if self.world > 1 or self.avg_in_collective:  # (a 1-rank RCCL group still runs the collective: exercises the launch / wait path)
+            op = dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM
+            b.work = dist.all_reduce(self._flat[b.lo:b.hi], op=op, group=self.pg, async_op=True)
         b.pending = -1
 
     def grad_ready(self, idx):
@@ -114,9 +118,9 @@ class HipDDP(nn.Module):
                 self._launch(b)
         for b in self.buckets:
             if b.work is not None:
-                b.work.wait()
-        if self.world > 1:
-            self._flat.div_(self.world)
+                b.work.wait()  # orders the compute stream behind the collective; no host block on RCCL
+                if not self.avg_in_collective:
+                    self._flat[b.lo:b.hi].div_(self.world)
         return grads
 
 
