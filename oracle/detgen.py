@@ -82,6 +82,53 @@ def fill_state_dict(sd: dict, seed: int = 0) -> dict:
     return out
 
 
+def condition_state_dict(vals: dict, residual_gain=0.25, head_gain=30.0, na=3, nc=80) -> dict:
+    """Make a fill_state_dict network well conditioned at FULL depth / resolution (used by the detset_* fixtures):
+    * every shortcut Bottleneck's last BatchNorm (`...m.<i>.cv2.bn.{weight,bias}`) is scaled by `residual_gain`: with He-scaled
+      filters each `x + f(x)` doubles the activation variance, and yolov5x stacks up to 12 of them per C3 (logits saturate,
+      fp16 overflows) -- real checkpoints have small residual branches too;
+    * the objectness / class rows of the Detect / Segment 1x1 filters (`<last>.m.<level>.weight`, rows a*no + 4 .. a*no + 4 + nc)
+      are scaled by `head_gain`, so that scores spread over (0, 1) instead of clustering at one value (a ranking among thousands
+      of near ties is not a parity test); the box and mask-coefficient rows keep their scale (boxes stay well formed).
+    Works in place on {name: np.ndarray | None} and returns it."""
+    import re
+
+    for k, v in vals.items():
+        if v is None:
+            continue
+        if re.search(r"\.m\.\d+\.cv2\.bn\.(weight|bias)$", k):
+            vals[k] = (v * np.float32(residual_gain)).astype(np.float32)
+        elif re.search(r"^model\.\d+\.m\.\d+\.weight$", k) and v.ndim == 4:
+            w = v.reshape(na, -1, *v.shape[1:]).copy()
+            w[:, 4:5 + nc] *= np.float32(head_gain)
+            vals[k] = w.reshape(v.shape).astype(np.float32)
+    return vals
+
+
+def scene(shape, *, seed=0, nrect=24) -> np.ndarray:
+    """Synthetic (bs, 3, H, W) float32 images in [0, 1] with STRUCTURE: a per-image colour gradient, `nrect` random rectangles of
+    random colour and a little noise.  (Uniform noise looks the same at every position to a convolutional net: its head outputs
+    barely vary over the grid.)"""
+    bs, c, H, W = shape
+    yy = np.linspace(0.0, 1.0, H, dtype=np.float32)[None, :, None]
+    xx = np.linspace(0.0, 1.0, W, dtype=np.float32)[None, None, :]
+    out = np.empty(shape, dtype=np.float32)
+    for b in range(bs):
+        g = uniform((c, 3), 0.0, 1.0, name="scene_grad", seed=seed * 1000 + b)
+        img = g[:, 0, None, None] * 0.4 + g[:, 1, None, None] * 0.3 * yy + g[:, 2, None, None] * 0.3 * xx
+        r = uniform((nrect, 4), 0.0, 1.0, name="scene_rect", seed=seed * 1000 + b)
+        col = uniform((nrect, c), 0.0, 1.0, name="scene_col", seed=seed * 1000 + b)
+        for k in range(nrect):
+            cx, cy, w, h = r[k]
+            w, h = 0.04 + 0.3 * w * w, 0.04 + 0.3 * h * h
+            x0, x1 = int(max(0.0, cx - w / 2) * W), int(min(1.0, cx + w / 2) * W)
+            y0, y1 = int(max(0.0, cy - h / 2) * H), int(min(1.0, cy + h / 2) * H)
+            img[:, y0:y1, x0:x1] = col[k][:, None, None]
+        out[b] = img
+    out += (uniform(shape, -0.03, 0.03, name="scene_noise", seed=seed)).astype(np.float32)
+    return np.clip(out, 0.0, 1.0)
+
+
 def synth_predictions(bs, n, no, *, obj_pow=8, seed=0, img=640.0) -> np.ndarray:
     """Synthetic Detect output (bs, n, no) float32 as SURVEY 8d defines for the NMS benchmark.
 

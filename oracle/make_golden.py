@@ -21,10 +21,12 @@ from . import detgen, ref_shim
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
-def load_det_weights(model, seed=0):
+def load_det_weights(model, seed=0, condition=False):
     """Overwrite every parameter/buffer of a reference model with detgen values (anchors kept)."""
     sd = model.state_dict()
     new = detgen.fill_state_dict(sd, seed)
+    if condition:
+        detgen.condition_state_dict(new)
     for k, v in new.items():
         if v is not None:
             sd[k] = torch.from_numpy(v).to(sd[k].dtype)
@@ -78,6 +80,55 @@ def gen_forward(ns, name, yaml_rel, hw, bs, seed, row_stride, seg=False):
     np.savez_compressed(os.path.join(OUT, f"fwd_{name}.npz"), **out)
     print("fwd", name, z_fused.shape, float(np.abs(z_fused - z_unfused).max()))
     return m
+
+
+def head_calibration(z: torch.Tensor, nc: int, obj_frac=0.04):
+    """Bias shifts that give a random-init head a realistic NMS load (same rule as bench.py:calibrate_head): objectness of the
+    top `obj_frac` rows above 0.5, median best-class score 0.7.  Returns (d_obj, d_cls) logit offsets as python floats."""
+    import math
+
+    obj = z[..., 4].flatten()
+    q = float(obj.kthvalue(max(int(obj.numel() * (1 - obj_frac)), 1)).values.clamp(1e-6, 1 - 1e-6))
+    qc = float(z[..., 5:5 + nc].max(-1).values.flatten().median().clamp(1e-6, 1 - 1e-6))
+    logit = lambda v: math.log(v / (1 - v))  # noqa: E731
+    return logit(0.5) - logit(q), logit(0.7) - logit(qc)
+
+
+def gen_detset(ns, name, yaml_rel, hw, bs, seed, row_stride, seg=False, conf=0.25, iou=0.45, max_det=1000, obj_frac=0.004):
+    """BASELINE configs C2 / C4 / C5 at their real resolution: the REFERENCE's fused fp32 forward and its own non_max_suppression
+    on a calibrated head -> strided z rows + checksums, the Detect bias offsets that were applied (the test applies the same ones)
+    and the detections per image (the detection-set agreement target for the fp16 HIP path)."""
+    torch.manual_seed(0)
+    Model = ns.yolo.SegmentationModel if seg else ns.yolo.DetectionModel
+    m = Model(os.path.join(ns.root, yaml_rel))
+    load_det_weights(m, seed, condition=True)
+    m.eval().fuse()
+    det = m.model[-1]
+    x = torch.from_numpy(detgen.scene((bs, 3, hw, hw), seed=seed))
+    with torch.no_grad():
+        z0 = m(x)[0]
+        d_obj, d_cls = head_calibration(z0, det.nc, obj_frac)
+        for mi in det.m:
+            b = mi.bias.view(det.na, -1)
+            b[:, 4] += d_obj
+            b[:, 5:5 + det.nc] += d_cls
+        y = m(x)
+    z = y[0]
+    out = {"bias_shift": np.array([d_obj, d_cls], dtype=np.float64), "row_stride": np.array(row_stride), "shape": np.array(z.shape)}
+    sm = summarize(z.numpy(), row_stride)
+    out["z_rows"], out["z_sum"] = sm["rows"], sm["sum"]
+    nm = det.nm if seg else 0
+    if seg:
+        proto = y[1].numpy()
+        out["proto_sum"] = np.array([proto.astype(np.float64).sum(), np.abs(proto.astype(np.float64)).sum()])
+        out["proto_sample"] = proto[:, :, ::5, ::5]
+    with ref_shim.oracle_nms_mode():
+        res = ns.general.non_max_suppression(z.clone(), conf, iou, max_det=max_det, nm=nm)
+    for i, r in enumerate(res):
+        out[f"det{i}"] = r.numpy().astype(np.float32)
+    out["nms"] = np.array([conf, iou, max_det], dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, f"detset_{name}.npz"), **out)
+    print("detset", name, tuple(z.shape), [int(r.shape[0]) for r in res], "bias shift", d_obj, d_cls)
 
 
 def gen_fuse(ns):
@@ -387,10 +438,18 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     ns = ref_shim.load()
     torch.set_num_threads(os.cpu_count() or 1)
+    if len(sys.argv) > 1 and sys.argv[1] == "detset":  # only the full-resolution fixtures (the rest is unchanged)
+        gen_detset(ns, "yolov5s_640", "models/yolov5s.yaml", 640, 2, 3, 97)
+        gen_detset(ns, "yolov5x_1280", "models/yolov5x.yaml", 1280, 1, 4, 397, conf=0.40)
+        gen_detset(ns, "yolov5s-seg_640", "models/segment/yolov5s-seg.yaml", 640, 2, 5, 97, seg=True)
+        return 0
     gen_fuse(ns)
     gen_forward(ns, "yolov5n_64", "models/yolov5n.yaml", 64, 2, 0, 1)
     gen_forward(ns, "yolov5s_320", "models/yolov5s.yaml", 320, 2, 1, 41)
     gen_forward(ns, "yolov5n-seg_64", "models/segment/yolov5n-seg.yaml", 64, 2, 2, 1, seg=True)
+    gen_detset(ns, "yolov5s_640", "models/yolov5s.yaml", 640, 2, 3, 97)                                   # C2 shape class
+    gen_detset(ns, "yolov5x_1280", "models/yolov5x.yaml", 1280, 1, 4, 397, conf=0.40)                                # C4
+    gen_detset(ns, "yolov5s-seg_640", "models/segment/yolov5s-seg.yaml", 640, 2, 5, 97, seg=True)         # C5
     gen_nms(ns)
     gen_loss(ns)
     gen_mask(ns)

@@ -59,9 +59,10 @@ def test_hipddp_buckets_over_rccl_world1(pg):
     # the first bucket is complete (and on the wire) long before the last gradient of the plan is produced
     order = sorted(ddp._eng.goff, key=ddp._eng.goff.get)
     assert ddp.buckets[0].idxs == order[:len(ddp.buckets[0].idxs)]
-    for a, b in zip(local, red):
-        assert torch.equal(a, b)                                      # AVG over one rank = identity, bit for bit
-    # and a second step re-uses the buckets (same arena, same ranges)
-    red2 = grads(ddp)
-    for a, b in zip(local, red2):
-        assert torch.equal(a, b)
+    def same(u, v):  # AVG over one rank = identity; weight gradients are fp32 atomic sums (order-dependent in the last bits)
+        for a, b in zip(u, v):
+            tol = 1e-5 * float(a.abs().max()) + 1e-30
+            assert float((a - b).abs().max()) <= tol
+
+    same(local, red)
+    same(local, grads(ddp))   # a second step re-uses the buckets (same arena, same ranges)

@@ -46,6 +46,32 @@ def test_forward_matches_reference_golden(name, model, hw, bs, seed):
             np.testing.assert_allclose(proto[:, :, ::5, ::5], g["proto_sample"], rtol=2e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("name", ["yolov5s_640", "yolov5x_1280", "yolov5s-seg_640"])
+def test_full_resolution_forward_and_nms_match_reference_golden(name):
+    """BASELINE configs C2 / C4 / C5 at their real resolution: the oracle's fused forward and NMS against the reference's own
+    (tests/golden/detset_*.npz): z within 2e-4, detections identical in count, order and class, boxes / confidences within 1e-3."""
+    from tests import detset
+
+    g, cfg, x, seed, seg = detset.load(name)
+    sd = detset.state_dict(name, g, fused=True)
+    with torch.no_grad():
+        out = yo.model_forward(cfg, sd, x)
+    z = out[0].numpy()
+    assert tuple(g["shape"]) == z.shape
+    rs = int(g["row_stride"])
+    np.testing.assert_allclose(z.reshape(-1, z.shape[-1])[::rs], g["z_rows"], rtol=2e-4, atol=1e-3)
+    s = z.astype(np.float64)
+    np.testing.assert_allclose([s.sum(), np.abs(s).sum(), (s * s).sum()], g["z_sum"], rtol=1e-5)
+    if seg:
+        np.testing.assert_allclose(out[1].numpy()[:, :, ::5, ::5], g["proto_sample"], rtol=2e-4, atol=2e-4)
+    conf, iou, max_det = float(g["nms"][0]), float(g["nms"][1]), int(g["nms"][2])
+    dets = yo.non_max_suppression(z, conf, iou, max_det=max_det, nm=32 if seg else 0)
+    for i, d in enumerate(dets):
+        ref = g[f"det{i}"]
+        a = detset.agreement(ref, d, conf, box_atol=0.05, conf_atol=1e-3, iou_min=0.99, margin=1e-3)
+        assert a["unmatched_ref"] == 0 and a["unmatched_got"] == 0 and abs(len(ref) - len(d)) <= 2, (name, i, a, len(ref), len(d))
+
+
 def test_nparams_match():
     g = _load("fwd_yolov5s_320.npz")
     spec = yo.state_spec(yo.model_cfg("yolov5s"))
