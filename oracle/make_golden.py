@@ -434,10 +434,51 @@ def gen_letterbox(ns):
     np.savez_compressed(os.path.join(OUT, "letterbox.npz"), **out)
 
 
+TINY_CFG = {  # a 0.13 M-parameter YOLOv5 (reference schema, models/yolov5n.yaml with width 0.125): checkpoint fixtures stay small
+    "nc": 80, "depth_multiple": 0.33, "width_multiple": 0.125,
+    "anchors": [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]],
+    "backbone": [[-1, 1, "Conv", [64, 6, 2, 2]], [-1, 1, "Conv", [128, 3, 2]], [-1, 3, "C3", [128]], [-1, 1, "Conv", [256, 3, 2]],
+                 [-1, 6, "C3", [256]], [-1, 1, "Conv", [512, 3, 2]], [-1, 9, "C3", [512]], [-1, 1, "Conv", [1024, 3, 2]],
+                 [-1, 3, "C3", [1024]], [-1, 1, "SPPF", [1024, 5]]],
+    "head": [[-1, 1, "Conv", [512, 1, 1]], [-1, 1, "nn.Upsample", ["None", 2, "nearest"]], [[-1, 6], 1, "Concat", [1]],
+             [-1, 3, "C3", [512, False]], [-1, 1, "Conv", [256, 1, 1]], [-1, 1, "nn.Upsample", ["None", 2, "nearest"]],
+             [[-1, 4], 1, "Concat", [1]], [-1, 3, "C3", [256, False]], [-1, 1, "Conv", [256, 3, 2]], [[-1, 14], 1, "Concat", [1]],
+             [-1, 3, "C3", [512, False]], [-1, 1, "Conv", [512, 3, 2]], [[-1, 10], 1, "Concat", [1]], [-1, 3, "C3", [1024, False]],
+             [[17, 20, 23], 1, "Detect", ["nc", "anchors"]]],
+}
+
+
+def gen_ckpt(ns):
+    """A checkpoint exactly as the reference's train.py:469-488 writes it -- pickled REFERENCE classes (models.yolo.DetectionModel,
+    models.common.Conv, ...), fp16 -- of the tiny model above, plus what the reference computes from it after
+    models/experimental.py:attempt_load's steps (float, fuse, eval): tests load the file into the yolov5_amd classes."""
+    import copy
+    from copy import deepcopy
+
+    torch.manual_seed(0)
+    m = ns.yolo.DetectionModel(copy.deepcopy(TINY_CFG))
+    load_det_weights(m, 11)
+    m.names = {i: f"class{i}" for i in range(80)}
+    opt = ns.torch_utils.smart_optimizer(m, "SGD", 0.01, 0.937, 5e-4)
+    ckpt = {"epoch": 3, "best_fitness": 0.25, "model": deepcopy(m).half(), "ema": None, "updates": 7, "optimizer": opt.state_dict(),
+            "opt": {"imgsz": 64, "batch_size": 2}, "git": None, "date": "2026-01-01T00:00:00"}
+    path = os.path.join(OUT, "ckpt_ref_tiny.pt")
+    torch.save(ckpt, path)
+    mm = torch.load(path, map_location="cpu", weights_only=False)["model"].float().fuse().eval()
+    x = torch.from_numpy(detgen.uniform((2, 3, 64, 64), 0.0, 1.0, name="img", seed=11))
+    with torch.no_grad():
+        z, raw = mm(x)
+    np.savez_compressed(os.path.join(OUT, "ckpt_ref_tiny.npz"), z=z.numpy(), raw0=raw[0].numpy(), nparams=np.array(sum(p.numel() for p in mm.parameters())))
+    print("ckpt", os.path.getsize(path), tuple(z.shape))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = ref_shim.load()
     torch.set_num_threads(os.cpu_count() or 1)
+    if len(sys.argv) > 1 and sys.argv[1] == "ckpt":
+        gen_ckpt(ns)
+        return 0
     if len(sys.argv) > 1 and sys.argv[1] == "detset":  # only the full-resolution fixtures (the rest is unchanged)
         gen_detset(ns, "yolov5s_640", "models/yolov5s.yaml", 640, 2, 3, 97)
         gen_detset(ns, "yolov5x_1280", "models/yolov5x.yaml", 1280, 1, 4, 397, conf=0.40)
@@ -457,6 +498,7 @@ def main():
     gen_optim(ns)
     gen_metrics(ns)
     gen_letterbox(ns)
+    gen_ckpt(ns)
     sizes = {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT))}
     print(sizes, sum(sizes.values()))
 

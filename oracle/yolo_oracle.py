@@ -370,6 +370,36 @@ def scale_boxes(img1_shape, boxes, img0_shape, ratio_pad=None):
 # --------------------------------------------------------------------------------------------------
 # validation metrics (utils/metrics.py:25-126,224-265; val.py:296-307)
 # --------------------------------------------------------------------------------------------------
+def letterbox(im, new_shape=(640, 640), color=(114, 114, 114), auto=True, scaleFill=False, scaleup=True, stride=32):
+    """Restatement of utils/augmentations.py:85-115 on the restated OpenCV primitives (oracle/thirdparty.py: cv2_resize,
+    cv2_copy_make_border): uint8 HWC image -> (letterboxed image, (rw, rh), (dw, dh)).  Pinned against the reference's own
+    function through tests/golden/letterbox.npz (tests/test_oracle_golden.py)."""
+    from . import thirdparty as tp
+
+    h0, w0 = im.shape[:2]
+    if isinstance(new_shape, int):
+        new_shape = (new_shape, new_shape)
+    r = min(new_shape[0] / h0, new_shape[1] / w0)                      # :92
+    if not scaleup:
+        r = min(r, 1.0)                                                # :93-94
+    ratio = (r, r)
+    new_unpad = (round(w0 * r), round(h0 * r))                         # :98 (w, h)
+    dw, dh = new_shape[1] - new_unpad[0], new_shape[0] - new_unpad[1]  # :99
+    if auto:
+        dw, dh = dw % stride, dh % stride                              # :101 minimum rectangle
+    elif scaleFill:
+        dw, dh = 0.0, 0.0                                              # :103-105 stretch
+        new_unpad = (new_shape[1], new_shape[0])
+        ratio = (new_shape[1] / w0, new_shape[0] / h0)
+    dw, dh = dw / 2, dh / 2                                            # :107-108
+    if (w0, h0) != new_unpad:
+        im = tp.cv2_resize(im, new_unpad, interpolation=1)             # :110-111 INTER_LINEAR
+    top, bottom = round(dh - 0.1), round(dh + 0.1)                     # :112
+    left, right = round(dw - 0.1), round(dw + 0.1)                     # :113
+    im = tp.cv2_copy_make_border(im, top, bottom, left, right, 0, value=color)  # :114 BORDER_CONSTANT
+    return im, ratio, (dw, dh)
+
+
 def box_iou_np(box1, box2, eps=1e-7):
     """ultralytics.utils.metrics.box_iou (call site utils/metrics.py:252), float32 numpy, same operation order."""
     box1 = np.asarray(box1, np.float32)

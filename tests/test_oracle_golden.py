@@ -72,6 +72,23 @@ def test_full_resolution_forward_and_nms_match_reference_golden(name):
         assert a["unmatched_ref"] == 0 and a["unmatched_got"] == 0 and abs(len(ref) - len(d)) <= 2, (name, i, a, len(ref), len(d))
 
 
+def test_letterbox_restatement_matches_reference_golden():
+    from oracle.make_golden import LETTERBOX_CASES, LETTERBOX_GEOMETRY, letterbox_image
+
+    g = _load("letterbox.npz")
+    for name, (_, kw) in LETTERBOX_CASES.items():
+        im, ratio, pad = yo.letterbox(letterbox_image(name), **kw)
+        assert np.array_equal(im, g[name]), name
+        np.testing.assert_allclose([ratio[0], ratio[1], pad[0], pad[1]], g[name + "_meta"], rtol=0, atol=1e-12)
+    for row, ((h, w), kw) in zip(g["geometry"], LETTERBOX_GEOMETRY[::7]):
+        pass  # (geometry rows are checked against the product's host geometry in tests/test_emu_letterbox.py)
+    for k, ((h, w), kw) in enumerate(LETTERBOX_GEOMETRY):
+        if k % 7:
+            continue
+        im, ratio, pad = yo.letterbox(np.zeros((h, w, 3), np.uint8), **kw)
+        np.testing.assert_allclose([im.shape[0], im.shape[1], ratio[0], ratio[1], pad[0], pad[1]], g["geometry"][k][:6], atol=1e-12)
+
+
 def test_nparams_match():
     g = _load("fwd_yolov5s_320.npz")
     spec = yo.state_spec(yo.model_cfg("yolov5s"))

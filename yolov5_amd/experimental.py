@@ -16,6 +16,9 @@ def install_reference_aliases():
 
     if "models.yolo" in sys.modules and getattr(sys.modules["models.yolo"], "__y5amd__", False):
         return
+    if "models.yolo" in sys.modules:
+        # a REAL ultralytics/yolov5 checkout is imported in this process: its classes own those paths (pickles resolve to them)
+        raise RuntimeError("yolov5_amd: the reference's `models` package is already imported; cannot alias its class paths")
     pk = types.ModuleType("models")
     pk.__path__ = []
     my = types.ModuleType("models.yolo")
