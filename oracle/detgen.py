@@ -82,26 +82,39 @@ def fill_state_dict(sd: dict, seed: int = 0) -> dict:
     return out
 
 
-def condition_state_dict(vals: dict, residual_gain=0.25, head_gain=30.0, na=3, nc=80) -> dict:
-    """Make a fill_state_dict network well conditioned at FULL depth / resolution (used by the detset_* fixtures):
-    * every shortcut Bottleneck's last BatchNorm (`...m.<i>.cv2.bn.{weight,bias}`) is scaled by `residual_gain`: with He-scaled
-      filters each `x + f(x)` doubles the activation variance, and yolov5x stacks up to 12 of them per C3 (logits saturate,
-      fp16 overflows) -- real checkpoints have small residual branches too;
-    * the objectness / class rows of the Detect / Segment 1x1 filters (`<last>.m.<level>.weight`, rows a*no + 4 .. a*no + 4 + nc)
-      are scaled by `head_gain`, so that scores spread over (0, 1) instead of clustering at one value (a ranking among thousands
-      of near ties is not a parity test); the box and mask-coefficient rows keep their scale (boxes stay well formed).
+def condition_state_dict(vals: dict, bn_stats=None, head_affine=None) -> dict:
+    """Make a fill_state_dict network well conditioned at FULL depth / resolution (the detset_* fixtures):
+    * `bn_stats` = (means, vars): float32 vectors holding, concatenated in state_dict order, the running_mean / running_var of every
+      BatchNorm.  oracle/make_golden.py:gen_detset sets them to the batch statistics of the fixture's own input (one train-mode
+      pass of the reference with momentum 1), i.e. every layer's activations are normalised the way a trained network's are --
+      with the raw U(-0.1, 0.1) / U(0.8, 1.2) statistics the deep models saturate (yolov5x: 12 stacked shortcuts per C3) and the
+      head sees almost no position-dependent signal;
+    * `head_affine` = [(scale_l, bias_l)] per pyramid level, each (na*no,) float32: row r of the Detect / Segment 1x1 filter
+      `<last>.m.<l>.weight` is multiplied by scale_l[r] and the bias is REPLACED by bias_l (measured on the reference so that box /
+      objectness / class logits are spread like a trained head's: a ranking among near-tied scores is not a parity test).
     Works in place on {name: np.ndarray | None} and returns it."""
     import re
 
-    for k, v in vals.items():
-        if v is None:
-            continue
-        if re.search(r"\.m\.\d+\.cv2\.bn\.(weight|bias)$", k):
-            vals[k] = (v * np.float32(residual_gain)).astype(np.float32)
-        elif re.search(r"^model\.\d+\.m\.\d+\.weight$", k) and v.ndim == 4:
-            w = v.reshape(na, -1, *v.shape[1:]).copy()
-            w[:, 4:5 + nc] *= np.float32(head_gain)
-            vals[k] = w.reshape(v.shape).astype(np.float32)
+    if bn_stats is not None:
+        off = {"running_mean": 0, "running_var": 0}
+        for k, v in list(vals.items()):
+            for which, src in (("running_mean", bn_stats[0]), ("running_var", bn_stats[1])):
+                if k.endswith(which):
+                    n = int(v.size)
+                    vals[k] = np.asarray(src[off[which]:off[which] + n], dtype=np.float32).reshape(v.shape).copy()
+                    off[which] += n
+        assert off["running_mean"] == len(bn_stats[0]) and off["running_var"] == len(bn_stats[1]), "bn_stats length mismatch"
+    if head_affine is not None:
+        for k, v in list(vals.items()):
+            if v is None:
+                continue
+            mw = re.search(r"^model\.\d+\.m\.(\d+)\.weight$", k)
+            mb = re.search(r"^model\.\d+\.m\.(\d+)\.bias$", k)
+            if mw and v.ndim == 4:
+                sc = np.asarray(head_affine[int(mw.group(1))][0], dtype=np.float32)
+                vals[k] = (v * sc[:, None, None, None]).astype(np.float32)
+            elif mb and v.ndim == 1:
+                vals[k] = np.asarray(head_affine[int(mb.group(1))][1], dtype=np.float32).copy()
     return vals
 
 

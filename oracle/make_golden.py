@@ -21,12 +21,10 @@ from . import detgen, ref_shim
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
-def load_det_weights(model, seed=0, condition=False):
+def load_det_weights(model, seed=0):
     """Overwrite every parameter/buffer of a reference model with detgen values (anchors kept)."""
     sd = model.state_dict()
     new = detgen.fill_state_dict(sd, seed)
-    if condition:
-        detgen.condition_state_dict(new)
     for k, v in new.items():
         if v is not None:
             sd[k] = torch.from_numpy(v).to(sd[k].dtype)
@@ -82,39 +80,57 @@ def gen_forward(ns, name, yaml_rel, hw, bs, seed, row_stride, seg=False):
     return m
 
 
-def head_calibration(z: torch.Tensor, nc: int, obj_frac=0.04):
-    """Bias shifts that give a random-init head a realistic NMS load (same rule as bench.py:calibrate_head): objectness of the
-    top `obj_frac` rows above 0.5, median best-class score 0.7.  Returns (d_obj, d_cls) logit offsets as python floats."""
-    import math
+def head_affine_from_logits(raws, nc, obj=(-6.0, 2.0), cls=(-1.5, 1.5), xy=(0.0, 1.0), wh=(0.0, 0.7)):
+    """Per (anchor, output) affine that gives the objectness / class LOGITS of a random-init head a trained-looking spread: measured
+    mean / std over all positions of the raw (bs, na, ny, nx, no) maps -> target N(mean, std) for the box (anchor-sized boxes
+    instead of pixel-thin ones), objectness and class rows; mask-coefficient rows untouched.
+    Returns [(scale (na*no,), shift (na*no,))] per level, logit_new = scale * logit_old + shift."""
+    out = []
+    for r in raws:
+        na, no = r.shape[1], r.shape[4]
+        m = r.mean(dim=(0, 2, 3)).double()                      # (na, no)
+        sd = r.std(dim=(0, 2, 3)).double().clamp_min(1e-6)
+        scale = torch.ones(na, no, dtype=torch.float64)
+        shift = torch.zeros(na, no, dtype=torch.float64)
+        for cols, (tm, ts) in ((slice(0, 2), xy), (slice(2, 4), wh), (slice(4, 5), obj), (slice(5, 5 + nc), cls)):
+            scale[:, cols] = ts / sd[:, cols]
+            shift[:, cols] = tm - m[:, cols] * scale[:, cols]
+        out.append((scale.reshape(-1).float(), shift.reshape(-1).float()))
+    return out
 
-    obj = z[..., 4].flatten()
-    q = float(obj.kthvalue(max(int(obj.numel() * (1 - obj_frac)), 1)).values.clamp(1e-6, 1 - 1e-6))
-    qc = float(z[..., 5:5 + nc].max(-1).values.flatten().median().clamp(1e-6, 1 - 1e-6))
-    logit = lambda v: math.log(v / (1 - v))  # noqa: E731
-    return logit(0.5) - logit(q), logit(0.7) - logit(qc)
 
-
-def gen_detset(ns, name, yaml_rel, hw, bs, seed, row_stride, seg=False, conf=0.25, iou=0.45, max_det=1000, obj_frac=0.004):
+def gen_detset(ns, name, yaml_rel, hw, bs, seed, row_stride, seg=False, conf=0.25, iou=0.45, max_det=1000, obj=(-6.0, 2.0)):
     """BASELINE configs C2 / C4 / C5 at their real resolution: the REFERENCE's fused fp32 forward and its own non_max_suppression
-    on a calibrated head -> strided z rows + checksums, the Detect bias offsets that were applied (the test applies the same ones)
-    and the detections per image (the detection-set agreement target for the fp16 HIP path)."""
+    on a conditioned network (detgen.condition_state_dict: BatchNorm statistics calibrated on the input, head logits spread) ->
+    strided z rows + checksums, the statistics / head affine that were applied (the tests apply the same ones) and the detections per image (the detection-set agreement target for the fp16 HIP path)."""
     torch.manual_seed(0)
     Model = ns.yolo.SegmentationModel if seg else ns.yolo.DetectionModel
     m = Model(os.path.join(ns.root, yaml_rel))
-    load_det_weights(m, seed, condition=True)
-    m.eval().fuse()
+    load_det_weights(m, seed)
     det = m.model[-1]
     x = torch.from_numpy(detgen.scene((bs, 3, hw, hw), seed=seed))
+    out = {}
     with torch.no_grad():
-        z0 = m(x)[0]
-        d_obj, d_cls = head_calibration(z0, det.nc, obj_frac)
-        for mi in det.m:
-            b = mi.bias.view(det.na, -1)
-            b[:, 4] += d_obj
-            b[:, 5:5 + det.nc] += d_cls
+        # BatchNorm calibration: one train-mode pass with momentum 1 -> running statistics := batch statistics of this input
+        bns = [b for b in m.modules() if isinstance(b, torch.nn.BatchNorm2d)]
+        for b in bns:
+            b.momentum = 1.0
+        m.train()
+        m(x)
+        m.eval()
+        out["bn_mean"] = torch.cat([b.running_mean.flatten() for b in bns]).numpy().astype(np.float32)
+        out["bn_var"] = torch.cat([b.running_var.flatten() for b in bns]).numpy().astype(np.float32)
+        y0 = m(x)
+        aff = head_affine_from_logits(y0[2] if seg else y0[1], det.nc, obj=obj)
+        for i, (mi, (sc, sh)) in enumerate(zip(det.m, aff)):
+            new_b = (mi.bias.detach().float() * sc + sh).float()      # logit_new = sc * (w x + b) + sh
+            mi.weight.mul_(sc.view(-1, 1, 1, 1))
+            mi.bias.copy_(new_b)
+            out[f"head_scale{i}"], out[f"head_bias{i}"] = sc.numpy(), new_b.numpy()
+        m.fuse()
         y = m(x)
     z = y[0]
-    out = {"bias_shift": np.array([d_obj, d_cls], dtype=np.float64), "row_stride": np.array(row_stride), "shape": np.array(z.shape)}
+    out.update(row_stride=np.array(row_stride), shape=np.array(z.shape))
     sm = summarize(z.numpy(), row_stride)
     out["z_rows"], out["z_sum"] = sm["rows"], sm["sum"]
     nm = det.nm if seg else 0
@@ -127,8 +143,23 @@ def gen_detset(ns, name, yaml_rel, hw, bs, seed, row_stride, seg=False, conf=0.2
     for i, r in enumerate(res):
         out[f"det{i}"] = r.numpy().astype(np.float32)
     out["nms"] = np.array([conf, iou, max_det], dtype=np.float64)
+    # The same reference model in float64 (the "truth" both fp32 implementations are measured against: deep nets amplify
+    # accumulation-order noise beyond 1e-4) and in float16 (what `model.half()` computes on torch-CPU: fp32 accumulation, fp16
+    # storage -- the envelope an fp16 implementation of this network can be held to).
+    import copy
+
+    with torch.no_grad():
+        z64 = copy.deepcopy(m).double()(x.double())[0]
+        z16 = copy.deepcopy(m).half()(x.half())[0].float()
+    out["z64_rows"] = z64.numpy().reshape(-1, z64.shape[-1])[::row_stride]
+    out["z16_rows"] = z16.numpy().reshape(-1, z16.shape[-1])[::row_stride]
+    with ref_shim.oracle_nms_mode():
+        res16 = ns.general.non_max_suppression(z16.clone(), conf, iou, max_det=max_det, nm=nm)  # (fp32 arithmetic on the fp16 values)
+    for i, r in enumerate(res16):
+        out[f"det16_{i}"] = r.numpy().astype(np.float32)
     np.savez_compressed(os.path.join(OUT, f"detset_{name}.npz"), **out)
-    print("detset", name, tuple(z.shape), [int(r.shape[0]) for r in res], "bias shift", d_obj, d_cls)
+    print("detset", name, tuple(z.shape), [int(r.shape[0]) for r in res], [int(r.shape[0]) for r in res16],
+          "fp32 vs fp64 max", float((z.double() - z64).abs().max()), "fp16 vs fp32 max", float((z16 - z).abs().max()))
 
 
 def gen_fuse(ns):
@@ -481,7 +512,7 @@ def main():
         return 0
     if len(sys.argv) > 1 and sys.argv[1] == "detset":  # only the full-resolution fixtures (the rest is unchanged)
         gen_detset(ns, "yolov5s_640", "models/yolov5s.yaml", 640, 2, 3, 97)
-        gen_detset(ns, "yolov5x_1280", "models/yolov5x.yaml", 1280, 1, 4, 397, conf=0.40)
+        gen_detset(ns, "yolov5x_1280", "models/yolov5x.yaml", 1280, 1, 4, 397, obj=(-10.5, 2.0))
         gen_detset(ns, "yolov5s-seg_640", "models/segment/yolov5s-seg.yaml", 640, 2, 5, 97, seg=True)
         return 0
     gen_fuse(ns)
@@ -489,7 +520,7 @@ def main():
     gen_forward(ns, "yolov5s_320", "models/yolov5s.yaml", 320, 2, 1, 41)
     gen_forward(ns, "yolov5n-seg_64", "models/segment/yolov5n-seg.yaml", 64, 2, 2, 1, seg=True)
     gen_detset(ns, "yolov5s_640", "models/yolov5s.yaml", 640, 2, 3, 97)                                   # C2 shape class
-    gen_detset(ns, "yolov5x_1280", "models/yolov5x.yaml", 1280, 1, 4, 397, conf=0.40)                                # C4
+    gen_detset(ns, "yolov5x_1280", "models/yolov5x.yaml", 1280, 1, 4, 397, obj=(-10.5, 2.0))                                # C4
     gen_detset(ns, "yolov5s-seg_640", "models/segment/yolov5s-seg.yaml", 640, 2, 5, 97, seg=True)         # C5
     gen_nms(ns)
     gen_loss(ns)

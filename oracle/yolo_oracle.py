@@ -676,24 +676,15 @@ def state_spec(cfg: dict, ch: int = 3) -> dict:
     return spec
 
 
-def det_state_dict(cfg: dict, seed: int = 0, fused: bool = False, conditioned: bool = False, bias_shift=None) -> dict:
-    """The deterministic weights the golden fixtures were generated with (torch fp32 tensors).  conditioned / bias_shift: the
-    full-resolution detset_* fixtures (oracle/make_golden.py:gen_detset): detgen.condition_state_dict and the (d_obj, d_cls)
-    Detect bias offsets stored in the fixture."""
+def det_state_dict(cfg: dict, seed: int = 0, fused: bool = False, bn_stats=None, head_affine=None) -> dict:
+    """The deterministic weights the golden fixtures were generated with (torch fp32 tensors).  bn_stats / head_affine: the
+    full-resolution detset_* fixtures (oracle/make_golden.py:gen_detset -> detgen.condition_state_dict)."""
     from . import detgen
 
     spec = state_spec(cfg)
     vals = detgen.fill_state_dict(spec, seed)
-    if conditioned:
-        detgen.condition_state_dict(vals)
-    if bias_shift is not None:
-        nc = cfg["nc"]
-        for k, v in vals.items():
-            if v is not None and re.search(r"^model\.\d+\.m\.\d+\.bias$", k) and v.ndim == 1:
-                b = v.reshape(3, -1).astype(np.float64)  # (na, no): columns 4 = objectness, 5..5+nc = classes
-                b[:, 4] += float(bias_shift[0])
-                b[:, 5:5 + nc] += float(bias_shift[1])
-                vals[k] = b.reshape(-1).astype(np.float32)
+    if bn_stats is not None or head_affine is not None:
+        detgen.condition_state_dict(vals, bn_stats=bn_stats, head_affine=head_affine)
     sd = {}
     for k, v in vals.items():
         if v is None:

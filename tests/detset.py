@@ -25,7 +25,8 @@ def load(name):
 
 def state_dict(name, g, fused):
     model, _, _, seed, _ = CASES[name]
-    return yo.det_state_dict(yo.model_cfg(model), seed, fused=fused, conditioned=True, bias_shift=g["bias_shift"])
+    aff = [(g[f"head_scale{i}"], g[f"head_bias{i}"]) for i in range(3)]
+    return yo.det_state_dict(yo.model_cfg(model), seed, fused=fused, bn_stats=(g["bn_mean"], g["bn_var"]), head_affine=aff)
 
 
 def box_iou(a, b):
@@ -36,12 +37,12 @@ def box_iou(a, b):
     return inter / (aa[:, None] + bb[None, :] - inter + 1e-9)
 
 
-def agreement(ref, got, conf_thres, box_atol=2.0, conf_atol=0.02, iou_min=0.9, margin=0.01):
+def agreement(ref, got, conf_thres, box_atol=2.0, conf_atol=0.02, margin=0.01):
     """Detection-set agreement between two NMS outputs (k, 6+) [x1,y1,x2,y2,conf,cls]: every reference detection whose confidence
-    clears the threshold by `margin` must have a partner of the same class with IoU >= iou_min, corners within box_atol px and
-    confidence within conf_atol -- and vice versa.  Detections inside the margin around the confidence threshold may legitimately
-    appear on one side only (their kept / dropped decision flips within fp16 resolution), as may detections whose NMS decision was
-    a near tie (an IoU within 0.02 of the NMS threshold against a kept box); those are counted and bounded by the caller.
+    clears the threshold by `margin` must have a partner of the same class with all four corners within box_atol px and confidence
+    within conf_atol -- and vice versa.  Detections inside the margin around the confidence threshold may legitimately appear on
+    one side only (their kept / dropped decision flips within fp16 resolution), as may detections whose NMS decision was a near tie
+    (an IoU within fp16 noise of the NMS threshold against a kept box); those are counted and bounded by the caller.
     Returns dict(matched, ref_strong, got_strong, unmatched_ref, unmatched_got, max_box_err, max_conf_err)."""
     out = dict(matched=0, unmatched_ref=0, unmatched_got=0, max_box_err=0.0, max_conf_err=0.0)
     rs = ref[ref[:, 4] >= conf_thres + margin]
@@ -53,17 +54,16 @@ def agreement(ref, got, conf_thres, box_atol=2.0, conf_atol=0.02, iou_min=0.9, m
         if len(b) == 0:
             out[key] += len(a)
             continue
-        iou = box_iou(a[:, :4], b[:, :4])
-        same = a[:, None, 5] == b[None, :, 5]
-        iou = np.where(same, iou, -1.0)
-        j = iou.argmax(1)
-        ok = iou[np.arange(len(a)), j] >= iou_min
-        be = np.abs(a[:, :4] - b[j, :4]).max(1)
-        ce = np.abs(a[:, 4] - b[j, 4])
-        good = ok & (be <= box_atol) & (ce <= conf_atol)
+        dist = np.abs(a[:, None, :4] - b[None, :, :4]).max(2)                     # (na, nb) worst corner distance
+        dist = np.where(a[:, None, 5] == b[None, :, 5], dist, np.inf)
+        dist = np.where(np.abs(a[:, None, 4] - b[None, :, 4]) <= conf_atol, dist, np.inf)
+        j = dist.argmin(1)
+        be = dist[np.arange(len(a)), j]
+        good = be <= box_atol
         out[key] += int((~good).sum())
         if key == "unmatched_ref":
             out["matched"] = int(good.sum())
             if good.any():
-                out["max_box_err"], out["max_conf_err"] = float(be[good].max()), float(ce[good].max())
+                out["max_box_err"] = float(be[good].max())
+                out["max_conf_err"] = float(np.abs(a[good, 4] - b[j[good], 4]).max())
     return out

@@ -203,7 +203,10 @@ def test_yolov5s_fp16_640_vs_oracle(dev):
     assert z.shape == (2, 25200, 85)
     err_box = np.abs(z[..., :4] - ref[..., :4]).max()
     err_conf = np.abs(z[..., 4:] - ref[..., 4:]).max()
-    assert err_box < 1.0 and err_conf < 3e-2, (err_box, err_conf)  # check_amp-class tolerance (general.py:420: atol 0.1)
+    # utils/general.py:410-435 `check_amp` accepts AMP when the post-NMS *normalised* xywhn rows agree to atol 0.1 (= 64 px at 640^2);
+    # this bound is 64x tighter on the raw rows.  The envelope-based fp16 criteria (reference's own model.half() as yardstick,
+    # detection-set agreement) at the BASELINE configurations are tests/test_gpu_configs.py.
+    assert err_box < 1.0 and err_conf < 3e-2, (err_box, err_conf)
     assert np.abs(z[..., :4] - ref[..., :4]).mean() < 0.05
 
 

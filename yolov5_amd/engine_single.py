@@ -5,6 +5,7 @@ from __future__ import annotations
 
 import torch
 
+from . import _lib
 from .engine import Engine, PlanSpec, _Planner
 
 
