@@ -1,0 +1,125 @@
+"""GPU (-m gpu): the reference-shaped loops on the MI355X.
+  * C3 in miniature: yolov5n trained for 50 iterations on a fixed 32-image synthetic set by yolov5_amd.train_loop.train (warm-up,
+    accumulate, LambdaLR, loss scaling, fused clip + SGD + EMA) against oracle/train_oracle.py (fp32 torch-CPU autograd running the
+    same schedule, pinned to the reference's pieces in tests/test_oracle_vs_reference.py): schedule identical, loss curve within the
+    fp16 band, the model actually learns (loss falls), EMA / BatchNorm statistics track the oracle's;
+  * detect(): letterbox -> forward -> NMS -> scale_boxes for a batch of frames vs the oracle pipeline (detect.py:204-248);
+  * DetectPipeline: overlapped stages return exactly what the sequential calls return."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import detgen, train_oracle as to, yolo_oracle as yo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def test_train_loop_50_iterations_vs_oracle(dev):
+    from yolov5_amd.train_loop import TensorLoader, train
+    from yolov5_amd.yolo import DetectionModel
+
+    cfg = yo.model_cfg("yolov5n")
+    sd = yo.det_state_dict(cfg, 0, fused=False)
+    m = DetectionModel("yolov5n.yaml")
+    m.load_state_dict(sd)
+    m = m.to(dev)
+    imgs, tpi = to.synthetic_set(32, 128, per_img=3, seed=1)
+    bs, epochs = 8, 13                                   # 4 batches per epoch -> 52 iterations
+    hyp = dict(to.HYP)
+    res = train(m, TensorLoader(imgs.to(dev), [t.to(dev) for t in tpi], bs), hyp=dict(hyp), epochs=epochs, device=dev, amp=True)
+    torch.cuda.synchronize()
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = to.train_oracle(cfg, sd, imgs, tpi, bs, hyp=dict(hyp), epochs=epochs)
+    a, b = res["losses"].numpy(), ref["losses"].numpy()
+    assert a.shape == b.shape == (52, 3)
+    np.testing.assert_allclose(np.array(res["lr"]), np.array(ref["lr"]), rtol=1e-12)        # same schedule
+    assert res["ema"].updates == ref["updates"]
+    rel = np.abs(a.sum(1) - b.sum(1)) / b.sum(1)
+    print(f"\\n[train-loop] total loss first/last: hip {a.sum(1)[0]:.4f}/{a.sum(1)[-4:].mean():.4f}  oracle {b.sum(1)[0]:.4f}/{b.sum(1)[-4:].mean():.4f}; "
+          f"rel. deviation max {rel.max():.4f} mean {rel.mean():.4f}; scaler scale {res['scaler'].scale}, skipped {res['scaler'].skipped}")
+    assert rel[:8].max() < 0.03 and rel.mean() < 0.03 and rel.max() < 0.10, (rel.max(), rel.mean())
+    # it trains: the last epoch's mean loss is clearly below the first epoch's, for both
+    assert a.sum(1)[-4:].mean() < 0.9 * a.sum(1)[:4].mean() and b.sum(1)[-4:].mean() < 0.9 * b.sum(1)[:4].mean()
+    assert abs(a.sum(1)[-4:].mean() - b.sum(1)[-4:].mean()) < 0.03 * b.sum(1)[-4:].mean()     # final loss within 3 %
+    # EMA and BatchNorm running statistics follow the oracle's
+    esd = res["ema"].ema.state_dict()
+    worst = 0.0
+    for k, v in ref["ema"].items():
+        if v.dtype.is_floating_point and not k.endswith("anchors"):
+            d = float((esd[k].float().cpu() - v).norm() / (v.norm() + 1e-12))
+            worst = max(worst, d)
+    assert worst < 0.02, worst
+
+
+def test_detect_loop_batch_vs_oracle_pipeline(dev):
+    from yolov5_amd.detect_loop import detect
+    from yolov5_amd.yolo import DetectionModel
+
+    cfg = yo.model_cfg("yolov5n")
+    sd = yo.det_state_dict(cfg, 7, fused=False)
+    m = DetectionModel("yolov5n.yaml")
+    m.load_state_dict(sd)
+    det = m.model[-1]
+    with torch.no_grad():
+        for mi in det.m:
+            b = mi.bias.view(det.na, -1)
+            b[:, 4] += 1.5
+            b[:, 5:] += 1.0
+    m = m.eval().fuse().to(dev)
+    sd_f = {k: v.detach().float().cpu().clone() for k, v in m.state_dict().items()}
+    rng = np.random.default_rng(3)
+    ims = [rng.integers(0, 256, s, dtype=np.uint8) for s in ((240, 320, 3), (300, 200, 3), (128, 128, 3), (90, 400, 3))]
+    out = detect(m, ims, imgsz=320, conf_thres=0.25, iou_thres=0.45, max_det=300)
+    assert len(out) == 4
+    for im, got in zip(ims, out):
+        lb, _, _ = yo.letterbox(im, (320, 320), auto=False)
+        x = torch.from_numpy(np.ascontiguousarray(lb.transpose(2, 0, 1))[None]).float() / 255
+        with torch.no_grad():
+            z = yo.model_forward(cfg, sd_f, x)[0]
+        e = yo.non_max_suppression(z.numpy(), 0.25, 0.45, max_det=300)[0].copy()
+        yo.scale_boxes((320, 320), e[:, :4], im.shape[:2])
+        e[:, :4] = np.round(e[:, :4])
+        assert abs(len(got) - len(e)) <= max(1, 0.02 * len(e)) and len(e) > 5, (len(got), len(e))
+        if len(got) == len(e):
+            g = got.numpy()
+            assert np.array_equal(g[:, 5], e[:, 5])
+            assert np.abs(g[:, :4] - e[:, :4]).max() <= 1.0 and (np.abs(g[:, :4] - e[:, :4]) > 0).mean() < 0.02
+            np.testing.assert_allclose(g[:, 4], e[:, 4], rtol=1e-3, atol=1e-4)
+
+
+def test_detect_pipeline_equals_sequential(dev):
+    from yolov5_amd.detect_loop import DetectPipeline
+    from yolov5_amd.general import non_max_suppression
+    from yolov5_amd.yolo import DetectionModel
+
+    torch.manual_seed(0)
+    m = DetectionModel("yolov5n.yaml")
+    det = m.model[-1]
+    with torch.no_grad():
+        for mi in det.m:
+            b = mi.bias.view(det.na, -1)
+            b[:, 4] += 4.0
+            b[:, 5:] += 3.0
+    m = m.eval().fuse().half().to(dev)
+    det.export = True
+    xs = [torch.rand((4, 3, 256, 256), device=dev).half() for _ in range(5)]
+    seq = [non_max_suppression(m(x)[0].clone(), 0.25, 0.45, max_det=300) for x in xs]
+    pipe = DetectPipeline(m, 0.25, 0.45, max_det=300)
+    got = []
+    for x in xs:
+        r = pipe.submit(x)
+        if r is not None:
+            got.append(r)
+    got.append(pipe.flush())
+    assert len(got) == len(seq) == 5
+    for a, b in zip(seq, got):
+        assert len(a) == len(b) == 4
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+    assert sum(len(u) for a in seq for u in a) > 20

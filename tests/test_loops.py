@@ -1,0 +1,112 @@
+"""CPU (emulator seam): the reference-shaped loops of yolov5_amd/train_loop.py and detect_loop.py.
+  * the schedule arithmetic of train.py:234-248,372-434 (accumulate, weight-decay scaling, warm-up interpolation of lr / momentum,
+    LambdaLR) is compared exactly with the oracle loop (oracle/train_oracle.py) -- it does not depend on the kernels;
+  * a short run of the tiny model: the fp16 HIP loss curve follows the fp32 oracle's (the long run at yolov5n scale, 50 steps, is the
+    GPU test tests/test_gpu_loops.py);
+  * detect(): letterbox -> forward -> NMS -> scale_boxes against the same steps taken with the oracle's pieces (detect.py:204-248)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import detgen, train_oracle as to, yolo_oracle as yo
+from oracle.make_golden import TINY_CFG
+from tests.hipemu import backend as emu_backend
+
+
+@pytest.fixture(autouse=True)
+def _seam():
+    emu_backend.install()
+    yield
+    emu_backend.uninstall()
+
+
+def _tiny(seed=0):
+    from yolov5_amd.yolo import DetectionModel
+
+    cfg = copy.deepcopy(TINY_CFG)
+    spec = yo.state_spec(cfg)
+    sd = yo.det_state_dict(cfg, seed, fused=False)
+    m = DetectionModel(copy.deepcopy(TINY_CFG))
+    m.load_state_dict(sd)
+    return m, cfg, sd
+
+
+def test_lr_lambda_and_scaler_policy():
+    from yolov5_amd.train_loop import LossScaler, lr_lambda
+
+    lin, cos = lr_lambda(10, 0.01), lr_lambda(10, 0.01, cos_lr=True)
+    assert lin(0) == 1.0 and abs(lin(10) - 0.01) < 1e-12 and abs(lin(5) - 0.505) < 1e-12       # train.py:243-246
+    assert cos(0) == 1.0 and abs(cos(10) - 0.01) < 1e-12 and abs(cos(5) - 0.505) < 1e-12       # one_cycle(1, lrf, epochs)
+    s = LossScaler(enabled=True, init_scale=1024.0, growth_interval=2)
+    s.record(torch.tensor([1.0, 1.0, 1.0, 0.0])); s.update()
+    assert s.scale == 512.0 and s.skipped == 1                                                  # overflow: x0.5
+    for _ in range(2):
+        s.record(torch.tensor([1.0, 1.0, 0.0, 0.0])); s.update()
+    assert s.scale == 1024.0                                                                    # 2 clean steps: x2
+    assert LossScaler(enabled=False).scale == 1.0
+
+
+def test_train_loop_schedule_and_loss_curve_vs_oracle():
+    from yolov5_amd.train_loop import TensorLoader, train
+
+    m, cfg, sd = _tiny(seed=2)
+    imgs, tpi = to.synthetic_set(6, 64, per_img=2, seed=4)
+    bs, epochs = 2, 2
+    hyp = dict(to.HYP)
+    seen = []
+    res = train(m, TensorLoader(imgs, tpi, bs), hyp=dict(hyp), epochs=epochs, device="cpu", amp=True,
+                on_batch_end=lambda ni, li, opt: seen.append((ni, [g["lr"] for g in opt.param_groups], [g["momentum"] for g in opt.param_groups])))
+    ref = to.train_oracle(cfg, sd, imgs, tpi, bs, hyp=dict(hyp), epochs=epochs)
+    # schedule: identical numbers (pure host arithmetic)
+    np.testing.assert_allclose(np.array(res["lr"]), np.array(ref["lr"]), rtol=1e-12)
+    assert len(seen) == 6 and seen[0][0] == 0
+    nw = max(round(hyp["warmup_epochs"] * 3), 100)
+    assert abs(seen[3][1][0] - np.interp(3, [0, nw], [hyp["warmup_bias_lr"], hyp["lr0"] * ((1 - 1 / epochs) * (1 - hyp["lrf"]) + hyp["lrf"])])) < 1e-12
+    assert abs(seen[3][2][0] - np.interp(3, [0, nw], [hyp["warmup_momentum"], hyp["momentum"]])) < 1e-12
+    # weight decay scaled by batch_size * accumulate / nbs (train.py:236): 2 * 32 / 64 = 1
+    assert abs(res["optimizer"].param_groups[1]["weight_decay"] - hyp["weight_decay"] * bs * round(64 / bs) / 64) < 1e-15
+    # accumulate follows np.interp(ni, [0, nw], [1, 32]).round() = 1, 1, 2, 2, 2, 3: the optimizer steps at ni = 0, 1, 3 only
+    assert res["ema"].updates == ref["updates"] == 3
+    # loss curve: fp16 HIP vs fp32 oracle
+    a, b = res["losses"].numpy(), ref["losses"].numpy()
+    assert a.shape == b.shape == (6, 3)
+    np.testing.assert_allclose(a, b, rtol=0.05, atol=2e-3)
+    assert res["scaler"].skipped == 0 and res["scaler"].scale == 65536.0
+    # parameters moved the same way (fp16 gradients vs fp32): direction of the total update
+    d_h = torch.cat([(p.detach() - sd[k]).flatten() for k, p in m.named_parameters()])
+    d_o = torch.cat([(ref["sd"][k] - sd[k]).flatten() for k, _ in m.named_parameters()])
+    cosine = float(d_h @ d_o / (d_h.norm() * d_o.norm()))
+    assert cosine > 0.9, cosine
+
+
+def test_detect_loop_matches_oracle_pipeline():
+    from yolov5_amd.detect_loop import detect
+
+    m, cfg, sd = _tiny(seed=5)
+    det = m.model[-1]
+    with torch.no_grad():
+        for mi in det.m:
+            b = mi.bias.view(det.na, -1)
+            b[:, 4] += 3.0
+            b[:, 5:] += 2.0
+    m = m.eval().fuse()
+    sd_f = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    rng = np.random.default_rng(9)
+    ims = [rng.integers(0, 256, (40, 72, 3), dtype=np.uint8), rng.integers(0, 256, (64, 48, 3), dtype=np.uint8),
+           rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)]
+    out = detect(m, ims, imgsz=64, conf_thres=0.3, iou_thres=0.45, max_det=40, batch_size=2)
+    assert len(out) == 3
+    for im, got in zip(ims, out):
+        lb, ratio, pad = yo.letterbox(im, (64, 64), auto=False)                                        # detect.py's LoadImages
+        x = torch.from_numpy(np.ascontiguousarray(lb.transpose(2, 0, 1))[None]).float() / 255            # :205-210
+        with torch.no_grad():
+            z = yo.model_forward(cfg, sd_f, x)[0]
+        e = yo.non_max_suppression(z.numpy(), 0.3, 0.45, max_det=40)[0].copy()                          # :225
+        yo.scale_boxes((64, 64), e[:, :4], im.shape[:2])
+        e[:, :4] = np.round(e[:, :4])                                                                     # :248
+        assert got.shape == e.shape and len(e) > 0
+        np.testing.assert_allclose(got.numpy()[:, :4], e[:, :4], atol=1.0)    # a coordinate at x.5 +- 1e-4 may round either way
+        assert (np.abs(got.numpy()[:, :4] - e[:, :4]) > 0).mean() < 0.05
+        np.testing.assert_allclose(got.numpy()[:, 4:], e[:, 4:], rtol=1e-4, atol=1e-4)

@@ -79,3 +79,68 @@ def test_process_batch_and_ap_match_live_reference(ns):
     o = yo.ap_per_class(tp, conf, pcls, tcls)
     for a, b in zip(r, o):
         np.testing.assert_allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), rtol=0, atol=1e-12)
+
+
+def test_training_loop_restatement_matches_reference_pieces(ns):
+    """oracle/train_oracle.py (the fp32 yardstick of the train-loop tests) against the same schedule driven through the REFERENCE's own
+    DetectionModel (train mode), ComputeLoss, smart_optimizer and ModelEMA (train.py:234-248,372-434): per-iteration loss items,
+    final parameters and EMA must agree to fp32 round-off."""
+    import copy
+
+    from oracle import train_oracle as to
+    from oracle.make_golden import TINY_CFG, load_det_weights
+
+    imgs, tpi = to.synthetic_set(8, 64, per_img=2, seed=6)
+    bs, epochs = 4, 3
+    hyp = dict(to.HYP)
+    cfg = copy.deepcopy(TINY_CFG)
+    sd = yo.det_state_dict(cfg, 9, fused=False)
+    ref = to.train_oracle(cfg, sd, imgs, tpi, bs, hyp=dict(hyp), epochs=epochs, cos_lr=True)
+
+    torch.manual_seed(0)
+    m = ns.yolo.DetectionModel(copy.deepcopy(TINY_CFG))
+    load_det_weights(m, 9)
+    h = dict(hyp)
+    nbs, nb = 64, 2
+    accumulate = max(round(nbs / bs), 1)
+    h["weight_decay"] *= bs * accumulate / nbs
+    opt = ns.torch_utils.smart_optimizer(m, "SGD", h["lr0"], h["momentum"], h["weight_decay"])
+    import math
+
+    lf = lambda x: ((1 - math.cos(x * math.pi / epochs)) / 2) * (h["lrf"] - 1) + 1  # noqa: E731  one_cycle(1, lrf, epochs)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lf)
+    ema = ns.torch_utils.ModelEMA(m)
+    m.hyp = h
+    cl = ns.loss.ComputeLoss(m)
+    nw = max(round(h["warmup_epochs"] * nb), 100)
+    last, losses = -1, []
+    for epoch in range(epochs):
+        m.train()
+        opt.zero_grad()
+        for i in range(nb):
+            ids = list(range(i * bs, (i + 1) * bs))
+            ni = i + nb * epoch
+            x = imgs[ids].float() / 255
+            t = torch.cat([torch.cat((torch.full((len(tpi[j]), 1), float(k)), tpi[j][:, 1:]), 1) for k, j in enumerate(ids)], 0)
+            if ni <= nw:
+                accumulate = max(1, np.interp(ni, [0, nw], [1, nbs / bs]).round())
+                for j, g in enumerate(opt.param_groups):
+                    g["lr"] = np.interp(ni, [0, nw], [h["warmup_bias_lr"] if j == 0 else 0.0, g["initial_lr"] * lf(epoch)])
+                    g["momentum"] = np.interp(ni, [0, nw], [h["warmup_momentum"], h["momentum"]])
+            loss, items = cl(m(x), t)
+            loss.backward()
+            if ni - last >= accumulate:
+                torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=10.0)
+                opt.step()
+                opt.zero_grad()
+                ema.update(m)
+                last = ni
+            losses.append(items.detach().clone())
+        sched.step()
+    np.testing.assert_allclose(ref["losses"].numpy(), torch.stack(losses).numpy(), rtol=2e-4, atol=1e-6)
+    assert ref["updates"] == ema.updates
+    msd, esd = m.state_dict(), ema.ema.state_dict()
+    for k, v in ref["sd"].items():
+        if v.dtype.is_floating_point and not k.endswith("anchors"):
+            np.testing.assert_allclose(v.numpy(), msd[k].numpy(), rtol=2e-3, atol=2e-5, err_msg=k)
+            np.testing.assert_allclose(ref["ema"][k].numpy(), esd[k].numpy(), rtol=2e-3, atol=2e-5, err_msg="ema " + k)

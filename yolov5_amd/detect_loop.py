@@ -1,0 +1,108 @@
+"""The reference's detection loop, composed from the yolov5_amd seams (detect.py:201-260): per source image
+`letterbox -> CHW / RGB / float / 255 -> model -> non_max_suppression -> scale_boxes(...).round()`, here batched on the device:
+
+  * images are decoded on the host (PIL; the reference uses cv2.imread, BGR -- `bgr=True` for arrays that come from cv2);
+  * letterbox + layout + normalisation of a whole batch is ONE launch over the raw uint8 frames (augmentations.letterbox_batch:
+    the host computes only utils/augmentations.py:85-115's geometry), the model forward is one plan replay, NMS is one kernel chain
+    for all images and the de-letterboxing of all detections (general.py:613-626, detect.py:248 with .round()) one more launch;
+  * `DetectPipeline` overlaps stages of consecutive batches on two HIP streams: the NMS + scale_boxes of batch i run while the
+    forward of batch i+1 occupies the chip (the tails of the forward's persistent kernels leave CUs idle; NMS is latency-bound).
+
+Not the CLI: no argparse, video / stream sources, annotator or file writers."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from .augmentations import letterbox_batch
+from .general import non_max_suppression, scale_boxes_batch
+
+
+def load_image(path):
+    """HWC uint8 RGB array of an image file (detect.py's LoadImages decodes with cv2.imread -> BGR; the channel order is a flag here)."""
+    from PIL import Image
+
+    with Image.open(path) as im:
+        return np.asarray(im.convert("RGB"))
+
+
+def _to_device_frames(images, device):
+    return [torch.from_numpy(np.ascontiguousarray(im)).to(device) if not torch.is_tensor(im) else im.to(device) for im in images]
+
+
+@torch.no_grad()
+def detect(model, images, imgsz=640, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic_nms=False, max_det=1000, bgr=False,
+           auto=False, stride=32, half=None, batch_size=None):
+    """images: list of HWC uint8 arrays / tensors (or file paths).  Returns a list (one entry per image) of (k, 6) fp32 CPU tensors
+    [x1, y1, x2, y2, conf, cls] in ORIGINAL image pixels, rounded like detect.py:248.  model: DetectionModel / DetectMultiBackend."""
+    inner = getattr(model, "model", model) if hasattr(model, "pt") else model
+    p = next(inner.parameters())
+    device = p.device
+    dtype = torch.float16 if (half if half is not None else p.dtype == torch.float16) else torch.float32
+    imgs = [load_image(im) if isinstance(im, (str, os.PathLike)) else im for im in images]
+    if isinstance(imgsz, int):
+        imgsz = (imgsz, imgsz)
+    out = []
+    bs = batch_size or len(imgs)
+    for b0 in range(0, len(imgs), bs):
+        frames = _to_device_frames(imgs[b0:b0 + bs], device)
+        # rect inference (`auto=True`, dataloaders.py LoadImages) gives per-image shapes; one batch needs one shape
+        x, shapes = letterbox_batch(frames, imgsz, auto=auto and len(frames) == 1, stride=stride, dtype=dtype, swap_rb=bgr)
+        y = model(x)
+        pred = y[0] if isinstance(y, (list, tuple)) else y
+        det, cnt = non_max_suppression(pred, conf_thres, iou_thres, classes, agnostic_nms, max_det=max_det, padded=True)
+        # detect.py:248 calls scale_boxes WITHOUT ratio_pad: gain / pad are recomputed from the two shapes (general.py:615-617), which
+        # differs from the letterbox's own (rounded) padding by a fraction of a pixel -- val.py:298 is the caller that passes it
+        scale_boxes_batch(tuple(x.shape[2:]), det, cnt, [s[0] for s in shapes], None, round_=True)
+        counts = cnt.tolist()
+        out += [det[i, :counts[i]].cpu() for i in range(len(frames))]
+    return out
+
+
+class DetectPipeline:
+    """Two-stage software pipeline over batches that are already resident in HBM: `submit(x)` launches the forward of `x` on the
+    caller's stream and the NMS (+ optional de-letterboxing) of the PREVIOUS batch on a side stream, and returns the previous batch's
+    result (None for the first call); `flush()` returns the last one.  Every batch goes through exactly the kernels of
+    `non_max_suppression(model(x)[0])`; only their placement in time changes."""
+
+    def __init__(self, model, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, max_det=1000, nm=0):
+        self.model = model
+        self.kw = dict(conf_thres=conf_thres, iou_thres=iou_thres, classes=classes, agnostic=agnostic, max_det=max_det, nm=nm)
+        self.side = None
+        self._inflight = None  # (z, event: forward done)
+
+    def _post(self, z, ev):
+        cur = torch.cuda.current_stream(z.device)
+        if self.side is None:
+            self.side = torch.cuda.Stream(z.device)
+        self.side.wait_event(ev)
+        with torch.cuda.stream(self.side):
+            det, cnt = non_max_suppression(z, padded=True, **self.kw)
+            z.record_stream(self.side)
+            done = torch.cuda.Event()
+            done.record(self.side)
+        return det, cnt, done
+
+    def submit(self, x):
+        prev = self._inflight
+        post = self._post(*prev) if prev is not None else None   # queue the previous batch's NMS first: it starts as soon as its forward ends
+        z = self.model(x)[0]
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(z.device))
+        self._inflight = (z, ev)
+        return self._collect(post)
+
+    def flush(self):
+        prev, self._inflight = self._inflight, None
+        return self._collect(self._post(*prev)) if prev is not None else None
+
+    @staticmethod
+    def _collect(post):
+        if post is None:
+            return None
+        det, cnt, done = post
+        done.synchronize()                      # the one host sync per batch (the counts' D2H copy needs the kernels done)
+        counts = cnt.tolist()
+        return [det[i, :counts[i]] for i in range(det.shape[0])]
