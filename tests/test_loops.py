@@ -110,3 +110,44 @@ def test_detect_loop_matches_oracle_pipeline():
         np.testing.assert_allclose(got.numpy()[:, :4], e[:, :4], atol=1.0)    # a coordinate at x.5 +- 1e-4 may round either way
         assert (np.abs(got.numpy()[:, :4] - e[:, :4]) > 0).mean() < 0.05
         np.testing.assert_allclose(got.numpy()[:, 4:], e[:, 4:], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/data/images"), reason="the reference's sample images are only in the build container")
+def test_detect_on_reference_sample_images_C1():
+    """BASELINE config C1 (plumbing): data/images/{bus,zidane}.jpg -> detect() end to end (PIL decode, device letterbox, yolov5n
+    forward, NMS, scale_boxes + round), small imgsz so the emulator finishes; against the oracle pipeline on the same decoded pixels."""
+    import os
+
+    from yolov5_amd.detect_loop import detect, load_image
+    from yolov5_amd.yolo import DetectionModel
+
+    cfg = yo.model_cfg("yolov5n")
+    sd = yo.det_state_dict(cfg, 0, fused=False)
+    m = DetectionModel("yolov5n.yaml")
+    m.load_state_dict(sd)
+    det = m.model[-1]
+    with torch.no_grad():
+        for mi in det.m:
+            b = mi.bias.view(det.na, -1)
+            b[:, 4] += 1.5
+            b[:, 5:] += 1.0
+    m = m.eval().fuse()
+    sd_f = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    paths = [os.path.join("/root/reference/data/images", f) for f in ("bus.jpg", "zidane.jpg")]
+    out = detect(m, paths, imgsz=96, conf_thres=0.25, iou_thres=0.45, max_det=100)
+    assert len(out) == 2
+    from tests import detset
+
+    for pth, got in zip(paths, out):
+        im = load_image(pth)
+        assert im.ndim == 3 and im.shape[2] == 3 and im.dtype == np.uint8
+        lb, _, _ = yo.letterbox(im, (96, 96), auto=False)
+        x = torch.from_numpy(np.ascontiguousarray(lb.transpose(2, 0, 1))[None]).float() / 255
+        with torch.no_grad():
+            z = yo.model_forward(cfg, sd_f, x)[0]
+        e = yo.non_max_suppression(z.numpy(), 0.25, 0.45, max_det=100)[0].copy()
+        yo.scale_boxes((96, 96), e[:, :4], im.shape[:2])
+        e[:, :4] = np.round(e[:, :4])
+        assert (got[:, 2] <= im.shape[1]).all() and (got[:, 3] <= im.shape[0]).all() and len(e) > 3
+        a = detset.agreement(e, got.numpy(), 0.25, box_atol=1.0, conf_atol=1e-3, margin=1e-3)
+        assert a["unmatched_ref"] + a["unmatched_got"] <= 1, a

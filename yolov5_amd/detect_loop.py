@@ -25,7 +25,7 @@ def load_image(path):
     from PIL import Image
 
     with Image.open(path) as im:
-        return np.asarray(im.convert("RGB"))
+        return np.array(im.convert("RGB"))  # (a writable copy: torch.from_numpy wants one)
 
 
 def _to_device_frames(images, device):
