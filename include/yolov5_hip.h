@@ -304,6 +304,26 @@ int y5_scale_boxes_batch(float* det, int ld_det, int max_det, const int* det_cou
                          void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * y5_mosaic_batch -- the training input pipeline for a whole batch in one launch: utils/dataloaders.py:798-855 `load_mosaic`
+ * (four images resized to the training size by `load_image` :770-790 and tiled on a 2s x 2s canvas of 114s), the image half of
+ * utils/augmentations.py:118-166 `random_perspective` (cv2.warpAffine, INTER_LINEAR, border 114, output s x s), :69-83 `augment_hsv`,
+ * the flips of dataloaders.py:747-757, `img.transpose((2, 0, 1))[::-1]` (:761) and collate_fn's torch.stack (:862).  Draws, geometry
+ * and labels are the host's (yolov5_amd/dataloaders.py); jobs_dev is a DEVICE array of B descriptors.  Source images: uint8 HWC BGR.
+ * dst: (B, 3, S, S) RGB planes, uint8 / fp16 / fp32 (div255: divide by 255 like train.py:375).
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* src[4];            /* the four source images of the mosaic in tile order (NULL = no tile) */
+  int h0[4], w0[4], stride[4];   /* original size, row stride in bytes */
+  int rh[4], rw[4];              /* size after load_image's resize (longest side = s) */
+  int x1a[4], y1a[4], x2a[4], y2a[4];  /* tile rectangle on the canvas (dataloaders.py:812-822) */
+  int x1b[4], y1b[4];            /* top-left corner of the part of the resized image that lands there */
+  double A[6];                   /* INVERSE affine map of cv2.warpAffine: src = A @ (x, y, 1) */
+  unsigned char lut[3][256];     /* hue / saturation / value look-up tables of augment_hsv */
+  int hsv, flipud, fliplr, reserved;
+} y5_mosaic_job;
+int y5_mosaic_batch(const y5_mosaic_job* jobs_dev, int B, int S, int pad_value, void* dst, int dst_dtype, int div255, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Execution plan: a recorded list of the calls above, replayed by ONE host call (and optionally through a
  * captured hipGraph).  Replaces the Python module walk of models/yolo.py:160-170 `_forward_once`.
  * ------------------------------------------------------------------------------------------------------- */

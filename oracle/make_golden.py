@@ -465,6 +465,54 @@ def gen_letterbox(ns):
     np.savez_compressed(os.path.join(OUT, "letterbox.npz"), **out)
 
 
+def gen_augment(ns):
+    """The reference's own `LoadImagesAndLabels.__getitem__` (mosaic branch: load_mosaic -> random_perspective -> augment_hsv -> flips ->
+    CHW / RGB) + `collate_fn` on a synthetic 6-image dataset, one batch per seed, with Python's / numpy's generators seeded so that
+    oracle/augment_oracle.py:reference_draws reproduces the draws.  The dataset object is a bare namespace carrying exactly the
+    attributes those methods read (no files, no cache)."""
+    import types
+
+    import utils.dataloaders as dl
+
+    from . import augment_oracle as ao, thirdparty as tp
+
+    dl.xywhn2xyxy, dl.xyxy2xywhn = tp.xywhn2xyxy, tp.xyxy2xywhn
+    s = 96
+    ims, labs = ao.synthetic_dataset(6, seed=3)
+    hyp = dict(ao.HYP_AUG, degrees=5.0, shear=2.0, flipud=0.3)  # exercise rotation / shear / up-down flip too
+    cls = dl.LoadImagesAndLabels
+    ds = types.SimpleNamespace(img_size=s, mosaic=True, augment=True, hyp=hyp, mosaic_border=[-s // 2, -s // 2], rect=False,
+                               indices=list(range(len(ims))), labels=[lb.astype(np.float32).copy() for lb in labs],
+                               segments=[[] for _ in ims], ims=[None] * len(ims), im_files=[f"im{i}" for i in range(len(ims))],
+                               npy_files=[types.SimpleNamespace(exists=lambda: False)] * len(ims), albumentations=lambda im, lb: (im, lb))
+    ds.load_mosaic = types.MethodType(cls.load_mosaic, ds)
+
+    def load_image(self, i):  # dataloaders.py:770-790 with cv2.imread replaced by the in-memory image
+        im = ims[i]
+        h0, w0 = im.shape[:2]
+        r = self.img_size / max(h0, w0)
+        if r != 1:
+            im = dl.cv2.resize(im, (math.ceil(w0 * r), math.ceil(h0 * r)), interpolation=dl.cv2.INTER_LINEAR)
+        return im, (h0, w0), im.shape[:2]
+
+    import math
+    import random
+
+    ds.load_image = types.MethodType(load_image, ds)
+    out = {"s": np.array(s)}
+    for seed in (1, 2, 3, 4):
+        batch = []
+        for index in (seed % 6, (seed + 3) % 6):
+            random.seed(seed * 10 + index)
+            np.random.seed(seed * 10 + index)
+            im, lab, _, _ = cls.__getitem__(ds, index)
+            batch.append((im, lab, "", None))
+        imb, labb, _, _ = cls.collate_fn(batch)
+        out[f"img{seed}"], out[f"lab{seed}"] = imb.numpy(), labb.numpy()
+        print("augment", seed, tuple(imb.shape), tuple(labb.shape))
+    np.savez_compressed(os.path.join(OUT, "augment.npz"), **out)
+
+
 TINY_CFG = {  # a 0.13 M-parameter YOLOv5 (reference schema, models/yolov5n.yaml with width 0.125): checkpoint fixtures stay small
     "nc": 80, "depth_multiple": 0.33, "width_multiple": 0.125,
     "anchors": [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]],
@@ -507,6 +555,9 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     ns = ref_shim.load()
     torch.set_num_threads(os.cpu_count() or 1)
+    if len(sys.argv) > 1 and sys.argv[1] == "augment":
+        gen_augment(ns)
+        return 0
     if len(sys.argv) > 1 and sys.argv[1] == "ckpt":
         gen_ckpt(ns)
         return 0
@@ -530,6 +581,7 @@ def main():
     gen_metrics(ns)
     gen_letterbox(ns)
     gen_ckpt(ns)
+    gen_augment(ns)
     sizes = {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT))}
     print(sizes, sum(sizes.values()))
 

@@ -78,6 +78,11 @@ def load():
     sys.modules["cv2"].INTER_LINEAR, sys.modules["cv2"].BORDER_CONSTANT = 1, 0
     sys.modules["cv2"].resize = tp.cv2_resize  # restated, parity unpinned (oracle/thirdparty.py)
     sys.modules["cv2"].copyMakeBorder = tp.cv2_copy_make_border
+    cv2m = sys.modules["cv2"]  # training augmentations (restated, parity unpinned): warpAffine, HSV conversion, LUT
+    cv2m.INTER_AREA, cv2m.COLOR_BGR2HSV, cv2m.COLOR_HSV2BGR = 3, tp.COLOR_BGR2HSV, tp.COLOR_HSV2BGR
+    cv2m.getRotationMatrix2D = lambda angle=0, center=(0, 0), scale=1.0: tp.cv2_get_rotation_matrix_2d(center, angle, scale)
+    cv2m.warpAffine = tp.cv2_warp_affine
+    cv2m.cvtColor, cv2m.LUT, cv2m.split, cv2m.merge = tp.cv2_cvt_color, tp.cv2_lut, tp.cv2_split, tp.cv2_merge
     sys.modules["torchvision"].__version__ = "0.19.0"
 
     # --- real implementations for the symbols the hot path touches -------------------

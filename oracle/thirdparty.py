@@ -253,3 +253,205 @@ def nms(boxes, scores, iou_threshold):
                 ovr = inter / (areas[i] + areas[i + 1:] - inter)
             suppressed[i + 1:] |= ovr > thr
     return torch.as_tensor(np.asarray(keep, dtype=np.int64), device=boxes.device)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# OpenCV primitives of the training augmentations (utils/augmentations.py:69-83 augment_hsv, :118-190 random_perspective).
+# PARITY UNPINNED: opencv-python (requirements.txt:9) is neither in the tree nor installed; these restate the published 8-bit
+# algorithms of modules/imgproc (imgwarp.cpp: warpAffine -> remap with INTER_BITS = 5 fixed-point coordinates and 15-bit bilinear
+# weights; color_hsv: the integer RGB->HSV of RGB2HSV_b and the float HSV->RGB of HSV2RGB_b).
+# --------------------------------------------------------------------------------------------------------------------
+COLOR_BGR2HSV, COLOR_HSV2BGR = 40, 54
+
+
+def cv2_get_rotation_matrix_2d(center, angle, scale):
+    """cv2.getRotationMatrix2D; call site utils/augmentations.py:143.  angle in degrees, positive = counter-clockwise (image y down)."""
+    import numpy as np
+
+    a = angle * math.pi / 180.0
+    alpha, beta = math.cos(a) * scale, math.sin(a) * scale
+    cx, cy = center
+    return np.array([[alpha, beta, (1 - alpha) * cx - beta * cy], [-beta, alpha, beta * cx + (1 - alpha) * cy]], dtype=np.float64)
+
+
+def _sat_int(v):
+    """saturate_cast<int>(double): round half to even (cvRound / lrint), clamped to int32."""
+    import numpy as np
+
+    return np.clip(np.rint(v), -2147483648.0, 2147483647.0).astype(np.int64)
+
+
+def warp_affine_coeffs(M):
+    """The inverse map cv::warpAffine derives from the forward 2x3 matrix (imgwarp.cpp): dst(x, y) = src(A @ (x, y, 1))."""
+    import numpy as np
+
+    m = np.array(M, dtype=np.float64).reshape(2, 3).copy()
+    D = m[0, 0] * m[1, 1] - m[0, 1] * m[1, 0]
+    D = 1.0 / D if D != 0 else 0.0
+    A11, A22 = m[1, 1] * D, m[0, 0] * D
+    m[0, 0] = A11
+    m[0, 1] *= -D
+    m[1, 0] *= -D
+    m[1, 1] = A22
+    b1 = -m[0, 0] * m[0, 2] - m[0, 1] * m[1, 2]
+    b2 = -m[1, 0] * m[0, 2] - m[1, 1] * m[1, 2]
+    m[0, 2], m[1, 2] = b1, b2
+    return m
+
+
+def warp_affine_fixed_point(A, width, height):
+    """Fixed-point source coordinates of every destination pixel exactly as WarpAffineInvoker forms them: AB_BITS = 10,
+    INTER_BITS = 5, round_delta = AB_SCALE / INTER_TAB_SIZE / 2.  Returns int64 (X, Y) arrays (height, width) with 5 fractional bits."""
+    import numpy as np
+
+    AB, IB = 10, 5
+    x = np.arange(width, dtype=np.float64)
+    y = np.arange(height, dtype=np.float64)
+    adelta = _sat_int(A[0, 0] * x * (1 << AB))
+    bdelta = _sat_int(A[1, 0] * x * (1 << AB))
+    rd = (1 << AB) // (1 << IB) // 2
+    X0 = _sat_int((A[0, 1] * y + A[0, 2]) * (1 << AB)) + rd
+    Y0 = _sat_int((A[1, 1] * y + A[1, 2]) * (1 << AB)) + rd
+    X = (X0[:, None] + adelta[None, :]) >> (AB - IB)
+    Y = (Y0[:, None] + bdelta[None, :]) >> (AB - IB)
+    return X, Y
+
+
+def cv2_warp_affine(src, M, dsize, dst=None, flags=1, borderMode=0, borderValue=(0, 0, 0)):
+    """cv2.warpAffine(im, M[:2], dsize=(w, h), borderValue=(114, 114, 114)) for 8-bit images, INTER_LINEAR + BORDER_CONSTANT;
+    call site utils/augmentations.py:166.  Each destination pixel: fixed-point source position (above), integer part (sx, sy),
+    5-bit fractions (fx, fy); the four neighbours (constant border value where outside the image) weighted by
+    (32 - fx)(32 - fy), fx (32 - fy), (32 - fx) fy, fx fy (x 32 = 15-bit weights that sum to 32768); out = (sum + 2^14) >> 15."""
+    import numpy as np
+
+    assert flags == 1 and borderMode == 0 and src.dtype == np.uint8
+    s3 = src[:, :, None] if src.ndim == 2 else src
+    sh, sw, cn = s3.shape
+    w, h = int(dsize[0]), int(dsize[1])
+    A = warp_affine_coeffs(M)
+    X, Y = warp_affine_fixed_point(A, w, h)
+    sx = np.clip(X >> 5, -32768, 32767)  # saturate_cast<short>
+    sy = np.clip(Y >> 5, -32768, 32767)
+    fx, fy = X & 31, Y & 31
+    bv = np.zeros(cn, dtype=np.int64)
+    bvs = np.atleast_1d(np.asarray(borderValue, dtype=np.float64))
+    for c in range(cn):
+        bv[c] = int(np.clip(np.rint(bvs[c] if c < len(bvs) else 0.0), 0, 255))
+    a = s3.astype(np.int64)
+
+    def sample(yy, xx):
+        inside = (yy >= 0) & (yy < sh) & (xx >= 0) & (xx < sw)
+        v = a[np.clip(yy, 0, sh - 1), np.clip(xx, 0, sw - 1)]
+        return np.where(inside[..., None], v, bv[None, None, :])
+
+    w00 = ((32 - fx) * (32 - fy) * 32)[..., None]
+    w01 = (fx * (32 - fy) * 32)[..., None]
+    w10 = ((32 - fx) * fy * 32)[..., None]
+    w11 = (fx * fy * 32)[..., None]
+    out = (sample(sy, sx) * w00 + sample(sy, sx + 1) * w01 + sample(sy + 1, sx) * w10 + sample(sy + 1, sx + 1) * w11 + (1 << 14)) >> 15
+    out = np.clip(out, 0, 255).astype(np.uint8)
+    return out[:, :, 0] if src.ndim == 2 else out
+
+
+def _hsv_div_tables():
+    import numpy as np
+
+    i = np.arange(1, 256, dtype=np.float64)
+    sdiv = np.zeros(256, dtype=np.int64)
+    hdiv = np.zeros(256, dtype=np.int64)
+    sdiv[1:] = _sat_int((255 << 12) / (1.0 * i))
+    hdiv[1:] = _sat_int((180 << 12) / (6.0 * i))
+    return sdiv, hdiv
+
+
+def cv2_bgr2hsv(im):
+    """cv2.cvtColor(im, cv2.COLOR_BGR2HSV) for uint8 (H in 0..179): RGB2HSV_b's integer arithmetic, hsv_shift = 12."""
+    import numpy as np
+
+    sdiv, hdiv = _hsv_div_tables()
+    b, g, r = (im[..., k].astype(np.int64) for k in range(3))
+    v = np.maximum(np.maximum(b, g), r)
+    vmin = np.minimum(np.minimum(b, g), r)
+    diff = v - vmin
+    vr, vg = v == r, v == g
+    s = (diff * sdiv[v] + (1 << 11)) >> 12
+    h = np.where(vr, g - b, np.where(vg, b - r + 2 * diff, r - g + 4 * diff))
+    h = (h * hdiv[diff] + (1 << 11)) >> 12
+    h = h + np.where(h < 0, 180, 0)
+    return np.stack((np.clip(h, 0, 255), s, v), -1).astype(np.uint8)
+
+
+def cv2_hsv2bgr(hsv):
+    """cv2.cvtColor(hsv, cv2.COLOR_HSV2BGR) for uint8: HSV2RGB_b = the float conversion on (h, s / 255, v / 255) with hscale = 6 / 180,
+    result * 255 rounded (half to even) and saturated."""
+    import numpy as np
+
+    f32 = np.float32
+    h = hsv[..., 0].astype(f32) * f32(6.0 / 180.0)
+    s = hsv[..., 1].astype(f32) * f32(1.0 / 255.0)
+    v = hsv[..., 2].astype(f32) * f32(1.0 / 255.0)
+    h = np.where(h < 0, h + f32(6), h)
+    h = np.where(h >= 6, h - f32(6), h)
+    sector = np.floor(h).astype(np.int64)
+    frac = (h - sector.astype(f32)).astype(f32)
+    bad = (sector < 0) | (sector >= 6)
+    sector = np.where(bad, 0, sector)
+    frac = np.where(bad, f32(0), frac)
+    one = f32(1.0)
+    tab = np.stack((v, (v * (one - s)).astype(f32), (v * (one - (s * frac).astype(f32))).astype(f32),
+                    (v * (one - (s * (one - frac)).astype(f32))).astype(f32)), -1)
+    sd = np.array([[1, 3, 0], [1, 0, 2], [3, 0, 1], [0, 2, 1], [0, 1, 3], [2, 1, 0]], dtype=np.int64)  # (b, g, r) <- tab index per sector
+    idx = sd[sector]
+    bgr = np.take_along_axis(tab, idx, -1)
+    grey = (hsv[..., 1] == 0)[..., None]
+    bgr = np.where(grey, v[..., None], bgr)
+    out = np.rint((bgr * f32(255.0)).astype(f32))
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def cv2_cvt_color(src, code, dst=None):
+    """cv2.cvtColor for the two codes augment_hsv uses (utils/augmentations.py:73,83); `dst=` is filled in place like OpenCV does."""
+    out = cv2_bgr2hsv(src) if code == COLOR_BGR2HSV else cv2_hsv2bgr(src) if code == COLOR_HSV2BGR else None
+    if out is None:
+        raise NotImplementedError(f"cvtColor code {code}")
+    if dst is not None:
+        dst[...] = out
+        return dst
+    return out
+
+
+def cv2_lut(src, lut):
+    return lut[src]
+
+
+def cv2_split(m):
+    return [m[..., k] for k in range(m.shape[-1])]
+
+
+def cv2_merge(mv):
+    import numpy as np
+
+    return np.stack(list(mv), -1)
+
+
+def xywhn2xyxy(x, w=640, h=640, padw=0, padh=0):
+    """ultralytics.utils.ops.xywhn2xyxy; call sites utils/dataloaders.py:721,838: normalised (cx, cy, w, h) -> pixel corners + padding."""
+    y = x.clone() if isinstance(x, torch.Tensor) else x.copy()
+    y[..., 0] = w * (x[..., 0] - x[..., 2] / 2) + padw
+    y[..., 1] = h * (x[..., 1] - x[..., 3] / 2) + padh
+    y[..., 2] = w * (x[..., 0] + x[..., 2] / 2) + padw
+    y[..., 3] = h * (x[..., 1] + x[..., 3] / 2) + padh
+    return y
+
+
+def xyxy2xywhn(x, w=640, h=640, clip=False, eps=0.0):
+    """ultralytics.utils.ops.xyxy2xywhn; call site utils/dataloaders.py:737: pixel corners -> normalised (cx, cy, w, h), optionally
+    clipped to the image (minus eps) IN PLACE first."""
+    if clip:
+        clip_boxes(x, (h - eps, w - eps))
+    y = x.clone() if isinstance(x, torch.Tensor) else x.copy()
+    y[..., 0] = ((x[..., 0] + x[..., 2]) / 2) / w
+    y[..., 1] = ((x[..., 1] + x[..., 3]) / 2) / h
+    y[..., 2] = (x[..., 2] - x[..., 0]) / w
+    y[..., 3] = (x[..., 3] - x[..., 1]) / h
+    return y

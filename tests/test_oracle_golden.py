@@ -188,3 +188,23 @@ def test_scale_boxes():
     b = detgen.uniform((20, 4), -20, 660, name="sb", seed=14)
     np.testing.assert_allclose(yo.scale_boxes((640, 640), b.copy(), (1080, 810)), g["a"], rtol=1e-6, atol=1e-5)
     np.testing.assert_allclose(yo.scale_boxes((384, 640), b.copy(), (720, 1280)), g["b"], rtol=1e-6, atol=1e-5)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_training_sample_pipeline_matches_reference_golden(seed):
+    """oracle/augment_oracle.py (mosaic + random_perspective + HSV + flips + CHW/RGB + collate, draws passed in) against the batch the
+    reference's own LoadImagesAndLabels.__getitem__ / collate_fn produced (tests/golden/augment.npz): pixels and labels identical."""
+    from oracle import augment_oracle as ao
+
+    g = _load("augment.npz")
+    s = int(g["s"])
+    ims, labs = ao.synthetic_dataset(6, seed=3)
+    labs = [lb.astype(np.float32) for lb in labs]
+    hyp = dict(ao.HYP_AUG, degrees=5.0, shear=2.0, flipud=0.3)
+    samples = []
+    for index in (seed % 6, (seed + 3) % 6):
+        d = ao.reference_draws(seed * 10 + index, index, 6, s, hyp)
+        samples.append(ao.mosaic_sample(ims, labs, d, s, hyp))
+    imb, labb = ao.collate(samples)
+    assert np.array_equal(imb, g[f"img{seed}"])
+    assert labb.shape == g[f"lab{seed}"].shape and np.array_equal(labb, g[f"lab{seed}"])

@@ -45,6 +45,12 @@ class LetterboxJob(C.Structure):
     _fields_ = [("src", C.c_void_p)] + [(n, C.c_int) for n in ("h0", "w0", "stride", "nw", "nh", "top", "left")]
 
 
+class MosaicJob(C.Structure):
+    """include/yolov5_hip.h: y5_mosaic_job (one output image of a y5_mosaic_batch launch)."""
+    _fields_ = [("src", C.c_void_p * 4)] + [(n, C.c_int * 4) for n in ("h0", "w0", "stride", "rh", "rw", "x1a", "y1a", "x2a", "y2a", "x1b", "y1b")] + \
+               [("A", C.c_double * 6), ("lut", (C.c_ubyte * 256) * 3), ("hsv", C.c_int), ("flipud", C.c_int), ("fliplr", C.c_int), ("reserved", C.c_int)]
+
+
 class MtTensor(C.Structure):
     """include/yolov5_hip.h: y5_mt_tensor (one row of the fused optimizer's device-resident tensor table)."""
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("mom", C.c_void_p), ("ema", C.c_void_p), ("n", C.c_longlong),
@@ -110,6 +116,7 @@ EXPORTS = {
     "y5_loss_targets_layout": (C.c_int, [C.POINTER(LossDesc), C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_longlong)]),
     "y5_process_mask": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "y5_mosaic_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "y5_letterbox_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "y5_val_match": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1,0 +1,157 @@
+// Training input pipeline on the device: one launch renders a whole batch of training images, each of them
+//     load_mosaic            utils/dataloaders.py:798-855   4 images resized to the training size, tiled on a 2s x 2s canvas of 114s
+//     random_perspective     utils/augmentations.py:118-166 cv2.warpAffine(canvas, M[:2], (s, s), borderValue 114), INTER_LINEAR
+//     augment_hsv            utils/augmentations.py:69-83   BGR -> HSV, three 256-entry LUTs, HSV -> BGR
+//     flipud / fliplr        utils/dataloaders.py:747-757
+//     img.transpose((2, 0, 1))[::-1]  + collate's torch.stack   :761-762, :858-863   -> (B, 3, s, s) RGB planes, uint8 or fp16 / 255
+// without ever materialising the resized tiles or the canvas: an output pixel is traced back through the flips and the inverse
+// affine map to four canvas pixels, each of which is either the 114 fill or ONE pixel of a resized tile, itself computed from four
+// pixels of the original image with cv2.resize's fixed-point arithmetic (resize_u8.h).  All random draws, the geometry (tile
+// rectangles, inverse matrix, LUTs) and the label transform are the host's business (yolov5_amd/dataloaders.py); the kernel is
+// integer / fixed-point byte work, bit-identical to the oracle restatement (oracle/augment_oracle.py + oracle/thirdparty.py).
+// cv2 is a third-party dependency of the reference (opencv-python, absent here): warpAffine's coordinate generation (AB_BITS = 10,
+// INTER_BITS = 5, round_delta = 16), its 15-bit bilinear weights, RGB2HSV_b's integer arithmetic (hsv_shift = 12) and HSV2RGB_b's
+// float path are restated from the published algorithms (modules/imgproc/src/imgwarp.cpp, color_hsv).
+// HBM-bound byte gathers; built with -ffp-contract=off (the double-precision coordinate set-up must round like the CPU's).
+#include <hip/hip_runtime.h>
+
+#include "../../include/yolov5_hip.h"
+#include "y5_common.h"
+#include "y5_host.h"
+#include "resize_u8.h"
+
+namespace {
+struct AugParams {
+  const y5_mosaic_job* jobs;
+  void* dst;
+  int B, S, dst_dtype, div255, pad;
+};
+
+__device__ inline long long sat_int(double v) {  // saturate_cast<int>(double): cvRound = round half to even, clamped
+  const double r = rint(v);
+  return r < -2147483648.0 ? -2147483648LL : (r > 2147483647.0 ? 2147483647LL : (long long)r);
+}
+
+// pixel (yy, xx) of the virtual 2s x 2s mosaic canvas
+__device__ inline void canvas_pixel(const y5_mosaic_job& j, const ResizeGeom* g, int S2, int pad, int yy, int xx, int out[3]) {
+  out[0] = out[1] = out[2] = pad;
+  if (yy < 0 || xx < 0 || yy >= S2 || xx >= S2) return;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {  // later tiles overwrite earlier ones where rectangles touch (assignment order of load_mosaic)
+    if (j.src[t] && yy >= j.y1a[t] && yy < j.y2a[t] && xx >= j.x1a[t] && xx < j.x2a[t])
+      resized_pixel(static_cast<const unsigned char*>(j.src[t]), j.h0[t], j.w0[t], j.stride[t], g[t], yy - j.y1a[t] + j.y1b[t],
+                    xx - j.x1a[t] + j.x1b[t], out);
+  }
+}
+
+__device__ inline void bgr2hsv_u8(int b, int g, int r, int& h, int& s, int& v) {  // RGB2HSV_b, H in 0..179
+  v = b > g ? b : g; v = v > r ? v : r;
+  int vmin = b < g ? b : g; vmin = vmin < r ? vmin : r;
+  const int diff = v - vmin;
+  const int sdiv = v ? (int)sat_int((double)(255 << 12) / (double)v) : 0;
+  const int hdiv = diff ? (int)sat_int((double)(180 << 12) / (6.0 * (double)diff)) : 0;
+  s = (diff * sdiv + (1 << 11)) >> 12;
+  int hh = v == r ? g - b : (v == g ? b - r + 2 * diff : r - g + 4 * diff);
+  hh = (hh * hdiv + (1 << 11)) >> 12;
+  if (hh < 0) hh += 180;
+  h = hh > 255 ? 255 : hh;
+}
+
+__device__ inline void hsv2bgr_u8(int h8, int s8, int v8, int out[3]) {  // HSV2RGB_b: float path, hscale = 6 / 180
+  float h = (float)h8 * (float)(6.0 / 180.0);
+  const float s = (float)s8 * (float)(1.0 / 255.0), v = (float)v8 * (float)(1.0 / 255.0);
+  float bgr[3];
+  if (s8 == 0) {
+    bgr[0] = bgr[1] = bgr[2] = v;
+  } else {
+    if (h < 0.f) h += 6.f;
+    if (h >= 6.f) h -= 6.f;
+    int sector = (int)floorf(h);
+    h -= (float)sector;
+    if ((unsigned)sector >= 6u) { sector = 0; h = 0.f; }
+    float tab[4];
+    tab[0] = v;
+    tab[1] = v * (1.f - s);
+    tab[2] = v * (1.f - s * h);
+    tab[3] = v * (1.f - s * (1.f - h));
+    const int sd[6][3] = {{1, 3, 0}, {1, 0, 2}, {3, 0, 1}, {0, 2, 1}, {0, 1, 3}, {2, 1, 0}};
+    bgr[0] = tab[sd[sector][0]]; bgr[1] = tab[sd[sector][1]]; bgr[2] = tab[sd[sector][2]];
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int q = (int)rintf(bgr[c] * 255.f);
+    out[c] = q < 0 ? 0 : (q > 255 ? 255 : q);
+  }
+}
+}  // namespace
+
+__global__ __launch_bounds__(256)
+void y5_mosaic_kernel(const AugParams p) {
+  const int b = blockIdx.y;
+  const int id = blockIdx.x * 256 + threadIdx.x;
+  const int S = p.S;
+  if (id >= S * S) return;
+  const int oy = id / S, ox = id - oy * S;
+  const y5_mosaic_job& j = p.jobs[b];
+  const int y = j.flipud ? S - 1 - oy : oy, x = j.fliplr ? S - 1 - ox : ox;   // np.flipud / np.fliplr of the warped image
+  ResizeGeom g[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) g[t] = resize_geom(j.h0[t], j.w0[t], j.rh[t], j.rw[t]);
+  // WarpAffineInvoker: fixed-point source position with 5 fractional bits
+  const long long adelta = sat_int(j.A[0] * (double)x * 1024.0), bdelta = sat_int(j.A[3] * (double)x * 1024.0);
+  const long long X0 = sat_int((j.A[1] * (double)y + j.A[2]) * 1024.0) + 16, Y0 = sat_int((j.A[4] * (double)y + j.A[5]) * 1024.0) + 16;
+  const long long X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
+  long long sxl = X >> 5, syl = Y >> 5;
+  sxl = sxl < -32768 ? -32768 : (sxl > 32767 ? 32767 : sxl);  // saturate_cast<short>
+  syl = syl < -32768 ? -32768 : (syl > 32767 ? 32767 : syl);
+  const int sx = (int)sxl, sy = (int)syl, fx = (int)(X & 31), fy = (int)(Y & 31);
+  int p00[3], p01[3], p10[3], p11[3];
+  const int S2 = 2 * S;
+  canvas_pixel(j, g, S2, p.pad, sy, sx, p00);
+  canvas_pixel(j, g, S2, p.pad, sy, sx + 1, p01);
+  canvas_pixel(j, g, S2, p.pad, sy + 1, sx, p10);
+  canvas_pixel(j, g, S2, p.pad, sy + 1, sx + 1, p11);
+  const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+  int bgr[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int q = (p00[c] * w00 + p01[c] * w01 + p10[c] * w10 + p11[c] * w11 + (1 << 14)) >> 15;
+    bgr[c] = q < 0 ? 0 : (q > 255 ? 255 : q);
+  }
+  if (j.hsv) {
+    int h, s, v;
+    bgr2hsv_u8(bgr[0], bgr[1], bgr[2], h, s, v);
+    hsv2bgr_u8(j.lut[0][h], j.lut[1][s], j.lut[2][v], bgr);
+  }
+  const size_t plane = (size_t)S * S, o = (size_t)oy * S + ox;
+  // CHW, RGB: plane 0 = R = bgr[2]
+  if (p.dst_dtype == Y5_U8) {
+    unsigned char* d = static_cast<unsigned char*>(p.dst) + (size_t)b * 3 * plane;
+    d[o] = (unsigned char)bgr[2]; d[plane + o] = (unsigned char)bgr[1]; d[2 * plane + o] = (unsigned char)bgr[0];
+  } else if (p.dst_dtype == Y5_F16) {
+    _Float16* d = static_cast<_Float16*>(p.dst) + (size_t)b * 3 * plane;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float f = (float)bgr[2 - c];
+      d[c * plane + o] = (_Float16)(p.div255 ? f / 255.0f : f);
+    }
+  } else {
+    float* d = static_cast<float*>(p.dst) + (size_t)b * 3 * plane;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float f = (float)bgr[2 - c];
+      d[c * plane + o] = p.div255 ? f / 255.0f : f;
+    }
+  }
+}
+
+extern "C" int y5_mosaic_batch(const y5_mosaic_job* jobs_dev, int B, int S, int pad_value, void* dst, int dst_dtype, int div255, void* stream_) {
+  if (!jobs_dev || !dst) return y5_fail(Y5_ERR_BAD_ARG, "mosaic_batch: null pointer");
+  if (B < 1 || B > 65535 || S < 2 || S > 16384 || pad_value < 0 || pad_value > 255) return y5_fail(Y5_ERR_BAD_ARG, "mosaic_batch: bad B / S / pad value");
+  if (dst_dtype != Y5_U8 && dst_dtype != Y5_F16 && dst_dtype != Y5_F32) return y5_fail(Y5_ERR_BAD_ARG, "mosaic_batch: dst dtype must be u8, f16 or f32");
+  AugParams p{};
+  p.jobs = jobs_dev; p.dst = dst; p.B = B; p.S = S; p.dst_dtype = dst_dtype; p.div255 = div255; p.pad = pad_value;
+  const long long n = (long long)S * S;
+  hipLaunchKernelGGL(y5_mosaic_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, static_cast<hipStream_t>(stream_), p);
+  return y5_check_launch("y5_mosaic_batch");
+}

@@ -18,6 +18,7 @@
 #include "../../include/yolov5_hip.h"
 #include "y5_common.h"
 #include "y5_host.h"
+#include "resize_u8.h"
 
 namespace {
 constexpr int PX = 8;  // output pixels per lane
@@ -28,37 +29,6 @@ struct LbParams {
   int B, H, W, pad, swap_rb, dst_dtype, chw, div255;
 };
 
-struct Axis { int s0, s1, w0, w1; };  // two taps and their 11-bit weights
-
-__device__ inline int rint_short(float v) {  // saturate_cast<short>(float): round half to even
-  const int i = (int)rintf(v);
-  return i < -32768 ? -32768 : (i > 32767 ? 32767 : i);
-}
-
-__device__ inline Axis axis_x(int d, double scale, int n) {
-  float f = (float)(((double)d + 0.5) * scale - 0.5);
-  int s = (int)floorf(f);
-  f -= (float)s;
-  if (s < 0) { s = 0; f = 0.f; }
-  if (s >= n - 1) { s = n - 1; f = 0.f; }
-  Axis a;
-  a.s0 = s; a.s1 = s + 1 < n ? s + 1 : n - 1;
-  a.w0 = rint_short((1.f - f) * 2048.f); a.w1 = rint_short(f * 2048.f);
-  return a;
-}
-
-__device__ inline Axis axis_y(int d, double scale, int n) {
-  float f = (float)(((double)d + 0.5) * scale - 0.5);
-  const int s = (int)floorf(f);
-  f -= (float)s;
-  Axis a;
-  a.s0 = s < 0 ? 0 : (s < n ? s : n - 1);
-  a.s1 = s + 1 < 0 ? 0 : (s + 1 < n ? s + 1 : n - 1);
-  a.w0 = rint_short((1.f - f) * 2048.f); a.w1 = rint_short(f * 2048.f);
-  return a;
-}
-
-__device__ inline bool is_int_scale(double scale, int k) { return fabs(scale - (double)k) < 2.220446049250313e-16 && (int)rint(scale) == k; }
 }  // namespace
 
 __global__ __launch_bounds__(256)
