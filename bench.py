@@ -74,12 +74,14 @@ def conv_flops(engine):
     out = []
     B = engine.spec.B
     for i, op in enumerate(engine.spec.ops):
-        if op["op"] != "conv":
+        subs = [op] if op["op"] == "conv" else [op["cv1"], op["cv2"]] if op["op"] == "bneck" else []
+        if not subs:
             continue
         fl = 0
-        for m in op["mods"]:
-            cv = m.conv if hasattr(m, "conv") else m
-            fl += 2 * B * op["y"].H * op["y"].W * cv.out_channels * cv.in_channels * cv.kernel_size[0] * cv.kernel_size[1]
+        for sub in subs:
+            for m in sub["mods"]:
+                cv = m.conv if hasattr(m, "conv") else m
+                fl += 2 * B * sub["y"].H * sub["y"].W * cv.out_channels * cv.in_channels * cv.kernel_size[0] * cv.kernel_size[1]
         out.append((i, fl))
     return out
 
@@ -87,21 +89,29 @@ def conv_flops(engine):
 def conv_bytes(engine, esize=2):
     """Algorithmic HBM bytes per conv launch (SURVEY.md 8(d) "per-layer unfused conv traffic"): input read once + output
     written once (+ the residual read of a Bottleneck add) + filter read once, true channel counts, `esize` bytes/element.
-    The input of the NCHW stem is its 3-channel image.  yolov5s bs=64 640^2: 7.8 GB per forward."""
+    The input of the NCHW stem is its 3-channel image.  yolov5s bs=64 640^2: 7.3 GB per forward.  A fused launch (Bottleneck: cv1 +
+    cv2 + residual in one pass) is charged the sum of the layers it replaces -- the figure stays the per-layer one whatever the plan
+    fuses, so that `achieved` measures time, not accounting."""
     out = []
     B = engine.spec.B
-    for i, op in enumerate(engine.spec.ops):
-        if op["op"] != "conv":
-            continue
+
+    def one(op, residual):
         x, y = op["x"], op["y"]
         cin = sum((m.conv if hasattr(m, "conv") else m).in_channels for m in op["mods"][:1])
-        by = B * x.H * x.W * cin + B * y.H * y.W * sum((m.conv if hasattr(m, "conv") else m).out_channels for m in op["mods"])
-        if op.get("res") is not None:
-            by += B * y.H * y.W * y.C
+        cout = sum((m.conv if hasattr(m, "conv") else m).out_channels for m in op["mods"])
+        by = B * x.H * x.W * cin + B * y.H * y.W * cout
+        if residual:
+            by += B * y.H * y.W * cout
         for m in op["mods"]:
             cv = m.conv if hasattr(m, "conv") else m
             by += cv.out_channels * cv.in_channels * cv.kernel_size[0] * cv.kernel_size[1]
-        out.append((i, by * esize))
+        return by
+
+    for i, op in enumerate(engine.spec.ops):
+        if op["op"] == "conv":
+            out.append((i, one(op, op.get("res") is not None) * esize))
+        elif op["op"] == "bneck":
+            out.append((i, (one(op["cv1"], False) + one(op["cv2"], op["add"])) * esize))
     return out
 
 
@@ -432,6 +442,8 @@ def main():
         for i, op in enumerate(eng.spec.ops):
             if op["op"] == "conv":
                 cfg_of[i] = next(ci)
+            elif op["op"] == "bneck":
+                cfg_of[i] = "bneck"
         table = []
         for i, (name, iso), (_, ms) in timed:
             row = {"op": name, "cfg": cfg_of.get(i), "ms": round(ms, 5), "ms_isolated": round(iso, 5), "gflop": round(fl.get(i, 0) / 1e9, 3)}

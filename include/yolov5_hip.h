@@ -55,6 +55,9 @@ typedef struct {
    * fall outside the input read zeros).  Used by the data-gradient of strided convolutions (one launch per output
    * parity class); general implicit-GEMM configurations only. */
   int out_mul_h, out_mul_w, out_off_h, out_off_w, out_H, out_W;
+  int split_n;  /* > 0: channels [0, split_n) are stored to y (pixel stride ldy), channels [split_n, C2) to the y_up2 ARGUMENT (pixel stride
+                 * ld2, channel n - split_n) -- one GEMM for C3's cv1 + cv2 (models/common.py:246) whose halves land in different buffers;
+                 * no upsampled replica, residual or output placement in that mode */
 } y5_conv_desc;
 
 #define Y5_CONV_NUM_CFGS 57   /* 0..13 implicit-GEMM tiles (2 LDS stages), 14..21 streaming pointwise (1x1 s1, fp16),
@@ -304,6 +307,15 @@ int y5_scale_boxes_batch(float* det, int ld_det, int max_det, const int* det_cou
                          void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * y5_bottleneck_fwd -- models/common.py:164-181 `Bottleneck.forward` inside C3 (e = 1.0, :242): y = [x +] cv2(cv1(x)) with cv1 = 1x1
+ * C->C and cv2 = 3x3 pad 1 C->C (BN folded, bias + SiLU each), fp16, as ONE pass: the 1x1 output stays in LDS (csrc/conv_bneck.h).
+ * x / y: NHWC channel slices with pixel strides ldx / ldy (elements); y must NOT overlap x.  C = 32 or 64, H % 4 == 0, W % 8 == 0.
+ * Filters packed like y5_conv2d_fwd's ([32-padded C][Kpad], k = (kh, kw, c)), biases fp32 [C].
+ * ------------------------------------------------------------------------------------------------------- */
+int y5_bottleneck_fwd(const void* x, int ldx, const void* w1_packed, const float* bias1, int Kpad1, const void* w2_packed, const float* bias2,
+                      int Kpad2, void* y, int ldy, int B, int H, int W, int C, int add, int max_blocks, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * y5_mosaic_batch -- the training input pipeline for a whole batch in one launch: utils/dataloaders.py:798-855 `load_mosaic`
  * (four images resized to the training size by `load_image` :770-790 and tiled on a 2s x 2s canvas of 114s), the image half of
  * utils/augmentations.py:118-166 `random_perspective` (cv2.warpAffine, INTER_LINEAR, border 114, output s x s), :69-83 `augment_hsv`,
@@ -334,6 +346,8 @@ int y5_plan_add_conv(y5_plan*, const y5_conv_desc* d, const void* x, const void*
                      const void* residual, void* y, void* y_up2);
 int y5_plan_add_detect_head(y5_plan*, const y5_conv_desc* d, const void* x, const void* w_packed, const float* bias, int ny, int nx,
                             float stride, const float* anchors_px, void* z, long long nrows_total, long long row_off);
+int y5_plan_add_bottleneck(y5_plan*, const void* x, int ldx, const void* w1_packed, const float* bias1, int Kpad1, const void* w2_packed,
+                           const float* bias2, int Kpad2, void* y, int ldy, int B, int H, int W, int C, int add);
 int y5_plan_add_nop(y5_plan*);  /* placeholder op: keeps the op numbering of the conv + decode form next to a fused head */
 int y5_plan_add_conv_stem(y5_plan*, const void* x_nchw, int B, int H, int W, const void* w_stem, const float* bias, int C2,
                           int Npad, void* y, int ldy);

@@ -1,0 +1,93 @@
+"""CPU (emulator): the fused Bottleneck kernel (csrc/conv_bneck.h, y5_bottleneck_fwd: 1x1 -> SiLU -> 3x3 -> SiLU -> [+ x] with the
+intermediate in LDS; models/common.py:164-181) against torch fp32 on the same fp16 data, and the split store of y5_conv2d_fwd
+(C3's cv1 + cv2 as one GEMM whose halves land in two buffers, models/common.py:246)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.hipemu.emu import aligned, emu, ptr
+from yolov5_amd import _lib
+from yolov5_amd.packing import pack_conv_weight
+
+
+def _ref_bneck(x, w1, b1, w2, b2, add):
+    """x (B,H,W,C) fp16 values; t is stored in fp16 by the kernel (LDS), accumulation fp32."""
+    xf = torch.from_numpy(x.astype(np.float32)).permute(0, 3, 1, 2)
+    t = F.silu(F.conv2d(xf, w1.half().float(), b1)).half().float()
+    y = F.silu(F.conv2d(t, w2.half().float(), b2, padding=1)).half().float()
+    if add:
+        y = (y + xf).half().float()
+    return y.permute(0, 2, 3, 1).numpy()
+
+
+@pytest.mark.parametrize("Cc,B,H,W,add,ldx,ldy,mb", [(32, 2, 8, 16, True, 32, 32, 0), (32, 1, 12, 8, False, 64, 40, 0), (64, 1, 8, 8, True, 128, 64, 0),
+                                                      (64, 2, 4, 24, True, 64, 72, 0), (32, 3, 4, 8, True, 32, 32, 0),
+                                                      # many tiles per wave (grid capped at 1-2 workgroups) for every ring depth: ramp, steady state, drain
+                                                      (32, 1, 24, 32, True, 32, 32, 1 | (1 << 16)), (32, 1, 24, 32, True, 64, 32, 1 | (2 << 16)),
+                                                      (32, 2, 16, 40, False, 32, 32, 2 | (3 << 16)), (64, 1, 16, 32, True, 64, 64, 1 | (1 << 16))])
+def test_fused_bottleneck_matches_torch(Cc, B, H, W, add, ldx, ldy, mb):
+    lib = emu()
+    rng = np.random.default_rng(Cc + H + W)
+    w1 = torch.from_numpy(rng.standard_normal((Cc, Cc, 1, 1)).astype(np.float32) * (2.0 / Cc) ** 0.5)
+    w2 = torch.from_numpy(rng.standard_normal((Cc, Cc, 3, 3)).astype(np.float32) * (2.0 / (9 * Cc)) ** 0.5)
+    b1 = torch.from_numpy(rng.standard_normal(Cc).astype(np.float32) * 0.3)
+    b2 = torch.from_numpy(rng.standard_normal(Cc).astype(np.float32) * 0.3)
+    w1p, b1p, _, K1, _ = pack_conv_weight(w1, b1, torch.float16)
+    w2p, b2p, _, K2, _ = pack_conv_weight(w2, b2, torch.float16)
+    xbuf = aligned((B, H, W, ldx), np.float16)
+    xbuf[...] = rng.standard_normal(xbuf.shape).astype(np.float16)
+    x = xbuf[..., ldx - Cc:]                                        # a channel slice at an offset, like a concat buffer's
+    ybuf = aligned((B, H, W, ldy), np.float16, 7)
+    W1, B1, W2, B2 = (aligned(t.shape, t.numpy().dtype) for t in (w1p, b1p, w2p, b2p))
+    for dst, src in ((W1, w1p), (B1, b1p), (W2, w2p), (B2, b2p)):
+        dst[...] = src.numpy()
+    xoff = (ldx - Cc) * 2
+    rc = lib.y5_bottleneck_fwd(C.c_void_p(xbuf.ctypes.data + xoff), ldx, ptr(W1), ptr(B1), K1, ptr(W2), ptr(B2), K2, ptr(ybuf), ldy, B, H, W, Cc,
+                               int(add), mb, None)
+    assert rc == 0, lib.y5_last_error()
+    ref = _ref_bneck(np.ascontiguousarray(x), w1, b1, w2, b2, add)
+    got = ybuf[..., :Cc].astype(np.float32)
+    np.testing.assert_allclose(got, ref, rtol=4e-3, atol=4e-3)
+    assert np.all(ybuf[..., Cc:] == 7)                               # nothing written outside the slice
+
+
+def test_fused_bottleneck_rejects_overlap_and_bad_shapes():
+    lib = emu()
+    buf = aligned((1, 8, 8, 64), np.float16)
+    w = aligned((32, 320), np.float16)
+    b = aligned((32,), np.float32)
+    args = lambda x, y, ldx=64, ldy=64, Cc=32, H=8, W=8: (x, ldx, ptr(w), ptr(b), 64, ptr(w), ptr(b), 320, y, ldy, 1, H, W, Cc, 1, 0, None)  # noqa: E731
+    assert lib.y5_bottleneck_fwd(*args(ptr(buf), ptr(buf))) != 0                                   # in place: neighbours' halos would be clobbered
+    assert lib.y5_bottleneck_fwd(*args(ptr(buf), C.c_void_p(buf.ctypes.data + 64))) == 0          # disjoint channel slices of one buffer are fine
+    assert lib.y5_bottleneck_fwd(*args(ptr(buf), C.c_void_p(buf.ctypes.data + 64), Cc=48)) != 0
+    assert lib.y5_bottleneck_fwd(*args(ptr(buf), C.c_void_p(buf.ctypes.data + 64), H=6)) != 0
+
+
+@pytest.mark.parametrize("cfg", [-1, 2, 17])
+def test_conv_split_store(cfg):
+    """1x1 64 -> 64 conv whose channels [0, 32) go to one buffer and [32, 64) to a slice of another (desc.split_n)."""
+    lib = emu()
+    rng = np.random.default_rng(5)
+    B, H, W, C1, C2 = 2, 8, 8, 64, 64
+    w = torch.from_numpy(rng.standard_normal((C2, C1, 1, 1)).astype(np.float32) * 0.2)
+    b = torch.from_numpy(rng.standard_normal(C2).astype(np.float32) * 0.2)
+    wp, bp, K, Kpad, Npad = pack_conv_weight(w, b, torch.float16)
+    x = aligned((B, H, W, C1), np.float16)
+    x[...] = rng.standard_normal(x.shape).astype(np.float16)
+    lo = aligned((B, H, W, 32), np.float16, 3)
+    hi = aligned((B, H, W, 96), np.float16, 3)
+    Wp, Bp = aligned(wp.shape, np.float16), aligned(bp.shape, np.float32)
+    Wp[...] = wp.numpy(); Bp[...] = bp.numpy()
+    d = _lib.ConvDesc(dtype=_lib.Y5_F16, B=B, H=H, W=W, C1=C1, ldx=C1, OH=H, OW=W, C2=C2, ldy=32, KH=1, KW=1, SH=1, SW=1, PH=0, PW=0, act=1,
+                      Kpad=Kpad, Npad=Npad, ldr=0, ld2=96, cfg=cfg, max_blocks=0, split_n=32)
+    rc = lib.y5_conv2d_fwd(C.byref(d), ptr(x), ptr(Wp), ptr(Bp), None, ptr(lo), C.c_void_p(hi.ctypes.data + 64 * 2), None)
+    if cfg == 17 and rc != 0:
+        pytest.skip("pointwise configuration 17 does not take this shape")
+    assert rc == 0, lib.y5_last_error()
+    ref = F.silu(F.conv2d(torch.from_numpy(x.astype(np.float32)).permute(0, 3, 1, 2), w.half().float(), b)).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(lo.astype(np.float32), ref[..., :32], rtol=3e-3, atol=3e-3)
+    np.testing.assert_allclose(hi[..., 64:].astype(np.float32), ref[..., 32:], rtol=3e-3, atol=3e-3)
+    assert np.all(hi[..., :64] == 3)

@@ -94,3 +94,23 @@ def test_head_side_branch_schedule(monkeypatch):
         b = Engine(m, (2, 3, 64, 64), torch.float32, "cpu", backend=EmuBackend(), spec=br)(x)
         for k in a:
             assert np.array_equal(a[k], b[k]), (name, k)
+
+
+def test_fused_bottleneck_plan_same_outputs(monkeypatch):
+    """fp16 plans run the Bottlenecks of 32-channel C3 blocks as one launch each (engine._Planner.c3 -> y5_bottleneck_fwd, with C3's
+    cv1 half stored to its own buffer by the split store): same result as the conv + conv(+ residual) form, here on yolov5n whose
+    layers 4 (two Bottlenecks: ping-pong buffers) and 17 (shortcut=False) qualify."""
+    m = det_model("yolov5n", 0, True).half()
+    x = torch.from_numpy(detgen.uniform((2, 3, 64, 64), 0.0, 1.0, name="img", seed=0)).half()
+    monkeypatch.setenv("Y5_FUSED_BNECK", "0")
+    plain = Engine(m, (2, 3, 64, 64), torch.float16, "cpu", want_raw=True, backend=EmuBackend())
+    monkeypatch.setenv("Y5_FUSED_BNECK", "1")
+    fused = Engine(m, (2, 3, 64, 64), torch.float16, "cpu", want_raw=True, backend=EmuBackend())
+    kinds = [o["op"] for o in fused.spec.ops]
+    assert kinds.count("bneck") == 3 and "bneck" not in [o["op"] for o in plain.spec.ops]
+    assert sum(1 for o in fused.spec.ops if o.get("split_n")) == 2
+    a, b = plain(x), fused(x)
+    for k in a:  # same arithmetic, another fp32 summation order inside the 3x3 (two accumulators): a few fp16 ulps
+        u, v = np.asarray(a[k]).astype(np.float32), np.asarray(b[k]).astype(np.float32)
+        assert np.abs(u - v).max() <= 4e-3 * max(1.0, np.abs(u).max()), (k, np.abs(u - v).max())
+        assert (u != v).mean() < 0.2, k

@@ -21,7 +21,7 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "dtype", "B", "H", "W", "C1", "ldx", "OH", "OW", "C2", "ldy", "KH", "KW", "SH", "SW", "PH", "PW",
         "act", "Kpad", "Npad", "ldr", "ld2", "cfg", "max_blocks",
-        "out_mul_h", "out_mul_w", "out_off_h", "out_off_w", "out_H", "out_W")]
+        "out_mul_h", "out_mul_w", "out_off_h", "out_off_w", "out_H", "out_W", "split_n")]
 
 
 class LossDesc(C.Structure):
@@ -132,6 +132,10 @@ EXPORTS = {
     "y5_plan_add_detect_head": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
                                           C.POINTER(C.c_float), C.c_void_p, C.c_longlong, C.c_longlong]),
     "y5_plan_add_nop": (C.c_int, [C.c_void_p]),
+    "y5_plan_add_bottleneck": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "y5_bottleneck_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "y5_plan_set_input": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "y5_plan_set_branch": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "y5_plan_set_anchors": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int]),

@@ -218,9 +218,9 @@ int launch_pw_v(const Y5ConvParams& p, int max_blocks, hipStream_t stream) {
 template <int KC, int RB, int NT, int S, int OS = 1>
 int launch_pw(const Y5ConvParams& p, int mb, hipStream_t st) {
   if constexpr (OS == 1) {
-    if (p.y2) return p.act ? launch_pw_v<KC, RB, NT, S, true, true>(p, mb, st) : launch_pw_v<KC, RB, NT, S, true, false>(p, mb, st);
+    if (p.y2 && !p.split_n) return p.act ? launch_pw_v<KC, RB, NT, S, true, true>(p, mb, st) : launch_pw_v<KC, RB, NT, S, true, false>(p, mb, st);
   } else {
-    if (p.y2) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: split-epilogue pointwise configuration has no upsampled replica");
+    if (p.y2 && !p.split_n) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: split-epilogue pointwise configuration has no upsampled replica");
   }
   return p.act ? launch_pw_v<KC, RB, NT, S, false, true, OS>(p, mb, st) : launch_pw_v<KC, RB, NT, S, false, false, OS>(p, mb, st);
 }
@@ -388,6 +388,13 @@ extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w
   p.KH = d->KH; p.KW = d->KW; p.SH = d->SH; p.SW = d->SW; p.PH = d->PH; p.PW = d->PW;
   p.act = d->act; p.Kpad = d->Kpad; p.Npad = d->Npad; p.K = d->KH * d->KW * d->C1;
   p.ldr = d->ldr; p.ld2 = d->ld2;
+  p.split_n = d->split_n;
+  if (d->split_n) {
+    if (d->split_n < 0 || d->split_n % epp || d->split_n >= d->C2 || !y || !y_up2 || d->ld2 % epp || d->ld2 < d->C2 - d->split_n || d->ldy < d->split_n ||
+        placed || residual)
+      return y5_fail(Y5_ERR_BAD_ARG, "conv: bad split store (split_n multiple of 16 bytes inside C2, both destinations, no residual / placement)");
+    if (k3) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: split store needs a pointwise / implicit-GEMM configuration");
+  }
   p.M = d->B * oh * ow;
   p.o_mul_h = d->out_mul_h; p.o_mul_w = d->out_mul_w; p.o_off_h = d->out_off_h; p.o_off_w = d->out_off_w; p.o_H = d->out_H; p.o_W = d->out_W;
   if (placed && (pw || k3)) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: output placement needs a general implicit-GEMM configuration");

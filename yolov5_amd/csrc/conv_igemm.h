@@ -48,6 +48,8 @@ struct Y5ConvParams {
   int ldr, ld2;
   int M;  // B*OH*OW
   int tilesM, tilesN, nk;
+  int split_n;  // > 0: output channels >= split_n go to y2 (pixel stride ld2, channel n - split_n) instead of y -- C3's cv1 / cv2 halves
+                // of one GEMM landing in two different buffers (y2 is then NOT the upsampled replica)
 };
 
 #define Y5_CONV_MAXTAB 4096   // max k-pieces in TABLE mode (LDS: 8 B each)
@@ -358,6 +360,10 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
                 raw = __builtin_bit_cast(uint4_t, a);
               }
             }
+            if (p.split_n) {
+              T* d = n < p.split_n ? yg + mo * p.ldy + n : y2g + mo * p.ld2 + (n - p.split_n);
+              *reinterpret_cast<uint4_t*>(d) = raw;
+            } else {
             if (yg) *reinterpret_cast<uint4_t*>(yg + mo * p.ldy + n) = raw;
             if (y2g) {
               const int ohw = p.OH * p.OW;
@@ -371,6 +377,7 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
               *reinterpret_cast<uint4_t*>(d0 + p.ld2) = raw;
               *reinterpret_cast<uint4_t*>(d1) = raw;
               *reinterpret_cast<uint4_t*>(d1 + p.ld2) = raw;
+            }
             }
           }
         }

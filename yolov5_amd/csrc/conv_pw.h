@@ -242,6 +242,10 @@ __device__ __forceinline__ void y5_conv_pw_body(const Y5ConvParams& p, const Y5H
         const uint4_t raw = *reinterpret_cast<const uint4_t*>(st + row * (NPH * 2) + ((oslot ^ (row & SWM)) * 16));
         const int m = m0 + row, n = h * NPH + oslot * 8;
         if (n < p.C2) {
+          if (!UP2 && p.split_n) {
+            T* d = n < p.split_n ? yg + (size_t)m * p.ldy + n : y2g + (size_t)m * p.ld2 + (n - p.split_n);
+            *reinterpret_cast<uint4_t*>(d) = raw;
+          } else
           *reinterpret_cast<uint4_t*>(yg + (size_t)m * p.ldy + n) = raw;
           if constexpr (UP2) {
             const int ohw = p.OH * p.OW;

@@ -48,7 +48,7 @@ extern "C" const char* y5_last_error(void) { return g_err.c_str(); }
 // ---------------------------------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------------------------------
-enum OpKind { OP_CONV, OP_TO_NHWC, OP_SPPF, OP_UPS, OP_COPY, OP_DECODE, OP_TO_NCHW, OP_STEM, OP_HEAD, OP_NOP };
+enum OpKind { OP_CONV, OP_TO_NHWC, OP_SPPF, OP_UPS, OP_COPY, OP_DECODE, OP_TO_NCHW, OP_STEM, OP_HEAD, OP_NOP, OP_BNECK };
 
 struct Op {
   OpKind kind;
@@ -153,6 +153,14 @@ extern "C" int y5_plan_add_detect_head(y5_plan* pl, const y5_conv_desc* d, const
   pl->ops.push_back(o);
   return Y5_OK;
 }
+extern "C" int y5_plan_add_bottleneck(y5_plan* pl, const void* x, int ldx, const void* w1, const float* b1, int Kpad1, const void* w2, const float* b2,
+                                      int Kpad2, void* y, int ldy, int B, int H, int W, int C, int add) {
+  if (!pl) return y5_fail(Y5_ERR_BAD_ARG, "plan: null");
+  Op o{}; o.kind = OP_BNECK; o.p0 = x; o.p1 = w1; o.p2 = b1; o.p3 = w2; o.q0 = y; o.q1 = const_cast<float*>(b2);
+  o.i[0] = ldx; o.i[1] = Kpad1; o.i[2] = Kpad2; o.i[3] = ldy; o.i[4] = B; o.i[5] = H; o.i[6] = W; o.i[7] = C; o.i[8] = add;
+  pl->ops.push_back(o);
+  return Y5_OK;
+}
 extern "C" int y5_plan_add_nop(y5_plan* pl) {
   if (!pl) return y5_fail(Y5_ERR_BAD_ARG, "plan: null");
   Op o{}; o.kind = OP_NOP;
@@ -183,7 +191,7 @@ extern "C" int y5_plan_rebind_output(y5_plan* pl, int first, int last, const voi
   for (int k = first; k < last; ++k) {
     Op& o = pl->ops[k];
     if (o.q0 == old_ptr) { o.q0 = new_ptr; ++n; }
-    if (o.q1 == old_ptr) { o.q1 = new_ptr; ++n; }
+    if (o.q1 == old_ptr && o.kind != OP_BNECK) { o.q1 = new_ptr; ++n; }
   }
   if (!n) return y5_fail(Y5_ERR_BAD_ARG, "plan_rebind_output: no op writes that pointer");
   return Y5_OK;
@@ -228,6 +236,9 @@ static int run_op(const Op& o, void* st) {
     case OP_HEAD:
       return y5_detect_head_fwd(&o.conv, o.p0, o.p1, (const float*)o.p2, o.i[0], o.i[1], o.f[0], o.anchors, o.q0, o.l[0], o.l[1], st);
     case OP_NOP: return Y5_OK;
+    case OP_BNECK:
+      return y5_bottleneck_fwd(o.p0, o.i[0], o.p1, (const float*)o.p2, o.i[1], o.p3, (const float*)o.q1, o.i[2], o.q0, o.i[3], o.i[4], o.i[5], o.i[6],
+                               o.i[7], o.i[8], 0, st);
     case OP_DECODE:
       return y5_detect_decode(o.p0, o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], o.i[6], o.i[7], o.f[0], o.anchors, o.q0, o.i[8],
                               o.l[0], o.l[1], o.q1, st);

@@ -80,18 +80,20 @@ def _pair(v):
 class _Planner:
     """Walks the module tree once and emits PlanSpec ops."""
 
-    def __init__(self, model, B, ch, H, W, want_raw=False):
+    def __init__(self, model, B, ch, H, W, want_raw=False, fuse_bneck=False):
         from . import common, yolo
 
         self.cm, self.yo = common, yolo
         self.model = model
         self.spec = PlanSpec(B, ch, (H, W))
         self.want_raw = want_raw
+        self.fuse_bneck = fuse_bneck  # fp16 plans: Bottlenecks of 32-channel C3 blocks as one launch (csrc/conv_bneck.h)
 
     # ---- leaf emitters ----------------------------------------------------------------------------
     def conv(self, mods, x: TRef, dest: TRef | None = None, res: TRef | None = None, up2: TRef | None = None,
-             act=True, name="", view=None, c2_store=None):
-        """mods: list of Conv-like modules stacked along output channels (same input, same k/s/p)."""
+             act=True, name="", view=None, c2_store=None, split=None, emit=True):
+        """mods: list of Conv-like modules stacked along output channels (same input, same k/s/p).
+        split = (n, hi): output channels [0, n) go to `dest` (n channels wide), channels [n, c2) to the slice `hi`."""
         m0 = mods[0]
         cv = m0.conv if hasattr(m0, "conv") else m0
         k, s, p = _pair(cv.kernel_size), _pair(cv.stride), _pair(cv.padding)
@@ -99,20 +101,52 @@ class _Planner:
         oh, ow = _conv_out_hw(x.H, x.W, k, s, p)
         cst = c2 if c2_store is None else c2_store
         if dest is None:
-            dest = self.spec.new_buf(oh, ow, cst, name)
-        assert dest.C == cst and (dest.H, dest.W) == (oh, ow), (name, dest, cst, oh, ow)
-        self.spec.ops.append(dict(op="conv", mods=mods, x=x, y=dest, res=res, y2=up2, k=k, s=s, p=p, act=act,
-                                  c2=c2, c2_store=cst, name=name, view=view))
-        return dest
+            dest = self.spec.new_buf(oh, ow, cst if split is None else split[0], name)
+        if split is None:
+            assert dest.C == cst and (dest.H, dest.W) == (oh, ow), (name, dest, cst, oh, ow)
+        else:
+            assert up2 is None and res is None and dest.C == split[0] and split[1].C == cst - split[0], (name, dest, split)
+            up2 = split[1]
+        op = dict(op="conv", mods=mods, x=x, y=dest, res=res, y2=up2, k=k, s=s, p=p, act=act, c2=c2, c2_store=cst, name=name, view=view,
+                  split_n=0 if split is None else split[0])
+        if emit:
+            self.spec.ops.append(op)
+            return dest
+        return op
 
     def bottleneck(self, m, x: TRef, dest: TRef, tmp: TRef):
         """Bottleneck (common.py:164-181) with e=1.0; dest may alias x (in-place residual)."""
         t = self.conv([m.cv1], x, tmp, name="b.cv1")
         return self.conv([m.cv2], t, dest, res=x if m.add else None, name="b.cv2")
 
+    def _bneck_fusable(self, m, c_, x):
+        if not self.fuse_bneck or c_ != 32 or x.H % 4 or x.W % 8 or not len(m.m):
+            return False
+        for b in m.m:
+            c1, c2 = b.cv1.conv, b.cv2.conv
+            if not (c1.in_channels == c1.out_channels == c2.in_channels == c2.out_channels == c_ and _pair(c1.kernel_size) == (1, 1)
+                    and _pair(c2.kernel_size) == (3, 3) and _pair(c2.stride) == (1, 1) and _pair(c2.padding) == (1, 1)):
+                return False
+        return True
+
     def c3(self, m, x: TRef, dest: TRef | None, up2=None, name="C3"):
         c_ = m.cv1.conv.out_channels
         cat = self.spec.new_buf(x.H, x.W, 2 * c_, name + ".cat")
+        if self._bneck_fusable(m, c_, x):
+            # cv1's half of the GEMM lands in a buffer of its own (split store), every Bottleneck is ONE launch that reads one buffer
+            # and writes another (a tile needs its neighbours' input pixels: not in place), the last one writes its slice of `cat`
+            ping = [self.spec.new_buf(x.H, x.W, c_, name + ".a0")]
+            if len(m.m) > 1:
+                ping.append(self.spec.new_buf(x.H, x.W, c_, name + ".a1"))
+            self.conv([m.cv1, m.cv2], x, ping[0], name=name + ".cv1+cv2", split=(c_, _slice(cat, c_, c_)))
+            src = ping[0]
+            for i, b in enumerate(m.m):
+                dst = _slice(cat, 0, c_) if i == len(m.m) - 1 else ping[(i + 1) % 2]
+                self.spec.ops.append(dict(op="bneck", x=src, y=dst, add=bool(b.add), name=f"{name}.m{i}",
+                                          cv1=self.conv([b.cv1], src, dst, name="b.cv1", emit=False),
+                                          cv2=self.conv([b.cv2], src, dst, name="b.cv2", emit=False)))
+                src = dst
+            return self.conv([m.cv3], cat, dest, up2=up2, name=name + ".cv3")
         self.conv([m.cv1, m.cv2], x, cat, name=name + ".cv1+cv2")  # one GEMM, N = 2*c_
         a = _slice(cat, 0, c_)
         if len(m.m):
@@ -315,9 +349,9 @@ class _Planner:
             row_off += na * x.H * x.W
 
 
-def build_plan_spec(model, B, ch, H, W, want_raw=False) -> PlanSpec:
+def build_plan_spec(model, B, ch, H, W, want_raw=False, fuse_bneck=False) -> PlanSpec:
     """Device-independent kernel schedule for `model` (a yolov5_amd.yolo.BaseModel) at input (B,ch,H,W)."""
-    return _Planner(model, B, ch, H, W, want_raw).run()
+    return _Planner(model, B, ch, H, W, want_raw, fuse_bneck).run()
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -489,7 +523,8 @@ class Engine:
         self.es = 2 if dtype == torch.float16 else 4
         B, ch, H, W = x_shape
         self.x_shape = tuple(x_shape)
-        self.spec = spec if spec is not None else build_plan_spec(model, B, ch, H, W, want_raw)
+        self.spec = spec if spec is not None else build_plan_spec(
+            model, B, ch, H, W, want_raw, fuse_bneck=dtype == torch.float16 and os.environ.get("Y5_FUSED_BNECK", "1") != "0")
         det = getattr(model, "model", [None])[-1] if model is not None else None
         self._det = det if det is not None and hasattr(det, "anchors") else None
         self._anchor_ops = []  # (plan op index, pyramid level) of every op that holds anchor sizes
@@ -570,6 +605,8 @@ class Engine:
             self.op_names.append("to_nhwc")
         elif kind == "conv":
             rc = self._add_conv(op)
+        elif kind == "bneck":
+            rc = self._add_bneck(op)
         elif kind == "sppf_pool":
             b = op["buf"]
             rc = lib.y5_plan_add_sppf_pool(self.plan, self._ptr(b), self.dt, B, b.H, b.W, op["C"], self._ld(b), op["k"])
@@ -657,6 +694,22 @@ class Engine:
                 self._graph = False
                 self._graph_gen = getattr(self, "_graph_gen", 0) + 1
 
+    def _add_bneck(self, op):
+        """Fused Bottleneck (y5_bottleneck_fwd): both filters packed like ordinary convs; refresh_weights() re-packs them too."""
+        x, y = op["x"], op["y"]
+        packs = []
+        for sub in (op["cv1"], op["cv2"]):
+            _, (wp, bp, _K, Kpad, _Npad), _ = self._conv_weights(sub)
+            wp, bp = self.be.from_torch(wp), self.be.from_torch(bp)
+            self._keep += [wp, bp]
+            self._conv_bufs.append((sub, wp, bp, None, None))
+            packs.append((wp, bp, Kpad))
+        (w1, b1, k1), (w2, b2, k2) = packs
+        self.op_names.append("bneck:" + op["name"])
+        return self.lib.y5_plan_add_bottleneck(self.plan, self._ptr(x), self._ld(x), C.c_void_p(self.be.ptr(w1)), C.c_void_p(self.be.ptr(b1)), k1,
+                                               C.c_void_p(self.be.ptr(w2)), C.c_void_p(self.be.ptr(b2)), k2, self._ptr(y), self._ld(y),
+                                               self.spec.B, x.H, x.W, x.C, int(op["add"]))
+
     def _add_conv(self, op):
         x, y, res, y2 = op["x"], op["y"], op["res"], op["y2"]
         (H, W, C1, ldx, kh, kw, sh, sw, ph, pw), (wp, bp, K, Kpad, Npad), stem = self._conv_weights(op)
@@ -674,7 +727,10 @@ class Engine:
         c2s = op["c2_store"]
         d = _lib.ConvDesc(dtype=self.dt, B=self.spec.B, H=H, W=W, C1=C1, ldx=ldx, OH=y.H, OW=y.W, C2=c2s, ldy=self._ld(y),
                           KH=kh, KW=kw, SH=sh, SW=sw, PH=ph, PW=pw, act=1 if op["act"] else 0, Kpad=Kpad, Npad=Npad,
-                          ldr=self._ld(res) if res is not None else 0, ld2=self._ld(y2) if y2 is not None else 0, cfg=-1, max_blocks=0)
+                          ldr=self._ld(res) if res is not None else 0, ld2=self._ld(y2) if y2 is not None else 0, cfg=-1, max_blocks=0,
+                          split_n=op.get("split_n", 0))
+        if d.split_n:
+            d.ldy = self._ld(y)
         assert Npad >= c2s
         ptrs = (self._ptr(x), C.c_void_p(self.be.ptr(wp)), C.c_void_p(self.be.ptr(bp)), self._ptr(res), self._ptr(y), self._ptr(y2))
         if getattr(self.be, "autotune", False):
