@@ -195,6 +195,43 @@ def stats(ms):
     return {"median": round(_pct(ms, 0.5), 4), "p10": round(_pct(ms, 0.1), 4), "p90": round(_pct(ms, 0.9), 4), "n": len(ms)}
 
 
+def gpu_state_probe(fn, dev, seconds=1.6):
+    """Clocks and socket power WHILE `fn` (one forward) runs in a loop: two `rocm-smi --json` samples taken by a side thread.  The same
+    binary runs 15 % apart on different MI355X boxes of the pool; this records what the box was doing (box-to-box variance)."""
+    import re
+    import subprocess
+    import threading
+
+    samples = []
+
+    def sample():
+        for _ in range(2):
+            time.sleep(0.45)
+            try:
+                out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=10).stdout
+                card = next(iter(json.loads(out).values()))
+                num = lambda k: float(re.sub(r"[^0-9.]", "", str(card.get(k, "")) or "0") or 0)  # noqa: E731
+                samples.append({"sclk_mhz": num("sclk clock speed:"), "mclk_mhz": num("mclk clock speed:"), "fclk_mhz": num("fclk clock speed:"),
+                                "power_w": num("Current Socket Graphics Package Power (W)")})
+            except Exception as e:  # the probe must never break the benchmark
+                samples.append({"error": f"{type(e).__name__}: {e}"})
+
+    th = threading.Thread(target=sample)
+    th.start()
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds or th.is_alive():
+        fn()
+        n += 1
+        if n % 16 == 0:
+            torch.cuda.synchronize(dev)
+        if time.perf_counter() - t0 > 20:
+            break
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    th.join()
+    return {"forward_ms_sustained": round(dt / max(n, 1) * 1e3, 4), "samples": samples}
+
+
 TRAIN_GFLOP_PER_IMG = {"yolov5s": 49.3}  # SURVEY 8d: forward + data gradient + weight gradient = 3 x 16.43 GFLOP at 640^2
 
 
@@ -457,6 +494,8 @@ def main():
         with open(a.op_table, "w") as f:
             json.dump(table, f, indent=1)
 
+    gpu_state = gpu_state_probe(lambda: model(x), dev) if rank == 0 else None
+
     # ---- secondary: the detect.py pipeline around the hot path (SURVEY 8(f) rank 1 + 3 rows) ---------------------------------
     pipeline = None
     if world == 1 and a.imgsz == 640 and not a.no_pipeline:
@@ -494,8 +533,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "y5_conv_{igemm,pw,k3,stem}_kernel (all conv launches of one forward)",
                          "achieved": round(achieved_bw, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_bw / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(a, conv_by * parts),
-                         "timing": "in situ: HIP event between consecutive ops of one eager forward on the launch stream, median of 9 passes "
-                                   "(event-to-event: includes the dispatch gap of each launch)",
+                         "timing": "in situ: HIP event between consecutive ops of one eager forward on the launch stream, median of 9 passes, "
+                                   "minus the cost of the event record itself (empty interval measured in the same passes)",
                          "plans_per_step": parts, "images_per_plan": images_per_plan,
                          "algorithmic_gbytes_per_step": round(conv_by * parts / 1e9, 3), "algorithmic_gflop_per_step": round(conv_fl * parts / 1e9, 1),
                          "arithmetic_intensity_flop_per_byte": round(conv_fl / conv_by, 1) if conv_by else None,
@@ -504,6 +543,8 @@ def main():
                          "conv_ms_per_step": round(conv_ms * parts, 4), "conv_ms_per_step_isolated": round(conv_ms_iso * parts, 4),
                          "launches_per_step": nconv * parts, "other_kernels_ms_per_step": round(other_ms * parts, 4)},
         }
+        if gpu_state is not None:
+            res["gpu_state"] = gpu_state
         if pipeline is not None:
             res["pipeline"] = pipeline
         if train is not None:

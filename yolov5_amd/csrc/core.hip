@@ -374,15 +374,17 @@ extern "C" int y5_plan_time_range(y5_plan* pl, int first, int last, int iters, v
 // times; ms_out[k - first] = median over the passes of op k's event-to-event time.  Unlike y5_plan_time_range (back-to-back
 // launches of one op on warm buffers) every op here runs in its real position: inputs produced by the previous op, caches in the
 // state the previous layer left them.  Side-branch ops run on `st` too (serialised), so the figures add up to a single-stream
-// forward.  Synchronises the stream.
+// forward.  The cost of the event record itself (an empty event-to-event interval, measured in the same passes) is subtracted.
+// Synchronises the stream.
 extern "C" int y5_plan_profile_range(y5_plan* pl, int first, int last, int iters, void* st_, float* ms_out) {
   if (!pl || !ms_out || iters < 1 || first < 0 || last > (int)pl->ops.size() || first >= last) return y5_fail(Y5_ERR_BAD_ARG, "plan_profile_range: bad args");
   hipStream_t st = static_cast<hipStream_t>(st_);
   const int n = last - first;
-  std::vector<hipEvent_t> ev(n + 1, nullptr);
-  for (int k = 0; k <= n; ++k)
+  std::vector<hipEvent_t> ev(n + 2, nullptr);  // ev[n] -> ev[n + 1]: nothing in between = the cost of the event pair itself
+  for (int k = 0; k <= n + 1; ++k)
     if (hipEventCreate(&ev[k]) != hipSuccess) return y5_fail(Y5_ERR_RUNTIME, "plan_profile_range: event create failed");
   std::vector<std::vector<float>> samples(n);
+  std::vector<float> empty;
   int rc = Y5_OK;
   pl->flat = true;
   rc = y5_plan_run_range(pl, first, last, st_);  // warm-up pass
@@ -392,19 +394,31 @@ extern "C" int y5_plan_profile_range(y5_plan* pl, int first, int last, int iters
       rc = run_op(pl->ops[first + k], st_);
       hipEventRecord(ev[k + 1], st);
     }
-    if (!rc && hipEventSynchronize(ev[n]) != hipSuccess) rc = y5_fail(Y5_ERR_RUNTIME, "plan_profile_range: sync failed");
+    hipEventRecord(ev[n + 1], st);
+    if (!rc && hipEventSynchronize(ev[n + 1]) != hipSuccess) rc = y5_fail(Y5_ERR_RUNTIME, "plan_profile_range: sync failed");
     for (int k = 0; k < n && !rc; ++k) {
       float ms = 0.f;
       hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
       samples[k].push_back(ms);
     }
+    if (!rc) {
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, ev[n], ev[n + 1]);
+      empty.push_back(ms);
+    }
   }
   pl->flat = false;
-  for (int k = 0; k < n && !rc; ++k) {
-    std::vector<float>& v = samples[k];
+  auto median = [](std::vector<float>& v) {
     for (size_t a = 1; a < v.size(); ++a)  // insertion sort (iters is small)
       for (size_t b = a; b > 0 && v[b] < v[b - 1]; --b) { const float t = v[b]; v[b] = v[b - 1]; v[b - 1] = t; }
-    ms_out[k] = v[v.size() / 2];
+    return v.empty() ? 0.f : v[v.size() / 2];
+  };
+  // an interval = [dispatch + run of the op] + [one event record]; the record's own cost (measured on the empty interval, ~5 us:
+  // the completion signal + timestamp write-back of the marker packet) is taken off every op
+  const float ev_cost = median(empty);
+  for (int k = 0; k < n && !rc; ++k) {
+    const float m = median(samples[k]) - ev_cost;
+    ms_out[k] = m > 0.f ? m : 0.f;
   }
   for (hipEvent_t e : ev) hipEventDestroy(e);
   return rc;

@@ -419,10 +419,23 @@ def autotune_conv(lib, d, ptrs, st):
 _TUNE_FILE_STATE = {"loaded": False}
 
 
-def _load_tune_cache():
-    """Optional persistence of the per-layer tile choices (env Y5_TUNE_CACHE=<json path>): skips the timing launches of
-    later processes (plan build in production, clean rocprof traces)."""
+def _tune_cache_path():
+    """Where the per-layer tile choices persist: $Y5_TUNE_CACHE (a json path; "0" / "off" disables), default
+    ~/.cache/yolov5_amd/tune_<library version>_<kernel configurations>.json -- later processes (plan build in production, rectangular
+    validation shapes seen before, clean rocprof traces) skip the timing launches."""
     path = os.environ.get("Y5_TUNE_CACHE")
+    if path is not None:
+        return None if path in ("", "0", "off") else path
+    try:
+        lib = _lib.lib()
+        tag = f"{lib.y5_version()}_{lib.y5_conv_num_cfgs()}"
+    except Exception:
+        return None
+    return os.path.join(os.path.expanduser("~"), ".cache", "yolov5_amd", f"tune_{tag}.json")
+
+
+def _load_tune_cache():
+    path = _tune_cache_path()
     if not path or _TUNE_FILE_STATE["loaded"]:
         return
     _TUNE_FILE_STATE["loaded"] = True
@@ -437,14 +450,17 @@ def _load_tune_cache():
 
 
 def _save_tune_cache():
-    path = os.environ.get("Y5_TUNE_CACHE")
+    path = _tune_cache_path()
     if not path:
         return
     try:
         import json
 
-        with open(path, "w") as f:
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "w") as f:
             json.dump({",".join(str(x) for x in k): v for k, v in _TUNE_CACHE.items()}, f)
+        os.replace(tmp, path)  # atomic: several ranks tune at once
     except OSError:
         pass
 
