@@ -19,6 +19,7 @@ Layout layout(int bs, int n, int no, int nm, int flags, int max_nms) {
   L.off_keys = o; o += ((size_t)bs * L.cap_pad * 8 + 255) & ~(size_t)255;
   L.off_cls = o; o += ((size_t)bs * n + 255) & ~(size_t)255;
   L.gcap = L.cap < max_nms ? L.cap : max_nms;
+  L.gcap = (L.gcap + 63) / 64 * 64;  // whole chunks of 64 candidates (field planes, nms_kernels.h)
   if (L.gcap < 64) L.gcap = 64;
   L.off_gbox = o; o += ((size_t)bs * L.gcap * Y5_NMS_REC * 4 + 255) & ~(size_t)255;
   L.total = o;
@@ -64,11 +65,11 @@ extern "C" int y5_nms_batched(const void* pred, int dt, int bs, int n, int no, i
   static bool attr = false;
   if (!attr) {
     hipFuncSetAttribute((const void*)y5_nms_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Y5_NMS_SORT_LDS_KEYS * 8);
-    hipFuncSetAttribute((const void*)y5_nms_greedy_kernel<half_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    hipFuncSetAttribute((const void*)y5_nms_greedy_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    hipFuncSetAttribute((const void*)y5_nms_greedy_kernel<half_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipFuncSetAttribute((const void*)y5_nms_greedy_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     attr = true;
   }
-  const size_t greedy_lds = (size_t)max_det * 20 + 2 * Y5_NMS_REC * 64 * 4 + 64 * 8 + Y5_NMS_GREEDY_WAVES * 8 + 16;
+  const size_t greedy_lds = (((size_t)max_det * 6 + 3) & ~(size_t)3) * 4 + (size_t)Y5_NMS_RING * Y5_NMS_REC * 64 * 4 + 64 * 8 + Y5_NMS_GREEDY_WAVES * 8 + 16;
   {
     // rows per workgroup of the LDS-staged filter: as many as fit 64 KiB (multiple of 64); unstaged fallback for very wide rows
     const int es = dt == Y5_F16 ? 2 : 4;

@@ -29,7 +29,8 @@ struct Y5NmsParams {
   int* count;                 // [bs]
   unsigned long long* keys;   // [bs][cap_pad]
   unsigned char* best_cls;    // [bs][n] (best-class mode)
-  float* gbox;                // [bs][gcap][12]: bx1,by1,bx2,by2,area, x1,y1,x2,y2,conf,cls, row index (as int bits)
+  float* gbox;                // [bs][gcap / 64][12][64] (chunk-major, field planes of 64 candidates): bx1,by1,bx2,by2,area, x1,y1,x2,y2,conf,cls,
+                              // row index (as int bits); gcap is a multiple of 64
   long long cap, cap_pad, gcap;
 };
 
@@ -183,7 +184,8 @@ __global__ void y5_nms_sort_kernel(const Y5NmsParams p) {
 
 // ---- K2b: gather -- sorted keys -> compact per-candidate records (fully parallel over the GPU) ---------------
 // Takes the dependent key -> row -> box load chain off the serial greedy walk: record ci of image b =
-// {class-offset box, area, output box, conf, cls, row}, 48 bytes, read back coalesced (and prefetched) by K3.
+// {class-offset box, area, output box, conf, cls, row}, 12 floats, stored as field planes per chunk of 64 candidates -- one chunk is
+// 3 KiB of contiguous memory that K3 pulls into its LDS ring with three LDS-DMA instructions.
 #define Y5_NMS_REC 12
 template <typename T>
 __global__ void y5_nms_gather_kernel(const Y5NmsParams p) {
@@ -207,27 +209,34 @@ __global__ void y5_nms_gather_kernel(const Y5NmsParams p) {
   const float clsf = (float)cls;
   const float c = clsf * ((p.flags & 2) ? 0.0f : p.max_wh);             // general.py:748
   const float bx1 = x1 + c, by1 = y1 + c, bx2 = x2 + c, by2 = y2 + c;
-  float* r = p.gbox + ((long long)b * p.gcap + ci) * Y5_NMS_REC;
-  r[0] = bx1; r[1] = by1; r[2] = bx2; r[3] = by2; r[4] = (bx2 - bx1) * (by2 - by1);
-  r[5] = x1; r[6] = y1; r[7] = x2; r[8] = y2; r[9] = conf; r[10] = clsf; r[11] = __uint_as_float((unsigned)rowi);
+  float* r = p.gbox + ((long long)b * p.gcap + (ci & ~63LL)) * Y5_NMS_REC + (ci & 63);  // chunk base + lane; field f at r[f * 64]
+  r[0] = bx1; r[64] = by1; r[128] = bx2; r[192] = by2; r[256] = (bx2 - bx1) * (by2 - by1);
+  r[320] = x1; r[384] = y1; r[448] = x2; r[512] = y2; r[576] = conf; r[640] = clsf; r[704] = __uint_as_float((unsigned)rowi);
 }
 
 // ---- K3: greedy suppression, kept boxes in LDS -------------------------------------------------------
-// One workgroup of 16 waves per image walks the sorted candidates in chunks of 64 (records double-buffered in LDS:
-// wave 1 prefetches chunk c+1 from the compact array while chunk c is resolved):
+// One workgroup of 16 waves per image walks the sorted candidates in chunks of 64.  The chunk records come through a ring of
+// Y5_NMS_RING LDS slots filled by LDS-DMA: wave 1 requests chunk c + RING - 1 at the top of iteration c and waits with a COUNTED vmcnt
+// until chunk c + 1 has landed -- RING - 2 chunks stay in flight, so the walk never waits for a memory round trip (one dependent
+// load per chunk cost 2-4 us x 24 chunks of the 112 us this kernel took with a one-deep register prefetch):
 //   (A) every wave tests the 64 candidates (lane = candidate) against a 1/16 slice of the kept list -> suppression ballots;
 //   (M) every wave also forms 4 rows of the chunk's 64x64 "i suppresses j > i" bit matrix (one ballot per row);
 //   (B) wave 0 resolves the chunk serially with scalar bit operations only (ctz / readlane / andn2), then appends the
 //       survivors to the kept list and writes their output rows in parallel.
 // Same decisions as torchvision.ops.nms: candidate i is kept iff no EARLIER KEPT candidate has IoU > thr with it.
 #define Y5_NMS_GREEDY_WAVES 16
+#define Y5_NMS_RING 8
+#ifndef Y5_NMS_ABL   // kernel-experiment builds only: 1 = no kept-list test, 2 = no intra-chunk matrix, 4 = no serial resolution (keeps nothing)
+#define Y5_NMS_ABL 0
+#endif
 template <typename T>
 __global__ __launch_bounds__(1024)
 void y5_nms_greedy_kernel(const Y5NmsParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* kept = reinterpret_cast<float*>(smem);                                   // [max_det][5]: x1,y1,x2,y2 (class offset), area
-  float* cand = kept + (size_t)p.max_det * 5;                                     // [2][12][64] (record fields x candidates)
-  unsigned long long* matrix = reinterpret_cast<unsigned long long*>(cand + 2 * Y5_NMS_REC * 64);  // [64]
+  constexpr int KS = 6;                                                           // floats per kept box
+  float* kept = reinterpret_cast<float*>(smem);                                   // [max_det][6]: x1,y1,x2,y2 (class offset), area, class
+  float* cand = kept + (((size_t)p.max_det * KS + 3) & ~(size_t)3);              // [RING][12][64] (record fields x candidates), 16-byte aligned
+  unsigned long long* matrix = reinterpret_cast<unsigned long long*>(cand + Y5_NMS_RING * Y5_NMS_REC * 64);  // [64]
   unsigned long long* supmask = matrix + 64;                                      // [16]
   int* s_nkept = reinterpret_cast<int*>(supmask + Y5_NMS_GREEDY_WAVES);
 
@@ -244,29 +253,42 @@ void y5_nms_greedy_kernel(const Y5NmsParams p) {
   float* out = p.out + (long long)b * p.max_det * ow;
 
   if (tid == 0) *s_nkept = 0;
-  if (wave == 1 || Y5_NMS_GREEDY_WAVES == 1) {  // chunk 0 -> buffer 0
-    for (int f = 0; f < Y5_NMS_REC; ++f) cand[f * 64 + lane] = lane < n ? gb[(long long)lane * Y5_NMS_REC + f] : 0.f;
+  const long long last_chunk = p.gcap / 64 - 1;  // requests beyond the candidate list re-read the last chunk: the per-iteration LDS-DMA
+                                                  // count stays uniform (counted vmcnt), the data is never looked at
+  auto request = [&](long long chunk, int slot) {  // 3 KiB = three 1 KiB LDS-DMA instructions of wave 1
+    const float* src = gb + (chunk < last_chunk ? chunk : last_chunk) * (Y5_NMS_REC * 64);
+    float* dst = cand + slot * (Y5_NMS_REC * 64);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) y5_glds16(src + q * 256 + lane * 4, dst + q * 256);
+  };
+  if (wave == 1) {
+    for (int c = 0; c < Y5_NMS_RING - 1; ++c) request(c, c);
+    y5_wait_vm<3 * (Y5_NMS_RING - 2)>();  // chunk 0 has landed
   }
   __syncthreads();
   int nkept = 0, cb = 0;
+  long long chunk = 0;
 
-  for (long long base = 0; base < n && nkept < p.max_det; base += 64, cb ^= 1) {
+  for (long long base = 0; base < n && nkept < p.max_det; base += 64, ++chunk, cb = cb + 1 == Y5_NMS_RING ? 0 : cb + 1) {
     const float* cd = cand + cb * (Y5_NMS_REC * 64);
-    // prefetch: wave 1 pulls the next chunk's records into registers now, parks them in the other buffer below
-    float nxt[Y5_NMS_REC];
-    const bool do_pf = wave == 1 && base + 64 < n;
-    if (do_pf) {
-      const long long ci = base + 64 + lane;
-#pragma unroll
-      for (int f = 0; f < Y5_NMS_REC; ++f) nxt[f] = ci < n ? gb[ci * Y5_NMS_REC + f] : 0.f;
-    }
+    // the slot chunk - 1 occupied is free (its readers passed the barrier that ended the previous iteration): refill it
+    if (wave == 1) request(chunk + Y5_NMS_RING - 1, cb == 0 ? Y5_NMS_RING - 1 : cb - 1);
     const bool valid = base + lane < n;
     const float bx1 = cd[lane], by1 = cd[64 + lane], bx2 = cd[128 + lane], by2 = cd[192 + lane], area = cd[256 + lane];
     // (A) against the kept list
+    // Boxes of different classes never overlap (general.py:748 shifts them by cls * max_wh), so a kept box can only suppress candidates
+    // of its own class: one compare + ballot per kept box decides whether the 35-instruction IoU test runs at all for this wave's 64
+    // candidates.  The kernel is VALU-throughput-bound on ONE CU per image (1200 candidates x the growing kept list = 2e5 lane-tests);
+    // with 80 classes most (kept box, chunk) pairs share no class.  Agnostic mode (all classes collide) tests everything.
     bool sup = false;
-    for (int k = wave; k < nkept; k += Y5_NMS_GREEDY_WAVES) {
-      const float kx1 = kept[k * 5 + 0], ky1 = kept[k * 5 + 1], kx2 = kept[k * 5 + 2], ky2 = kept[k * 5 + 3];
-      const float ka = kept[k * 5 + 4];
+    const int nk_eff = (Y5_NMS_ABL & 1) ? 0 : nkept;
+    const float my_cls = cd[10 * 64 + lane];
+    const bool by_class = !(p.flags & 2);
+    for (int k = wave; k < nk_eff; k += Y5_NMS_GREEDY_WAVES) {
+      const float kc = kept[k * KS + 5];
+      if (by_class && __ballot(valid && my_cls == kc) == 0ull) continue;
+      const float kx1 = kept[k * KS + 0], ky1 = kept[k * KS + 1], kx2 = kept[k * KS + 2], ky2 = kept[k * KS + 3];
+      const float ka = kept[k * KS + 4];
       const float iw = fmaxf(0.0f, fminf(kx2, bx2) - fmaxf(kx1, bx1));
       const float ih = fmaxf(0.0f, fminf(ky2, by2) - fmaxf(ky1, by1));
       const float inter = iw * ih;
@@ -276,7 +298,7 @@ void y5_nms_greedy_kernel(const Y5NmsParams p) {
     if (lane == 0) supmask[wave] = m;
     // (M) rows 4*wave .. 4*wave+3 of the intra-chunk matrix
 #pragma unroll
-    for (int q = 0; q < 64 / Y5_NMS_GREEDY_WAVES; ++q) {
+    for (int q = 0; q < ((Y5_NMS_ABL & 2) ? 0 : 64 / Y5_NMS_GREEDY_WAVES); ++q) {
       const int i = wave * (64 / Y5_NMS_GREEDY_WAVES) + q;
       const float kx1 = cd[i], ky1 = cd[64 + i], kx2 = cd[128 + i], ky2 = cd[192 + i], ka = cd[256 + i];
       const float iw = fmaxf(0.0f, fminf(kx2, bx2) - fmaxf(kx1, bx1));
@@ -286,11 +308,7 @@ void y5_nms_greedy_kernel(const Y5NmsParams p) {
       const unsigned long long mm = __ballot(s2);
       if (lane == 0) matrix[i] = mm;
     }
-    if (do_pf) {
-      float* cn = cand + (cb ^ 1) * (Y5_NMS_REC * 64);
-#pragma unroll
-      for (int f = 0; f < Y5_NMS_REC; ++f) cn[f * 64 + lane] = nxt[f];
-    }
+    if (wave == 1) y5_wait_vm<3 * (Y5_NMS_RING - 2)>();  // chunk + 1 is in LDS for the next iteration
     __syncthreads();
     // (B) serial resolution on wave 0: uniform bit arithmetic only
     if (wave == 0) {
@@ -301,7 +319,7 @@ void y5_nms_greedy_kernel(const Y5NmsParams p) {
       const unsigned mlo = (unsigned)mrow, mhi = (unsigned)(mrow >> 32);
       unsigned long long keepm = 0ull;
       int cnt = nkept;
-      while (alive != 0ull && cnt < p.max_det) {
+      while (alive != 0ull && cnt < p.max_det && !(Y5_NMS_ABL & 4)) {
         const int i = __builtin_ctzll(alive);
         keepm |= 1ull << i;
         ++cnt;
@@ -312,8 +330,8 @@ void y5_nms_greedy_kernel(const Y5NmsParams p) {
       }
       if ((keepm >> lane) & 1ull) {
         const int slot = nkept + __popcll(keepm & ((1ull << lane) - 1ull));
-        kept[slot * 5 + 0] = bx1; kept[slot * 5 + 1] = by1; kept[slot * 5 + 2] = bx2; kept[slot * 5 + 3] = by2;
-        kept[slot * 5 + 4] = area;
+        kept[slot * KS + 0] = bx1; kept[slot * KS + 1] = by1; kept[slot * KS + 2] = bx2; kept[slot * KS + 3] = by2;
+        kept[slot * KS + 4] = area; kept[slot * KS + 5] = cd[10 * 64 + lane];
         float* o = out + (long long)slot * ow;
         o[0] = cd[5 * 64 + lane]; o[1] = cd[6 * 64 + lane]; o[2] = cd[7 * 64 + lane]; o[3] = cd[8 * 64 + lane];
         o[4] = cd[9 * 64 + lane]; o[5] = cd[10 * 64 + lane];

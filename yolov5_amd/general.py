@@ -138,4 +138,7 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     if padded:
         return out, cnt
     counts = cnt.tolist()  # the single D2H sync
-    return [out[i, :counts[i]] for i in range(bs)]
+    # per-image views of the padded buffer through ONE split call (sizes c0, max_det - c0, c1, ...: the even parts are the results) --
+    # 64 Python-level slicings cost ~100 us per batch, a third of the kernels' time
+    sizes = [v for c in counts for v in (c, max_det - c)]
+    return list(out.view(bs * max_det, 6 + nm).split(sizes)[::2])
