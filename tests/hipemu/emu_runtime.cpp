@@ -66,7 +66,10 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& fn
   const int nwaves = (T + 63) / 64;
   for (unsigned bz = 0; bz < grid.z; ++bz)
     for (unsigned by = 0; by < grid.y; ++by)
-      for (unsigned bx = 0; bx < grid.x; ++bx) {
+      for (unsigned bxr = 0; bxr < grid.x; ++bxr) {
+        // blocks run one after another, HIGHEST x first: hardware promises no dispatch order, and the one inter-workgroup protocol of
+        // the library (stream-K, conv_igemm.h) has every workgroup depend on higher-numbered ones only
+        const unsigned bx = grid.x - 1 - bxr;
         g_blockIdx = dim3(bx, by, bz);
         memset(smem, 0xCD, shmem);  // poison: uninitialised LDS reads show up as garbage, as on hardware
         lanes.assign(T, Lane{});

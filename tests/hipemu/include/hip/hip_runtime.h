@@ -95,6 +95,11 @@ inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_amdgcn_sched_barrier(a) ((void)0)
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_s_sleep(n) ((void)0)
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+#define __hip_atomic_load(p, order, scope) (*(p))
+#define Y5_EMU 1
 inline void emu_wave_barrier() { const void* o[64]; char c = 0; emu::wave_exchange(&c, 1, o); }
 #define __builtin_amdgcn_wave_barrier() emu_wave_barrier()
 inline float __expf(float x) { return expf(x); }

@@ -65,7 +65,21 @@ constexpr TileCfg kCfgs[kNumIgemm] = {
 
 int g_num_cu = 0;
 
-template <typename T, int WM, int WN, int TM, int TN, int RB, bool TABLE, int NS = 2, bool PROD = false, bool ALIAS = false>
+// stream-K configurations (conv_igemm.h SK): ids kSk0 + index; (wm, wn, tm, tn), 128-byte LDS rows (BK64), 2 stages
+constexpr int kSk0 = 57, kNumSk = 4;
+constexpr TileCfg kSkCfgs[kNumSk] = {
+    {2, 2, 2, 2, 128},  // 57: 128 x 128
+    {2, 4, 4, 2, 128},  // 58: 256 x 256, 8 waves
+    {2, 2, 4, 2, 128},  // 59: 256 x 128
+    {2, 2, 2, 4, 128},  // 60: 128 x 256
+};
+constexpr size_t kSkMaxGrid = 1024;                                   // workgroups a stream-K launch may have
+constexpr size_t kSkSlabBytes = (size_t)256 * 256 * 4;                // largest tile, fp32
+constexpr size_t kSkFlagBytes = kSkMaxGrid * 4;
+struct SkWs { void* ws; size_t bytes; };
+SkWs g_sk[64] = {};
+
+template <typename T, int WM, int WN, int TM, int TN, int RB, bool TABLE, int NS = 2, bool PROD = false, bool ALIAS = false, bool SK = false>
 int launch_cfg(const Y5ConvParams& p0, int max_blocks, hipStream_t stream) {
   using Gm = Y5ConvGeom<T, RB>;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -81,7 +95,7 @@ int launch_cfg(const Y5ConvParams& p0, int max_blocks, hipStream_t stream) {
   }
   const size_t lds = y5_conv_lds_bytes<T, WM, WN, TM, TN, RB, NS, ALIAS>(pieces);
   if (lds > 160 * 1024) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: tile configuration exceeds 160 KiB of LDS");
-  auto kern = y5_conv_igemm_kernel<T, WM, WN, TM, TN, RB, TABLE, NS, PROD, ALIAS>;
+  auto kern = y5_conv_igemm_kernel<T, WM, WN, TM, TN, RB, TABLE, NS, PROD, ALIAS, SK>;
   constexpr int NTHREADS = WM * WN * 64 * (PROD ? 2 : 1);
   static bool attr_done = false;  // per instantiation
   if (!attr_done) {
@@ -104,8 +118,23 @@ int launch_cfg(const Y5ConvParams& p0, int max_blocks, hipStream_t stream) {
       occ = 1;
     G = (long long)g_num_cu * occ;
   }
-  if (G > ntiles) G = ntiles;
-  if (G >= 8) G &= ~7LL;  // y5_xcd_remap of the virtual block id needs G % 8 == 0 when blocks own several tiles
+  if constexpr (SK) {
+    // every resident workgroup gets an equal share of the tiles * nk chunk-units (at least two chunks each)
+    const long long U = ntiles * p.nk;
+    if (G > U / 2) G = U / 2 > 0 ? U / 2 : 1;
+    if (G > (long long)kSkMaxGrid) G = kSkMaxGrid;
+    int dev = 0;
+    hipGetDevice(&dev);
+    const SkWs& w = g_sk[dev < 64 ? dev : 0];
+    const size_t need = kSkFlagBytes + (size_t)G * BM * BN * 4;
+    if (!w.ws || w.bytes < need) return y5_fail(Y5_ERR_WORKSPACE, "conv: stream-K configuration needs y5_conv_set_sk_workspace()");
+    p.sk_flags = static_cast<unsigned*>(w.ws);
+    p.sk_ws = reinterpret_cast<float*>(static_cast<char*>(w.ws) + kSkFlagBytes);
+    if (p.o_mul_h) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: stream-K with output placement is not built");
+  } else {
+    if (G > ntiles) G = ntiles;
+    if (G >= 8) G &= ~7LL;  // y5_xcd_remap of the virtual block id needs G % 8 == 0 when blocks own several tiles
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(NTHREADS), lds, stream, p);
   return y5_check_launch("y5_conv2d_fwd");
 }
@@ -166,6 +195,10 @@ int launch_by_cfg(const Y5ConvParams& p, int cfg, int mb, hipStream_t s) {
       case kBig0 + 18: return launch_cfg<T, 4, 1, 1, 3, 128, TABLE, 2>(p, mb, s);
       case kBig0 + 19: return launch_cfg<T, 4, 2, 2, 5, 64, TABLE, 2>(p, mb, s);
       case kBig0 + 20: return launch_cfg<T, 4, 2, 2, 3, 64, TABLE, 2>(p, mb, s);
+      case kSk0 + 0: return launch_cfg<T, 2, 2, 2, 2, 128, TABLE, 2, false, false, true>(p, mb, s);
+      case kSk0 + 1: return launch_cfg<T, 2, 4, 4, 2, 128, TABLE, 2, false, false, true>(p, mb, s);
+      case kSk0 + 2: return launch_cfg<T, 2, 2, 4, 2, 128, TABLE, 2, false, false, true>(p, mb, s);
+      case kSk0 + 3: return launch_cfg<T, 2, 2, 2, 4, 128, TABLE, 2, false, false, true>(p, mb, s);
     }
     return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown tile config");
   }
@@ -310,8 +343,28 @@ int default_cfg(const y5_conv_desc* d) {
 
 extern "C" int y5_conv_num_cfgs(void) { return Y5_CONV_NUM_CFGS; }
 
+// flags + the largest slab set: 1024 workgroups x 128x128 = 512 x 256x128 = 256 x 256x256 fp32 tiles = 64 MiB
+extern "C" size_t y5_conv_sk_workspace_bytes(void) { return kSkFlagBytes + kSkMaxGrid * (size_t)128 * 128 * 4; }
+
+extern "C" int y5_conv_set_sk_workspace(void* ws, size_t bytes, void* stream_) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return y5_fail(Y5_ERR_RUNTIME, "conv_set_sk_workspace: no device");
+  if (!ws) { g_sk[dev] = SkWs{nullptr, 0}; return Y5_OK; }
+  if (((uintptr_t)ws & 255) || bytes < kSkFlagBytes + kSkSlabBytes) return y5_fail(Y5_ERR_BAD_ARG, "conv_set_sk_workspace: misaligned or too small");
+  if (hipMemsetAsync(ws, 0, kSkFlagBytes, static_cast<hipStream_t>(stream_)) != hipSuccess) return y5_fail(Y5_ERR_RUNTIME, "conv_set_sk_workspace: memset failed");
+  g_sk[dev] = SkWs{ws, bytes};
+  return Y5_OK;
+}
+
 extern "C" int y5_conv_cfg_info(int cfg, int* bm, int* bn, int* bk_bytes) {
   if (cfg < 0 || cfg >= Y5_CONV_NUM_CFGS) return y5_fail(Y5_ERR_BAD_ARG, "conv_cfg_info: bad id");
+  if (cfg >= kSk0) {
+    const TileCfg& c = kSkCfgs[cfg - kSk0];
+    if (bm) *bm = c.wm * c.tm * 32;
+    if (bn) *bn = c.wn * c.tn * 32;
+    if (bk_bytes) *bk_bytes = c.rb;
+    return Y5_OK;
+  }
   if (cfg >= kPw2_0) {
     const PwCfg& c = kPwCfgs[8 + cfg - kPw2_0];
     if (bm) *bm = 128;
@@ -356,11 +409,12 @@ extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w
   const int epp = 16 / es;
   int cfg = d->cfg < 0 ? default_cfg(d) : d->cfg;
   if (cfg >= Y5_CONV_NUM_CFGS) return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown tile config");
-  const bool pw = (cfg >= kNumIgemm && cfg < kRing0) || cfg >= kPw2_0;
+  const bool sk = cfg >= kSk0;
+  const bool pw = (cfg >= kNumIgemm && cfg < kRing0) || (cfg >= kPw2_0 && !sk);
   const int pwi = cfg >= kPw2_0 ? 8 + cfg - kPw2_0 : cfg - kNumIgemm;
   const bool big = cfg >= kBig0 && cfg < kPw2_0;
   const bool k3 = cfg >= kK3_0 && cfg < kBig0;
-  const int bk = (pw || k3) ? 8 : (big ? kBigCfgs[cfg - kBig0].rb : kCfgs[cfg >= kRing0 ? kRingBase[cfg - kRing0] : cfg].rb) / es;
+  const int bk = (pw || k3) ? 8 : (sk ? kSkCfgs[cfg - kSk0].rb : big ? kBigCfgs[cfg - kBig0].rb : kCfgs[cfg >= kRing0 ? kRingBase[cfg - kRing0] : cfg].rb) / es;
   if (cfg >= kRing0 && d->dtype != Y5_F16) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: ring configurations are fp16 only");
   if (d->C1 % epp || d->ldx % epp) return y5_fail(Y5_ERR_BAD_ARG, "conv: C1 and ldx must be multiples of 16 bytes");
   if (d->C2 % epp || (y && d->ldy % epp) || (residual && d->ldr % epp) || (y_up2 && d->ld2 % epp))

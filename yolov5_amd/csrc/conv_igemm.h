@@ -48,6 +48,8 @@ struct Y5ConvParams {
   int ldr, ld2;
   int M;  // B*OH*OW
   int tilesM, tilesN, nk;
+  float* sk_ws;        // stream-K (SK kernels): one fp32 partial-tile slab per workgroup, [G][WM*WN*TM*TN*16*64]
+  unsigned* sk_flags;  // [G]: 1 = workgroup g's slab holds the partial sums of the tile its unit range starts in; reset to 0 by the reader
   int split_n;  // > 0: output channels >= split_n go to y2 (pixel stride ld2, channel n - split_n) instead of y -- C3's cv1 / cv2 halves
                 // of one GEMM landing in two different buffers (y2 is then NOT the upsampled replica)
 };
@@ -88,10 +90,23 @@ constexpr int y5_conv_min_waves(int tm, int tn) { return tm * tn <= 1 ? 5 : tm *
 // of in LDS of its own, and one more wave per SIMD is requested from the register allocator -- more workgroups per CU, so
 // that layers whose tile count is just above the resident-workgroup count finish in one round instead of two.  The
 // prefetch of the new tile's second chunk starts after the epilogue (one extra barrier per tile).
-template <typename T, int WM, int WN, int TM, int TN, int RB, bool TABLE, int NS = 2, bool PROD = false, bool ALIAS = false>
+//
+// SK (2-stage only): stream-K decomposition.  A layer of yolov5s at bs = 64 has 200 .. 1600 output tiles for 256 .. 512 resident
+// workgroups, so the last round of a tile-per-workgroup schedule is 22-56 % empty (M = 25600 = 2^10 * 25 pixels at P5: no power-of-two
+// tile shape divides the work evenly).  With SK the unit of work is one K chunk of one tile: workgroup g owns the contiguous range
+// [g * U / G, (g + 1) * U / G) of the U = tiles * nk units in (tile, k) order, so every workgroup multiplies the same number of chunks.
+// A range boundary inside a tile splits that tile's K loop between consecutive workgroups: the workgroup holding the FIRST k-part
+// (always the last thing it does) is the tile's owner; every later part is the FIRST thing its workgroup does -- it parks its fp32
+// partial sums in its slab of `sk_ws` (write-through stores), raises its flag and moves on.  The owner, having finished its own
+// part long after, polls each flag (one lane, relaxed agent-scope load, workgroup barrier), adds the slabs with cache-bypassing loads,
+// clears the flags for the next launch and runs the ordinary epilogue.  Dependencies only point
+// from a workgroup to higher-numbered ones that started at the same time (or are dispatched as lower-numbered ones retire), so there
+// is nothing to deadlock on; the poll is bounded all the same.
+template <typename T, int WM, int WN, int TM, int TN, int RB, bool TABLE, int NS = 2, bool PROD = false, bool ALIAS = false, bool SK = false>
 __global__ __launch_bounds__(WM * WN * 64 * (PROD ? 2 : 1), y5_conv_min_waves(TM, TN) + (ALIAS ? 1 : 0))
 void y5_conv_igemm_kernel(const Y5ConvParams p) {
   static_assert(!PROD || NS >= 3, "producer/consumer needs a ring");
+  static_assert(!SK || (NS == 2 && !PROD && !ALIAS), "stream-K is implemented for the plain 2-stage kernel");
   static_assert(!ALIAS || (NS == 2 && !PROD), "scratch aliasing is implemented for the 2-stage kernel");
   static_assert(!ALIAS || (WM * TM * 32 + WN * TN * 32) * RB >= WM * WN * Y5ConvGeom<T, RB>::SCR_BYTES, "stage too small for the scratch");
   using Gm = Y5ConvGeom<T, RB>;
@@ -125,9 +140,20 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
   const int G = gridDim.x;
   const int bid = blockIdx.x;
   const int ntiles = p.tilesM * p.tilesN;
-  const int nmine = (ntiles - bid + G - 1) / G;  // host guarantees G <= ntiles
   const int nk = p.nk;
-  const int total = nmine * nk;
+  // SK: this workgroup's unit range -> first tile, first chunk inside it, number of tiles touched, chunk where the last one stops
+  long long sk_u0 = 0, sk_u1 = 0;
+  int sk_tf = 0, sk_kb0 = 0, sk_ke_last = nk;
+  if constexpr (SK) {
+    const long long U = (long long)ntiles * nk;
+    sk_u0 = U * bid / G;
+    sk_u1 = U * (bid + 1) / G;
+    sk_tf = (int)(sk_u0 / nk);
+    sk_kb0 = (int)(sk_u0 - (long long)sk_tf * nk);
+    sk_ke_last = (int)((sk_u1 - 1) % nk) + 1;
+  }
+  const int nmine = SK ? (sk_u1 > sk_u0 ? (int)((sk_u1 - 1) / nk) - sk_tf + 1 : 0) : (ntiles - bid + G - 1) / G;  // host guarantees G <= ntiles
+  const int total = SK ? (int)(sk_u1 - sk_u0) : nmine * nk;
 
   const y5_rsrc_t xrs = y5_make_rsrc(p.x, p.x_bytes);
   const y5_rsrc_t wrs = y5_make_rsrc(p.w, p.w_bytes);
@@ -160,10 +186,10 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
   unsigned a_mask[ACT_PER_WAVE];   // UNIFORM mode: bit (kh*KW + kw) CLEAR <=> that tap of this row lies inside the image
   unsigned w_off[WGT_PER_WAVE];    // byte offset of the filter row + source slot, Y5_OOB for rows beyond the tile / Npad
   int u_kh = 0, u_kw = 0, u_c0 = 0;  // uniform tap walker (UNIFORM mode: C1 % BK == 0)
-  int s_t = 0, s_kc = 0;             // staged tile (index into this block's tile list) / K chunk
+  int s_t = 0, s_kc = SK ? sk_kb0 : 0;  // staged tile (index into this block's tile list) / K chunk
 
   auto tile_coords = [&](int j, int& m0, int& n0) {
-    const int t = y5_xcd_remap(bid + j * G, ntiles);
+    const int t = SK ? sk_tf + j : y5_xcd_remap(bid + j * G, ntiles);
     const int tn = t % p.tilesN, tm = t / p.tilesN;
     m0 = tm * BM;
     n0 = tn * BN;
@@ -209,6 +235,15 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
       w_off[i] = (row < BN) && (n < p.Npad) ? (unsigned)((n * p.Kpad + sslot * EPP) * ES) : 0x80000000u;
     }
     u_kh = 0; u_kw = 0; u_c0 = 0;
+    if constexpr (SK && !TABLE) {
+      if (j == 0 && sk_kb0 > 0) {  // the range starts inside this tile: put the uniform tap walker on chunk sk_kb0
+        const int k = sk_kb0 * BK;
+        const int tap = k / p.C1;
+        u_c0 = k - tap * p.C1;
+        u_kh = tap / p.KW;
+        u_kw = tap - u_kh * p.KW;
+      }
+    }
   };
 
   // One chunk = LPC LDS-DMA instructions per wave.  The vector-memory path moves 64 B/clk/CU, so a chunk's loads occupy it
@@ -485,6 +520,92 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
         cur = cur + 1 == NS ? 0 : cur + 1;
       }
     }
+  } else if constexpr (SK) {
+    // ---- stream-K main loop: `total` chunk-units in (tile, k) order, first tile entered at chunk sk_kb0 --------------------
+    // Slabs travel with sc1 (write-through / cache-bypassing) 16-byte buffer stores and loads: no agent-scope fence anywhere (a
+    // release fence is a write-back of the XCD's whole L2 -- every workgroup doing one made the first version 2x slower than no
+    // stream-K at all).  Publish = stores, s_waitcnt vmcnt(0) in every wave, workgroup barrier, relaxed agent-scope flag store;
+    // consume = relaxed agent-scope poll by one lane, workgroup barrier, sc1 loads (cdna guide, split-K recipe, second form).
+    constexpr int SLAB_BYTES = NW * TM * TN * 16 * 64 * 4;  // per workgroup
+    constexpr int SC1 = 16;
+    auto slab_rsrc = [&](int g) { return y5_make_rsrc(reinterpret_cast<const char*>(p.sk_ws) + (size_t)g * SLAB_BYTES, (unsigned)SLAB_BYTES); };
+    auto park_partial = [&]() {  // this workgroup holds a LATER k-part of the tile: publish the sums, the owner adds them
+      const y5_rsrc_t rs = slab_rsrc(bid);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            uint4_t v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __float_as_uint(acc[i][j][q * 4 + e]);
+            y5_buffer_store16(v, rs, ((((wave * TM + i) * TN + j) * 4 + q) * 64 + lane) * 16, SC1);
+          }
+      Y5_DRAIN_VM();
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(p.sk_flags + bid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto gather_partials = [&](int tile) {  // owner: add the slabs of the workgroups whose ranges start inside `tile`
+      const long long tile_end = (long long)(tile + 1) * nk, U = (long long)ntiles * nk;
+      for (int g2 = bid + 1; g2 < G && U * g2 / G < tile_end; ++g2) {
+        if (tid == 0) {
+          unsigned spins = 0;
+          while (__hip_atomic_load(p.sk_flags + g2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(1);
+        }
+        __syncthreads();
+        const y5_rsrc_t rs = slab_rsrc(g2);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const uint4_t v = y5_buffer_load16(rs, ((((wave * TM + i) * TN + j) * 4 + q) * 64 + lane) * 16, SC1);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[i][j][q * 4 + e] += __uint_as_float(v[e]);
+            }
+        __syncthreads();  // every wave has read the slab before the flag lets its writer (next launch) reuse it
+        if (tid == 0) __hip_atomic_store(p.sk_flags + g2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    };
+    // kind of the segment whose sums sit in acc: 0 = whole tile, 1 = later k-part (park), 2 = first k-part of a split tile (owner)
+    auto finish_segment = [&](int ti) {
+      const int kb = ti == 0 ? sk_kb0 : 0, ke = ti == nmine - 1 ? sk_ke_last : nk;
+      if (kb > 0) { park_partial(); return; }
+      if (ke < nk) gather_partials(sk_tf + ti);
+      epilogue(pm0, pn0);
+    };
+    if (total > 0) {
+      stage(0);
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+      __syncthreads();
+      int ti = 0, kc = sk_kb0;
+      for (int it = 0; it < total; ++it) {
+        const int cur = it & 1;
+        const bool more = it + 1 < total;
+        const bool seg_start = it == 0 || kc == 0;
+        const bool spread = more && !seg_start;
+        if (more) { if (spread) stage_begin(cur ^ 1); else stage(cur ^ 1); }
+        if (seg_start) {
+          if (it > 0) finish_segment(ti - 1);
+          tile_coords(ti, pm0, pn0);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+        compute(smem + cur * BUF_BYTES, spread);
+        if (spread) stage_end();
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        if (++kc == nk) { kc = 0; ++ti; }
+      }
+      finish_segment(nmine - 1);
+    }
+    return;
   } else if constexpr (NS == 2) {
     stage(0);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)

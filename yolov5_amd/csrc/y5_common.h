@@ -34,6 +34,26 @@ __device__ __forceinline__ void y5_bglds16(y5_rsrc_t r, unsigned voff, void* lds
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, Y5_LDS_PTR(lds_wave_base), 16, (int)voff, 0, 0, 0);
 }
 
+// 16-byte buffer store / load with an explicit cache policy (aux: 16 = sc1, write-through / bypass of the non-coherent levels): the
+// transport of data that another workgroup -- possibly on another XCD -- reads within the same launch (stream-K slabs)
+__device__ __forceinline__ void y5_buffer_store16(uint4_t v, y5_rsrc_t r, int voff, int aux) {
+#ifdef Y5_EMU
+  memcpy(const_cast<char*>(r.base) + voff, &v, 16);
+#else
+  if (aux == 16) __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 16);
+  else __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 0);
+#endif
+}
+__device__ __forceinline__ uint4_t y5_buffer_load16(y5_rsrc_t r, int voff, int aux) {
+#ifdef Y5_EMU
+  uint4_t v;
+  memcpy(&v, r.base + voff, 16);
+  return v;
+#else
+  return aux == 16 ? __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 16) : __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+#endif
+}
+
 __device__ __forceinline__ float y5_sigmoid(float v) { return 1.0f / (1.0f + __expf(-v)); }
 __device__ __forceinline__ float y5_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
@@ -53,6 +73,14 @@ template <int N> __device__ __forceinline__ void y5_wait_vm() {
   __builtin_amdgcn_s_waitcnt(y5_waitcnt_vm(N < 63 ? N : 63));
   asm volatile("" ::: "memory");
 }
+
+// drain the vector-memory queue with an instruction the compiler can neither drop nor merge (the guide's split-K recipe: hipcc's
+// scoreboard removes a builtin wait it believes redundant, e.g. behind a fence)
+#ifdef Y5_EMU
+#define Y5_DRAIN_VM() ((void)0)
+#else
+#define Y5_DRAIN_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
 
 // compile-time loop: f(std::integral_constant<int, I>{}) for I in [B, E)
 template <int B, int E, typename F>

@@ -379,10 +379,15 @@ def folded_weights(mods):
 _TUNE_CACHE = {}  # conv descriptor (shape/dtype/strides) -> fastest tile configuration id, per process
 
 
-def autotune_conv(lib, d, ptrs, st):
+SK_CFGS = frozenset(range(57, 61))  # stream-K configurations: they share one registered workspace (include/yolov5_hip.h)
+
+
+def autotune_conv(lib, d, ptrs, st, exclude=()):
     """Measure-don't-guess tile selection: HIP-event timing of every kernel configuration on the real buffers
-    (cached per descriptor for the life of the process).  ptrs = (x, w, bias, residual, y, y2) as c_void_p / None."""
-    key = tuple(getattr(d, f) for f, _ in _lib.ConvDesc._fields_ if f not in ("cfg", "max_blocks")) + tuple(p is None or p.value is None for p in ptrs)
+    (cached per descriptor for the life of the process).  ptrs = (x, w, bias, residual, y, y2) as c_void_p / None.
+    exclude: configuration ids that must not be chosen for this launch (stream-K on ops that overlap with others in time)."""
+    key = tuple(getattr(d, f) for f, _ in _lib.ConvDesc._fields_ if f not in ("cfg", "max_blocks")) + tuple(p is None or p.value is None for p in ptrs) \
+        + (bool(exclude),)
     _load_tune_cache()
     best = _TUNE_CACHE.get(key)
     if best is not None:
@@ -398,7 +403,7 @@ def autotune_conv(lib, d, ptrs, st):
             lo, _, hi = part.partition("-")
             skip.update(range(int(lo), int(hi or lo) + 1))
     for cfg in range(ncfg):
-        if cfg in skip:
+        if cfg in skip or cfg in exclude:
             continue
         lib.y5_conv_cfg_info(cfg, C.byref(bm), C.byref(bn), C.byref(kb))
         if bn.value >= 2 * d.Npad and bn.value > 32:
@@ -470,6 +475,21 @@ def default_backend(device):
     if _lib._test_backend is not None and torch.device(device).type == "cpu":
         return _lib._test_backend()
     return _HipBackend(device)
+
+
+_SK_WS = {}  # device -> workspace tensor registered with the library (kept alive for the life of the process)
+
+
+def _ensure_sk_workspace(be, lib, st):
+    """Register the stream-K scratch (64 MiB of the 288 GB) for this device once; every plan of the process shares it."""
+    dev = str(getattr(be, "device", "cpu"))
+    if dev in _SK_WS or os.environ.get("Y5_STREAMK", "0") != "1":
+        return
+    nbytes = int(lib.y5_conv_sk_workspace_bytes())
+    ws = be.empty((nbytes + 256,), torch.uint8)
+    off = (-be.ptr(ws)) % 256
+    _lib.check(lib.y5_conv_set_sk_workspace(C.c_void_p(be.ptr(ws) + off), nbytes, st), lib)
+    _SK_WS[dev] = ws
 
 
 class _HipBackend:
@@ -750,7 +770,10 @@ class Engine:
         assert Npad >= c2s
         ptrs = (self._ptr(x), C.c_void_p(self.be.ptr(wp)), C.c_void_p(self.be.ptr(bp)), self._ptr(res), self._ptr(y), self._ptr(y2))
         if getattr(self.be, "autotune", False):
-            d.cfg = self._autotune_conv(d, ptrs)
+            # stream-K kernels combine split tiles through ONE registered workspace: not for ops that run beside others (side stream)
+            # (measured, scripts/streamk_bench.py: at yolov5s bs=64 sizes the slab round trip costs more than the tail it removes --
+            # 60-119 us against 42-69 us for the plain tiles -- so they only enter the race when asked for: Y5_STREAMK=1)
+            d.cfg = self._autotune_conv(d, ptrs, exclude=SK_CFGS if (op.get("side") or os.environ.get("Y5_STREAMK", "0") != "1") else ())
         head = self._fused_head_args(op, d, ptrs)
         if head is not None:
             self._fused_heads.add(head["level"])
@@ -806,8 +829,9 @@ class Engine:
         self._keep.append(arr)
         return dict(level=lvl, args=args)
 
-    def _autotune_conv(self, d, ptrs):
-        return autotune_conv(self.lib, d, ptrs, self._stream())
+    def _autotune_conv(self, d, ptrs, exclude=()):
+        _ensure_sk_workspace(self.be, self.lib, self._stream())
+        return autotune_conv(self.lib, d, ptrs, self._stream(), exclude)
 
     # -- execution ---------------------------------------------------------------------------------------------
     def _stream(self):
