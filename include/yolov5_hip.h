@@ -202,6 +202,11 @@ int y5_raw_to_nhwc(const void* draw, void* dlogits, int B, int npix, int na, int
 int y5_upsample2x_bwd(const void* gup, void* gsrc, int B, int H, int W, int C, int ld_up, int ld_src, int accumulate, void* stream);
 int y5_add_slice(const void* src, void* dst, long long npix, int C, int lds, int ldd, int accumulate, void* stream);
 int y5_sppf_pool_bwd(const void* act, void* grad, int B, int H, int W, int C, int ld_act, int ld_grad, int k, void* stream);
+/* fp32 twins of the five glue calls above for the training plan's reference-precision mode (one entry, `op` selects):
+ * 0 nhwc_to_raw (H = npix, W = na, C = no, a = ld)   1 raw_to_nhwc (same)   2 upsample2x_bwd (a = ld_up, b = ld_src, c = accumulate)
+ * 3 add_slice (B*H*W pixels, a = lds, b = ldd, c = accumulate)   4 sppf_pool_bwd (src = activations, dst = gradients, a = ld_act, b = ld_grad, c = k).
+ * y5_conv2d_wgrad and y5_filter_jobs (job.reserved = 1: fp32 destination) take fp32 through their existing signatures. */
+int y5_train_glue_f32(int op, const void* src, void* dst, int B, int H, int W, int C, int a, int b, int c, void* stream);
 /* Filter (re)packing on the device -- fp32 master weights (C2, C1, KH, KW) change at every optimizer step:
  * y5_pack_conv_weight : -> fp16 [Npad][Kpad], k = (kh*KW + kw)*C1_view + c (C1_view >= C1: channel padding of the stem view)
  * y5_pack_dgrad_weight: -> fp16 [Npad][Kpad] sub-filter of one data-gradient parity class, out[c1][(a*ntw + b)*C2_view + c2] =

@@ -117,3 +117,42 @@ def test_filter_jobs_match_single_filter_entry_points():
     assert lib.y5_filter_jobs(C.byref(arr), len(jobs), max(r[2] for r in jobs), None) == 0, lib.y5_last_error()
     for got, want in checks:
         assert np.array_equal(got, want)
+
+
+def test_fp32_training_plan_exact_gradients_vs_oracle_autograd():
+    """TrainEngine(dtype=float32): the whole step in fp32 (exact-fp32 MFMA forward / data gradient, plain fp32 weight gradient, fp32
+    BatchNorm / SiLU / pooling / upsample backward) against torch autograd over the CPU oracle -- no fp16 envelope: every parameter
+    gradient to 1e-3 relative L2 (the tiny model of oracle/make_golden.py:TINY_CFG, 2 x 3 x 64 x 64)."""
+    import copy
+
+    from oracle.make_golden import TINY_CFG
+
+    cfg = copy.deepcopy(TINY_CFG)
+    sd = yo.det_state_dict(cfg, 4, fused=False)
+    m = DetectionModel(copy.deepcopy(TINY_CFG))
+    m.load_state_dict(sd)
+    m.train()
+    B = 2
+    x = torch.from_numpy(detgen.uniform((B, 3, 64, 64), 0.0, 1.0, name="img", seed=4))
+    eng = TrainEngine(m, (B, 3, 64, 64), "cpu", backend=EmuBackend(), dtype=torch.float32)
+    p = [eng.be.to_torch(o) for o in eng.forward(x)]
+    assert all(t.dtype == torch.float32 for t in p)
+    sdo, leaves = {}, {}
+    for k, v in sd.items():
+        sdo[k] = v.clone()
+        if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var", "anchors")):
+            sdo[k] = v.clone().requires_grad_(True)
+            leaves[k] = sdo[k]
+    ref = yo.model_forward(cfg, sdo, x, training=True, bn_batch_stats=True)
+    for a, b in zip(p, ref):
+        np.testing.assert_allclose(a.numpy(), b.detach().numpy(), rtol=2e-4, atol=2e-4)
+    rs = [torch.from_numpy(detgen.uniform(tuple(b.shape), -1, 1, name=f"up{i}", seed=5)) for i, b in enumerate(ref)]
+    sum((b * r).sum() for b, r in zip(ref, rs)).backward()
+    grads = eng.backward(rs)
+    worst = 0.0
+    for (n, _), g in zip(m.named_parameters(), grads):
+        rg = leaves[n].grad
+        rel = float((g.double() - rg.double()).norm() / (rg.double().norm() + 1e-30))
+        worst = max(worst, rel)
+        assert rel < 1e-3, (n, rel)
+    print(f"\\n[train-emu fp32] worst relative L2 error over {len(grads)} parameter gradients: {worst:.2e}")

@@ -60,6 +60,31 @@ def test_train_loop_50_iterations_vs_oracle(dev):
     assert errs[len(errs) // 2][0] < 0.02 and errs[0][0] < 0.6, errs[:5]
 
 
+def test_train_loop_fp32_mode_tracks_oracle_per_step(dev):
+    """train(..., amp=False): the fp32 training plan under the same schedule -- every one of the 24 per-iteration loss triples within 1e-3
+    of the oracle loop's (oracle/train_oracle.py), parameters after training within 1e-3 relative."""
+    from yolov5_amd.train_loop import TensorLoader, train
+    from yolov5_amd.yolo import DetectionModel
+
+    cfg = yo.model_cfg("yolov5n")
+    sd = yo.det_state_dict(cfg, 1, fused=False)
+    m = DetectionModel("yolov5n.yaml")
+    m.load_state_dict(sd)
+    m = m.to(dev)
+    imgs, tpi = to.synthetic_set(16, 128, per_img=3, seed=2)
+    bs, epochs = 4, 6
+    hyp = dict(to.HYP)
+    res = train(m, TensorLoader(imgs.to(dev), [t.to(dev) for t in tpi], bs), hyp=dict(hyp), epochs=epochs, device=dev, amp=False)
+    ref = to.train_oracle(cfg, sd, imgs, tpi, bs, hyp=dict(hyp), epochs=epochs)
+    a, b = res["losses"].numpy(), ref["losses"].numpy()
+    assert a.shape == b.shape == (24, 3)
+    rel = np.abs(a - b) / np.maximum(np.abs(b), 1e-3)
+    print(f"\n[train-loop fp32] per-step loss deviation from the oracle: max {rel.max():.2e}, mean {rel.mean():.2e}; final loss {a.sum(1)[-1]:.5f} vs {b.sum(1)[-1]:.5f}")
+    assert rel.max() < 1e-3, rel.max()
+    worst = max(float((p.detach().cpu() - ref["sd"][k]).norm() / (ref["sd"][k].norm() + 1e-12)) for k, p in m.named_parameters())
+    assert worst < 1e-3, worst
+
+
 def test_detect_loop_batch_vs_oracle_pipeline(dev):
     from yolov5_amd.detect_loop import detect
     from yolov5_amd.yolo import DetectionModel

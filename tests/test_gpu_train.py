@@ -148,3 +148,37 @@ def test_train_step_yolov5s_bs64_timing(dev):
     ms = (time.time() - t0) / 3 * 1e3
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]  # the loss goes down on a fixed batch
     print(f"\n[train] yolov5s bs=64 640^2: {ms:.1f} ms per step (fwd + ComputeLoss + bwd + SGD) = {B / ms * 1e3:.0f} img/s; losses {['%.3f' % l for l in losses]}")
+
+
+def test_fp32_training_plan_exact_gradients_vs_oracle_autograd(dev):
+    """The whole training step in fp32 (TrainEngine dtype=float32, selected by float32 images): yolov5n, 4 x 3 x 128 x 128 -- loss and
+    EVERY parameter gradient against torch autograd over the CPU oracle at 1e-3 relative (no fp16 envelope)."""
+    from yolov5_amd.loss import ComputeLoss
+
+    m, cfg, sd = _model("yolov5n", dev)
+    B, S = 4, 128
+    x = torch.from_numpy(detgen.uniform((B, 3, S, S), 0.0, 1.0, name="timg", seed=9))
+    t = torch.from_numpy(detgen.synth_targets(B, 5, seed=9))
+    compute_loss = ComputeLoss(m)
+    pred = m(x.to(dev))                       # float32 images -> fp32 plan
+    assert all(p.dtype == torch.float32 for p in pred)
+    loss, items = compute_loss(pred, t.to(dev))
+    loss.backward()
+    torch.cuda.synchronize()
+    sdo, leaves, ref, rloss, ritems = _oracle_grads(cfg, sd, x, t, 0)
+    for a, b in zip(pred, ref):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().numpy(), rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(loss.item(), rloss.item(), rtol=1e-4)
+    np.testing.assert_allclose(items.cpu().numpy(), ritems.numpy(), rtol=1e-4)
+    worst = 0.0
+    for n, p in m.named_parameters():
+        assert p.grad is not None, n
+        a, b = p.grad.cpu().flatten().double(), leaves[n].grad.flatten().double()
+        rel = float((a - b).norm() / (b.norm() + 1e-30))
+        worst = max(worst, rel)
+        assert rel < 1e-3, (n, rel)
+    for name, mod in m.named_modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            np.testing.assert_allclose(mod.running_var.cpu().numpy(), sdo[name + ".running_var"].numpy(), rtol=1e-4, atol=1e-6)
+    print(f"\\n[train fp32] yolov5n bs={B} {S}^2: loss {loss.item():.6f} vs oracle {rloss.item():.6f}; worst relative L2 error over "
+          f"{len(leaves)} parameter gradients {worst:.2e}")

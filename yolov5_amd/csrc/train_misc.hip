@@ -162,6 +162,109 @@ void y5_sppf_pool_bwd_kernel(const char* __restrict__ act, char* __restrict__ gr
   }
 }
 
+// ---- fp32 twins (TrainEngine's reference-precision mode: the whole step in fp32 for an exact gradient check against the oracle's
+// autograd; simple one-element-per-thread kernels, nothing here is on a hot path) ------------------------------------------------
+__global__ void y5_nhwc_to_raw_f32_kernel(const float* __restrict__ lg, float* __restrict__ raw, int npix, int na, int no, int ld, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int o = (int)(i % no);
+  long long t = i / no;
+  const int pix = (int)(t % npix);
+  t /= npix;
+  const int a = (int)(t % na);
+  const long long b = t / na;
+  raw[i] = lg[(b * npix + pix) * ld + a * no + o];
+}
+__global__ void y5_raw_to_nhwc_f32_kernel(const float* __restrict__ draw, float* __restrict__ dlg, int npix, int na, int no, int ld, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int n = (int)(i % ld);
+  const long long bp = i / ld;
+  float v = 0.f;
+  if (n < na * no) {
+    const int a = n / no, o = n - a * no;
+    const long long b = bp / npix;
+    const int pix = (int)(bp - b * npix);
+    v = draw[((b * na + a) * npix + pix) * no + o];
+  }
+  dlg[i] = v;
+}
+__global__ void y5_upsample2x_bwd_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int C, int lds, int ldd, int acc,
+                                             long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over dst elements (pixel, channel)
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const long long pix = i / C;
+  const int w = (int)(pix % W);
+  const long long t = pix / W;
+  const int h = (int)(t % H);
+  const long long b = t / H;
+  float s = acc ? dst[pix * ldd + c] : 0.f;
+  for (int dy = 0; dy < 2; ++dy)
+    for (int dx = 0; dx < 2; ++dx) s += src[((b * 2 * H + 2 * h + dy) * (2 * W) + 2 * w + dx) * lds + c];
+  dst[pix * ldd + c] = s;
+}
+__global__ void y5_add_slice_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int lds, int ldd, int acc, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const long long pix = i / C;
+  dst[pix * ldd + c] = src[pix * lds + c] + (acc ? dst[pix * ldd + c] : 0.f);
+}
+// SPPF backward in place, one thread per (image, channel): the gradient of pool `pass` (held in slice `pass`) is scattered to the first
+// maximum of every window of slice pass - 1 (torch's tie rule) on top of that slice's direct gradient; after pass 1 slice 0 holds dx.
+__global__ void y5_sppf_pool_bwd_f32_kernel(const float* __restrict__ act, float* __restrict__ grad, int H, int W, int C, int lda, int ldg, int k, int total) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = i % C, b = i / C, r = k / 2;
+  const float* a0 = act + (size_t)b * H * W * lda + c;
+  float* g0 = grad + (size_t)b * H * W * ldg + c;
+  for (int pass = 3; pass >= 1; --pass) {
+    const float* ain = a0 + (size_t)(pass - 1) * C;
+    float* gin = g0 + (size_t)(pass - 1) * C;
+    const float* gout = g0 + (size_t)pass * C;
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) {
+        const int y0 = y - r < 0 ? 0 : y - r, y1 = y + r >= H ? H - 1 : y + r, x0 = x - r < 0 ? 0 : x - r, x1 = x + r >= W ? W - 1 : x + r;
+        float best = ain[(size_t)(y0 * W + x0) * lda];
+        int bi = y0 * W + x0;
+        for (int yy = y0; yy <= y1; ++yy)
+          for (int xx = x0; xx <= x1; ++xx) {
+            const float t = ain[(size_t)(yy * W + xx) * lda];
+            if (t > best) { best = t; bi = yy * W + xx; }
+          }
+        gin[(size_t)bi * ldg] += gout[(size_t)(y * W + x) * ldg];
+      }
+  }
+}
+
+extern "C" int y5_train_glue_f32(int op, const void* src, void* dst, int B, int H, int W, int C, int a, int b2, int c3, void* stream_) {
+  // op 0: nhwc_to_raw (H = npix, W = na, C = no, a = ld)      op 1: raw_to_nhwc (same)
+  // op 2: upsample2x_bwd (a = ld_up, b2 = ld_src, c3 = accumulate)   op 3: add_slice (B*H*W pixels; a = lds, b2 = ldd, c3 = accumulate)
+  // op 4: sppf_pool_bwd (src = act, dst = grad; a = ld_act, b2 = ld_grad, c3 = k)
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (!src || !dst) return y5_fail(Y5_ERR_BAD_ARG, "train_glue_f32: null pointer");
+  if (op == 0) {
+    const long long total = (long long)B * W * H * C;
+    hipLaunchKernelGGL(y5_nhwc_to_raw_f32_kernel, dim3(nblk(total, 256)), dim3(256), 0, st, (const float*)src, (float*)dst, H, W, C, a, total);
+  } else if (op == 1) {
+    const long long total = (long long)B * H * a;
+    hipLaunchKernelGGL(y5_raw_to_nhwc_f32_kernel, dim3(nblk(total, 256)), dim3(256), 0, st, (const float*)src, (float*)dst, H, W, C, a, total);
+  } else if (op == 2) {
+    const long long total = (long long)B * H * W * C;
+    hipLaunchKernelGGL(y5_upsample2x_bwd_f32_kernel, dim3(nblk(total, 256)), dim3(256), 0, st, (const float*)src, (float*)dst, H, W, C, a, b2, c3, total);
+  } else if (op == 3) {
+    const long long total = (long long)B * H * W * C;
+    hipLaunchKernelGGL(y5_add_slice_f32_kernel, dim3(nblk(total, 256)), dim3(256), 0, st, (const float*)src, (float*)dst, C, a, b2, c3, total);
+  } else if (op == 4) {
+    const int total = B * C;
+    hipLaunchKernelGGL(y5_sppf_pool_bwd_f32_kernel, dim3(nblk(total, 64)), dim3(64), 0, st, (const float*)src, (float*)dst, H, W, C, a, b2, c3, total);
+  } else {
+    return y5_fail(Y5_ERR_BAD_ARG, "train_glue_f32: unknown op");
+  }
+  return y5_check_launch("y5_train_glue_f32");
+}
+
 extern "C" int y5_raw_to_nhwc_tiled(const void* draw, void* dlogits, int B, int npix, int na, int no, int ld, void* stream_);
 extern "C" int y5_nhwc_to_raw(const void* logits, void* raw, int B, int npix, int na, int no, int ld, void* stream_) {
   if (!logits || !raw || B < 1 || npix < 1 || na < 1 || no < 1 || ld < na * no) return y5_fail(Y5_ERR_BAD_ARG, "nhwc_to_raw: bad args");
@@ -334,7 +437,8 @@ void y5_filter_jobs_kernel(const y5_filter_job* __restrict__ jobs) {
         if (c2 < j.C2) v = w[((c2 * j.C1 + n) * j.KH + j.th[a]) * j.KW + j.tw[b]];
       }
     }
-    static_cast<half_t*>(j.dst)[i] = (half_t)v;
+    if (j.reserved == 1) static_cast<float*>(j.dst)[i] = v;  // fp32 training plan (reference-precision mode)
+    else static_cast<half_t*>(j.dst)[i] = (half_t)v;
   }
 }
 

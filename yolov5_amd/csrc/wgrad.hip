@@ -189,10 +189,41 @@ void y5_conv_wgrad_kernel(const Y5WgradParams p) {
   }
 }
 
+// fp32 weight gradient (TrainEngine's reference-precision mode): one thread per packed filter element, a plain fp32 sum over all output
+// pixels in a fixed order -- deterministic, exact fp32; not a hot path
+__global__ void y5_conv_wgrad_f32_kernel(const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ dw, int B, int H, int W, int C1,
+                                         int ldx, int OH, int OW, int C2, int ldz, int KH, int KW, int SH, int SW, int PH, int PW, int Kpad, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int k = (int)(i % Kpad), n = (int)(i / Kpad);
+  if (n >= C2 || k >= KH * KW * C1) return;
+  const int c = k % C1, t = k / C1, kh = t / KW, kw = t - kh * KW;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b)
+    for (int oh = 0; oh < OH; ++oh) {
+      const int ih = oh * SH - PH + kh;
+      if ((unsigned)ih >= (unsigned)H) continue;
+      for (int ow = 0; ow < OW; ++ow) {
+        const int iw = ow * SW - PW + kw;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        s += dz[(((size_t)b * OH + oh) * OW + ow) * ldz + n] * x[(((size_t)b * H + ih) * W + iw) * ldx + c];
+      }
+    }
+  dw[(size_t)n * Kpad + k] += s;
+}
+
 extern "C" int y5_conv2d_wgrad(const y5_conv_desc* d, const void* x, const void* dz, int ld_dz, float* dw_packed, void* stream_) {
   hipStream_t st = static_cast<hipStream_t>(stream_);
   if (!d || !x || !dz || !dw_packed) return y5_fail(Y5_ERR_BAD_ARG, "wgrad: null pointer");
-  if (d->dtype != Y5_F16) return y5_fail(Y5_ERR_UNSUPPORTED, "wgrad: fp16 activations / gradients only");
+  if (d->dtype == Y5_F32) {
+    const int oh32 = (d->H + 2 * d->PH - d->KH) / d->SH + 1, ow32 = (d->W + 2 * d->PW - d->KW) / d->SW + 1;
+    if (oh32 != d->OH || ow32 != d->OW || d->Kpad < d->KH * d->KW * d->C1 || d->Npad < d->C2) return y5_fail(Y5_ERR_BAD_ARG, "wgrad: inconsistent geometry");
+    const long long total = (long long)d->C2 * d->Kpad;
+    hipLaunchKernelGGL(y5_conv_wgrad_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)x, (const float*)dz, dw_packed, d->B, d->H,
+                       d->W, d->C1, d->ldx, oh32, ow32, d->C2, ld_dz, d->KH, d->KW, d->SH, d->SW, d->PH, d->PW, d->Kpad, total);
+    return y5_check_launch("y5_conv2d_wgrad(f32)");
+  }
+  if (d->dtype != Y5_F16) return y5_fail(Y5_ERR_UNSUPPORTED, "wgrad: fp16 or fp32 activations / gradients only");
   if (d->C1 % 8 || d->ldx % 8 || ld_dz % 8 || d->C2 % 8) return y5_fail(Y5_ERR_BAD_ARG, "wgrad: C1, C2, ldx, ld_dz must be multiples of 8");
   const int oh = (d->H + 2 * d->PH - d->KH) / d->SH + 1, ow = (d->W + 2 * d->PW - d->KW) / d->SW + 1;
   if (oh != d->OH || ow != d->OW) return y5_fail(Y5_ERR_BAD_ARG, "wgrad: OH/OW inconsistent with H/W/k/s/p");

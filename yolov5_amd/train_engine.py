@@ -47,7 +47,13 @@ def _vp(v):
 class TrainEngine:
     """Materialised training plan for one (batch, resolution) on one GPU."""
 
-    def __init__(self, model, x_shape, device, backend=None):
+    def __init__(self, model, x_shape, device, backend=None, dtype=torch.float16):
+        """dtype: torch.float16 = AMP semantics (fp16 activations / gradients, fp32 master weights and accumulators: the production
+        path); torch.float32 = the whole step in fp32 (exact-fp32 MFMA forward / data gradient, plain fp32 weight gradient): the
+        reference-precision mode the end-to-end gradient check against the oracle's autograd runs in."""
+        if dtype not in (torch.float16, torch.float32):
+            raise TypeError("TrainEngine dtype must be float16 or float32")
+        self.dtype, self.dt, self.es = dtype, (_lib.Y5_F16 if dtype == torch.float16 else _lib.Y5_F32), (2 if dtype == torch.float16 else 4)
         self.be = backend if backend is not None else default_backend(device)
         self.lib = self.be.lib
         self.model = model
@@ -56,7 +62,7 @@ class TrainEngine:
         self.spec = _TrainPlanner(model, B, ch, H, W, want_raw=True).run()
         if any(o["op"] in ("copy", "upsample") for o in self.spec.ops):
             raise NotImplementedError("training plan: standalone Concat copy / Upsample ops are not supported")
-        f16 = torch.float16
+        f16 = dtype  # (activation / gradient storage type of this plan)
         self.bufs = [self.be.empty((B, b.H, b.W, b.C), f16) for b in self.spec.bufs]
         self.gbufs = [self.be.empty((B, b.H, b.W, b.C), f16) for b in self.spec.bufs]
         self.params = list(model.parameters())
@@ -111,7 +117,7 @@ class TrainEngine:
     # ---- helpers ---------------------------------------------------------------------------------------------------
     def _ptr(self, t: TRef, grad=False):
         bufs = self.gbufs if grad else self.bufs
-        return self.be.ptr(bufs[t.buf]) + t.c_off * 2
+        return self.be.ptr(bufs[t.buf]) + t.c_off * self.es
 
     def _ld(self, t: TRef):
         return self.spec.bufs[t.buf].C
@@ -136,7 +142,7 @@ class TrainEngine:
         x = op["x"]
         (kh, kw), (sh, sw), (ph, pw) = op["k"], op["s"], op["p"]
         H, W, C1, ldx = x.H, x.W, x.C, self._ld(x)
-        paired = op["view"] == "first" and C1 == 4 and kw % 2 == 0 and sw % 2 == 0 and pw % 2 == 0 and W % 2 == 0
+        paired = self.dtype == torch.float16 and op["view"] == "first" and C1 == 4 and kw % 2 == 0 and sw % 2 == 0 and pw % 2 == 0 and W % 2 == 0
         if paired:
             W, C1, ldx, kw, sw, pw = W // 2, 8, 8, kw // 2, sw // 2, pw // 2
         return dict(H=H, W=W, C1=C1, ldx=ldx, k=(kh, kw), s=(sh, sw), p=(ph, pw), paired=paired)
@@ -150,7 +156,7 @@ class TrainEngine:
         c1v = x.C if op["view"] == "first" else c1           # channels of the NHWC input view (stem: 3 -> 4)
         K = kh * kw * c1v
         st["c1v"], st["K"], st["Kpad"], st["Npad"] = c1v, K, round_up(K, 64), round_up(c2, 32)
-        st["wp"] = be.empty((st["Npad"], st["Kpad"]), torch.float16)
+        st["wp"] = be.empty((st["Npad"], st["Kpad"]), self.dtype)
         st["bp"] = be.empty((st["Npad"],), torch.float32)
         be.zero_(st["bp"])
         st["dw_off"] = self._dw_total  # slot in the packed weight-gradient arena (one memset per backward pass)
@@ -169,7 +175,7 @@ class TrainEngine:
                     K2 = len(th) * len(tw) * st["c2s"]
                     Kp2, Np2 = round_up(K2, 64), round_up(c1, 32)
                     subs.append(dict(rh=rh, rw=rw, nh=nh, nw=nw, th=(C.c_int * len(th))(*th), tw=(C.c_int * len(tw))(*tw), nth=len(th),
-                                     ntw=len(tw), pad=(padh, padw), Kpad=Kp2, Npad=Np2, w=be.empty((Np2, Kp2), torch.float16), cfg={}))
+                                     ntw=len(tw), pad=(padh, padw), Kpad=Kp2, Npad=Np2, w=be.empty((Np2, Kp2), self.dtype), cfg={}))
             st["zb"] = be.empty((round_up(c1, 32),), torch.float32)
             be.zero_(st["zb"])
         st["subs"] = subs
@@ -191,17 +197,21 @@ class TrainEngine:
             if kind == "to_nhwc":
                 d = op["dst"]
                 scale = 1.0 / 255.0 if src_dt == _lib.Y5_U8 else 1.0
-                _lib.check(lib.y5_nchw_to_nhwc(_vp(xptr), src_dt, _vp(self._ptr(d)), _lib.Y5_F16, B, op["C"], d.H, d.W, self._ld(d), scale, stm), lib)
+                _lib.check(lib.y5_nchw_to_nhwc(_vp(xptr), src_dt, _vp(self._ptr(d)), self.dt, B, op["C"], d.H, d.W, self._ld(d), scale, stm), lib)
             elif kind == "conv":
                 self._fwd_conv(op["_st"], stm)
             elif kind == "sppf_pool":
                 b = op["buf"]
-                _lib.check(lib.y5_sppf_pool(_vp(self._ptr(b)), _lib.Y5_F16, B, b.H, b.W, op["C"], self._ld(b), op["k"], stm), lib)
+                _lib.check(lib.y5_sppf_pool(_vp(self._ptr(b)), self.dt, B, b.H, b.W, op["C"], self._ld(b), op["k"], stm), lib)
             elif kind == "decode":
                 lg = op["x"]
-                self.raw[op["level"]] = be.empty((B, op["na"], op["ny"], op["nx"], op["no"]), torch.float16)
-                _lib.check(lib.y5_nhwc_to_raw(_vp(self._ptr(lg)), _vp(be.ptr(self.raw[op["level"]])), B, op["ny"] * op["nx"], op["na"], op["no"],
-                                              self._ld(lg), stm), lib)
+                self.raw[op["level"]] = be.empty((B, op["na"], op["ny"], op["nx"], op["no"]), self.dtype)
+                if self.dtype == torch.float16:
+                    _lib.check(lib.y5_nhwc_to_raw(_vp(self._ptr(lg)), _vp(be.ptr(self.raw[op["level"]])), B, op["ny"] * op["nx"], op["na"], op["no"],
+                                                  self._ld(lg), stm), lib)
+                else:
+                    _lib.check(lib.y5_train_glue_f32(0, _vp(self._ptr(lg)), _vp(be.ptr(self.raw[op["level"]])), B, op["ny"] * op["nx"], op["na"], op["no"],
+                                                     self._ld(lg), 0, 0, stm), lib)
             else:
                 raise NotImplementedError(kind)
         if self._nbt:
@@ -224,7 +234,7 @@ class TrainEngine:
             out_ptr, ldo = be.ptr(st["z"]), c2
         else:
             out_ptr, ldo = self._ptr(y), self._ld(y)
-        d = _lib.ConvDesc(dtype=_lib.Y5_F16, B=B, H=g["H"], W=g["W"], C1=g["C1"], ldx=g["ldx"], OH=y.H, OW=y.W, C2=st["c2s"], ldy=ldo,
+        d = _lib.ConvDesc(dtype=self.dt, B=B, H=g["H"], W=g["W"], C1=g["C1"], ldx=g["ldx"], OH=y.H, OW=y.W, C2=st["c2s"], ldy=ldo,
                           KH=g["k"][0], KW=g["k"][1], SH=g["s"][0], SW=g["s"][1], PH=g["p"][0], PW=g["p"][1], act=0, Kpad=Kpad, Npad=Npad,
                           ldr=0, ld2=0, cfg=st["fcfg"], max_blocks=0)
         ptrs = (_vp(self._ptr(x)), _vp(be.ptr(st["wp"])), _vp(be.ptr(st["bp"])), None, _vp(out_ptr), None)
@@ -236,14 +246,14 @@ class TrainEngine:
             npix = B * y.H * y.W
             st["gamma"], st["beta"] = self._f32(bn.weight), self._f32(bn.bias)
             rm, rv = self._running(bn)
-            _lib.check(lib.y5_bn_silu_fwd(_vp(be.ptr(st["z"])), _lib.Y5_F16, npix, c2, c2, _vp(st["gamma"]), _vp(st["beta"]), float(bn.eps),
+            _lib.check(lib.y5_bn_silu_fwd(_vp(be.ptr(st["z"])), self.dt, npix, c2, c2, _vp(st["gamma"]), _vp(st["beta"]), float(bn.eps),
                                           float(bn.momentum if bn.momentum is not None else 0.1), rm, rv, _vp(be.ptr(st["mean"])),
                                           _vp(be.ptr(st["invstd"])), _vp(self._ptr(res)) if res is not None else None,
                                           self._ld(res) if res is not None else 0, _vp(self._ptr(y)), self._ld(y), _vp(be.ptr(self.ws)),
                                           self.ws_bytes, stm), lib)
             self._running_done(bn)
         if y2 is not None:
-            _lib.check(lib.y5_upsample2x(_vp(self._ptr(y)), _lib.Y5_F16, _vp(self._ptr(y2)), B, y.H, y.W, y.C, self._ld(y), self._ld(y2), stm), lib)
+            _lib.check(lib.y5_upsample2x(_vp(self._ptr(y)), self.dt, _vp(self._ptr(y2)), B, y.H, y.W, y.C, self._ld(y), self._ld(y2), stm), lib)
 
     def _running(self, bn):
         """Device pointers of the BatchNorm running statistics (updated in place by the kernel)."""
@@ -313,13 +323,19 @@ class TrainEngine:
                 lg = op["x"]
                 dph, dpp, _ = be.input(dps[op["level"]])
                 hold.append(dph)
-                _lib.check(lib.y5_raw_to_nhwc(_vp(dpp), _vp(self._ptr(lg, True)), B, op["ny"] * op["nx"], op["na"], op["no"], self._ld(lg), stm), lib)
+                if self.dtype == torch.float16:
+                    _lib.check(lib.y5_raw_to_nhwc(_vp(dpp), _vp(self._ptr(lg, True)), B, op["ny"] * op["nx"], op["na"], op["no"], self._ld(lg), stm), lib)
+                else:
+                    _lib.check(lib.y5_train_glue_f32(1, _vp(dpp), _vp(self._ptr(lg, True)), B, op["ny"] * op["nx"], op["na"], op["no"], self._ld(lg), 0, 0, stm), lib)
                 mark(lg)
             elif kind == "sppf_pool":
                 b = op["buf"]
                 if not is_written(b):
                     raise RuntimeError("training plan: SPPF gradient buffer not produced")
-                _lib.check(lib.y5_sppf_pool_bwd(_vp(self._ptr(b)), _vp(self._ptr(b, True)), B, b.H, b.W, op["C"], self._ld(b), self._ld(b), op["k"], stm), lib)
+                if self.dtype == torch.float16:
+                    _lib.check(lib.y5_sppf_pool_bwd(_vp(self._ptr(b)), _vp(self._ptr(b, True)), B, b.H, b.W, op["C"], self._ld(b), self._ld(b), op["k"], stm), lib)
+                else:
+                    _lib.check(lib.y5_train_glue_f32(4, _vp(self._ptr(b)), _vp(self._ptr(b, True)), B, b.H, b.W, op["C"], self._ld(b), self._ld(b), op["k"], stm), lib)
             elif kind == "conv":
                 self._bwd_conv(op["_st"], stm, is_written, mark, grads, hold)
             elif kind == "to_nhwc":
@@ -367,6 +383,7 @@ class TrainEngine:
                     j.th[q] = v
                 for q, v in enumerate(r[15]):
                     j.tw[q] = v
+                j.reserved = 1 if (self.dtype == torch.float32 and j.kind != 2) else 0  # fp32 plan: packed filters are fp32
             tab = be.from_torch(torch.from_numpy(np.frombuffer(arr, dtype=np.uint8).copy()))
             ent = (wkey, tab, len(rows), max(r[2] for r in rows))
             cache[kind] = ent
@@ -380,17 +397,25 @@ class TrainEngine:
         c2, c1, kh, kw = cv.weight.shape
         c2s = st["c2s"]
         if y2 is not None:
-            _lib.check(lib.y5_upsample2x_bwd(_vp(self._ptr(y2, True)), _vp(self._ptr(y, True)), B, y.H, y.W, y.C, self._ld(y2), self._ld(y),
-                                             1 if is_written(y) else 0, stm), lib)
+            if self.dtype == torch.float16:
+                _lib.check(lib.y5_upsample2x_bwd(_vp(self._ptr(y2, True)), _vp(self._ptr(y, True)), B, y.H, y.W, y.C, self._ld(y2), self._ld(y),
+                                                 1 if is_written(y) else 0, stm), lib)
+            else:
+                _lib.check(lib.y5_train_glue_f32(2, _vp(self._ptr(y2, True)), _vp(self._ptr(y, True)), B, y.H, y.W, y.C, self._ld(y2), self._ld(y),
+                                                 1 if is_written(y) else 0, stm), lib)
             mark(y)
         if not is_written(y):
             raise RuntimeError(f"training plan: gradient of {op['name']} output was never produced")
         if st["has_bn"]:
             if res is not None:
-                _lib.check(lib.y5_add_slice(_vp(self._ptr(y, True)), _vp(self._ptr(res, True)), npix, y.C, self._ld(y), self._ld(res),
-                                            1 if is_written(res) else 0, stm), lib)
+                if self.dtype == torch.float16:
+                    _lib.check(lib.y5_add_slice(_vp(self._ptr(y, True)), _vp(self._ptr(res, True)), npix, y.C, self._ld(y), self._ld(res),
+                                                1 if is_written(res) else 0, stm), lib)
+                else:
+                    _lib.check(lib.y5_train_glue_f32(3, _vp(self._ptr(y, True)), _vp(self._ptr(res, True)), npix, 1, 1, y.C, self._ld(y), self._ld(res),
+                                                     1 if is_written(res) else 0, stm), lib)
                 mark(res)
-            _lib.check(lib.y5_bn_silu_bwd(_vp(self._ptr(y, True)), self._ld(y), _vp(be.ptr(st["z"])), c2, _lib.Y5_F16, npix, c2,
+            _lib.check(lib.y5_bn_silu_bwd(_vp(self._ptr(y, True)), self._ld(y), _vp(be.ptr(st["z"])), c2, self.dt, npix, c2,
                                           _vp(st["gamma"]), _vp(st["beta"]), _vp(be.ptr(st["mean"])), _vp(be.ptr(st["invstd"])),
                                           _vp(be.ptr(self.dz)), c2, _vp(self._gptr(m.bn.weight)), _vp(self._gptr(m.bn.bias)),
                                           _vp(be.ptr(self.ws)), self.ws_bytes, stm), lib)
@@ -400,13 +425,13 @@ class TrainEngine:
         else:
             dz_ptr, ld_dz = self._ptr(y, True), self._ld(y)
             dbias = self._gptr(cv.bias) if cv.bias is not None else be.ptr(st["dbias"])  # (arena slots are 64-float padded: c2s fits)
-            _lib.check(lib.y5_channel_sum(_vp(dz_ptr), _lib.Y5_F16, npix, c2s, ld_dz, _vp(dbias), _vp(be.ptr(self.ws)), self.ws_bytes, stm), lib)
+            _lib.check(lib.y5_channel_sum(_vp(dz_ptr), self.dt, npix, c2s, ld_dz, _vp(dbias), _vp(be.ptr(self.ws)), self.ws_bytes, stm), lib)
             if cv.bias is not None:
                 grads[self._pidx[id(cv.bias)]] = True
         # weight gradient: packed fp32 accumulator -> parameter layout
         g = self._geom(st)
         Kpad, Npad = st["Kpad"], st["Npad"]
-        d = _lib.ConvDesc(dtype=_lib.Y5_F16, B=B, H=g["H"], W=g["W"], C1=g["C1"], ldx=g["ldx"], OH=y.H, OW=y.W, C2=c2s, ldy=ld_dz,
+        d = _lib.ConvDesc(dtype=self.dt, B=B, H=g["H"], W=g["W"], C1=g["C1"], ldx=g["ldx"], OH=y.H, OW=y.W, C2=c2s, ldy=ld_dz,
                           KH=g["k"][0], KW=g["k"][1], SH=g["s"][0], SW=g["s"][1], PH=g["p"][0], PW=g["p"][1], act=0, Kpad=Kpad, Npad=Npad,
                           cfg=-1, max_blocks=0)
         _lib.check(lib.y5_conv2d_wgrad(C.byref(d), _vp(self._ptr(x)), _vp(dz_ptr), ld_dz, _vp(be.ptr(self.dwflat) + st["dw_off"] * 4), stm), lib)
@@ -422,7 +447,7 @@ class TrainEngine:
         acc = is_written(x)
         dense = tuple(op["s"]) == (1, 1)
         for sub in st["subs"]:
-            dd = _lib.ConvDesc(dtype=_lib.Y5_F16, B=B, H=y.H, W=y.W, C1=c2s, ldx=ld_dz, OH=sub["nh"], OW=sub["nw"], C2=x.C, ldy=self._ld(x),
+            dd = _lib.ConvDesc(dtype=self.dt, B=B, H=y.H, W=y.W, C1=c2s, ldx=ld_dz, OH=sub["nh"], OW=sub["nw"], C2=x.C, ldy=self._ld(x),
                                KH=sub["nth"], KW=sub["ntw"], SH=1, SW=1, PH=sub["pad"][0], PW=sub["pad"][1], act=0, Kpad=sub["Kpad"],
                                Npad=sub["Npad"], ldr=self._ld(x) if acc else 0, ld2=0, cfg=sub["cfg"].get(acc, -1), max_blocks=0,
                                out_mul_h=0 if dense else op["s"][0], out_mul_w=0 if dense else op["s"][1], out_off_h=sub["rh"],
@@ -472,12 +497,14 @@ class _TrainFn(torch.autograd.Function):
 
 def train_forward(model, x):
     """Train-mode `BaseModel._forward_once` (models/yolo.py:160-170): list of (bs, na, ny, nx, no) fp16 tensors."""
-    key = (tuple(x.shape), str(x.device))
+    # fp32 images -> the fp32 plan (reference-precision mode: train.py without AMP); fp16 / uint8 images -> the fp16 (AMP) plan
+    dtype = torch.float32 if x.dtype == torch.float32 else torch.float16
+    key = (tuple(x.shape), str(x.device), dtype)
     cache = model.__dict__.setdefault("_train_engines", {})
     eng = cache.get(key)
     if eng is None:
         cache.clear()
-        eng = TrainEngine(model, tuple(x.shape), x.device)
+        eng = TrainEngine(model, tuple(x.shape), x.device, dtype=dtype)
         cache[key] = eng
     eng.grad_sink = model.__dict__.get("_ddp_sink")
     return list(_TrainFn.apply(eng, x, *eng.params))

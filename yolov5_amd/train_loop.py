@@ -128,7 +128,10 @@ def train(model, loader, hyp=None, epochs=1, device=None, batch_size=None, cos_l
                     g["lr"] = float(np.interp(ni, xi, [hyp["warmup_bias_lr"] if j == 0 else 0.0, g["initial_lr"] * lf(epoch)]))
                     if "momentum" in g:
                         g["momentum"] = float(np.interp(ni, xi, [hyp["warmup_momentum"], hyp["momentum"]]))
-            x = imgs if imgs.dtype == torch.uint8 else (imgs.half() if amp else imgs.float())
+            if amp:   # fp16 plan: uint8 goes in as it is (the input kernel divides by 255), floats as fp16
+                x = imgs if imgs.dtype == torch.uint8 else imgs.half()
+            else:     # fp32 plan (train.py without AMP): float32 images select it (train_engine.train_forward)
+                x = imgs.float() / 255 if imgs.dtype == torch.uint8 else imgs.float()
             pred = ddp(x)                                                           # :399
             loss, loss_items = compute_loss(pred, targets.to(device))               # :400
             if rank != -1:
