@@ -229,7 +229,9 @@ def gpu_state_probe(fn, dev, seconds=1.6):
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     th.join()
-    return {"forward_ms_sustained": round(dt / max(n, 1) * 1e3, 4), "samples": samples}
+    props = torch.cuda.get_device_properties(dev)
+    return {"forward_ms_sustained": round(dt / max(n, 1) * 1e3, 4), "samples": samples, "device": props.name, "compute_units": props.multi_processor_count,
+            "hbm_gb": round(props.total_memory / 2 ** 30, 1)}
 
 
 TRAIN_GFLOP_PER_IMG = {"yolov5s": 49.3}  # forward + data gradient + weight gradient = 3 x 16.43 GFLOP at 640^2
