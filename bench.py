@@ -532,7 +532,7 @@ def main():
             # arithmetic intensity of the conv stack at this config = algorithmic flops / algorithmic bytes (144 flop/B for
             # yolov5s bs=64 640^2) is below the ridge (2500 TF / 8 TB/s = 312 flop/B): the stack as a whole is HBM-bound;
             # the MFMA view of the same launches is kept beside it
-            "roofline": {"bound": "hbm", "kernel": "y5_conv_{igemm,pw,k3,stem}_kernel (all conv launches of one forward)",
+            "roofline": {"bound": "hbm", "kernel": "y5_conv_{igemm,pw,k3,stem,bneck}_kernel (all conv launches of one forward)",
                          "achieved": round(achieved_bw, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_bw / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(a, conv_by * parts),
                          "timing": "in situ: HIP event between consecutive ops of one eager forward on the launch stream, median of 9 passes, "

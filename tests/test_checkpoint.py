@@ -160,6 +160,17 @@ def test_save_checkpoint_round_trip_and_resume(tmp_path):
     for (k, a), (_, b) in zip(ema.ema.state_dict().items(), ema2.ema.state_dict().items()):
         if a.dtype.is_floating_point:
             assert float((a - b).abs().max()) <= 1e-3 * (1 + float(a.abs().max())), k   # through fp16
+    # strip_optimizer (general.py:770-787): EMA becomes the model, bookkeeping cleared, fp16, no grad; still reference class paths
+    from yolov5_amd.checkpoint import strip_optimizer
+
+    best = tmp_path / "best.pt"
+    mb_size = strip_optimizer(path, best)
+    sk = load_checkpoint(best)
+    assert mb_size > 0 and sk["epoch"] == -1 and all(sk[k] is None for k in ("optimizer", "best_fitness", "ema", "updates"))
+    assert all(p.dtype == torch.float16 and not p.requires_grad for p in sk["model"].parameters())
+    assert b"yolov5_amd" not in open(best, "rb").read()
+    for (k, a), (_, b) in zip(ck["ema"].state_dict().items(), sk["model"].state_dict().items()):
+        assert torch.equal(a, b), k
 
 
 @pytest.mark.skipif(not ref_shim.available(), reason="needs the reference tree (build container only)")

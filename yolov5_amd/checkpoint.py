@@ -93,3 +93,22 @@ def smart_resume(ckpt, optimizer, ema=None, weights="yolov5s.pt", epochs=300, re
     if epochs < start_epoch:
         epochs += ckpt["epoch"]
     return best_fitness, start_epoch, epochs
+
+
+def strip_optimizer(f="best.pt", s="", reference_paths=True):
+    """utils/general.py:770-787: finalise a training checkpoint -- the EMA becomes the model, the optimizer / EMA / bookkeeping entries
+    are cleared, epoch = -1, weights fp16 with requires_grad off; written to `s` or back over `f`.  Returns the file size in MB."""
+    import os
+
+    x = load_checkpoint(f)
+    if x.get("ema"):
+        x["model"] = x["ema"]
+    for k in ("optimizer", "best_fitness", "ema", "updates"):
+        x[k] = None
+    x["epoch"] = -1
+    x["model"].half()
+    for p in x["model"].parameters():
+        p.requires_grad = False
+    with (reference_class_paths() if reference_paths else contextlib.nullcontext()):
+        torch.save(x, str(s or f))
+    return os.path.getsize(s or f) / 1e6
