@@ -45,6 +45,24 @@ CASES = [
     (1, 24, 16, 32, 64, 3, 2, 1, 1, False, False, 34, 1, "f16"),
     (3, 8, 8, 64, 64, 3, 1, 1, 1, True, False, 32, 1, "f16"),
     (1, 4, 24, 64, 56, 3, 1, 1, 1, False, False, 32, 2, "f16"),
+    # halo-resident 3x3 kernel (conv_h3.h): one / several channel chunks, spatial tiles that do not divide the image, N tiles with a
+    # padded tail, residual in place, several tiles per workgroup, 4- and 8-wave layouts
+    (2, 9, 8, 32, 64, 3, 1, 1, 1, True, False, 61, 0, "f16"),
+    (1, 12, 44, 64, 160, 3, 1, 1, 1, False, False, 61, 2, "f16"),   # 2 row tiles x 2 N tiles (second one 32 real channels) on 2 workgroups
+    (2, 7, 50, 64, 64, 3, 1, 1, 0, True, False, 62, 1, "f16"),      # one workgroup walks every tile
+    (3, 20, 20, 96, 96, 3, 1, 1, 1, True, False, 63, 2, "f16"),     # whole 20x20 images, 3 chunks
+    (1, 13, 40, 64, 128, 3, 1, 1, 1, False, False, 64, 2, "f16"),
+    (2, 22, 20, 32, 48, 3, 1, 1, 1, False, False, 65, 0, "f16"),
+    (1, 10, 24, 64, 64, 3, 1, 1, 1, True, False, 66, 1, "f16"),
+    (1, 12, 44, 64, 160, 3, 1, 1, 1, True, False, 67, 2, "f16"),
+    (2, 20, 20, 64, 128, 3, 1, 1, 1, False, False, 68, 0, "f16"),
+    (1, 13, 40, 96, 136, 3, 1, 1, 0, False, False, 69, 1, "f16"),
+    (2, 11, 23, 64, 96, 3, 1, 1, 1, True, False, 70, 2, "f16"),
+    (2, 20, 20, 64, 128, 3, 1, 1, 1, True, False, 71, 1, "f16"),
+    (1, 25, 21, 32, 160, 3, 1, 1, 1, False, False, 72, 2, "f16"),
+    (2, 13, 40, 96, 128, 3, 1, 1, 1, True, False, 73, 2, "f16"),     # 4-stage ring: 3 chunks, stage index wraps inside and across chunks
+    (1, 20, 20, 160, 64, 3, 1, 1, 1, False, False, 74, 1, "f16"),
+    (2, 9, 33, 32, 144, 3, 1, 1, 0, True, False, 75, 0, "f16"),
 ] + [
     # every fp16 tile configuration on one shape with M, N tails and K = 9*64 (uniform) / 9*48 (table for BK64)
     (2, 9, 9, c1, 160, 3, 1, 1, 1, True, False, cfg, 2, "f16") for cfg in list(range(14)) + list(range(22, 30)) + list(range(35, 56)) for c1 in (64, 48)

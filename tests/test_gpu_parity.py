@@ -87,6 +87,26 @@ CONV_CASES = [
     (4, 80, 80, 32, 64, 3, 2, 1, 1, False, False, 34, 0, "f16"),
     (8, 40, 40, 64, 64, 3, 1, 1, 1, True, False, 32, 8, "f16"),
     (2, 20, 24, 64, 56, 3, 1, 1, 1, False, False, 32, 0, "f16"),
+    # halo-resident 3x3 kernel (conv_h3.h, cfg 61..70): several chunks per tile and several tiles per workgroup so that the counted-vmcnt
+    # filter ring, the next-chunk halo prefetch and the cross-tile prologue all reach steady state on the real memory system
+    (8, 80, 80, 64, 64, 3, 1, 1, 1, True, False, 62, 16, "f16"),
+    (8, 40, 40, 128, 128, 3, 1, 1, 1, True, False, 61, 8, "f16"),
+    (8, 40, 40, 128, 120, 3, 1, 1, 1, False, False, 63, 0, "f16"),
+    (8, 20, 20, 256, 256, 3, 1, 1, 1, True, False, 64, 8, "f16"),
+    (4, 42, 38, 96, 96, 3, 1, 1, 0, False, False, 65, 8, "f16"),
+    (8, 80, 80, 64, 64, 3, 1, 1, 1, False, False, 66, 0, "f16"),
+    (8, 40, 40, 128, 128, 3, 1, 1, 1, True, False, 67, 8, "f16"),
+    (8, 40, 40, 128, 128, 3, 1, 1, 1, False, False, 68, 0, "f16"),
+    (8, 20, 20, 256, 256, 3, 1, 1, 1, True, False, 69, 8, "f16"),
+    (8, 80, 80, 64, 64, 3, 1, 1, 1, True, False, 70, 24, "f16"),
+    (16, 23, 21, 160, 160, 3, 1, 1, 1, True, False, 67, 0, "f16"),
+    (8, 40, 40, 128, 128, 3, 1, 1, 1, True, False, 71, 8, "f16"),
+    (8, 40, 40, 128, 128, 3, 1, 1, 1, False, False, 72, 0, "f16"),
+    (8, 20, 20, 256, 256, 3, 1, 1, 1, True, False, 70, 0, "f16"),
+    (8, 40, 40, 128, 128, 3, 1, 1, 1, True, False, 73, 8, "f16"),
+    (8, 40, 40, 128, 128, 3, 1, 1, 1, False, False, 73, 0, "f16"),
+    (8, 80, 80, 64, 64, 3, 1, 1, 1, True, False, 74, 0, "f16"),
+    (8, 20, 20, 256, 256, 3, 1, 1, 1, True, False, 75, 16, "f16"),
 ]
 
 

@@ -330,6 +330,12 @@ int launch_k3_by_cfg(const Y5ConvParams& p, int idx, int mb, hipStream_t s) {
   return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown 3x3 streaming config");
 }
 
+}  // namespace
+int y5_launch_h3_by_cfg(const Y5ConvParams& p, int idx, int mb, hipStream_t s);
+void y5_h3_cfg_info(int idx, int* bm, int* bn);
+namespace {
+constexpr int kH3_0 = 61;
+
 int default_cfg(const y5_conv_desc* d) {
   const int n = d->Npad;
   if (d->dtype == Y5_F32) return n <= 32 ? 0 : n <= 64 ? 1 : 2;
@@ -358,6 +364,14 @@ extern "C" int y5_conv_set_sk_workspace(void* ws, size_t bytes, void* stream_) {
 
 extern "C" int y5_conv_cfg_info(int cfg, int* bm, int* bn, int* bk_bytes) {
   if (cfg < 0 || cfg >= Y5_CONV_NUM_CFGS) return y5_fail(Y5_ERR_BAD_ARG, "conv_cfg_info: bad id");
+  if (cfg >= kH3_0) {
+    int m = 0, n = 0;
+    y5_h3_cfg_info(cfg - kH3_0, &m, &n);
+    if (bm) *bm = m;
+    if (bn) *bn = n;
+    if (bk_bytes) *bk_bytes = 64;
+    return Y5_OK;
+  }
   if (cfg >= kSk0) {
     const TileCfg& c = kSkCfgs[cfg - kSk0];
     if (bm) *bm = c.wm * c.tm * 32;
@@ -409,12 +423,13 @@ extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w
   const int epp = 16 / es;
   int cfg = d->cfg < 0 ? default_cfg(d) : d->cfg;
   if (cfg >= Y5_CONV_NUM_CFGS) return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown tile config");
-  const bool sk = cfg >= kSk0;
-  const bool pw = (cfg >= kNumIgemm && cfg < kRing0) || (cfg >= kPw2_0 && !sk);
+  const bool h3 = cfg >= kH3_0;
+  const bool sk = cfg >= kSk0 && !h3;
+  const bool pw = (cfg >= kNumIgemm && cfg < kRing0) || (cfg >= kPw2_0 && !sk && !h3);
   const int pwi = cfg >= kPw2_0 ? 8 + cfg - kPw2_0 : cfg - kNumIgemm;
   const bool big = cfg >= kBig0 && cfg < kPw2_0;
   const bool k3 = cfg >= kK3_0 && cfg < kBig0;
-  const int bk = (pw || k3) ? 8 : (sk ? kSkCfgs[cfg - kSk0].rb : big ? kBigCfgs[cfg - kBig0].rb : kCfgs[cfg >= kRing0 ? kRingBase[cfg - kRing0] : cfg].rb) / es;
+  const int bk = (pw || k3 || h3) ? 8 : (sk ? kSkCfgs[cfg - kSk0].rb : big ? kBigCfgs[cfg - kBig0].rb : kCfgs[cfg >= kRing0 ? kRingBase[cfg - kRing0] : cfg].rb) / es;
   if (cfg >= kRing0 && d->dtype != Y5_F16) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: ring configurations are fp16 only");
   if (d->C1 % epp || d->ldx % epp) return y5_fail(Y5_ERR_BAD_ARG, "conv: C1 and ldx must be multiples of 16 bytes");
   if (d->C2 % epp || (y && d->ldy % epp) || (residual && d->ldr % epp) || (y_up2 && d->ld2 % epp))
@@ -447,14 +462,20 @@ extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w
     if (d->split_n < 0 || d->split_n % epp || d->split_n >= d->C2 || !y || !y_up2 || d->ld2 % epp || d->ld2 < d->C2 - d->split_n || d->ldy < d->split_n ||
         placed || residual)
       return y5_fail(Y5_ERR_BAD_ARG, "conv: bad split store (split_n multiple of 16 bytes inside C2, both destinations, no residual / placement)");
-    if (k3) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: split store needs a pointwise / implicit-GEMM configuration");
+    if (k3 || h3) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: split store needs a pointwise / implicit-GEMM configuration");
   }
   p.M = d->B * oh * ow;
   p.o_mul_h = d->out_mul_h; p.o_mul_w = d->out_mul_w; p.o_off_h = d->out_off_h; p.o_off_w = d->out_off_w; p.o_H = d->out_H; p.o_W = d->out_W;
-  if (placed && (pw || k3)) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: output placement needs a general implicit-GEMM configuration");
+  if (placed && (pw || k3 || h3)) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: output placement needs a general implicit-GEMM configuration");
   p.x_bytes = (unsigned)((((long long)d->B * d->H * d->W - 1) * d->ldx + d->C1) * es);
   p.w_bytes = (unsigned)((long long)d->Npad * d->Kpad * es);
 
+  if (h3) {
+    if (d->dtype != Y5_F16 || d->KH != 3 || d->KW != 3 || d->SH != 1 || d->SW != 1 || d->PH != 1 || d->PW != 1 || !y || y_up2 || d->C1 % 32 ||
+        d->Kpad < 9 * d->C1)
+      return y5_fail(Y5_ERR_UNSUPPORTED, "conv: halo 3x3 configuration needs a 3x3 s1 p1 fp16 layer with C1 % 32 == 0 and a single destination");
+    return y5_launch_h3_by_cfg(p, cfg - kH3_0, d->max_blocks, stream);
+  }
   if (k3) {
     const K3Cfg& c = kK3Cfgs[cfg - kK3_0];
     if (d->dtype != Y5_F16 || d->KH != 3 || d->KW != 3 || d->SH != c.sh || d->SW != c.sh || d->PH != 1 || d->PW != 1 || !y || y_up2 ||

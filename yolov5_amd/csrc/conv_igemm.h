@@ -50,6 +50,7 @@ struct Y5ConvParams {
   int tilesM, tilesN, nk;
   float* sk_ws;        // stream-K (SK kernels): one fp32 partial-tile slab per workgroup, [G][WM*WN*TM*TN*16*64]
   unsigned* sk_flags;  // [G]: 1 = workgroup g's slab holds the partial sums of the tile its unit range starts in; reset to 0 by the reader
+  int h3_th, h3_tw, h3_tiles_h, h3_tiles_w;  // conv_h3.h: spatial tile (output rows x columns) and tiles per image
   int split_n;  // > 0: output channels >= split_n go to y2 (pixel stride ld2, channel n - split_n) instead of y -- C3's cv1 / cv2 halves
                 // of one GEMM landing in two different buffers (y2 is then NOT the upsampled replica)
 };

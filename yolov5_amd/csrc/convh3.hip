@@ -1,0 +1,129 @@
+// Host-side launcher of the halo-resident 3x3 convolution (conv_h3.h); reached through y5_conv2d_fwd (conv.hip), configuration ids 61..
+#include <hip/hip_runtime.h>
+
+#include "../../include/yolov5_hip.h"
+#include "conv_h3.h"
+#include "y5_host.h"
+
+namespace {
+int g_num_cu = 0;
+
+// ---- halo-resident 3x3 configurations (conv_h3.h): ids kH3_0 + index ------------------------------------------------------------
+struct H3Cfg { int wm, wn, tm, tn, hpmax; };
+constexpr int kNumH3 = 15;
+constexpr H3Cfg kH3Cfgs[kNumH3] = {
+    {2, 2, 5, 2, 496},  // 61: 320 pixels x 128 channels (8 x 40, 4 x 80, 16 x 20 output tiles)
+    {2, 2, 5, 1, 496},  // 62: 320 x  64
+    {2, 2, 7, 2, 512},  // 63: 448 x 128 (10 x 40: four tiles per 40 x 40 image; 20 x 20 whole images)
+    {2, 2, 4, 2, 400},  // 64: 256 x 128 (5 x 40, 10 x 20)
+    {2, 2, 7, 1, 512},  // 65: 448 x  64
+    {2, 2, 4, 1, 400},  // 66: 256 x  64
+    // eight waves (two per SIMD: one wave's LDS latency and DMA issue hide behind the other's MFMAs)
+    {2, 4, 5, 1, 496},  // 67: 320 x 128
+    {2, 4, 7, 1, 512},  // 68: 448 x 128
+    {2, 4, 4, 1, 400},  // 69: 256 x 128
+    {4, 2, 2, 2, 400},  // 70: 256 x 128, waves 4 x 2
+    // 128 x 128 (four waves) / 128 x 64 (eight waves) register tiles per wave: 2 MFMAs per fragment read
+    {4, 1, 4, 4, 512},  // 71: 512 x 128
+    {4, 2, 4, 2, 512},  // 72: 512 x 128, eight waves
+    // 4-stage filter ring: two workgroups per CU (independent barriers: one's LDS-DMA issue and epilogue overlap the other's MFMAs)
+    {2, 2, 4, 2, 320},  // 73: 256 x 128 (5 x 40, 10 x 20)
+    {2, 2, 4, 1, 320},  // 74: 256 x  64
+    {2, 2, 3, 2, 320},  // 75: 192 x 128
+};
+
+// spatial tile for an H x W output: TW = ceil(W / d), TH as tall as the pixel budget and the LDS halo allow, then evened out over the
+// image height; the candidate that needs the fewest rounds of `slots` concurrent workgroups wins, ties go to the smaller staged halo
+bool h3_pick_tile(int B, int H, int W, int BM, int hpmax, long long tiles_n, long long slots, int* th, int* tw) {
+  long long best = -1;
+  for (int d = 1; d <= 16 && d <= W; ++d) {
+    const int TW = (W + d - 1) / d;
+    if (TW > BM || TW + 2 > 255) continue;
+    int thm = BM / TW < H ? BM / TW : H;
+    while (thm >= 1 && (thm + 2) * (TW + 2) > hpmax) --thm;
+    if (thm < 1) continue;
+    if (thm + 2 > 255) thm = 253;
+    const int nth = (H + thm - 1) / thm;
+    const int TH = (H + nth - 1) / nth;
+    const int ntw = (W + TW - 1) / TW;
+    const long long tiles = (long long)B * nth * ntw * tiles_n;
+    const long long rounds = (tiles + slots - 1) / slots;
+    const long long cost = rounds * (1LL << 32) + (long long)(TH + 2) * (TW + 2) * nth * ntw;
+    if (best < 0 || cost < best) { best = cost; *th = TH; *tw = TW; }
+  }
+  return best >= 0;
+}
+
+template <int WM, int WN, int TM, int TN, int HPMAX, int NSW = 9>
+int launch_h3(const Y5ConvParams& p0, int max_blocks, hipStream_t stream) {
+  using Gm = Y5H3Geom<WM, WN, TM, TN, HPMAX, NSW>;
+  static_assert(Gm::LDS <= 160 * 1024, "halo configuration exceeds 160 KiB of LDS");
+  auto kern = y5_conv_h3_kernel<WM, WN, TM, TN, HPMAX, NSW>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  Y5ConvParams p = p0;
+  p.tilesN = (p.Npad + Gm::BN - 1) / Gm::BN;
+  long long G = max_blocks;
+  if (G <= 0) {
+    if (!g_num_cu) {
+      int dev = 0, n = 0;
+      hipGetDevice(&dev);
+      hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+      g_num_cu = n > 0 ? n : 256;
+    }
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), Gm::NW * 64, Gm::LDS) != hipSuccess || occ < 1) occ = 1;
+    G = (long long)g_num_cu * occ;
+  }
+  int th = 0, tw = 0;
+  if (!h3_pick_tile(p.B, p.OH, p.OW, Gm::BM, HPMAX, p.tilesN, G, &th, &tw))
+    return y5_fail(Y5_ERR_UNSUPPORTED, "conv: no spatial tile of this halo configuration fits the layer");
+  p.h3_th = th; p.h3_tw = tw;
+  p.h3_tiles_h = (p.OH + th - 1) / th;
+  p.h3_tiles_w = (p.OW + tw - 1) / tw;
+  const long long ntiles = (long long)p.B * p.h3_tiles_h * p.h3_tiles_w * p.tilesN;
+  if (ntiles <= 0 || ntiles > 0x7fffffffLL) return y5_fail(Y5_ERR_BAD_ARG, "conv: grid out of range");
+  if (G > ntiles) G = ntiles;
+  if (G >= 8) G &= ~7LL;
+  hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(Gm::NW * 64), Gm::LDS, stream, p);
+  return y5_check_launch("y5_conv2d_fwd(h3)");
+}
+
+}  // namespace
+
+void y5_h3_cfg_info(int idx, int* bm, int* bn) {
+  const H3Cfg& c = kH3Cfgs[idx < 0 || idx >= kNumH3 ? 0 : idx];
+  *bm = c.wm * c.tm * 32;
+  *bn = c.wn * c.tn * 32;
+}
+
+int y5_launch_h3_by_cfg(const Y5ConvParams& p, int idx, int mb, hipStream_t s) {
+  switch (idx) {
+    case 0: return launch_h3<2, 2, 5, 2, 496>(p, mb, s);
+    case 1: return launch_h3<2, 2, 5, 1, 496>(p, mb, s);
+    case 2: return launch_h3<2, 2, 7, 2, 512>(p, mb, s);
+    case 3: return launch_h3<2, 2, 4, 2, 400>(p, mb, s);
+    case 4: return launch_h3<2, 2, 7, 1, 512>(p, mb, s);
+    case 5: return launch_h3<2, 2, 4, 1, 400>(p, mb, s);
+    case 6: return launch_h3<2, 4, 5, 1, 496>(p, mb, s);
+    case 7: return launch_h3<2, 4, 7, 1, 512>(p, mb, s);
+    case 8: return launch_h3<2, 4, 4, 1, 400>(p, mb, s);
+    case 9: return launch_h3<4, 2, 2, 2, 400>(p, mb, s);
+    case 10: return launch_h3<4, 1, 4, 4, 512>(p, mb, s);
+    case 11: return launch_h3<4, 2, 4, 2, 512>(p, mb, s);
+    case 12: return launch_h3<2, 2, 4, 2, 320, 4>(p, mb, s);
+    case 13: return launch_h3<2, 2, 4, 1, 320, 4>(p, mb, s);
+    case 14: return launch_h3<2, 2, 3, 2, 320, 4>(p, mb, s);
+  }
+  return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown halo 3x3 config");
+}
+
+#ifdef Y5_H3_TIMING
+extern "C" int y5_h3_dbg_read(unsigned long long* dbg, unsigned long long* blocks) {  // kernel-experiment builds only (not part of the ABI)
+  if (hipMemcpyFromSymbol(dbg, HIP_SYMBOL(y5_h3_dbg), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
+  return hipMemcpyFromSymbol(blocks, HIP_SYMBOL(y5_h3_blocks), sizeof(unsigned long long) * 4096) == hipSuccess ? 0 : -1;
+}
+#endif
