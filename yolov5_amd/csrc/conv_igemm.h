@@ -434,24 +434,39 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
     return;
 #endif
     if constexpr (sizeof(T) == 2) {
+      // Software-pipelined over the k-steps of the chunk: the fragments of k-step ks+1 are fetched from LDS BEFORE the MFMAs of k-step ks
+      // are issued (second register set), and the next chunk's LDS-DMA pieces are issued AFTER them -- the matrix cores work through the
+      // LDS round trip and through the 100+ cycles an LDS-DMA instruction holds its wave at issue.  (Left to the compiler the loop was
+      // read -> DMA -> wait -> 4 MFMAs per k-step with one register set: the LDS-DMA builtins are LDS writes it will not move reads across.)
       constexpr int KS = RB / 32, LPK = (LPC + KS - 1) / KS;
-      y5_static_for<0, KS>([&](auto ksc) {
-        constexpr int ks = decltype(ksc)::value;
+      half8_t af[2][TM], wf[2][TN];
+      auto rd = [&](auto ksc, auto bc) {
+        constexpr int ks = decltype(ksc)::value, b = decltype(bc)::value;
         const int so = ((ks * 2 + g) ^ fsw) * 16;
-        half8_t af[TM], wf[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const half8_t*>(lds + a_rd[i] + so);
+        for (int i = 0; i < TM; ++i) af[b][i] = *reinterpret_cast<const half8_t*>(lds + a_rd[i] + so);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const half8_t*>(lds + w_rd[j] + so);
-        if (with_loads) {
-          constexpr int Q0 = ks * LPK < LPC ? ks * LPK : LPC, Q1 = (ks + 1) * LPK < LPC ? (ks + 1) * LPK : LPC;
-          y5_static_for<Q0, Q1>([&](auto qc) { stage_load(qc); });
-        }
+        for (int j = 0; j < TN; ++j) wf[b][j] = *reinterpret_cast<const half8_t*>(lds + w_rd[j] + so);
+      };
+      rd(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+      y5_static_for<0, KS>([&](auto ksc) {
+        constexpr int ks = decltype(ksc)::value, b = ks & 1;
+        if constexpr (ks + 1 < KS) rd(std::integral_constant<int, ks + 1>{}, std::integral_constant<int, b ^ 1>{});
+#ifndef Y5_EMU
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[b][j], af[b][i], acc[i][j], 0, 0, 0);
+#ifndef Y5_EMU
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        if (with_loads) {
+          constexpr int Q0 = ks * LPK < LPC ? ks * LPK : LPC, Q1 = (ks + 1) * LPK < LPC ? (ks + 1) * LPK : LPC;
+          y5_static_for<Q0, Q1>([&](auto qc) { stage_load(qc); });
+        }
       });
     } else {
       if (with_loads) y5_static_for<0, LPC>([&](auto qc) { stage_load(qc); });
