@@ -63,6 +63,8 @@ CASES = [
     (2, 13, 40, 96, 128, 3, 1, 1, 1, True, False, 73, 2, "f16"),     # 4-stage ring: 3 chunks, stage index wraps inside and across chunks
     (1, 20, 20, 160, 64, 3, 1, 1, 1, False, False, 74, 1, "f16"),
     (2, 9, 33, 32, 144, 3, 1, 1, 0, True, False, 75, 0, "f16"),
+    (2, 13, 40, 96, 128, 3, 1, 1, 1, True, False, 76, 2, "f16"),
+    (1, 10, 40, 64, 48, 3, 1, 1, 1, False, False, 77, 1, "f16"),
 ] + [
     # every fp16 tile configuration on one shape with M, N tails and K = 9*64 (uniform) / 9*48 (table for BK64)
     (2, 9, 9, c1, 160, 3, 1, 1, 1, True, False, cfg, 2, "f16") for cfg in list(range(14)) + list(range(22, 30)) + list(range(35, 56)) for c1 in (64, 48)

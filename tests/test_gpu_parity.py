@@ -107,6 +107,8 @@ CONV_CASES = [
     (8, 40, 40, 128, 128, 3, 1, 1, 1, False, False, 73, 0, "f16"),
     (8, 80, 80, 64, 64, 3, 1, 1, 1, True, False, 74, 0, "f16"),
     (8, 20, 20, 256, 256, 3, 1, 1, 1, True, False, 75, 16, "f16"),
+    (8, 40, 40, 128, 128, 3, 1, 1, 1, True, False, 76, 0, "f16"),
+    (8, 80, 80, 64, 64, 3, 1, 1, 1, True, False, 77, 16, "f16"),
 ]
 
 

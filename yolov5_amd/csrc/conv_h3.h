@@ -31,7 +31,7 @@ struct Y5H3Geom {
   static constexpr int NAI_MAX = (HPMAX + 15) / 16;  // LDS-DMA instructions per activation stage (16 halo pixels x 64 B each)
   static constexpr int A_STAGE = NAI_MAX * 1024;
   static constexpr int W_INSTR = BN / 16;            // per filter stage: BN rows x 64 B
-  static constexpr int WPW = W_INSTR / NW;            // filter pieces per wave per step
+  static constexpr int WPW = (W_INSTR + NW - 1) / NW;  // filter pieces per wave per step (a wave without a piece issues a dummy: uniform counts)
   static constexpr int W_STAGE = BN * 64;
   static constexpr int NSW = NSW_;                     // filter ring: 9 = one stage per tap, slices issued eight steps ahead; 4 = three ahead,
                                                        // 32 KB instead of 72 KB so that two workgroups share a CU
@@ -40,8 +40,7 @@ struct Y5H3Geom {
   static constexpr int PPS = (APS + 1) / 2;            // ... issued in the first two steps of the previous chunk (seven steps ahead)
   static constexpr int SCR_ROWB = 32 * 2 + 16, SCR_BYTES = 32 * SCR_ROWB;
   // the epilogue's transposition scratch lives in halo stage 1 (idle between a tile's last step and the next tile's step 0)
-  static constexpr size_t LDS = (size_t)2 * A_STAGE + (size_t)NSW * W_STAGE + (size_t)NW * 1024;
-  static_assert(W_INSTR % NW == 0, "filter stage must split evenly over the waves (static vmcnt bookkeeping)");
+  static constexpr size_t LDS = (size_t)2 * A_STAGE + (size_t)NSW * W_STAGE + 1024;  // + one dummy slot (zeros from any wave)
   static_assert(NW * SCR_BYTES <= A_STAGE, "epilogue scratch must fit into a halo stage");
   static_assert(NSW == 9 || NSW == 4, "ring depths with bookkeeping: 9 and 4");
   // LDS-DMA instructions (dummies included) a wave has issued for the NEXT chunk's halo (taps 0 and 1) within the WIN steps before tap t
@@ -87,7 +86,7 @@ void y5_conv_h3_kernel(const Y5ConvParams p) {
   const int wm = wave / WN, wn = wave % WN;
   const int g = lane >> 5, frow = lane & 31;
   char* const scratch = smem + A_STAGE + wave * Gm::SCR_BYTES;  // halo stage 1
-  char* const dummy = smem + 2 * A_STAGE + NSW * W_STAGE + wave * 1024;
+  char* const dummy = smem + 2 * A_STAGE + NSW * W_STAGE;  // shared by all waves: only ever receives zero fill, never read
 
   const int TH = p.h3_th, TW = p.h3_tw, HW = TW + 2;
   const int HP = (TH + 2) * HW;
@@ -180,7 +179,10 @@ void y5_conv_h3_kernel(const Y5ConvParams p) {
   auto issue_w = [&](int stage, int tap, int cc) {
     const unsigned koff = (unsigned)((tap * p.C1 + cc * 32) * 2);
 #pragma unroll
-    for (int q = 0; q < WPW; ++q) y5_bglds16(wrs, w_off[q] + koff, w_lds + stage * W_STAGE + (q * NW + wave) * 1024);
+    for (int q = 0; q < WPW; ++q) {
+      if (Gm::W_INSTR % NW == 0 || q * NW + wave < Gm::W_INSTR) y5_bglds16(wrs, w_off[q] + koff, w_lds + stage * W_STAGE + (q * NW + wave) * 1024);
+      else y5_bglds16(wrs, Y5_OOB, dummy);
+    }
   };
   auto prologue = [&](int j) {  // first halo chunk + the filter slices of steps 0..NSW-2 (a tile has at least nine steps)
     loader_setup(j);

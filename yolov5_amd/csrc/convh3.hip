@@ -10,7 +10,7 @@ int g_num_cu = 0;
 
 // ---- halo-resident 3x3 configurations (conv_h3.h): ids kH3_0 + index ------------------------------------------------------------
 struct H3Cfg { int wm, wn, tm, tn, hpmax; };
-constexpr int kNumH3 = 15;
+constexpr int kNumH3 = 17;
 constexpr H3Cfg kH3Cfgs[kNumH3] = {
     {2, 2, 5, 2, 496},  // 61: 320 pixels x 128 channels (8 x 40, 4 x 80, 16 x 20 output tiles)
     {2, 2, 5, 1, 496},  // 62: 320 x  64
@@ -30,6 +30,8 @@ constexpr H3Cfg kH3Cfgs[kNumH3] = {
     {2, 2, 4, 2, 320},  // 73: 256 x 128 (5 x 40, 10 x 20)
     {2, 2, 4, 1, 320},  // 74: 256 x  64
     {2, 2, 3, 2, 320},  // 75: 192 x 128
+    {4, 2, 2, 2, 320},  // 76: 256 x 128, eight waves, two workgroups per CU
+    {4, 2, 2, 1, 320},  // 77: 256 x  64, eight waves, two workgroups per CU
 };
 
 // spatial tile for an H x W output: TW = ceil(W / d), TH as tall as the pixel budget and the LDS halo allow, then evened out over the
@@ -117,6 +119,8 @@ int y5_launch_h3_by_cfg(const Y5ConvParams& p, int idx, int mb, hipStream_t s) {
     case 12: return launch_h3<2, 2, 4, 2, 320, 4>(p, mb, s);
     case 13: return launch_h3<2, 2, 4, 1, 320, 4>(p, mb, s);
     case 14: return launch_h3<2, 2, 3, 2, 320, 4>(p, mb, s);
+    case 15: return launch_h3<4, 2, 2, 2, 320, 4>(p, mb, s);
+    case 16: return launch_h3<4, 2, 2, 1, 320, 4>(p, mb, s);
   }
   return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown halo 3x3 config");
 }
