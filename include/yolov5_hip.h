@@ -323,6 +323,17 @@ int y5_scale_boxes_batch(float* det, int ld_det, int max_det, const int* det_cou
                          void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * y5_conv_k3pw_fwd -- `Conv(c1, c2, 3, 2)` followed by a pointwise convolution as ONE launch (csrc/conv_k3.h, PW2): models/yolo.py:160-170
+ * walking `1.Conv` into `2.C3`, whose cv1 and cv2 (common.py:246, one GEMM with N = 2 c_) are the only readers of the Conv's output -- the
+ * 3x3's bias + SiLU result stays in LDS and is multiplied with the second filter by the wave that produced it.  d describes the 3x3 layer
+ * (fp16, 3x3 s2 p1, C1 = 32, <= 64 output channels, SiLU; d->cfg = 31 / 34 or -1; OH % 4 == 0, OW % 8 == 0); the pointwise layer has C3 <= 64
+ * output channels (filter packed [64][Kpad2], k = the 3x3's output channel, bias fp32 [64]), activation act2; its channels [0, split_n) go
+ * to y (pixel stride ldy), [split_n, C3) to y2 (pixel stride ld2, channel n - split_n); split_n == C3: everything to y.
+ * ------------------------------------------------------------------------------------------------------- */
+int y5_conv_k3pw_fwd(const y5_conv_desc* d, const void* x, const void* w1_packed, const float* bias1, const void* w2_packed, const float* bias2,
+                     int C3, int Npad2, int Kpad2, int act2, void* y, int ldy, void* y2, int ld2, int split_n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * y5_bottleneck_fwd -- models/common.py:164-181 `Bottleneck.forward` inside C3 (e = 1.0, :242): y = [x +] cv2(cv1(x)) with cv1 = 1x1
  * C->C and cv2 = 3x3 pad 1 C->C (BN folded, bias + SiLU each), fp16, as ONE pass: the 1x1 output stays in LDS (csrc/conv_bneck.h).
  * x / y: NHWC channel slices with pixel strides ldx / ldy (elements); y must NOT overlap x.  C = 32 or 64, H % 4 == 0, W % 8 == 0.
@@ -364,6 +375,8 @@ int y5_plan_add_detect_head(y5_plan*, const y5_conv_desc* d, const void* x, cons
                             float stride, const float* anchors_px, void* z, long long nrows_total, long long row_off);
 int y5_plan_add_bottleneck(y5_plan*, const void* x, int ldx, const void* w1_packed, const float* bias1, int Kpad1, const void* w2_packed,
                            const float* bias2, int Kpad2, void* y, int ldy, int B, int H, int W, int C, int add);
+int y5_plan_add_conv_k3pw(y5_plan*, const y5_conv_desc* d, const void* x, const void* w1_packed, const float* bias1, const void* w2_packed,
+                          const float* bias2, int C3, int Npad2, int Kpad2, int act2, void* y, int ldy, void* y2, int ld2, int split_n);
 int y5_plan_add_nop(y5_plan*);  /* placeholder op: keeps the op numbering of the conv + decode form next to a fused head */
 int y5_plan_add_conv_stem(y5_plan*, const void* x_nchw, int B, int H, int W, const void* w_stem, const float* bias, int C2,
                           int Npad, void* y, int ldy);

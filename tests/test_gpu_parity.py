@@ -370,3 +370,63 @@ def test_split_engine_matches_single_plan(dev):
         assert torch.equal(b[k], b2[k])
         # tile configurations differ between the batch-32 plan and the batch-16 sub-plans: fp16 accumulation-order noise only
         torch.testing.assert_close(b[k], a[k], rtol=2e-2, atol=2e-2 if k != "z" else 0.5)
+
+
+# ---- 3x3 s2 Conv + the pointwise convolution behind it as one launch (conv_k3.h PW2) ------------------------------------------------
+@pytest.mark.parametrize("B,H,W,c3,split,mb", [(8, 160, 160, 64, 32, 0), (4, 96, 64, 48, 48, 4), (16, 64, 128, 64, 16, 0)])
+def test_conv_k3pw_matches_torch(B, H, W, c3, split, mb, dev):
+    """y5_conv_k3pw_fwd (models/yolo.py walking 1.Conv -> 2.C3.cv1+cv2) on the real memory system: many tiles per wave, so the counted-vmcnt ring
+    with the second epilogue's stores reaches steady state; reference = torch fp32 on the same fp16 data with the intermediate rounded to fp16."""
+    from yolov5_amd import _lib
+    from yolov5_amd.packing import pack_conv_weight
+
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(B + H)
+    w1 = torch.randn((64, 32, 3, 3), generator=g) * (2.0 / 288) ** 0.5
+    b1 = torch.randn(64, generator=g) * 0.3
+    w2 = torch.randn((c3, 64, 1, 1), generator=g) * (2.0 / 64) ** 0.5
+    b2 = torch.randn(c3, generator=g) * 0.3
+    x = torch.randn((B, H, W, 32), generator=g).half()
+    w1p, b1p, _, K1, N1 = pack_conv_weight(w1, b1, torch.float16)
+    w2p, b2p, _, K2, N2 = pack_conv_weight(w2, b2, torch.float16)
+    xd, w1d, b1d, w2d, b2d = (t.to(dev) for t in (x, w1p, b1p, w2p, b2p))
+    OH, OW = H // 2, W // 2
+    ldy, ld2 = split + 8, (c3 - split) + 8
+    y = torch.full((B, OH, OW, ldy), 7.0, dtype=torch.float16, device=dev)
+    y2 = torch.full((B, OH, OW, ld2), 7.0, dtype=torch.float16, device=dev) if split < c3 else None
+    d = _lib.ConvDesc(dtype=_lib.Y5_F16, B=B, H=H, W=W, C1=32, ldx=32, OH=OH, OW=OW, C2=64, ldy=64, KH=3, KW=3, SH=2, SW=2, PH=1, PW=1, act=1,
+                      Kpad=K1, Npad=N1, ldr=0, ld2=0, cfg=-1, max_blocks=mb)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    rc = lib.y5_conv_k3pw_fwd(C.byref(d), C.c_void_p(xd.data_ptr()), C.c_void_p(w1d.data_ptr()), C.c_void_p(b1d.data_ptr()), C.c_void_p(w2d.data_ptr()),
+                              C.c_void_p(b2d.data_ptr()), c3, N2, K2, 1, C.c_void_p(y.data_ptr()), ldy, C.c_void_p(y2.data_ptr()) if y2 is not None else None,
+                              ld2, split, st)
+    assert rc == 0, lib.y5_last_error()
+    torch.cuda.synchronize()
+    t = F.silu(F.conv2d(x.float().permute(0, 3, 1, 2), w1.half().float(), b1, stride=2, padding=1)).half().float()
+    ref = F.silu(F.conv2d(t, w2.half().float(), b2)).permute(0, 2, 3, 1)
+    torch.testing.assert_close(y[..., :split].float().cpu(), ref[..., :split], rtol=5e-3, atol=5e-3)
+    assert bool((y[..., split:] == 7).all())
+    if y2 is not None:
+        torch.testing.assert_close(y2[..., :c3 - split].float().cpu(), ref[..., split:], rtol=5e-3, atol=5e-3)
+        assert bool((y2[..., c3 - split:] == 7).all())
+
+
+def test_plan_k3pw_fused_equals_unfused_on_gpu(dev, monkeypatch):
+    """yolov5s 2 x 3 x 320 x 320 fp16: the plan with 1.Conv + 2.C3.cv1+cv2 as one launch against the plan with two launches (same fp16 intermediate,
+    LDS instead of HBM)."""
+    from yolov5_amd.yolo import DetectionModel
+
+    cfg = yo.model_cfg("yolov5s")
+    sd = yo.det_state_dict(cfg, 0, fused=False)
+    x = torch.from_numpy(detgen.uniform((2, 3, 320, 320), 0.0, 1.0, name="img", seed=0)).half().to(dev)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("Y5_FUSED_K3PW", mode)
+        m = DetectionModel("yolov5s.yaml")
+        m.load_state_dict(sd)
+        m = m.eval().fuse().half().to(dev)
+        outs[mode] = m(x)[0].float().cpu()
+        eng = next(iter(m._engines.values()))
+        assert any(n.startswith("conv+pw:") for n in eng.op_names) == (mode == "1"), eng.op_names
+    u, v = outs["0"], outs["1"]
+    assert float((u - v).abs().max()) <= 4e-3 * max(1.0, float(u.abs().max()))

@@ -137,6 +137,10 @@ EXPORTS = {
     "y5_plan_add_nop": (C.c_int, [C.c_void_p]),
     "y5_plan_add_bottleneck": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                          C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "y5_conv_k3pw_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                   C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "y5_plan_add_conv_k3pw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]),
     "y5_bottleneck_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "y5_plan_set_input": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

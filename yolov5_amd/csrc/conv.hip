@@ -284,11 +284,11 @@ constexpr K3Cfg kK3Cfgs[kNumK3] = {
     {32, 2, 2, 3},  // 34: 3x3 s2 32->64, 3 stages
 };
 
-template <int C1, int NT, int SH, int S, bool RES, bool ACT>
+template <int C1, int NT, int SH, int S, bool RES, bool ACT, int NT2 = 0>
 int launch_k3_v(const Y5ConvParams& p, int max_blocks, hipStream_t stream) {
-  const size_t lds = y5_conv_k3_lds_bytes<C1, NT, SH, S>();
+  const size_t lds = y5_conv_k3_lds_bytes<C1, NT, SH, S, NT2>();
   if (lds > 160 * 1024) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: 3x3 streaming configuration exceeds 160 KiB of LDS");
-  auto kern = y5_conv_k3_kernel<C1, NT, SH, S, RES, ACT>;
+  auto kern = y5_conv_k3_kernel<C1, NT, SH, S, RES, ACT, NT2>;
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -512,6 +512,40 @@ extern "C" int y5_conv2d_time(const y5_conv_desc* d, const void* x, const void* 
   hipEventDestroy(e0);
   hipEventDestroy(e1);
   return rc;
+}
+
+// ---- 3x3 s2 Conv + the pointwise convolution behind it as one launch (conv_k3.h, PW2) --------------------------------------------
+extern "C" int y5_conv_k3pw_fwd(const y5_conv_desc* d, const void* x, const void* w1_packed, const float* bias1, const void* w2_packed,
+                                const float* bias2, int C3, int Npad2, int Kpad2, int act2, void* y, int ldy, void* y2, int ld2, int split_n,
+                                void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (!d || !x || !w1_packed || !bias1 || !w2_packed || !bias2 || !y) return y5_fail(Y5_ERR_BAD_ARG, "conv_k3pw: null pointer");
+  const int cfg = d->cfg < 0 ? kK3_0 + 4 : d->cfg;
+  if (cfg != kK3_0 + 1 && cfg != kK3_0 + 4) return y5_fail(Y5_ERR_UNSUPPORTED, "conv_k3pw: built for the 3x3 s2 32->64 streaming configurations (31, 34)");
+  const K3Cfg& c = kK3Cfgs[cfg - kK3_0];
+  const int oh = (d->H + 2 - 3) / 2 + 1, ow = (d->W + 2 - 3) / 2 + 1;
+  if (d->dtype != Y5_F16 || d->KH != 3 || d->KW != 3 || d->SH != 2 || d->SW != 2 || d->PH != 1 || d->PW != 1 || d->C1 != c.c1 || d->Npad != c.nt * 32 ||
+      d->C2 > d->Npad || (d->C2 & 7) || oh != d->OH || ow != d->OW || (oh & 3) || (ow & 7) || d->Kpad < 9 * c.c1 || d->H > 255 * 4 || d->W > 65535 || (d->ldx & 7) ||
+      d->ldx < d->C1 || !d->act)
+    return y5_fail(Y5_ERR_UNSUPPORTED, "conv_k3pw: the 3x3 layer does not match the streaming configuration");
+  if (Npad2 != 64 || C3 < 8 || C3 > Npad2 || (C3 & 7) || Kpad2 < d->Npad || (Kpad2 & 7) || (ldy & 7) || split_n < 0 || split_n > C3 || (split_n & 7) ||
+      (split_n < C3 && (!y2 || (ld2 & 7) || ld2 < C3 - split_n)) || ldy < (split_n ? split_n : 0) || (split_n == 0 && !y2))
+    return y5_fail(Y5_ERR_UNSUPPORTED, "conv_k3pw: the pointwise layer must have <= 64 output channels in multiples of 8, split on a multiple of 8");
+  if (((uintptr_t)x | (uintptr_t)w1_packed | (uintptr_t)bias1 | (uintptr_t)w2_packed | (uintptr_t)bias2 | (uintptr_t)y | (uintptr_t)y2) & 15)
+    return y5_fail(Y5_ERR_BAD_ARG, "conv_k3pw: pointers must be 16-byte aligned");
+  if ((long long)d->B * d->H * d->W * d->ldx * 2 >= 0x7fffffffLL) return y5_fail(Y5_ERR_UNSUPPORTED, "conv_k3pw: input exceeds 2^31 bytes");
+  Y5ConvParams p{};
+  p.x = x; p.w = w1_packed; p.bias = bias1; p.y = y; p.y2 = y2;
+  p.B = d->B; p.H = d->H; p.W = d->W; p.C1 = d->C1; p.ldx = d->ldx;
+  p.OH = oh; p.OW = ow; p.C2 = d->C2; p.ldy = ldy; p.ld2 = ld2;
+  p.KH = 3; p.KW = 3; p.SH = 2; p.SW = 2; p.PH = 1; p.PW = 1; p.act = 1;
+  p.Kpad = d->Kpad; p.Npad = d->Npad; p.K = 9 * d->C1; p.M = d->B * oh * ow;
+  p.x_bytes = (unsigned)((((long long)d->B * d->H * d->W - 1) * d->ldx + d->C1) * 2);
+  p.w_bytes = (unsigned)((long long)d->Npad * d->Kpad * 2);
+  p.pw2_w = w2_packed; p.pw2_bias = bias2; p.pw2_w_bytes = (unsigned)((long long)Npad2 * Kpad2 * 2);
+  p.pw2_kpad = Kpad2; p.pw2_npad = Npad2; p.pw2_c2 = C3; p.pw2_act = act2; p.pw2_split = split_n;
+  // two ring stages: with the second filter beside the first a third stage per wave does not fit the 160 KiB (cfg 34 maps to the same kernel)
+  return launch_k3_v<32, 2, 2, 2, false, true, 2>(p, d->max_blocks, stream);
 }
 
 // ---- stem (conv_stem.h) -----------------------------------------------------------------------------------

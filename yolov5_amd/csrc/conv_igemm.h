@@ -50,6 +50,12 @@ struct Y5ConvParams {
   int tilesM, tilesN, nk;
   float* sk_ws;        // stream-K (SK kernels): one fp32 partial-tile slab per workgroup, [G][WM*WN*TM*TN*16*64]
   unsigned* sk_flags;  // [G]: 1 = workgroup g's slab holds the partial sums of the tile its unit range starts in; reset to 0 by the reader
+  // conv_k3.h with a fused 1x1 behind the 3x3 (PW2): second filter [pw2_npad][pw2_kpad] (k = the 3x3's output channels), fp32 bias, activation,
+  // output channels [0, pw2_split) -> y (pixel stride ldy), [pw2_split, pw2_c2) -> y2 (pixel stride ld2); pw2_split == pw2_c2: everything to y
+  const void* pw2_w;
+  const float* pw2_bias;
+  unsigned pw2_w_bytes;
+  int pw2_kpad, pw2_npad, pw2_c2, pw2_act, pw2_split;
   int h3_th, h3_tw, h3_tiles_h, h3_tiles_w;  // conv_h3.h: spatial tile (output rows x columns) and tiles per image
   int split_n;  // > 0: output channels >= split_n go to y2 (pixel stride ld2, channel n - split_n) instead of y -- C3's cv1 / cv2 halves
                 // of one GEMM landing in two different buffers (y2 is then NOT the upsampled replica)

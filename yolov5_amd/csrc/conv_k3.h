@@ -12,14 +12,20 @@
 #pragma once
 #include "conv_pw.h"
 
-template <int C1, int NT, int SH, int S>
+template <int C1, int NT, int SH, int S, int NT2 = 0>
 constexpr size_t y5_conv_k3_lds_bytes() {
   constexpr int RH = 3 * SH + 3, RW = 7 * SH + 3, NSL = C1 / 8;
   constexpr int NI = (RH * RW * NSL + 63) / 64;
-  return (size_t)NT * 32 * 9 * C1 * 2 + (size_t)NT * 32 * 4 + (size_t)4 * S * NI * 1024;
+  return (size_t)NT * 32 * 9 * C1 * 2 + (size_t)NT * 32 * 4 + (size_t)4 * S * NI * 1024 + (size_t)NT2 * 32 * (NT * 32 * 2 + 4);
 }
 
-template <int C1, int NT, int SH, int S, bool RES, bool ACT = true>
+// NT2 > 0 (PW2): a pointwise convolution with NT2 * 32 (padded) output channels is applied to every finished tile before it leaves the wave --
+// `Conv(3x3, s2)` followed by the merged `C3.cv1 + C3.cv2` GEMM (models/yolo.py walks 1.Conv -> 2.C3; common.py:246 reads the Conv's output
+// through cv1 and cv2 only), so the 3x3's output never reaches HBM: its bias + SiLU result is parked in the vacated stage in exactly the
+// layout an MFMA activation fragment is read from (pixel rows, 16-byte slots XOR-swizzled by the row), multiplied with the second filter
+// (resident in LDS beside the first), and the SECOND epilogue's result is what the tile stores (split over two destinations like the
+// split store of conv_igemm.h).
+template <int C1, int NT, int SH, int S, bool RES, bool ACT = true, int NT2 = 0>
 __global__ __launch_bounds__(256)
 void y5_conv_k3_kernel(const Y5ConvParams p) {
   typedef half_t T;
@@ -37,15 +43,21 @@ void y5_conv_k3_kernel(const Y5ConvParams p) {
   constexpr int KS = C1 / 16;                         // MFMA k-steps per tap
   constexpr int SPR = NPAD / 8, RPP = 64 / SPR, NPASS = 32 / RPP;
   constexpr int SWM = SPR >= 8 ? 7 : SPR - 1;
-  constexpr int LP = NI, SP = NPASS, RP = RES ? NPASS : 0;
+  constexpr int NPAD2 = 32 * NT2;                     // PW2: padded output channels of the fused 1x1
+  constexpr int SPR2 = NT2 ? NPAD2 / 8 : 8, RPP2 = 64 / SPR2, NPASS2 = 32 / RPP2, SWM2 = SPR2 >= 8 ? 7 : SPR2 - 1;
+  constexpr int LP = NI, SP = NT2 ? NPASS2 : NPASS, RP = RES ? NPASS : 0;
   static_assert(STAGE >= 32 * NPAD * 2, "epilogue scratch must fit in a stage");
+  static_assert(NT2 == 0 || (!RES && STAGE >= 32 * NPAD2 * 2), "fused 1x1: no residual, second scratch must fit in a stage");
+  constexpr int K2B = NPAD * 2;                       // bytes per row of the second filter in LDS (k = the 3x3's padded output channels)
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* wlds = smem;
   float* blds = reinterpret_cast<float*>(smem + W_BYTES);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  char* ring = smem + W_BYTES + NPAD * 4 + wave * (S * STAGE);
+  char* w2lds = smem + W_BYTES + NPAD * 4;
+  float* b2lds = reinterpret_cast<float*>(w2lds + NPAD2 * K2B);
+  char* ring = smem + W_BYTES + NPAD * 4 + NPAD2 * (K2B + 4) + wave * (S * STAGE);
 
   const y5_rsrc_t xrs = y5_make_rsrc(p.x, p.x_bytes);
   const y5_rsrc_t wrs = y5_make_rsrc(p.w, p.w_bytes);
@@ -64,6 +76,17 @@ void y5_conv_k3_kernel(const Y5ConvParams p) {
       y5_bglds16(wrs, (unsigned)((n * p.Kpad) * 2 + src_slot * 16), wlds + I * 1024);
     }
     for (int i = tid; i < NPAD; i += 256) blds[i] = p.bias[i];
+    if constexpr (NT2 > 0) {
+      const y5_rsrc_t w2rs = y5_make_rsrc(p.pw2_w, p.pw2_w_bytes);
+      constexpr int NSL2 = NPAD / 8, W2I = NPAD2 * NSL2 / 64;
+      for (int I = wave; I < W2I; I += 4) {
+        const int pidx = I * 64 + lane;
+        const int n = pidx / NSL2, ps = pidx - n * NSL2;
+        const int sw = NSL2 >= 8 ? ((n >> 1) & 7) : ((n >> 2) & 3);
+        y5_bglds16(w2rs, (unsigned)(n * p.pw2_kpad * 2 + ((ps ^ sw) * 16)), w2lds + I * 1024);
+      }
+      for (int i = tid; i < NPAD2; i += 256) b2lds[i] = i < p.pw2_npad ? p.pw2_bias[i] : 0.f;
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
   }
@@ -94,6 +117,8 @@ void y5_conv_k3_kernel(const Y5ConvParams p) {
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) wsl[ks] = pl * K2 + (((ks * 2 + g) ^ fsw(pl)) * 16);
   const int orow = lane / SPR, oslot = lane % SPR;
+  const int orow2 = lane / SPR2, oslot2 = lane % SPR2;
+  T* __restrict__ y2g = static_cast<T*>(p.y2);
 
   // ---- tile schedule ---------------------------------------------------------------------------------------------
   const int tw = p.OW / TC, th = p.OH / TR;
@@ -195,6 +220,50 @@ void y5_conv_k3_kernel(const Y5ConvParams p) {
       }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if constexpr (NT2 > 0) {
+      // ---- fused 1x1: the parked tile is the activation operand (lane = pixel row pl, k-half g), K = NPAD channels -----------------
+      float16_t acc3[NT2];
+#pragma unroll
+      for (int j = 0; j < NT2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc3[j][r] = 0.f;
+      const int sw2 = NPAD >= 64 ? ((pl >> 1) & 7) : ((pl >> 2) & 3);
+#pragma unroll
+      for (int ks = 0; ks < NPAD / 16; ++ks) {
+        const half8_t af = *reinterpret_cast<const half8_t*>(st + pl * (NPAD * 2) + (((ks * 2 + g) ^ (pl & SWM)) * 16));
+#pragma unroll
+        for (int j = 0; j < NT2; ++j) {
+          const half8_t wf = *reinterpret_cast<const half8_t*>(w2lds + (j * 32 + pl) * K2B + (((ks * 2 + g) ^ sw2) * 16));
+          acc3[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, af, acc3[j], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();  // every lane has read the parked tile: the stage becomes the second epilogue's scratch
+#pragma unroll
+      for (int j = 0; j < NT2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4_t bv = *reinterpret_cast<const float4_t*>(b2lds + j * 32 + q * 8 + g * 4);
+          half4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float t = acc3[j][q * 4 + e] + bv[e]; o[e] = (half_t)(p.pw2_act ? y5_silu(t) : t); }
+          const int slot = j * 4 + q;
+          *reinterpret_cast<half4_t*>(st + pl * (NPAD2 * 2) + ((slot ^ (pl & SWM2)) * 16) + g * 8) = o;
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int ps = 0; ps < NPASS2; ++ps) {
+        const int row = ps * RPP2 + orow2;
+        const uint4_t raw = *reinterpret_cast<const uint4_t*>(st + row * (NPAD2 * 2) + ((oslot2 ^ (row & SWM2)) * 16));
+        const size_t m = ((size_t)b * p.OH + oh0 + (row >> 3)) * p.OW + ow0 + (row & 7);
+        const int n = oslot2 * 8;
+        if (n < p.pw2_c2) {
+          T* d = n < p.pw2_split ? yg + m * p.ldy + n : y2g + m * p.ld2 + (n - p.pw2_split);  // ONE store instruction either way (counted vmcnt)
+          *reinterpret_cast<uint4_t*>(d) = raw;
+        }
+      }
+    } else {
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       const int row = ps * RPP + orow;
@@ -208,6 +277,7 @@ void y5_conv_k3_kernel(const Y5ConvParams p) {
       const size_t m = ((size_t)b * p.OH + oh0 + (row >> 3)) * p.OW + ow0 + (row & 7);
       const int n = oslot * 8;
       if (n < p.C2) *reinterpret_cast<uint4_t*>(yg + m * p.ldy + n) = raw;
+    }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();

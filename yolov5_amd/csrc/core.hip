@@ -48,7 +48,7 @@ extern "C" const char* y5_last_error(void) { return g_err.c_str(); }
 // ---------------------------------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------------------------------
-enum OpKind { OP_CONV, OP_TO_NHWC, OP_SPPF, OP_UPS, OP_COPY, OP_DECODE, OP_TO_NCHW, OP_STEM, OP_HEAD, OP_NOP, OP_BNECK };
+enum OpKind { OP_CONV, OP_TO_NHWC, OP_SPPF, OP_UPS, OP_COPY, OP_DECODE, OP_TO_NCHW, OP_STEM, OP_HEAD, OP_NOP, OP_BNECK, OP_K3PW };
 
 struct Op {
   OpKind kind;
@@ -161,6 +161,15 @@ extern "C" int y5_plan_add_bottleneck(y5_plan* pl, const void* x, int ldx, const
   pl->ops.push_back(o);
   return Y5_OK;
 }
+extern "C" int y5_plan_add_conv_k3pw(y5_plan* pl, const y5_conv_desc* d, const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
+                                     int C3, int Npad2, int Kpad2, int act2, void* y, int ldy, void* y2, int ld2, int split_n) {
+  if (!pl || !d) return y5_fail(Y5_ERR_BAD_ARG, "plan: null");
+  Op o{}; o.kind = OP_K3PW; o.conv = *d; o.p0 = x; o.p1 = w1; o.p2 = b1; o.p3 = w2; o.q0 = y; o.q1 = y2;
+  o.l[0] = (long long)(uintptr_t)b2;
+  o.i[0] = C3; o.i[1] = Npad2; o.i[2] = Kpad2; o.i[3] = act2; o.i[4] = ldy; o.i[5] = ld2; o.i[6] = split_n;
+  pl->ops.push_back(o);
+  return Y5_OK;
+}
 extern "C" int y5_plan_add_nop(y5_plan* pl) {
   if (!pl) return y5_fail(Y5_ERR_BAD_ARG, "plan: null");
   Op o{}; o.kind = OP_NOP;
@@ -236,6 +245,9 @@ static int run_op(const Op& o, void* st) {
     case OP_HEAD:
       return y5_detect_head_fwd(&o.conv, o.p0, o.p1, (const float*)o.p2, o.i[0], o.i[1], o.f[0], o.anchors, o.q0, o.l[0], o.l[1], st);
     case OP_NOP: return Y5_OK;
+    case OP_K3PW:
+      return y5_conv_k3pw_fwd(&o.conv, o.p0, o.p1, (const float*)o.p2, o.p3, (const float*)(uintptr_t)o.l[0], o.i[0], o.i[1], o.i[2], o.i[3], o.q0, o.i[4],
+                              o.q1, o.i[5], o.i[6], st);
     case OP_BNECK:
       return y5_bottleneck_fwd(o.p0, o.i[0], o.p1, (const float*)o.p2, o.i[1], o.p3, (const float*)o.q1, o.i[2], o.q0, o.i[3], o.i[4], o.i[5], o.i[6],
                                o.i[7], o.i[8], 0, st);

@@ -639,6 +639,10 @@ class Engine:
             self._first_op = (d, op["C"])
             rc = lib.y5_plan_add_nchw_to_nhwc(self.plan, None, self.dt, self._ptr(d), self.dt, B, op["C"], d.H, d.W, self._ld(d), 1.0)
             self.op_names.append("to_nhwc")
+        elif kind == "conv" and getattr(self, "_k3pw_skip", -1) == self._cur:
+            rc = lib.y5_plan_add_nop(self.plan)  # multiplied inside the 3x3 in front of it (y5_plan_add_conv_k3pw)
+            self.conv_cfgs.append(-2)
+            self.op_names.append("conv:" + op["name"] + "(fused)")
         elif kind == "conv":
             rc = self._add_conv(op)
         elif kind == "bneck":
@@ -774,6 +778,12 @@ class Engine:
             # (measured, scripts/streamk_bench.py: at yolov5s bs=64 sizes the slab round trip costs more than the tail it removes --
             # 60-119 us against 42-69 us for the plain tiles -- so they only enter the race when asked for: Y5_STREAMK=1)
             d.cfg = self._autotune_conv(d, ptrs, exclude=SK_CFGS if (op.get("side") or os.environ.get("Y5_STREAMK", "0") != "1") else ())
+        k3pw = self._fused_k3pw_args(op, d, ptrs)
+        if k3pw is not None:
+            self._k3pw_skip = self._cur + 1
+            self.conv_cfgs.append(int(d.cfg))
+            self.op_names.append("conv+pw:" + op["name"] + "+" + k3pw["name"])
+            return self.lib.y5_plan_add_conv_k3pw(self.plan, C.byref(d), ptrs[0], ptrs[1], ptrs[2], *k3pw["args"])
         head = self._fused_head_args(op, d, ptrs)
         if head is not None:
             self._fused_heads.add(head["level"])
@@ -785,6 +795,76 @@ class Engine:
         self.op_names.append("conv:" + op["name"])
         return self.lib.y5_plan_add_conv(self.plan, C.byref(d), self._ptr(x), C.c_void_p(self.be.ptr(wp)), C.c_void_p(self.be.ptr(bp)),
                                          self._ptr(res), self._ptr(y), self._ptr(y2))
+
+    def _fused_k3pw_args(self, op, d, ptrs):
+        """`Conv(32, 64, 3, 2)` + the pointwise convolution that is its only reader (yolov5s: 1.Conv -> 2.C3.cv1+cv2) as ONE launch
+        (csrc/conv_k3.h PW2, y5_conv_k3pw_fwd): the 3x3's output never reaches HBM.  Y5_FUSED_K3PW = 0: never, 1: whenever the shapes fit,
+        auto (default): both forms are timed on the real buffers at plan build and the faster one is kept."""
+        mode = os.environ.get("Y5_FUSED_K3PW", "auto")
+        nxt_i = self._cur + 1
+        if mode == "0" or self.dt != _lib.Y5_F16 or nxt_i >= len(self.spec.ops) or op.get("side"):
+            return None
+        nxt = self.spec.ops[nxt_i]
+        y = op["y"]
+        if not (_pair(op["k"]) == (3, 3) and _pair(op["s"]) == (2, 2) and _pair(op["p"]) == (1, 1) and op["act"] and op["res"] is None and op["y2"] is None and not op.get("split_n")
+                and d.C1 == 32 and d.C2 == 64 and d.Npad == 64 and y.H % 4 == 0 and y.W % 8 == 0):
+            return None
+        if not (nxt["op"] == "conv" and _pair(nxt["k"]) == (1, 1) and _pair(nxt["s"]) == (1, 1) and _pair(nxt["p"]) == (0, 0) and nxt["res"] is None and nxt["c2_store"] <= 64
+                and nxt["c2_store"] % 8 == 0 and not nxt.get("side") and nxt["x"].buf == y.buf and nxt["x"].c_off == y.c_off and nxt["x"].C == d.C2):
+            return None
+        if nxt["y2"] is not None and not nxt.get("split_n"):
+            return None  # an upsampled replica behind the pointwise layer: not built
+        for k, o in enumerate(self.spec.ops):  # the 3x3's output must have no other reader
+            if k in (self._cur, nxt_i):
+                continue
+            for v in o.values():
+                if isinstance(v, TRef) and v.buf == y.buf:
+                    return None
+        if mode != "1" and not getattr(self.be, "autotune", False):
+            return None
+        (_g, (wp2, bp2, _K2, Kpad2, Npad2), stem2) = self._conv_weights(nxt)
+        if stem2 is not None or Npad2 != 64:
+            return None
+        wp2, bp2 = self.be.from_torch(wp2), self.be.from_torch(bp2)
+        c3 = nxt["c2_store"]
+        split = nxt.get("split_n") or c3
+        y1, y2 = nxt["y"], nxt["y2"]
+        args = (C.c_void_p(self.be.ptr(wp2)), C.c_void_p(self.be.ptr(bp2)), c3, Npad2, Kpad2, 1 if nxt["act"] else 0, self._ptr(y1), self._ld(y1),
+                self._ptr(y2), self._ld(y2) if y2 is not None else 0, split)
+        lib, st = self.lib, self._stream()
+        d3 = _lib.ConvDesc.from_buffer_copy(d)
+        if d3.cfg not in (31, 34):
+            d3.cfg = -1
+        fused = C.c_void_p(lib.y5_plan_create())
+        try:
+            if lib.y5_plan_add_conv_k3pw(fused, C.byref(d3), ptrs[0], ptrs[1], ptrs[2], *args) != 0:
+                return None
+            ms_f = C.c_float(0)
+            if lib.y5_plan_time_range(fused, 0, 1, 1 if mode == "1" else 10, st, C.byref(ms_f)) != 0:
+                return None
+            if mode != "1":
+                (H2, W2, C12, ldx2, *_r) = _g
+                d2 = _lib.ConvDesc(dtype=self.dt, B=self.spec.B, H=H2, W=W2, C1=C12, ldx=ldx2, OH=y1.H, OW=y1.W, C2=c3, ldy=self._ld(y1), KH=1, KW=1, SH=1, SW=1,
+                                   PH=0, PW=0, act=1 if nxt["act"] else 0, Kpad=Kpad2, Npad=Npad2, ldr=0, ld2=self._ld(y2) if y2 is not None else 0, cfg=-1,
+                                   max_blocks=0, split_n=nxt.get("split_n", 0))
+                ptrs2 = (self._ptr(nxt["x"]), args[0], args[1], None, self._ptr(y1), self._ptr(y2))
+                d2.cfg = self._autotune_conv(d2, ptrs2, exclude=SK_CFGS)
+                two = C.c_void_p(lib.y5_plan_create())
+                try:
+                    _lib.check(lib.y5_plan_add_conv(two, C.byref(d), *ptrs), lib)
+                    _lib.check(lib.y5_plan_add_conv(two, C.byref(d2), *ptrs2), lib)
+                    ms_t = C.c_float(0)
+                    _lib.check(lib.y5_plan_time_range(two, 0, 2, 10, st, C.byref(ms_t)), lib)
+                finally:
+                    lib.y5_plan_destroy(two)
+                if not ms_f.value < ms_t.value:
+                    return None
+        finally:
+            lib.y5_plan_destroy(fused)
+        d.cfg = d3.cfg
+        self._keep += [wp2, bp2]
+        self._conv_bufs.append((nxt, wp2, bp2, None, None))
+        return dict(args=args, name=nxt["name"])
 
     def _fused_head_args(self, op, d, ptrs):
         """Detect convolution of one level + its decode as ONE launch (csrc/head.hip) when only `z` is wanted (export mode: no raw
