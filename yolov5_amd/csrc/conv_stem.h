@@ -125,18 +125,30 @@ void y5_conv_stem_kernel(const Y5StemParams p) {
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; acc2[j][r] = 0.f; }
+    // all nine activation fragments first (36 dwords in flight), then the nine MFMAs back to back: left to the scheduler the loop was
+    // read -> lgkmcnt(0) -> MFMA per k-step, an LDS round trip in front of every multiply
+    half8_t afr[9];
 #pragma unroll
     for (int ks = 0; ks < 9; ++ks) {
       const uint32_t* src = reinterpret_cast<const uint32_t*>(st + (2 * ks + g) * 160 + 4 * frow + 12);
       uint4_t raw;
       raw[0] = src[0]; raw[1] = src[1]; raw[2] = src[2]; raw[3] = src[3];
-      const half8_t af = __builtin_bit_cast(half8_t, raw);
+      afr[ks] = __builtin_bit_cast(half8_t, raw);
+    }
+#ifndef Y5_EMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+    for (int ks = 0; ks < 9; ++ks) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        if (ks & 1) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j][ks], af, acc2[j], 0, 0, 0);
-        else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j][ks], af, acc[j], 0, 0, 0);
+        if (ks & 1) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j][ks], afr[ks], acc2[j], 0, 0, 0);
+        else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j][ks], afr[ks], acc[j], 0, 0, 0);
       }
     }
+#ifndef Y5_EMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[j] += acc2[j];
     // epilogue: bias + SiLU -> scratch (vacated stage) -> full-row 16-byte stores
