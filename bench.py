@@ -175,6 +175,33 @@ def cpu_baseline(seconds_budget=10.0):
             "sample": f"oracle/yolo_oracle.py forward+NMS, yolov5s fused fp32, {n} images of 3x640x640 (batches of {bs}), {dt:.1f} s"}
 
 
+def measured_ceilings(dev):
+    """What THIS box sustains, measured now: MFMA throughput and shader clock under back-to-back 32x32x16 fp16 MFMAs (y5_probe_mfma, no memory
+    traffic) and device-to-device copy bandwidth (read + write counted once each) -- the ceilings the practical per-layer floor is computed from."""
+    import ctypes as C
+
+    from yolov5_amd import _lib
+
+    lib = _lib.lib()
+    scratch = torch.empty(4 << 20, dtype=torch.uint8, device=dev)
+    tf, ghz = C.c_float(0), C.c_float(0)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(lib.y5_probe_mfma(C.c_void_p(scratch.data_ptr()), scratch.numel(), 20000, C.byref(tf), C.byref(ghz), st), lib)
+    a = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    copy_gbs = 10 * 2 * a.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del a, b
+    torch.cuda.empty_cache()
+    return {"mfma_sustained_tflops": round(tf.value, 1), "shader_clock_ghz_under_mfma": round(ghz.value, 3), "copy_gbytes_per_s": round(copy_gbs, 1)}
+
+
 def _pct(v, q):
     v = sorted(v)
     return v[min(len(v) - 1, max(0, int(round(q * (len(v) - 1)))))]
@@ -475,6 +502,19 @@ def main():
     achieved_bw = conv_by / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0  # GB/s
     nconv = sum(1 for i, _, _ in timed if i in fl)
     images_per_plan = eng.spec.B
+    # practical per-layer floor: every conv launch at the ceilings this box just showed (copy bandwidth, sustained MFMA rate)
+    ceil = None
+    if rank == 0:
+        try:
+            ceil = measured_ceilings(dev)
+            floor_ms = sum(max(by[i] / (ceil["copy_gbytes_per_s"] * 1e9), fl[i] / (ceil["mfma_sustained_tflops"] * 1e12)) for i, _, _ in timed if i in fl) * 1e3
+            nominal_ms = sum(max(by[i] / (HBM_PEAK_GBS * 1e9), fl[i] / (MFMA_PEAK_TFLOPS * 1e12)) for i, _, _ in timed if i in fl) * 1e3
+            ceil.update(per_layer_floor_ms=round(floor_ms, 4), per_layer_floor_ms_at_datasheet_peaks=round(nominal_ms, 4),
+                        conv_ms_over_floor=round(conv_ms / floor_ms, 3) if floor_ms > 0 else None,
+                        note="floor = sum over conv launches of max(algorithmic bytes / measured copy bandwidth, flops / measured sustained MFMA rate); "
+                             "the data-sheet figures (8 TB/s, 2.5 PFLOP/s at 2.4 GHz) are not what the part sustains")
+        except Exception as e:  # a probe must never take the headline down
+            ceil = {"error": f"{type(e).__name__}: {e}"}
     if a.op_table and rank == 0:
         cfg_of = {}
         ci = iter(eng.conv_cfgs)
@@ -532,7 +572,7 @@ def main():
             # arithmetic intensity of the conv stack at this config = algorithmic flops / algorithmic bytes (144 flop/B for
             # yolov5s bs=64 640^2) is below the ridge (2500 TF / 8 TB/s = 312 flop/B): the stack as a whole is HBM-bound;
             # the MFMA view of the same launches is kept beside it
-            "roofline": {"bound": "hbm", "kernel": "y5_conv_{igemm,pw,k3,stem,bneck}_kernel (all conv launches of one forward)",
+            "roofline": {"bound": "hbm", "kernel": "y5_conv_{igemm,h3,pw,k3,stem,bneck}_kernel (all conv launches of one forward)",
                          "achieved": round(achieved_bw, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_bw / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(a, conv_by * parts),
                          "timing": "in situ: HIP event between consecutive ops of one eager forward on the launch stream, median of 9 passes, "
@@ -543,7 +583,8 @@ def main():
                          "mfma_achieved_tflops": round(achieved, 2), "mfma_peak_tflops": MFMA_PEAK_TFLOPS,
                          "mfma_frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                          "conv_ms_per_step": round(conv_ms * parts, 4), "conv_ms_per_step_isolated": round(conv_ms_iso * parts, 4),
-                         "launches_per_step": nconv * parts, "other_kernels_ms_per_step": round(other_ms * parts, 4)},
+                         "launches_per_step": nconv * parts, "other_kernels_ms_per_step": round(other_ms * parts, 4),
+                         "measured_ceilings": ceil},
         }
         if gpu_state is not None:
             res["gpu_state"] = gpu_state

@@ -79,6 +79,10 @@ typedef struct {
 size_t y5_conv_sk_workspace_bytes(void);
 int y5_conv_set_sk_workspace(void* ws, size_t bytes, void* stream);
 int y5_conv_num_cfgs(void);
+/* Measurement aid: back-to-back independent v_mfma_f32_32x32x16_f16 on every SIMD (two waves each, no memory traffic) for `iters` iterations of
+ * eight MFMAs per wave; reports the TFLOP/s the device sustains and the shader clock it held meanwhile (s_memtime against the 100 MHz
+ * s_memrealtime).  scratch: >= 2 * CUs * 1024 + 64 bytes of device memory.  bench.py prints it beside the data-sheet peak. */
+int y5_probe_mfma(void* scratch, size_t scratch_bytes, int iters, float* tflops, float* shader_ghz, void* stream);
 int y5_conv_cfg_info(int cfg, int* bm_pixels, int* bn_channels, int* k_bytes_per_stage);
 
 int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w_packed, const float* bias,

@@ -4,14 +4,14 @@
     python scripts/rocprof_frac.py <..._kernel_trace.csv> [--gbytes G] [--out f.json]
 
 A forward is the run of dispatches from one stem launch (y5_conv_stem_kernel) to the next; the conv launches inside it
-(igemm / pw / k3 / stem / bneck / pw_head) are summed per forward from the trace's own begin/end timestamps (pure kernel
+(igemm / h3 / pw / k3 / stem / bneck / pw_head) are summed per forward from the trace's own begin/end timestamps (pure kernel
 durations: no dispatch gaps, so this sum is a lower bound of the in-situ event-to-event figure bench.py uses).  Groups that
 are not whole forwards (autotune bursts, isolated per-op timing) have a different launch count and are dropped by keeping the
 most common count only.  frac = algorithmic GB (bench.py's `algorithmic_gbytes_per_step`) / median sum / 8000 GB/s.
 """
 import argparse, collections, csv, json, statistics, sys
 
-CONV = ("conv_igemm", "conv_pw", "conv_k3", "conv_stem", "conv_bneck")
+CONV = ("conv_igemm", "conv_h3", "conv_pw", "conv_k3", "conv_stem", "conv_bneck")
 
 
 def main():

@@ -131,3 +131,59 @@ extern "C" int y5_h3_dbg_read(unsigned long long* dbg, unsigned long long* block
   return hipMemcpyFromSymbol(blocks, HIP_SYMBOL(y5_h3_blocks), sizeof(unsigned long long) * 4096) == hipSuccess ? 0 : -1;
 }
 #endif
+
+// ---- y5_probe_mfma: what the matrix cores of this device sustain (bench.py reports it beside the data-sheet peak) ---------------------------
+namespace {
+__global__ __launch_bounds__(256) void y5_mfma_probe_kernel(float* out, unsigned long long* ticks, int iters) {
+  float16_t acc[8];
+  for (int i = 0; i < 8; ++i)
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  half8_t a, b;
+  for (int e = 0; e < 8; ++e) { a[e] = (half_t)(threadIdx.x * 0.001f + e); b[e] = (half_t)(e * 0.5f - threadIdx.x * 0.002f); }
+#ifndef Y5_EMU
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < 8; ++i)
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+#ifndef Y5_EMU
+  if (threadIdx.x == 0 && blockIdx.x == 0) { ticks[0] = __builtin_amdgcn_s_memtime() - t0; ticks[1] = __builtin_amdgcn_s_memrealtime() - r0; }
+#endif
+}
+}  // namespace
+
+extern "C" int y5_probe_mfma(void* scratch, size_t scratch_bytes, int iters, float* tflops, float* shader_ghz, void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  int dev = 0, ncu = 0;
+  hipGetDevice(&dev);
+  hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  if (ncu <= 0) ncu = 256;
+  const int grid = 2 * ncu;
+  const size_t need = (size_t)grid * 256 * 4 + 64;
+  if (!scratch || scratch_bytes < need || iters < 1 || !tflops) return y5_fail(Y5_ERR_BAD_ARG, "probe_mfma: scratch too small / bad args");
+  float* out = static_cast<float*>(scratch);
+  unsigned long long* ticks = reinterpret_cast<unsigned long long*>(static_cast<char*>(scratch) + (size_t)grid * 256 * 4);
+  hipLaunchKernelGGL(y5_mfma_probe_kernel, dim3(grid), dim3(256), 0, st, out, ticks, iters / 10 + 1);  // warm-up
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return y5_fail(Y5_ERR_RUNTIME, "probe_mfma: event create failed");
+  hipEventRecord(e0, st);
+  hipLaunchKernelGGL(y5_mfma_probe_kernel, dim3(grid), dim3(256), 0, st, out, ticks, iters);
+  hipEventRecord(e1, st);
+  int rc = Y5_OK;
+  float ms = 0.f;
+  if (hipEventSynchronize(e1) != hipSuccess) rc = y5_fail(Y5_ERR_RUNTIME, "probe_mfma: sync failed");
+  else hipEventElapsedTime(&ms, e0, e1);
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  if (rc) return rc;
+  unsigned long long h[2] = {0, 0};
+  hipMemcpy(h, ticks, sizeof(h), hipMemcpyDeviceToHost);
+  *tflops = (float)((double)grid * 4 * iters * 8 * 32768.0 / (ms * 1e-3) / 1e12);
+  if (shader_ghz) *shader_ghz = h[1] ? (float)((double)h[0] / ((double)h[1] * 10.0)) : 0.f;
+  return y5_check_launch("y5_probe_mfma");
+}
