@@ -182,7 +182,11 @@ extern "C" int y5_probe_mfma(void* scratch, size_t scratch_bytes, int iters, flo
   hipEventDestroy(e1);
   if (rc) return rc;
   unsigned long long h[2] = {0, 0};
+#ifdef Y5_EMU
+  memcpy(h, ticks, sizeof(h));
+#else
   hipMemcpy(h, ticks, sizeof(h), hipMemcpyDeviceToHost);
+#endif
   *tflops = (float)((double)grid * 4 * iters * 8 * 32768.0 / (ms * 1e-3) / 1e12);
   if (shader_ghz) *shader_ghz = h[1] ? (float)((double)h[0] / ((double)h[1] * 10.0)) : 0.f;
   return y5_check_launch("y5_probe_mfma");

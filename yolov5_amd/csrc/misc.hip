@@ -50,23 +50,22 @@ extern "C" int y5_sppf_pool(void* buf, int dt, int B, int H, int W, int C, int l
   int gv = 2;
   if (const char* e = getenv("Y5_SPPF_GV")) gv = atoi(e);
   if (gv != 1 && gv != 2 && gv != 4 && gv != 8) gv = 2;
-  while (gv > 1 && ((C * es) % (16 * gv) != 0 || (size_t)H * W * 16 * gv * 2 > 150 * 1024)) gv >>= 1;
-  const size_t lds = (size_t)H * W * 16 * gv * 2;
+  while (gv > 1 && ((C * es) % (16 * gv) != 0 || (size_t)H * W * 16 * gv * 3 > 150 * 1024)) gv >>= 1;
+  const bool sep = (size_t)H * W * 16 * gv * 3 <= 150 * 1024;  // separable row / column passes need a third plane; otherwise the k x k window directly
+  const size_t lds = (size_t)H * W * 16 * gv * (sep ? 3 : 2);
   if (lds > 150 * 1024) return y5_fail(Y5_ERR_UNSUPPORTED, "sppf_pool: H*W plane does not fit in LDS");
   const dim3 g((unsigned)(B * (C * es / (16 * gv)))), b(256);
-  static bool attr = false;
-  if (!attr) {
-    hipFuncSetAttribute((const void*)y5_sppf_pool_kernel<half8_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    hipFuncSetAttribute((const void*)y5_sppf_pool_kernel<half8_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    hipFuncSetAttribute((const void*)y5_sppf_pool_kernel<half8_t, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    hipFuncSetAttribute((const void*)y5_sppf_pool_kernel<half8_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    hipFuncSetAttribute((const void*)y5_sppf_pool_kernel<float4_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    hipFuncSetAttribute((const void*)y5_sppf_pool_kernel<float4_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    hipFuncSetAttribute((const void*)y5_sppf_pool_kernel<float4_t, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    hipFuncSetAttribute((const void*)y5_sppf_pool_kernel<float4_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    attr = true;
-  }
-#define Y5_SPPF_LAUNCH(V, G) hipLaunchKernelGGL((y5_sppf_pool_kernel<V, G>), g, b, lds, st, (char*)buf, H, W, C * es, ld * es, k)
+#define Y5_SPPF_LAUNCH(V, G)                                                                                                             \
+  do {                                                                                                                                   \
+    static bool attr = false;                                                                                                            \
+    if (!attr) {                                                                                                                         \
+      hipFuncSetAttribute((const void*)y5_sppf_pool_kernel<V, G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);         \
+      hipFuncSetAttribute((const void*)y5_sppf_pool_kernel<V, G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);        \
+      attr = true;                                                                                                                       \
+    }                                                                                                                                    \
+    if (sep) hipLaunchKernelGGL((y5_sppf_pool_kernel<V, G, true>), g, b, lds, st, (char*)buf, H, W, C * es, ld * es, k);                 \
+    else hipLaunchKernelGGL((y5_sppf_pool_kernel<V, G, false>), g, b, lds, st, (char*)buf, H, W, C * es, ld * es, k);                    \
+  } while (0)
   if (dt == Y5_F16) {
     switch (gv) { case 8: Y5_SPPF_LAUNCH(half8_t, 8); break; case 4: Y5_SPPF_LAUNCH(half8_t, 4); break; case 2: Y5_SPPF_LAUNCH(half8_t, 2); break;
                   default: Y5_SPPF_LAUNCH(half8_t, 1); }

@@ -42,12 +42,13 @@ __global__ void y5_nhwc_to_nchw_kernel(const T* __restrict__ src, T* __restrict_
 // ---------------------------------------------------------------------------------------------------
 // GV = 16-byte vectors of one pixel a workgroup owns (1 = a 16-byte channel group; 2 / 4 / 8 = 32 / 64 / 128 contiguous bytes per
 // pixel instead of 16 bytes out of every 2 KiB-strided row -- against fewer, larger workgroups).
-template <typename V, int GV>  // V = half8_t (8 channels) or float4_t (4 channels): 16 bytes
+template <typename V, int GV, bool SEP = true>  // V = half8_t (8 channels) or float4_t (4 channels): 16 bytes; SEP: row pass + column pass (third LDS plane)
 __global__ void y5_sppf_pool_kernel(char* __restrict__ buf, int H, int W, int C_bytes, int ld_bytes, int k) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int HW = H * W;
   V* p0 = reinterpret_cast<V*>(smem);
   V* p1 = p0 + HW * GV;
+  V* tmp = p1 + HW * GV;
   const int groups = C_bytes / (16 * GV);
   const int b = blockIdx.x / groups, cg = blockIdx.x - b * groups;
   char* base = buf + (size_t)b * HW * ld_bytes + (size_t)cg * 16 * GV;
@@ -58,16 +59,39 @@ __global__ void y5_sppf_pool_kernel(char* __restrict__ buf, int H, int W, int C_
   V* in = p0;
   V* out = p1;
   for (int pass = 1; pass <= 3; ++pass) {
-    for (int v = threadIdx.x; v < n; v += blockDim.x) {
-      const int i = v / GV, gl = v % GV;
-      const int y = i / W, x = i - y * W;
-      const int y0 = y - r < 0 ? 0 : y - r, y1 = y + r >= H ? H - 1 : y + r;
-      const int x0 = x - r < 0 ? 0 : x - r, x1 = x + r >= W ? W - 1 : x + r;
-      V m = in[(y0 * W + x0) * GV + gl];
-      for (int yy = y0; yy <= y1; ++yy)
-        for (int xx = x0; xx <= x1; ++xx) m = __builtin_elementwise_max(m, in[(yy * W + xx) * GV + gl]);
-      out[v] = m;
-      *reinterpret_cast<V*>(base + (size_t)i * ld_bytes + (size_t)pass * C_bytes + gl * 16) = m;
+    // max is exact, so the k x k window is taken separably: k reads along the row into `tmp`, k reads down the column (2k instead of k^2
+    // LDS reads per output -- the kernel is bound by them)
+    if constexpr (SEP) {
+      for (int v = threadIdx.x; v < n; v += blockDim.x) {
+        const int i = v / GV, gl = v % GV;
+        const int y = i / W, x = i - y * W;
+        const int x0 = x - r < 0 ? 0 : x - r, x1 = x + r >= W ? W - 1 : x + r;
+        V m = in[(y * W + x0) * GV + gl];
+        for (int xx = x0 + 1; xx <= x1; ++xx) m = __builtin_elementwise_max(m, in[(y * W + xx) * GV + gl]);
+        tmp[v] = m;
+      }
+      __syncthreads();
+      for (int v = threadIdx.x; v < n; v += blockDim.x) {
+        const int i = v / GV, gl = v % GV;
+        const int y = i / W, x = i - y * W;
+        const int y0 = y - r < 0 ? 0 : y - r, y1 = y + r >= H ? H - 1 : y + r;
+        V m = tmp[(y0 * W + x) * GV + gl];
+        for (int yy = y0 + 1; yy <= y1; ++yy) m = __builtin_elementwise_max(m, tmp[(yy * W + x) * GV + gl]);
+        out[v] = m;
+        *reinterpret_cast<V*>(base + (size_t)i * ld_bytes + (size_t)pass * C_bytes + gl * 16) = m;
+      }
+    } else {  // planes too large for a third one: the k x k window directly
+      for (int v = threadIdx.x; v < n; v += blockDim.x) {
+        const int i = v / GV, gl = v % GV;
+        const int y = i / W, x = i - y * W;
+        const int y0 = y - r < 0 ? 0 : y - r, y1 = y + r >= H ? H - 1 : y + r;
+        const int x0 = x - r < 0 ? 0 : x - r, x1 = x + r >= W ? W - 1 : x + r;
+        V m = in[(y0 * W + x0) * GV + gl];
+        for (int yy = y0; yy <= y1; ++yy)
+          for (int xx = x0; xx <= x1; ++xx) m = __builtin_elementwise_max(m, in[(yy * W + xx) * GV + gl]);
+        out[v] = m;
+        *reinterpret_cast<V*>(base + (size_t)i * ld_bytes + (size_t)pass * C_bytes + gl * 16) = m;
+      }
     }
     __syncthreads();
     V* t = in; in = out; out = t;

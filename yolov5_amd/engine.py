@@ -271,7 +271,9 @@ class _Planner:
                 out[i] = buf
             elif isinstance(m, yo.Detect):
                 self.detect(m, ins)
-        if os.environ.get("Y5_HEAD_BRANCH", "1") != "0":
+        # opt-in since round 2: the A/B on MI355X (scripts/ab_head_branch.sh) shows no gain any more, and without overlapping launches the
+        # per-kernel durations of a rocprofv3 trace add up to the forward
+        if os.environ.get("Y5_HEAD_BRANCH", "0") != "0":
             self._schedule_heads()
         return spec
 
