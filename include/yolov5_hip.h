@@ -138,6 +138,10 @@ int y5_copy_slice(const void* src, int dtype, void* dst, int npix, int C, int ld
 int y5_detect_decode(const void* logits, int dtype, int B, int ny, int nx, int na, int no, int nm, int ld,
                      float stride, const float* anchors_px, void* z, int z_dtype, long long nrows_total,
                      long long row_off, void* raw, void* stream);
+/* ... additionally writing every row's objectness to obj_hint ((B, nrows_total), z's dtype; NULL: none) for y5_nms_batched_hint */
+int y5_detect_decode_hint(const void* logits, int dtype, int B, int ny, int nx, int na, int no, int nm, int ld, float stride,
+                          const float* anchors_px, void* z, int z_dtype, long long nrows_total, long long row_off, void* raw,
+                          void* obj_hint, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * y5_detect_head_fwd -- one pyramid level of `Detect.forward` in export / z-only mode (models/yolo.py:83-108 with
@@ -148,6 +152,8 @@ int y5_detect_decode(const void* logits, int dtype, int B, int ny, int nx, int n
  * ------------------------------------------------------------------------------------------------------- */
 int y5_detect_head_fwd(const y5_conv_desc* d, const void* x, const void* w_packed, const float* bias, int ny, int nx, float stride,
                        const float* anchors_px, void* z, long long nrows_total, long long row_off, void* stream);
+int y5_detect_head_fwd_hint(const y5_conv_desc* d, const void* x, const void* w_packed, const float* bias, int ny, int nx, float stride,
+                            const float* anchors_px, void* z, long long nrows_total, long long row_off, void* obj_hint, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * y5_nms_batched -- utils/general.py:658-767 `non_max_suppression` incl. torchvision.ops.nms (general.py:750).
@@ -163,6 +169,13 @@ size_t y5_nms_workspace_bytes(int bs, int n, int no, int nm, int flags, int max_
 int y5_nms_batched(const void* pred, int dtype, int bs, int n, int no, int nm, float conf_thres, float iou_thres,
                    int max_det, int max_nms, float max_wh, int flags, const int* classes, int nclasses,
                    float* out, int* out_count, void* workspace, size_t workspace_bytes, void* stream);
+/* The same with an objectness HINT: obj_hint (bs, n), pred's dtype, holds (approximately) pred[..., 4] -- the plane y5_detect_decode_hint /
+ * y5_detect_head_fwd_hint write beside z.  The filter reads 2 bytes per row instead of the whole row and fetches a row from `pred` only where
+ * the plane cannot exclude it with a 2^-8 relative margin; every decision is then taken on `pred` itself, so results are those of y5_nms_batched.
+ * obj_hint = NULL: identical to y5_nms_batched. */
+int y5_nms_batched_hint(const void* pred, int dtype, int bs, int n, int no, int nm, float conf_thres, float iou_thres,
+                        int max_det, int max_nms, float max_wh, int flags, const int* classes, int nclasses, float* out,
+                        int* out_count, void* workspace, size_t workspace_bytes, const void* obj_hint, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * y5_conv2d_wgrad -- weight gradient of the convolution described by `d` (same descriptor as the forward call; act,
@@ -381,6 +394,7 @@ int y5_plan_add_bottleneck(y5_plan*, const void* x, int ldx, const void* w1_pack
                            const float* bias2, int Kpad2, void* y, int ldy, int B, int H, int W, int C, int add);
 int y5_plan_add_conv_k3pw(y5_plan*, const y5_conv_desc* d, const void* x, const void* w1_packed, const float* bias1, const void* w2_packed,
                           const float* bias2, int C3, int Npad2, int Kpad2, int act2, void* y, int ldy, void* y2, int ld2, int split_n);
+int y5_plan_set_obj_hint(y5_plan*, int op_index, void* obj_hint);  /* Detect decode / fused head op: also write the objectness plane */
 int y5_plan_add_nop(y5_plan*);  /* placeholder op: keeps the op numbering of the conv + decode form next to a fused head */
 int y5_plan_add_conv_stem(y5_plan*, const void* x_nchw, int B, int H, int W, const void* w_stem, const float* bias, int C2,
                           int Npad, void* y, int ldy);

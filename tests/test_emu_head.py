@@ -50,6 +50,15 @@ def test_fused_head_bit_identical_to_conv_plus_decode(B, ny, nx, max_blocks, row
     assert (z[:, :row_off] == 7.0).all() and (z[:, row_off + 3 * npix:] == 7.0).all()  # rows of other levels untouched
     zw = z[:, row_off:row_off + 3 * npix].astype(np.float32)
     assert np.isfinite(zw).all() and zw[..., 4:].max() <= 1.0 and zw[..., 2:4].min() >= 0.0
+    # the hint form: same z, plus a plane holding z[..., 4] bit for bit (one more store per anchor block in the counted-vmcnt pipeline)
+    z2 = aligned((B, nrows, 85), np.float16, 7.0)
+    hint = aligned((B, nrows), np.float16, -3.0)
+    rc = lib.y5_detect_head_fwd_hint(C.byref(d), ptr(x), ptr(wp), ptr(bp), ny, nx, 8.0, anchors, ptr(z2), nrows, row_off, ptr(hint), None)
+    assert rc == 0, lib.y5_last_error()
+    assert np.array_equal(z2.view(np.uint16), z_ref.view(np.uint16))
+    sl = slice(row_off, row_off + 3 * npix)
+    assert np.array_equal(hint[:, sl].view(np.uint16), z2[:, sl, 4].view(np.uint16))
+    assert (hint[:, :row_off] == -3.0).all() and (hint[:, row_off + 3 * npix:] == -3.0).all()
 
 
 def test_fused_head_rejects_other_shapes():

@@ -174,3 +174,56 @@ def test_layout_and_copy_kernels_emulated():
     e = aligned((B, H, W, 24), np.float16, 1.0)
     assert lib.y5_copy_slice(ptr(s), _lib.Y5_F16, ptr(e[..., 16:]), B * H * W, 8, 8, 24, None) == 0
     assert np.array_equal(e[..., 16:], s) and np.all(e[..., :16] == 1)
+
+
+# ---- objectness hint plane (y5_detect_decode_hint -> y5_nms_batched_hint) ------------------------------------------------------------
+def _run_nms_hint(lib, pred, hint, dtype, **kw):
+    bs, n, no = pred.shape
+    p = aligned(pred.shape, dtype); p[...] = pred.astype(dtype)
+    h = aligned((bs, n), dtype); h[...] = hint.astype(dtype)
+    max_det, max_nms = kw.get("max_det", 300), 30000
+    flags = _lib.NMS_MULTI_LABEL if kw.get("multi_label") else 0
+    wsb = lib.y5_nms_workspace_bytes(bs, n, no, 0, flags, max_nms)
+    ws = aligned((wsb,), np.uint8)
+    out = aligned((bs, max_det, 6), np.float32, -1.0)
+    cnt = aligned((bs,), np.int32, -1)
+    rc = lib.y5_nms_batched_hint(ptr(p), _lib.Y5_F16 if dtype == np.float16 else _lib.Y5_F32, bs, n, no, 0, kw.get("conf_thres", 0.25), kw.get("iou_thres", 0.45),
+                                 max_det, max_nms, 7680.0, flags, None, 0, ptr(out), ptr(cnt), ptr(ws), wsb, ptr(h), None)
+    assert rc == 0, lib.y5_last_error()
+    return [out[i, :cnt[i]].copy() for i in range(bs)]
+
+
+@pytest.mark.parametrize("dtype,multi", [(np.float16, False), (np.float32, False), (np.float16, True)])
+def test_nms_with_objectness_hint_is_the_plain_result(dtype, multi):
+    """The plane is a hint: rows it cannot exclude with the margin are decided on `pred` itself.  Exact copy of pred[..., 4], a copy off by
+    one / two fp16 ulps in either direction, and a plane that says 1.0 everywhere all give the detections of the plain filter."""
+    lib = emu()
+    p = detgen.synth_predictions(2, 1500, 85, obj_pow=4, seed=31).astype(dtype)
+    kw = dict(conf_thres=0.25, iou_thres=0.45, max_det=300, multi_label=multi)
+    ref = run_nms(lib, p, dtype=dtype, **kw)
+    obj = p[..., 4].astype(np.float16)
+    ulp = lambda a, k: (a.view(np.int16) + np.int16(k)).view(np.float16)  # noqa: E731
+    for hint in (obj, ulp(obj.copy(), 1), ulp(obj.copy(), -2), np.ones_like(obj)):
+        res = _run_nms_hint(lib, p, hint.astype(np.float32), dtype, **kw)
+        for r, o in zip(res, ref):
+            assert np.array_equal(r, o)
+
+
+def test_decode_hint_plane_equals_z_objectness():
+    """y5_detect_decode_hint: the plane holds z[..., 4] of every row it decodes (same formula as the path that writes z), untouched elsewhere."""
+    lib = emu()
+    B, ny, nx, na, no, ld, row_off = 2, 8, 8, 3, 85, 256, 64
+    lg = aligned((B, ny, nx, ld), np.float16, 1.0)
+    lg[..., : na * no] = detgen.uniform((B, ny, nx, na * no), -5, 5, name="lgh2", seed=5).astype(np.float16)
+    apx = (C.c_float * 6)(10, 13, 16, 30, 33, 23)
+    nrows = row_off + na * ny * nx + 8
+    for with_raw in (False, True):
+        z = aligned((B, nrows, no), np.float16, -1.0)
+        raw = aligned((B, na, ny, nx, no), np.float16, -1.0)
+        hint = aligned((B, nrows), np.float16, -7.0)
+        rc = lib.y5_detect_decode_hint(ptr(lg), _lib.Y5_F16, B, ny, nx, na, no, 0, ld, 8.0, apx, ptr(z), _lib.Y5_F16, nrows, row_off,
+                                       ptr(raw) if with_raw else None, ptr(hint), None)
+        assert rc == 0, lib.y5_last_error()
+        sl = slice(row_off, row_off + na * ny * nx)
+        assert np.array_equal(hint[:, sl].view(np.uint16), z[:, sl, 4].view(np.uint16))
+        assert np.all(hint[:, :row_off] == -7.0) and np.all(hint[:, row_off + na * ny * nx:] == -7.0)

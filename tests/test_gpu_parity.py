@@ -430,3 +430,34 @@ def test_plan_k3pw_fused_equals_unfused_on_gpu(dev, monkeypatch):
         assert any(n.startswith("conv+pw:") for n in eng.op_names) == (mode == "1"), eng.op_names
     u, v = outs["0"], outs["1"]
     assert float((u - v).abs().max()) <= 4e-3 * max(1.0, float(u.abs().max()))
+
+
+def test_nms_objectness_hint_from_the_engine(dev):
+    """The engine writes an objectness plane beside z (y5_plan_set_obj_hint) and hangs it on the tensor; non_max_suppression(z) then filters through
+    the plane.  Same detections, bit for bit, as on a copy of z (no plane: the filter reads the rows), for the conv + decode levels and the fused P3 head;
+    an in-place edit of z drops the plane."""
+    import bench
+    from yolov5_amd.general import non_max_suppression
+
+    model = bench.build_model("yolov5s", dev)
+    model.model[-1].export = True
+    x = torch.rand((4, 3, 640, 640), generator=torch.Generator().manual_seed(3)).half().to(dev)
+    bench.calibrate_head(model, x)
+    z = model(x)[0]
+    tag = getattr(z, "_y5_obj_hint", None)
+    assert tag is not None and tuple(tag[0].shape) == tuple(z.shape[:2])
+    assert torch.equal(tag[0], z[..., 4])                       # the plane is z's objectness, bit for bit
+    a = non_max_suppression(z, 0.25, 0.45, max_det=1000)        # through the plane
+    b = non_max_suppression(z.clone(), 0.25, 0.45, max_det=1000)
+    assert sum(len(t) for t in a) > 100
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    c = non_max_suppression(z, 0.001, 0.6, max_det=300, multi_label=True)   # val.py settings: nearly every row passes the plane
+    d = non_max_suppression(z.clone(), 0.001, 0.6, max_det=300, multi_label=True)
+    for u, v in zip(c, d):
+        assert torch.equal(u, v)
+    z[0, 0, 4] = 0.0                                             # in-place edit: version counter moves, the plane is ignored from here on
+    e = non_max_suppression(z, 0.25, 0.45, max_det=1000)
+    f = non_max_suppression(z.clone(), 0.25, 0.45, max_det=1000)
+    for u, v in zip(e, f):
+        assert torch.equal(u, v)

@@ -83,6 +83,13 @@ EXPORTS = {
     "y5_detect_decode": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_float, C.POINTER(C.c_float), C.c_void_p, C.c_int, C.c_longlong, C.c_longlong,
                                    C.c_void_p, C.c_void_p]),
+    "y5_detect_decode_hint": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_float, C.POINTER(C.c_float), C.c_void_p, C.c_int, C.c_longlong, C.c_longlong,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    "y5_nms_batched_hint": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                      C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "y5_plan_set_obj_hint": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "y5_nms_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "y5_nms_batched": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                  C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
@@ -133,6 +140,8 @@ EXPORTS = {
                                         C.c_void_p, C.c_int]),
     "y5_detect_head_fwd": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_float),
                                      C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p]),
+    "y5_detect_head_fwd_hint": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_float),
+                                          C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p]),
     "y5_plan_add_detect_head": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
                                           C.POINTER(C.c_float), C.c_void_p, C.c_longlong, C.c_longlong]),
     "y5_plan_add_nop": (C.c_int, [C.c_void_p]),

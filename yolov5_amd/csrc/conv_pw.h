@@ -34,9 +34,10 @@ struct Y5HeadParams {
   unsigned inv_nx;         // ceil(2^32 / nx)
   float stride;
   float anchors_px[6];     // 3 anchors x (w, h) in pixels
+  void* obj_hint;          // HINT kernels: (B, nrows_total) fp16 plane receiving a copy of every row's objectness (z[..., 4]) for the NMS filter
 };
 
-template <int KC, int RB, int NT, int S, bool UP2, bool ACT, int OS, bool DEC>
+template <int KC, int RB, int NT, int S, bool UP2, bool ACT, int OS, bool DEC, bool HINT = false>
 __device__ __forceinline__ void y5_conv_pw_body(const Y5ConvParams& p, const Y5HeadParams* hp) {
   typedef half_t T;
   static_assert(NT % OS == 0, "output split must divide the channel sub-tiles");
@@ -52,7 +53,7 @@ __device__ __forceinline__ void y5_conv_pw_body(const Y5ConvParams& p, const Y5H
   constexpr int SPR = NPH / 8;                              // 16-byte slots per output row (of one epilogue group)
   constexpr int RPP = 64 / SPR;                             // output rows per store pass
   constexpr int NPASS = 32 / RPP;
-  constexpr int SP = DEC ? 3 * ((32 * 85 / 8 + 63) / 64) : NPASS * OS * (UP2 ? 5 : 1);  // stores per tile per wave
+  constexpr int SP = DEC ? 3 * ((32 * 85 / 8 + 63) / 64 + (HINT ? 1 : 0)) : NPASS * OS * (UP2 ? 5 : 1);  // stores per tile per wave
   constexpr int SWM = SPR >= 8 ? 7 : SPR - 1;               // scratch swizzle mask
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -214,6 +215,10 @@ __device__ __forceinline__ void y5_conv_pw_body(const Y5ConvParams& p, const Y5H
           const int v = it * 64 + lane;
           if (v < NV) *reinterpret_cast<uint4_t*>(zrow + v * 8) = *reinterpret_cast<const uint4_t*>(sc + v * 8);
         }
+        if constexpr (HINT) {  // the rows' objectness, bit for bit what z holds (one more store per anchor block: counted in SP)
+          if (lane < 32)
+            static_cast<half_t*>(hd.obj_hint)[(long long)bimg * hd.nrows_total + hd.row_off + (long long)a * hd.npix + pix0 + lane] = sc[lane * NO + 4];
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();  // the scratch is rewritten by the next anchor / refilled by the next tile's loads
       }
@@ -278,8 +283,8 @@ void y5_conv_pw_kernel(const Y5ConvParams p) {
 }
 
 // 1x1 Detect convolution (128 -> 3 x 85 channels) + Detect decode in one pass (export / z-only mode)
-template <int KC, int RB, int NT, int S, int OS>
+template <int KC, int RB, int NT, int S, int OS, bool HINT = false>
 __global__ __launch_bounds__(256)
 void y5_conv_pw_head_kernel(const Y5ConvParams p, const Y5HeadParams h) {
-  y5_conv_pw_body<KC, RB, NT, S, false, false, OS, true>(p, &h);
+  y5_conv_pw_body<KC, RB, NT, S, false, false, OS, true, HINT>(p, &h);
 }

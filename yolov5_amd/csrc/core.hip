@@ -170,6 +170,13 @@ extern "C" int y5_plan_add_conv_k3pw(y5_plan* pl, const y5_conv_desc* d, const v
   pl->ops.push_back(o);
   return Y5_OK;
 }
+// Detect decode / fused head op `op`: also write every row's objectness to `hint` ((B, nrows_total), z's dtype) -- the NMS filter's shortcut
+extern "C" int y5_plan_set_obj_hint(y5_plan* pl, int op, void* hint) {
+  if (!pl || op < 0 || op >= (int)pl->ops.size() || (pl->ops[op].kind != OP_DECODE && pl->ops[op].kind != OP_HEAD))
+    return y5_fail(Y5_ERR_BAD_ARG, "plan_set_obj_hint: not a Detect decode / fused head op");
+  pl->ops[op].p3 = hint;
+  return Y5_OK;
+}
 extern "C" int y5_plan_add_nop(y5_plan* pl) {
   if (!pl) return y5_fail(Y5_ERR_BAD_ARG, "plan: null");
   Op o{}; o.kind = OP_NOP;
@@ -201,6 +208,7 @@ extern "C" int y5_plan_rebind_output(y5_plan* pl, int first, int last, const voi
     Op& o = pl->ops[k];
     if (o.q0 == old_ptr) { o.q0 = new_ptr; ++n; }
     if (o.q1 == old_ptr && o.kind != OP_BNECK) { o.q1 = new_ptr; ++n; }
+    if (o.p3 == old_ptr && (o.kind == OP_DECODE || o.kind == OP_HEAD)) { o.p3 = new_ptr; ++n; }  // objectness hint plane (y5_plan_set_obj_hint)
   }
   if (!n) return y5_fail(Y5_ERR_BAD_ARG, "plan_rebind_output: no op writes that pointer");
   return Y5_OK;
@@ -243,7 +251,7 @@ static int run_op(const Op& o, void* st) {
     case OP_UPS: return y5_upsample2x(o.p0, o.i[0], o.q0, o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], o.i[6], st);
     case OP_COPY: return y5_copy_slice(o.p0, o.i[0], o.q0, o.i[1], o.i[2], o.i[3], o.i[4], st);
     case OP_HEAD:
-      return y5_detect_head_fwd(&o.conv, o.p0, o.p1, (const float*)o.p2, o.i[0], o.i[1], o.f[0], o.anchors, o.q0, o.l[0], o.l[1], st);
+      return y5_detect_head_fwd_hint(&o.conv, o.p0, o.p1, (const float*)o.p2, o.i[0], o.i[1], o.f[0], o.anchors, o.q0, o.l[0], o.l[1], const_cast<void*>(o.p3), st);
     case OP_NOP: return Y5_OK;
     case OP_K3PW:
       return y5_conv_k3pw_fwd(&o.conv, o.p0, o.p1, (const float*)o.p2, o.p3, (const float*)(uintptr_t)o.l[0], o.i[0], o.i[1], o.i[2], o.i[3], o.q0, o.i[4],
@@ -252,8 +260,8 @@ static int run_op(const Op& o, void* st) {
       return y5_bottleneck_fwd(o.p0, o.i[0], o.p1, (const float*)o.p2, o.i[1], o.p3, (const float*)o.q1, o.i[2], o.q0, o.i[3], o.i[4], o.i[5], o.i[6],
                                o.i[7], o.i[8], 0, st);
     case OP_DECODE:
-      return y5_detect_decode(o.p0, o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], o.i[6], o.i[7], o.f[0], o.anchors, o.q0, o.i[8],
-                              o.l[0], o.l[1], o.q1, st);
+      return y5_detect_decode_hint(o.p0, o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], o.i[6], o.i[7], o.f[0], o.anchors, o.q0, o.i[8],
+                                   o.l[0], o.l[1], o.q1, const_cast<void*>(o.p3), st);
   }
   return y5_fail(Y5_ERR_BAD_ARG, "plan: unknown op");
 }

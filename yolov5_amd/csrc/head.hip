@@ -9,8 +9,8 @@
 #include "conv_pw.h"
 #include "y5_host.h"
 
-extern "C" int y5_detect_head_fwd(const y5_conv_desc* d, const void* x, const void* w_packed, const float* bias, int ny, int nx, float stride,
-                                  const float* anchors_px, void* z, long long nrows_total, long long row_off, void* stream_) {
+extern "C" int y5_detect_head_fwd_hint(const y5_conv_desc* d, const void* x, const void* w_packed, const float* bias, int ny, int nx, float stride,
+                                       const float* anchors_px, void* z, long long nrows_total, long long row_off, void* obj_hint, void* stream_) {
   if (!d || !x || !w_packed || !bias || !anchors_px || !z) return y5_fail(Y5_ERR_BAD_ARG, "detect_head: null pointer");
   constexpr int KC = 2, RB = 128, NT = 8, S = 2, OS = 2;
   const long long npix = (long long)ny * nx;
@@ -37,12 +37,15 @@ extern "C" int y5_detect_head_fwd(const y5_conv_desc* d, const void* x, const vo
   h.inv_nx = (unsigned)((0x100000000ULL + (unsigned)nx - 1) / (unsigned)nx);
   h.stride = stride;
   for (int i = 0; i < 6; ++i) h.anchors_px[i] = anchors_px[i];
+  h.obj_hint = obj_hint;
+  if (obj_hint && ((uintptr_t)obj_hint & 15)) return y5_fail(Y5_ERR_BAD_ARG, "detect_head: hint plane must be 16-byte aligned");
 
   const size_t lds = y5_conv_pw_lds_bytes<KC, RB, NT, S, OS>();
-  auto kern = y5_conv_pw_head_kernel<KC, RB, NT, S, OS>;
+  auto kern = obj_hint ? y5_conv_pw_head_kernel<KC, RB, NT, S, OS, true> : y5_conv_pw_head_kernel<KC, RB, NT, S, OS, false>;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(y5_conv_pw_head_kernel<KC, RB, NT, S, OS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(y5_conv_pw_head_kernel<KC, RB, NT, S, OS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   const long long nbt = ((long long)(p.M >> 5) + 3) >> 2;
@@ -63,4 +66,9 @@ extern "C" int y5_detect_head_fwd(const y5_conv_desc* d, const void* x, const vo
   if (G >= 8) G &= ~7LL;
   hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(256), lds, static_cast<hipStream_t>(stream_), p, h);
   return y5_check_launch("y5_detect_head_fwd");
+}
+
+extern "C" int y5_detect_head_fwd(const y5_conv_desc* d, const void* x, const void* w_packed, const float* bias, int ny, int nx, float stride,
+                                  const float* anchors_px, void* z, long long nrows_total, long long row_off, void* stream_) {
+  return y5_detect_head_fwd_hint(d, x, w_packed, bias, ny, nx, stride, anchors_px, z, nrows_total, row_off, nullptr, stream_);
 }

@@ -99,14 +99,14 @@ extern "C" int y5_copy_slice(const void* src, int dt, void* dst, int npix, int C
   return y5_check_launch("y5_copy_slice");
 }
 
-extern "C" int y5_detect_decode(const void* logits, int dt, int B, int ny, int nx, int na, int no, int nm, int ld, float stride,
-                                const float* anchors_px, void* z, int zdt, long long nrows_total, long long row_off, void* raw,
-                                void* stream_) {
+extern "C" int y5_detect_decode_hint(const void* logits, int dt, int B, int ny, int nx, int na, int no, int nm, int ld, float stride,
+                                     const float* anchors_px, void* z, int zdt, long long nrows_total, long long row_off, void* raw,
+                                     void* obj_hint, void* stream_) {
   hipStream_t st = static_cast<hipStream_t>(stream_);
   if (!logits || (!z && !raw) || !anchors_px || na < 1 || na > 8 || ld < na * no || nm < 0 || nm > no - 5)
     return y5_fail(Y5_ERR_BAD_ARG, "detect_decode: bad args");
   Y5DecodeParams p{};
-  p.logits = logits; p.z = z; p.raw = raw;
+  p.logits = logits; p.z = z; p.raw = raw; p.obj_hint = obj_hint;
   p.nrows_total = nrows_total; p.row_off = row_off;
   p.ny = ny; p.nx = nx; p.na = na; p.no = no; p.nm = nm; p.ld = ld; p.stride = stride;
   for (int i = 0; i < na * 2; ++i) p.anchors_px[i] = anchors_px[i];
@@ -132,6 +132,12 @@ extern "C" int y5_detect_decode(const void* logits, int dt, int B, int ny, int n
   else if (dt == Y5_F32 && zdt == Y5_F32) hipLaunchKernelGGL((y5_detect_decode_kernel<float, float>), g, b, lds, st, p);
   else return y5_fail(Y5_ERR_BAD_ARG, "detect_decode: dtype pair");
   return y5_check_launch("y5_detect_decode");
+}
+
+extern "C" int y5_detect_decode(const void* logits, int dt, int B, int ny, int nx, int na, int no, int nm, int ld, float stride,
+                                const float* anchors_px, void* z, int zdt, long long nrows_total, long long row_off, void* raw,
+                                void* stream_) {
+  return y5_detect_decode_hint(logits, dt, B, ny, nx, na, no, nm, ld, stride, anchors_px, z, zdt, nrows_total, row_off, raw, nullptr, stream_);
 }
 
 // tiled fp16 head-layout kernels used by the training path (train_misc.hip declares the simple per-element versions)

@@ -144,6 +144,7 @@ struct Y5DecodeParams {
   unsigned inv_nx;  // ceil(2^32 / nx): pix / nx for pix < 2^16 (fast path only when ny*nx < 65536)
   float stride;
   float anchors_px[16];  // na*2
+  void* obj_hint;        // optional (B, nrows_total) plane of z's dtype: a copy of every row's objectness for the NMS filter (y5_nms_batched_hint)
 };
 
 template <typename T>
@@ -213,6 +214,16 @@ void y5_detect_decode_kernel(const Y5DecodeParams p) {
         q[3] = (T)(s2[3] * s2[3] * ah);
       }
       __syncthreads();
+    }
+  }
+  if (p.obj_hint && p.z) {
+    // objectness of every (anchor, pixel) row with the formula of the path that writes z below (rcp form in the light path, true division
+    // otherwise).  The NMS filter treats it as a HINT -- rows it cannot exclude with a margin are read from z -- so exactness is not required.
+    for (int rix = threadIdx.x; rix < np * p.na; rix += blockDim.x) {
+      const int a = rix / np, pl = rix - a * np;
+      const float v = (float)tile[pl * p.ld + a * p.no + 4];
+      const float sgm = light ? __builtin_amdgcn_rcpf(1.0f + __expf(-v)) : y5_sigmoid(v);
+      static_cast<Z*>(p.obj_hint)[(long long)b * p.nrows_total + p.row_off + (long long)a * npix + pix0 + pl] = (Z)sgm;
     }
   }
   for (int a = 0; a < p.na; ++a) {

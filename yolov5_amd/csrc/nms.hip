@@ -6,7 +6,7 @@
 #include "y5_host.h"
 
 namespace {
-struct Layout { size_t off_count, off_keys, off_cls, off_gbox, total; long long cap, cap_pad, gcap; };
+struct Layout { size_t off_count, off_keys, off_cls, off_gbox, off_rows, total; long long cap, cap_pad, gcap; };
 Layout layout(int bs, int n, int no, int nm, int flags, int max_nms) {
   Layout L{};
   const int nc = no - 5 - nm;
@@ -15,13 +15,14 @@ Layout layout(int bs, int n, int no, int nm, int flags, int max_nms) {
   while (p2 < L.cap) p2 <<= 1;
   L.cap_pad = p2;
   size_t o = 0;
-  L.off_count = o; o += ((size_t)bs * 4 + 255) & ~(size_t)255;
+  L.off_count = o; o += ((size_t)bs * 8 + 255) & ~(size_t)255;  // count[bs] + rcount[bs] (hint path)
   L.off_keys = o; o += ((size_t)bs * L.cap_pad * 8 + 255) & ~(size_t)255;
   L.off_cls = o; o += ((size_t)bs * n + 255) & ~(size_t)255;
   L.gcap = L.cap < max_nms ? L.cap : max_nms;
   L.gcap = (L.gcap + 63) / 64 * 64;  // whole chunks of 64 candidates (field planes, nms_kernels.h)
   if (L.gcap < 64) L.gcap = 64;
   L.off_gbox = o; o += ((size_t)bs * L.gcap * Y5_NMS_REC * 4 + 255) & ~(size_t)255;
+  L.off_rows = o; o += ((size_t)bs * n * 4 + 255) & ~(size_t)255;  // hint path: rows the objectness plane could not exclude
   L.total = o;
   return L;
 }
@@ -31,9 +32,9 @@ extern "C" size_t y5_nms_workspace_bytes(int bs, int n, int no, int nm, int flag
   return layout(bs, n, no, nm, flags, max_nms > 0 ? max_nms : 30000).total;
 }
 
-extern "C" int y5_nms_batched(const void* pred, int dt, int bs, int n, int no, int nm, float conf_thres, float iou_thres, int max_det,
-                              int max_nms, float max_wh, int flags, const int* classes, int nclasses, float* out, int* out_count,
-                              void* ws, size_t ws_bytes, void* stream_) {
+extern "C" int y5_nms_batched_hint(const void* pred, int dt, int bs, int n, int no, int nm, float conf_thres, float iou_thres, int max_det,
+                                   int max_nms, float max_wh, int flags, const int* classes, int nclasses, float* out, int* out_count,
+                                   void* ws, size_t ws_bytes, const void* obj_hint, void* stream_) {
   hipStream_t st = static_cast<hipStream_t>(stream_);
   const int nc = no - 5 - nm;
   if (!pred || !out || !out_count || !ws || bs <= 0 || n <= 0 || nc < 1 || nc > 256 || nm < 0)
@@ -48,19 +49,21 @@ extern "C" int y5_nms_batched(const void* pred, int dt, int bs, int n, int no, i
   if (ws_bytes < L.total || ((uintptr_t)ws & 255)) return y5_fail(Y5_ERR_WORKSPACE, "nms: workspace too small or misaligned");
 
   Y5NmsParams p{};
-  p.pred = pred; p.bs = bs; p.n = n; p.no = no; p.nc = nc; p.nm = nm;
+  p.pred = pred; p.obj_hint = obj_hint; p.bs = bs; p.n = n; p.no = no; p.nc = nc; p.nm = nm;
   p.conf_thres = conf_thres; p.iou_thres = iou_thres; p.max_wh = max_wh;
   p.max_det = max_det; p.max_nms = max_nms; p.flags = flags;
   p.classes = nclasses > 0 ? classes : nullptr; p.nclasses = nclasses;
   p.out = out; p.out_count = out_count;
   char* w = static_cast<char*>(ws);
   p.count = reinterpret_cast<int*>(w + L.off_count);
+  p.rcount = p.count + bs;
+  p.rows = reinterpret_cast<int*>(w + L.off_rows);
   p.keys = reinterpret_cast<unsigned long long*>(w + L.off_keys);
   p.best_cls = reinterpret_cast<unsigned char*>(w + L.off_cls);
   p.gbox = reinterpret_cast<float*>(w + L.off_gbox);
   p.cap = L.cap; p.cap_pad = L.cap_pad; p.gcap = L.gcap;
 
-  if (hipMemsetAsync(p.count, 0, (size_t)bs * 4, st) != hipSuccess) return y5_fail(Y5_ERR_RUNTIME, "nms: memset failed");
+  if (hipMemsetAsync(p.count, 0, (size_t)bs * 8, st) != hipSuccess) return y5_fail(Y5_ERR_RUNTIME, "nms: memset failed");
   const dim3 fg((unsigned)((n + 255) / 256), (unsigned)bs), fb(256);
   static bool attr = false;
   if (!attr) {
@@ -75,7 +78,24 @@ extern "C" int y5_nms_batched(const void* pred, int dt, int bs, int n, int no, i
     const int es = dt == Y5_F16 ? 2 : 4;
     int rows = (int)(65536 / ((long long)no * es)) / 64 * 64;
     if (rows > 256) rows = 256;
-    if (rows >= 64) {
+    if (p.obj_hint) {
+      // objectness plane beside z: a scan of the plane lists the rows it cannot exclude (wave-aggregated compaction), then one thread per
+      // listed row decides it on `pred` itself (grid-stride over the list: 8 workgroups of 256 threads per image)
+      const dim3 rg(8, (unsigned)bs);
+      const size_t rl = (size_t)256 * no * es;  // the workgroup's rows
+      if (rl > 64 * 1024) {  // very wide rows: the plain filters below (obj_hint unused)
+        p.obj_hint = nullptr;
+      } else if (dt == Y5_F16) {
+        hipLaunchKernelGGL((y5_nms_hint_scan_kernel<half_t>), fg, fb, 0, st, p);
+        hipLaunchKernelGGL((y5_nms_hint_rows_kernel<half_t>), rg, dim3(256), rl, st, p);
+      } else {
+        hipLaunchKernelGGL((y5_nms_hint_scan_kernel<float>), fg, fb, 0, st, p);
+        hipLaunchKernelGGL((y5_nms_hint_rows_kernel<float>), rg, dim3(256), rl, st, p);
+      }
+    }
+    if (p.obj_hint) {
+      // (filtered above through the objectness plane)
+    } else if (rows >= 64) {
       const dim3 sg((unsigned)((n + rows - 1) / rows), (unsigned)bs);
       const size_t lds = (size_t)rows * no * es;
       if (dt == Y5_F16) hipLaunchKernelGGL((y5_nms_filter_kernel<half_t, true>), sg, dim3(rows), lds, st, p);
@@ -95,4 +115,11 @@ extern "C" int y5_nms_batched(const void* pred, int dt, int bs, int n, int no, i
   if (dt == Y5_F16) hipLaunchKernelGGL((y5_nms_greedy_kernel<half_t>), dim3((unsigned)bs), dim3(64 * Y5_NMS_GREEDY_WAVES), greedy_lds, st, p);
   else hipLaunchKernelGGL((y5_nms_greedy_kernel<float>), dim3((unsigned)bs), dim3(64 * Y5_NMS_GREEDY_WAVES), greedy_lds, st, p);
   return y5_check_launch("y5_nms_batched");
+}
+
+extern "C" int y5_nms_batched(const void* pred, int dt, int bs, int n, int no, int nm, float conf_thres, float iou_thres, int max_det,
+                              int max_nms, float max_wh, int flags, const int* classes, int nclasses, float* out, int* out_count,
+                              void* ws, size_t ws_bytes, void* stream_) {
+  return y5_nms_batched_hint(pred, dt, bs, n, no, nm, conf_thres, iou_thres, max_det, max_nms, max_wh, flags, classes, nclasses, out, out_count, ws, ws_bytes,
+                             nullptr, stream_);
 }

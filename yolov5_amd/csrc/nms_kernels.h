@@ -18,6 +18,7 @@
 
 struct Y5NmsParams {
   const void* pred;
+  const void* obj_hint;  // optional (bs, n) plane of pred's dtype: (approximately) pred[..., 4]; rows it excludes with a margin are never read
   int bs, n, no, nc, nm;
   float conf_thres, iou_thres, max_wh;
   int max_det, max_nms, flags;
@@ -27,6 +28,8 @@ struct Y5NmsParams {
   int* out_count;
   // workspace
   int* count;                 // [bs]
+  int* rcount;                // [bs]    hint path: rows the objectness plane could not exclude
+  int* rows;                  // [bs][n] hint path: their indices (any order)
   unsigned long long* keys;   // [bs][cap_pad]
   unsigned char* best_cls;    // [bs][n] (best-class mode)
   float* gbox;                // [bs][gcap / 64][12][64] (chunk-major, field planes of 64 candidates): bx1,by1,bx2,by2,area, x1,y1,x2,y2,conf,cls,
@@ -35,6 +38,60 @@ struct Y5NmsParams {
 };
 
 template <typename T> __device__ __forceinline__ float y5_ldf(const T* p, long long i) { return (float)p[i]; }
+
+// One prediction row per lane -> candidate key(s): the test of general.py:679,719-731 on the row's own values (shared by the plain filter and
+// the objectness-plane path, so both produce the same candidates by construction).  EVERY lane of the wave calls it (valid = 0 for lanes
+// without a row): candidates are appended by wave-aggregated compaction -- one ballot, ONE atomicAdd per wave, slots by popcount prefix --
+// because 1200 same-address returning atomics per image (one per candidate lane) serialise at ~30 ns each: 40 us of a 55 us filter.
+// Candidate order in `keys` is irrelevant (the keys are sorted next).
+template <typename T>
+__device__ __forceinline__ void y5_nms_eval_row(const Y5NmsParams& p, int b, int r, const T* row, bool valid) {
+  const int lane = threadIdx.x & 63;
+  const float obj = valid ? (float)row[4] : 0.f;
+  const bool live = valid && obj > p.conf_thres;
+  unsigned long long* keys = p.keys + (long long)b * p.cap_pad;
+  auto class_ok = [&](int j) {
+    if (!p.classes) return true;
+    bool ok = false;
+    for (int c = 0; c < p.nclasses; ++c) ok |= (p.classes[c] == j);
+    return ok;
+  };
+  auto append = [&](bool hit, unsigned long long key) {  // wave-uniform call
+    const unsigned long long m = __ballot(hit);
+    if (m == 0ull) return;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(p.count + b, __popcll(m));
+    base = __shfl(base, 0);
+    if (hit) keys[base + __popcll(m & ((1ull << lane) - 1ull))] = key;
+  };
+  if (p.flags & 1) {  // multi_label: every (row, class) with obj*cls > thres (general.py:726-728)
+    if (__ballot(live) == 0ull) return;  // wave-uniform
+    for (int j = 0; j < p.nc; ++j) {
+      bool hit = false;
+      float conf = 0.f;
+      if (live) {
+        conf = (float)row[5 + j] * obj;
+        hit = conf > p.conf_thres && class_ok(j);
+      }
+      const unsigned idx = (unsigned)r * (unsigned)p.nc + (unsigned)j;
+      append(hit, ((unsigned long long)__float_as_uint(conf) << 32) | (unsigned long long)(0xFFFFFFFFu - idx));
+    }
+  } else {  // best class only: first maximal class (general.py:730)
+    bool hit = false;
+    float best = 0.f;
+    int bj = 0;
+    if (live) {
+      best = (float)row[5] * obj;
+      for (int j = 1; j < p.nc; ++j) {
+        const float conf = (float)row[5 + j] * obj;
+        if (conf > best) { best = conf; bj = j; }
+      }
+      hit = best > p.conf_thres && class_ok(bj);
+      if (hit) p.best_cls[(long long)b * p.n + r] = (unsigned char)bj;
+    }
+    append(hit, ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)r));
+  }
+}
 
 // ---- K1: filter + compaction -----------------------------------------------------------------------
 // STAGED: the workgroup's blockDim.x consecutive prediction rows (one contiguous block of memory) are first copied into LDS
@@ -62,50 +119,81 @@ __global__ void y5_nms_filter_kernel(const Y5NmsParams p) {
     }
     for (int i = done + threadIdx.x; i < total; i += blockDim.x) tile[i] = src[i];
     __syncthreads();
-    if (r >= p.n) return;
     row = tile + (long long)threadIdx.x * p.no;
   } else {
-    if (r >= p.n) return;
-    row = static_cast<const T*>(p.pred) + ((long long)b * p.n + r) * p.no;
+    row = static_cast<const T*>(p.pred) + ((long long)b * p.n + (r < p.n ? r : 0)) * p.no;
   }
-  const float obj = (float)row[4];
-  if (!(obj > p.conf_thres)) return;
-  unsigned long long* keys = p.keys + (long long)b * p.cap_pad;
-  if (p.flags & 1) {  // multi_label: every (row, class) with obj*cls > thres (general.py:726-728)
-    for (int j = 0; j < p.nc; ++j) {
-      const float conf = (float)row[5 + j] * obj;
-      if (conf > p.conf_thres) {
-        bool ok = true;
-        if (p.classes) {
-          ok = false;
-          for (int c = 0; c < p.nclasses; ++c) ok |= (p.classes[c] == j);
-        }
-        if (ok) {
-          const unsigned idx = (unsigned)r * (unsigned)p.nc + (unsigned)j;
-          const int slot = atomicAdd(p.count + b, 1);
-          keys[slot] = ((unsigned long long)__float_as_uint(conf) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
-        }
+  y5_nms_eval_row<T>(p, b, r, row, r < p.n);
+}
+
+// ---- K1 through the objectness plane (y5_nms_batched_hint) ----------------------------------------------------------------------------
+// K1a: one thread per row reads 2-4 bytes of the plane written beside z by the Detect decode (y5_detect_decode_hint /
+// y5_detect_head_fwd_hint) instead of the row's 85 values.  The plane is a HINT: a row is dropped only if its plane value is below the
+// threshold by more than 2^-8 relative (four fp16 ulps: the plane may have been rounded through another instruction sequence than z);
+// the others are appended to the image's row list by wave-aggregated compaction (ballot, one atomicAdd per wave, prefix by popcount).
+template <typename T>
+__global__ void y5_nms_hint_scan_kernel(const Y5NmsParams p) {
+  const int b = blockIdx.y;
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  bool pass = false;
+  if (r < p.n) {
+    const float hv = (float)static_cast<const T*>(p.obj_hint)[(long long)b * p.n + r];
+    pass = hv * 1.00390625f > p.conf_thres;  // NaN: false, like a NaN objectness in general.py:679
+  }
+  const unsigned long long m = __ballot(pass);
+  if (m == 0ull) return;
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == 0) base = atomicAdd(p.rcount + b, __popcll(m));
+  base = __shfl(base, 0);
+  if (pass) p.rows[(long long)b * p.n + base + __popcll(m & ((1ull << lane) - 1ull))] = r;
+}
+
+// K1b: the listed rows are copied into LDS by whole waves (a row is 2-3 consecutive cache lines: lane l fetches elements l, l + 64, ...; all
+// loads of a workgroup's 256 rows are independent and in flight together), then one thread per row runs the plain filter's row test
+// (y5_nms_eval_row) on the LDS copy -- the list is dense, so every lane works.  Reading the row from global memory inside the test instead
+// (85 dependent-latency loads per lane) measured 48 us for 77 k rows, a wave per row with a shuffle reduction 525 us; this form is bound by
+// one memory round trip per 256 rows.
+template <typename T>
+__global__ __launch_bounds__(256) void y5_nms_hint_rows_kernel(const Y5NmsParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* tile = reinterpret_cast<T*>(smem);  // [256][no]
+  const int b = blockIdx.y;
+  const int nrows = p.rcount[b];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const T* __restrict__ pred = static_cast<const T*>(p.pred) + (long long)b * p.n * p.no;
+  for (int base = blockIdx.x * 256; base < nrows; base += gridDim.x * 256) {
+    // wave w owns rows [64 w, 64 w + 64) of this chunk of the list; lane l keeps row index l in a register (the copy loop below must not
+    // read it back from LDS: with the index in LDS every iteration waited for the previous iteration's LDS stores, 64 serial memory round
+    // trips per wave)
+    const int mine = base + wave * 64 + lane;
+    const bool valid = mine < nrows;
+    const int my_r = valid ? p.rows[(long long)b * p.n + mine] : 0;
+    T* wt = tile + (size_t)wave * 64 * p.no;
+    constexpr int RB = 32;  // rows whose loads are in flight together (then their LDS stores): two memory round trips per 64 rows
+    for (int k0 = 0; k0 < 64; k0 += RB) {
+      T v0[RB], v1[RB];
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        const int rk = __shfl(my_r, k0 + u);
+        const T* src = pred + (long long)rk * p.no;
+        v0[u] = lane < p.no ? src[lane] : (T)0;
+        v1[u] = lane + 64 < p.no ? src[lane + 64] : (T)0;
       }
-    }
-  } else {  // best class only: first maximal class (general.py:730)
-    float best = (float)row[5] * obj;
-    int bj = 0;
-    for (int j = 1; j < p.nc; ++j) {
-      const float conf = (float)row[5 + j] * obj;
-      if (conf > best) { best = conf; bj = j; }
-    }
-    if (best > p.conf_thres) {
-      bool ok = true;
-      if (p.classes) {
-        ok = false;
-        for (int c = 0; c < p.nclasses; ++c) ok |= (p.classes[c] == bj);
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        if (lane < p.no) wt[(k0 + u) * p.no + lane] = v0[u];
+        if (lane + 64 < p.no) wt[(k0 + u) * p.no + lane + 64] = v1[u];
       }
-      if (ok) {
-        p.best_cls[(long long)b * p.n + r] = (unsigned char)bj;
-        const int slot = atomicAdd(p.count + b, 1);
-        keys[slot] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)r);
-      }
+      for (int o = lane + 128; o < p.no; o += 64)  // rows wider than 128 values (Segment: 117 fits; multi-hundred-class heads)
+#pragma unroll
+        for (int u = 0; u < RB; ++u) wt[(k0 + u) * p.no + o] = pred[(long long)__shfl(my_r, k0 + u) * p.no + o];
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // a wave evaluates only rows it copied itself: no workgroup barrier
+    y5_nms_eval_row<T>(p, b, my_r, wt + (size_t)lane * p.no, valid);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 

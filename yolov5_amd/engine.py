@@ -589,6 +589,14 @@ class Engine:
                 self.outputs[name] = t
             else:
                 self.outputs[name] = self.be.empty(o["shape"], dtype)
+        # Objectness plane beside z (one value per prediction row, written by the Detect decode / fused head): the NMS filter reads it instead
+        # of the 85-value rows and fetches only the rows it cannot exclude (general.non_max_suppression picks it up from the z tensor it is
+        # attached to).  Engine-owned outputs on the device only; Y5_OBJ_HINT=0 switches it off.
+        self._hint = ("z" in self.outputs and outputs is None and getattr(self.be, "direct", False) and os.environ.get("Y5_OBJ_HINT", "1") != "0")
+        if self._hint:
+            zs = self.spec.outputs["z"]["shape"]
+            self._hint_shape = (zs[0], zs[1])  # (neither a spec output nor a key of self.outputs: it travels on the z tensor)
+            self._hint_t = self.be.empty(self._hint_shape, dtype)
         self.plan = C.c_void_p(self.lib.y5_plan_create())
         self.op_names = []
         self.conv_cfgs = []
@@ -616,6 +624,8 @@ class Engine:
         # raw VIEWS of eval mode stay views of plan buffers (valid until the next forward; see DetectionModel.forward).
         self.fresh_outputs = outputs is None and os.environ.get("Y5_FRESH_OUTPUTS", "1") != "0"
         self._bound = {k: self.be.ptr(v) for k, v in self.outputs.items() if not (self.raw_views and k.startswith("raw"))}
+        if self._hint:
+            self._bound["obj_hint"] = self.be.ptr(self._hint_t)
 
     def __del__(self):
         try:
@@ -678,6 +688,8 @@ class Engine:
             rc = lib.y5_plan_add_detect_decode(self.plan, self._ptr(x), self.dt, B, op["ny"], op["nx"], op["na"], op["no"], op["nm"],
                                                self._ld(x), self.stride_t[i], arr, C.c_void_p(self.be.ptr(self.outputs["z"])), self.dt,
                                                op["nrows"], op["row_off"], C.c_void_p(self.be.ptr(raw)) if raw is not None else None)
+            if rc == 0 and self._hint:
+                rc = lib.y5_plan_set_obj_hint(self.plan, lib.y5_plan_size(self.plan) - 1, C.c_void_p(self.be.ptr(self._hint_t)))
             self.op_names.append(f"decode{i}")
         elif kind == "to_nchw":
             s = op["src"]
@@ -792,7 +804,10 @@ class Engine:
             self._anchor_ops.append((self.lib.y5_plan_size(self.plan), head["level"]))
             self.conv_cfgs.append(56)
             self.op_names.append("conv+decode:" + op["name"])
-            return self.lib.y5_plan_add_detect_head(self.plan, C.byref(d), ptrs[0], ptrs[1], ptrs[2], *head["args"])
+            rc = self.lib.y5_plan_add_detect_head(self.plan, C.byref(d), ptrs[0], ptrs[1], ptrs[2], *head["args"])
+            if rc == 0 and self._hint:
+                rc = self.lib.y5_plan_set_obj_hint(self.plan, self.lib.y5_plan_size(self.plan) - 1, C.c_void_p(self.be.ptr(self._hint_t)))
+            return rc
         self.conv_cfgs.append(int(d.cfg))
         self.op_names.append("conv:" + op["name"])
         return self.lib.y5_plan_add_conv(self.plan, C.byref(d), self._ptr(x), C.c_void_p(self.be.ptr(wp)), C.c_void_p(self.be.ptr(bp)),
@@ -947,26 +962,39 @@ class Engine:
                 _lib.check(self.lib.y5_plan_launch_graph(self.plan, st), self.lib)
             else:
                 _lib.check(self.lib.y5_plan_run_range(self.plan, 2, self._stem, st), self.lib)
-            return self.outputs
+            return self._tag_hint()
         self._stem_active = False
         scale = 1.0 / 255.0 if src_dt == _lib.Y5_U8 else 1.0  # train.py:379 / detect.py:209: uint8 images -> 0..1
         _lib.check(self.lib.y5_nchw_to_nhwc(C.c_void_p(xptr), src_dt, self._ptr(d), self.dt, B, cin, d.H, d.W, self._ld(d),
                                             scale, st), self.lib)
         _lib.check(self.lib.y5_plan_run_range(self.plan, 1, n if self._stem is None else self._stem, st), self.lib)
+        return self._tag_hint()
+
+    def _tag_hint(self):
+        """Hang the objectness plane on the z tensor it was written with (general.non_max_suppression looks for it there and checks that z is
+        still the tensor of this forward: same object, unchanged version counter)."""
+        if self._hint:
+            z = self.outputs["z"]
+            z._y5_obj_hint = (self._hint_t, z._version, z.data_ptr())
         return self.outputs
 
     def _rebind_fresh(self, n, outputs=None):
         """Point the plan at newly allocated (or caller-provided) output tensors and select the graph captured for that binding."""
         changed = False
         for name, old in list(self._bound.items()):
+            if outputs is not None and name == "obj_hint":
+                continue  # (caller-owned outputs never carry a hint plane: self._hint is False for such engines)
             if outputs is not None:
                 t = outputs[name]
                 if tuple(t.shape) != tuple(self.spec.outputs[name]["shape"]) or not t.is_contiguous():
                     raise ValueError(f"engine output {name}: expected contiguous {tuple(self.spec.outputs[name]['shape'])}")
             else:
-                t = self.be.empty(self.spec.outputs[name]["shape"], self.dtype)
+                t = self.be.empty(self._hint_shape if name == "obj_hint" else self.spec.outputs[name]["shape"], self.dtype)
             new = self.be.ptr(t)
-            self.outputs[name] = t
+            if name == "obj_hint":
+                self._hint_t = t
+            else:
+                self.outputs[name] = t
             if new != old:
                 _lib.check(self.lib.y5_plan_rebind_output(self.plan, 0, n, C.c_void_p(old), C.c_void_p(new)), self.lib)
                 self._bound[name] = new

@@ -112,6 +112,15 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     if prediction.dtype not in (torch.float16, torch.float32):
         prediction = prediction.float()
     prediction = prediction.contiguous()
+    # objectness plane the engine wrote beside this very tensor (engine.Engine._tag_hint): used only while `prediction` is still the object the
+    # forward returned, unmodified -- any copy, cast, slice or in-place edit drops it and the filter reads the rows themselves
+    hint = None
+    tag = getattr(prediction, "_y5_obj_hint", None)
+    if tag is not None:
+        h, ver, ptr0 = tag
+        if (ver == prediction._version and ptr0 == prediction.data_ptr() and h.dtype == prediction.dtype and h.device == prediction.device
+                and tuple(h.shape) == tuple(prediction.shape[:2]) and h.is_contiguous()):
+            hint = h
     lib = _lib.lib()
     bs, n, no = prediction.shape
     nc = no - nm - 5
@@ -130,10 +139,10 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     if classes is not None:
         cls_t = torch.tensor(list(classes), dtype=torch.int32, device=dev)
     dt = _lib.Y5_F16 if prediction.dtype == torch.float16 else _lib.Y5_F32
-    rc = lib.y5_nms_batched(C.c_void_p(prediction.data_ptr()), dt, bs, n, no, nm, float(conf_thres), float(iou_thres), int(max_det),
-                            max_nms, 7680.0, flags, C.c_void_p(cls_t.data_ptr()) if cls_t is not None else None,
-                            0 if cls_t is None else cls_t.numel(), C.c_void_p(out.data_ptr()), C.c_void_p(cnt.data_ptr()),
-                            C.c_void_p(ws[0].data_ptr()), ws[1], _lib.stream(dev))
+    rc = lib.y5_nms_batched_hint(C.c_void_p(prediction.data_ptr()), dt, bs, n, no, nm, float(conf_thres), float(iou_thres), int(max_det),
+                                 max_nms, 7680.0, flags, C.c_void_p(cls_t.data_ptr()) if cls_t is not None else None,
+                                 0 if cls_t is None else cls_t.numel(), C.c_void_p(out.data_ptr()), C.c_void_p(cnt.data_ptr()),
+                                 C.c_void_p(ws[0].data_ptr()), ws[1], C.c_void_p(hint.data_ptr()) if hint is not None else None, _lib.stream(dev))
     _lib.check(rc, lib)
     if padded:
         return out, cnt
