@@ -358,6 +358,12 @@ int y5_conv_k3pw_fwd(const y5_conv_desc* d, const void* x, const void* w1_packed
  * ------------------------------------------------------------------------------------------------------- */
 int y5_bottleneck_fwd(const void* x, int ldx, const void* w1_packed, const float* bias1, int Kpad1, const void* w2_packed, const float* bias2,
                       int Kpad2, void* y, int ldy, int B, int H, int W, int C, int add, int max_blocks, void* stream);
+/* The last Bottleneck of a C3 + the C3's cv3 (models/common.py:246: cv3(cat(m(cv1(x)), cv2(x)))) as ONE launch: the Bottleneck's result
+ * stays in LDS and is the first half of the 1x1's input, y2 (C3's cv2 output: NHWC slice, pixel stride ld2) the second; out (pixel stride
+ * ldo, C3 <= 2 C channels) = act3(W3 [y ; y2] + b3) with W3 packed [2 C padded][Kpad3], k = (y's C channels, then y2's).  C = 32. */
+int y5_bottleneck_cv3_fwd(const void* x, int ldx, const void* w1_packed, const float* bias1, int Kpad1, const void* w2_packed, const float* bias2,
+                          int Kpad2, const void* y2, int ld2, const void* w3_packed, const float* bias3, int Kpad3, int C3, int act3, void* out,
+                          int ldo, int B, int H, int W, int C, int add, int max_blocks, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * y5_mosaic_batch -- the training input pipeline for a whole batch in one launch: utils/dataloaders.py:798-855 `load_mosaic`
@@ -395,6 +401,9 @@ int y5_plan_add_bottleneck(y5_plan*, const void* x, int ldx, const void* w1_pack
 int y5_plan_add_conv_k3pw(y5_plan*, const y5_conv_desc* d, const void* x, const void* w1_packed, const float* bias1, const void* w2_packed,
                           const float* bias2, int C3, int Npad2, int Kpad2, int act2, void* y, int ldy, void* y2, int ld2, int split_n);
 int y5_plan_set_obj_hint(y5_plan*, int op_index, void* obj_hint);  /* Detect decode / fused head op: also write the objectness plane */
+int y5_plan_add_bottleneck_cv3(y5_plan*, const void* x, int ldx, const void* w1_packed, const float* bias1, int Kpad1, const void* w2_packed,
+                               const float* bias2, int Kpad2, const void* y2, int ld2, const void* w3_packed, const float* bias3, int Kpad3, int C3,
+                               int act3, void* out, int ldo, int B, int H, int W, int C, int add);
 int y5_plan_add_nop(y5_plan*);  /* placeholder op: keeps the op numbering of the conv + decode form next to a fused head */
 int y5_plan_add_conv_stem(y5_plan*, const void* x_nchw, int B, int H, int W, const void* w_stem, const float* bias, int C2,
                           int Npad, void* y, int ldy);

@@ -91,3 +91,60 @@ def test_conv_split_store(cfg):
     np.testing.assert_allclose(lo.astype(np.float32), ref[..., :32], rtol=3e-3, atol=3e-3)
     np.testing.assert_allclose(hi[..., 64:].astype(np.float32), ref[..., 32:], rtol=3e-3, atol=3e-3)
     assert np.all(hi[..., :64] == 3)
+
+
+@pytest.mark.parametrize("B,H,W,add,c3,ldx,ld2,ldo,act3,mb", [(1, 8, 16, True, 64, 32, 64, 64, 1, 0), (2, 12, 8, False, 64, 64, 96, 72, 1, 0),
+                                                             (1, 24, 32, True, 48, 32, 64, 48, 0, 1), (3, 4, 8, True, 64, 32, 32, 64, 1, 2)])
+def test_fused_bottleneck_cv3_matches_torch(B, H, W, add, c3, ldx, ld2, ldo, act3, mb):
+    """y5_bottleneck_cv3_fwd: the last Bottleneck of a C3 + the C3's cv3 (models/common.py:246) in one launch; the Bottleneck's result is rounded to
+    fp16 (LDS) exactly as the two-launch form stores it, cat order = (m output, cv2 output)."""
+    lib = emu()
+    Cc = 32
+    rng = np.random.default_rng(H * W + c3)
+    w1 = torch.from_numpy(rng.standard_normal((Cc, Cc, 1, 1)).astype(np.float32) * (2.0 / Cc) ** 0.5)
+    w2 = torch.from_numpy(rng.standard_normal((Cc, Cc, 3, 3)).astype(np.float32) * (2.0 / (9 * Cc)) ** 0.5)
+    w3 = torch.from_numpy(rng.standard_normal((c3, 2 * Cc, 1, 1)).astype(np.float32) * (2.0 / (2 * Cc)) ** 0.5)
+    b1, b2 = (torch.from_numpy(rng.standard_normal(Cc).astype(np.float32) * 0.3) for _ in range(2))
+    b3 = torch.from_numpy(rng.standard_normal(c3).astype(np.float32) * 0.3)
+    w1p, b1p, _, K1, _ = pack_conv_weight(w1, b1, torch.float16)
+    w2p, b2p, _, K2, _ = pack_conv_weight(w2, b2, torch.float16)
+    w3p, b3p, _, K3, N3 = pack_conv_weight(w3, b3, torch.float16)
+    assert N3 == 64
+    xbuf = aligned((B, H, W, ldx), np.float16)
+    xbuf[...] = rng.standard_normal(xbuf.shape).astype(np.float16)
+    y2buf = aligned((B, H, W, ld2), np.float16)
+    y2buf[...] = rng.standard_normal(y2buf.shape).astype(np.float16)
+    x, y2 = xbuf[..., ldx - Cc:], y2buf[..., ld2 - Cc:]
+    out = aligned((B, H, W, ldo), np.float16, 7)
+    bufs = [aligned(t.shape, t.numpy().dtype) for t in (w1p, b1p, w2p, b2p, w3p, b3p)]
+    for dst, src in zip(bufs, (w1p, b1p, w2p, b2p, w3p, b3p)):
+        dst[...] = src.numpy()
+    W1, B1, W2, B2, W3, B3 = bufs
+    rc = lib.y5_bottleneck_cv3_fwd(C.c_void_p(xbuf.ctypes.data + (ldx - Cc) * 2), ldx, ptr(W1), ptr(B1), K1, ptr(W2), ptr(B2), K2,
+                                   C.c_void_p(y2buf.ctypes.data + (ld2 - Cc) * 2), ld2, ptr(W3), ptr(B3), K3, c3, act3, ptr(out), ldo, B, H, W, Cc, int(add), mb, None)
+    assert rc == 0, lib.y5_last_error()
+    m = torch.from_numpy(_ref_bneck(np.ascontiguousarray(x), w1, b1, w2, b2, add)).permute(0, 3, 1, 2)
+    cat = torch.cat((m, torch.from_numpy(np.ascontiguousarray(y2).astype(np.float32)).permute(0, 3, 1, 2)), 1)
+    ref = F.conv2d(cat, w3.half().float(), b3)
+    ref = (F.silu(ref) if act3 else ref).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(out[..., :c3].astype(np.float32), ref, rtol=5e-3, atol=5e-3)
+    assert np.all(out[..., c3:] == 7)
+
+
+def test_plan_fuses_cv3_into_the_last_bottleneck(monkeypatch):
+    """yolov5s 2.C3 (c_ = 32): the plan with Bottleneck + cv3 as one launch (Y5_FUSED_CV3=1) against the two-launch plan on the emulator."""
+    from oracle import detgen
+    from tests.hipemu.backend import EmuBackend
+    from tests.test_emu_model import det_model
+    from yolov5_amd.engine import Engine
+
+    m = det_model("yolov5s", 0, True).half()
+    x = torch.from_numpy(detgen.uniform((1, 3, 64, 64), 0.0, 1.0, name="img", seed=0)).half()
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("Y5_FUSED_CV3", mode)
+        eng = Engine(m, (1, 3, 64, 64), torch.float16, "cpu", want_raw=False, backend=EmuBackend())
+        outs[mode] = np.asarray(eng(x)["z"]).astype(np.float32).copy()
+        assert any(n.startswith("bneck+cv3:") for n in eng.op_names) == (mode == "1"), eng.op_names
+    u, v = outs["0"], outs["1"]
+    assert np.abs(u - v).max() <= 4e-3 * max(1.0, np.abs(u).max()), np.abs(u - v).max()

@@ -461,3 +461,24 @@ def test_nms_objectness_hint_from_the_engine(dev):
     f = non_max_suppression(z.clone(), 0.25, 0.45, max_det=1000)
     for u, v in zip(e, f):
         assert torch.equal(u, v)
+
+
+def test_plan_bneck_cv3_fused_equals_unfused_on_gpu(dev, monkeypatch):
+    """yolov5s 4 x 3 x 320 x 320 fp16: 2.C3's Bottleneck + cv3 as one launch (y5_bottleneck_cv3_fwd, many tiles per wave on the real memory system) against
+    the two-launch plan -- same fp16 intermediate (LDS instead of HBM), same k order in the third GEMM."""
+    from yolov5_amd.yolo import DetectionModel
+
+    cfg = yo.model_cfg("yolov5s")
+    sd = yo.det_state_dict(cfg, 0, fused=False)
+    x = torch.from_numpy(detgen.uniform((4, 3, 320, 320), 0.0, 1.0, name="img", seed=1)).half().to(dev)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("Y5_FUSED_CV3", mode)
+        m = DetectionModel("yolov5s.yaml")
+        m.load_state_dict(sd)
+        m = m.eval().fuse().half().to(dev)
+        outs[mode] = m(x)[0].float().cpu()
+        eng = next(iter(m._engines.values()))
+        assert any(n.startswith("bneck+cv3:") for n in eng.op_names) == (mode == "1"), eng.op_names
+    u, v = outs["0"], outs["1"]
+    assert float((u - v).abs().max()) <= 4e-3 * max(1.0, float(u.abs().max()))

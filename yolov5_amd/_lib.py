@@ -153,6 +153,10 @@ EXPORTS = {
                                         C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]),
     "y5_bottleneck_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "y5_bottleneck_cv3_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                        C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "y5_plan_add_bottleneck_cv3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                             C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "y5_plan_set_input": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "y5_plan_set_branch": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "y5_plan_set_anchors": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int]),

@@ -7,11 +7,11 @@
 #include "y5_host.h"
 
 namespace {
-template <int C, int S, bool ADD>
+template <int C, int S, bool ADD, bool CV3 = false>
 int launch_bneck(const Y5BneckParams& p, int max_blocks, hipStream_t stream) {
-  const size_t lds = y5_conv_bneck_lds_bytes<C, S>();
+  const size_t lds = y5_conv_bneck_lds_bytes<C, S, CV3>();
   if (lds > 160 * 1024) return y5_fail(Y5_ERR_UNSUPPORTED, "bottleneck: exceeds 160 KiB of LDS");
-  auto kern = y5_conv_bneck_kernel<C, S, ADD>;
+  auto kern = y5_conv_bneck_kernel<C, S, ADD, CV3>;
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -55,7 +55,7 @@ extern "C" int y5_bottleneck_fwd(const void* x, int ldx, const void* w1_packed, 
   if (npix * ldx * 2 >= 0x7fffffffLL || npix * ldy * 2 >= 0x7fffffffLL) return y5_fail(Y5_ERR_UNSUPPORTED, "bottleneck: tensor exceeds 2^31 bytes");
   const char* xb = static_cast<const char*>(x);
   char* yb = static_cast<char*>(y);
-  if (xb < yb + npix * ldy * 2 && yb < xb + npix * ldx * 2 && (ldx != ldy || ((yb - xb) % (ldx * 2) + ldx * 2) % (ldx * 2) < C * 2 || ((xb - yb) % (ldx * 2) + ldx * 2) % (ldx * 2) < C * 2))
+  if (xb < yb + ((npix - 1) * ldy + C) * 2 && yb < xb + ((npix - 1) * ldx + C) * 2 && (ldx != ldy || ((yb - xb) % (ldx * 2) + ldx * 2) % (ldx * 2) < C * 2 || ((xb - yb) % (ldx * 2) + ldx * 2) % (ldx * 2) < C * 2))
     return y5_fail(Y5_ERR_BAD_ARG, "bottleneck: y must not overlap x (a tile reads its neighbours' pixels of x)");
   Y5BneckParams p{};
   p.x = x; p.w1 = w1_packed; p.w2 = w2_packed; p.b1 = bias1; p.b2 = bias2; p.y = y;
@@ -75,4 +75,43 @@ extern "C" int y5_bottleneck_fwd(const void* x, int ldx, const void* w1_packed, 
     return add ? launch_bneck<64, 1, true>(p, max_blocks, st) : launch_bneck<64, 1, false>(p, max_blocks, st);
   }
   return y5_fail(Y5_ERR_UNSUPPORTED, "bottleneck: unsupported number of stages");
+}
+
+
+// Bottleneck + C3's cv3 as one launch (conv_bneck.h CV3): out = act3(W3 [y ; y2] + b3) with y = the Bottleneck's result (never stored)
+extern "C" int y5_bottleneck_cv3_fwd(const void* x, int ldx, const void* w1_packed, const float* bias1, int Kpad1, const void* w2_packed,
+                                     const float* bias2, int Kpad2, const void* y2, int ld2, const void* w3_packed, const float* bias3, int Kpad3,
+                                     int C3, int act3, void* out, int ldo, int B, int H, int W, int C, int add, int max_blocks, void* stream_) {
+  if (!x || !w1_packed || !bias1 || !w2_packed || !bias2 || !y2 || !w3_packed || !bias3 || !out) return y5_fail(Y5_ERR_BAD_ARG, "bottleneck_cv3: null pointer");
+  if (C != 32) return y5_fail(Y5_ERR_UNSUPPORTED, "bottleneck_cv3: built for 32-channel Bottlenecks (cv3: 64 -> <= 64 channels)");
+  if (B < 1 || H < 4 || W < 8 || (H & 3) || (W & 7) || H > 255 * 4 || W > 65535) return y5_fail(Y5_ERR_UNSUPPORTED, "bottleneck_cv3: needs H % 4 == 0 and W % 8 == 0");
+  if ((ldx & 7) || (ld2 & 7) || (ldo & 7) || ldx < C || ld2 < C || Kpad1 < C || (Kpad1 & 7) || Kpad2 < 9 * C || (Kpad2 & 7) || Kpad3 < 2 * C || (Kpad3 & 7) ||
+      C3 < 8 || C3 > 2 * C || (C3 & 7) || ldo < C3)
+    return y5_fail(Y5_ERR_BAD_ARG, "bottleneck_cv3: bad strides / packed filter dims / output channels");
+  if (((uintptr_t)x | (uintptr_t)w1_packed | (uintptr_t)bias1 | (uintptr_t)w2_packed | (uintptr_t)bias2 | (uintptr_t)y2 | (uintptr_t)w3_packed | (uintptr_t)bias3 |
+       (uintptr_t)out) & 15)
+    return y5_fail(Y5_ERR_BAD_ARG, "bottleneck_cv3: pointers must be 16-byte aligned");
+  const long long npix = (long long)B * H * W;
+  if (npix * ldx * 2 >= 0x7fffffffLL || npix * ld2 * 2 >= 0x7fffffffLL || npix * ldo * 2 >= 0x7fffffffLL) return y5_fail(Y5_ERR_UNSUPPORTED, "bottleneck_cv3: tensor exceeds 2^31 bytes");
+  auto overlaps = [&](const void* a_, long long lda, int ca, const void* b_, long long ldb, int cb) {  // channel slices of NHWC buffers
+    const char* a = static_cast<const char*>(a_);
+    const char* b = static_cast<const char*>(b_);
+    if (!(a < b + ((npix - 1) * ldb + cb) * 2 && b < a + ((npix - 1) * lda + ca) * 2)) return false;  // exact extents: a slice ends ca channels into its last pixel
+    if (lda != ldb) return true;
+    const long long d = ((b - a) % (lda * 2) + lda * 2) % (lda * 2), e = ((a - b) % (lda * 2) + lda * 2) % (lda * 2);
+    return d < ca * 2 || e < cb * 2;
+  };
+  if (overlaps(x, ldx, C, out, ldo, C3) || overlaps(y2, ld2, C, out, ldo, C3))
+    return y5_fail(Y5_ERR_BAD_ARG, "bottleneck_cv3: out must not overlap x or y2 (tiles read their neighbours' pixels of x)");
+  Y5BneckParams p{};
+  p.x = x; p.w1 = w1_packed; p.w2 = w2_packed; p.b1 = bias1; p.b2 = bias2; p.y = out;
+  p.B = B; p.H = H; p.W = W; p.ldx = ldx; p.ldy = ldo; p.Kpad1 = Kpad1; p.Kpad2 = Kpad2; p.add = add;
+  p.x_bytes = (unsigned)(((npix - 1) * ldx + C) * 2);
+  p.w1_bytes = (unsigned)((long long)C * Kpad1 * 2);
+  p.w2_bytes = (unsigned)((long long)C * Kpad2 * 2);
+  p.y2 = y2; p.ld2 = ld2; p.y2_bytes = (unsigned)(((npix - 1) * ld2 + C) * 2);
+  p.w3 = w3_packed; p.b3 = bias3; p.Kpad3 = Kpad3; p.C3 = C3; p.act3 = act3; p.w3_bytes = (unsigned)((long long)2 * C * Kpad3 * 2);
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  max_blocks &= 0xffff;
+  return add ? launch_bneck<32, 1, true, true>(p, max_blocks, st) : launch_bneck<32, 1, false, true>(p, max_blocks, st);
 }

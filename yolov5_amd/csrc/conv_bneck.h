@@ -25,10 +25,11 @@
 #endif
 __device__ __forceinline__ float y5_bneck_act(float v) { return (Y5_BNECK_ABL & 1) ? v : y5_silu(v); }
 
-template <int C, int S>
+template <int C, int S, bool CV3 = false>
 constexpr size_t y5_conv_bneck_lds_bytes() {
   constexpr int NSL = C / 8, NI = (60 * NSL + 63) / 64;
-  return (size_t)C * C * 2 + (size_t)C * 9 * C * 2 + (size_t)2 * C * 4 + (size_t)4 * (S * NI * 1024 + 64 * C * 2);
+  // CV3: + the third bias (the third filter lives in registers, the cv2 half of its input comes straight from global memory)
+  return (size_t)C * C * 2 + (size_t)C * 9 * C * 2 + (size_t)2 * C * 4 + (size_t)4 * (S * NI * 1024 + 64 * C * 2) + (CV3 ? (size_t)2 * C * 4 : 0);
 }
 
 struct Y5BneckParams {
@@ -40,10 +41,18 @@ struct Y5BneckParams {
   void* y;             // NHWC slice, pixel stride ldy (may alias x: every tile reads its receptive field before any neighbour... NO: must not alias)
   unsigned x_bytes, w1_bytes, w2_bytes;
   int B, H, W, ldx, ldy, Kpad1, Kpad2, add;
+  // CV3 kernels: C3's cv3 (1x1 over cat(m(cv1(x)), cv2(x)), models/common.py:246) applied to the finished tile: the other half of its input,
+  // the third filter [2C padded][Kpad3] (k = (this kernel's C outputs, then y2's C channels)), bias, activation, real output channels;
+  // the result goes to y (pixel stride ldy) INSTEAD of the Bottleneck's own output
+  const void* y2;
+  const void* w3;
+  const float* b3;
+  unsigned y2_bytes, w3_bytes;
+  int ld2, Kpad3, C3, act3;
 };
 
-template <int C, int S, bool ADD>
-__global__ __launch_bounds__(256)
+template <int C, int S, bool ADD, bool CV3 = false>
+__global__ __launch_bounds__(256, CV3 ? 3 : 1)  // CV3: three waves per SIMD as without it (the third filter's 32 registers must not cost a workgroup per CU)
 void y5_conv_bneck_kernel(const Y5BneckParams p) {
   typedef half_t T;
   constexpr int NT = C / 32;
@@ -55,7 +64,12 @@ void y5_conv_bneck_kernel(const Y5BneckParams p) {
   constexpr int K1B = C * 2, K2B = 9 * C * 2;                // bytes per filter row in LDS
   constexpr int W1_BYTES = C * K1B, W2_BYTES = C * K2B;
   constexpr int SPR = C / 8, RPP = 64 / SPR, NPASS = 32 / RPP, SWM = SPR >= 8 ? 7 : SPR - 1;
-  constexpr int SP = NPASS, LP = NI;                         // stores / loads per tile per wave
+  constexpr int C3P = 2 * C;                                 // CV3: (padded) output channels of the third GEMM = its K
+  constexpr int STAGE2 = STAGE;
+  constexpr int SPR3 = C3P / 8, RPP3 = 64 / SPR3, NPASS3 = 32 / RPP3, SWM3 = SPR3 >= 8 ? 7 : SPR3 - 1;
+  constexpr int SP = CV3 ? NPASS3 : NPASS, LP = NI;          // stores / LDS-DMA loads per tile per wave (CV3's two register loads of the cv2 half are
+                                                             // issued at the top of their tile: older than everything the counted waits leave in flight)
+  static_assert(!CV3 || (C == 32 && S == 1 && TBYTES >= 32 * C3P * 2), "cv3 fusion is built for C = 32 (third GEMM 64 -> 64), one ring stage");
   static_assert(S >= 1 && S <= 3, "1 to 3 stages");
   static_assert(TBYTES >= 32 * C * 2, "epilogue scratch must fit in the t buffer");
 
@@ -66,12 +80,14 @@ void y5_conv_bneck_kernel(const Y5BneckParams p) {
   float* b2l = b1l + C;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  char* ring = smem + W1_BYTES + W2_BYTES + 2 * C * 4 + wave * (S * STAGE + TBYTES);
-  char* ts = ring + S * STAGE;
+  float* b3l = reinterpret_cast<float*>(smem + W1_BYTES + W2_BYTES + 2 * C * 4);
+  char* ring = smem + W1_BYTES + W2_BYTES + 2 * C * 4 + (CV3 ? C3P * 4 : 0) + wave * (S * STAGE2 + TBYTES);
+  char* ts = ring + S * STAGE2;
 
   const y5_rsrc_t xrs = y5_make_rsrc(p.x, p.x_bytes);
   const y5_rsrc_t w1rs = y5_make_rsrc(p.w1, p.w1_bytes);
   const y5_rsrc_t w2rs = y5_make_rsrc(p.w2, p.w2_bytes);
+  const y5_rsrc_t y2rs = y5_make_rsrc(CV3 ? p.y2 : p.x, CV3 ? p.y2_bytes : 0u);
   T* __restrict__ yg = static_cast<T*>(p.y);
 
   auto fsw = [](int q) { return C == 32 ? ((q >> 2) & 3) : ((q >> 1) & 7); };  // pixel-row swizzle (64 / 128-byte rows)
@@ -92,6 +108,9 @@ void y5_conv_bneck_kernel(const Y5BneckParams p) {
       y5_bglds16(w2rs, (unsigned)(n * p.Kpad2 * 2 + src_slot * 16), w2l + I * 1024);
     }
     for (int i = tid; i < C; i += 256) { b1l[i] = p.b1[i]; b2l[i] = p.b2[i]; }
+    if constexpr (CV3) {
+      for (int i = tid; i < C3P; i += 256) b3l[i] = p.b3[i];
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
   }
@@ -132,6 +151,15 @@ void y5_conv_bneck_kernel(const Y5BneckParams p) {
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) w2sl[ks] = pl * K2B + (((ks * 2 + g) ^ fsw(pl)) * 16);
   const int orow = lane / SPR, oslot = lane % SPR;
+  // CV3: the third filter's fragments stay in registers for the lifetime of the workgroup (lane (n = pl, g), k-step ks: 8 halfs of row j*32 + pl)
+  half8_t w3f[CV3 ? C3P / 32 : 1][CV3 ? 2 * KS : 1];
+  if constexpr (CV3) {
+    const T* w3g = static_cast<const T*>(p.w3);
+#pragma unroll
+    for (int j = 0; j < C3P / 32; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2 * KS; ++ks) w3f[j][ks] = *reinterpret_cast<const half8_t*>(w3g + (size_t)(j * 32 + pl) * p.Kpad3 + (ks * 2 + g) * 8);
+  }
 
   // ---- tile schedule (conv_k3.h) -----------------------------------------------------------------------------------------
   const int tw = p.W / TC, th = p.H / TR;
@@ -149,7 +177,7 @@ void y5_conv_bneck_kernel(const Y5BneckParams p) {
     b = r / th; oh0 = ty * TR; ow0 = tx * TC;
   };
   auto issue = [&](int j, int buf) {
-    char* xs = ring + buf * STAGE;
+    char* xs = ring + buf * STAGE2;
     int b, oh0, ow0;
     tile_origin(j, b, oh0, ow0);
     const int ih0 = oh0 - 1, iw0 = ow0 - 1;
@@ -182,9 +210,17 @@ void y5_conv_bneck_kernel(const Y5BneckParams p) {
       y5_wait_vm<SP + (S - 1) * (LP + SP)>();
     }
     __builtin_amdgcn_wave_barrier();
-    char* xs = ring + buf * STAGE;
+    char* xs = ring + buf * STAGE2;
     int b, oh0, ow0;
     tile_origin(i, b, oh0, ow0);
+    // CV3: this lane's activation fragments of C3's cv2 half (pixel pl, channels (2 ks + g) * 8 .. + 7), straight into registers; they are
+    // needed by the third GEMM only -- two whole GEMMs later
+    uint4_t y2f[CV3 ? KS : 1];
+    if constexpr (CV3) {
+      const int poff = (((b * p.H + oh0 + (pl >> 3)) * p.W + ow0 + (pl & 7)) * p.ld2) * 2;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) y2f[ks] = y5_buffer_load16(y2rs, poff + (ks * 2 + g) * 16, 0);
+    }
     // ---- GEMM 1: t = SiLU(W1 x + b1) on the receptive field, zero outside the image -------------------------------------
     {
       float16_t acc1[2][NT];
@@ -276,19 +312,77 @@ void y5_conv_bneck_kernel(const Y5BneckParams p) {
       }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if constexpr (CV3) {
+      // ---- cv3: the finished tile (+ residual) goes back into the scratch, and is the first half of the third GEMM's K; the second half are the
+      // lifted fragments of C3's cv2 output.  K order = (m channels, cv2 channels) = the order of torch.cat at common.py:246.
 #pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-      const int row = ps * RPP + orow;
-      uint4_t raw = *reinterpret_cast<const uint4_t*>(ts + row * (C * 2) + ((oslot ^ (row & SWM)) * 16));
-      if constexpr (ADD) {
-        half8_t a = __builtin_bit_cast(half8_t, raw), r8 = __builtin_bit_cast(half8_t, resv[ps]), c;
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int row = ps * RPP + orow;
+        char* q = ts + row * (C * 2) + ((oslot ^ (row & SWM)) * 16);
+        uint4_t raw = *reinterpret_cast<const uint4_t*>(q);
+        if constexpr (ADD) {
+          half8_t a = __builtin_bit_cast(half8_t, raw), r8 = __builtin_bit_cast(half8_t, resv[ps]), c;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) c[e] = (half_t)((float)a[e] + (float)r8[e]);
-        raw = __builtin_bit_cast(uint4_t, c);
+          for (int e = 0; e < 8; ++e) c[e] = (half_t)((float)a[e] + (float)r8[e]);
+          raw = __builtin_bit_cast(uint4_t, c);
+          *reinterpret_cast<uint4_t*>(q) = raw;
+        }
       }
-      const size_t m = ((size_t)b * p.H + oh0 + (row >> 3)) * p.W + ow0 + (row & 7);
-      if (!(Y5_BNECK_ABL & 8)) *reinterpret_cast<uint4_t*>(yg + m * p.ldy + oslot * 8) = raw;
-      else asm volatile("" ::"v"(raw));
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      constexpr int NT3 = C3P / 32;
+      float16_t acc3[NT3];
+#pragma unroll
+      for (int j = 0; j < NT3; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc3[j][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2 * KS; ++ks) {
+        half8_t af;
+        if (ks < KS) af = *reinterpret_cast<const half8_t*>(ts + pl * (C * 2) + (((ks * 2 + g) ^ (pl & SWM)) * 16));
+        else af = __builtin_bit_cast(half8_t, y2f[ks - KS]);
+#pragma unroll
+        for (int j = 0; j < NT3; ++j) acc3[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3f[j][ks], af, acc3[j], 0, 0, 0);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();  // every lane has read the tile: the scratch takes the third epilogue
+#pragma unroll
+      for (int j = 0; j < NT3; ++j)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          const float4_t bv = *reinterpret_cast<const float4_t*>(b3l + j * 32 + qq * 8 + g * 4);
+          half4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float t = acc3[j][qq * 4 + e] + bv[e]; o[e] = (half_t)(p.act3 ? y5_bneck_act(t) : t); }
+          const int slot = j * 4 + qq;
+          *reinterpret_cast<half4_t*>(ts + pl * (C3P * 2) + ((slot ^ (pl & SWM3)) * 16) + g * 8) = o;
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int orow3 = lane / SPR3, oslot3 = lane % SPR3;
+#pragma unroll
+      for (int ps = 0; ps < NPASS3; ++ps) {
+        const int row = ps * RPP3 + orow3;
+        const uint4_t raw = *reinterpret_cast<const uint4_t*>(ts + row * (C3P * 2) + ((oslot3 ^ (row & SWM3)) * 16));
+        const size_t m = ((size_t)b * p.H + oh0 + (row >> 3)) * p.W + ow0 + (row & 7);
+        const int n = oslot3 * 8;
+        if (n < p.C3) *reinterpret_cast<uint4_t*>(yg + m * p.ldy + n) = raw;
+      }
+    } else {
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int row = ps * RPP + orow;
+        uint4_t raw = *reinterpret_cast<const uint4_t*>(ts + row * (C * 2) + ((oslot ^ (row & SWM)) * 16));
+        if constexpr (ADD) {
+          half8_t a = __builtin_bit_cast(half8_t, raw), r8 = __builtin_bit_cast(half8_t, resv[ps]), c;
+  #pragma unroll
+          for (int e = 0; e < 8; ++e) c[e] = (half_t)((float)a[e] + (float)r8[e]);
+          raw = __builtin_bit_cast(uint4_t, c);
+        }
+        const size_t m = ((size_t)b * p.H + oh0 + (row >> 3)) * p.W + ow0 + (row & 7);
+        if (!(Y5_BNECK_ABL & 8)) *reinterpret_cast<uint4_t*>(yg + m * p.ldy + oslot * 8) = raw;
+        else asm volatile("" ::"v"(raw));
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // the scratch is rewritten by the next tile's GEMM 1

@@ -48,12 +48,13 @@ extern "C" const char* y5_last_error(void) { return g_err.c_str(); }
 // ---------------------------------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------------------------------
-enum OpKind { OP_CONV, OP_TO_NHWC, OP_SPPF, OP_UPS, OP_COPY, OP_DECODE, OP_TO_NCHW, OP_STEM, OP_HEAD, OP_NOP, OP_BNECK, OP_K3PW };
+enum OpKind { OP_CONV, OP_TO_NHWC, OP_SPPF, OP_UPS, OP_COPY, OP_DECODE, OP_TO_NCHW, OP_STEM, OP_HEAD, OP_NOP, OP_BNECK, OP_K3PW, OP_BNECK_CV3 };
 
 struct Op {
   OpKind kind;
   y5_conv_desc conv;
   const void* p0; const void* p1; const void* p2; const void* p3; void* q0; void* q1;
+  const void* r0; const void* r1; const void* r2;  // further read-only operands (OP_BNECK_CV3: y2, w3, bias3)
   int i[12];
   float f[2];
   long long l[2];
@@ -177,6 +178,17 @@ extern "C" int y5_plan_set_obj_hint(y5_plan* pl, int op, void* hint) {
   pl->ops[op].p3 = hint;
   return Y5_OK;
 }
+extern "C" int y5_plan_add_bottleneck_cv3(y5_plan* pl, const void* x, int ldx, const void* w1, const float* b1, int Kpad1, const void* w2, const float* b2,
+                                          int Kpad2, const void* y2, int ld2, const void* w3, const float* b3, int Kpad3, int C3, int act3, void* out, int ldo,
+                                          int B, int H, int W, int C, int add) {
+  if (!pl) return y5_fail(Y5_ERR_BAD_ARG, "plan: null");
+  Op o{}; o.kind = OP_BNECK_CV3; o.p0 = x; o.p1 = w1; o.p2 = b1; o.p3 = w2; o.q0 = out; o.q1 = const_cast<float*>(b2);
+  o.r0 = y2; o.r1 = w3; o.r2 = b3;
+  o.i[0] = ldx; o.i[1] = Kpad1; o.i[2] = Kpad2; o.i[3] = ldo; o.i[4] = B; o.i[5] = H; o.i[6] = W; o.i[7] = C; o.i[8] = add;
+  o.i[9] = ld2; o.i[10] = Kpad3; o.i[11] = C3 | (act3 ? 1 << 16 : 0);
+  pl->ops.push_back(o);
+  return Y5_OK;
+}
 extern "C" int y5_plan_add_nop(y5_plan* pl) {
   if (!pl) return y5_fail(Y5_ERR_BAD_ARG, "plan: null");
   Op o{}; o.kind = OP_NOP;
@@ -207,7 +219,7 @@ extern "C" int y5_plan_rebind_output(y5_plan* pl, int first, int last, const voi
   for (int k = first; k < last; ++k) {
     Op& o = pl->ops[k];
     if (o.q0 == old_ptr) { o.q0 = new_ptr; ++n; }
-    if (o.q1 == old_ptr && o.kind != OP_BNECK) { o.q1 = new_ptr; ++n; }
+    if (o.q1 == old_ptr && o.kind != OP_BNECK && o.kind != OP_BNECK_CV3) { o.q1 = new_ptr; ++n; }
     if (o.p3 == old_ptr && (o.kind == OP_DECODE || o.kind == OP_HEAD)) { o.p3 = new_ptr; ++n; }  // objectness hint plane (y5_plan_set_obj_hint)
   }
   if (!n) return y5_fail(Y5_ERR_BAD_ARG, "plan_rebind_output: no op writes that pointer");
@@ -253,6 +265,9 @@ static int run_op(const Op& o, void* st) {
     case OP_HEAD:
       return y5_detect_head_fwd_hint(&o.conv, o.p0, o.p1, (const float*)o.p2, o.i[0], o.i[1], o.f[0], o.anchors, o.q0, o.l[0], o.l[1], const_cast<void*>(o.p3), st);
     case OP_NOP: return Y5_OK;
+    case OP_BNECK_CV3:
+      return y5_bottleneck_cv3_fwd(o.p0, o.i[0], o.p1, (const float*)o.p2, o.i[1], o.p3, (const float*)o.q1, o.i[2], o.r0, o.i[9], o.r1, (const float*)o.r2,
+                                   o.i[10], o.i[11] & 0xffff, o.i[11] >> 16, o.q0, o.i[3], o.i[4], o.i[5], o.i[6], o.i[7], o.i[8], 0, st);
     case OP_K3PW:
       return y5_conv_k3pw_fwd(&o.conv, o.p0, o.p1, (const float*)o.p2, o.p3, (const float*)(uintptr_t)o.l[0], o.i[0], o.i[1], o.i[2], o.i[3], o.q0, o.i[4],
                               o.q1, o.i[5], o.i[6], st);

@@ -749,7 +749,9 @@ class Engine:
                 self._graph_gen = getattr(self, "_graph_gen", 0) + 1
 
     def _add_bneck(self, op):
-        """Fused Bottleneck (y5_bottleneck_fwd): both filters packed like ordinary convs; refresh_weights() re-packs them too."""
+        """Fused Bottleneck (y5_bottleneck_fwd): both filters packed like ordinary convs; refresh_weights() re-packs them too.  When it is the last
+        Bottleneck of a C3 and the op behind it is that C3's cv3, both can run as ONE launch (y5_bottleneck_cv3_fwd): the Bottleneck's result
+        stays in LDS.  Y5_FUSED_CV3 = 0: never, 1: whenever the shapes fit, auto (default): both forms are timed at plan build."""
         x, y = op["x"], op["y"]
         packs = []
         for sub in (op["cv1"], op["cv2"]):
@@ -759,10 +761,74 @@ class Engine:
             self._conv_bufs.append((sub, wp, bp, None, None))
             packs.append((wp, bp, Kpad))
         (w1, b1, k1), (w2, b2, k2) = packs
+        base = (self._ptr(x), self._ld(x), C.c_void_p(self.be.ptr(w1)), C.c_void_p(self.be.ptr(b1)), k1, C.c_void_p(self.be.ptr(w2)), C.c_void_p(self.be.ptr(b2)), k2)
+        tail = (self.spec.B, x.H, x.W, x.C, int(op["add"]))
+        cv3 = self._fused_cv3_args(op, base, tail)
+        if cv3 is not None:
+            self._k3pw_skip = self._cur + 1
+            self.op_names.append("bneck+cv3:" + op["name"] + "+" + cv3["name"])
+            return self.lib.y5_plan_add_bottleneck_cv3(self.plan, *base, *cv3["args"], *tail)
         self.op_names.append("bneck:" + op["name"])
-        return self.lib.y5_plan_add_bottleneck(self.plan, self._ptr(x), self._ld(x), C.c_void_p(self.be.ptr(w1)), C.c_void_p(self.be.ptr(b1)), k1,
-                                               C.c_void_p(self.be.ptr(w2)), C.c_void_p(self.be.ptr(b2)), k2, self._ptr(y), self._ld(y),
-                                               self.spec.B, x.H, x.W, x.C, int(op["add"]))
+        return self.lib.y5_plan_add_bottleneck(self.plan, *base, self._ptr(y), self._ld(y), *tail)
+
+    def _fused_cv3_args(self, op, base, tail):
+        mode = os.environ.get("Y5_FUSED_CV3", "auto")
+        nxt_i = self._cur + 1
+        x, y = op["x"], op["y"]
+        if mode == "0" or self.dt != _lib.Y5_F16 or x.C != 32 or nxt_i >= len(self.spec.ops):
+            return None
+        nxt = self.spec.ops[nxt_i]
+        if not (nxt["op"] == "conv" and _pair(nxt["k"]) == (1, 1) and _pair(nxt["s"]) == (1, 1) and _pair(nxt["p"]) == (0, 0) and nxt["res"] is None
+                and nxt["y2"] is None and not nxt.get("split_n") and not nxt.get("side") and nxt["c2_store"] <= 64 and nxt["c2_store"] % 8 == 0):
+            return None
+        cat = nxt["x"]
+        if not (cat.buf == y.buf and cat.c_off == y.c_off and cat.C == 2 * y.C and y.C == 32):  # this Bottleneck writes the first half of cv3's input
+            return None
+        for k, o in enumerate(self.spec.ops):  # the Bottleneck's own output must have no other reader
+            if k in (self._cur, nxt_i):
+                continue
+            for v in o.values():
+                if isinstance(v, TRef) and v.buf == y.buf and v.c_off < y.c_off + y.C and y.c_off < v.c_off + v.C and k > self._cur:
+                    return None
+        if mode != "1" and not getattr(self.be, "autotune", False):
+            return None
+        (_g, (wp3, bp3, _K3, Kpad3, Npad3), stem3) = self._conv_weights(nxt)
+        if stem3 is not None or Npad3 != 64:
+            return None
+        wp3, bp3 = self.be.from_torch(wp3), self.be.from_torch(bp3)
+        y2 = _slice(cat, y.C, y.C)
+        out = nxt["y"]
+        args = (self._ptr(y2), self._ld(y2), C.c_void_p(self.be.ptr(wp3)), C.c_void_p(self.be.ptr(bp3)), Kpad3, nxt["c2_store"], 1 if nxt["act"] else 0,
+                self._ptr(out), self._ld(out))
+        lib, st = self.lib, self._stream()
+        fused = C.c_void_p(lib.y5_plan_create())
+        try:
+            if lib.y5_plan_add_bottleneck_cv3(fused, *base, *args, *tail) != 0:
+                return None
+            ms_f = C.c_float(0)
+            if lib.y5_plan_time_range(fused, 0, 1, 1 if mode == "1" else 10, st, C.byref(ms_f)) != 0:
+                return None
+            if mode != "1":
+                (H3, W3, C13, ldx3, *_r) = _g
+                d3 = _lib.ConvDesc(dtype=self.dt, B=self.spec.B, H=H3, W=W3, C1=C13, ldx=ldx3, OH=out.H, OW=out.W, C2=nxt["c2_store"], ldy=self._ld(out), KH=1, KW=1,
+                                   SH=1, SW=1, PH=0, PW=0, act=1 if nxt["act"] else 0, Kpad=Kpad3, Npad=Npad3, ldr=0, ld2=0, cfg=-1, max_blocks=0, split_n=0)
+                ptrs3 = (self._ptr(cat), args[2], args[3], None, self._ptr(out), None)
+                d3.cfg = self._autotune_conv(d3, ptrs3, exclude=SK_CFGS)
+                two = C.c_void_p(lib.y5_plan_create())
+                try:
+                    _lib.check(lib.y5_plan_add_bottleneck(two, *base, self._ptr(y), self._ld(y), *tail), lib)
+                    _lib.check(lib.y5_plan_add_conv(two, C.byref(d3), *ptrs3), lib)
+                    ms_t = C.c_float(0)
+                    _lib.check(lib.y5_plan_time_range(two, 0, 2, 10, st, C.byref(ms_t)), lib)
+                finally:
+                    lib.y5_plan_destroy(two)
+                if not ms_f.value < ms_t.value:
+                    return None
+        finally:
+            lib.y5_plan_destroy(fused)
+        self._keep += [wp3, bp3]
+        self._conv_bufs.append((nxt, wp3, bp3, None, None))
+        return dict(args=args, name=nxt["name"])
 
     def _add_conv(self, op):
         x, y, res, y2 = op["x"], op["y"], op["res"], op["y2"]
