@@ -259,7 +259,7 @@ int y5_memset_zero(void* p, size_t bytes, void* stream);
  *           (autograd grad_output, e.g. GradScaler scale x WORLD_SIZE) or NULL for 1.  Needs the workspace of the
  *           matching y5_loss_forward call untouched.  No host synchronisation in either call.
  * Contracts: duplicate (b,a,gj,gi) rows -> tobj takes the LAST row's iou (loss.py:163 on CPU); row gradients of
- * duplicate cells are summed in ascending row order; fl_gamma = 0, gr = 1, autobalance off, sort_obj_iou off.
+ * duplicate cells are summed in ascending row order; gr = 1, autobalance off, sort_obj_iou off.
  * anchors: [level * 16 + a * 2 + {0,1}] in grid units (Detect.anchors); balance: loss.py:125.
  * ------------------------------------------------------------------------------------------------------- */
 typedef struct {
@@ -269,6 +269,7 @@ typedef struct {
   float anchors[5 * 16];
   float balance[5];
   float hyp_box, hyp_obj, hyp_cls, cls_pw, obj_pw, anchor_t, cp, cn;
+  float fl_gamma;  /* hyp['fl_gamma'] (loss.py:120-122): > 0 wraps both BCE terms in FocalLoss(gamma, alpha = 0.25), loss.py:77-98; 0 = plain BCE */
 } y5_loss_desc;
 size_t y5_loss_workspace_bytes(const y5_loss_desc* d, int nt);   /* 0 on invalid descriptor */
 int y5_loss_forward(const y5_loss_desc* d, const void* const* p, const float* targets, int nt, float* out4,

@@ -278,6 +278,24 @@ def gen_loss(ns):
                 out[f"{name}_grad{i}"] = g
         print("loss", name, loss.item(), items.tolist(), [int(ix[0].numel()) for ix in indices])
     np.savez_compressed(os.path.join(OUT, "loss.npz"), **out)
+    # focal loss (hyp fl_gamma = 1.5, loss.py:120-122 -> FocalLoss :77-98) with label smoothing 0.1 on the synthetic case: loss, items, gradients
+    fo = {}
+    m.hyp = dict(m.hyp, fl_gamma=1.5, label_smoothing=0.1)
+    clf = ns.loss.ComputeLoss(m)
+    pn, tn = loss_case("synthetic")
+    p = [torch.from_numpy(a).clone().requires_grad_(True) for a in pn]
+    loss, items = clf(p, torch.from_numpy(tn))
+    loss.backward()
+    fo["loss"], fo["items"] = loss.detach().numpy(), items.numpy()
+    for i in range(3):
+        gq = p[i].grad.numpy()
+        fo[f"grad{i}_sum"] = np.array([gq.astype(np.float64).sum(), np.abs(gq.astype(np.float64)).sum()])
+        nz = np.argwhere(np.abs(gq[..., :4]).sum(-1) > 0)[:64]
+        fo[f"grad{i}_nzidx"] = nz
+        fo[f"grad{i}_nzrows"] = gq[tuple(nz.T)]
+        fo[f"grad{i}_obj_head"] = gq[0, 0, :4, :8, 4].copy()   # objectness gradients of cells without targets too
+    print("loss focal", loss.item(), items.tolist())
+    np.savez_compressed(os.path.join(OUT, "loss_focal.npz"), **fo)
 
 
 def gen_mask(ns):
@@ -555,6 +573,9 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     ns = ref_shim.load()
     torch.set_num_threads(os.cpu_count() or 1)
+    if len(sys.argv) > 1 and sys.argv[1] == "loss":  # only the ComputeLoss fixtures
+        gen_loss(ns)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "augment":
         gen_augment(ns)
         return 0

@@ -557,7 +557,7 @@ def bbox_ciou(box1, box2, eps=1e-7):
 
 
 def compute_loss(p, targets, anchors, hyp=None, nc=80, balance=(4.0, 1.0, 0.4)):
-    """utils/loss.py:134-183 (fl_gamma=0, gr=1, autobalance off, sort_obj_iou off).
+    """utils/loss.py:134-183 (gr=1, autobalance off, sort_obj_iou off; hyp['fl_gamma'] > 0: focal loss).
 
     p: list of (bs,na,ny,nx,no) tensors (may require grad); returns (loss[1], loss_items[3])."""
     hyp = hyp or HYP_SCRATCH_LOW
@@ -565,6 +565,17 @@ def compute_loss(p, targets, anchors, hyp=None, nc=80, balance=(4.0, 1.0, 0.4)):
     lcls, lbox, lobj = torch.zeros(1), torch.zeros(1), torch.zeros(1)
     tcls, tbox, indices, anch = build_targets([pi.shape for pi in p], targets, anchors, hyp["anchor_t"])
     pw_cls, pw_obj = torch.tensor([hyp["cls_pw"]]), torch.tensor([hyp["obj_pw"]])
+    g = float(hyp.get("fl_gamma", 0.0))
+
+    def bce(pred, true, pw):
+        """BCEWithLogitsLoss(pos_weight), mean; fl_gamma > 0: wrapped in FocalLoss(gamma, alpha=0.25) -- utils/loss.py:77-98, :120-122."""
+        if g <= 0:
+            return F.binary_cross_entropy_with_logits(pred, true, pos_weight=pw)
+        loss = F.binary_cross_entropy_with_logits(pred, true, pos_weight=pw, reduction="none")
+        prob = pred.sigmoid()
+        p_t = true * prob + (1 - true) * (1 - prob)
+        return (loss * (true * 0.25 + (1 - true) * 0.75) * (1.0 - p_t) ** g).mean()
+
     for i, pi in enumerate(p):
         b, a, gj, gi = indices[i]
         tobj = torch.zeros(pi.shape[:4], dtype=pi.dtype)
@@ -585,8 +596,8 @@ def compute_loss(p, targets, anchors, hyp=None, nc=80, balance=(4.0, 1.0, 0.4)):
             if nc > 1:
                 t = torch.full_like(pcls, cn)
                 t[range(n), tcls[i]] = cp
-                lcls = lcls + F.binary_cross_entropy_with_logits(pcls, t, pos_weight=pw_cls)
-        obji = F.binary_cross_entropy_with_logits(pi[..., 4], tobj, pos_weight=pw_obj)
+                lcls = lcls + bce(pcls, t, pw_cls)
+        obji = bce(pi[..., 4], tobj, pw_obj)
         lobj = lobj + obji * balance[i]
     lbox = lbox * hyp["box"]
     lobj = lobj * hyp["obj"]

@@ -17,7 +17,7 @@ G = np.load(os.path.join(os.path.dirname(__file__), "golden", "loss.npz"))
 HYP = yo.HYP_SCRATCH_LOW
 
 
-def make_desc(shapes, anchors, dtype):
+def make_desc(shapes, anchors, dtype, fl_gamma=0.0, smoothing=0.0):
     d = _lib.LossDesc()
     d.dtype = _lib.Y5_F16 if dtype == np.float16 else _lib.Y5_F32
     d.nl, d.na, d.nc, d.bs = len(shapes), shapes[0][1], shapes[0][4] - 5, shapes[0][0]
@@ -27,13 +27,14 @@ def make_desc(shapes, anchors, dtype):
         for a in range(d.na):
             d.anchors[i * 16 + a * 2], d.anchors[i * 16 + a * 2 + 1] = float(anchors[i, a, 0]), float(anchors[i, a, 1])
     d.hyp_box, d.hyp_obj, d.hyp_cls = HYP["box"], HYP["obj"], HYP["cls"]
-    d.cls_pw, d.obj_pw, d.anchor_t, d.cp, d.cn = HYP["cls_pw"], HYP["obj_pw"], HYP["anchor_t"], 1.0, 0.0
+    d.cls_pw, d.obj_pw, d.anchor_t, d.cp, d.cn = HYP["cls_pw"], HYP["obj_pw"], HYP["anchor_t"], 1.0 - 0.5 * smoothing, 0.5 * smoothing
+    d.fl_gamma = fl_gamma
     return d
 
 
-def run_emu_loss(pn, tn, anchors, dtype=np.float32, scale=None):
+def run_emu_loss(pn, tn, anchors, dtype=np.float32, scale=None, fl_gamma=0.0, smoothing=0.0):
     lib = emu()
-    d = make_desc([p.shape for p in pn], anchors, dtype)
+    d = make_desc([p.shape for p in pn], anchors, dtype, fl_gamma, smoothing)
     nt = len(tn)
     nbytes = lib.y5_loss_workspace_bytes(C.byref(d), nt)
     assert nbytes > 0
@@ -130,3 +131,18 @@ def test_emu_loss_duplicate_cells_last_write_wins():
     np.testing.assert_allclose(out[1:], items.numpy(), rtol=1e-5, atol=1e-7)
     for i in range(3):
         np.testing.assert_allclose(D[i], p[i].grad.numpy(), rtol=2e-4, atol=2e-9)
+
+
+def test_emu_loss_focal_vs_reference_golden():
+    """fl_gamma = 1.5, label smoothing 0.1: the kernels' focal BCE (value and derivative) against the reference's FocalLoss-wrapped ComputeLoss."""
+    F_ = np.load(os.path.join(os.path.dirname(__file__), "golden", "loss_focal.npz"))
+    pn, tn = loss_case("synthetic")
+    out, D, _rows = run_emu_loss(pn, tn, G["anchors"], fl_gamma=1.5, smoothing=0.1)
+    np.testing.assert_allclose(out[0], F_["loss"][0], rtol=1e-5)
+    np.testing.assert_allclose(out[1:], F_["items"], rtol=1e-5)
+    for i in range(3):
+        s = D[i].astype(np.float64)
+        np.testing.assert_allclose([s.sum(), np.abs(s).sum()], F_[f"grad{i}_sum"], rtol=2e-5)
+        nz = F_[f"grad{i}_nzidx"]
+        np.testing.assert_allclose(D[i][tuple(nz.T)], F_[f"grad{i}_nzrows"], rtol=3e-4, atol=2e-9)
+        np.testing.assert_allclose(D[i][0, 0, :4, :8, 4], F_[f"grad{i}_obj_head"], rtol=3e-4, atol=1e-10)

@@ -104,3 +104,27 @@ def test_loss_full_size_vs_oracle_and_determinism(compute_loss, dev):
         l.backward()
     torch.cuda.synchronize()
     print(f"\n[loss] bs=64 640^2 nt=512 fp16: {(time.time() - t0) / 10 * 1e3:.3f} ms fwd+bwd on MI355X; CPU oracle fp32 {cpu_s * 1e3:.0f} ms")
+
+
+def test_loss_focal_vs_reference_golden(dev):
+    """hyp fl_gamma = 1.5 + label smoothing 0.1 through yolov5_amd.loss.ComputeLoss on the GPU against the reference's FocalLoss-wrapped ComputeLoss."""
+    from yolov5_amd.loss import ComputeLoss
+    from yolov5_amd.yolo import DetectionModel
+
+    F_ = np.load(os.path.join(os.path.dirname(__file__), "golden", "loss_focal.npz"))
+    m = DetectionModel("yolov5s.yaml").to(dev)
+    m.hyp = dict(yo.HYP_SCRATCH_LOW, fl_gamma=1.5, label_smoothing=0.1)
+    cl = ComputeLoss(m)
+    pn, tn = loss_case("synthetic")
+    p = [torch.from_numpy(a).to(dev).requires_grad_(True) for a in pn]
+    loss, items = cl(p, torch.from_numpy(tn).to(dev))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), F_["loss"][0], rtol=1e-4)
+    np.testing.assert_allclose(items.cpu().numpy(), F_["items"], rtol=1e-4)
+    for i in range(3):
+        g = p[i].grad.cpu().numpy()
+        s = g.astype(np.float64)
+        np.testing.assert_allclose([s.sum(), np.abs(s).sum()], F_[f"grad{i}_sum"], rtol=1e-4)
+        nz = F_[f"grad{i}_nzidx"]
+        np.testing.assert_allclose(g[tuple(nz.T)], F_[f"grad{i}_nzrows"], rtol=1e-3, atol=1e-8)
+        np.testing.assert_allclose(g[0, 0, :4, :8, 4], F_[f"grad{i}_obj_head"], rtol=1e-3, atol=1e-9)

@@ -208,3 +208,23 @@ def test_training_sample_pipeline_matches_reference_golden(seed):
     imb, labb = ao.collate(samples)
     assert np.array_equal(imb, g[f"img{seed}"])
     assert labb.shape == g[f"lab{seed}"].shape and np.array_equal(labb, g[f"lab{seed}"])
+
+
+def test_loss_focal():
+    """hyp fl_gamma = 1.5 + label smoothing 0.1 (utils/loss.py:120-122 -> FocalLoss :77-98): the oracle's restatement against the reference's own
+    ComputeLoss (tests/golden/loss_focal.npz, oracle/make_golden.py gen_loss)."""
+    g, gp = _load("loss_focal.npz"), _load("loss.npz")
+    pn, tn = loss_case("synthetic")
+    p = [torch.from_numpy(a).clone().requires_grad_(True) for a in pn]
+    hyp = dict(yo.HYP_SCRATCH_LOW, fl_gamma=1.5, label_smoothing=0.1)
+    loss, items = yo.compute_loss(p, torch.from_numpy(tn), torch.from_numpy(gp["anchors"]), hyp=hyp)
+    loss.backward()
+    np.testing.assert_allclose(loss.detach().numpy(), g["loss"], rtol=1e-6)
+    np.testing.assert_allclose(items.numpy(), g["items"], rtol=1e-6)
+    for i in range(3):
+        gr = p[i].grad.numpy()
+        s = gr.astype(np.float64)
+        np.testing.assert_allclose([s.sum(), np.abs(s).sum()], g[f"grad{i}_sum"], rtol=1e-6)
+        nz = g[f"grad{i}_nzidx"]
+        np.testing.assert_allclose(gr[tuple(nz.T)], g[f"grad{i}_nzrows"], rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(gr[0, 0, :4, :8, 4], g[f"grad{i}_obj_head"], rtol=1e-5, atol=1e-10)

@@ -30,7 +30,7 @@ class LossDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("nl", C.c_int), ("na", C.c_int), ("nc", C.c_int), ("bs", C.c_int),
                 ("ny", C.c_int * 5), ("nx", C.c_int * 5), ("anchors", C.c_float * 80), ("balance", C.c_float * 5),
                 ("hyp_box", C.c_float), ("hyp_obj", C.c_float), ("hyp_cls", C.c_float), ("cls_pw", C.c_float),
-                ("obj_pw", C.c_float), ("anchor_t", C.c_float), ("cp", C.c_float), ("cn", C.c_float)]
+                ("obj_pw", C.c_float), ("anchor_t", C.c_float), ("cp", C.c_float), ("cn", C.c_float), ("fl_gamma", C.c_float)]
 
 
 class FilterJob(C.Structure):

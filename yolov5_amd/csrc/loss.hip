@@ -52,7 +52,7 @@ Layout layout(const y5_loss_desc* d, int nt) {
 
 void fill(Y5LossParams& P, const y5_loss_desc* d, const Layout& L, char* ws, int nt) {
   P.nl = d->nl; P.na = d->na; P.nc = d->nc; P.no = 5 + d->nc; P.bs = d->bs; P.nt = nt;
-  P.hyp_box = d->hyp_box; P.hyp_obj = d->hyp_obj; P.hyp_cls = d->hyp_cls; P.cls_pw = d->cls_pw; P.obj_pw = d->obj_pw;
+  P.hyp_box = d->hyp_box; P.hyp_obj = d->hyp_obj; P.hyp_cls = d->hyp_cls; P.cls_pw = d->cls_pw; P.obj_pw = d->obj_pw; P.fl_gamma = d->fl_gamma;
   P.anchor_t = d->anchor_t; P.cp = d->cp; P.cn = d->cn;
   P.n_rows = reinterpret_cast<int*>(ws + L.n_rows);
   for (int i = 0; i < d->nl; ++i) {

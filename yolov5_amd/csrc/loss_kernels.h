@@ -50,15 +50,31 @@ struct Y5LossParams {
   const float* gscale;   // device scalar multiplied into the gradient (may be null = 1)
   int nl, na, nc, no, bs, nt;
   float hyp_box, hyp_obj, hyp_cls, cls_pw, obj_pw, anchor_t, cp, cn;
+  float fl_gamma;  // > 0: focal loss around both BCE terms (utils/loss.py:77-98 FocalLoss(alpha = 0.25), :120-122)
 };
 
 __device__ __forceinline__ float y5_sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 // BCEWithLogits(x, t, pos_weight) element and its derivative w.r.t. x (torch: binary_cross_entropy_with_logits)
-__device__ __forceinline__ float y5_bce(float x, float t, float pw, float& dx) {
+// gamma > 0: FocalLoss (utils/loss.py:77-98, alpha = 0.25 as ComputeLoss constructs it, :120-122): the element becomes
+//     bce * (t a + (1-t)(1-a)) * (1 - p_t)^gamma,   p_t = t s + (1-t)(1-s),  s = sigmoid(x)
+// and its derivative follows by the product rule (d p_t / dx = (2t - 1) s (1 - s)).
+__device__ __forceinline__ float y5_bce(float x, float t, float pw, float& dx, float gamma = 0.0f) {
   const float lw = 1.0f + (pw - 1.0f) * t;
   const float sp = log1pf(expf(-fabsf(x))) + fmaxf(-x, 0.0f);  // softplus(-x)
-  dx = (1.0f - t) + lw * (y5_sigmoid_acc(x) - 1.0f);
-  return (1.0f - t) * x + lw * sp;
+  const float sg = y5_sigmoid_acc(x);
+  const float dbce = (1.0f - t) + lw * (sg - 1.0f);
+  const float bce = (1.0f - t) * x + lw * sp;
+  if (!(gamma > 0.0f)) {
+    dx = dbce;
+    return bce;
+  }
+  const float af = t * 0.25f + (1.0f - t) * 0.75f;
+  const float q = 1.0f - (t * sg + (1.0f - t) * (1.0f - sg));  // 1 - p_t
+  const float m = powf(q, gamma);
+  const float dq = -(2.0f * t - 1.0f) * sg * (1.0f - sg);
+  const float dm = gamma * powf(q, gamma - 1.0f) * dq;
+  dx = af * (dbce * m + bce * dm);
+  return bce * af * m;
 }
 
 template <typename T> __device__ __forceinline__ float y5_round_to(float v) { return (float)(T)v; }
@@ -167,7 +183,7 @@ void y5_loss_rows_kernel(const Y5LossParams p, int lvl) {
       const float x = (float)row[5 + c];
       const float t = c == cls ? p.cp : p.cn;
       float dx;
-      lsum += y5_bce(x, t, p.cls_pw, dx);
+      lsum += y5_bce(x, t, p.cls_pw, dx, p.fl_gamma);
       G[5 + c] = dx * gk;
     }
   } else {
@@ -268,7 +284,7 @@ void y5_loss_obj_fwd_kernel(const Y5LossParams p, int lvl) {
     const int w = y5_loss_winner(L, L.head[cell]);
     const float t = w >= 0 ? L.iou[w] : 0.f;
     float dx;
-    l = y5_bce(x, t, p.obj_pw, dx);
+    l = y5_bce(x, t, p.obj_pw, dx, p.fl_gamma);
   }
   s_red[threadIdx.x] = l;
   __syncthreads();
@@ -341,7 +357,7 @@ void y5_loss_bwd_kernel(const Y5LossParams p, int lvl) {
     const int w = y5_loss_winner(L, h);
     const float t = w >= 0 ? L.iou[w] : 0.f;
     float dx;
-    y5_bce(x, t, p.obj_pw, dx);
+    y5_bce(x, t, p.obj_pw, dx, p.fl_gamma);
     g4 = dx * gobj;
   }
   s_g[tid] = g4;

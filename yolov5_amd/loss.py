@@ -83,8 +83,6 @@ class ComputeLoss:
         if autobalance:
             raise NotImplementedError("ComputeLoss(autobalance=True) (loss.py:173-177) needs a per-step host read-back; not supported")
         h = model.hyp
-        if h.get("fl_gamma", 0.0) > 0:
-            raise NotImplementedError("focal loss (fl_gamma > 0, loss.py:120-122) is not part of the hot path")
         self.cp, self.cn = smooth_bce(eps=h.get("label_smoothing", 0.0))
         m = de_parallel(model).model[-1]  # Detect()
         self.balance = {3: [4.0, 1.0, 0.4]}.get(m.nl, [4.0, 1.0, 0.25, 0.06, 0.02])
@@ -125,6 +123,7 @@ class ComputeLoss:
         h = self.hyp
         d.hyp_box, d.hyp_obj, d.hyp_cls = float(h["box"]), float(h["obj"]), float(h["cls"])
         d.cls_pw, d.obj_pw, d.anchor_t = float(h["cls_pw"]), float(h["obj_pw"]), float(h["anchor_t"])
+        d.fl_gamma = float(h.get("fl_gamma", 0.0))  # loss.py:120-122: > 0 wraps BCEcls and BCEobj in FocalLoss(gamma) (alpha = 0.25)
         d.cp, d.cn = float(self.cp), float(self.cn)
         return d
 
