@@ -87,6 +87,8 @@ CONV_CASES = [
     (4, 80, 80, 32, 64, 3, 2, 1, 1, False, False, 34, 0, "f16"),
     (8, 40, 40, 64, 64, 3, 1, 1, 1, True, False, 32, 8, "f16"),
     (2, 20, 24, 64, 56, 3, 1, 1, 1, False, False, 32, 0, "f16"),
+    (8, 80, 80, 64, 64, 3, 1, 1, 1, True, False, 78, 0, "f16"),     # filter fragments in registers
+    (8, 40, 40, 64, 64, 3, 1, 1, 1, False, False, 79, 8, "f16"),
     # halo-resident 3x3 kernel (conv_h3.h, cfg 61..70): several chunks per tile and several tiles per workgroup so that the counted-vmcnt
     # filter ring, the next-chunk halo prefetch and the cross-tile prologue all reach steady state on the real memory system
     (8, 80, 80, 64, 64, 3, 1, 1, 1, True, False, 62, 16, "f16"),

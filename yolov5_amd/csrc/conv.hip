@@ -275,20 +275,23 @@ int launch_pw_by_cfg(const Y5ConvParams& p, int idx, int mb, hipStream_t s) {
 
 // ---- streaming 3x3 configurations (conv_k3.h): ids kK3_0 + index ------------------------------------------------
 struct K3Cfg { int c1, nt, sh, s; };
-constexpr int kK3_0 = 30, kNumK3 = 5;
+constexpr int kK3_0 = 30, kNumK3 = 7;
+constexpr int kK3W_0 = 78;  // ids 78, 79 = kK3Cfgs[5], [6]: the 64-channel kernel with the filter in registers (added after the id space was laid out)
 constexpr K3Cfg kK3Cfgs[kNumK3] = {
     {32, 1, 1, 3},  // 30: 3x3 s1 32->32, 3 stages   (Bottleneck.cv2 @160)
     {32, 2, 2, 2},  // 31: 3x3 s2 32->64, 2 stages   (Conv 1 @320->160)
     {64, 2, 1, 2},  // 32: 3x3 s1 64->64, 2 stages   (Bottleneck.cv2 @80)
     {32, 1, 1, 2},  // 33: 3x3 s1 32->32, 2 stages
     {32, 2, 2, 3},  // 34: 3x3 s2 32->64, 3 stages
+    {64, 2, 1, 3},  // 78: 3x3 s1 64->64, filter fragments in registers, 3 stages
+    {64, 2, 1, 4},  // 79: the same, 4 stages
 };
 
-template <int C1, int NT, int SH, int S, bool RES, bool ACT, int NT2 = 0>
+template <int C1, int NT, int SH, int S, bool RES, bool ACT, int NT2 = 0, bool WREG = false>
 int launch_k3_v(const Y5ConvParams& p, int max_blocks, hipStream_t stream) {
-  const size_t lds = y5_conv_k3_lds_bytes<C1, NT, SH, S, NT2>();
+  const size_t lds = y5_conv_k3_lds_bytes<C1, NT, SH, S, NT2, WREG>();
   if (lds > 160 * 1024) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: 3x3 streaming configuration exceeds 160 KiB of LDS");
-  auto kern = y5_conv_k3_kernel<C1, NT, SH, S, RES, ACT, NT2>;
+  auto kern = y5_conv_k3_kernel<C1, NT, SH, S, RES, ACT, NT2, WREG>;
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -313,14 +316,16 @@ int launch_k3_v(const Y5ConvParams& p, int max_blocks, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(256), lds, stream, p);
   return y5_check_launch("y5_conv2d_fwd(k3)");
 }
-template <int C1, int NT, int SH, int S>
+template <int C1, int NT, int SH, int S, bool WREG = false>
 int launch_k3(const Y5ConvParams& p, int mb, hipStream_t st) {
-  if (p.res) return p.act ? launch_k3_v<C1, NT, SH, S, true, true>(p, mb, st) : launch_k3_v<C1, NT, SH, S, true, false>(p, mb, st);
-  return p.act ? launch_k3_v<C1, NT, SH, S, false, true>(p, mb, st) : launch_k3_v<C1, NT, SH, S, false, false>(p, mb, st);
+  if (p.res) return p.act ? launch_k3_v<C1, NT, SH, S, true, true, 0, WREG>(p, mb, st) : launch_k3_v<C1, NT, SH, S, true, false, 0, WREG>(p, mb, st);
+  return p.act ? launch_k3_v<C1, NT, SH, S, false, true, 0, WREG>(p, mb, st) : launch_k3_v<C1, NT, SH, S, false, false, 0, WREG>(p, mb, st);
 }
 
 int launch_k3_by_cfg(const Y5ConvParams& p, int idx, int mb, hipStream_t s) {
   switch (idx) {
+    case 5: return launch_k3<64, 2, 1, 3, true>(p, mb, s);
+    case 6: return launch_k3<64, 2, 1, 4, true>(p, mb, s);
     case 0: return launch_k3<32, 1, 1, 3>(p, mb, s);
     case 1: return launch_k3<32, 2, 2, 2>(p, mb, s);
     case 2: return launch_k3<64, 2, 1, 2>(p, mb, s);
@@ -364,6 +369,13 @@ extern "C" int y5_conv_set_sk_workspace(void* ws, size_t bytes, void* stream_) {
 
 extern "C" int y5_conv_cfg_info(int cfg, int* bm, int* bn, int* bk_bytes) {
   if (cfg < 0 || cfg >= Y5_CONV_NUM_CFGS) return y5_fail(Y5_ERR_BAD_ARG, "conv_cfg_info: bad id");
+  if (cfg >= kK3W_0) {
+    const K3Cfg& c = kK3Cfgs[5 + cfg - kK3W_0];
+    if (bm) *bm = 128;
+    if (bn) *bn = c.nt * 32;
+    if (bk_bytes) *bk_bytes = 9 * c.c1 * 2;
+    return Y5_OK;
+  }
   if (cfg >= kH3_0) {
     int m = 0, n = 0;
     y5_h3_cfg_info(cfg - kH3_0, &m, &n);
@@ -423,12 +435,14 @@ extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w
   const int epp = 16 / es;
   int cfg = d->cfg < 0 ? default_cfg(d) : d->cfg;
   if (cfg >= Y5_CONV_NUM_CFGS) return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown tile config");
-  const bool h3 = cfg >= kH3_0;
-  const bool sk = cfg >= kSk0 && !h3;
-  const bool pw = (cfg >= kNumIgemm && cfg < kRing0) || (cfg >= kPw2_0 && !sk && !h3);
+  const bool k3w = cfg >= kK3W_0;                 // streaming 3x3 with the filter in registers (ids 78..)
+  const bool h3 = cfg >= kH3_0 && !k3w;
+  const bool sk = cfg >= kSk0 && !h3 && !k3w;
+  const bool pw = (cfg >= kNumIgemm && cfg < kRing0) || (cfg >= kPw2_0 && !sk && !h3 && !k3w);
   const int pwi = cfg >= kPw2_0 ? 8 + cfg - kPw2_0 : cfg - kNumIgemm;
   const bool big = cfg >= kBig0 && cfg < kPw2_0;
-  const bool k3 = cfg >= kK3_0 && cfg < kBig0;
+  const bool k3 = (cfg >= kK3_0 && cfg < kBig0) || k3w;
+  const int k3i = k3w ? 5 + cfg - kK3W_0 : cfg - kK3_0;
   const int bk = (pw || k3 || h3) ? 8 : (sk ? kSkCfgs[cfg - kSk0].rb : big ? kBigCfgs[cfg - kBig0].rb : kCfgs[cfg >= kRing0 ? kRingBase[cfg - kRing0] : cfg].rb) / es;
   if (cfg >= kRing0 && d->dtype != Y5_F16) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: ring configurations are fp16 only");
   if (d->C1 % epp || d->ldx % epp) return y5_fail(Y5_ERR_BAD_ARG, "conv: C1 and ldx must be multiples of 16 bytes");
@@ -477,11 +491,11 @@ extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w
     return y5_launch_h3_by_cfg(p, cfg - kH3_0, d->max_blocks, stream);
   }
   if (k3) {
-    const K3Cfg& c = kK3Cfgs[cfg - kK3_0];
+    const K3Cfg& c = kK3Cfgs[k3i];
     if (d->dtype != Y5_F16 || d->KH != 3 || d->KW != 3 || d->SH != c.sh || d->SW != c.sh || d->PH != 1 || d->PW != 1 || !y || y_up2 ||
         d->C1 != c.c1 || d->Npad != c.nt * 32 || (oh & 3) || (ow & 7) || d->Kpad < 9 * c.c1 || d->H > 255 * 4 || d->W > 65535)
       return y5_fail(Y5_ERR_UNSUPPORTED, "conv: 3x3 streaming configuration does not match this layer");
-    return launch_k3_by_cfg(p, cfg - kK3_0, d->max_blocks, stream);
+    return launch_k3_by_cfg(p, k3i, d->max_blocks, stream);
   }
   if (pw) {
     const PwCfg& c = kPwCfgs[pwi];

@@ -12,11 +12,11 @@
 #pragma once
 #include "conv_pw.h"
 
-template <int C1, int NT, int SH, int S, int NT2 = 0>
+template <int C1, int NT, int SH, int S, int NT2 = 0, bool WREG = false>
 constexpr size_t y5_conv_k3_lds_bytes() {
   constexpr int RH = 3 * SH + 3, RW = 7 * SH + 3, NSL = C1 / 8;
   constexpr int NI = (RH * RW * NSL + 63) / 64;
-  return (size_t)NT * 32 * 9 * C1 * 2 + (size_t)NT * 32 * 4 + (size_t)4 * S * NI * 1024 + (size_t)NT2 * 32 * (NT * 32 * 2 + 4);
+  return (WREG ? 0 : (size_t)NT * 32 * 9 * C1 * 2) + (size_t)NT * 32 * 4 + (size_t)4 * S * NI * 1024 + (size_t)NT2 * 32 * (NT * 32 * 2 + 4);
 }
 
 // NT2 > 0 (PW2): a pointwise convolution with NT2 * 32 (padded) output channels is applied to every finished tile before it leaves the wave --
@@ -25,7 +25,11 @@ constexpr size_t y5_conv_k3_lds_bytes() {
 // layout an MFMA activation fragment is read from (pixel rows, 16-byte slots XOR-swizzled by the row), multiplied with the second filter
 // (resident in LDS beside the first), and the SECOND epilogue's result is what the tile stores (split over two destinations like the
 // split store of conv_igemm.h).
-template <int C1, int NT, int SH, int S, bool RES, bool ACT = true, int NT2 = 0>
+// WREG: the filter's MFMA fragments (9 taps x C1/16 k-steps x NT blocks x 16 bytes per lane) live in REGISTERS for the lifetime of the workgroup
+// instead of LDS.  At C1 = 64 the LDS-resident filter (74 KB) leaves room for one workgroup of four waves per CU and every MFMA waits for a filter
+// fragment read (72 of the 108 ds_read_b128 per tile: the loop ran at ~30 % matrix-core occupancy, 62 us for a layer whose HBM floor is 31 us); one
+// wave per SIMD has 512 registers, 288 of which hold the filter here, and LDS carries only the activation stages (more of them).
+template <int C1, int NT, int SH, int S, bool RES, bool ACT = true, int NT2 = 0, bool WREG = false>
 __global__ __launch_bounds__(256)
 void y5_conv_k3_kernel(const Y5ConvParams p) {
   typedef half_t T;
@@ -39,7 +43,7 @@ void y5_conv_k3_kernel(const Y5ConvParams p) {
   constexpr int STAGE = NI * 1024;
   constexpr int K2 = 9 * C1 * 2;                      // bytes per filter row in LDS
   constexpr int WSL = 9 * NSL;                        // 16-byte slots per filter row
-  constexpr int W_BYTES = NPAD * K2;
+  constexpr int W_BYTES = WREG ? 0 : NPAD * K2;
   constexpr int KS = C1 / 16;                         // MFMA k-steps per tap
   constexpr int SPR = NPAD / 8, RPP = 64 / SPR, NPASS = 32 / RPP;
   constexpr int SWM = SPR >= 8 ? 7 : SPR - 1;
@@ -68,7 +72,7 @@ void y5_conv_k3_kernel(const Y5ConvParams p) {
 
   // ---- prologue: filter (swizzled per row like the activation rows) + bias into LDS ---------------------------
   {
-    constexpr int WI = NPAD * WSL / 64;
+    constexpr int WI = WREG ? 0 : NPAD * WSL / 64;
     for (int I = wave; I < WI; I += 4) {
       const int pidx = I * 64 + lane;
       const int n = pidx / WSL, ps = pidx - n * WSL;
@@ -116,6 +120,18 @@ void y5_conv_k3_kernel(const Y5ConvParams p) {
   int wsl[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) wsl[ks] = pl * K2 + (((ks * 2 + g) ^ fsw(pl)) * 16);
+  half8_t wreg[WREG ? 9 : 1][WREG ? KS : 1][WREG ? NT : 1];
+  if constexpr (WREG) {
+    const T* wg = static_cast<const T*>(p.w);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          wreg[t][ks][j] = *reinterpret_cast<const half8_t*>(wg + (size_t)(j * 32 + pl) * p.Kpad + t * C1 + ks * 16 + g * 8);
+    y5_wait_vm<0>();  // retired here, ahead of the counted-vmcnt ring: none of these loads may sit in the queue the tile loop counts
+  }
   const int orow = lane / SPR, oslot = lane % SPR;
   const int orow2 = lane / SPR2, oslot2 = lane % SPR2;
   T* __restrict__ y2g = static_cast<T*>(p.y2);
@@ -199,7 +215,9 @@ void y5_conv_k3_kernel(const Y5ConvParams p) {
         const half8_t af = *reinterpret_cast<const half8_t*>(st + rd[t][ks]);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          const half8_t wf = *reinterpret_cast<const half8_t*>(wlds + j * 32 * K2 + t * NSL * 16 + wsl[ks]);
+          half8_t wf;
+          if constexpr (WREG) wf = wreg[t][ks][j];
+          else wf = *reinterpret_cast<const half8_t*>(wlds + j * 32 * K2 + t * NSL * 16 + wsl[ks]);
           if ((t * KS + ks) & 1) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, af, acc2[j], 0, 0, 0);
           else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, af, acc[j], 0, 0, 0);
         }
