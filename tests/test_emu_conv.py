@@ -47,6 +47,10 @@ CASES = [
     (1, 4, 24, 64, 56, 3, 1, 1, 1, False, False, 32, 2, "f16"),
     (3, 8, 8, 64, 64, 3, 1, 1, 1, True, False, 78, 1, "f16"),       # the 64-channel kernel with the filter in registers
     (1, 12, 24, 64, 56, 3, 1, 1, 0, False, False, 79, 2, "f16"),
+    (3, 8, 16, 64, 64, 3, 1, 1, 1, True, False, 80, 1, "f16"),      # eight waves per workgroup, one stage each
+    (2, 16, 32, 32, 64, 3, 2, 1, 1, False, False, 81, 1, "f16"),
+    (3, 8, 16, 32, 32, 3, 1, 1, 1, True, False, 82, 1, "f16"),
+    (1, 12, 24, 32, 32, 3, 1, 1, 0, False, False, 83, 2, "f16"),
     # halo-resident 3x3 kernel (conv_h3.h): one / several channel chunks, spatial tiles that do not divide the image, N tiles with a
     # padded tail, residual in place, several tiles per workgroup, 4- and 8-wave layouts
     (2, 9, 8, 32, 64, 3, 1, 1, 1, True, False, 61, 0, "f16"),

@@ -20,6 +20,7 @@ from yolov5_amd.packing import pack_conv_weight
     (2, 16, 32, 64, 64, 64, 40, 31, 1, 1),      # everything to y, input a slice of a wider buffer, one workgroup walks all tiles (2-stage ring)
     (1, 24, 48, 64, 48, 16, 32, 34, 2, 0),      # 48 real output channels (padded to 64), no activation behind the 1x1, 3-stage ring steady state
     (3, 8, 16, 56, 64, 32, 32, -1, 0, 1),       # 3x3 with 56 real channels (padded filter rows / columns are zeros)
+    (2, 16, 48, 64, 64, 32, 32, 81, 1, 1),      # eight waves per workgroup, one stage each
 ])
 def test_k3pw_matches_torch(B, H, W, c2, c3, split, ldx, cfg, mb, act2):
     lib = emu()

@@ -89,6 +89,10 @@ CONV_CASES = [
     (2, 20, 24, 64, 56, 3, 1, 1, 1, False, False, 32, 0, "f16"),
     (8, 80, 80, 64, 64, 3, 1, 1, 1, True, False, 78, 0, "f16"),     # filter fragments in registers
     (8, 40, 40, 64, 64, 3, 1, 1, 1, False, False, 79, 8, "f16"),
+    (8, 80, 80, 64, 64, 3, 1, 1, 1, True, False, 80, 0, "f16"),     # eight waves per workgroup
+    (8, 160, 160, 32, 64, 3, 2, 1, 1, False, False, 81, 0, "f16"),
+    (8, 80, 80, 32, 32, 3, 1, 1, 1, True, False, 82, 8, "f16"),
+    (8, 80, 80, 32, 32, 3, 1, 1, 1, False, False, 83, 0, "f16"),
     # halo-resident 3x3 kernel (conv_h3.h, cfg 61..70): several chunks per tile and several tiles per workgroup so that the counted-vmcnt
     # filter ring, the next-chunk halo prefetch and the cross-tile prologue all reach steady state on the real memory system
     (8, 80, 80, 64, 64, 3, 1, 1, 1, True, False, 62, 16, "f16"),
@@ -375,7 +379,7 @@ def test_split_engine_matches_single_plan(dev):
 
 
 # ---- 3x3 s2 Conv + the pointwise convolution behind it as one launch (conv_k3.h PW2) ------------------------------------------------
-@pytest.mark.parametrize("B,H,W,c3,split,mb", [(8, 160, 160, 64, 32, 0), (4, 96, 64, 48, 48, 4), (16, 64, 128, 64, 16, 0)])
+@pytest.mark.parametrize("B,H,W,c3,split,mb", [(8, 160, 160, 64, 32, 0), (4, 96, 64, 48, 48, 4), (16, 64, 128, 64, 16, 0), (8, 160, 160, 64, 32, 81 << 16)])
 def test_conv_k3pw_matches_torch(B, H, W, c3, split, mb, dev):
     """y5_conv_k3pw_fwd (models/yolo.py walking 1.Conv -> 2.C3.cv1+cv2) on the real memory system: many tiles per wave, so the counted-vmcnt ring
     with the second epilogue's stores reaches steady state; reference = torch fp32 on the same fp16 data with the intermediate rounded to fp16."""
@@ -397,7 +401,7 @@ def test_conv_k3pw_matches_torch(B, H, W, c3, split, mb, dev):
     y = torch.full((B, OH, OW, ldy), 7.0, dtype=torch.float16, device=dev)
     y2 = torch.full((B, OH, OW, ld2), 7.0, dtype=torch.float16, device=dev) if split < c3 else None
     d = _lib.ConvDesc(dtype=_lib.Y5_F16, B=B, H=H, W=W, C1=32, ldx=32, OH=OH, OW=OW, C2=64, ldy=64, KH=3, KW=3, SH=2, SW=2, PH=1, PW=1, act=1,
-                      Kpad=K1, Npad=N1, ldr=0, ld2=0, cfg=-1, max_blocks=mb)
+                      Kpad=K1, Npad=N1, ldr=0, ld2=0, cfg=(mb >> 16) or -1, max_blocks=mb & 0xffff)
     st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     rc = lib.y5_conv_k3pw_fwd(C.byref(d), C.c_void_p(xd.data_ptr()), C.c_void_p(w1d.data_ptr()), C.c_void_p(b1d.data_ptr()), C.c_void_p(w2d.data_ptr()),
                               C.c_void_p(b2d.data_ptr()), c3, N2, K2, 1, C.c_void_p(y.data_ptr()), ldy, C.c_void_p(y2.data_ptr()) if y2 is not None else None,

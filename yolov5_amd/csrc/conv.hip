@@ -275,7 +275,7 @@ int launch_pw_by_cfg(const Y5ConvParams& p, int idx, int mb, hipStream_t s) {
 
 // ---- streaming 3x3 configurations (conv_k3.h): ids kK3_0 + index ------------------------------------------------
 struct K3Cfg { int c1, nt, sh, s; };
-constexpr int kK3_0 = 30, kNumK3 = 7;
+constexpr int kK3_0 = 30, kNumK3 = 11;
 constexpr int kK3W_0 = 78;  // ids 78, 79 = kK3Cfgs[5], [6]: the 64-channel kernel with the filter in registers (added after the id space was laid out)
 constexpr K3Cfg kK3Cfgs[kNumK3] = {
     {32, 1, 1, 3},  // 30: 3x3 s1 32->32, 3 stages   (Bottleneck.cv2 @160)
@@ -285,20 +285,24 @@ constexpr K3Cfg kK3Cfgs[kNumK3] = {
     {32, 2, 2, 3},  // 34: 3x3 s2 32->64, 3 stages
     {64, 2, 1, 3},  // 78: 3x3 s1 64->64, filter fragments in registers, 3 stages
     {64, 2, 1, 4},  // 79: the same, 4 stages
+    {64, 2, 1, 1},  // 80: 3x3 s1 64->64, EIGHT waves with one stage each (two waves per SIMD under one LDS filter copy)
+    {32, 2, 2, 1},  // 81: 3x3 s2 32->64, eight waves, one stage
+    {32, 1, 1, 1},  // 82: 3x3 s1 32->32, eight waves, one stage
+    {32, 1, 1, 2},  // 83: 3x3 s1 32->32, eight waves, two stages
 };
 
-template <int C1, int NT, int SH, int S, bool RES, bool ACT, int NT2 = 0, bool WREG = false>
+template <int C1, int NT, int SH, int S, bool RES, bool ACT, int NT2 = 0, bool WREG = false, int NWV = 4>
 int launch_k3_v(const Y5ConvParams& p, int max_blocks, hipStream_t stream) {
-  const size_t lds = y5_conv_k3_lds_bytes<C1, NT, SH, S, NT2, WREG>();
+  const size_t lds = y5_conv_k3_lds_bytes<C1, NT, SH, S, NT2, WREG, NWV>();
   if (lds > 160 * 1024) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: 3x3 streaming configuration exceeds 160 KiB of LDS");
-  auto kern = y5_conv_k3_kernel<C1, NT, SH, S, RES, ACT, NT2, WREG>;
+  auto kern = y5_conv_k3_kernel<C1, NT, SH, S, RES, ACT, NT2, WREG, NWV>;
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   const long long nwt = (long long)p.B * (p.OH / 4) * (p.OW / 8);
-  const long long nbt = (nwt + 3) >> 2;
+  const long long nbt = (nwt + NWV - 1) / NWV;
   long long G = max_blocks;
   if (G <= 0) {
     if (!g_num_cu) {
@@ -308,24 +312,28 @@ int launch_k3_v(const Y5ConvParams& p, int max_blocks, hipStream_t stream) {
       g_num_cu = n > 0 ? n : 256;
     }
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), 256, lds) != hipSuccess || occ < 1) occ = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), NWV * 64, lds) != hipSuccess || occ < 1) occ = 1;
     G = (long long)g_num_cu * occ;
   }
   if (G > nbt) G = nbt;
   if (G >= 8) G &= ~7LL;
-  hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(NWV * 64), lds, stream, p);
   return y5_check_launch("y5_conv2d_fwd(k3)");
 }
-template <int C1, int NT, int SH, int S, bool WREG = false>
+template <int C1, int NT, int SH, int S, bool WREG = false, int NWV = 4>
 int launch_k3(const Y5ConvParams& p, int mb, hipStream_t st) {
-  if (p.res) return p.act ? launch_k3_v<C1, NT, SH, S, true, true, 0, WREG>(p, mb, st) : launch_k3_v<C1, NT, SH, S, true, false, 0, WREG>(p, mb, st);
-  return p.act ? launch_k3_v<C1, NT, SH, S, false, true, 0, WREG>(p, mb, st) : launch_k3_v<C1, NT, SH, S, false, false, 0, WREG>(p, mb, st);
+  if (p.res) return p.act ? launch_k3_v<C1, NT, SH, S, true, true, 0, WREG, NWV>(p, mb, st) : launch_k3_v<C1, NT, SH, S, true, false, 0, WREG, NWV>(p, mb, st);
+  return p.act ? launch_k3_v<C1, NT, SH, S, false, true, 0, WREG, NWV>(p, mb, st) : launch_k3_v<C1, NT, SH, S, false, false, 0, WREG, NWV>(p, mb, st);
 }
 
 int launch_k3_by_cfg(const Y5ConvParams& p, int idx, int mb, hipStream_t s) {
   switch (idx) {
     case 5: return launch_k3<64, 2, 1, 3, true>(p, mb, s);
     case 6: return launch_k3<64, 2, 1, 4, true>(p, mb, s);
+    case 7: return launch_k3<64, 2, 1, 1, false, 8>(p, mb, s);
+    case 8: return launch_k3<32, 2, 2, 1, false, 8>(p, mb, s);
+    case 9: return launch_k3<32, 1, 1, 1, false, 8>(p, mb, s);
+    case 10: return launch_k3<32, 1, 1, 2, false, 8>(p, mb, s);
     case 0: return launch_k3<32, 1, 1, 3>(p, mb, s);
     case 1: return launch_k3<32, 2, 2, 2>(p, mb, s);
     case 2: return launch_k3<64, 2, 1, 2>(p, mb, s);
@@ -535,8 +543,8 @@ extern "C" int y5_conv_k3pw_fwd(const y5_conv_desc* d, const void* x, const void
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (!d || !x || !w1_packed || !bias1 || !w2_packed || !bias2 || !y) return y5_fail(Y5_ERR_BAD_ARG, "conv_k3pw: null pointer");
   const int cfg = d->cfg < 0 ? kK3_0 + 4 : d->cfg;
-  if (cfg != kK3_0 + 1 && cfg != kK3_0 + 4) return y5_fail(Y5_ERR_UNSUPPORTED, "conv_k3pw: built for the 3x3 s2 32->64 streaming configurations (31, 34)");
-  const K3Cfg& c = kK3Cfgs[cfg - kK3_0];
+  if (cfg != kK3_0 + 1 && cfg != kK3_0 + 4 && cfg != 81) return y5_fail(Y5_ERR_UNSUPPORTED, "conv_k3pw: built for the 3x3 s2 32->64 streaming configurations (31, 34, 81)");
+  const K3Cfg& c = kK3Cfgs[1];
   const int oh = (d->H + 2 - 3) / 2 + 1, ow = (d->W + 2 - 3) / 2 + 1;
   if (d->dtype != Y5_F16 || d->KH != 3 || d->KW != 3 || d->SH != 2 || d->SW != 2 || d->PH != 1 || d->PW != 1 || d->C1 != c.c1 || d->Npad != c.nt * 32 ||
       d->C2 > d->Npad || (d->C2 & 7) || oh != d->OH || ow != d->OW || (oh & 3) || (ow & 7) || d->Kpad < 9 * c.c1 || d->H > 255 * 4 || d->W > 65535 || (d->ldx & 7) ||
@@ -559,6 +567,7 @@ extern "C" int y5_conv_k3pw_fwd(const y5_conv_desc* d, const void* x, const void
   p.pw2_w = w2_packed; p.pw2_bias = bias2; p.pw2_w_bytes = (unsigned)((long long)Npad2 * Kpad2 * 2);
   p.pw2_kpad = Kpad2; p.pw2_npad = Npad2; p.pw2_c2 = C3; p.pw2_act = act2; p.pw2_split = split_n;
   // two ring stages: with the second filter beside the first a third stage per wave does not fit the 160 KiB (cfg 34 maps to the same kernel)
+  if (cfg == 81) return launch_k3_v<32, 2, 2, 1, false, true, 2, false, 8>(p, d->max_blocks, stream);  // eight waves, one stage each
   return launch_k3_v<32, 2, 2, 2, false, true, 2>(p, d->max_blocks, stream);
 }
 
@@ -610,6 +619,12 @@ extern "C" int y5_conv_stem_fwd(const void* x_nchw, int B, int H, int W, const v
   p.nwt = B * p.OH * p.tiles_per_row;
   return Npad == 32 ? launch_stem<1, 4>(p, max_blocks, stream) : launch_stem<2, 3>(p, max_blocks, stream);
 }
+
+#ifdef Y5_K3_TIMING
+extern "C" int y5_k3_dbg_read(unsigned long long* out) {  // kernel-experiment builds only (not part of the ABI)
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(y5_k3_dbg), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
 
 #ifdef Y5_DBG_TIMING
 extern "C" int y5_dbg_read_timing(unsigned long long* out) {  // kernel-experiment builds only (not part of the ABI)

@@ -12,11 +12,15 @@
 #pragma once
 #include "conv_pw.h"
 
-template <int C1, int NT, int SH, int S, int NT2 = 0, bool WREG = false>
+#ifdef Y5_K3_TIMING
+__device__ unsigned long long y5_k3_dbg[64];  // workgroup 0, per wave: stage wait, residual issue, MFMA loop, epilogue + stores, refill issue (s_memtime), tiles
+#endif
+
+template <int C1, int NT, int SH, int S, int NT2 = 0, bool WREG = false, int NWV = 4>
 constexpr size_t y5_conv_k3_lds_bytes() {
   constexpr int RH = 3 * SH + 3, RW = 7 * SH + 3, NSL = C1 / 8;
   constexpr int NI = (RH * RW * NSL + 63) / 64;
-  return (WREG ? 0 : (size_t)NT * 32 * 9 * C1 * 2) + (size_t)NT * 32 * 4 + (size_t)4 * S * NI * 1024 + (size_t)NT2 * 32 * (NT * 32 * 2 + 4);
+  return (WREG ? 0 : (size_t)NT * 32 * 9 * C1 * 2) + (size_t)NT * 32 * 4 + (size_t)NWV * S * NI * 1024 + (size_t)NT2 * 32 * (NT * 32 * 2 + 4);
 }
 
 // NT2 > 0 (PW2): a pointwise convolution with NT2 * 32 (padded) output channels is applied to every finished tile before it leaves the wave --
@@ -29,8 +33,12 @@ constexpr size_t y5_conv_k3_lds_bytes() {
 // instead of LDS.  At C1 = 64 the LDS-resident filter (74 KB) leaves room for one workgroup of four waves per CU and every MFMA waits for a filter
 // fragment read (72 of the 108 ds_read_b128 per tile: the loop ran at ~30 % matrix-core occupancy, 62 us for a layer whose HBM floor is 31 us); one
 // wave per SIMD has 512 registers, 288 of which hold the filter here, and LDS carries only the activation stages (more of them).
-template <int C1, int NT, int SH, int S, bool RES, bool ACT = true, int NT2 = 0, bool WREG = false>
-__global__ __launch_bounds__(256)
+// NWV: waves per workgroup (4 or 8).  The in-kernel phase timing (scripts/k3_timing.py) shows a wave spending ~55 % of a tile outside the MFMA loop -- every
+// vector-memory instruction (stage refill, residual loads, stores) holds it 100-160 cycles at issue, plus the epilogue -- and with the filter in LDS only one
+// workgroup fits a CU: at 4 waves every SIMD idles through all of that.  Eight waves with ONE stage each share the same filter copy: two waves per SIMD,
+// one's memory phases under the other's MFMAs ("resident waves beat prefetch depth", as measured for conv_bneck.h).
+template <int C1, int NT, int SH, int S, bool RES, bool ACT = true, int NT2 = 0, bool WREG = false, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64)
 void y5_conv_k3_kernel(const Y5ConvParams p) {
   typedef half_t T;
   constexpr int NPAD = 32 * NT;
@@ -73,23 +81,23 @@ void y5_conv_k3_kernel(const Y5ConvParams p) {
   // ---- prologue: filter (swizzled per row like the activation rows) + bias into LDS ---------------------------
   {
     constexpr int WI = WREG ? 0 : NPAD * WSL / 64;
-    for (int I = wave; I < WI; I += 4) {
+    for (int I = wave; I < WI; I += NWV) {
       const int pidx = I * 64 + lane;
       const int n = pidx / WSL, ps = pidx - n * WSL;
       const int src_slot = (ps & ~(NSL - 1)) | ((ps & (NSL - 1)) ^ fsw(n));
       y5_bglds16(wrs, (unsigned)((n * p.Kpad) * 2 + src_slot * 16), wlds + I * 1024);
     }
-    for (int i = tid; i < NPAD; i += 256) blds[i] = p.bias[i];
+    for (int i = tid; i < NPAD; i += NWV * 64) blds[i] = p.bias[i];
     if constexpr (NT2 > 0) {
       const y5_rsrc_t w2rs = y5_make_rsrc(p.pw2_w, p.pw2_w_bytes);
       constexpr int NSL2 = NPAD / 8, W2I = NPAD2 * NSL2 / 64;
-      for (int I = wave; I < W2I; I += 4) {
+      for (int I = wave; I < W2I; I += NWV) {
         const int pidx = I * 64 + lane;
         const int n = pidx / NSL2, ps = pidx - n * NSL2;
         const int sw = NSL2 >= 8 ? ((n >> 1) & 7) : ((n >> 2) & 3);
         y5_bglds16(w2rs, (unsigned)(n * p.pw2_kpad * 2 + ((ps ^ sw) * 16)), w2lds + I * 1024);
       }
-      for (int i = tid; i < NPAD2; i += 256) b2lds[i] = i < p.pw2_npad ? p.pw2_bias[i] : 0.f;
+      for (int i = tid; i < NPAD2; i += NWV * 64) b2lds[i] = i < p.pw2_npad ? p.pw2_bias[i] : 0.f;
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
@@ -140,9 +148,9 @@ void y5_conv_k3_kernel(const Y5ConvParams p) {
   const int tw = p.OW / TC, th = p.OH / TR;
   const int nwt = p.B * th * tw;
   const int G = gridDim.x, bid = blockIdx.x;
-  const int nbt = (nwt + 3) >> 2;
+  const int nbt = (nwt + NWV - 1) / NWV;
   const int nmine = (nbt - bid + G - 1) / G;
-  auto tile_id = [&](int j) { return y5_xcd_remap(bid + j * G, nbt) * 4 + wave; };
+  auto tile_id = [&](int j) { return y5_xcd_remap(bid + j * G, nbt) * NWV + wave; };
   int nw = nmine;
   if (nw > 0 && tile_id(nw - 1) >= nwt) --nw;
   auto tile_origin = [&](int j, int& b, int& oh0, int& ow0) {
@@ -173,8 +181,14 @@ void y5_conv_k3_kernel(const Y5ConvParams p) {
   for (int s = 0; s < S; ++s)
     if (s < nw) issue(s, s);
 
+#ifdef Y5_K3_TIMING
+  unsigned long long d_wait = 0, d_res = 0, d_mfma = 0, d_epi = 0, d_issue = 0;
+#endif
   int buf = 0;
   for (int i = 0; i < nw; ++i) {
+#ifdef Y5_K3_TIMING
+    const unsigned long long k_t0 = __builtin_amdgcn_s_memtime();
+#endif
     constexpr int PER = LP + SP + RP;
     if (i + S - 1 >= nw) {
       y5_wait_vm<0>();
@@ -189,6 +203,9 @@ void y5_conv_k3_kernel(const Y5ConvParams p) {
       y5_wait_vm<(S - 1) * PER>();
     }
     __builtin_amdgcn_wave_barrier();
+#ifdef Y5_K3_TIMING
+    const unsigned long long k_t1 = __builtin_amdgcn_s_memtime();
+#endif
     char* st = ring + buf * STAGE;
     int b, oh0, ow0;
     tile_origin(i, b, oh0, ow0);
@@ -202,6 +219,9 @@ void y5_conv_k3_kernel(const Y5ConvParams p) {
         resv[ps] = *reinterpret_cast<const uint4_t*>(rg + m * p.ldr + oslot * 8);
       }
     }
+#ifdef Y5_K3_TIMING
+    const unsigned long long k_t2 = __builtin_amdgcn_s_memtime();
+#endif
     // two accumulators per output tile (alternating k-steps): back-to-back MFMAs never wait on their own result
     float16_t acc[NT], acc2[NT];
 #pragma unroll
@@ -224,6 +244,10 @@ void y5_conv_k3_kernel(const Y5ConvParams p) {
       }
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[j] += acc2[j];
+#ifdef Y5_K3_TIMING
+    asm volatile("" :: "v"(acc[0][0]));
+    const unsigned long long k_t3 = __builtin_amdgcn_s_memtime();
+#endif
     // epilogue: bias + SiLU -> scratch (vacated stage) -> (+ residual) -> 16-byte stores
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -299,7 +323,20 @@ void y5_conv_k3_kernel(const Y5ConvParams p) {
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+#ifdef Y5_K3_TIMING
+    const unsigned long long k_t4 = __builtin_amdgcn_s_memtime();
+#endif
     if (i + S < nw) issue(i + S, buf);
     buf = buf + 1 == S ? 0 : buf + 1;
+#ifdef Y5_K3_TIMING
+    const unsigned long long k_t5 = __builtin_amdgcn_s_memtime();
+    d_wait += k_t1 - k_t0; d_res += k_t2 - k_t1; d_mfma += k_t3 - k_t2; d_epi += k_t4 - k_t3; d_issue += k_t5 - k_t4;
+#endif
   }
+#ifdef Y5_K3_TIMING
+  if (lane == 0 && blockIdx.x == 0) {
+    unsigned long long* o = y5_k3_dbg + wave * 8;
+    o[0] = d_wait; o[1] = d_res; o[2] = d_mfma; o[3] = d_epi; o[4] = d_issue; o[5] = nw;
+  }
+#endif
 }
