@@ -60,7 +60,7 @@ typedef struct {
                  * no upsampled replica, residual or output placement in that mode */
 } y5_conv_desc;
 
-#define Y5_CONV_NUM_CFGS 84   /* 0..13 implicit-GEMM tiles (2 LDS stages), 14..21 streaming pointwise (1x1 s1, fp16),
+#define Y5_CONV_NUM_CFGS 88   /* 0..13 implicit-GEMM tiles (2 LDS stages), 14..21 streaming pointwise (1x1 s1, fp16),
                                 22..29 implicit-GEMM tiles with a 3-stage LDS ring (fp16), 30..34 streaming 3x3 (small C, fp16),
                                 35..39 256-row implicit-GEMM tiles with 2-4 stage rings, 4 or 8 waves (fp16, deep layers),
                                 40..45 producer/consumer implicit GEMM: 4 MFMA waves + 4 LDS-DMA waves per workgroup (fp16),
@@ -72,7 +72,8 @@ typedef struct {
                                 61..77 halo-resident 3x3 s1 (fp16, C1 % 32 == 0): a workgroup owns a spatial output tile, the input halo is
                                 staged once per 32-channel chunk and serves all nine taps, only the filter streams per tap,
                                 78..79 streaming 3x3 s1 64 -> 64 with the filter's MFMA fragments in registers (3 / 4 LDS stages),
-                                80..83 streaming 3x3 with EIGHT waves per workgroup and one (two) stage(s) per wave: 64->64 s1, 32->64 s2, 32->32 s1 */
+                                80..83 streaming 3x3 with EIGHT waves per workgroup and one (two) stage(s) per wave: 64->64 s1, 32->64 s2, 32->32 s1,
+                                84..87 streaming pointwise with eight waves per workgroup, one stage per wave: 128->128, 64->64, 128->64, 128->256 */
 /* Scratch for the stream-K configurations (57..60): `bytes` of device memory (256-byte aligned; bytes >= y5_conv_sk_workspace_bytes())
  * that the CALLER owns and keeps alive; registered per device, used by every later y5_conv2d_fwd with such a configuration on ANY
  * stream -- so launches that may overlap in time must not both use stream-K (the engine keeps it off its side-stream ops).  The

@@ -38,6 +38,11 @@ CASES = [
     (6, 8, 16, 128, 64, 1, 1, 0, 1, False, False, 21, 1, "f16"),
     (5, 8, 16, 128, 256, 1, 1, 0, 0, False, False, 56, 1, "f16"),  # 128->256 without activation (P3 Detect head), epilogue in two groups
     (3, 8, 16, 128, 248, 1, 1, 0, 1, False, False, 56, 2, "f16"),  # C2 tail inside the second group, partial workgroup tile
+    # eight waves per workgroup, one stage per wave
+    (5, 8, 16, 128, 128, 1, 1, 0, 1, False, True, 84, 1, "f16"),
+    (7, 8, 16, 64, 64, 1, 1, 0, 1, False, False, 85, 1, "f16"),
+    (5, 8, 16, 128, 64, 1, 1, 0, 1, False, False, 86, 2, "f16"),
+    (3, 8, 16, 128, 248, 1, 1, 0, 0, False, False, 87, 1, "f16"),
     # streaming 3x3 kernel (conv_k3.h): borders on all sides, partial workgroup tile, residual (in place), stride 2
     (2, 8, 16, 32, 32, 3, 1, 1, 1, True, False, 30, 1, "f16"),
     (1, 12, 8, 32, 32, 3, 1, 1, 0, False, False, 33, 2, "f16"),

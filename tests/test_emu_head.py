@@ -25,7 +25,7 @@ def _inputs(B, ny, nx, ldx, seed):
     return x, wp_a, bp_a, Kpad, Npad
 
 
-@pytest.mark.parametrize("B,ny,nx,max_blocks,row_off,extra", [(2, 8, 8, 0, 0, 0), (3, 8, 12, 1, 8, 16), (1, 16, 20, 2, 0, 8)])
+@pytest.mark.parametrize("B,ny,nx,max_blocks,row_off,extra", [(2, 8, 8, 0, 0, 0), (3, 8, 12, 1, 8, 16), (1, 16, 20, 2, 0, 8), (3, 8, 12, 1 | (87 << 16), 8, 16)])
 def test_fused_head_bit_identical_to_conv_plus_decode(B, ny, nx, max_blocks, row_off, extra):
     lib = emu()
     ldx = 136
@@ -35,7 +35,7 @@ def test_fused_head_bit_identical_to_conv_plus_decode(B, ny, nx, max_blocks, row
     nrows = row_off + 3 * npix + extra
     anchors = (C.c_float * 6)(10.0, 13.0, 16.0, 30.0, 33.0, 23.0)
     d = _lib.ConvDesc(dtype=_lib.Y5_F16, B=B, H=ny, W=nx, C1=128, ldx=ldx, OH=ny, OW=nx, C2=256, ldy=256, KH=1, KW=1, SH=1, SW=1, PH=0, PW=0,
-                      act=0, Kpad=Kpad, Npad=Npad, ldr=0, ld2=0, cfg=56, max_blocks=max_blocks)
+                      act=0, Kpad=Kpad, Npad=Npad, ldr=0, ld2=0, cfg=(max_blocks >> 16) or 56, max_blocks=max_blocks & 0xffff)  # (87 << 16: the eight-wave kernels)
     # two-call form
     lg = aligned((B, ny, nx, 256), np.float16, -9.0)
     assert lib.y5_conv2d_fwd(C.byref(d), ptr(x), ptr(wp), ptr(bp), None, ptr(lg), None, None) == 0, lib.y5_last_error()

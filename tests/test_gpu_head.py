@@ -17,7 +17,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("B,ny,nx,max_blocks,row_off,extra", [(4, 80, 80, 0, 0, 6000), (2, 8, 12, 1, 8, 16), (3, 40, 40, 0, 0, 0)])
+@pytest.mark.parametrize("B,ny,nx,max_blocks,row_off,extra", [(4, 80, 80, 0, 0, 6000), (2, 8, 12, 1, 8, 16), (3, 40, 40, 0, 0, 0), (4, 80, 80, 87 << 16, 0, 6000)])
 def test_fused_head_bit_identical(B, ny, nx, max_blocks, row_off, extra, dev):
     from yolov5_amd import _lib
     from yolov5_amd.packing import pack_conv_weight
@@ -34,7 +34,7 @@ def test_fused_head_bit_identical(B, ny, nx, max_blocks, row_off, extra, dev):
     nrows = row_off + 3 * npix + extra
     anchors = (C.c_float * 6)(10.0, 13.0, 16.0, 30.0, 33.0, 23.0)
     d = _lib.ConvDesc(dtype=_lib.Y5_F16, B=B, H=ny, W=nx, C1=128, ldx=ldx, OH=ny, OW=nx, C2=256, ldy=256, KH=1, KW=1, SH=1, SW=1, PH=0, PW=0,
-                      act=0, Kpad=Kpad, Npad=Npad, ldr=0, ld2=0, cfg=56, max_blocks=max_blocks)
+                      act=0, Kpad=Kpad, Npad=Npad, ldr=0, ld2=0, cfg=(max_blocks >> 16) or 56, max_blocks=max_blocks & 0xffff)  # (87 << 16: the eight-wave kernels)
     st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
     lg = torch.full((B, ny, nx, 256), -9.0, dtype=torch.float16, device=dev)

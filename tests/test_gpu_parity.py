@@ -61,6 +61,10 @@ CONV_CASES = [
     (5, 8, 16, 128, 256, 1, 1, 0, 0, False, False, 56, 1, "f16"),  # P3 Detect head shape: split-epilogue pointwise kernel
     (3, 8, 16, 128, 248, 1, 1, 0, 1, False, False, 56, 2, "f16"),
     (16, 80, 80, 128, 256, 1, 1, 0, 0, False, False, 56, 0, "f16"),  # many tiles per wave on the full grid
+    (16, 40, 40, 128, 128, 1, 1, 0, 1, False, True, 84, 8, "f16"),    # eight waves per workgroup
+    (64, 40, 40, 64, 64, 1, 1, 0, 1, False, False, 85, 0, "f16"),
+    (16, 20, 20, 128, 64, 1, 1, 0, 1, False, False, 86, 8, "f16"),
+    (16, 80, 80, 128, 256, 1, 1, 0, 0, False, False, 87, 0, "f16"),
     # 256-row tiles with deep rings (cfg 35..39) at deep-layer shapes: many chunks per tile, several tiles per workgroup
     (8, 40, 40, 128, 128, 3, 1, 1, 1, True, False, 35, 16, "f16"),
     (8, 40, 40, 128, 128, 3, 1, 1, 1, False, False, 36, 0, "f16"),

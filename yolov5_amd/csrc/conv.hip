@@ -206,7 +206,8 @@ int launch_by_cfg(const Y5ConvParams& p, int cfg, int mb, hipStream_t s) {
 
 // ---- streaming pointwise configurations (conv_pw.h): id = kNumIgemm + index ---------------------------------
 struct PwCfg { int kc, rb, nt, s; };
-constexpr int kNumPw = 9;
+constexpr int kNumPw = 13;
+constexpr int kPw8_0 = 84;  // ids 84.. = kPwCfgs[9..]: eight waves per workgroup, one stage per wave
 constexpr int kPw2_0 = 56;  // pointwise configurations added after the id space was laid out: ids 56.. = kPwCfgs[8..]
 constexpr PwCfg kPwCfgs[kNumPw] = {
     {1, 64, 1, 4},   // 14:  32 ->  32, 4 stages
@@ -218,19 +219,23 @@ constexpr PwCfg kPwCfgs[kNumPw] = {
     {2, 128, 4, 2},  // 20: 128 -> 128, 2 stages
     {2, 128, 2, 4},  // 21: 128 ->  64, 4 stages
     {2, 128, 8, 2},  // 56: 128 -> 256 (the P3 Detect head), epilogue in two channel groups
+    {2, 128, 4, 1},  // 84: 128 -> 128, eight waves
+    {1, 128, 2, 1},  // 85:  64 ->  64, eight waves
+    {2, 128, 2, 1},  // 86: 128 ->  64, eight waves
+    {2, 128, 8, 1},  // 87: 128 -> 256, eight waves, epilogue in two channel groups
 };
 
-template <int KC, int RB, int NT, int S, bool UP2, bool ACT, int OS = 1>
+template <int KC, int RB, int NT, int S, bool UP2, bool ACT, int OS = 1, int NWV = 4>
 int launch_pw_v(const Y5ConvParams& p, int max_blocks, hipStream_t stream) {
-  const size_t lds = y5_conv_pw_lds_bytes<KC, RB, NT, S, OS>();
+  const size_t lds = y5_conv_pw_lds_bytes<KC, RB, NT, S, OS, NWV>();
   if (lds > 160 * 1024) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: pointwise configuration exceeds 160 KiB of LDS");
-  auto kern = y5_conv_pw_kernel<KC, RB, NT, S, UP2, ACT, OS>;
+  auto kern = y5_conv_pw_kernel<KC, RB, NT, S, UP2, ACT, OS, NWV>;
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  const long long nbt = ((long long)(p.M >> 5) + 3) >> 2;
+  const long long nbt = ((long long)(p.M >> 5) + NWV - 1) / NWV;
   long long G = max_blocks;
   if (G <= 0) {
     if (!g_num_cu) {
@@ -240,22 +245,22 @@ int launch_pw_v(const Y5ConvParams& p, int max_blocks, hipStream_t stream) {
       g_num_cu = n > 0 ? n : 256;
     }
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), 256, lds) != hipSuccess || occ < 1) occ = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), NWV * 64, lds) != hipSuccess || occ < 1) occ = 1;
     G = (long long)g_num_cu * occ;
   }
   if (G > nbt) G = nbt;
   if (G >= 8) G &= ~7LL;
-  hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(NWV * 64), lds, stream, p);
   return y5_check_launch("y5_conv2d_fwd(pw)");
 }
-template <int KC, int RB, int NT, int S, int OS = 1>
+template <int KC, int RB, int NT, int S, int OS = 1, int NWV = 4>
 int launch_pw(const Y5ConvParams& p, int mb, hipStream_t st) {
   if constexpr (OS == 1) {
-    if (p.y2 && !p.split_n) return p.act ? launch_pw_v<KC, RB, NT, S, true, true>(p, mb, st) : launch_pw_v<KC, RB, NT, S, true, false>(p, mb, st);
+    if (p.y2 && !p.split_n) return p.act ? launch_pw_v<KC, RB, NT, S, true, true, 1, NWV>(p, mb, st) : launch_pw_v<KC, RB, NT, S, true, false, 1, NWV>(p, mb, st);
   } else {
     if (p.y2 && !p.split_n) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: split-epilogue pointwise configuration has no upsampled replica");
   }
-  return p.act ? launch_pw_v<KC, RB, NT, S, false, true, OS>(p, mb, st) : launch_pw_v<KC, RB, NT, S, false, false, OS>(p, mb, st);
+  return p.act ? launch_pw_v<KC, RB, NT, S, false, true, OS, NWV>(p, mb, st) : launch_pw_v<KC, RB, NT, S, false, false, OS, NWV>(p, mb, st);
 }
 
 int launch_pw_by_cfg(const Y5ConvParams& p, int idx, int mb, hipStream_t s) {
@@ -269,6 +274,10 @@ int launch_pw_by_cfg(const Y5ConvParams& p, int idx, int mb, hipStream_t s) {
     case 6: return launch_pw<2, 128, 4, 2>(p, mb, s);
     case 7: return launch_pw<2, 128, 2, 4>(p, mb, s);
     case 8: return launch_pw<2, 128, 8, 2, 2>(p, mb, s);
+    case 9: return launch_pw<2, 128, 4, 1, 1, 8>(p, mb, s);
+    case 10: return launch_pw<1, 128, 2, 1, 1, 8>(p, mb, s);
+    case 11: return launch_pw<2, 128, 2, 1, 1, 8>(p, mb, s);
+    case 12: return launch_pw<2, 128, 8, 1, 2, 8>(p, mb, s);
   }
   return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown pointwise config");
 }
@@ -377,6 +386,13 @@ extern "C" int y5_conv_set_sk_workspace(void* ws, size_t bytes, void* stream_) {
 
 extern "C" int y5_conv_cfg_info(int cfg, int* bm, int* bn, int* bk_bytes) {
   if (cfg < 0 || cfg >= Y5_CONV_NUM_CFGS) return y5_fail(Y5_ERR_BAD_ARG, "conv_cfg_info: bad id");
+  if (cfg >= kPw8_0) {
+    const PwCfg& c = kPwCfgs[9 + cfg - kPw8_0];
+    if (bm) *bm = 256;
+    if (bn) *bn = c.nt * 32;
+    if (bk_bytes) *bk_bytes = c.kc * c.rb;
+    return Y5_OK;
+  }
   if (cfg >= kK3W_0) {
     const K3Cfg& c = kK3Cfgs[5 + cfg - kK3W_0];
     if (bm) *bm = 128;
@@ -443,11 +459,12 @@ extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w
   const int epp = 16 / es;
   int cfg = d->cfg < 0 ? default_cfg(d) : d->cfg;
   if (cfg >= Y5_CONV_NUM_CFGS) return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown tile config");
-  const bool k3w = cfg >= kK3W_0;                 // streaming 3x3 with the filter in registers (ids 78..)
-  const bool h3 = cfg >= kH3_0 && !k3w;
-  const bool sk = cfg >= kSk0 && !h3 && !k3w;
+  const bool pw8 = cfg >= kPw8_0;                 // streaming pointwise with eight waves per workgroup (ids 84..)
+  const bool k3w = cfg >= kK3W_0 && !pw8;         // streaming 3x3 added after the id space was laid out (ids 78..83)
+  const bool h3 = cfg >= kH3_0 && !k3w && !pw8;
+  const bool sk = cfg >= kSk0 && !h3 && !k3w && !pw8;
   const bool pw = (cfg >= kNumIgemm && cfg < kRing0) || (cfg >= kPw2_0 && !sk && !h3 && !k3w);
-  const int pwi = cfg >= kPw2_0 ? 8 + cfg - kPw2_0 : cfg - kNumIgemm;
+  const int pwi = pw8 ? 9 + cfg - kPw8_0 : cfg >= kPw2_0 ? 8 + cfg - kPw2_0 : cfg - kNumIgemm;
   const bool big = cfg >= kBig0 && cfg < kPw2_0;
   const bool k3 = (cfg >= kK3_0 && cfg < kBig0) || k3w;
   const int k3i = k3w ? 5 + cfg - kK3W_0 : cfg - kK3_0;

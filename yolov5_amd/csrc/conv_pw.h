@@ -15,12 +15,12 @@
 #pragma once
 #include "conv_igemm.h"
 
-template <int KC, int RB, int NT, int S, int OS = 1>
+template <int KC, int RB, int NT, int S, int OS = 1, int NWV = 4>
 constexpr size_t y5_conv_pw_lds_bytes() {
   constexpr int NPAD = 32 * NT;
   constexpr int STAGE_A = 32 * KC * RB, STAGE_O = 32 * NPAD * 2 / OS;
   constexpr int STAGE = STAGE_A > STAGE_O ? STAGE_A : STAGE_O;
-  return (size_t)KC * NPAD * RB + (size_t)NPAD * 4 + (size_t)4 * S * STAGE;
+  return (size_t)KC * NPAD * RB + (size_t)NPAD * 4 + (size_t)NWV * S * STAGE;
 }
 
 // OS > 1 (wide outputs, e.g. the 255-channel Detect heads): the epilogue leaves in OS channel groups of NT/OS sub-tiles each, so
@@ -37,7 +37,7 @@ struct Y5HeadParams {
   void* obj_hint;          // HINT kernels: (B, nrows_total) fp16 plane receiving a copy of every row's objectness (z[..., 4]) for the NMS filter
 };
 
-template <int KC, int RB, int NT, int S, bool UP2, bool ACT, int OS, bool DEC, bool HINT = false>
+template <int KC, int RB, int NT, int S, bool UP2, bool ACT, int OS, bool DEC, bool HINT = false, int NWV = 4>
 __device__ __forceinline__ void y5_conv_pw_body(const Y5ConvParams& p, const Y5HeadParams* hp) {
   typedef half_t T;
   static_assert(NT % OS == 0, "output split must divide the channel sub-tiles");
@@ -73,12 +73,12 @@ __device__ __forceinline__ void y5_conv_pw_body(const Y5ConvParams& p, const Y5H
   {
     constexpr int WI = NPAD * RB / 1024;  // LDS-DMA instructions per filter chunk
     for (int kc = 0; kc < KC; ++kc)
-      for (int idx = wave; idx < WI; idx += 4) {
+      for (int idx = wave; idx < WI; idx += NWV) {
         const int row = idx * RPI + lrow;
         const int sslot = lslot ^ Y5ConvGeom<T, RB>::swz(row);
         y5_glds16(reinterpret_cast<const char*>(wg + (size_t)row * p.Kpad) + kc * RB + sslot * 16, wlds + kc * NPAD * RB + idx * 1024);
       }
-    for (int i = tid; i < NPAD; i += 256) blds[i] = p.bias[i];
+    for (int i = tid; i < NPAD; i += NWV * 64) blds[i] = p.bias[i];
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
   }
@@ -86,9 +86,9 @@ __device__ __forceinline__ void y5_conv_pw_body(const Y5ConvParams& p, const Y5H
   // ---- tile schedule: workgroup tiles of 128 pixels, wave w takes rows [32w, 32w+32) --------------------
   const int G = gridDim.x, bid = blockIdx.x;
   const int nwt = p.M >> 5;                 // 32-pixel wave tiles (host guarantees M % 32 == 0)
-  const int nbt = (nwt + 3) >> 2;
+  const int nbt = (nwt + NWV - 1) / NWV;
   const int nmine = (nbt - bid + G - 1) / G;
-  auto tile_m0 = [&](int j) { return (y5_xcd_remap(bid + j * G, nbt) * 4 + wave) * 32; };
+  auto tile_m0 = [&](int j) { return (y5_xcd_remap(bid + j * G, nbt) * NWV + wave) * 32; };
   int nw = nmine;                           // this wave's tile count (the last workgroup tile may be partial)
   if (nw > 0 && tile_m0(nw - 1) >= p.M) --nw;
 
@@ -276,15 +276,16 @@ __device__ __forceinline__ void y5_conv_pw_body(const Y5ConvParams& p, const Y5H
   }
 }
 
-template <int KC, int RB, int NT, int S, bool UP2, bool ACT = true, int OS = 1>
-__global__ __launch_bounds__(256)
+// NWV = 8: eight waves per workgroup under one LDS filter copy (two per SIMD), normally with a single stage each -- as conv_k3.h
+template <int KC, int RB, int NT, int S, bool UP2, bool ACT = true, int OS = 1, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64)
 void y5_conv_pw_kernel(const Y5ConvParams p) {
-  y5_conv_pw_body<KC, RB, NT, S, UP2, ACT, OS, false>(p, nullptr);
+  y5_conv_pw_body<KC, RB, NT, S, UP2, ACT, OS, false, false, NWV>(p, nullptr);
 }
 
 // 1x1 Detect convolution (128 -> 3 x 85 channels) + Detect decode in one pass (export / z-only mode)
-template <int KC, int RB, int NT, int S, int OS, bool HINT = false>
-__global__ __launch_bounds__(256)
+template <int KC, int RB, int NT, int S, int OS, bool HINT = false, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64)
 void y5_conv_pw_head_kernel(const Y5ConvParams p, const Y5HeadParams h) {
-  y5_conv_pw_body<KC, RB, NT, S, false, false, OS, true, HINT>(p, &h);
+  y5_conv_pw_body<KC, RB, NT, S, false, false, OS, true, HINT, NWV>(p, &h);
 }

@@ -40,15 +40,21 @@ extern "C" int y5_detect_head_fwd_hint(const y5_conv_desc* d, const void* x, con
   h.obj_hint = obj_hint;
   if (obj_hint && ((uintptr_t)obj_hint & 15)) return y5_fail(Y5_ERR_BAD_ARG, "detect_head: hint plane must be 16-byte aligned");
 
-  const size_t lds = y5_conv_pw_lds_bytes<KC, RB, NT, S, OS>();
-  auto kern = obj_hint ? y5_conv_pw_head_kernel<KC, RB, NT, S, OS, true> : y5_conv_pw_head_kernel<KC, RB, NT, S, OS, false>;
+  // d->cfg == 87: eight waves per workgroup with one stage each (two waves per SIMD under one filter copy); otherwise four waves, two stages
+  const bool w8 = d->cfg == 87;
+  const int nwv = w8 ? 8 : 4;
+  const size_t lds = w8 ? y5_conv_pw_lds_bytes<KC, RB, NT, 1, OS, 8>() : y5_conv_pw_lds_bytes<KC, RB, NT, S, OS>();
+  auto kern = w8 ? (obj_hint ? y5_conv_pw_head_kernel<KC, RB, NT, 1, OS, true, 8> : y5_conv_pw_head_kernel<KC, RB, NT, 1, OS, false, 8>)
+                 : (obj_hint ? y5_conv_pw_head_kernel<KC, RB, NT, S, OS, true> : y5_conv_pw_head_kernel<KC, RB, NT, S, OS, false>);
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(y5_conv_pw_head_kernel<KC, RB, NT, S, OS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(y5_conv_pw_head_kernel<KC, RB, NT, S, OS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(y5_conv_pw_head_kernel<KC, RB, NT, 1, OS, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(y5_conv_pw_head_kernel<KC, RB, NT, 1, OS, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  const long long nbt = ((long long)(p.M >> 5) + 3) >> 2;
+  const long long nbt = ((long long)(p.M >> 5) + nwv - 1) / nwv;
   long long G = d->max_blocks;
   if (G <= 0) {
     static int num_cu = 0;
@@ -59,12 +65,12 @@ extern "C" int y5_detect_head_fwd_hint(const y5_conv_desc* d, const void* x, con
       num_cu = n > 0 ? n : 256;
     }
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), 256, lds) != hipSuccess || occ < 1) occ = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), nwv * 64, lds) != hipSuccess || occ < 1) occ = 1;
     G = (long long)num_cu * occ;
   }
   if (G > nbt) G = nbt;
   if (G >= 8) G &= ~7LL;
-  hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(256), lds, static_cast<hipStream_t>(stream_), p, h);
+  hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(nwv * 64), lds, static_cast<hipStream_t>(stream_), p, h);
   return y5_check_launch("y5_detect_head_fwd");
 }
 

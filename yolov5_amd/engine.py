@@ -868,7 +868,7 @@ class Engine:
         if head is not None:
             self._fused_heads.add(head["level"])
             self._anchor_ops.append((self.lib.y5_plan_size(self.plan), head["level"]))
-            self.conv_cfgs.append(56)
+            self.conv_cfgs.append(head["cfg"])
             self.op_names.append("conv+decode:" + op["name"])
             rc = self.lib.y5_plan_add_detect_head(self.plan, C.byref(d), ptrs[0], ptrs[1], ptrs[2], *head["args"])
             if rc == 0 and self._hint:
@@ -975,30 +975,38 @@ class Engine:
         zp = C.c_void_p(self.be.ptr(self.outputs["z"]))
         args = (dec["ny"], dec["nx"], self.stride_t[lvl], arr, zp, dec["nrows"], dec["row_off"])
         lib, st = self.lib, self._stream()
-        fused = C.c_void_p(lib.y5_plan_create())
-        try:
-            if lib.y5_plan_add_detect_head(fused, C.byref(d), ptrs[0], ptrs[1], ptrs[2], *args) != 0:
+        # two builds of the fused kernel: four waves x two stages (cfg 56) and eight waves x one stage (cfg 87); timed, faster kept
+        best, tuned = None, int(d.cfg)
+        for hc in (56, 87):
+            d.cfg = hc
+            one = C.c_void_p(lib.y5_plan_create())
+            try:
+                ms_h = C.c_float(0)
+                if (lib.y5_plan_add_detect_head(one, C.byref(d), ptrs[0], ptrs[1], ptrs[2], *args) == 0
+                        and lib.y5_plan_time_range(one, 0, 1, 1 if mode == "1" else 10, st, C.byref(ms_h)) == 0
+                        and (best is None or ms_h.value < best[0])):
+                    best = (ms_h.value, hc)
+            finally:
+                lib.y5_plan_destroy(one)
+        d.cfg = tuned
+        if best is None:
+            return None  # shape not supported by the fused kernel
+        if mode != "1":
+            two = C.c_void_p(lib.y5_plan_create())
+            try:
+                x = dec["x"]
+                _lib.check(lib.y5_plan_add_conv(two, C.byref(d), *ptrs), lib)
+                _lib.check(lib.y5_plan_add_detect_decode(two, self._ptr(x), self.dt, self.spec.B, dec["ny"], dec["nx"], 3, 85, 0, self._ld(x),
+                                                         self.stride_t[lvl], arr, zp, self.dt, dec["nrows"], dec["row_off"], None), lib)
+                ms_t = C.c_float(0)
+                _lib.check(lib.y5_plan_time_range(two, 0, 2, 10, st, C.byref(ms_t)), lib)
+            finally:
+                lib.y5_plan_destroy(two)
+            if not best[0] < ms_t.value:
                 return None
-            ms_f = C.c_float(0)
-            if lib.y5_plan_time_range(fused, 0, 1, 1 if mode == "1" else 10, st, C.byref(ms_f)) != 0:
-                return None  # shape not supported by the fused kernel
-            if mode != "1":
-                two = C.c_void_p(lib.y5_plan_create())
-                try:
-                    x = dec["x"]
-                    _lib.check(lib.y5_plan_add_conv(two, C.byref(d), *ptrs), lib)
-                    _lib.check(lib.y5_plan_add_detect_decode(two, self._ptr(x), self.dt, self.spec.B, dec["ny"], dec["nx"], 3, 85, 0, self._ld(x),
-                                                             self.stride_t[lvl], arr, zp, self.dt, dec["nrows"], dec["row_off"], None), lib)
-                    ms_t = C.c_float(0)
-                    _lib.check(lib.y5_plan_time_range(two, 0, 2, 10, st, C.byref(ms_t)), lib)
-                finally:
-                    lib.y5_plan_destroy(two)
-                if not ms_f.value < ms_t.value:
-                    return None
-        finally:
-            lib.y5_plan_destroy(fused)
+        d.cfg = best[1]
         self._keep.append(arr)
-        return dict(level=lvl, args=args)
+        return dict(level=lvl, args=args, cfg=best[1])
 
     def _autotune_conv(self, d, ptrs, exclude=()):
         _ensure_sk_workspace(self.be, self.lib, self._stream())
