@@ -276,11 +276,11 @@ void y5_conv_bneck_kernel(const Y5BneckParams p) {
     if (i + S < nw && !(Y5_BNECK_ABL & 4)) issue(i + S, buf);
     buf = buf + 1 == S ? 0 : buf + 1;
     // ---- GEMM 2: 3x3 over t ---------------------------------------------------------------------------------------------------
-    float16_t acc[NT], acc2[NT];
+    float16_t acc[NT];  // one accumulation chain per block, as conv_k3.h
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; acc2[j][r] = 0.f; }
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -290,12 +290,9 @@ void y5_conv_bneck_kernel(const Y5BneckParams p) {
         for (int j = 0; j < NT; ++j) {
           const half8_t wf = *reinterpret_cast<const half8_t*>(w2l + j * 32 * K2B + t * NSL * 16 + w2sl[ks]);
           if (Y5_BNECK_ABL & 2) { asm volatile("" ::"v"(wf), "v"(af)); continue; }
-          if ((t * KS + ks) & 1) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, af, acc2[j], 0, 0, 0);
-          else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, af, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, af, acc[j], 0, 0, 0);
         }
       }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[j] += acc2[j];
     // ---- epilogue: bias + SiLU -> scratch (the t buffer) -> + residual -> 16-byte stores -----------------------------------------
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // every lane's fragment reads of t are done before t is overwritten

@@ -222,12 +222,13 @@ void y5_conv_k3_kernel(const Y5ConvParams p) {
 #ifdef Y5_K3_TIMING
     const unsigned long long k_t2 = __builtin_amdgcn_s_memtime();
 #endif
-    // two accumulators per output tile (alternating k-steps): back-to-back MFMAs never wait on their own result
-    float16_t acc[NT], acc2[NT];
+    // one accumulation chain per output block (a dependent MFMA takes its SrcC from the previous one without a bubble that would pay for the
+    // 16 v_accvgpr_read + 8 v_pk_add_f32 per block a second accumulator costs in the epilogue, and for its 16 registers at two waves per SIMD)
+    float16_t acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; acc2[j][r] = 0.f; }
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -238,12 +239,9 @@ void y5_conv_k3_kernel(const Y5ConvParams p) {
           half8_t wf;
           if constexpr (WREG) wf = wreg[t][ks][j];
           else wf = *reinterpret_cast<const half8_t*>(wlds + j * 32 * K2 + t * NSL * 16 + wsl[ks]);
-          if ((t * KS + ks) & 1) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, af, acc2[j], 0, 0, 0);
-          else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, af, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, af, acc[j], 0, 0, 0);
         }
       }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[j] += acc2[j];
 #ifdef Y5_K3_TIMING
     asm volatile("" :: "v"(acc[0][0]));
     const unsigned long long k_t3 = __builtin_amdgcn_s_memtime();

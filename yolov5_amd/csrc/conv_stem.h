@@ -119,12 +119,14 @@ void y5_conv_stem_kernel(const Y5StemParams p) {
     }
     __builtin_amdgcn_wave_barrier();
     char* st = ring + buf * STAGE;
-    // two accumulators per output tile (even / odd k-steps): back-to-back MFMAs never wait on their own result
-    float16_t acc[NT], acc2[NT];
+    // NT == 1: ONE accumulation chain (a dependent MFMA reads its SrcC from the previous one's result path without a bubble worth the
+    // 16 v_accvgpr_read + 8 v_pk_add_f32 a second accumulator adds to an epilogue that is this kernel's issue bound); NT == 2: the two
+    // output blocks interleave, a second accumulator per block buys nothing either
+    float16_t acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; acc2[j][r] = 0.f; }
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     // all nine activation fragments first (36 dwords in flight), then the nine MFMAs back to back: left to the scheduler the loop was
     // read -> lgkmcnt(0) -> MFMA per k-step, an LDS round trip in front of every multiply
     half8_t afr[9];
@@ -141,16 +143,11 @@ void y5_conv_stem_kernel(const Y5StemParams p) {
 #pragma unroll
     for (int ks = 0; ks < 9; ++ks) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        if (ks & 1) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j][ks], afr[ks], acc2[j], 0, 0, 0);
-        else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j][ks], afr[ks], acc[j], 0, 0, 0);
-      }
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j][ks], afr[ks], acc[j], 0, 0, 0);
     }
 #ifndef Y5_EMU
     __builtin_amdgcn_sched_barrier(0);
 #endif
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[j] += acc2[j];
     // epilogue: bias + SiLU -> scratch (vacated stage) -> full-row 16-byte stores
 #pragma unroll
     for (int j = 0; j < NT; ++j)
