@@ -27,6 +27,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--split-factors", default="", help="comma list f: also time the pixel-range split count f * CUs / tiles (default of the library: 4)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.lib()
@@ -58,7 +59,19 @@ def main():
         gb = (x.numel() + dz.numel()) * 2 / 1e9
         tot_ms += ms * cnt
         tot_fl += fl * cnt
-        print(f"H={H:3d} {C1:4d}->{C2:4d} k{k} s{s} x{cnt}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TF  {gb / ms * 1e3:6.2f} TB/s(min traffic)")
+        extra = ""
+        for f in [float(v) for v in a.split_factors.split(",") if v]:
+            tiles = -(-C2 // (128 if C2 >= 128 else 64)) * -(-K // (128 if K >= 128 else 64))
+            d.max_blocks = max(1, int(f * 256 + tiles - 1) // tiles)
+            lib.y5_conv2d_wgrad(*args)
+            e0.record()
+            for _ in range(a.iters):
+                lib.y5_conv2d_wgrad(*args)
+            e1.record()
+            torch.cuda.synchronize()
+            extra += f"  f={f:g}:{e0.elapsed_time(e1) / a.iters * 1e3:.1f}"
+        d.max_blocks = 0
+        print(f"H={H:3d} {C1:4d}->{C2:4d} k{k} s{s} x{cnt}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TF  {gb / ms * 1e3:6.2f} TB/s(min traffic){extra}")
     print(f"TOTAL {tot_ms:.3f} ms per step, {tot_fl / tot_ms / 1e9:.1f} TF")
 
 

@@ -16,6 +16,7 @@ Gradients can be streamed to a sink (HipDDP, torch_utils.py) the moment their ke
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -179,6 +180,46 @@ class TrainEngine:
             st["zb"] = be.empty((round_up(c1, 32),), torch.float32)
             be.zero_(st["zb"])
         st["subs"] = subs
+
+    def _tune_wgrad_splits(self, d, x_ptr, dz_ptr, ld_dz, dw_ptr, dw_bytes, stm):
+        """Pixel-range split count of one weight-gradient launch (csrc/wgrad.hip: grid = filter tiles x splits, partial sums combined by
+        atomics), chosen like the forward tiles -- by timing on the real buffers, once per geometry (persisted with the tile choices).
+        The library default (4 workgroups per CU) suits the P1/P2 layers; at P4/P5, where a filter tile is 128 x 128 and the pixel range
+        short, half as many splits halve the atomic traffic (measured, scripts/wgrad_bench.py --split-factors: 60 -> 37 us for
+        512->256 @20^2, 3.40 -> 2.75 ms over the yolov5s layer set).  Returns max_blocks for the descriptor (0 = library default)."""
+        mode = os.environ.get("Y5_WGRAD_SPLITS", "auto")  # auto | <n>: fixed split count for every layer (0 = library default)
+        if mode != "auto":
+            return int(mode)
+        if not getattr(self.be, "autotune", False) or self.dt != _lib.Y5_F16:
+            return 0
+        from .engine import _TUNE_CACHE, _load_tune_cache, _save_tune_cache
+        key = (-7001, d.B, d.H, d.W, d.C1, d.ldx, d.OH, d.OW, d.C2, ld_dz, d.KH, d.KW, d.SH, d.SW, d.Kpad, d.Npad)
+        _load_tune_cache()
+        if key in _TUNE_CACHE:
+            return _TUNE_CACHE[key]
+        lib = self.lib
+        K = d.KH * d.KW * d.C1
+        tiles = -(-d.C2 // (128 if d.C2 >= 128 else 64)) * -(-K // (128 if K >= 128 else 64))
+        ncu = torch.cuda.get_device_properties(self.be.device).multi_processor_count
+        cands = sorted({max(1, (int(f * ncu) + tiles - 1) // tiles) for f in (1, 1.5, 2, 3, 4, 6)})
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best, best_ms = 0, float("inf")
+        args = (C.byref(d), _vp(x_ptr), _vp(dz_ptr), ld_dz, _vp(dw_ptr), stm)
+        for mb in cands:
+            d.max_blocks = mb
+            _lib.check(lib.y5_conv2d_wgrad(*args), lib)
+            e0.record()
+            for _ in range(3):
+                lib.y5_conv2d_wgrad(*args)
+            e1.record()
+            e1.synchronize()
+            ms = e0.elapsed_time(e1)
+            if ms < best_ms:
+                best, best_ms = mb, ms
+        _lib.check(lib.y5_memset_zero(_vp(dw_ptr), dw_bytes, stm), lib)  # the timing launches accumulated into this layer's dW
+        _TUNE_CACHE[key] = best
+        _save_tune_cache()
+        return best
 
     # ---- forward ---------------------------------------------------------------------------------------------------
     def forward(self, x):
@@ -434,7 +475,11 @@ class TrainEngine:
         d = _lib.ConvDesc(dtype=self.dt, B=B, H=g["H"], W=g["W"], C1=g["C1"], ldx=g["ldx"], OH=y.H, OW=y.W, C2=c2s, ldy=ld_dz,
                           KH=g["k"][0], KW=g["k"][1], SH=g["s"][0], SW=g["s"][1], PH=g["p"][0], PW=g["p"][1], act=0, Kpad=Kpad, Npad=Npad,
                           cfg=-1, max_blocks=0)
-        _lib.check(lib.y5_conv2d_wgrad(C.byref(d), _vp(self._ptr(x)), _vp(dz_ptr), ld_dz, _vp(be.ptr(self.dwflat) + st["dw_off"] * 4), stm), lib)
+        dw_ptr = be.ptr(self.dwflat) + st["dw_off"] * 4
+        if "wg_splits" not in st:
+            st["wg_splits"] = self._tune_wgrad_splits(d, self._ptr(x), dz_ptr, ld_dz, dw_ptr, Npad * Kpad * 4, stm)
+        d.max_blocks = st["wg_splits"]
+        _lib.check(lib.y5_conv2d_wgrad(C.byref(d), _vp(self._ptr(x)), _vp(dz_ptr), ld_dz, _vp(dw_ptr), stm), lib)
         if self.grad_sink is not None:  # a gradient sink (HipDDP) wants every gradient as early as possible: unpack per layer
             _lib.check(lib.y5_unpack_conv_wgrad(_vp(be.ptr(self.dwflat) + st["dw_off"] * 4), Kpad, _vp(self._gptr(cv.weight)), c2, c1, kh, kw,
                                                 st["c1v"], stm), lib)
