@@ -31,3 +31,13 @@ if [ "$WHAT" = "all" ] || [ "$WHAT" = "prof" ]; then
   # keep the merged-back directory small: drop the raw per-dispatch trace, keep the summaries
   find gpurun_out/prof -name "*kernel_trace.csv" -size +20M -delete
 fi
+if [ "$WHAT" = "all" ] || [ "$WHAT" = "train" ]; then
+  # training step: per-kernel summary with warm tile / split choices (the first plain run fills the cache)
+  export Y5_TUNE_CACHE=/tmp/y5_tune_train.json
+  timeout 300 python scripts/train_bench.py --steps 5 --warmup 3 > gpurun_out/train_bench.log 2>&1; tail -1 gpurun_out/train_bench.log
+  rm -rf gpurun_out/trainprof
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/trainprof" -o t -- python "$OLDPWD/scripts/train_bench.py" --steps 10 --warmup 3 > "$OLDPWD/gpurun_out/train_prof.log" 2>&1); echo "train prof rc=$?"
+  f=$(find gpurun_out/trainprof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/train_kernel_stats.csv && head -12 "$f" | cut -c1-150
+  grep images/sec gpurun_out/train_prof.log | tail -1 > gpurun_out/train_line_under_rocprof.json
+  rm -rf gpurun_out/trainprof
+fi

@@ -33,7 +33,9 @@ template <> struct Y5Vec<half_t> { typedef half8_t V; static constexpr int N = 8
 template <> struct Y5Vec<float> { typedef float4_t V; static constexpr int N = 4; };
 
 __device__ __forceinline__ float y5_silu_grad(float v) {  // d/dv [v * sigmoid(v)]
-  const float s = 1.0f / (1.0f + __expf(-v));
+  // v_rcp_f32 (1 ulp), not an IEEE division (a 10-instruction sequence): the backward statistics pass runs this once per activation element
+  // and was VALU-bound on it (7.2 GB in 1.93 ms = 3.7 TB/s against the 5.4 TB/s of the forward statistics pass)
+  const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-v));
   return s * (1.0f + v * (1.0f - s));
 }
 
