@@ -151,7 +151,8 @@ int y5_detect_decode_hint(const void* logits, int dtype, int B, int ny, int nx, 
  * models/common.py:866): the 1x1 convolution `self.m[i]` (descriptor `d`: fp16, C1 = 128, 3 x 85 output channels stored as
  * Npad = 256, act = 0) and the decode of y5_detect_decode in one pass -- the logits are never written.  z rows as in
  * y5_detect_decode (fp16); ny*nx % 32 == 0, nrows_total / row_off / ny*nx multiples of 8.  Bit-identical to the two-call form.
- * Y5_ERR_UNSUPPORTED for any other shape (callers keep y5_conv2d_fwd + y5_detect_decode).
+ * Y5_ERR_UNSUPPORTED for any other shape (callers keep y5_conv2d_fwd + y5_detect_decode).  d->cfg == 87 selects the build with eight waves per
+ * workgroup and one LDS stage per wave, any other value four waves with two stages (identical results; the engine times both).
  * ------------------------------------------------------------------------------------------------------- */
 int y5_detect_head_fwd(const y5_conv_desc* d, const void* x, const void* w_packed, const float* bias, int ny, int nx, float stride,
                        const float* anchors_px, void* z, long long nrows_total, long long row_off, void* stream);
@@ -182,7 +183,8 @@ int y5_nms_batched_hint(const void* pred, int dtype, int bs, int n, int no, int 
 
 /* ---------------------------------------------------------------------------------------------------------
  * y5_conv2d_wgrad -- weight gradient of the convolution described by `d` (same descriptor as the forward call; act,
- * cfg, ldy, ldr, ld2 ignored; max_blocks > 0 forces the number of pixel splits -- tests):
+ * cfg, ldy, ldr, ld2 ignored; max_blocks > 0 sets the number of pixel-range splits (the train engine times a few per layer
+ * geometry and keeps the fastest; 0 = 4 workgroups per CU); k1 s1 p0 layers take a linear-staging build of the kernel):
  *   dw_packed[n][k] += sum_pixels dz[pixel][n] * im2col(x)[pixel][k]     fp32, layout [Npad][Kpad] of w_packed.
  * The caller zero-fills dw_packed; accumulation uses fp32 atomics (split over the pixel range).  x, dz: fp16 NHWC
  * slices (pixel strides d->ldx, ld_dz).  Replaces autograd's conv weight backward under train.py:410.
