@@ -1,4 +1,4 @@
-"""A/B: sequential forward -> NMS steps vs DetectPipeline (NMS of batch i overlapped with the forward of batch i+1), yolov5s bs=64."""
+"""A/B: sequential forward -> NMS steps vs DetectPipeline (batch i+1 queued before the host waits for batch i's counts), yolov5s bs=64."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -21,7 +21,7 @@ for rep in range(3):
     torch.cuda.synchronize()
     t_seq = (time.perf_counter() - t0) / 50
     pipe = DetectPipeline(model, 0.25, 0.45, max_det=1000)
-    for _ in range(5): pipe.submit(x)
+    for _ in range(8): r = pipe.submit(x)
     pipe.flush(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(50): pipe.submit(x)

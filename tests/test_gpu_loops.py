@@ -4,7 +4,7 @@
     same schedule, pinned to the reference's pieces in tests/test_oracle_vs_reference.py): schedule identical, loss curve within the
     fp16 band, the model actually learns (loss falls), EMA / BatchNorm statistics track the oracle's;
   * detect(): letterbox -> forward -> NMS -> scale_boxes for a batch of frames vs the oracle pipeline (detect.py:204-248);
-  * DetectPipeline: overlapped stages return exactly what the sequential calls return."""
+  * DetectPipeline: the deferred-collect pipeline returns exactly what the sequential calls return."""
 import numpy as np
 import pytest
 import torch

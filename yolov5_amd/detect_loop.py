@@ -5,8 +5,8 @@
   * letterbox + layout + normalisation of a whole batch is ONE launch over the raw uint8 frames (augmentations.letterbox_batch:
     the host computes only utils/augmentations.py:85-115's geometry), the model forward is one plan replay, NMS is one kernel chain
     for all images and the de-letterboxing of all detections (general.py:613-626, detect.py:248 with .round()) one more launch;
-  * `DetectPipeline` overlaps stages of consecutive batches on two HIP streams: the NMS + scale_boxes of batch i run while the
-    forward of batch i+1 occupies the chip (the tails of the forward's persistent kernels leave CUs idle; NMS is latency-bound).
+  * `DetectPipeline` keeps the GPU fed across batches: the forward of batch i+1 is queued behind the NMS of batch i before the host
+    waits for batch i's per-image counts (one stream, one-deep deferral of the only host sync).
 
 Not the CLI: no argparse, video / stream sources, annotator or file writers."""
 from __future__ import annotations
@@ -62,47 +62,49 @@ def detect(model, images, imgsz=640, conf_thres=0.25, iou_thres=0.45, classes=No
 
 
 class DetectPipeline:
-    """Two-stage software pipeline over batches that are already resident in HBM: `submit(x)` launches the forward of `x` on the
-    caller's stream and the NMS (+ optional de-letterboxing) of the PREVIOUS batch on a side stream, and returns the previous batch's
-    result (None for the first call); `flush()` returns the last one.  Every batch goes through exactly the kernels of
-    `non_max_suppression(model(x)[0])`; only their placement in time changes."""
+    """One-deep software pipeline over batches that are already resident in HBM, on ONE stream: `submit(x)` enqueues the forward of `x`,
+    its NMS and the copy of the per-image counts into pinned host memory, THEN waits for the previous batch's counts and returns the previous
+    batch's result (None for the first call); `flush()` returns the last one.  Every batch goes through exactly the kernels of
+    `non_max_suppression(model(x)[0])` in the same order; what changes is where the host waits: in the plain loop the GPU idles from the
+    count copy of batch i until the host has woken up, built the result list and launched the next forward (~140 us of every 2.7 ms step in
+    the rocprofv3 trace of bench.py, profiles/r02) -- here the next forward is already queued behind the NMS when the host goes to sleep.
+    (A first version ran the NMS of batch i on a side stream beside the forward of batch i+1: no gain, the forward's persistent kernels
+    own every CU slot and the starved NMS finished so late that the host wake-up gap came back -- profiles/r02/r02_pipeline_ab.log.)"""
 
     def __init__(self, model, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, max_det=1000, nm=0):
         self.model = model
         self.kw = dict(conf_thres=conf_thres, iou_thres=iou_thres, classes=classes, agnostic=agnostic, max_det=max_det, nm=nm)
-        self.side = None
-        self._inflight = None  # (z, event: forward done)
+        self._inflight = None  # (det, pinned counts, event: counts have landed)
+        self._pinned = []      # two host buffers, used alternately (one is being read while the other is being written)
+        self._k = 0
 
-    def _post(self, z, ev):
-        cur = torch.cuda.current_stream(z.device)
-        if self.side is None:
-            self.side = torch.cuda.Stream(z.device)
-        self.side.wait_event(ev)
-        with torch.cuda.stream(self.side):
-            det, cnt = non_max_suppression(z, padded=True, **self.kw)
-            z.record_stream(self.side)
-            done = torch.cuda.Event()
-            done.record(self.side)
-        return det, cnt, done
+    def _host_counts(self, n):
+        if len(self._pinned) < 2 or self._pinned[0].numel() != n:
+            self._pinned = [torch.empty((n,), dtype=torch.int32, pin_memory=True) for _ in range(2)]
+        self._k ^= 1
+        return self._pinned[self._k]
 
     def submit(self, x):
-        prev = self._inflight
-        post = self._post(*prev) if prev is not None else None   # queue the previous batch's NMS first: it starts as soon as its forward ends
         z = self.model(x)[0]
+        det, cnt = non_max_suppression(z, padded=True, **self.kw)
+        host = self._host_counts(cnt.numel())
+        host.copy_(cnt, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(z.device))
-        self._inflight = (z, ev)
-        return self._collect(post)
+        prev, self._inflight = self._inflight, (det, host, ev)
+        return self._collect(prev)
 
     def flush(self):
         prev, self._inflight = self._inflight, None
-        return self._collect(self._post(*prev)) if prev is not None else None
+        return self._collect(prev)
 
     @staticmethod
-    def _collect(post):
-        if post is None:
+    def _collect(prev):
+        if prev is None:
             return None
-        det, cnt, done = post
-        done.synchronize()                      # the one host sync per batch (the counts' D2H copy needs the kernels done)
-        counts = cnt.tolist()
-        return [det[i, :counts[i]] for i in range(det.shape[0])]
+        det, host, ev = prev
+        ev.synchronize()                        # the one host wait per batch; the GPU already has the next batch queued
+        counts = host.tolist()
+        bs, max_det, w = det.shape
+        sizes = [v for c in counts for v in (c, max_det - c)]   # one split call instead of bs slicings (general.non_max_suppression)
+        return list(det.view(bs * max_det, w).split(sizes)[::2])
