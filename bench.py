@@ -508,6 +508,7 @@ def main():
     fwd = event_times(lambda: model(x), n_it, dev)
     z = model(x)[0]
     nms = event_times(lambda: non_max_suppression(z, 0.25, 0.45, max_det=1000, nm=nm), n_it, dev)
+    nms_dev = event_times(lambda: non_max_suppression(z, 0.25, 0.45, max_det=1000, nm=nm, padded=True), n_it, dev)  # device side only: no host sync, as inside DetectPipeline
     fwd_ms, nms_ms = _pct(fwd, 0.5), _pct(nms, 0.5)
 
     # ---- per-kernel timing: IN SITU (one eager forward, a HIP event between consecutive ops, median of 9 passes) is what the
@@ -609,6 +610,7 @@ def main():
                               "images_per_sec": round(imgs / alt_dt, 1)},
             "step_ms": stats(step_ms), "forward_ms": round(fwd_ms, 4), "forward_ms_stats": stats(fwd), "nms_ms": round(nms_ms, 4),
             "nms_ms_stats": stats(nms), "nms_us_per_img": round(nms_ms * 1e3 / a.batch, 2),
+            "nms_device_ms": round(_pct(nms_dev, 0.5), 4), "nms_device_us_per_img": round(_pct(nms_dev, 0.5) * 1e3 / a.batch, 2),
             "forward_images_per_sec": round(a.batch / (fwd_ms * 1e-3), 1), "detections_per_img": round(ncand, 1),
             # arithmetic intensity of the conv stack at this config = algorithmic flops / algorithmic bytes (144 flop/B for
             # yolov5s bs=64 640^2) is below the ridge (2500 TF / 8 TB/s = 312 flop/B): the stack as a whole is HBM-bound;

@@ -72,7 +72,13 @@ extern "C" int y5_nms_batched_hint(const void* pred, int dt, int bs, int n, int 
     hipFuncSetAttribute((const void*)y5_nms_greedy_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     attr = true;
   }
-  const size_t greedy_lds = (((size_t)max_det * 6 + 3) & ~(size_t)3) * 4 + (size_t)Y5_NMS_RING * Y5_NMS_REC * 64 * 4 + 64 * 8 + Y5_NMS_GREEDY_WAVES * 8 + 16;
+  size_t greedy_lds = (((size_t)max_det * 6 + 3) & ~(size_t)3) * 4 + (size_t)Y5_NMS_RING * Y5_NMS_REC * 64 * 4 + 64 * Y5_NMS_GREEDY_WAVES + Y5_NMS_GREEDY_WAVES * 8 + 16;
+  {
+    // per-(class, wave) kept lists of the greedy kernel: when NMS is per class and heads + links fit beside the kept boxes
+    const size_t lists = ((size_t)nc * Y5_NMS_GREEDY_WAVES + (size_t)max_det) * 4;
+    p.cls_lists = !(flags & Y5_NMS_AGNOSTIC) && greedy_lds + lists <= 128 * 1024;
+    if (p.cls_lists) greedy_lds += lists;
+  }
   {
     // rows per workgroup of the LDS-staged filter: as many as fit 64 KiB (multiple of 64); unstaged fallback for very wide rows
     const int es = dt == Y5_F16 ? 2 : 4;
