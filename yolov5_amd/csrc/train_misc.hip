@@ -101,8 +101,10 @@ void y5_sppf_pool_bwd_kernel(const char* __restrict__ act, char* __restrict__ gr
   const int HW = H * W;
   const int n = HW * GV;                                               // vector index v = pixel * GV + group-in-workgroup
   half8_t* a_in = reinterpret_cast<half8_t*>(smem);                 // [n] activation of the pool input
-  float* g_out = reinterpret_cast<float*>(a_in + n);                // [n][8] gradient of the pool output
-  float* g_in = g_out + (size_t)n * 8;                              // [n][8] gradient accumulated for the pool input
+  // component-major planes [8][n]: consecutive lanes hit consecutive LDS banks (the [n][8] layout put a wave's scatter-adds 32 bytes apart: a
+  // 16-way bank conflict on every one of the eight ds_add_f32 per vector -- 246 us for a 26 MB tensor)
+  float* g_out = reinterpret_cast<float*>(a_in + n);                // [8][n] gradient of the pool output
+  float* g_in = g_out + (size_t)n * 8;                              // [8][n] gradient accumulated for the pool input
   const int groups = C_bytes / (16 * GV);
   const int b = blockIdx.x / groups, cg = blockIdx.x - b * groups;
   const char* abase = act + (size_t)b * HW * lda_b + (size_t)cg * 16 * GV;
@@ -112,7 +114,7 @@ void y5_sppf_pool_bwd_kernel(const char* __restrict__ act, char* __restrict__ gr
   for (int v = threadIdx.x; v < n; v += blockDim.x) {
     const half8_t q = *reinterpret_cast<const half8_t*>(gbase + (size_t)(v / GV) * ldg_b + 3 * (size_t)C_bytes + (v % GV) * 16);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) g_out[v * 8 + e] = (float)q[e];
+    for (int e = 0; e < 8; ++e) g_out[e * n + v] = (float)q[e];
   }
   for (int pass = 3; pass >= 1; --pass) {  // pool `pass`: input slice pass-1 -> output slice pass
     for (int v = threadIdx.x; v < n; v += blockDim.x) {
@@ -120,7 +122,7 @@ void y5_sppf_pool_bwd_kernel(const char* __restrict__ act, char* __restrict__ gr
       a_in[v] = *reinterpret_cast<const half8_t*>(abase + (size_t)(v / GV) * lda_b + po);
       const half8_t q = *reinterpret_cast<const half8_t*>(gbase + (size_t)(v / GV) * ldg_b + po);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) g_in[v * 8 + e] = (float)q[e];  // direct gradient of that slice (from cv2's data-gradient)
+      for (int e = 0; e < 8; ++e) g_in[e * n + v] = (float)q[e];  // direct gradient of that slice (from cv2's data-gradient)
     }
     __syncthreads();
     for (int v = threadIdx.x; v < n; v += blockDim.x) {
@@ -147,7 +149,7 @@ void y5_sppf_pool_bwd_kernel(const char* __restrict__ act, char* __restrict__ gr
           }
         }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) atomicAdd(&g_in[(bi[e] * GV + gl) * 8 + e], g_out[v * 8 + e]);
+      for (int e = 0; e < 8; ++e) atomicAdd(&g_in[e * n + bi[e] * GV + gl], g_out[e * n + v]);
     }
     __syncthreads();
     // the accumulated input gradient is the next pass's output gradient
@@ -157,7 +159,7 @@ void y5_sppf_pool_bwd_kernel(const char* __restrict__ act, char* __restrict__ gr
   for (int v = threadIdx.x; v < n; v += blockDim.x) {
     half8_t o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (half_t)g_out[v * 8 + e];
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)g_out[e * n + v];
     *reinterpret_cast<half8_t*>(gbase + (size_t)(v / GV) * ldg_b + (v % GV) * 16) = o;
   }
 }
