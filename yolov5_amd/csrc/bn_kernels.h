@@ -164,30 +164,42 @@ void y5_bn_finish_kernel(const Y5BnParams p) {
   }
 }
 
+// Thread mapping of the two apply kernels (as y5_chan_reduce_kernel): thread = (pixel row r of the block, channel vector cl) with cl FIXED for the
+// life of the thread, so the per-channel constants are loaded once into registers and a pixel costs no integer division -- the first version
+// decomposed a flat 64-bit vector index per iteration (a ~100-instruction division) and re-loaded 4-6 per-channel values per ELEMENT.
 template <typename T, bool RES>
 __global__ __launch_bounds__(256)
 void y5_bn_silu_apply_kernel(const Y5BnParams p) {
   typedef typename Y5Vec<T>::V V;
   constexpr int N = Y5Vec<T>::N;
+  constexpr bool FAST = sizeof(T) == 2;   // fp16 activations: v_rcp_f32 in the sigmoid; the fp32 plan keeps the IEEE division (see y5_silu_grad)
   const int lanes_c = p.C / N;
-  const long long total = p.npix * lanes_c;
-  for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long long)gridDim.x * 256) {
-    const long long px = v / lanes_c;
-    const int cl = (int)(v - px * lanes_c);
-    const V zv = *reinterpret_cast<const V*>(static_cast<const T*>(p.z) + px * p.ldz + cl * N);
+  const int rows = 256 / lanes_c;
+  const int r = threadIdx.x / lanes_c, cl = threadIdx.x - r * lanes_c;
+  if (r >= rows) return;
+  float mu[N], sc[N], be[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    const int c = cl * N + e;
+    mu[e] = p.mean[c]; sc[e] = p.gamma[c] * p.invstd[c]; be[e] = p.beta[c];
+  }
+  const T* zb = static_cast<const T*>(p.z) + cl * N;
+  const T* rb = static_cast<const T*>(p.res) + cl * N;
+  T* ob = static_cast<T*>(p.out) + cl * N;
+  for (long long px = (long long)blockIdx.x * rows + r; px < p.npix; px += (long long)gridDim.x * rows) {
+    const V zv = *reinterpret_cast<const V*>(zb + px * p.ldz);
     V rv;
-    if constexpr (RES) rv = *reinterpret_cast<const V*>(static_cast<const T*>(p.res) + px * p.ldr + cl * N);
+    if constexpr (RES) rv = *reinterpret_cast<const V*>(rb + px * p.ldr);
     V o;
 #pragma unroll
     for (int e = 0; e < N; ++e) {
-      const int c = cl * N + e;
-      const float sc = p.gamma[c] * p.invstd[c];
-      const float u = ((float)zv[e] - p.mean[c]) * sc + p.beta[c];
-      float y = u / (1.0f + __expf(-u));
+      const float u = ((float)zv[e] - mu[e]) * sc[e] + be[e];
+      const float d = 1.0f + __expf(-u);
+      float y = FAST ? u * __builtin_amdgcn_rcpf(d) : u / d;
       if constexpr (RES) y += (float)rv[e];
       o[e] = (T)y;
     }
-    *reinterpret_cast<V*>(static_cast<T*>(p.out) + px * p.ldo + cl * N) = o;
+    *reinterpret_cast<V*>(ob + px * p.ldo) = o;
   }
 }
 
@@ -197,22 +209,29 @@ void y5_bn_silu_bwd_apply_kernel(const Y5BnParams p) {
   typedef typename Y5Vec<T>::V V;
   constexpr int N = Y5Vec<T>::N;
   const int lanes_c = p.C / N;
-  const long long total = p.npix * lanes_c;
+  const int rows = 256 / lanes_c;
+  const int r = threadIdx.x / lanes_c, cl = threadIdx.x - r * lanes_c;
+  if (r >= rows) return;
   const float inv_n = 1.0f / (float)p.npix;
-  for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long long)gridDim.x * 256) {
-    const long long px = v / lanes_c;
-    const int cl = (int)(v - px * lanes_c);
-    const V zv = *reinterpret_cast<const V*>(static_cast<const T*>(p.z) + px * p.ldz + cl * N);
-    const V gv = *reinterpret_cast<const V*>(static_cast<const T*>(p.dy) + px * p.ldy + cl * N);
+  float mu[N], is[N], ga[N], be[N], db[N], dg[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    const int c = cl * N + e;
+    mu[e] = p.mean[c]; is[e] = p.invstd[c]; ga[e] = p.gamma[c]; be[e] = p.beta[c]; db[e] = p.dbeta[c] * inv_n; dg[e] = p.dgamma[c];
+  }
+  const T* zb = static_cast<const T*>(p.z) + cl * N;
+  const T* gb = static_cast<const T*>(p.dy) + cl * N;
+  T* ob = static_cast<T*>(p.out) + cl * N;
+  for (long long px = (long long)blockIdx.x * rows + r; px < p.npix; px += (long long)gridDim.x * rows) {
+    const V zv = *reinterpret_cast<const V*>(zb + px * p.ldz);
+    const V gv = *reinterpret_cast<const V*>(gb + px * p.ldy);
     V o;
 #pragma unroll
     for (int e = 0; e < N; ++e) {
-      const int c = cl * N + e;
-      const float is = p.invstd[c], ga = p.gamma[c];
-      const float zh = ((float)zv[e] - p.mean[c]) * is;
-      const float dv = (float)gv[e] * y5_silu_grad<sizeof(T) == 2>(ga * zh + p.beta[c]);
-      o[e] = (T)(ga * is * (dv - p.dbeta[c] * inv_n - zh * p.dgamma[c] * inv_n));
+      const float zh = ((float)zv[e] - mu[e]) * is[e];
+      const float dv = (float)gv[e] * y5_silu_grad<sizeof(T) == 2>(ga[e] * zh + be[e]);
+      o[e] = (T)(ga[e] * is[e] * (dv - db[e] - zh * dg[e] * inv_n));
     }
-    *reinterpret_cast<V*>(static_cast<T*>(p.out) + px * p.ldo + cl * N) = o;
+    *reinterpret_cast<V*>(ob + px * p.ldo) = o;
   }
 }
