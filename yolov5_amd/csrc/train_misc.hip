@@ -3,6 +3,7 @@
 // and the backward of nn.Upsample(2,'nearest'), of the Bottleneck shortcut / Concat fan-out (gradient accumulation)
 // and of SPPF's three chained MaxPool2d(k,1,k//2) (models/common.py:338-340).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "../../include/yolov5_hip.h"
 #include "y5_common.h"
@@ -307,17 +308,25 @@ extern "C" int y5_add_slice(const void* src, void* dst, long long npix, int C, i
 }
 extern "C" int y5_sppf_pool_bwd(const void* act, void* grad, int B, int H, int W, int C, int ld_act, int ld_grad, int k, void* stream_) {
   if (!act || !grad || C % 8 || ld_act % 8 || ld_grad % 8 || ld_act < 4 * C || ld_grad < 4 * C || !(k & 1)) return y5_fail(Y5_ERR_BAD_ARG, "sppf_pool_bwd: bad args");
-  const int gv = (C % 32 == 0 && (size_t)H * W * 4 * (16 + 32 + 32) <= 150 * 1024) ? 4 : 1;
+  // 16-byte channel groups per workgroup: 2 = whole 32-byte sectors per pixel access AND two or more workgroups per CU (the kernel is a chain of
+  // load -> barrier -> scatter-add -> barrier phases: with four groups one 128 KB workgroup per CU sat through every memory latency alone)
+  static const int force_gv = getenv("Y5_SPPF_BWD_GV") ? atoi(getenv("Y5_SPPF_BWD_GV")) : 0;
+  int gv = (C % 16 == 0 && (size_t)H * W * 2 * (16 + 32 + 32) <= 150 * 1024) ? 2 : 1;
+  if (force_gv == 4 && C % 32 == 0 && (size_t)H * W * 4 * (16 + 32 + 32) <= 150 * 1024) gv = 4;
+  if (force_gv == 1) gv = 1;
   const size_t lds = (size_t)H * W * gv * (16 + 32 + 32);
   if (lds > 150 * 1024) return y5_fail(Y5_ERR_UNSUPPORTED, "sppf_pool_bwd: H*W plane does not fit in LDS");
   static bool a = false;
   if (!a) {
     hipFuncSetAttribute((const void*)y5_sppf_pool_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute((const void*)y5_sppf_pool_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     hipFuncSetAttribute((const void*)y5_sppf_pool_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     a = true;
   }
   const dim3 g((unsigned)(B * (C / (8 * gv))));
-  if (gv == 4) hipLaunchKernelGGL(y5_sppf_pool_bwd_kernel<4>, g, dim3(256), lds, static_cast<hipStream_t>(stream_), (const char*)act, (char*)grad, H, W,
+  if (gv == 2) hipLaunchKernelGGL(y5_sppf_pool_bwd_kernel<2>, g, dim3(256), lds, static_cast<hipStream_t>(stream_), (const char*)act, (char*)grad, H, W,
+                                  C * 2, ld_act * 2, ld_grad * 2, k);
+  else if (gv == 4) hipLaunchKernelGGL(y5_sppf_pool_bwd_kernel<4>, g, dim3(256), lds, static_cast<hipStream_t>(stream_), (const char*)act, (char*)grad, H, W,
                                   C * 2, ld_act * 2, ld_grad * 2, k);
   else hipLaunchKernelGGL(y5_sppf_pool_bwd_kernel<1>, g, dim3(256), lds, static_cast<hipStream_t>(stream_), (const char*)act, (char*)grad, H, W, C * 2,
                           ld_act * 2, ld_grad * 2, k);
@@ -400,17 +409,27 @@ extern "C" int y5_unpack_conv_wgrad(const float* dw_packed, int Kpad, float* gw,
   return y5_check_launch("y5_unpack_conv_wgrad");
 }
 // ---- the three transforms above over MANY filters in one launch (one job per filter, table in device memory) ---------------
-// grid = (chunks of MT_CH output elements, jobs); workgroups past a job's end exit at once.  A training step re-packs ~57
-// forward filters and ~77 data-gradient sub-filters and unpacks ~60 weight gradients: 3 launches instead of ~194.
-namespace { constexpr int MT_CH = 4096; }
+// A training step re-packs ~57 forward filters and ~77 data-gradient sub-filters and unpacks ~60 weight gradients: 3 launches instead of ~194.
+namespace { constexpr int MT_CH = 1024; }
+// Persistent workgroups walk the global list of 1024-element chunks (job after job): chunk c -> (job, chunk of the job) by advancing a running
+// (job, first chunk of the job) pair -- every workgroup does real work and a thread touches 4 elements per chunk.  (The first version launched
+// (chunks of the LARGEST filter) x (jobs) workgroups of 4096 elements: most exited at once, the rest ran 16 dependent gather iterations per thread --
+// 137 us per launch for 20-30 MB of traffic.)
 __global__ __launch_bounds__(256)
-void y5_filter_jobs_kernel(const y5_filter_job* __restrict__ jobs) {
-  const y5_filter_job j = jobs[blockIdx.y];
-  const long long base = (long long)blockIdx.x * MT_CH;
-  if (base >= j.total) return;
-  const long long end = base + MT_CH < j.total ? base + MT_CH : j.total;
-  // element indices fit 32 bits (y5_filter_jobs checks): unsigned 32-bit divisions, not the ~100-instruction 64-bit sequences that made these
-  // three launches 0.41 ms of every training step
+void y5_filter_jobs_kernel(const y5_filter_job* __restrict__ jobs, int njobs) {
+  int job = 0;
+  long long first = 0;
+  long long nch = (jobs[0].total + MT_CH - 1) / MT_CH;
+  for (long long ch = blockIdx.x;; ch += gridDim.x) {
+    while (job < njobs && ch >= first + nch) {
+      first += nch;
+      if (++job < njobs) nch = (jobs[job].total + MT_CH - 1) / MT_CH;
+    }
+    if (job >= njobs) break;
+    const y5_filter_job& j = jobs[job];  // (read in place: a by-value copy that changes per chunk lands in scratch memory)
+    const long long base = (ch - first) * MT_CH;
+    const long long end = base + MT_CH < j.total ? base + MT_CH : j.total;
+  // element indices fit 32 bits (y5_filter_jobs checks): unsigned 32-bit divisions instead of the ~100-instruction 64-bit sequences
   for (unsigned i = (unsigned)base + threadIdx.x; i < (unsigned)end; i += 256) {
     if (j.kind == 2) {  // packed fp32 dW -> (C2, C1, KH, KW)
       const unsigned kw = i % (unsigned)j.KW;
@@ -444,14 +463,16 @@ void y5_filter_jobs_kernel(const y5_filter_job* __restrict__ jobs) {
     if (j.reserved == 1) static_cast<float*>(j.dst)[i] = v;  // fp32 training plan (reference-precision mode)
     else static_cast<half_t*>(j.dst)[i] = (half_t)v;
   }
+  }
 }
 
 extern "C" int y5_filter_jobs(const y5_filter_job* jobs_dev, int njobs, long long max_total, void* stream_) {
   if (!jobs_dev || njobs < 1 || njobs > 65535 || max_total < 1) return y5_fail(Y5_ERR_BAD_ARG, "filter_jobs: bad args");
   if (max_total >= 0x7fffffffLL) return y5_fail(Y5_ERR_UNSUPPORTED, "filter_jobs: filter exceeds 2^31 elements");
-  const long long chunks = (max_total + MT_CH - 1) / MT_CH;
-  if (chunks > 0x7fffffffLL) return y5_fail(Y5_ERR_UNSUPPORTED, "filter_jobs: filter too large");
-  hipLaunchKernelGGL(y5_filter_jobs_kernel, dim3((unsigned)chunks, (unsigned)njobs), dim3(256), 0, static_cast<hipStream_t>(stream_), jobs_dev);
+  // at most njobs * ceil(max_total / chunk) chunks exist; eight workgroups per CU walk them
+  const long long upper = (long long)njobs * ((max_total + MT_CH - 1) / MT_CH);
+  const long long grid = upper < 2048 ? upper : 2048;
+  hipLaunchKernelGGL(y5_filter_jobs_kernel, dim3((unsigned)grid), dim3(256), 0, static_cast<hipStream_t>(stream_), jobs_dev, njobs);
   return y5_check_launch("y5_filter_jobs");
 }
 extern "C" int y5_memset_zero(void* p, size_t bytes, void* stream_) {
