@@ -1,3 +1,4 @@
+"""Kernel-experiment aid (GPU): y5_sppf_pool_bwd on the yolov5s bs=64 P5 shape; Y5_SPPF_BWD_GV = 1 | 2 | 4 selects the channel groups per workgroup."""
 import ctypes as C, os, sys, torch
 sys.path.insert(0, os.getcwd())
 from yolov5_amd import _lib

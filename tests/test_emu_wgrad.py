@@ -41,6 +41,7 @@ CASES = [
     (3, 5, 5, 128, 64, (1, 1), (1, 1), (0, 0), 4),
     (2, 6, 6, 32, 136, (3, 3), (1, 1), (1, 1), 2),    # 128 x 128 block tile (2 x 2 accumulators per wave), n tail
     (2, 7, 5, 64, 128, (1, 1), (1, 1), (0, 0), 0),    # 128 x 64 block tile
+    (2, 6, 6, 128, 136, (1, 1), (1, 1), (0, 0), 3),   # pointwise (linear staging) on the 128 x 128 tile, n tail, 3 pixel splits
 ]
 
 

@@ -81,6 +81,8 @@ WG = [
     (8, 20, 20, 256, 128, (1, 1), (1, 1), (0, 0)),
     (2, 64, 32, 8, 32, (6, 3), (2, 1), (2, 1)),
     (4, 20, 20, 128, 256, (3, 3), (2, 2), (1, 1)),
+    (8, 40, 40, 64, 32, (1, 1), (1, 1), (0, 0)),      # pointwise layers: the linear-staging builds (64 x 64, 128 x 128 tiles)
+    (8, 20, 20, 256, 136, (1, 1), (1, 1), (0, 0)),
 ]
 
 
