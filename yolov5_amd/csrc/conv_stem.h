@@ -30,8 +30,10 @@ constexpr size_t y5_conv_stem_lds_bytes() {
   return (size_t)NT * 32 * 4 + (size_t)4 * S * STAGE;
 }
 
+// (launch bound 2: with a 256-register budget the compiler keeps the accumulators in VGPRs -- at a 512 budget it parks them in AGPRs and the epilogue,
+// which is this kernel's issue bound, pays 16 v_accvgpr_read per tile; LDS still limits a CU to three workgroups)
 template <int NT, int S>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, 2)
 void y5_conv_stem_kernel(const Y5StemParams p) {
   typedef half_t T;
   constexpr int NPAD = 32 * NT;
