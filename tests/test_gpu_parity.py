@@ -466,6 +466,16 @@ def test_nms_objectness_hint_from_the_engine(dev):
     d = non_max_suppression(z.clone(), 0.001, 0.6, max_det=300, multi_label=True)
     for u, v in zip(c, d):
         assert torch.equal(u, v)
+    # a LATER forward re-uses the engine's plane: the earlier tensor's tag no longer names the latest forward and its NMS must not look at the plane
+    x2 = torch.rand((4, 3, 640, 640), generator=torch.Generator().manual_seed(4)).half().to(dev)
+    z2 = model(x2)[0]
+    assert z._y5_obj_hint[3][0] != z._y5_obj_hint[4] and z2._y5_obj_hint[3][0] == z2._y5_obj_hint[4]
+    g = non_max_suppression(z, 0.25, 0.45, max_det=1000)
+    for u, v in zip(g, b):
+        assert torch.equal(u, v)
+    h2 = non_max_suppression(z2, 0.25, 0.45, max_det=1000)
+    for u, v in zip(h2, non_max_suppression(z2.clone(), 0.25, 0.45, max_det=1000)):
+        assert torch.equal(u, v)
     z[0, 0, 4] = 0.0                                             # in-place edit: version counter moves, the plane is ignored from here on
     e = non_max_suppression(z, 0.25, 0.45, max_det=1000)
     f = non_max_suppression(z.clone(), 0.25, 0.45, max_det=1000)

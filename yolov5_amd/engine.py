@@ -624,8 +624,11 @@ class Engine:
         # raw VIEWS of eval mode stay views of plan buffers (valid until the next forward; see DetectionModel.forward).
         self.fresh_outputs = outputs is None and os.environ.get("Y5_FRESH_OUTPUTS", "1") != "0"
         self._bound = {k: self.be.ptr(v) for k, v in self.outputs.items() if not (self.raw_views and k.startswith("raw"))}
-        if self._hint:
-            self._bound["obj_hint"] = self.be.ptr(self._hint_t)
+        # The objectness plane is NOT re-allocated per call: it is an engine-owned side channel guarded by a forward counter (the tag on z names the
+        # forward it belongs to; general.non_max_suppression drops a hint whose forward is no longer the engine's latest).  Re-pointing it per call
+        # made the binding key (z, plane) wander through more pointer pairs than the graph cache holds whenever several generations of NMS buffers
+        # were alive (DetectPipeline): a graph re-capture (~2.8 ms) on every forward.
+        self._hint_state = [0]
 
     def __del__(self):
         try:
@@ -1057,26 +1060,22 @@ class Engine:
         still the tensor of this forward: same object, unchanged version counter)."""
         if self._hint:
             z = self.outputs["z"]
-            z._y5_obj_hint = (self._hint_t, z._version, z.data_ptr())
+            self._hint_state[0] += 1
+            z._y5_obj_hint = (self._hint_t, z._version, z.data_ptr(), self._hint_state, self._hint_state[0])
         return self.outputs
 
     def _rebind_fresh(self, n, outputs=None):
         """Point the plan at newly allocated (or caller-provided) output tensors and select the graph captured for that binding."""
         changed = False
         for name, old in list(self._bound.items()):
-            if outputs is not None and name == "obj_hint":
-                continue  # (caller-owned outputs never carry a hint plane: self._hint is False for such engines)
             if outputs is not None:
                 t = outputs[name]
                 if tuple(t.shape) != tuple(self.spec.outputs[name]["shape"]) or not t.is_contiguous():
                     raise ValueError(f"engine output {name}: expected contiguous {tuple(self.spec.outputs[name]['shape'])}")
             else:
-                t = self.be.empty(self._hint_shape if name == "obj_hint" else self.spec.outputs[name]["shape"], self.dtype)
+                t = self.be.empty(self.spec.outputs[name]["shape"], self.dtype)
             new = self.be.ptr(t)
-            if name == "obj_hint":
-                self._hint_t = t
-            else:
-                self.outputs[name] = t
+            self.outputs[name] = t
             if new != old:
                 _lib.check(self.lib.y5_plan_rebind_output(self.plan, 0, n, C.c_void_p(old), C.c_void_p(new)), self.lib)
                 self._bound[name] = new

@@ -113,13 +113,14 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
         prediction = prediction.float()
     prediction = prediction.contiguous()
     # objectness plane the engine wrote beside this very tensor (engine.Engine._tag_hint): used only while `prediction` is still the object the
-    # forward returned, unmodified -- any copy, cast, slice or in-place edit drops it and the filter reads the rows themselves
+    # engine's LATEST forward returned, unmodified -- any copy, cast, slice, in-place edit or later forward drops it and the filter reads the rows themselves
     hint = None
     tag = getattr(prediction, "_y5_obj_hint", None)
     if tag is not None:
-        h, ver, ptr0 = tag
-        if (ver == prediction._version and ptr0 == prediction.data_ptr() and h.dtype == prediction.dtype and h.device == prediction.device
-                and tuple(h.shape) == tuple(prediction.shape[:2]) and h.is_contiguous()):
+        h, ver, ptr0, state, seq = tag
+        # (state[0] == seq: no later forward of that engine has overwritten the plane, which the engine owns and re-uses)
+        if (state[0] == seq and ver == prediction._version and ptr0 == prediction.data_ptr() and h.dtype == prediction.dtype
+                and h.device == prediction.device and tuple(h.shape) == tuple(prediction.shape[:2]) and h.is_contiguous()):
             hint = h
     lib = _lib.lib()
     bs, n, no = prediction.shape
