@@ -13,8 +13,8 @@ overlapped with backward, train.py:404-405 semantics) with `rccl_ranks` and the 
 
 Protocol: >= 10 warm-up + >= 50 timed steps; `value` = images of the K timed steps / wall time between two
 barrier + synchronize fences (max over ranks); per-step device-event times give median / p10 / p90 beside it.  The K steps run through
-`DetectPipeline` (same kernels, order and stream; the host's wait for batch i's per-image counts is taken after batch i+1 is queued, the
-last batch is collected inside the timed region); `--sequential` times the plain loop, and whichever is not the headline is reported as
+`DetectPipeline` (same kernels; the host's wait for batch i's per-image counts is taken after batch i+1 is queued, the NMS chain of batch i
+runs on a high-priority side stream beside forward i+1, the last batch is collected inside the timed region); `--sequential` times the plain loop, and whichever is not the headline is reported as
 `alt_step_mode` from a second timed run of the same K steps.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (all conv launches of one forward, durations
@@ -462,6 +462,7 @@ def main():
     # is taken AFTER batch i+1 has been queued, so the GPU does not idle while the host wakes up, builds the lists and launches the next forward
     # (~140 us of a 2.7 ms step in the rocprofv3 trace).  The last batch is collected (flush) before the closing fence.  --sequential times the
     # plain loop `non_max_suppression(model(x)[0])` instead; the other of the two is measured right after and reported as `alt_step_mode`.
+    # (DetectPipeline also moves the NMS chain of batch i to a high-priority side stream, where it overlaps forward i+1: detect_loop.py.)
     from yolov5_amd.detect_loop import DetectPipeline
 
     pipe = DetectPipeline(model, 0.25, 0.45, max_det=1000, nm=nm)
@@ -602,8 +603,9 @@ def main():
             "config": {"workload": f"{a.model} inference bs={a.batch}/GPU 3x{a.imgsz}x{a.imgsz} fp16: HIP forward (backbone+neck+Detect) + HIP NMS "
                                    "(conf 0.25, iou 0.45, max_det 1000) + per-image result lists; random-init weights, Detect biases calibrated to a realistic NMS load",
                        "step_mode": "sequential: non_max_suppression(model(x)[0]) per step, host sync inside every step" if a.sequential else
-                                    "DetectPipeline: same kernels, order and stream as the sequential step; the host waits for batch i's counts after batch i+1 "
-                                    "is queued (one-deep deferred collect, last batch flushed inside the timed region)",
+                                    "DetectPipeline: the kernels of the sequential step; the host waits for batch i's counts after batch i+1 is queued (one-deep "
+                                    "deferred collect, last batch flushed inside the timed region) and the NMS chain of batch i runs on a high-priority side stream "
+                                    "beside forward i+1",
                        "global_batch": a.batch * world, "parallelism": f"replicas x{world} (images independent, no data-path collective); "
                                                                        "the DDP training step with its RCCL all-reduce is the `train` object"},
             "alt_step_mode": {"mode": "DetectPipeline" if a.sequential else "sequential", "ms_per_step": round(alt_dt / a.steps * 1e3, 4),

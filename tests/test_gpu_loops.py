@@ -138,16 +138,17 @@ def test_detect_pipeline_equals_sequential(dev):
     det.export = True
     xs = [torch.rand((4, 3, 256, 256), device=dev).half() for _ in range(5)]
     seq = [non_max_suppression(m(x)[0].clone(), 0.25, 0.45, max_det=300) for x in xs]
-    pipe = DetectPipeline(m, 0.25, 0.45, max_det=300)
-    got = []
-    for x in xs:
-        r = pipe.submit(x)
-        if r is not None:
-            got.append(r)
-    got.append(pipe.flush())
-    assert len(got) == len(seq) == 5
-    for a, b in zip(seq, got):
-        assert len(a) == len(b) == 4
-        for u, v in zip(a, b):
-            assert torch.equal(u, v)
+    for overlap in (True, False):   # NMS on the high-priority side stream beside the next forward / everything on one stream
+        pipe = DetectPipeline(m, 0.25, 0.45, max_det=300, overlap=overlap)
+        got = []
+        for x in xs + xs:
+            r = pipe.submit(x)
+            if r is not None:
+                got.append(r)
+        got.append(pipe.flush())
+        assert len(got) == 2 * len(seq) == 10
+        for a, b in zip(seq + seq, got):
+            assert len(a) == len(b) == 4
+            for u, v in zip(a, b):
+                assert torch.equal(u, v)
     assert sum(len(u) for a in seq for u in a) > 20

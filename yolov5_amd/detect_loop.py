@@ -62,19 +62,25 @@ def detect(model, images, imgsz=640, conf_thres=0.25, iou_thres=0.45, classes=No
 
 
 class DetectPipeline:
-    """One-deep software pipeline over batches that are already resident in HBM, on ONE stream: `submit(x)` enqueues the forward of `x`,
-    its NMS and the copy of the per-image counts into pinned host memory, THEN waits for the previous batch's counts and returns the previous
-    batch's result (None for the first call); `flush()` returns the last one.  Every batch goes through exactly the kernels of
-    `non_max_suppression(model(x)[0])` in the same order; what changes is where the host waits: in the plain loop the GPU idles from the
-    count copy of batch i until the host has woken up, built the result list and launched the next forward (~140 us of every 2.7 ms step in
-    the rocprofv3 trace of bench.py, profiles/r02) -- here the next forward is already queued behind the NMS when the host goes to sleep.
-    (A first version ran the NMS of batch i on a side stream beside the forward of batch i+1: no gain, the forward's persistent kernels
-    own every CU slot and the starved NMS finished so late that the host wake-up gap came back -- profiles/r02/r02_pipeline_ab.log.)"""
+    """One-deep software pipeline over batches that are already resident in HBM: `submit(x)` enqueues the forward of `x`, its NMS and the copy
+    of the per-image counts into pinned host memory, THEN waits for the previous batch's counts and returns the previous batch's result (None
+    for the first call); `flush()` returns the last one.  Every batch goes through exactly the kernels of `non_max_suppression(model(x)[0])`;
+    what changes is where the host waits and where the NMS runs:
+      * the host: in the plain loop the GPU idles from the count copy of batch i until the host has woken up, built the result list and launched
+        the next forward (~140 us of every 2.7 ms step in the rocprofv3 trace of bench.py) -- here the next forward is already queued;
+      * `overlap=True` (default): the NMS chain of batch i runs on a HIGH-PRIORITY side stream, ordered behind forward i by an event, while the
+        caller's stream goes straight on to forward i+1.  The greedy / sort kernels are one workgroup per image (64 of 256 CUs for ~80 us);
+        with priority their workgroups take the first CU slots the forward's persistent kernels give back, and the rest of the chip keeps
+        working: 2.58 -> 2.51 ms per step.  (The same side stream at NORMAL priority showed no gain: the starved NMS finished so late that the
+        host wake-up gap came back -- profiles/r02/r02_pipeline_ab.log.)  Forward i+1 writes a different z block and the engine's other
+        objectness plane, and forward i+2 is only enqueued after batch i has been collected, so nothing the NMS reads is overwritten under it."""
 
-    def __init__(self, model, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, max_det=1000, nm=0):
+    def __init__(self, model, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, max_det=1000, nm=0, overlap=True):
         self.model = model
         self.kw = dict(conf_thres=conf_thres, iou_thres=iou_thres, classes=classes, agnostic=agnostic, max_det=max_det, nm=nm)
-        self._inflight = None  # (det, pinned counts, event: counts have landed)
+        self.overlap = overlap
+        self._side = None
+        self._inflight = None  # (det, pinned counts, event: counts have landed, z kept alive until then)
         self._pinned = []      # two host buffers, used alternately (one is being read while the other is being written)
         self._k = 0
 
@@ -84,14 +90,30 @@ class DetectPipeline:
         self._k ^= 1
         return self._pinned[self._k]
 
-    def submit(self, x):
-        z = self.model(x)[0]
+    def _post(self, z):
         det, cnt = non_max_suppression(z, padded=True, **self.kw)
         host = self._host_counts(cnt.numel())
         host.copy_(cnt, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(z.device))
-        prev, self._inflight = self._inflight, (det, host, ev)
+        return det, host
+
+    def submit(self, x):
+        z = self.model(x)[0]
+        cur = torch.cuda.current_stream(z.device)
+        if self.overlap:
+            if self._side is None:
+                self._side = torch.cuda.Stream(z.device, priority=-1)
+            fwd_done = torch.cuda.Event()
+            fwd_done.record(cur)
+            self._side.wait_event(fwd_done)
+            with torch.cuda.stream(self._side):
+                det, host = self._post(z)
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+        else:
+            det, host = self._post(z)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+        prev, self._inflight = self._inflight, (det, host, ev, z)
         return self._collect(prev)
 
     def flush(self):
@@ -102,7 +124,7 @@ class DetectPipeline:
     def _collect(prev):
         if prev is None:
             return None
-        det, host, ev = prev
+        det, host, ev, _z = prev
         ev.synchronize()                        # the one host wait per batch; the GPU already has the next batch queued
         counts = host.tolist()
         bs, max_det, w = det.shape

@@ -628,7 +628,14 @@ class Engine:
         # forward it belongs to; general.non_max_suppression drops a hint whose forward is no longer the engine's latest).  Re-pointing it per call
         # made the binding key (z, plane) wander through more pointer pairs than the graph cache holds whenever several generations of NMS buffers
         # were alive (DetectPipeline): a graph re-capture (~2.8 ms) on every forward.
-        self._hint_state = [0]
+        # Two planes, used alternately: the NMS of forward i may still be reading its plane on another stream while forward i+1 writes the other
+        # (DetectPipeline); bindings stay periodic (plane k x a handful of z blocks), well inside the graph cache.
+        self._hint_state = [0, 0]
+        self._hint_k = 0
+        self._hint_seq = 0
+        if self._hint:
+            self._hint_ring = [self._hint_t, self.be.empty(self._hint_shape, dtype)]
+            self._bound["obj_hint"] = self.be.ptr(self._hint_t)
 
     def __del__(self):
         try:
@@ -1060,14 +1067,23 @@ class Engine:
         still the tensor of this forward: same object, unchanged version counter)."""
         if self._hint:
             z = self.outputs["z"]
-            self._hint_state[0] += 1
-            z._y5_obj_hint = (self._hint_t, z._version, z.data_ptr(), self._hint_state, self._hint_state[0])
+            self._hint_seq += 1
+            self._hint_state[self._hint_k] = self._hint_seq
+            z._y5_obj_hint = (self._hint_t, z._version, z.data_ptr(), self._hint_state, self._hint_k, self._hint_seq)
         return self.outputs
 
     def _rebind_fresh(self, n, outputs=None):
         """Point the plan at newly allocated (or caller-provided) output tensors and select the graph captured for that binding."""
         changed = False
         for name, old in list(self._bound.items()):
+            if name == "obj_hint":  # the other plane of the ring
+                self._hint_k ^= 1
+                self._hint_t = self._hint_ring[self._hint_k]
+                new = self.be.ptr(self._hint_t)
+                _lib.check(self.lib.y5_plan_rebind_output(self.plan, 0, n, C.c_void_p(old), C.c_void_p(new)), self.lib)
+                self._bound[name] = new
+                changed = True
+                continue
             if outputs is not None:
                 t = outputs[name]
                 if tuple(t.shape) != tuple(self.spec.outputs[name]["shape"]) or not t.is_contiguous():

@@ -117,9 +117,9 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     hint = None
     tag = getattr(prediction, "_y5_obj_hint", None)
     if tag is not None:
-        h, ver, ptr0, state, seq = tag
-        # (state[0] == seq: no later forward of that engine has overwritten the plane, which the engine owns and re-uses)
-        if (state[0] == seq and ver == prediction._version and ptr0 == prediction.data_ptr() and h.dtype == prediction.dtype
+        h, ver, ptr0, state, k, seq = tag
+        # (state[k] == seq: no later forward of that engine has written into this plane -- the engine owns two and alternates)
+        if (state[k] == seq and ver == prediction._version and ptr0 == prediction.data_ptr() and h.dtype == prediction.dtype
                 and h.device == prediction.device and tuple(h.shape) == tuple(prediction.shape[:2]) and h.is_contiguous()):
             hint = h
     lib = _lib.lib()
