@@ -1,4 +1,6 @@
-"""Does the mere existence of other streams (a side stream, a high-priority stream, RCCL's) change the step time of the one-stream loops?"""
+"""Regression probe (GPU): step time of the plain loop and of DetectPipeline in one process, before / after other streams (a side stream, a
+high-priority stream, an RCCL process group) exist.  DetectPipeline must stay below the plain loop in every line; 4.1 ms against 2.7 ms was the signature
+of the per-forward graph re-capture fixed in round 2."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
