@@ -62,9 +62,10 @@ class TorchEmuBackend:
     def empty(self, shape, dtype):
         n = int(np.prod(shape)) if len(shape) else 1
         es = torch.empty((), dtype=dtype).element_size()
-        raw = torch.zeros(n * es + 256, dtype=torch.uint8)
-        off = (-raw.data_ptr()) % 256          # the C-ABI wants 256-byte aligned workspaces / 16-byte aligned tensors
-        return raw[off:off + n * es].view(dtype).reshape(tuple(shape))
+        with torch.inference_mode(False):      # as _HipBackend.empty: ordinary tensors also under torch.inference_mode()
+            raw = torch.zeros(n * es + 256, dtype=torch.uint8)
+            off = (-raw.data_ptr()) % 256      # the C-ABI wants 256-byte aligned workspaces / 16-byte aligned tensors
+            return raw[off:off + n * es].view(dtype).reshape(tuple(shape))
 
     def from_torch(self, t):
         return t.detach().cpu().contiguous().clone()

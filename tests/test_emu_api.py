@@ -140,3 +140,32 @@ def test_loss_targets_out_of_range():
     loss_fn.check_targets = True
     with pytest.raises(IndexError):
         loss_fn(p, bad)
+
+
+def test_forward_and_nms_under_inference_mode():
+    """detect.py / val.py run under `smart_inference_mode` (utils/torch_utils.py:34-43 -> torch.inference_mode).  Inference tensors
+    have no version counter; the engine's outputs therefore stay ordinary tensors (the objectness-hint tag keeps working), and NMS of a genuine
+    inference tensor (a copy made by the caller) falls back to reading the rows -- same detections either way."""
+    from yolov5_amd.general import non_max_suppression
+
+    m = _model().eval()
+    x = _img(0, B=2)
+    with torch.no_grad():
+        z_ref = m(x)[0].clone()
+        d_ref = non_max_suppression(z_ref, 0.001, 0.6, max_det=50)
+    with torch.inference_mode():
+        z = m(x)[0]
+        assert not z.is_inference() and getattr(z, "_y5_obj_hint", None) is not None   # ordinary tensor, tagged
+        d = non_max_suppression(z, 0.001, 0.6, max_det=50)                              # through the plane
+        zc = z.clone()                                                                   # an inference tensor: no version counter
+        assert zc.is_inference()
+        d2 = non_max_suppression(zc, 0.001, 0.6, max_det=50)
+        z[0, 0, 4] = 0.0                                                                 # in-place edit inside inference mode is still seen
+        d3 = non_max_suppression(z, 0.001, 0.6, max_det=50)
+        d4 = non_max_suppression(z.clone(), 0.001, 0.6, max_det=50)
+    assert torch.equal(z_ref, zc)
+    assert sum(len(t) for t in d_ref) > 0
+    for a, b, c in zip(d_ref, d, d2):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    for a, b in zip(d3, d4):
+        assert torch.equal(a, b)

@@ -485,6 +485,30 @@ def test_nms_objectness_hint_from_the_engine(dev):
         assert torch.equal(u, v)
 
 
+def test_forward_and_nms_under_inference_mode_on_gpu(dev):
+    """the reference's entry points run under torch.inference_mode (utils/torch_utils.py:34-43).  Engine outputs stay ordinary tensors
+    (hint tag alive), a caller's inference-tensor copy takes the plain filter; identical detections."""
+    import bench
+    from yolov5_amd.general import non_max_suppression
+
+    model = bench.build_model("yolov5s", dev)
+    model.model[-1].export = True
+    x = torch.rand((2, 3, 640, 640), generator=torch.Generator().manual_seed(5)).half().to(dev)
+    bench.calibrate_head(model, x)
+    with torch.no_grad():
+        ref = non_max_suppression(model(x)[0].clone(), 0.25, 0.45, max_det=1000)
+    with torch.inference_mode():
+        z = model(x)[0]
+        assert not z.is_inference() and getattr(z, "_y5_obj_hint", None) is not None
+        a = non_max_suppression(z, 0.25, 0.45, max_det=1000)
+        zc = z.clone()
+        assert zc.is_inference()
+        b = non_max_suppression(zc, 0.25, 0.45, max_det=1000)
+    assert sum(len(t) for t in ref) > 20
+    for u, v, w in zip(ref, a, b):
+        assert torch.equal(u, v) and torch.equal(u, w)
+
+
 def test_plan_bneck_cv3_fused_equals_unfused_on_gpu(dev, monkeypatch):
     """yolov5s 4 x 3 x 320 x 320 fp16: 2.C3's Bottleneck + cv3 as one launch (y5_bottleneck_cv3_fwd, many tiles per wave on the real memory system) against
     the two-launch plan -- same fp16 intermediate (LDS instead of HBM), same k order in the third GEMM."""

@@ -513,7 +513,10 @@ class _HipBackend:
             self.autotune = False
 
     def empty(self, shape, dtype):
-        return torch.empty(shape, dtype=dtype, device=self.device)
+        # outputs handed to the caller stay ORDINARY tensors under torch.inference_mode() (detect.py / val.py run inside
+        # smart_inference_mode): an inference tensor has no version counter, and the objectness-hint tag relies on it
+        with torch.inference_mode(False):
+            return torch.empty(shape, dtype=dtype, device=self.device)
 
     def from_torch(self, t):
         return t.to(self.device).contiguous()
@@ -1069,7 +1072,10 @@ class Engine:
             z = self.outputs["z"]
             self._hint_seq += 1
             self._hint_state[self._hint_k] = self._hint_seq
-            z._y5_obj_hint = (self._hint_t, z._version, z.data_ptr(), self._hint_state, self._hint_k, self._hint_seq)
+            # a caller-provided inference tensor cannot prove that it was not edited in place (no version counter): no hint for it,
+            # the NMS filter then reads the rows themselves
+            if not z.is_inference():
+                z._y5_obj_hint = (self._hint_t, z._version, z.data_ptr(), self._hint_state, self._hint_k, self._hint_seq)
         return self.outputs
 
     def _rebind_fresh(self, n, outputs=None):

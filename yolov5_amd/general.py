@@ -116,7 +116,7 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     # engine's LATEST forward returned, unmodified -- any copy, cast, slice, in-place edit or later forward drops it and the filter reads the rows themselves
     hint = None
     tag = getattr(prediction, "_y5_obj_hint", None)
-    if tag is not None:
+    if tag is not None and not prediction.is_inference():
         h, ver, ptr0, state, k, seq = tag
         # (state[k] == seq: no later forward of that engine has written into this plane -- the engine owns two and alternates)
         if (state[k] == seq and ver == prediction._version and ptr0 == prediction.data_ptr() and h.dtype == prediction.dtype
