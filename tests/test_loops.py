@@ -81,6 +81,83 @@ def test_train_loop_schedule_and_loss_curve_vs_oracle():
     assert cosine > 0.9, cosine
 
 
+def test_host_amp_step_skips_on_overflow_and_feeds_the_scaler():
+    """amp=True with a non-fused optimizer (Adam / AdamW / RMSProp of smart_optimizer).  GradScaler.step semantics: an inf / nan
+    gradient skips optimizer.step() and halves the scale; finite gradients are unscaled, clipped to max_norm and applied."""
+    from yolov5_amd.train_loop import LossScaler, host_amp_step
+
+    w = torch.nn.Parameter(torch.ones(4))
+    opt = torch.optim.Adam([w], lr=0.1)
+    sc = LossScaler(enabled=True, init_scale=1024.0)
+    w.grad = torch.tensor([1024.0, float("inf"), 0.0, 0.0])
+    assert host_amp_step(opt, [w], sc, max_norm=10.0) is False
+    sc.update()
+    assert torch.equal(w.detach(), torch.ones(4)) and sc.scale == 512.0 and sc.skipped == 1
+    w.grad = torch.full((4,), 512.0 * 20.0)                      # unscaled: 20 each, norm 40 -> clipped to 10
+    assert host_amp_step(opt, [w], sc, max_norm=10.0) is True
+    sc.update()
+    assert abs(float(w.grad.norm()) - 10.0) < 1e-3 and sc.scale == 512.0 and sc._clean == 1
+    assert float((w.detach() - 1.0).abs().max()) > 0.05           # Adam moved the weights
+
+
+def test_scale_is_frozen_inside_an_accumulation_window(monkeypatch):
+    """a pending back-off must not change the scale between two micro-batch backwards of one window (their gradients would be
+    unscaled with the wrong factor).  An overflow is injected into the first optimizer step of a run with accumulate = 2 from then on; the
+    scale every backward used is recorded."""
+    from yolov5_amd import train_loop as tl
+
+    m, cfg, sd = _tiny(seed=2)
+    imgs, tpi = to.synthetic_set(8, 64, per_img=2, seed=4)
+    used, windows = [], []
+    real_record = tl.LossScaler.record
+
+    def record(self, stats):
+        if not getattr(self, "_poisoned", False):               # first step reports an overflow
+            self._poisoned = True
+            stats = torch.tensor([0.0, 0.0, 1.0, 0.0])
+        real_record(self, stats)
+
+    monkeypatch.setattr(tl.LossScaler, "record", record)
+    real_backward = torch.Tensor.backward
+
+    def backward(self, *a, **k):
+        used.append(cur["scaler"].scale)
+        return real_backward(self, *a, **k)
+
+    cur = {}
+    real_init = tl.LossScaler.__init__
+
+    def init(self, *a, **k):
+        real_init(self, *a, **k)
+        cur["scaler"] = self
+
+    monkeypatch.setattr(tl.LossScaler, "__init__", init)
+    monkeypatch.setattr(torch.Tensor, "backward", backward)
+    res = tl.train(m, tl.TensorLoader(imgs, tpi, 2), hyp=dict(to.HYP), epochs=2, device="cpu", amp=True,
+                   on_batch_end=lambda ni, li, opt: windows.append(ni))
+    assert res["scaler"].skipped == 1
+    # ni:      0 | 1 | 2 3 | 4 5 | 6 7   (accumulate = 1, 1, 2, 2, 2, 3 ...: optimizer steps behind ni = 0, 1, 3, 5, ...)
+    assert used[0] == 65536.0 and all(u == 32768.0 for u in used[1:]), used
+    assert used[2] == used[3] and used[4] == used[5]
+
+
+def test_distributed_shards_have_equal_batch_counts():
+    """129 images over 2 ranks at batch 64 -- without padding rank 0 runs 2 batches and rank 1 one, and HipDDP's all-reduce of the extra
+    backward never completes.  SmartDistributedSampler (utils/dataloaders.py:79-103) pads every rank to ceil(n / world) samples."""
+    from yolov5_amd.train_loop import TensorLoader, pad_to_common
+
+    imgs = torch.zeros((129, 3, 8, 8), dtype=torch.uint8)
+    tpi = [torch.zeros((0, 6)) for _ in range(129)]
+    ls = [TensorLoader(imgs, tpi, 64, rank=r, world_size=2) for r in (0, 1)]
+    assert len(ls[0]) == len(ls[1]) == 2 and len(ls[0].idx) == len(ls[1].idx) == 65
+    assert ls[1].idx[-1] == ls[1].idx[0]                         # padded with the rank's own head, as DistributedSampler does
+    assert pad_to_common([5], 7, 4) == [5, 5] and pad_to_common([0, 4], 7, 4) == [0, 4]
+    from yolov5_amd.dataloaders import MosaicLoader
+
+    ml = [MosaicLoader([None] * 129, [None] * 129, batch_size=64, rank=r, world_size=2) for r in (0, 1)]
+    assert len(ml[0]) == len(ml[1]) == 2
+
+
 def test_detect_loop_matches_oracle_pipeline():
     from yolov5_amd.detect_loop import detect
 

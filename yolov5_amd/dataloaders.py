@@ -212,7 +212,8 @@ class MosaicLoader:
         self.dtype, self.rank, self.world, self.seed, self.epoch = dtype, rank, world_size, seed, 0
         self.paths = paths or [f"image{i}" for i in range(len(images))]
         n = len(images)
-        self.n_local = len(range(max(rank, 0), n, world_size if rank != -1 else 1))
+        # SmartDistributedSampler pads every rank to num_samples = ceil(n / world) (utils/dataloaders.py:94-101): same batch count on all ranks
+        self.n_local = (n + world_size - 1) // world_size if rank != -1 else n
 
     def set_epoch(self, epoch):
         self.epoch = epoch
@@ -229,7 +230,9 @@ class MosaicLoader:
         order = list(range(len(self.images)))
         g.shuffle(order)
         if self.rank != -1:
-            order = order[self.rank::self.world]
+            from .train_loop import pad_to_common
+
+            order = pad_to_common(order[self.rank::self.world], len(self.images), self.world)
         for b0 in range(0, len(order), self.bs):
             ids = order[b0:b0 + self.bs]
             draws = [draw_sample(i, len(self.images), self.s, self.hyp) for i in ids]

@@ -109,6 +109,11 @@ class DetectPipeline:
                 det, host = self._post(z)
                 ev = torch.cuda.Event()
                 ev.record(self._side)
+            # allocator bookkeeping across the two streams: the results were allocated on the side stream and are consumed by the caller on
+            # `cur` (scale_boxes, matching); z was allocated on `cur` and is read on the side stream.  Without this a freed block could be
+            # handed to the next side-stream NMS while consumer kernels on `cur` are still queued.
+            det.record_stream(cur)
+            z.record_stream(self._side)
         else:
             det, host = self._post(z)
             ev = torch.cuda.Event()

@@ -128,11 +128,15 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     flags = (_lib.NMS_MULTI_LABEL if (multi_label and nc > 1) else 0) | (_lib.NMS_AGNOSTIC if agnostic else 0)
     max_nms = 30000
     dev = prediction.device
-    key = (bs, n, no, nm, flags, max_det, str(dev))
+    # the scratch workspace is private to (shape, stream): a DetectPipeline's side-stream NMS and a main-stream call of the same shape
+    # may be in flight together and must not share candidate lists
+    sid = torch.cuda.current_stream(dev).cuda_stream if prediction.is_cuda else 0
+    key = (bs, n, no, nm, flags, max_det, str(dev), sid)
     ws = _nms_ws.get(key)
     if ws is None:
         nbytes = lib.y5_nms_workspace_bytes(bs, n, no, nm, flags, max_nms)
-        _nms_ws.clear()
+        while len(_nms_ws) >= 4:
+            _nms_ws.pop(next(iter(_nms_ws)))
         ws = _nms_ws[key] = (_lib.workspace(nbytes, dev), nbytes)
     out = torch.empty((bs, max_det, 6 + nm), dtype=torch.float32, device=dev)
     cnt = torch.empty((bs,), dtype=torch.int32, device=dev)

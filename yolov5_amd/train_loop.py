@@ -84,6 +84,22 @@ class LossScaler:
                     self._clean = 0
 
 
+def host_amp_step(optimizer, parameters, scaler, max_norm=10.0):
+    """GradScaler.unscale_ + clip_grad_norm_ + GradScaler.step for ANY torch optimizer (the Adam / AdamW / RMSProp choices of
+    smart_optimizer; train.py:411-414): unscale in place, clip, and SKIP optimizer.step() when the unscaled gradients are not finite;
+    the flag goes to the scale policy (back-off / growth at the next update()).  Returns True when the step was taken.
+    One host sync (the norm) -- this is the non-fused path; HipSGD.step_fused keeps the flag on the device."""
+    params = [p for p in parameters if p.grad is not None]
+    if scaler.scale != 1.0 and params:
+        torch._foreach_mul_([p.grad for p in params], 1.0 / scaler.scale)
+    total = torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm) if params else torch.zeros(())
+    found_inf = not bool(torch.isfinite(total))
+    if not found_inf:
+        optimizer.step()
+    scaler.record(torch.tensor([float("inf") if found_inf else float(total), 0.0, float(found_inf), 0.0]))
+    return not found_inf
+
+
 def train(model, loader, hyp=None, epochs=1, device=None, batch_size=None, cos_lr=False, amp=True, ema=True, world_size=1, rank=-1,
           optimizer_name="SGD", max_norm=10.0, start_epoch=0, on_batch_end=None, nbs=64):
     """Runs `epochs` epochs over `loader` (iterable of (imgs uint8|float BCHW, targets (nt, 6), *rest), re-iterable, len() = batches
@@ -136,22 +152,19 @@ def train(model, loader, hyp=None, epochs=1, device=None, batch_size=None, cos_l
             loss, loss_items = compute_loss(pred, targets.to(device))               # :400
             if rank != -1:
                 loss = loss * world_size                                            # :401-402
-            scaler.update()
+            # the scale is FROZEN for all micro-batches of an accumulation window (GradScaler only changes it in update(), right after
+            # an optimizer step, train.py:414): pending growth / back-off is applied below, behind zero_grad, never between two backwards
             (loss * scaler.scale).backward()                                        # :407
             if ni - last_opt_step >= accumulate:                                    # :410-419
                 if fused:
                     stats = optimizer.step_fused(inv_scale=1.0 / scaler.scale, max_norm=max_norm, ema=ema_obj, model=model)
                     scaler.record(stats)
                 else:
-                    if scaler.scale != 1.0:
-                        for p in model.parameters():
-                            if p.grad is not None:
-                                p.grad.mul_(1.0 / scaler.scale)
-                    torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=max_norm)
-                    optimizer.step()
+                    host_amp_step(optimizer, model.parameters(), scaler, max_norm)
                     if ema_obj is not None:
                         ema_obj.update(model)
                 optimizer.zero_grad()
+                scaler.update()   # window boundary: the only place the scale may change
                 last_opt_step = ni
             mloss = (mloss * i + loss_items) / (i + 1)                              # :423
             hist["losses"].append(loss_items.detach())
@@ -166,6 +179,18 @@ def train(model, loader, hyp=None, epochs=1, device=None, batch_size=None, cos_l
     return dict(model=de_parallel(ddp), ema=ema_obj, optimizer=optimizer, scheduler=scheduler, scaler=scaler, **hist)
 
 
+def pad_to_common(idx, n, world_size):
+    """DistributedSampler's non-drop_last rule (torch.utils.data.distributed; utils/dataloaders.py:94-101): every rank's index list is
+    extended to num_samples = ceil(n / world) by repeating its own head, so all ranks see the same number of batches -- a rank with
+    one batch more would wait forever in its gradient all-reduce."""
+    num = (n + world_size - 1) // world_size
+    idx = list(idx)
+    pad = num - len(idx)
+    if pad > 0 and idx:
+        idx += (idx * math.ceil(pad / len(idx)))[:pad]
+    return idx
+
+
 class TensorLoader:
     """Minimal re-iterable loader over an in-memory set: batches of (imgs, targets, paths, shapes) like the reference's collate_fn
     output (utils/dataloaders.py:858-863: column 0 of targets = image index inside the batch)."""
@@ -174,8 +199,8 @@ class TensorLoader:
         self.imgs, self.tpi, self.bs = imgs, targets_per_image, batch_size
         n = imgs.shape[0]
         idx = list(range(n))
-        if rank != -1:  # SmartDistributedSampler: a fixed disjoint subset per rank (dataloaders.py:79-103)
-            idx = idx[rank::world_size]
+        if rank != -1:  # SmartDistributedSampler: a fixed disjoint subset per rank (dataloaders.py:79-103) ...
+            idx = pad_to_common(idx[rank::world_size], n, world_size)  # ... padded so that every rank runs the same number of batches
         self.idx = idx
 
     def __len__(self):
