@@ -82,7 +82,7 @@ def fill_state_dict(sd: dict, seed: int = 0) -> dict:
     return out
 
 
-def condition_state_dict(vals: dict, bn_stats=None, head_affine=None) -> dict:
+def condition_state_dict(vals: dict, bn_stats=None, head_affine=None, bn_gamma_scale=None) -> dict:
     """Make a fill_state_dict network well conditioned at FULL depth / resolution (the detset_* fixtures):
     * `bn_stats` = (means, vars): float32 vectors holding, concatenated in state_dict order, the running_mean / running_var of every
       BatchNorm.  oracle/make_golden.py:gen_detset sets them to the batch statistics of the fixture's own input (one train-mode
@@ -92,8 +92,18 @@ def condition_state_dict(vals: dict, bn_stats=None, head_affine=None) -> dict:
     * `head_affine` = [(scale_l, bias_l)] per pyramid level, each (na*no,) float32: row r of the Detect / Segment 1x1 filter
       `<last>.m.<l>.weight` is multiplied by scale_l[r] and the bias is REPLACED by bias_l (measured on the reference so that box /
       objectness / class logits are spread like a trained head's: a ranking among near-tied scores is not a parity test).
+    * `bn_gamma_scale` (round 3): every BatchNorm weight is multiplied by it BEFORE the statistics are calibrated.  A random-init SiLU
+      stack with unit-variance pre-activations sits at the edge of chaos: fp16 storage noise grows with depth until, at the head, the
+      class argmax and the confidence of a third to all of the detections differ between the reference's OWN fp16 and fp32 forwards
+      (round-2 fixtures: 48 % / 97 % unpaired).  Trained networks are not like that.  Smaller pre-activations (std 0.07-0.2) keep the
+      stack in the ordered regime -- the reference agrees with itself (<= 3 % unpaired) and a detection-level comparison has power.
     Works in place on {name: np.ndarray | None} and returns it."""
     import re
+
+    if bn_gamma_scale is not None:
+        for k, v in list(vals.items()):
+            if v is not None and ".bn." in k and k.endswith("weight"):
+                vals[k] = (v * np.float32(bn_gamma_scale)).astype(np.float32)
 
     if bn_stats is not None:
         off = {"running_mean": 0, "running_var": 0}

@@ -687,15 +687,15 @@ def state_spec(cfg: dict, ch: int = 3) -> dict:
     return spec
 
 
-def det_state_dict(cfg: dict, seed: int = 0, fused: bool = False, bn_stats=None, head_affine=None) -> dict:
+def det_state_dict(cfg: dict, seed: int = 0, fused: bool = False, bn_stats=None, head_affine=None, bn_gamma_scale=None) -> dict:
     """The deterministic weights the golden fixtures were generated with (torch fp32 tensors).  bn_stats / head_affine: the
     full-resolution detset_* fixtures (oracle/make_golden.py:gen_detset -> detgen.condition_state_dict)."""
     from . import detgen
 
     spec = state_spec(cfg)
     vals = detgen.fill_state_dict(spec, seed)
-    if bn_stats is not None or head_affine is not None:
-        detgen.condition_state_dict(vals, bn_stats=bn_stats, head_affine=head_affine)
+    if bn_stats is not None or head_affine is not None or bn_gamma_scale is not None:
+        detgen.condition_state_dict(vals, bn_stats=bn_stats, head_affine=head_affine, bn_gamma_scale=bn_gamma_scale)
     sd = {}
     for k, v in vals.items():
         if v is None:

@@ -20,13 +20,14 @@ if [ "$WHAT" = "all" ] || [ "$WHAT" = "prof" ]; then
   rm -rf gpurun_out/prof
   # tile choices cached by a first plain run: the profiled run launches no autotune timing kernels
   export Y5_TUNE_CACHE=/tmp/y5_tune_prof.json
-  timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train > /dev/null 2>&1
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o r -- python "$OLDPWD/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-train > "$OLDPWD/gpurun_out/prof.log" 2>&1); echo "prof rc=$?"
+  timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train --no-configs --no-selfcheck > /dev/null 2>&1
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o r -- python "$OLDPWD/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-train --no-configs --no-selfcheck > "$OLDPWD/gpurun_out/prof.log" 2>&1); echo "prof rc=$?"
   find gpurun_out/prof -name "*stats*" | head; 
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -30 "$f"
   t=$(find gpurun_out/prof -name "*kernel_trace.csv" | head -1)
   gb=$(python -c "import json,re,sys; l=[x for x in open('gpurun_out/prof.log') if x.startswith('{')][-1]; print(json.loads(l)['roofline']['algorithmic_gbytes_per_step'])")
-  [ -n "$t" ] && python scripts/rocprof_frac.py "$t" --gbytes "$gb" --out gpurun_out/prof/rocprof_frac.json | head -30
+  gf=$(python -c "import json,re,sys; l=[x for x in open('gpurun_out/prof.log') if x.startswith('{')][-1]; print(json.loads(l)['roofline']['algorithmic_gflop_per_step'])")
+  [ -n "$t" ] && python scripts/rocprof_frac.py "$t" --gbytes "$gb" --gflop "$gf" --out gpurun_out/prof/rocprof_frac.json | head -30
   grep '^{' gpurun_out/prof.log | tail -1 > gpurun_out/prof/bench_line.json
   # keep the merged-back directory small: drop the raw per-dispatch trace, keep the summaries
   find gpurun_out/prof -name "*kernel_trace.csv" -size +20M -delete

@@ -30,6 +30,9 @@ out = {"forwards": N, "conv_launches_per_forward": sum(cnt[k] for k in ck) / N,
        "conv_fetch_gb_per_forward_x2_corrected": gb(ck, 'FETCH_SIZE', 2), "conv_write_gb_per_forward": gb(ck, 'WRITE_SIZE', 1),
        "other_fetch_gb_per_forward_x2_corrected": gb(ok, 'FETCH_SIZE', 2), "other_write_gb_per_forward": gb(ok, 'WRITE_SIZE', 1)}
 out["conv_traffic_gb_per_forward"] = out["conv_fetch_gb_per_forward_x2_corrected"] + out["conv_write_gb_per_forward"]
+import sys; sys.path.insert(0, '.')
+import bench
+out["kernel_src_sha16"] = bench.kernel_src_hash()   # bench.py reports this traffic only while csrc/ + engine.py still hash to it
 json.dump(out, open('gpurun_out/pmc_forward.json', 'w'), indent=1)
 print(json.dumps(out, indent=1))
 PY

@@ -7,7 +7,8 @@ A forward is the run of dispatches from one stem launch (y5_conv_stem_kernel) to
 (igemm / h3 / pw / k3 / stem / bneck / pw_head) are summed per forward from the trace's own begin/end timestamps (pure kernel
 durations: no dispatch gaps, so this sum is a lower bound of the in-situ event-to-event figure bench.py uses).  Groups that
 are not whole forwards (autotune bursts, isolated per-op timing) have a different launch count and are dropped by keeping the
-most common count only.  frac = algorithmic GB (bench.py's `algorithmic_gbytes_per_step`) / median sum / 8000 GB/s.
+most common count only.  mfma_frac = algorithmic GFLOP / median sum / 2500 TFLOP/s (bench.py roofline.frac);
+hbm frac = algorithmic GB (bench.py's `algorithmic_gbytes_per_step`) / median sum / 8000 GB/s.
 """
 import argparse, collections, csv, json, statistics, sys
 
@@ -18,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("trace")
     ap.add_argument("--gbytes", type=float, default=None, help="algorithmic GB per forward (bench.py roofline.algorithmic_gbytes_per_step)")
+    ap.add_argument("--gflop", type=float, default=None, help="algorithmic GFLOP per forward (bench.py roofline.algorithmic_gflop_per_step): the MFMA fraction")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     rows = []
@@ -54,6 +56,10 @@ def main():
     if a.gbytes:
         out["algorithmic_gbytes_per_forward"] = a.gbytes
         out["frac_from_trace"] = round(a.gbytes / statistics.median(sums) * 1e3 / 8000.0, 4)
+    if a.gflop:
+        out["algorithmic_gflop_per_forward"] = a.gflop
+        out["mfma_tflops_from_trace"] = round(a.gflop / statistics.median(sums), 2)           # GFLOP / ms = TFLOP/s
+        out["mfma_frac_from_trace"] = round(a.gflop / statistics.median(sums) / 2500.0, 4)   # bench.py roofline.frac (round 3 definition)
     s = json.dumps(out, indent=1)
     if a.out:
         open(a.out, "w").write(s)

@@ -26,7 +26,8 @@ def load(name):
 def state_dict(name, g, fused):
     model, _, _, seed, _ = CASES[name]
     aff = [(g[f"head_scale{i}"], g[f"head_bias{i}"]) for i in range(3)]
-    return yo.det_state_dict(yo.model_cfg(model), seed, fused=fused, bn_stats=(g["bn_mean"], g["bn_var"]), head_affine=aff)
+    gs = float(g["bn_gamma_scale"]) if "bn_gamma_scale" in g.files else None
+    return yo.det_state_dict(yo.model_cfg(model), seed, fused=fused, bn_stats=(g["bn_mean"], g["bn_var"]), head_affine=aff, bn_gamma_scale=gs)
 
 
 def box_iou(a, b):

@@ -11,7 +11,8 @@ reference's own error envelope:
         north-star 1e-4 holds wherever the reference itself achieves it (yolov5s / yolov5s-seg rows: checked absolutely);
   fp16: |hip16 - ref32| <= 1.5x |ref16 - ref32| in mean and in the 99.9th percentile (boxes, scores), and the detection sets
         after NMS agree with the reference's fp32 detections at least as well as the reference's own fp16 detections do
-        (unpaired fraction <= 1.5x + 2 %).  For scale: the reference's `check_amp` (utils/general.py:410-435) accepts AMP when the
+        (unpaired fraction <= 1.5x + 2 %; the fixtures are conditioned so that the reference's own fraction is <= 10 %: 3.2 % / 1.6 % /
+        0.4 % -- round 2's were 48 % / 97 % / 40 %, which no output could fail).  For scale: the reference's `check_amp` (utils/general.py:410-435) accepts AMP when the
         post-NMS xywhn rows agree to atol 0.1 of the image size (64 px at 640^2)."""
 import numpy as np
 import pytest
@@ -105,6 +106,9 @@ def test_fp16_forward_and_nms_detection_set_agreement(name, dev):
         assert loose["unmatched_ref"] + loose["unmatched_got"] <= 0.1 * (loose["ref_strong"] + loose["got_strong"]) + 4, (name, i, loose)
         assert abs(len(r32) - len(d)) <= max(6, 1.5 * abs(len(r32) - len(r16)) + 0.03 * len(r32)), (name, i, len(r32), len(d), len(r16))
     assert st_h > 50, "fixture lost its detections"
+    # the yardstick has power: on these fixtures (round 3 conditioning, oracle/detgen.py:condition_state_dict) the reference's own fp16
+    # detections pair up with its fp32 detections to >= 90 % -- a criterion relative to a 50-100 % disagreement could not fail
+    assert un_r / st_r <= 0.10, (name, un_r, st_r)
     assert un_h / st_h <= 1.5 * un_r / st_r + 0.02, (name, un_h, st_h, un_r, st_r)
     print(f"\n[fp16] {name}: box rel err mean {hb.mean():.3g} (reference fp16: {rb.mean():.3g}), score err mean {hc.mean():.3g} ({rc.mean():.3g}); "
           f"unpaired detections {un_h}/{st_h} (reference fp16 vs fp32: {un_r}/{st_r})")

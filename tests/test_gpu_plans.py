@@ -1,0 +1,173 @@
+"""GPU (-m gpu): parity of the PLANS THE BENCHMARK RUNS -- the timing-selected tile configurations and fusions at the BASELINE batch
+sizes, not a small-batch stand-in:
+
+  C2  yolov5s      bs = 64  3 x 640 x 640    fp16, export mode (z only), forward + NMS + DetectPipeline
+  C4  yolov5x      bs = 16  3 x 1280 x 1280  fp16
+  C5  yolov5s-seg  bs = 32  3 x 640 x 640    fp16 (z + prototypes)
+
+each in TWO plans: the one the autotuner picks (Y5_TUNE_RANK=0: what bench.py times) and the one built from every race's RUNNER-UP with the
+three timing-selected fusions switched off (Y5_TUNE_RANK=1, Y5_FUSED_K3PW / Y5_FUSED_CV3 / Y5_FUSED_HEAD = 0) -- a near-tie on another box
+selects something between the two, and both ends are checked.  The chosen configuration id of every launch is printed and written to
+gpurun_out/plan_cfgs_<case>_rank<r>.json.
+
+What is compared (reference lines: models/yolo.py:91-128,160-170 forward, utils/general.py:658-767 NMS):
+  * the first images of the batch ARE the images of the reference-generated full-resolution fixture (tests/golden/detset_*.npz, conditioned
+    network, oracle/make_golden.py:gen_detset): their rows are held to the reference's own fp16 envelope (mean and 99.9th percentile of box /
+    score error <= 1.5x the reference's fp16-vs-fp32 error) exactly as tests/test_gpu_configs.py does at bs = 2 / 1 / 2;
+  * images {bs/2 - 1, bs - 1} (31 and 63 at bs = 64): every row against the CPU oracle's fp32 forward of those two images (the oracle is
+    pinned to the reference on the same fixtures, tests/test_oracle_golden.py) inside THEIR envelope -- the oracle's own fp16-storage run of the
+    same two images, which reproduces the reference's fp16 rows on the fixture images;
+  * HIP NMS of the HIP z == oracle NMS of the same z, BIT-EXACT, for every image of the batch;
+  * DetectPipeline (NMS of batch i on a side stream beside forward i+1: what bench.py's timed region runs) == the sequential loop, bit-exact.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import detgen, yolo_oracle as yo
+from tests import detset
+
+pytestmark = pytest.mark.gpu
+
+CASES = {  # case -> (fixture, batch)
+    "C2": ("yolov5s_640", 64),
+    "C4": ("yolov5x_1280", 16),
+    "C5": ("yolov5s-seg_640", 32),
+}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _batch(name, bs):
+    """bs images: the fixture's own first, then scenes of other seeds (same generator, other rectangles / gradients)."""
+    g, cfg, x_fix, seed, seg = detset.load(name)
+    hw = x_fix.shape[-1]
+    rest = torch.from_numpy(detgen.scene((bs - x_fix.shape[0], 3, hw, hw), seed=1000 + seed))
+    return g, cfg, torch.cat([x_fix, rest], 0), seg
+
+
+def _errs(a, ref, nc=80):
+    d = np.abs(a.astype(np.float64) - ref.astype(np.float64))
+    size = np.maximum(ref[:, 2], ref[:, 3])[:, None].astype(np.float64) + 8.0
+    return d[:, :4] / size, d[:, 4:5 + nc]
+
+
+def _build(name, g, dev, seg):
+    from yolov5_amd.yolo import DetectionModel, SegmentationModel
+
+    model = detset.CASES[name][0]
+    m = (SegmentationModel if seg else DetectionModel)(model + ".yaml")
+    m.load_state_dict(detset.state_dict(name, g, fused=False))
+    m = m.eval().fuse().half().to(dev)
+    m.model[-1].export = True   # bench.py's mode: (z,) / (z, proto) only, the fused P3 head is eligible
+    return m
+
+
+@pytest.mark.parametrize("rank", [0, 1])
+@pytest.mark.parametrize("case", list(CASES))
+def test_benchmarked_plan_parity(case, rank, dev, monkeypatch, tmp_path):
+    from yolov5_amd.detect_loop import DetectPipeline
+    from yolov5_amd.general import non_max_suppression
+
+    name, bs = CASES[case]
+    monkeypatch.setenv("Y5_TUNE_RANK", str(rank))
+    monkeypatch.setenv("Y5_TUNE_CACHE", str(tmp_path / "tune.json"))   # this process' races only: rank 1 must see real runner-ups
+    if rank == 1:
+        for k in ("Y5_FUSED_K3PW", "Y5_FUSED_CV3", "Y5_FUSED_HEAD"):
+            monkeypatch.setenv(k, "0")
+    import yolov5_amd.engine as eng_mod
+
+    eng_mod._TUNE_CACHE.clear()
+    eng_mod._TUNE_FILE_STATE["loaded"] = False
+
+    g, cfg, X, seg = _batch(name, bs)
+    nfix = detset.CASES[name][2]
+    m = _build(name, g, dev, seg)
+    xd = X.half().to(dev)
+    out = m(xd)
+    z = out[0]
+    assert z.shape[0] == bs
+    eng = next(iter(m._engines.values()))
+    plan = [{"op": n, "cfg": c} for n, c in eng.plan_table()]
+    print(f"\n[plan {case} rank {rank}] " + " ".join(f"{p['op'].split(':')[0]}:{p.get('cfg')}" for p in plan))
+    if os.path.isdir("gpurun_out"):
+        with open(os.path.join("gpurun_out", f"plan_cfgs_{case}_rank{rank}.json"), "w") as f:
+            json.dump(plan, f, indent=0)
+    if rank == 0:
+        assert any(n.startswith(("conv+pw:", "bneck", "conv+decode:")) for n in eng.op_names) or "yolov5x" in name, eng.op_names
+    else:
+        assert not any(n.startswith(("conv+pw:", "bneck+cv3", "conv+decode:")) for n in eng.op_names), eng.op_names
+
+    zc = z.float().cpu().numpy()
+    no = zc.shape[-1]
+    rs = int(g["row_stride"])
+    ref32, ref16 = g["z_rows"], g["z16_rows"]
+    rb, rc = _errs(ref16, ref32)                      # the reference's own fp16-vs-fp32 error: the yardstick
+    # (1) fixture images: rows the unmodified reference produced
+    rows = zc[:nfix].reshape(-1, no)[::rs]
+    hb, hc = _errs(rows, ref32)
+    for what, h, r in (("box", hb, rb), ("score", hc, rc)):
+        assert h.mean() <= 1.5 * r.mean() + 1e-6, (case, rank, what, "mean", h.mean(), r.mean())
+        assert np.quantile(h, 0.999) <= 1.5 * np.quantile(r, 0.999) + 1e-4, (case, rank, what, "q999", np.quantile(h, 0.999), np.quantile(r, 0.999))
+    # (2) images from the middle and the end of the batch against the oracle's fp32 forward (all rows)
+    pick = [bs // 2 - 1, bs - 1]
+    sd = detset.state_dict(name, g, fused=True)
+    with torch.no_grad():
+        o = yo.model_forward(cfg, sd, X[pick])
+        # the envelope of THESE images (other scenes than the fixture's: their activations, hence their fp16 noise, differ): the oracle run the way
+        # `model.half()` runs the reference on torch-CPU (fp16 storage, fp32 accumulation; it reproduces the fixture's reference-fp16 rows to fp16
+        # resolution, checked below on the fixture images)
+        sdh = {k: (v.half() if v.dtype.is_floating_point else v) for k, v in sd.items()}
+        o16 = yo.model_forward(cfg, sdh, X[pick].half())[0].float().numpy()
+        f16 = yo.model_forward(cfg, sdh, X[:nfix].half())[0].float().numpy().reshape(-1, no)[::rs]
+    assert np.abs(f16 - ref16).max() <= 2e-3 * max(1.0, float(np.abs(ref16).max())), "oracle fp16 run no longer tracks the reference's fp16 rows"
+    zo = o[0].numpy()
+    ob, oc = _errs(zc[pick].reshape(-1, no), zo.reshape(-1, no))
+    yb, yc = _errs(o16.reshape(-1, no), zo.reshape(-1, no))
+    for what, h, r in (("box", ob, yb), ("score", oc, yc)):
+        assert h.mean() <= 1.5 * r.mean() + 1e-6, (case, rank, "oracle rows", what, h.mean(), r.mean())
+        assert np.quantile(h, 0.999) <= 1.5 * np.quantile(r, 0.999) + 1e-4, (case, rank, "oracle rows", what, np.quantile(h, 0.999), np.quantile(r, 0.999))
+    if seg:
+        pr = out[1].float().cpu().numpy()
+        np.testing.assert_allclose(pr[pick], o[1].numpy(), rtol=0.05, atol=0.02)
+    # (3) NMS of this very z: HIP == oracle, bit for bit, every image
+    conf, iou, max_det = float(g["nms"][0]), float(g["nms"][1]), int(g["nms"][2])
+    nm = 32 if seg else 0
+    dets = non_max_suppression(z, conf, iou, max_det=max_det, nm=nm)
+    exp = yo.non_max_suppression(zc, conf, iou, max_det=max_det, nm=nm)
+    assert len(dets) == len(exp) == bs
+    ndet = 0
+    for i, (d, e) in enumerate(zip(dets, exp)):
+        assert np.array_equal(d.cpu().numpy(), e), (case, rank, "NMS differs from the oracle on image", i, d.shape, e.shape)
+        ndet += len(e)
+    assert ndet > 10 * bs, ndet
+    # detections of the fixture images agree with the reference's fp32 detections as well as the reference's own fp16 ones do
+    un_h = st_h = un_r = st_r = 0
+    for i in range(nfix):
+        a = detset.agreement(g[f"det{i}"], exp[i], conf)
+        un_h, st_h = un_h + a["unmatched_ref"] + a["unmatched_got"], st_h + a["ref_strong"] + a["got_strong"]
+        a = detset.agreement(g[f"det{i}"], g[f"det16_{i}"], conf)
+        un_r, st_r = un_r + a["unmatched_ref"] + a["unmatched_got"], st_r + a["ref_strong"] + a["got_strong"]
+    assert un_r / st_r <= 0.10 and un_h / st_h <= 1.5 * un_r / st_r + 0.02, (case, rank, un_h, st_h, un_r, st_r)
+    # (4) the pipelined step of bench.py == the sequential loop (two different batches through the one-deep pipeline)
+    xd2 = xd.flip(0).contiguous()
+    seq = [non_max_suppression(m(b)[0], conf, iou, max_det=max_det, nm=nm) for b in (xd, xd2)]
+    pipe = DetectPipeline(m, conf_thres=conf, iou_thres=iou, max_det=max_det, nm=nm)
+    got = [pipe.submit(xd), pipe.submit(xd2), pipe.flush()]
+    assert got[0] is None
+    for s_, p_ in zip(seq, got[1:]):
+        assert len(s_) == len(p_) == bs
+        for u, v in zip(s_, p_):
+            assert torch.equal(u, v)
+    for u, v in zip(seq[0], dets):
+        assert torch.equal(u, v)
+    print(f"[plan {case} rank {rank}] fixture rows: box {hb.mean():.3g} (ref fp16 {rb.mean():.3g}) score {hc.mean():.3g} ({rc.mean():.3g}); "
+          f"oracle rows img {pick}: box {ob.mean():.3g} score {oc.mean():.3g}; NMS bit-exact on {bs} images ({ndet} detections); "
+          f"unpaired vs reference fp32 {un_h}/{st_h} (reference fp16: {un_r}/{st_r}); pipeline == sequential")

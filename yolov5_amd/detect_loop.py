@@ -80,7 +80,8 @@ class DetectPipeline:
         self.kw = dict(conf_thres=conf_thres, iou_thres=iou_thres, classes=classes, agnostic=agnostic, max_det=max_det, nm=nm)
         self.overlap = overlap
         self._side = None
-        self._inflight = None  # (det, pinned counts, event: counts have landed, z kept alive until then)
+        self._inflight = None  # (det, pinned counts, event: counts have landed, z kept alive until then, prototypes)
+        self.protos = None     # SegmentationModel: the mask prototypes (bs, 32, H/4, W/4) of the batch the last submit() / flush() RETURNED
         self._pinned = []      # two host buffers, used alternately (one is being read while the other is being written)
         self._k = 0
 
@@ -97,7 +98,9 @@ class DetectPipeline:
         return det, host
 
     def submit(self, x):
-        z = self.model(x)[0]
+        out = self.model(x)
+        z = out[0]
+        proto = out[1] if len(out) > 1 and torch.is_tensor(out[1]) else None  # segment/predict.py:139: pred, proto = model(im)[:2]
         cur = torch.cuda.current_stream(z.device)
         if self.overlap:
             if self._side is None:
@@ -118,18 +121,17 @@ class DetectPipeline:
             det, host = self._post(z)
             ev = torch.cuda.Event()
             ev.record(cur)
-        prev, self._inflight = self._inflight, (det, host, ev, z)
+        prev, self._inflight = self._inflight, (det, host, ev, z, proto)
         return self._collect(prev)
 
     def flush(self):
         prev, self._inflight = self._inflight, None
         return self._collect(prev)
 
-    @staticmethod
-    def _collect(prev):
+    def _collect(self, prev):
         if prev is None:
             return None
-        det, host, ev, _z = prev
+        det, host, ev, _z, self.protos = prev
         ev.synchronize()                        # the one host wait per batch; the GPU already has the next batch queued
         counts = host.tolist()
         bs, max_det, w = det.shape

@@ -391,12 +391,13 @@ def autotune_conv(lib, d, ptrs, st, exclude=()):
     key = tuple(getattr(d, f) for f, _ in _lib.ConvDesc._fields_ if f not in ("cfg", "max_blocks")) + tuple(p is None or p.value is None for p in ptrs) \
         + (bool(exclude),)
     _load_tune_cache()
-    best = _TUNE_CACHE.get(key)
-    if best is not None:
-        return best
+    rank = int(os.environ.get("Y5_TUNE_RANK", "0"))  # 1: the RUNNER-UP of every race (parity tests cover the plans a near-tie could select)
+    hit = _TUNE_CACHE.get(key)
+    if hit is not None and (rank == 0 or hit[1] >= 0):
+        return hit[1] if rank else hit[0]
     ncfg = lib.y5_conv_num_cfgs() if d.dtype == _lib.Y5_F16 else 4
     ms = C.c_float(0)
-    best, best_ms = -1, float("inf")
+    best, best_ms, second, second_ms = -1, float("inf"), -1, float("inf")
     bm, bn, kb = C.c_int(0), C.c_int(0), C.c_int(0)
     iters = int(os.environ.get("Y5_AUTOTUNE_ITERS", "5"))
     skip = set()
@@ -415,12 +416,17 @@ def autotune_conv(lib, d, ptrs, st, exclude=()):
         if rc != 0:
             continue  # configuration not applicable to this shape
         if ms.value < best_ms:
+            second, second_ms = best, best_ms
             best, best_ms = cfg, ms.value
+        elif ms.value < second_ms:
+            second, second_ms = cfg, ms.value
     if best < 0:
         _lib.check(-2, lib)
-    _TUNE_CACHE[key] = best
+    if second < 0:
+        second = best  # a single applicable configuration: the runner-up plan keeps it
+    _TUNE_CACHE[key] = (best, second)
     _save_tune_cache()
-    return best
+    return second if rank else best
 
 
 _TUNE_FILE_STATE = {"loaded": False}
@@ -451,7 +457,8 @@ def _load_tune_cache():
 
         with open(path) as f:
             for k, v in json.load(f).items():
-                _TUNE_CACHE[tuple(int(x) if x not in ("True", "False") else x == "True" for x in k.split(","))] = int(v)
+                v = (int(v), -1) if not isinstance(v, (list, tuple)) else (int(v[0]), int(v[1]))  # (best, runner-up); older files: best only
+                _TUNE_CACHE[tuple(int(x) if x not in ("True", "False") else x == "True" for x in k.split(","))] = v
     except (OSError, ValueError):
         pass
 
@@ -466,7 +473,7 @@ def _save_tune_cache():
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
         tmp = f"{path}.{os.getpid()}.tmp"
         with open(tmp, "w") as f:
-            json.dump({",".join(str(x) for x in k): v for k, v in _TUNE_CACHE.items()}, f)
+            json.dump({",".join(str(x) for x in k): list(v) for k, v in _TUNE_CACHE.items()}, f)
         os.replace(tmp, path)  # atomic: several ranks tune at once
     except OSError:
         pass
@@ -1105,6 +1112,22 @@ class Engine:
         if changed or not self._graph:
             key = hash((getattr(self, "_graph_gen", 0),) + tuple(sorted(self._bound.items()))) & 0xFFFFFFFFFFFFFFFF
             self._graph = self.lib.y5_plan_select_graph(self.plan, key) == 1
+
+    def plan_table(self):
+        """[(op name, tile configuration id | "stem" | "bneck" | None)] in launch order: what the autotuner / the fusion races chose for this
+        plan (logged by bench.py --op-table and tests/test_gpu_plans.py so that every measured number names the plan it belongs to)."""
+        ci = iter(self.conv_cfgs)
+        out = []
+        for n in self.op_names:
+            if n.endswith("[stem,nchw]"):
+                out.append((n, "stem"))
+            elif n.startswith(("conv:", "conv+pw:", "conv+decode:")):
+                out.append((n, next(ci, None)))
+            elif n.startswith("bneck"):
+                out.append((n, "bneck"))
+            else:
+                out.append((n, None))
+        return out
 
     def profile_ops(self, iters=5):
         """In-situ per-op HIP-event timing: [(name, ms)] in execution order, every op timed in its real position of one eager

@@ -196,7 +196,7 @@ class TrainEngine:
         key = (-7001, d.B, d.H, d.W, d.C1, d.ldx, d.OH, d.OW, d.C2, ld_dz, d.KH, d.KW, d.SH, d.SW, d.Kpad, d.Npad)
         _load_tune_cache()
         if key in _TUNE_CACHE:
-            return _TUNE_CACHE[key]
+            return _TUNE_CACHE[key][0]
         lib = self.lib
         K = d.KH * d.KW * d.C1
         tiles = -(-d.C2 // (128 if d.C2 >= 128 else 64)) * -(-K // (128 if K >= 128 else 64))
@@ -217,7 +217,7 @@ class TrainEngine:
             if ms < best_ms:
                 best, best_ms = mb, ms
         _lib.check(lib.y5_memset_zero(_vp(dw_ptr), dw_bytes, stm), lib)  # the timing launches accumulated into this layer's dW
-        _TUNE_CACHE[key] = best
+        _TUNE_CACHE[key] = (best, -1)   # (choice, no runner-up): the cache's value layout (engine.autotune_conv)
         _save_tune_cache()
         return best
 
