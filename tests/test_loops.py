@@ -158,6 +158,83 @@ def test_distributed_shards_have_equal_batch_counts():
     assert len(ml[0]) == len(ml[1]) == 2
 
 
+def _val_set(n, hw, seed):
+    """n images + labels + the dataloader's `shapes` tuples ((h0, w0), ((gain, gain), (pad_w, pad_h))) for a letterboxed hw x hw batch."""
+    imgs, tpi = to.synthetic_set(n, hw, per_img=3, seed=seed)
+    geo = [((48, 64), ((1.0, 1.0), (0.0, 8.0))), ((64, 64), ((1.0, 1.0), (0.0, 0.0))), ((128, 96), ((0.5, 0.5), (8.0, 0.0))), ((32, 64), ((1.0, 1.0), (0.0, 16.0)))]
+    return imgs, tpi, [geo[i % len(geo)] for i in range(n)]
+
+
+class _ValLoader:
+    def __init__(self, imgs, tpi, shapes, bs):
+        self.imgs, self.tpi, self.shapes, self.bs = imgs, tpi, shapes, bs
+
+    def __len__(self):
+        return (len(self.imgs) + self.bs - 1) // self.bs
+
+    def __iter__(self):
+        for b0 in range(0, len(self.imgs), self.bs):
+            ids = list(range(b0, min(b0 + self.bs, len(self.imgs))))
+            t = []
+            for k, i in enumerate(ids):
+                ti = self.tpi[i].clone()
+                ti[:, 0] = k
+                t.append(ti)
+            yield self.imgs[ids], torch.cat(t, 0), [f"img{i}" for i in ids], [self.shapes[i] for i in ids]
+
+
+def test_val_loop_matches_oracle_pipeline():
+    """val.py:255-333,390-396 through yolov5_amd.val_loop.run (fp32 model on the emulator) against the same steps taken with the oracle's pieces:
+    forward -> NMS(conf 0.001, iou 0.6, multi_label, max_det 300) -> per-image scale_boxes + process_batch -> ap_per_class; plus the validation loss
+    (ComputeLoss on the raw head outputs, averaged over batches)."""
+    from yolov5_amd import val_loop
+    from yolov5_amd.loss import ComputeLoss
+
+    m, cfg, sd = _tiny(seed=3)
+    m.hyp = dict(to.HYP)
+    imgs, tpi, shapes = _val_set(6, 64, seed=9)
+    # head biases up so that the random-init model produces detections over the 0.001 threshold that overlap the labels now and then
+    with torch.no_grad():
+        for mi in m.model[-1].m:
+            mi.bias.view(m.model[-1].na, -1)[:, 4:] += 3.0
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    nc = m.model[-1].nc
+    # labels that the model can hit: three of its own (oracle-computed) detections per image, shifted by a pixel or two, so that true positives
+    # exist at the low IoU thresholds and fade out towards 0.95
+    with torch.no_grad():
+        z0 = yo.model_forward(cfg, sd, imgs.float() / 255)[0].numpy()
+    d0 = yo.non_max_suppression(z0, 0.001, 0.6, multi_label=True, max_det=300)
+    for i, d in enumerate(d0):
+        pick = d[[0, min(5, len(d) - 1), min(11, len(d) - 1)]]
+        xywh = np.stack([(pick[:, 0] + pick[:, 2]) / 2 + 1.0 + i % 2, (pick[:, 1] + pick[:, 3]) / 2 - 1.0, (pick[:, 2] - pick[:, 0]) * 1.05, pick[:, 3] - pick[:, 1]], 1) / 64.0
+        tpi[i] = torch.from_numpy(np.concatenate([np.zeros((3, 1), np.float32), pick[:, 5:6], xywh.astype(np.float32)], 1))
+    loader = _ValLoader(imgs, tpi, shapes, 4)
+    (mp, mr, map50, map_, lb, lo, lc), maps, t = val_loop.run(m, loader, half=False, compute_loss=ComputeLoss(m), nc=nc)
+    # oracle pipeline
+    iouv = np.linspace(0.5, 0.95, 10)
+    stats, losses = [], []
+    for im, targets, _, shp in loader:
+        x = im.float() / 255 if im.dtype == torch.uint8 else im.float()
+        with torch.no_grad():
+            z, raws = yo.model_forward(cfg, sd, x)[:2]
+        tp_ = targets.numpy().copy()
+        losses.append(yo.compute_loss(list(raws), targets.clone(), yo.model_anchors(cfg), hyp=dict(to.HYP), nc=nc)[1].numpy())
+        tp_[:, 2:] *= 64.0
+        out = yo.non_max_suppression(z.numpy(), 0.001, 0.6, multi_label=True, max_det=300)
+        for si in range(len(out)):
+            lab = tp_[tp_[:, 0] == si, 1:]
+            c, _ = yo.val_match_image(out[si], lab, (64, 64), shp[si][0], shp[si][1], iouv.astype(np.float32))
+            stats.append((c, out[si][:, 4], out[si][:, 5], lab[:, 0]))
+    tp, conf, pcls, tcls = (np.concatenate(x_, 0) for x_ in zip(*stats))
+    assert tp.shape[0] > 50 and tp[:, 0].sum() >= 6 and tp[:, -1].sum() < tp[:, 0].sum()   # a non-trivial precision / recall curve
+    _, _, pp, rr, _, ap, cls = yo.ap_per_class(tp, conf, pcls, tcls)
+    ref = (pp.mean(), rr.mean(), ap[:, 0].mean(), ap.mean())
+    assert ref[2] > 0.05
+    np.testing.assert_allclose((mp, mr, map50, map_), ref, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose((lb, lo, lc), np.mean(np.array(losses, dtype=np.float64), 0), rtol=2e-4, atol=1e-6)
+    assert maps.shape == (nc,) and len(t) == 3
+
+
 def test_detect_loop_matches_oracle_pipeline():
     from yolov5_amd.detect_loop import detect
 

@@ -101,11 +101,12 @@ def host_amp_step(optimizer, parameters, scaler, max_norm=10.0):
 
 
 def train(model, loader, hyp=None, epochs=1, device=None, batch_size=None, cos_lr=False, amp=True, ema=True, world_size=1, rank=-1,
-          optimizer_name="SGD", max_norm=10.0, start_epoch=0, on_batch_end=None, nbs=64):
+          optimizer_name="SGD", max_norm=10.0, start_epoch=0, on_batch_end=None, nbs=64, val_loader=None, noval=False):
     """Runs `epochs` epochs over `loader` (iterable of (imgs uint8|float BCHW, targets (nt, 6), *rest), re-iterable, len() = batches
     per epoch).  Returns dict(model, ema, optimizer, scheduler, scaler, mloss per epoch, losses per iteration, lr per epoch).
     rank / world_size as train.py's RANK / WORLD_SIZE (-1 / 1: single process; otherwise torch.distributed is initialised and the
-    model is wrapped by smart_DDP)."""
+    model is wrapped by smart_DDP).  val_loader: validated once per epoch on rank -1 / 0 with the EMA model (train.py:440-455 -> val_loop.run;
+    noval: only after the final epoch); `results` per validated epoch = (P, R, mAP@.5, mAP@.5:.95, val box / obj / cls loss), `fitness` beside it."""
     hyp = dict(HYP_SCRATCH_LOW if hyp is None else hyp)
     device = torch.device(device) if device is not None else next(model.parameters()).device
     nb = len(loader)
@@ -126,7 +127,8 @@ def train(model, loader, hyp=None, epochs=1, device=None, batch_size=None, cos_l
     scheduler.last_epoch = start_epoch - 1                                          # :347
     scaler = LossScaler(enabled=amp)
     fused = hasattr(optimizer, "step_fused")
-    hist = {"losses": [], "mloss": [], "lr": []}
+    hist = {"losses": [], "mloss": [], "lr": [], "results": [], "fitness": []}
+    best_fitness = 0.0
     for epoch in range(start_epoch, epochs):
         model.train()
         mloss = torch.zeros(3, device=device)
@@ -173,10 +175,22 @@ def train(model, loader, hyp=None, epochs=1, device=None, batch_size=None, cos_l
         hist["lr"].append([g["lr"] for g in optimizer.param_groups])                # :432
         scheduler.step()                                                            # :433
         hist["mloss"].append(mloss.detach())
+        if val_loader is not None and rank in (-1, 0):                              # :440-455
+            final_epoch = epoch + 1 == epochs
+            if not noval or final_epoch:
+                from . import val_loop
+                from .metrics import fitness
+
+                vm = ema_obj.ema if ema_obj is not None else de_parallel(ddp)
+                results, _maps, _ = val_loop.run(vm, val_loader, half=amp, compute_loss=compute_loss)
+                fi = float(fitness(np.array(results).reshape(1, -1))[0])            # :457 weighted [P, R, mAP@.5, mAP@.5:.95]
+                best_fitness = max(best_fitness, fi)
+                hist["results"].append(tuple(float(v) for v in results))
+                hist["fitness"].append(fi)
     scaler.update(block=True)
     hist["losses"] = torch.stack(hist["losses"]).float().cpu() if hist["losses"] else torch.zeros(0, 3)
     hist["mloss"] = torch.stack(hist["mloss"]).float().cpu() if hist["mloss"] else torch.zeros(0, 3)
-    return dict(model=de_parallel(ddp), ema=ema_obj, optimizer=optimizer, scheduler=scheduler, scaler=scaler, **hist)
+    return dict(model=de_parallel(ddp), ema=ema_obj, optimizer=optimizer, scheduler=scheduler, scaler=scaler, best_fitness=best_fitness, **hist)
 
 
 def pad_to_common(idx, n, world_size):
