@@ -357,6 +357,21 @@ int y5_conv_k3pw_fwd(const y5_conv_desc* d, const void* x, const void* w1_packed
                      int C3, int Npad2, int Kpad2, int act2, void* y, int ldy, void* y2, int ld2, int split_n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * y5_conv_front_fwd -- the first three layers of the backbone as ONE launch (csrc/conv_front.h): models/yolov5s.yaml:17-19 walked by
+ * models/yolo.py:160-170 -- `0.Conv [64, 6, 2, 2]` read straight from the NCHW fp16 batch (train.py:379 / detect.py:206-210 input contract),
+ * `1.Conv [128, 3, 2]`, and the merged `2.C3.cv1 + 2.C3.cv2` pointwise GEMM that is the only reader of 1.Conv (models/common.py:246), each
+ * Conv.forward_fuse (common.py:90-92: folded-BN bias + SiLU).  The stem's and the 3x3's outputs stay in LDS / registers.
+ * x (B, 3, H, W) fp16 contiguous, H % 64 == 0, W % 64 == 0.  w_stem / bias0 as y5_conv_stem_fwd (C0 = 32 output channels);
+ * w1_packed [Npad1][Kpad1] fp16, k = (kh, kw, c) with c < 32 (y5_conv2d_fwd packing), bias1 fp32 [Npad1], C1 <= 64;
+ * w2_packed [Npad2][Kpad2] fp16, k = the 3x3's output channel, bias2 fp32 [Npad2], C3 <= 64 in multiples of 16;
+ * output channels [0, split_n) -> y (pixel stride ldy), [split_n, C3) -> y2 (pixel stride ld2, channel n - split_n); NHWC (B, H/4, W/4, .).
+ * Y5_ERR_UNSUPPORTED for other shapes: use y5_conv_stem_fwd + y5_conv_k3pw_fwd.
+ * ------------------------------------------------------------------------------------------------------- */
+int y5_conv_front_fwd(const void* x_nchw, int B, int H, int W, const void* w_stem, const float* bias0, int C0, const void* w1_packed,
+                      const float* bias1, int C1, int Npad1, int Kpad1, int act1, const void* w2_packed, const float* bias2, int C3, int Npad2,
+                      int Kpad2, int act2, void* y, int ldy, void* y2, int ld2, int split_n, int max_blocks, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * y5_bottleneck_fwd -- models/common.py:164-181 `Bottleneck.forward` inside C3 (e = 1.0, :242): y = [x +] cv2(cv1(x)) with cv1 = 1x1
  * C->C and cv2 = 3x3 pad 1 C->C (BN folded, bias + SiLU each), fp16, as ONE pass: the 1x1 output stays in LDS (csrc/conv_bneck.h).
  * x / y: NHWC channel slices with pixel strides ldx / ldy (elements); y must NOT overlap x.  C = 32 or 64, H % 4 == 0, W % 8 == 0.
@@ -406,6 +421,9 @@ int y5_plan_add_bottleneck(y5_plan*, const void* x, int ldx, const void* w1_pack
                            const float* bias2, int Kpad2, void* y, int ldy, int B, int H, int W, int C, int add);
 int y5_plan_add_conv_k3pw(y5_plan*, const y5_conv_desc* d, const void* x, const void* w1_packed, const float* bias1, const void* w2_packed,
                           const float* bias2, int C3, int Npad2, int Kpad2, int act2, void* y, int ldy, void* y2, int ld2, int split_n);
+int y5_plan_add_conv_front(y5_plan*, const void* x_nchw, int B, int H, int W, const void* w_stem, const float* bias0, int C0, const void* w1_packed,
+                           const float* bias1, int C1, int Npad1, int Kpad1, int act1, const void* w2_packed, const float* bias2, int C3, int Npad2,
+                           int Kpad2, int act2, void* y, int ldy, void* y2, int ld2, int split_n);  /* x_nchw may be NULL: y5_plan_set_input */
 int y5_plan_set_obj_hint(y5_plan*, int op_index, void* obj_hint);  /* Detect decode / fused head op: also write the objectness plane */
 int y5_plan_add_bottleneck_cv3(y5_plan*, const void* x, int ldx, const void* w1_packed, const float* bias1, int Kpad1, const void* w2_packed,
                                const float* bias2, int Kpad2, const void* y2, int ld2, const void* w3_packed, const float* bias3, int Kpad3, int C3,

@@ -137,6 +137,20 @@ template <typename T> inline T __shfl(T v, int src) {
   return r;
 }
 
+// v_permlane32_swap_b32 vdst, vsrc: vdst[lanes 32..63] <-> vsrc[lanes 0..31]; returns {new vdst, new vsrc} (pinned on the hardware by
+// scripts/ubench/permlane_probe.hip)
+typedef unsigned emu_uint2 __attribute__((ext_vector_type(2)));
+inline emu_uint2 __builtin_amdgcn_permlane32_swap(unsigned vdst, unsigned vsrc, bool, bool) {
+  struct P { unsigned d, s; } pl{vdst, vsrc};
+  const void* o[64];
+  emu::wave_exchange(&pl, sizeof(P), o);
+  const int l = emu::lane_id();
+  emu_uint2 r;
+  if (l < 32) { r[0] = vdst; r[1] = o[l + 32] ? ((const P*)o[l + 32])->d : vsrc; }
+  else { r[0] = o[l - 32] ? ((const P*)o[l - 32])->s : vdst; r[1] = vsrc; }
+  return r;
+}
+
 typedef _Float16 emu_half8 __attribute__((ext_vector_type(8)));
 typedef float emu_float16 __attribute__((ext_vector_type(16)));
 // D = A(32x16) * B(16x32) + C ; lane l holds A[i=l&31][k=8*(l>>5)+e], B[k=8*(l>>5)+e][j=l&31];

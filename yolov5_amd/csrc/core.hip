@@ -48,14 +48,14 @@ extern "C" const char* y5_last_error(void) { return g_err.c_str(); }
 // ---------------------------------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------------------------------
-enum OpKind { OP_CONV, OP_TO_NHWC, OP_SPPF, OP_UPS, OP_COPY, OP_DECODE, OP_TO_NCHW, OP_STEM, OP_HEAD, OP_NOP, OP_BNECK, OP_K3PW, OP_BNECK_CV3 };
+enum OpKind { OP_CONV, OP_TO_NHWC, OP_SPPF, OP_UPS, OP_COPY, OP_DECODE, OP_TO_NCHW, OP_STEM, OP_HEAD, OP_NOP, OP_BNECK, OP_K3PW, OP_BNECK_CV3, OP_FRONT };
 
 struct Op {
   OpKind kind;
   y5_conv_desc conv;
   const void* p0; const void* p1; const void* p2; const void* p3; void* q0; void* q1;
   const void* r0; const void* r1; const void* r2;  // further read-only operands (OP_BNECK_CV3: y2, w3, bias3)
-  int i[12];
+  int i[16];
   float f[2];
   long long l[2];
   float anchors[16];
@@ -189,6 +189,16 @@ extern "C" int y5_plan_add_bottleneck_cv3(y5_plan* pl, const void* x, int ldx, c
   pl->ops.push_back(o);
   return Y5_OK;
 }
+extern "C" int y5_plan_add_conv_front(y5_plan* pl, const void* x_nchw, int B, int H, int W, const void* w_stem, const float* bias0, int C0, const void* w1,
+                                      const float* bias1, int C1, int Npad1, int Kpad1, int act1, const void* w2, const float* bias2, int C3, int Npad2,
+                                      int Kpad2, int act2, void* y, int ldy, void* y2, int ld2, int split_n) {
+  if (!pl) return y5_fail(Y5_ERR_BAD_ARG, "plan: null");
+  Op o{}; o.kind = OP_FRONT; o.p0 = x_nchw; o.p1 = w_stem; o.p2 = bias0; o.p3 = w1; o.r0 = bias1; o.r1 = w2; o.r2 = bias2; o.q0 = y; o.q1 = y2;
+  o.i[0] = B; o.i[1] = H; o.i[2] = W; o.i[3] = C0; o.i[4] = C1; o.i[5] = Npad1; o.i[6] = Kpad1; o.i[7] = act1; o.i[8] = C3; o.i[9] = Npad2; o.i[10] = Kpad2;
+  o.i[11] = act2; o.i[12] = ldy; o.i[13] = ld2; o.i[14] = split_n;
+  pl->ops.push_back(o);
+  return Y5_OK;
+}
 extern "C" int y5_plan_add_nop(y5_plan* pl) {
   if (!pl) return y5_fail(Y5_ERR_BAD_ARG, "plan: null");
   Op o{}; o.kind = OP_NOP;
@@ -206,7 +216,7 @@ extern "C" int y5_plan_add_conv_stem(y5_plan* pl, const void* x_nchw, int B, int
 }
 extern "C" int y5_plan_set_input(y5_plan* pl, int op, const void* src) {
   if (!pl || op < 0 || op >= (int)pl->ops.size()) return y5_fail(Y5_ERR_BAD_ARG, "plan_set_input: bad op index");
-  if (pl->ops[op].kind != OP_STEM && pl->ops[op].kind != OP_TO_NHWC) return y5_fail(Y5_ERR_BAD_ARG, "plan_set_input: op does not read the model input");
+  if (pl->ops[op].kind != OP_STEM && pl->ops[op].kind != OP_TO_NHWC && pl->ops[op].kind != OP_FRONT) return y5_fail(Y5_ERR_BAD_ARG, "plan_set_input: op does not read the model input");
   pl->ops[op].p0 = src;
   return Y5_OK;
 }
@@ -268,6 +278,9 @@ static int run_op(const Op& o, void* st) {
     case OP_BNECK_CV3:
       return y5_bottleneck_cv3_fwd(o.p0, o.i[0], o.p1, (const float*)o.p2, o.i[1], o.p3, (const float*)o.q1, o.i[2], o.r0, o.i[9], o.r1, (const float*)o.r2,
                                    o.i[10], o.i[11] & 0xffff, o.i[11] >> 16, o.q0, o.i[3], o.i[4], o.i[5], o.i[6], o.i[7], o.i[8], 0, st);
+    case OP_FRONT:
+      return y5_conv_front_fwd(o.p0, o.i[0], o.i[1], o.i[2], o.p1, (const float*)o.p2, o.i[3], o.p3, (const float*)o.r0, o.i[4], o.i[5], o.i[6], o.i[7], o.r1,
+                               (const float*)o.r2, o.i[8], o.i[9], o.i[10], o.i[11], o.q0, o.i[12], o.q1, o.i[13], o.i[14], 0, st);
     case OP_K3PW:
       return y5_conv_k3pw_fwd(&o.conv, o.p0, o.p1, (const float*)o.p2, o.p3, (const float*)(uintptr_t)o.l[0], o.i[0], o.i[1], o.i[2], o.i[3], o.q0, o.i[4],
                               o.q1, o.i[5], o.i[6], st);
