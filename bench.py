@@ -558,7 +558,7 @@ def self_check(model, x, nm, dev, pick=None):
             xs = x[pick].float().cpu()
             o32 = yo.model_forward(ocfg, sd, xs)[0].numpy()
             sdh = {k: (v.half() if v.dtype.is_floating_point else v) for k, v in sd.items()}
-            o16 = yo.model_forward(ocfg, sdh, xs.half())[0].float().numpy()
+            o16 = yo.model_forward(ocfg, sdh, xs.half())[0].half().float().numpy()   # (fp16 OUTPUT too, as `model.half()` returns it: at 640 px a coordinate's ulp is 0.25-0.5 px)
         no = zc.shape[-1]
 
         def errs(a, ref):
@@ -760,11 +760,14 @@ def main():
     insitu = eng.profile_ops(iters=9)
     ops = eng.time_ops(iters=10)
     fl = dict(conv_flops(eng))
-    if eng._stem is not None:
-        fl[eng._stem] = fl[1]  # the fused NCHW stem op computes spec op 1 (0.Conv)
     by = dict(conv_bytes(eng))
     if eng._stem is not None:
+        fl[eng._stem] = fl[1]  # the fused NCHW stem op computes spec op 1 (0.Conv)
         by[eng._stem] = by[1]
+    if getattr(eng, "_front", None) is not None:
+        # the fused front computes spec ops 1..3 (0.Conv, 1.Conv, 2.C3.cv1+cv2): charged the per-layer sum, like every fused launch
+        fl[eng._front] = fl[1] + fl[2] + fl[3]
+        by[eng._front] = by[1] + by[2] + by[3]
     timed = list(zip(eng.timed_order, ops, insitu))  # (plan index, (name, isolated ms), (name, in-situ ms)) in execution order
     assert all(o[0] == s[0] for _, o, s in timed)
     conv_ms = sum(s[1] for i, o, s in timed if i in fl)
@@ -807,13 +810,7 @@ def main():
         except Exception as e:  # a probe must never take the headline down
             ceil = {"error": f"{type(e).__name__}: {e}"}
     if a.op_table and rank == 0:
-        cfg_of = {}
-        ci = iter(eng.conv_cfgs)
-        for i, op in enumerate(eng.spec.ops):
-            if op["op"] == "conv":
-                cfg_of[i] = next(ci)
-            elif op["op"] == "bneck":
-                cfg_of[i] = "bneck"
+        cfg_of = {i: c for i, (_n, c) in enumerate(eng.plan_table())}
         table = []
         for i, (name, iso), (_, ms) in timed:
             row = {"op": name, "cfg": cfg_of.get(i), "ms": round(ms, 5), "ms_isolated": round(iso, 5), "gflop": round(fl.get(i, 0) / 1e9, 3)}

@@ -66,3 +66,31 @@ def test_front_rejects_bad_shapes():
                                             kw.get("c3", 64), 64, 64, 1, ptr(a), 64, ptr(a), 64, kw.get("split", 32), 0, None)
     assert ok() == 0, lib.y5_last_error()
     assert ok(H=96) != 0 and ok(c0=16) != 0 and ok(c3=72) != 0 and ok(split=12) != 0
+
+
+def test_plan_with_fused_front_equals_two_launch_plan_on_yolov5s(monkeypatch):
+    """The planner's plan with the fused front (Y5_FUSED_FRONT=1: stem + 1.Conv + 2.C3.cv1+cv2 in one launch, then the graph body from op 4) and its
+    plan with the two launches (stem, conv+pw) give the same outputs on the emulator -- same fp16 intermediates, held in LDS / registers instead of HBM."""
+    import torch
+
+    from oracle import detgen
+    from tests.hipemu.backend import EmuBackend
+    from tests.test_emu_model import det_model
+    from yolov5_amd.engine import Engine
+
+    m = det_model("yolov5s", 0, True).half()
+    x = torch.from_numpy(detgen.uniform((2, 3, 64, 64), 0.0, 1.0, name="img", seed=0)).half()
+    monkeypatch.setenv("Y5_FUSED_K3PW", "1")
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("Y5_FUSED_FRONT", mode)
+        eng = Engine(m, (2, 3, 64, 64), torch.float16, "cpu", want_raw=False, backend=EmuBackend())
+        outs[mode] = np.asarray(eng(x)["z"]).astype(np.float32).copy()
+        assert any(n.startswith("front:") for n in eng.op_names) == (mode == "1"), eng.op_names
+        assert (eng._front is not None) == (mode == "1")
+        if mode == "1":
+            assert [n for n, c in eng.plan_table() if c == "front"] == [eng.op_names[eng._front]]
+            t = eng.time_ops(iters=1)
+            assert t[0][0].startswith("front:") and eng.timed_order[1] == 4
+    u, v = outs["0"], outs["1"]
+    assert np.abs(u - v).max() <= 4e-3 * max(1.0, np.abs(u).max()), np.abs(u - v).max()

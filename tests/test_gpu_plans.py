@@ -136,8 +136,8 @@ def test_benchmarked_plan_parity(case, rank, dev, monkeypatch, tmp_path):
         # resolution, checked below on the fixture images)
         if case != "C4":
             sdh = {k: (v.half() if v.dtype.is_floating_point else v) for k, v in sd.items()}
-            o16 = yo.model_forward(cfg, sdh, X[pick].half())[0].float().numpy()
-            f16 = yo.model_forward(cfg, sdh, X[:nfix].half())[0].float().numpy().reshape(-1, no)[::rs]
+            o16 = yo.model_forward(cfg, sdh, X[pick].half())[0].half().float().numpy()   # fp16 output as well, as `model.half()` returns it
+            f16 = yo.model_forward(cfg, sdh, X[:nfix].half())[0].half().float().numpy().reshape(-1, no)[::rs]
         else:
             o16 = f16 = None   # torch-CPU fp16 convolutions of yolov5x at 1280^2 take > 10 minutes on the GPU box's host: the fixture's envelope x2 instead
     track = None

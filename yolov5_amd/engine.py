@@ -613,6 +613,8 @@ class Engine:
         self._first_op = None
         self._stem = None      # plan index of the fused NCHW stem op (conv_stem.h), appended after the regular ops
         self._stem_args = None
+        self._front = None     # plan index of the fused backbone front (conv_front.h: stem + 1.Conv + 2.C3.cv1+cv2), appended after the stem op
+        self._front_args = None
         with torch.no_grad():
             self._fused_heads = set()
             for k, op in enumerate(self.spec.ops):
@@ -626,6 +628,7 @@ class Engine:
                 _lib.check(self.lib.y5_plan_add_conv_stem(self.plan, None, B, H, W, C.c_void_p(self.be.ptr(wp)), C.c_void_p(self.be.ptr(bp)),
                                                           c2, npad, self._ptr(y), self._ld(y)), self.lib)
                 self.op_names.append(self.op_names[1] + "[stem,nchw]")
+                self._add_front(B, H, W)
         self._graph = False
         self._use_graph = os.environ.get("Y5_GRAPH", "1") == "1" and isinstance(self.be, _HipBackend)
         # Fresh z / proto (/ raw copies) per call, as the reference returns new tensors from every forward (models/yolo.py:115):
@@ -975,7 +978,50 @@ class Engine:
         d.cfg = d3.cfg
         self._keep += [wp2, bp2]
         self._conv_bufs.append((nxt, wp2, bp2, None, None))
+        # what the fused backbone front (stem + this 3x3 + this 1x1 in one launch, _add_front) needs beside the stem's arguments
+        self._front_args = dict(w1=ptrs[1], b1=ptrs[2], C1=int(d.C2), Npad1=int(d.Npad), Kpad1=int(d.Kpad), act1=int(d.act), tail=args,
+                                name=op["name"] + "+" + nxt["name"], x_is_stem=op["x"], idx=self._cur)
         return dict(args=args, name=nxt["name"])
+
+    def _add_front(self, B, H, W):
+        """0.Conv (NCHW stem) + 1.Conv + the pointwise layer behind it as ONE launch (csrc/conv_front.h, y5_conv_front_fwd): available when the plan
+        already runs the stem from NCHW and `1.Conv + 2.C3.cv1+cv2` as one launch (their shapes are the front kernel's).  Y5_FUSED_FRONT = 0: never,
+        1: whenever the library accepts the shape, auto (default): timed against the two launches it replaces at plan build, faster form kept.
+        The op is appended behind the stem op; __call__ runs it instead of plan ops 1..3 for fp16 NCHW batches."""
+        mode = os.environ.get("Y5_FUSED_FRONT", "auto")
+        fa = self._front_args
+        if mode == "0" or fa is None or self._stem_args is None or self.dt != _lib.Y5_F16 or fa.get("idx") != 2:
+            return
+        if mode != "1" and not getattr(self.be, "autotune", False):
+            return
+        swp, sbp, sc2, snpad, sy = self._stem_args
+        if fa["x_is_stem"].buf != sy.buf or sc2 != 32 or snpad != 32:
+            return
+        lib, st = self.lib, self._stream()
+        w2, b2, c3, npad2, kpad2, act2, y, ldy, y2, ld2, split = fa["tail"]
+        args = (None, B, H, W, C.c_void_p(self.be.ptr(swp)), C.c_void_p(self.be.ptr(sbp)), sc2, fa["w1"], fa["b1"], fa["C1"], fa["Npad1"], fa["Kpad1"], fa["act1"],
+                w2, b2, c3, npad2, kpad2, act2, y, ldy, y2, ld2, split)
+        if mode != "1":
+            # race on the real buffers: a scratch input of the plan's shape stands in for the caller's batch
+            xs = self.be.empty((B, 3, H, W), torch.float16)
+            tmp = C.c_void_p(lib.y5_plan_create())
+            try:
+                if lib.y5_plan_add_conv_front(tmp, C.c_void_p(self.be.ptr(xs)), *args[1:]) != 0:
+                    return
+                ms_f, ms_s, ms_k = C.c_float(0), C.c_float(0), C.c_float(0)
+                if lib.y5_plan_time_range(tmp, 0, 1, 10, st, C.byref(ms_f)) != 0:
+                    return
+                _lib.check(lib.y5_plan_set_input(self.plan, self._stem, C.c_void_p(self.be.ptr(xs))), lib)
+                _lib.check(lib.y5_plan_time_range(self.plan, self._stem, self._stem + 1, 10, st, C.byref(ms_s)), lib)
+                _lib.check(lib.y5_plan_time_range(self.plan, 2, 3, 10, st, C.byref(ms_k)), lib)
+            finally:
+                lib.y5_plan_destroy(tmp)
+            if not ms_f.value < ms_s.value + ms_k.value:
+                return
+        if lib.y5_plan_add_conv_front(self.plan, *args) != 0:
+            return  # shape outside the kernel's range: the two-launch form stays
+        self._front = lib.y5_plan_size(self.plan) - 1
+        self.op_names.append("front:0.Conv+" + fa["name"])
 
     def _fused_head_args(self, op, d, ptrs):
         """Detect convolution of one level + its decode as ONE launch (csrc/head.hip) when only `z` is wanted (export mode: no raw
@@ -1048,22 +1094,25 @@ class Engine:
         if self.fresh_outputs or outputs is not None:
             self._rebind_fresh(n, outputs)
         if self._stem is not None and src_dt == _lib.Y5_F16:
-            # fp16 NCHW batch: the stem conv reads it in place (no NHWC repack pass), then the plan continues at op 2
+            # fp16 NCHW batch: the stem conv reads it in place (no NHWC repack pass), then the plan continues at op 2 -- or, with the fused
+            # front (stem + 1.Conv + 2.C3.cv1+cv2 in one launch), at op 4
             self._stem_active = True
-            _lib.check(self.lib.y5_plan_set_input(self.plan, self._stem, C.c_void_p(xptr)), self.lib)
-            _lib.check(self.lib.y5_plan_run_range(self.plan, self._stem, self._stem + 1, st), self.lib)
+            head = self._front if self._front is not None else self._stem
+            body0 = 4 if self._front is not None else 2
+            _lib.check(self.lib.y5_plan_set_input(self.plan, head, C.c_void_p(xptr)), self.lib)
+            _lib.check(self.lib.y5_plan_run_range(self.plan, head, head + 1, st), self.lib)
             if self._use_graph:
-                # ops 2.. only touch plan-owned buffers and the bound outputs: replayed as ONE hipGraph launch (captured on first
+                # the body only touches plan-owned buffers and the bound outputs: replayed as ONE hipGraph launch (captured on first
                 # use of every output binding)
                 if not self._graph:
-                    if self.lib.y5_plan_capture_range(self.plan, 2, self._stem, st) == 0:
+                    if self.lib.y5_plan_capture_range(self.plan, body0, self._stem, st) == 0:
                         self._graph = True
                     else:  # capture refused by the runtime: same kernels, launched one by one
                         self._use_graph = False
             if self._use_graph:
                 _lib.check(self.lib.y5_plan_launch_graph(self.plan, st), self.lib)
             else:
-                _lib.check(self.lib.y5_plan_run_range(self.plan, 2, self._stem, st), self.lib)
+                _lib.check(self.lib.y5_plan_run_range(self.plan, body0, self._stem, st), self.lib)
             return self._tag_hint()
         self._stem_active = False
         scale = 1.0 / 255.0 if src_dt == _lib.Y5_U8 else 1.0  # train.py:379 / detect.py:209: uint8 images -> 0..1
@@ -1121,6 +1170,8 @@ class Engine:
         for n in self.op_names:
             if n.endswith("[stem,nchw]"):
                 out.append((n, "stem"))
+            elif n.startswith("front:"):
+                out.append((n, "front"))
             elif n.startswith(("conv:", "conv+pw:", "conv+decode:")):
                 out.append((n, next(ci, None)))
             elif n.startswith("bneck"):
@@ -1136,7 +1187,7 @@ class Engine:
         n = self.lib.y5_plan_size(self.plan)
         res = []
         if self._stem is not None and getattr(self, "_stem_active", False):
-            ranges = [(self._stem, self._stem + 1), (2, self._stem)]
+            ranges = [(self._front, self._front + 1), (4, self._stem)] if self._front is not None else [(self._stem, self._stem + 1), (2, self._stem)]
         else:
             ranges = [(1, n if self._stem is None else self._stem)]
         for lo, hi in ranges:
@@ -1152,7 +1203,8 @@ class Engine:
         res = []
         ms = C.c_float(0)
         if self._stem is not None and getattr(self, "_stem_active", False):
-            order = [self._stem] + list(range(2, self._stem))   # as executed by __call__ for an fp16 batch
+            # as executed by __call__ for an fp16 batch
+            order = [self._front] + list(range(4, self._stem)) if self._front is not None else [self._stem] + list(range(2, self._stem))
         else:
             order = list(range(1, n if self._stem is None else self._stem))
         for i in order:
