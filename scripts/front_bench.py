@@ -71,6 +71,21 @@ def main():
     for mb in [int(v) for v in a.blocks.split(",")]:
         res[f"front_us_blocks{mb}"] = round(timed(lambda: front(mb)), 1)
     print(json.dumps(res))
+    if hasattr(lib, "y5_front_dbg_read") or os.environ.get("Y5_LIB_PATH"):
+        try:
+            lib.y5_front_dbg_read.restype = C.c_int
+            lib.y5_front_dbg_read.argtypes = [C.c_void_p]
+            front(0)
+            torch.cuda.synchronize()
+            dbg = (C.c_ulonglong * 64)()
+            assert lib.y5_front_dbg_read(dbg) == 0
+            for wv in range(8):
+                o = dbg[wv * 8: wv * 8 + 7]
+                n = max(o[6], 1)
+                print(f"   wave {wv}: tiles {o[6]}  cycles per tile: input wait+barrier {o[0] / n:.0f}  stem {o[1] / n:.0f}  patch barrier {o[2] / n:.0f}  "
+                      f"input issue {o[3] / n:.0f}  3x3 {o[4] / n:.0f}  1x1+stores {o[5] / n:.0f}  total {sum(o[:6]) / n:.0f}")
+        except AttributeError:
+            pass
 
 
 if __name__ == "__main__":

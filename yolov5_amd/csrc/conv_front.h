@@ -20,6 +20,13 @@
 #pragma once
 #include "conv_igemm.h"
 
+#ifdef Y5_FRONT_TIMING
+__device__ unsigned long long y5_front_dbg[64];  // workgroup 0, per wave: input wait + barrier, stem, patch barrier, input issue, 3x3, 1x1 + stores (s_memtime), tiles
+#define Y5_FT(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define Y5_FT(var)
+#endif
+
 struct Y5FrontParams {
   const void* x;                      // (B, 3, H, W) fp16
   const void* w0; const float* b0;    // stem filter [32][144], k = (c * 6 + kh) * 8 + kw (kw 6, 7 zero); bias [32]
@@ -58,6 +65,13 @@ constexpr size_t y5_conv_front_lds_bytes() {
   return (size_t)G::IN_BYTES + 1024 + G::SP_BYTES + (size_t)NT1 * 32 * 576 + (size_t)NT2 * 32 * (NT1 * 64) + (size_t)(32 + NT1 * 32 + NT2 * 32) * 4;
 }
 
+// experiment builds (scripts/front_ablate.sh): -DY5_FR_NOSILU identity instead of SiLU, -DY5_FR_NOSTEMMFMA / -DY5_FR_NOSTEM / -DY5_FR_NOL1 skip parts
+#ifdef Y5_FR_NOSILU
+#define Y5_FR_SILU(v) (v)
+#else
+#define Y5_FR_SILU(v) y5_silu(v)
+#endif
+
 __device__ __forceinline__ uint32_t y5_pack_h2(float a, float b) {
   typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
   h2_t v;
@@ -75,7 +89,7 @@ __device__ __forceinline__ void y5_d_to_b_frags(const float16_t& acc, half8_t (&
   for (int q = 0; q < 4; ++q) {
     float v[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = ACT ? y5_silu(acc[q * 4 + e]) : acc[q * 4 + e];
+    for (int e = 0; e < 4; ++e) v[e] = ACT ? Y5_FR_SILU(acc[q * 4 + e]) : acc[q * 4 + e];
     h[q][0] = y5_pack_h2(v[0], v[1]);
     h[q][1] = y5_pack_h2(v[2], v[3]);
   }
@@ -143,18 +157,27 @@ void y5_conv_front_kernel(const Y5FrontParams p) {
     pi_rel[i] = ((c * p.H + row) * p.W + 8 * j) * 2;
     pi_rj[i] = row | (j << 8) | ((idx < G::NPIECE ? 1 : 0) << 16);
   }
-  auto issue_input = [&](int jt) {
+  auto input_offsets = [&](int jt, unsigned (&voff)[G::NIW]) {
     int b, oh0, ow0;
     tile_origin(jt, b, oh0, ow0);
     const int ih0 = 4 * oh0 - 4, col0 = 4 * ow0 - 8;
     const int base = ((b * 3 * p.H + ih0) * p.W + col0) * 2;   // may be negative: only used when the piece is inside the image
 #pragma unroll
     for (int i = 0; i < G::NIW; ++i) {
-      const int I = wave + 8 * i;
       const int ih = ih0 + (pi_rj[i] & 0xff), col = col0 + 8 * ((pi_rj[i] >> 8) & 0xff);
       const bool ok = (pi_rj[i] >> 16) != 0 && (unsigned)ih < (unsigned)p.H && (unsigned)col < (unsigned)p.W;
-      y5_bglds16(xrs, ok ? (unsigned)(base + pi_rel[i]) : Y5_OOB, I < G::NI ? in_lds + I * 1024 : dummy);
+      voff[i] = ok ? (unsigned)(base + pi_rel[i]) : Y5_OOB;
     }
+  };
+  auto issue_piece = [&](int i, unsigned voff) {
+    const int I = wave + 8 * i;
+    y5_bglds16(xrs, voff, I < G::NI ? in_lds + I * 1024 : dummy);
+  };
+  auto issue_input = [&](int jt) {
+    unsigned voff[G::NIW];
+    input_offsets(jt, voff);
+#pragma unroll
+    for (int i = 0; i < G::NIW; ++i) issue_piece(i, voff[i]);
   };
   // (b) stem blocks of this wave: block = wave + 8 s, pixel m = block * 32 + pl -> (sr, sc)
   int sb_in[G::NBW], sb_out[G::NBW], sb_fl[G::NBW];
@@ -220,66 +243,150 @@ void y5_conv_front_kernel(const Y5FrontParams p) {
   // stores one wave issues per tile (the counted wait at the top of the next tile skips exactly these)
   const bool full_c3 = p.C3 == NPAD2;
 
+#ifdef Y5_FRONT_TIMING
+  unsigned long long d_wait = 0, d_stem = 0, d_bar = 0, d_issue = 0, d_l1 = 0, d_pw = 0;
+#endif
   for (int ti = 0; ti < nmine; ++ti) {
     int tb, oh0, ow0;
     tile_origin(ti, tb, oh0, ow0);
+    Y5_FT(ft0);
     if (ti > 0) {
       // this wave's share of the input patch has landed; the previous tile's stores (issued after it) may still be in flight
       if (full_c3) y5_wait_vm<2 * NT2>();
       else y5_wait_vm<0>();
       __builtin_amdgcn_s_barrier();  // everybody's share; every wave is done reading the previous tile's stem patch
     }
+    Y5_FT(ft1);
     // ================================ phase 1: stem ================================================================================
+    // Software-pipelined over the wave's blocks: the nine MFMAs of block s+1 (one dependent chain: an issue slot every 32 cycles) are interleaved
+    // with the ~100 VALU instructions of block s's epilogue (bias is the chain's initial value; SiLU, fp16 packing, the padding mask), and block
+    // s+1's fragment reads are issued ahead of both -- in the first version every block was read -> wait -> 9 MFMAs -> epilogue, the matrix core idle
+    // through each epilogue and the vector ALU idle through each chain: 9 000 of a tile's 19 800 cycles (in-kernel phase timing, scripts/front_bench.py).
+    auto stem_frags = [&](int s, half8_t (&afr)[9]) {
 #pragma unroll
-    for (int s = 0; s < G::NBW; ++s) {
-      if (wave + 8 * s < G::NB0) {  // wave-uniform
-        half8_t afr[9];
+      for (int ks = 0; ks < 9; ++ks) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(in_lds + sb_in[s] + ((ks / 3) * IR + 2 * (ks % 3)) * 160);
+        uint4_t raw;
+        raw[0] = src[0]; raw[1] = src[1]; raw[2] = src[2]; raw[3] = src[3];
+        afr[ks] = __builtin_bit_cast(half8_t, raw);
+      }
+    };
+    auto stem_bias = [&](float16_t& acc) {
 #pragma unroll
-        for (int ks = 0; ks < 9; ++ks) {
-          const uint32_t* src = reinterpret_cast<const uint32_t*>(in_lds + sb_in[s] + ((ks / 3) * IR + 2 * (ks % 3)) * 160);
-          uint4_t raw;
-          raw[0] = src[0]; raw[1] = src[1]; raw[2] = src[2]; raw[3] = src[3];
-          afr[ks] = __builtin_bit_cast(half8_t, raw);
-        }
-        float16_t acc;
+      for (int q = 0; q < 4; ++q) {
+        const float4_t bv = *reinterpret_cast<const float4_t*>(b0lds + q * 8 + g * 4);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4_t bv = *reinterpret_cast<const float4_t*>(b0lds + q * 8 + g * 4);
+        for (int e = 0; e < 4; ++e) acc[q * 4 + e] = bv[e];
+      }
+    };
+    auto stem_mfma = [&](const half8_t (&afr)[9], float16_t& acc) {
+#ifdef Y5_FR_NOSTEMMFMA
+      acc[0] += (float)afr[0][0] + (float)afr[8][7];
+      return;
+#endif
+#ifdef Y5_FR_ACC2
+      // two accumulation chains (k-steps 0-4 on top of the bias, 5-8 from zero), summed at the end
+      float16_t acc_b;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[q * 4 + e] = bv[e];
-        }
+      for (int r = 0; r < 16; ++r) acc_b[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf0[ks], afr[ks], acc, 0, 0, 0);
+        acc_b = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf0[5 + ks], afr[5 + ks], acc_b, 0, 0, 0);
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf0[4], afr[4], acc, 0, 0, 0);
+      acc += acc_b;
+      return;
+#endif
+#pragma unroll
+      for (int ks = 0; ks < 9; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf0[ks], afr[ks], acc, 0, 0, 0);
+    };
+    auto stem_epilogue = [&](int s, const float16_t& acc) {
+      const int fl = sb_fl[s];
+      // outside the stem image (row -1 at the top edge, column -1 at the left edge): 1.Conv's zero padding.  Branch-free: the activation is
+      // evaluated for every lane (written as `zero ? 0 : silu(v)` hipcc wrapped EACH element in its own exec-mask branch) and the packed result is
+      // ANDed with a lane mask; lanes past the patch's last pixel write to the dummy slot instead of being predicated off.
+      const uint32_t keep = (((fl & 16) && oh0 == 0) || ((fl & 32) && ow0 == 0)) ? 0u : 0xffffffffu;
+      const int fq = fl & 3;
+      char* const dst = (fl & 64) ? sp_lds + sb_out[s] : dummy + lane * 8;
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = Y5_FR_SILU(acc[r]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint2_t o;
+        o[0] = y5_pack_h2(v[q * 4 + 0], v[q * 4 + 1]) & keep;
+        o[1] = y5_pack_h2(v[q * 4 + 2], v[q * 4 + 3]) & keep;
+        *reinterpret_cast<uint2_t*>(dst + ((fl & 64) ? ((q ^ fq) * 16) : 0)) = o;
+      }
+    };
+    // interleave request to the scheduler for one pipelined step: the next block's LDS reads, a first slice of VALU while they are in flight, then
+    // one MFMA per ~10 VALU
+    auto stem_interleave = [&]() {
+#ifndef Y5_EMU
+      __builtin_amdgcn_sched_group_barrier(0x100, 22, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+      }
+#endif
+    };
+#ifndef Y5_FR_NOSTEM
+    {
+      static_assert(G::NBW == 5 && G::NB0 > 32, "pipeline written for four full rounds of blocks + a partial fifth");
+      float16_t acc_c, acc_n;
+      half8_t afr[9];
+      stem_frags(0, afr);
+      stem_bias(acc_c);
+      stem_mfma(afr, acc_c);
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        stem_frags(s + 1, afr);
+        stem_bias(acc_n);
+        stem_mfma(afr, acc_n);
+        stem_epilogue(s, acc_c);
+        stem_interleave();
 #ifndef Y5_EMU
         __builtin_amdgcn_sched_barrier(0);
 #endif
-#pragma unroll
-        for (int ks = 0; ks < 9; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf0[ks], afr[ks], acc, 0, 0, 0);
+        acc_c = acc_n;
+      }
+      if (wave + 32 < G::NB0) {  // wave-uniform: the partial fifth round
+        stem_frags(4, afr);
+        stem_bias(acc_n);
+        stem_mfma(afr, acc_n);
+        stem_epilogue(3, acc_c);
+        stem_interleave();
 #ifndef Y5_EMU
         __builtin_amdgcn_sched_barrier(0);
 #endif
-        const int fl = sb_fl[s];
-        // outside the stem image (row -1 at the top edge, column -1 at the left edge): 1.Conv's zero padding
-        const bool zero = ((fl & 16) && oh0 == 0) || ((fl & 32) && ow0 == 0);
-        const int fq = fl & 3;
-        if (fl & 64) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            half4_t o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = zero ? (half_t)0.f : (half_t)y5_silu(acc[q * 4 + e]);
-            *reinterpret_cast<half4_t*>(sp_lds + sb_out[s] + ((q ^ fq) * 16)) = o;
-          }
-        }
+        stem_epilogue(4, acc_n);
+      } else {
+        stem_epilogue(3, acc_c);
       }
     }
+#endif
+    Y5_FT(ft2);
     // the patch is complete and nobody reads the input buffer any more
 #ifndef Y5_EMU
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
     __builtin_amdgcn_s_barrier();
-    if (ti + 1 < nmine) issue_input(ti + 1);
-    else if (full_c3) {
-      // keep the per-tile vector-memory count uniform (the counted wait of a following tile never runs, nothing to do)
-    }
+    Y5_FT(ft3);
+    // the next tile's input patch: addresses now, the LDS-DMA instructions between the taps of the 3x3 (an LDS-DMA issue holds its wave for 100-400
+    // cycles in a busy phase -- 1 200-1 900 cycles per tile when the five were issued back to back here -- time the matrix core now spends on MFMAs)
+    unsigned in_voff[G::NIW];
+    const bool more_tiles = ti + 1 < nmine;
+    if (more_tiles) input_offsets(ti + 1, in_voff);
+    Y5_FT(ft4);
+#ifdef Y5_FR_NOL1
+    if (more_tiles)
+      for (int i = 0; i < G::NIW; ++i) issue_piece(i, in_voff[i]);
+    y5_wait_vm<0>();
+    continue;
+#endif
     // ================================ phase 2: 3x3 stride 2 ========================================================================
     float16_t acc1[NT1];
 #pragma unroll
@@ -290,8 +397,9 @@ void y5_conv_front_kernel(const Y5FrontParams p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc1[j][q * 4 + e] = bv[e];
       }
+    static_assert(G::NIW <= 5, "one LDS-DMA instruction behind each of the taps 1, 3, 5, 7, 8");
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 9; ++t) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const half8_t af = *reinterpret_cast<const half8_t*>(sp_lds + rdA[t][ks]);
@@ -301,6 +409,21 @@ void y5_conv_front_kernel(const Y5FrontParams p) {
           acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, af, acc1[j], 0, 0, 0);
         }
       }
+      constexpr int slot_of_tap[9] = {-1, 0, -1, 1, -1, 2, -1, 3, 4};
+      if (slot_of_tap[t] >= 0 && slot_of_tap[t] < G::NIW && more_tiles) {
+#ifndef Y5_EMU
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        issue_piece(slot_of_tap[t], in_voff[slot_of_tap[t]]);
+#ifndef Y5_EMU
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+      }
+    }
+#ifdef Y5_FRONT_TIMING
+    asm volatile("" :: "v"(acc1[0][0]));
+#endif
+    Y5_FT(ft5);
     // ================================ phase 3: 1x1 on the register-resident result ==================================================
     half8_t bf[NT1][2];
 #pragma unroll
@@ -341,5 +464,17 @@ void y5_conv_front_kernel(const Y5FrontParams p) {
         }
       }
     }
+#ifdef Y5_FRONT_TIMING
+    {
+      const unsigned long long ft6 = __builtin_amdgcn_s_memtime();
+      d_wait += ft1 - ft0; d_stem += ft2 - ft1; d_bar += ft3 - ft2; d_issue += ft4 - ft3; d_l1 += ft5 - ft4; d_pw += ft6 - ft5;
+    }
+#endif
   }
+#ifdef Y5_FRONT_TIMING
+  if (lane == 0 && blockIdx.x == 0) {
+    unsigned long long* o = y5_front_dbg + wave * 8;
+    o[0] = d_wait; o[1] = d_stem; o[2] = d_bar; o[3] = d_issue; o[4] = d_l1; o[5] = d_pw; o[6] = nmine;
+  }
+#endif
 }

@@ -62,3 +62,9 @@ extern "C" int y5_conv_front_fwd(const void* x_nchw, int B, int H, int W, const 
   if (Npad1 == 64 && Npad2 == 32) return launch_front<16, 16, 2, 1>(p, max_blocks, stream);
   return launch_front<16, 16, 1, 2>(p, max_blocks, stream);
 }
+
+#ifdef Y5_FRONT_TIMING
+extern "C" int y5_front_dbg_read(unsigned long long* out) {  // kernel-experiment builds only (not part of the ABI)
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(y5_front_dbg), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
