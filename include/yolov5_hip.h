@@ -190,6 +190,13 @@ int y5_nms_batched_hint(const void* pred, int dtype, int bs, int n, int no, int 
  * slices (pixel strides d->ldx, ld_dz).  Replaces autograd's conv weight backward under train.py:410.
  * ------------------------------------------------------------------------------------------------------- */
 int y5_conv2d_wgrad(const y5_conv_desc* d, const void* x, const void* dz, int ld_dz, float* dw_packed, void* stream);
+/* Deterministic form: the pixel-range splits write their partial sums into `workspace` ([splits][Npad][Kpad] fp32, size from
+ * y5_conv2d_wgrad_ws_bytes for the same descriptor incl. max_blocks; 16-byte aligned) and a second launch adds them to dw_packed in split order --
+ * bit-identical from run to run and from rank to rank, where the atomic form above is order-dependent in the last bits of fp32 (what
+ * torch.use_deterministic_algorithms asks of cudnn's weight gradient in the reference's --seed runs, train.py:105 init_seeds(deterministic=True)). */
+int y5_conv2d_wgrad_det(const y5_conv_desc* d, const void* x, const void* dz, int ld_dz, float* dw_packed, void* workspace, size_t workspace_bytes,
+                        void* stream);
+long long y5_conv2d_wgrad_ws_bytes(const y5_conv_desc* d, int ld_dz);   /* < 0: error (y5_last_error) */
 
 /* ---------------------------------------------------------------------------------------------------------
  * Train-mode Conv block pieces (models/common.py:82-88 `Conv.forward` = SiLU(BatchNorm2d(conv(x))) with BATCH

@@ -182,6 +182,11 @@ def load():
     sys.modules["torchvision.ops"].nms = tp.nms
     sys.modules["torchvision"].ops = sys.modules["torchvision.ops"]
 
+    # yolov5_amd.experimental.install_reference_aliases (checkpoint save / load) registers ALIAS modules `models.yolo` / `models.common` whose
+    # classes are yolov5_amd's: a test that ran earlier in this process may have left them -- the reference must import its own files
+    if getattr(sys.modules.get("models.yolo"), "__y5amd__", False):
+        for name in [n for n in sys.modules if n == "models" or n.startswith("models.")]:
+            del sys.modules[name]
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
     cwd = os.getcwd()
@@ -223,6 +228,24 @@ def load():
     )
     _loaded = ns
     return ns
+
+
+def unload():
+    """Forget the imported reference: its `models` / `utils` packages leave sys.modules and its root leaves sys.path, so that code which must NOT
+    see a live reference checkout in the process (yolov5_amd.experimental.install_reference_aliases refuses to alias `models.yolo` then) behaves
+    as on a clean interpreter.  The stub modules (cv2, torchvision, ultralytics.*) stay: they are harmless.  Test modules that load() the reference
+    call this when they are done (module-scoped fixture finaliser) -- pytest-xdist may run any other test file in the same worker afterwards."""
+    global _loaded
+    _loaded = None
+    for name in list(sys.modules):
+        if name in ("models", "utils", "export", "val", "train", "detect") or name.startswith(("models.", "utils.")):
+            mod = sys.modules.get(name)
+            f = getattr(mod, "__file__", None) or ""
+            if f.startswith(REFERENCE_ROOT) or (not f and name.split(".")[0] in ("models", "utils") and not getattr(mod, "__y5amd__", False)
+                                                and not getattr(sys.modules.get("models.yolo"), "__y5amd__", False)):
+                del sys.modules[name]
+    while REFERENCE_ROOT in sys.path:
+        sys.path.remove(REFERENCE_ROOT)
 
 
 @contextlib.contextmanager

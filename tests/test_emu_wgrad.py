@@ -58,3 +58,35 @@ def test_emu_wgrad_matches_torch(case):
     ref = w.grad.permute(0, 2, 3, 1).reshape(C2, K).numpy()   # k = (kh, kw, c)
     np.testing.assert_allclose(dw[:C2, :K], ref, rtol=2e-3, atol=2e-3)
     assert np.all(dw[C2:] == 0) and np.all(dw[:, K:] == 0)
+
+
+@pytest.mark.parametrize("case", [CASES[1], CASES[5], CASES[8]])
+def test_emu_wgrad_deterministic_form_equals_atomic_form(case):
+    """y5_conv2d_wgrad_det: the pixel-range splits park their partial tiles in a workspace and a second launch adds them in
+    split order.  Same sums as the atomic form up to fp32 association; on top of a non-zero dW (+=); too small a workspace is refused."""
+    B, H, W, C1, C2, k, s, p, splits = case
+    lib = emu()
+    x = torch.from_numpy(detgen.uniform((B, C1, H, W), -1, 1, name="wx")).half()
+    OH, OW = (H + 2 * p[0] - k[0]) // s[0] + 1, (W + 2 * p[1] - k[1]) // s[1] + 1
+    dz = torch.from_numpy(detgen.uniform((B, C2, OH, OW), -1, 1, name="wdz")).half()
+    ref, K, Kpad = run_wgrad(lib, x, dz, k, s, p, splits)
+    Npad = round_up(C2, 32)
+    ldx, ldz = C1 + 8, C2 + 8
+    xa = aligned((B, H, W, ldx), np.float16, 5.0); xa[..., :C1] = x.permute(0, 2, 3, 1).numpy()
+    za = aligned((B, OH, OW, ldz), np.float16, 5.0); za[..., :C2] = dz.permute(0, 2, 3, 1).numpy()
+    d = _lib.ConvDesc(dtype=_lib.Y5_F16, B=B, H=H, W=W, C1=C1, ldx=ldx, OH=OH, OW=OW, C2=C2, ldy=ldz, KH=k[0], KW=k[1], SH=s[0], SW=s[1],
+                      PH=p[0], PW=p[1], act=0, Kpad=Kpad, Npad=Npad, ldr=0, ld2=0, cfg=-1, max_blocks=splits)
+    need = lib.y5_conv2d_wgrad_ws_bytes(C.byref(d), ldz)
+    assert need > 0 and need % (Npad * Kpad * 4) == 0
+    ws = aligned((need // 4,), np.float32, 123.0)                      # garbage: every slab element that is read must have been written
+    outs = []
+    for _ in range(2):
+        dw = aligned((Npad, Kpad), np.float32, 0.0)
+        dw[:C2, :K] = 1.5                                              # accumulates on top of what is there
+        rc = lib.y5_conv2d_wgrad_det(C.byref(d), ptr(xa), ptr(za), ldz, ptr(dw), ptr(ws), need, None)
+        assert rc == 0, lib.y5_last_error()
+        outs.append(dw.copy())
+    assert np.array_equal(outs[0], outs[1])
+    np.testing.assert_allclose(outs[0][:C2, :K] - 1.5, ref[:C2, :K], rtol=1e-5, atol=1e-4)
+    assert np.all(outs[0][C2:] == 0) and np.all(outs[0][:, K:] == 0)
+    assert lib.y5_conv2d_wgrad_det(C.byref(d), ptr(xa), ptr(za), ldz, ptr(outs[0]), ptr(ws), need - 16, None) != 0

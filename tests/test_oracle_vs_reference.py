@@ -12,7 +12,8 @@ pytestmark = pytest.mark.skipif(not ref_shim.available(), reason="reference tree
 
 @pytest.fixture(scope="module")
 def ns():
-    return ref_shim.load()
+    yield ref_shim.load()
+    ref_shim.unload()   # the next test file in this xdist worker starts without the reference's `models` / `utils` packages in sys.modules
 
 
 def test_build_targets_and_loss_match_live_reference(ns):

@@ -112,6 +112,8 @@ EXPORTS = {
                                  C.c_void_p, C.c_float, C.c_void_p]),
     "y5_mt_lerp": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_void_p]),
     "y5_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "y5_conv2d_wgrad_det": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "y5_conv2d_wgrad_ws_bytes": (C.c_longlong, [C.POINTER(ConvDesc), C.c_int]),
     "y5_bn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_longlong]),
     "y5_bn_silu_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,

@@ -23,12 +23,15 @@ struct Y5WgradParams {
   int M;            // B*OH*OW
   int tiles_n, tiles_k, splits;
   int pix_per_split;  // multiple of 32
+  float* ws;          // DET kernels: [splits][Npad][Kpad] partial sums, one slab per pixel-range split (plain stores, no atomics)
 };
 
 // LIN: pointwise layers (k1 s1 p0: the x pixel of a staged row IS its output pixel) -- both operands advance by a constant byte step per chunk, so staging
 // a row costs an add, a compare and a select instead of the coordinate walk + bounds tests of the general gather (33 of yolov5s' 57 layers; the ablation
 // builds put staging -- LDS-DMA issue plus its address arithmetic -- at 40 % of this kernel)
-template <int TNB, int TKB, int S, bool LIN>
+// DET: deterministic reduction -- every (tile, split) workgroup writes its partial tile into ITS slab of p.ws with plain stores; y5_wgrad_reduce_kernel adds
+// the slabs in split order.  The default (atomics into dW) is order-dependent in the last bits of fp32 (run-to-run, rank-to-rank).
+template <int TNB, int TKB, int S, bool LIN, bool DET = false>
 __global__ __launch_bounds__(256)
 void y5_conv_wgrad_kernel(const Y5WgradParams p) {
   typedef half_t T;
@@ -196,12 +199,25 @@ void y5_conv_wgrad_kernel(const Y5WgradParams p) {
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wn * 32 * TNB + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
 #ifndef Y5_WG_NOATOM
-        if (n < p.C2) atomicAdd(p.dw + (size_t)n * p.Kpad + kcol, acc[a][b2][r]);
+        if constexpr (DET) {
+          if (n < p.C2) p.ws[((size_t)sp * p.Npad + n) * p.Kpad + kcol] = acc[a][b2][r];
+        } else if (n < p.C2) atomicAdd(p.dw + (size_t)n * p.Kpad + kcol, acc[a][b2][r]);
 #else
         if (n < p.C2 && acc[a][b2][r] == 1.2345f) p.dw[(size_t)n * p.Kpad + kcol] = acc[a][b2][r];
 #endif
       }
   }
+}
+
+// dW[n][k] += sum over the splits, in split order, of the slabs the DET kernel wrote (fixed summation order: bit-identical run to run)
+__global__ void y5_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int C2, int K, int Npad, int Kpad, int splits) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)C2 * Kpad) return;
+  const int k = (int)(i % Kpad), n = (int)(i / Kpad);
+  if (k >= K) return;
+  float s = 0.f;
+  for (int sp = 0; sp < splits; ++sp) s += ws[((size_t)sp * Npad + n) * Kpad + k];
+  dw[(size_t)n * Kpad + k] += s;
 }
 
 // fp32 weight gradient (TrainEngine's reference-precision mode): one thread per packed filter element, a plain fp32 sum over all output
@@ -227,10 +243,12 @@ __global__ void y5_conv_wgrad_f32_kernel(const float* __restrict__ x, const floa
   dw[(size_t)n * Kpad + k] += s;
 }
 
-extern "C" int y5_conv2d_wgrad(const y5_conv_desc* d, const void* x, const void* dz, int ld_dz, float* dw_packed, void* stream_) {
+static int wgrad_impl(const y5_conv_desc* d, const void* x, const void* dz, int ld_dz, float* dw_packed, float* ws, size_t ws_bytes, size_t* need, void* stream_) {
   hipStream_t st = static_cast<hipStream_t>(stream_);
-  if (!d || !x || !dz || !dw_packed) return y5_fail(Y5_ERR_BAD_ARG, "wgrad: null pointer");
+  if (need) *need = 0;
+  if (!d || (!need && (!x || !dz || !dw_packed))) return y5_fail(Y5_ERR_BAD_ARG, "wgrad: null pointer");
   if (d->dtype == Y5_F32) {
+    if (need) return Y5_OK;  // the fp32 kernel is a fixed-order sum already: no workspace
     const int oh32 = (d->H + 2 * d->PH - d->KH) / d->SH + 1, ow32 = (d->W + 2 * d->PW - d->KW) / d->SW + 1;
     if (oh32 != d->OH || ow32 != d->OW || d->Kpad < d->KH * d->KW * d->C1 || d->Npad < d->C2) return y5_fail(Y5_ERR_BAD_ARG, "wgrad: inconsistent geometry");
     const long long total = (long long)d->C2 * d->Kpad;
@@ -242,7 +260,7 @@ extern "C" int y5_conv2d_wgrad(const y5_conv_desc* d, const void* x, const void*
   if (d->C1 % 8 || d->ldx % 8 || ld_dz % 8 || d->C2 % 8) return y5_fail(Y5_ERR_BAD_ARG, "wgrad: C1, C2, ldx, ld_dz must be multiples of 8");
   const int oh = (d->H + 2 * d->PH - d->KH) / d->SH + 1, ow = (d->W + 2 * d->PW - d->KW) / d->SW + 1;
   if (oh != d->OH || ow != d->OW) return y5_fail(Y5_ERR_BAD_ARG, "wgrad: OH/OW inconsistent with H/W/k/s/p");
-  if (((uintptr_t)x | (uintptr_t)dz | (uintptr_t)dw_packed) & 15) return y5_fail(Y5_ERR_BAD_ARG, "wgrad: pointers must be 16-byte aligned");
+  if (!need && (((uintptr_t)x | (uintptr_t)dz | (uintptr_t)dw_packed) & 15)) return y5_fail(Y5_ERR_BAD_ARG, "wgrad: pointers must be 16-byte aligned");
   const long long xb = (((long long)d->B * d->H * d->W - 1) * d->ldx + d->C1) * 2;
   const long long zb = (((long long)d->B * oh * ow - 1) * ld_dz + d->C2) * 2;
   if (xb >= 0x7fffffffLL || zb >= 0x7fffffffLL) return y5_fail(Y5_ERR_UNSUPPORTED, "wgrad: tensor exceeds 2^31 bytes");
@@ -271,11 +289,19 @@ extern "C" int y5_conv2d_wgrad(const y5_conv_desc* d, const void* x, const void*
   p.splits = (p.M + p.pix_per_split - 1) / p.pix_per_split;
   const long long grid = (long long)tiles * p.splits;
   if (grid > 0x7fffffffLL) return y5_fail(Y5_ERR_UNSUPPORTED, "wgrad: grid too large");
+  const size_t ws_need = (size_t)p.splits * p.Npad * p.Kpad * sizeof(float);
+  if (need) { *need = ws_need; return Y5_OK; }
+  const bool det = ws != nullptr;
+  if (det && (ws_bytes < ws_need || ((uintptr_t)ws & 15))) return y5_fail(Y5_ERR_BAD_ARG, "wgrad: workspace too small (y5_conv2d_wgrad_ws_bytes) or misaligned");
+  p.ws = ws;
   // ring depth: as many 32-pixel chunks in flight as ~48 KiB of LDS per workgroup allows (3 workgroups per CU)
   const bool lin = d->KH == 1 && d->KW == 1 && d->SH == 1 && d->SW == 1 && d->PH == 0 && d->PW == 0;
 #define Y5_WG_LAUNCH(TN, TK, SS, BYTES)                                                                                          \
   do {                                                                                                                           \
-    if (lin) hipLaunchKernelGGL((y5_conv_wgrad_kernel<TN, TK, SS, true>), dim3((unsigned)grid), dim3(256), BYTES, st, p);         \
+    if (det) {                                                                                                                   \
+      if (lin) hipLaunchKernelGGL((y5_conv_wgrad_kernel<TN, TK, SS, true, true>), dim3((unsigned)grid), dim3(256), BYTES, st, p);  \
+      else hipLaunchKernelGGL((y5_conv_wgrad_kernel<TN, TK, SS, false, true>), dim3((unsigned)grid), dim3(256), BYTES, st, p);     \
+    } else if (lin) hipLaunchKernelGGL((y5_conv_wgrad_kernel<TN, TK, SS, true>), dim3((unsigned)grid), dim3(256), BYTES, st, p);   \
     else hipLaunchKernelGGL((y5_conv_wgrad_kernel<TN, TK, SS, false>), dim3((unsigned)grid), dim3(256), BYTES, st, p);            \
   } while (0)
   if (tnb == 2 && tkb == 2) Y5_WG_LAUNCH(2, 2, 3, 3 * 16384);
@@ -283,5 +309,23 @@ extern "C" int y5_conv2d_wgrad(const y5_conv_desc* d, const void* x, const void*
   else if (tkb == 2) Y5_WG_LAUNCH(1, 2, 4, 4 * 12288);
   else Y5_WG_LAUNCH(1, 1, 6, 6 * 8192);
 #undef Y5_WG_LAUNCH
+  if (det) {
+    const long long total = (long long)d->C2 * p.Kpad;
+    hipLaunchKernelGGL(y5_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws, dw_packed, d->C2, p.K, p.Npad, p.Kpad, p.splits);
+  }
   return y5_check_launch("y5_conv2d_wgrad");
+}
+
+extern "C" int y5_conv2d_wgrad(const y5_conv_desc* d, const void* x, const void* dz, int ld_dz, float* dw_packed, void* stream_) {
+  return wgrad_impl(d, x, dz, ld_dz, dw_packed, nullptr, 0, nullptr, stream_);
+}
+extern "C" int y5_conv2d_wgrad_det(const y5_conv_desc* d, const void* x, const void* dz, int ld_dz, float* dw_packed, void* workspace, size_t workspace_bytes,
+                                   void* stream_) {
+  if (!workspace) return y5_fail(Y5_ERR_BAD_ARG, "wgrad_det: null workspace");
+  return wgrad_impl(d, x, dz, ld_dz, dw_packed, static_cast<float*>(workspace), workspace_bytes, nullptr, stream_);
+}
+extern "C" long long y5_conv2d_wgrad_ws_bytes(const y5_conv_desc* d, int ld_dz) {
+  size_t need = 0;
+  if (wgrad_impl(d, nullptr, nullptr, ld_dz, nullptr, nullptr, 0, &need, nullptr) != Y5_OK) return -1;
+  return (long long)need;
 }

@@ -58,6 +58,11 @@ class TrainEngine:
         self.be = backend if backend is not None else default_backend(device)
         self.lib = self.be.lib
         self.model = model
+        # Y5_DETERMINISTIC=1 (or torch.use_deterministic_algorithms(True), as the reference's init_seeds(deterministic=True) sets, utils/general.py):
+        # weight gradients are reduced over their pixel-range splits in a fixed order instead of with fp32 atomics -- the one order-dependent
+        # step of the training plan; a few % slower (one more small launch per layer)
+        self.deterministic = os.environ.get("Y5_DETERMINISTIC", "0") == "1" or torch.are_deterministic_algorithms_enabled()
+        self._wg_ws, self._wg_ws_bytes = None, 0
         B, ch, H, W = x_shape
         self.x_shape = tuple(x_shape)
         self.spec = _TrainPlanner(model, B, ch, H, W, want_raw=True).run()
@@ -479,7 +484,19 @@ class TrainEngine:
         if "wg_splits" not in st:
             st["wg_splits"] = self._tune_wgrad_splits(d, self._ptr(x), dz_ptr, ld_dz, dw_ptr, Npad * Kpad * 4, stm)
         d.max_blocks = st["wg_splits"]
-        _lib.check(lib.y5_conv2d_wgrad(C.byref(d), _vp(self._ptr(x)), _vp(dz_ptr), ld_dz, _vp(dw_ptr), stm), lib)
+        if self.deterministic and self.dt == _lib.Y5_F16:
+            # fixed-order reduction of the pixel-range splits through a workspace (csrc/wgrad.hip DET): bit-identical gradients run to run
+            need = int(lib.y5_conv2d_wgrad_ws_bytes(C.byref(d), ld_dz))
+            if need < 0:
+                _lib.check(-1, lib)
+            if self._wg_ws is None or self._wg_ws_bytes < need:
+                self._wg_ws_bytes = max(need, 1 << 20)
+                self._wg_ws = be.empty((self._wg_ws_bytes // 4 + 64,), torch.float32)
+            wsp = be.ptr(self._wg_ws)
+            wsp += (-wsp) % 16
+            _lib.check(lib.y5_conv2d_wgrad_det(C.byref(d), _vp(self._ptr(x)), _vp(dz_ptr), ld_dz, _vp(dw_ptr), _vp(wsp), need, stm), lib)
+        else:
+            _lib.check(lib.y5_conv2d_wgrad(C.byref(d), _vp(self._ptr(x)), _vp(dz_ptr), ld_dz, _vp(dw_ptr), stm), lib)
         if self.grad_sink is not None:  # a gradient sink (HipDDP) wants every gradient as early as possible: unpack per layer
             _lib.check(lib.y5_unpack_conv_wgrad(_vp(be.ptr(self.dwflat) + st["dw_off"] * 4), Kpad, _vp(self._gptr(cv.weight)), c2, c1, kh, kw,
                                                 st["c1v"], stm), lib)
