@@ -66,3 +66,39 @@ def test_hipddp_buckets_over_rccl_world1(pg):
 
     same(local, red)
     same(local, grads(ddp))   # a second step re-uses the buckets (same arena, same ranges)
+
+
+def test_deterministic_mode_gradients_are_bit_identical_with_and_without_ddp(pg, monkeypatch):
+    """with Y5_DETERMINISTIC=1 (TrainEngine: weight gradients reduced over their pixel-range splits in a fixed order through
+    y5_conv2d_wgrad_det instead of fp32 atomics) two backward passes give the SAME BITS, and the RCCL world-1 all-reduce (AVG over one rank = the
+    identity) leaves them unchanged -- the statement DESIGN.md section 6 makes for the multi-rank case, now actually asserted."""
+    from yolov5_amd.loss import ComputeLoss
+    from yolov5_amd.torch_utils import smart_DDP
+    from yolov5_amd.yolo import DetectionModel
+
+    monkeypatch.setenv("Y5_DETERMINISTIC", "1")
+    dev = torch.device("cuda:0")
+    m = DetectionModel("yolov5s.yaml")
+    m.load_state_dict(yo.det_state_dict(yo.model_cfg("yolov5s"), 0, fused=False))
+    m.hyp = dict(yo.HYP_SCRATCH_LOW)
+    m = m.to(dev).train()
+    B, S = 8, 256
+    x = torch.from_numpy(detgen.uniform((B, 3, S, S), 0.0, 1.0, name="ddp", seed=3)).half().to(dev)
+    t = torch.from_numpy(detgen.synth_targets(B, 6, seed=3)).to(dev)
+    loss_fn = ComputeLoss(m)
+
+    def grads(model):
+        for p in m.parameters():
+            p.grad = None
+        loss, _ = loss_fn(model(x), t)
+        (loss * 1024.0).backward()
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in m.parameters()]
+
+    a, b = grads(m), grads(m)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    c = grads(smart_DDP(m))
+    for u, v in zip(a, c):
+        assert torch.equal(u, v)
+    assert sum(float(g.abs().sum()) for g in a) > 0
