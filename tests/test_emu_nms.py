@@ -115,11 +115,14 @@ def test_detect_decode_fp16_paths_agree(ny, nx, no, nm, row_off):
     np.testing.assert_allclose(outs[0][:, row_off:].astype(np.float32), ref, rtol=3e-3, atol=3e-3)
 
 
-@pytest.mark.parametrize("dt,Cc", [("f16", 16), ("f32", 16), ("f16", 128), ("f32", 64)])   # 128 x f16 / 64 x f32: 128-byte channel groups
-def test_sppf_pool_emulated(dt, Cc):
+@pytest.mark.parametrize("dt,Cc,H,W", [("f16", 16, 6, 5), ("f32", 16, 6, 5), ("f16", 128, 6, 5), ("f32", 64, 6, 5),   # 128 x f16 / 64 x f32: 128-byte channel groups
+                                       ("f16", 32, 20, 20),    # the yolov5 P5 plane at 640^2: several vectors per thread, windows precomputed per thread
+                                       ("f16", 16, 44, 48),    # more than 8 vectors per thread: generic index path, separable
+                                       ("f16", 16, 60, 56)])   # plane too large for the third LDS plane: direct k x k window
+def test_sppf_pool_emulated(dt, Cc, H, W):
     lib = emu()
     npdt = np.float16 if dt == "f16" else np.float32
-    B, H, W = 2, 6, 5
+    B = 2 if H * W < 1000 else 1
     x = detgen.uniform((B, Cc, H, W), -2, 2, name="pool").astype(npdt)
     buf = aligned((B, H, W, 4 * Cc), npdt, 0.0)
     buf[..., :Cc] = x.transpose(0, 2, 3, 1)

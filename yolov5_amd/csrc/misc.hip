@@ -45,11 +45,11 @@ extern "C" int y5_sppf_pool(void* buf, int dt, int B, int H, int W, int C, int l
   hipStream_t st = static_cast<hipStream_t>(stream_);
   const int es = esize(dt);
   if (!buf || es < 2 || (C * es) % 16 || (ld * es) % 16 || ld < 4 * C || !(k & 1)) return y5_fail(Y5_ERR_BAD_ARG, "sppf_pool: bad args");
-  // channel-group width: measured at the yolov5s shape (20x20, 256 of 1024 channels, bs 64): 16 B 52 us, 32 B 49.5, 64 B 49.9,
-  // 128 B 76 (one workgroup per CU) -- the kernel is bound by its LDS window loops, not by the strided rows.  Y5_SPPF_GV overrides.
-  int gv = 2;
+  // channel-group width, measured at the yolov5s shape (20x20, 256 of 1024 channels, bs 64) with the separable kernel and per-thread precomputed
+  // windows (round 3): 16 B per pixel 46 us, 32 B 28 us, 64 B 23 us (whole 64-byte sectors of the 2 KiB-strided rows).  Y5_SPPF_GV overrides.
+  int gv = 4;
   if (const char* e = getenv("Y5_SPPF_GV")) gv = atoi(e);
-  if (gv != 1 && gv != 2 && gv != 4 && gv != 8) gv = 2;
+  if (gv != 1 && gv != 2 && gv != 4 && gv != 8) gv = 4;
   while (gv > 1 && ((C * es) % (16 * gv) != 0 || (size_t)H * W * 16 * gv * 3 > 150 * 1024)) gv >>= 1;
   const bool sep = (size_t)H * W * 16 * gv * 3 <= 150 * 1024;  // separable row / column passes need a third plane; otherwise the k x k window directly
   const size_t lds = (size_t)H * W * 16 * gv * (sep ? 3 : 2);

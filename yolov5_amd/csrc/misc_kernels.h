@@ -53,34 +53,18 @@ __global__ void y5_sppf_pool_kernel(char* __restrict__ buf, int H, int W, int C_
   const int b = blockIdx.x / groups, cg = blockIdx.x - b * groups;
   char* base = buf + (size_t)b * HW * ld_bytes + (size_t)cg * 16 * GV;
   const int n = HW * GV;  // vector index v = pixel * GV + lane-in-pixel
-  for (int v = threadIdx.x; v < n; v += blockDim.x) p0[v] = *reinterpret_cast<const V*>(base + (size_t)(v / GV) * ld_bytes + (v % GV) * 16);
-  __syncthreads();
+  // every thread owns the SAME vector slots (v = tid + it * blockDim) in all six sub-passes: their (row, column) and clamped window bounds are
+  // computed once (the first version re-derived them with two integer divisions per vector per sub-pass -- more instructions than the max chain itself)
+  constexpr int MAXIT = 8;
+  const int nit = (n + (int)blockDim.x - 1) / (int)blockDim.x;
   const int r = k / 2;
-  V* in = p0;
-  V* out = p1;
-  for (int pass = 1; pass <= 3; ++pass) {
-    // max is exact, so the k x k window is taken separably: k reads along the row into `tmp`, k reads down the column (2k instead of k^2
-    // LDS reads per output -- the kernel is bound by them)
-    if constexpr (SEP) {
-      for (int v = threadIdx.x; v < n; v += blockDim.x) {
-        const int i = v / GV, gl = v % GV;
-        const int y = i / W, x = i - y * W;
-        const int x0 = x - r < 0 ? 0 : x - r, x1 = x + r >= W ? W - 1 : x + r;
-        V m = in[(y * W + x0) * GV + gl];
-        for (int xx = x0 + 1; xx <= x1; ++xx) m = __builtin_elementwise_max(m, in[(y * W + xx) * GV + gl]);
-        tmp[v] = m;
-      }
-      __syncthreads();
-      for (int v = threadIdx.x; v < n; v += blockDim.x) {
-        const int i = v / GV, gl = v % GV;
-        const int y = i / W, x = i - y * W;
-        const int y0 = y - r < 0 ? 0 : y - r, y1 = y + r >= H ? H - 1 : y + r;
-        V m = tmp[(y0 * W + x) * GV + gl];
-        for (int yy = y0 + 1; yy <= y1; ++yy) m = __builtin_elementwise_max(m, tmp[(yy * W + x) * GV + gl]);
-        out[v] = m;
-        *reinterpret_cast<V*>(base + (size_t)i * ld_bytes + (size_t)pass * C_bytes + gl * 16) = m;
-      }
-    } else {  // planes too large for a third one: the k x k window directly
+  if (nit > MAXIT || !SEP) {  // planes larger than MAXIT * blockDim vectors, or too large for the third LDS plane of the separable form (not a
+                             // YOLOv5 P5 shape): generic index arithmetic, the k x k window directly
+    for (int v = threadIdx.x; v < n; v += blockDim.x) p0[v] = *reinterpret_cast<const V*>(base + (size_t)(v / GV) * ld_bytes + (v % GV) * 16);
+    __syncthreads();
+    V* in = p0;
+    V* out = p1;
+    for (int pass = 1; pass <= 3; ++pass) {
       for (int v = threadIdx.x; v < n; v += blockDim.x) {
         const int i = v / GV, gl = v % GV;
         const int y = i / W, x = i - y * W;
@@ -92,6 +76,57 @@ __global__ void y5_sppf_pool_kernel(char* __restrict__ buf, int H, int W, int C_
         out[v] = m;
         *reinterpret_cast<V*>(base + (size_t)i * ld_bytes + (size_t)pass * C_bytes + gl * 16) = m;
       }
+      __syncthreads();
+      V* t = in; in = out; out = t;
+    }
+    return;
+  }
+  int rowlo[MAXIT], rowcnt[MAXIT], collo[MAXIT], colcnt[MAXIT], pix[MAXIT];
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int v = threadIdx.x + it * blockDim.x;
+    const int vv = v < n ? v : 0;
+    const int i = vv / GV, gl = vv % GV;
+    const int y = i / W, x = i - y * W;
+    const int x0 = x - r < 0 ? 0 : x - r, x1 = x + r >= W ? W - 1 : x + r;
+    const int y0 = y - r < 0 ? 0 : y - r, y1 = y + r >= H ? H - 1 : y + r;
+    rowlo[it] = (y * W + x0) * GV + gl; rowcnt[it] = v < n && it < nit ? x1 - x0 : -1;   // window = first element + cnt more, stride GV
+    collo[it] = (y0 * W + x) * GV + gl; colcnt[it] = y1 - y0;                            // ... stride W * GV
+    pix[it] = i;
+  }
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it)
+    if (rowcnt[it] >= 0) {
+      const int v = threadIdx.x + it * blockDim.x;
+      p0[v] = *reinterpret_cast<const V*>(base + (size_t)pix[it] * ld_bytes + (v % GV) * 16);
+    }
+  __syncthreads();
+  V* in = p0;
+  V* out = p1;
+  const int cs = W * GV;
+  for (int pass = 1; pass <= 3; ++pass) {
+    // max is exact, so the k x k window is taken separably: k reads along the row into `tmp`, k reads down the column (2k instead of k^2
+    // LDS reads per output)
+    {
+#pragma unroll
+      for (int it = 0; it < MAXIT; ++it)
+        if (rowcnt[it] >= 0) {
+          const V* q = in + rowlo[it];
+          V m = q[0];
+          for (int j = 1; j <= rowcnt[it]; ++j) m = __builtin_elementwise_max(m, q[j * GV]);
+          tmp[threadIdx.x + it * blockDim.x] = m;
+        }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < MAXIT; ++it)
+        if (rowcnt[it] >= 0) {
+          const int v = threadIdx.x + it * blockDim.x;
+          const V* q = tmp + collo[it];
+          V m = q[0];
+          for (int j = 1; j <= colcnt[it]; ++j) m = __builtin_elementwise_max(m, q[j * cs]);
+          out[v] = m;
+          *reinterpret_cast<V*>(base + (size_t)pix[it] * ld_bytes + (size_t)pass * C_bytes + (v % GV) * 16) = m;
+        }
     }
     __syncthreads();
     V* t = in; in = out; out = t;
