@@ -72,14 +72,6 @@ constexpr size_t y5_conv_front_lds_bytes() {
 #define Y5_FR_SILU(v) y5_silu(v)
 #endif
 
-__device__ __forceinline__ uint32_t y5_pack_h2(float a, float b) {
-  typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
-  h2_t v;
-  v[0] = (half_t)a;
-  v[1] = (half_t)b;
-  return __builtin_bit_cast(uint32_t, v);
-}
-
 // D-layout registers of one 32-channel block (16 fp32 per lane: channels 8 q + 4 g + e) -> the two B-operand fragments (k-steps 0 / 1 of the block's 32
 // channels: lane (pixel, g) holds channels 16 ks + 8 g .. + 7) after bias-free activation; see the header comment
 template <bool ACT>
@@ -93,16 +85,10 @@ __device__ __forceinline__ void y5_d_to_b_frags(const float16_t& acc, half8_t (&
     h[q][0] = y5_pack_h2(v[0], v[1]);
     h[q][1] = y5_pack_h2(v[2], v[3]);
   }
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    // v_permlane32_swap a, b: a[lanes 32..63] <-> b[lanes 0..31].  Lower lane: keeps its group 2ks, receives the upper lane's group 2ks;
-    // upper lane: receives the lower lane's group 2ks+1, keeps its own.
-    const auto r0 = __builtin_amdgcn_permlane32_swap(h[2 * ks][0], h[2 * ks + 1][0], false, false);
-    const auto r1 = __builtin_amdgcn_permlane32_swap(h[2 * ks][1], h[2 * ks + 1][1], false, false);
-    uint4_t f;
-    f[0] = r0[0]; f[1] = r1[0]; f[2] = r0[1]; f[3] = r1[1];
-    out[ks] = __builtin_bit_cast(half8_t, f);
-  }
+  uint4_t f[2];
+  y5_swap_to_pixel_vectors(h, f);
+  out[0] = __builtin_bit_cast(half8_t, f[0]);
+  out[1] = __builtin_bit_cast(half8_t, f[1]);
 }
 
 template <int TH, int TW, int NT1, int NT2>

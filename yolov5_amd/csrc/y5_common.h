@@ -57,6 +57,29 @@ __device__ __forceinline__ uint4_t y5_buffer_load16(y5_rsrc_t r, int voff, int a
 __device__ __forceinline__ float y5_sigmoid(float v) { return 1.0f / (1.0f + __expf(-v)); }
 __device__ __forceinline__ float y5_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
+// two fp32 -> one packed fp16 pair (round to nearest even, as the scalar conversions of the LDS-transposed epilogues)
+__device__ __forceinline__ uint32_t y5_pack_h2(float a, float b) {
+  typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+  h2_t v;
+  v[0] = (half_t)a;
+  v[1] = (half_t)b;
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+// MFMA 32x32 D layout -> pixel-major 16-byte vectors WITHOUT an LDS round trip.  After `mfma(W, A)` lane (pixel = lane & 31, g = lane >> 5) owns the
+// sixteen values of channels 8 q + 4 g + e (q, e = 0..3) of its pixel.  Packed to fp16 pairs h[q][0..1] and exchanged with v_permlane32_swap
+// (a[lanes 32..63] <-> b[lanes 0..31], pinned on the hardware by scripts/ubench/permlane_probe.hip), lane (pixel, g) ends up with the EIGHT
+// consecutive channels 16 ks + 8 g .. + 7 for ks = 0, 1: a 16-byte store per lane (two lanes = 32 contiguous bytes of the pixel), and at the same
+// time exactly the B-operand fragment of a following MFMA over these channels (conv_front.h).
+__device__ __forceinline__ void y5_swap_to_pixel_vectors(const uint32_t (&h)[4][2], uint4_t (&out)[2]) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const auto r0 = __builtin_amdgcn_permlane32_swap(h[2 * ks][0], h[2 * ks + 1][0], false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(h[2 * ks][1], h[2 * ks + 1][1], false, false);
+    out[ks][0] = r0[0]; out[ks][1] = r1[0]; out[ks][2] = r0[1]; out[ks][3] = r1[1];
+  }
+}
+
 // XCD-aware bijective remap of a 1-D block id: blocks that land on the same XCD (bid % 8) get a
 // contiguous range of logical tile ids so that neighbouring tiles share that XCD's L2.
 __device__ __forceinline__ int y5_xcd_remap(int bid, int nwg) {
