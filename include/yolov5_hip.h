@@ -284,6 +284,9 @@ typedef struct {
   float fl_gamma;  /* hyp['fl_gamma'] (loss.py:120-122): > 0 wraps both BCE terms in FocalLoss(gamma, alpha = 0.25), loss.py:77-98; 0 = plain BCE */
 } y5_loss_desc;
 size_t y5_loss_workspace_bytes(const y5_loss_desc* d, int nt);   /* 0 on invalid descriptor */
+/* Byte offset, inside the workspace, of float obji[nl]: each level's mean objectness BCE before its balance factor (utils/loss.py:171),
+ * valid after y5_loss_forward -- the input of ComputeLoss(autobalance=True) (utils/loss.py:173-177, host arithmetic).  -1 on invalid descriptor. */
+long long y5_loss_obji_offset(const y5_loss_desc* d, int nt);
 int y5_loss_forward(const y5_loss_desc* d, const void* const* p, const float* targets, int nt, float* out4,
                     void* workspace, size_t workspace_bytes, void* stream);
 int y5_loss_backward(const y5_loss_desc* d, const void* const* p, int nt, const float* grad_scale, void* const* dp,

@@ -310,7 +310,7 @@ def greedy_nms(boxes: np.ndarray, scores: np.ndarray, iou_thres: float) -> np.nd
 
 
 def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False,
-                        multi_label=False, max_det=300, nm=0, max_nms=30000, max_wh=7680):
+                        multi_label=False, max_det=300, nm=0, max_nms=30000, max_wh=7680, labels=()):
     """utils/general.py:658-767 restated on numpy float32 (the reference's arithmetic dtype for fp32 input).
 
     prediction (bs, n, 5+nc+nm) -> list of (k, 6+nm) float32 arrays [x1,y1,x2,y2,conf,cls,(mask..)].
@@ -327,6 +327,13 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     for xi in range(bs):
         x = pred[xi]
         x = x[x[:, 4] > conf_t].copy()  # general.py:679,703
+        if len(labels) and len(labels[xi]):  # general.py:706-712: a-priori labels (autolabelling) join the candidates with confidence 1
+            lb = np.asarray(labels[xi], dtype=np.float32)
+            v = np.zeros((len(lb), nc + nm + 5), dtype=np.float32)
+            v[:, :4] = lb[:, 1:5]
+            v[:, 4] = 1.0
+            v[np.arange(len(lb)), lb[:, 0].astype(np.int64) + 5] = 1.0
+            x = np.concatenate((x, v), 0)
         if not x.shape[0]:
             continue
         x[:, 5:] *= x[:, 4:5]  # general.py:719  (note: also scales the mask columns, as the reference does)
@@ -556,10 +563,12 @@ def bbox_ciou(box1, box2, eps=1e-7):
     return iou - (rho2 / c2 + v * alpha)
 
 
-def compute_loss(p, targets, anchors, hyp=None, nc=80, balance=(4.0, 1.0, 0.4)):
-    """utils/loss.py:134-183 (gr=1, autobalance off, sort_obj_iou off; hyp['fl_gamma'] > 0: focal loss).
+def compute_loss(p, targets, anchors, hyp=None, nc=80, balance=(4.0, 1.0, 0.4), autobalance_ssi=None):
+    """utils/loss.py:134-183 (gr=1, sort_obj_iou off; hyp['fl_gamma'] > 0: focal loss).
 
-    p: list of (bs,na,ny,nx,no) tensors (may require grad); returns (loss[1], loss_items[3])."""
+    p: list of (bs,na,ny,nx,no) tensors (may require grad); returns (loss[1], loss_items[3]).
+    autobalance_ssi = index of the stride-16 level (loss.py:127): `balance` must then be a LIST and is updated in place as
+    loss.py:173-177 does (EMA of 1/obji per level in Python doubles, then normalised by the stride-16 entry)."""
     hyp = hyp or HYP_SCRATCH_LOW
     cp, cn = 1.0 - 0.5 * hyp.get("label_smoothing", 0.0), 0.5 * hyp.get("label_smoothing", 0.0)
     lcls, lbox, lobj = torch.zeros(1), torch.zeros(1), torch.zeros(1)
@@ -599,6 +608,10 @@ def compute_loss(p, targets, anchors, hyp=None, nc=80, balance=(4.0, 1.0, 0.4)):
                 lcls = lcls + bce(pcls, t, pw_cls)
         obji = bce(pi[..., 4], tobj, pw_obj)
         lobj = lobj + obji * balance[i]
+        if autobalance_ssi is not None:
+            balance[i] = balance[i] * 0.9999 + 0.0001 / obji.detach().item()  # loss.py:174
+    if autobalance_ssi is not None:
+        balance[:] = [x / balance[autobalance_ssi] for x in balance]  # loss.py:177
     lbox = lbox * hyp["box"]
     lobj = lobj * hyp["obj"]
     lcls = lcls * hyp["cls"]

@@ -142,6 +142,35 @@ def test_loss_targets_out_of_range():
         loss_fn(p, bad)
 
 
+def test_autobalance_follows_oracle():
+    """ComputeLoss(model, autobalance=True) (utils/loss.py:127, :173-177): the kernels hand each level's objectness loss back through the workspace
+    (y5_loss_obji_offset) and the balance list drifts as in the oracle (pinned to the live reference in tests/test_oracle_vs_reference.py); loss AND
+    gradient of every call use the factors the call started with."""
+    m = _model().train()
+    loss_fn = ComputeLoss(m, autobalance=True)
+    assert loss_fn.ssi == 1
+    anchors = yo.model_anchors(yo.model_cfg("yolov5n"))
+    bal = [4.0, 1.0, 0.4]
+    for step in range(3):
+        pn = [detgen.uniform((2, 3, s, s, 85), -3.0, 3.0, name=f"ab{s}", seed=40 + step) for s in (16, 8, 4)]
+        t = torch.from_numpy(detgen.synth_targets(2, 6, seed=40 + step))
+        p = [torch.from_numpy(a).clone().requires_grad_(True) for a in pn]
+        q = [torch.from_numpy(a).clone().requires_grad_(True) for a in pn]
+        loss, items = loss_fn(p, t)
+        loss.backward()
+        lo, io = yo.compute_loss(q, t, anchors, nc=80, balance=bal, autobalance_ssi=1)
+        lo.backward()
+        np.testing.assert_allclose(loss.detach().numpy(), lo.detach().numpy(), rtol=2e-6)
+        np.testing.assert_allclose(items.numpy(), io.numpy(), rtol=2e-6)
+        np.testing.assert_allclose(loss_fn.balance, bal, rtol=1e-9)   # obji differs from torch's mean in the last fp32 bit at most: 1e-4 of that in the EMA
+        for a, b in zip(p, q):
+            np.testing.assert_allclose(a.grad.numpy(), b.grad.numpy(), rtol=2e-4, atol=2e-9)
+    assert loss_fn.balance[1] == 1.0 and loss_fn.balance[0] != 4.0
+    with pytest.raises(ValueError):                       # loss.py:127: list(m.stride).index(16) on a head without a stride-16 level
+        m.model[-1].stride = torch.tensor([8.0, 32.0, 64.0])
+        ComputeLoss(m, autobalance=True)
+
+
 def test_forward_and_nms_under_inference_mode():
     """detect.py / val.py run under `smart_inference_mode` (utils/torch_utils.py:34-43 -> torch.inference_mode).  Inference tensors
     have no version counter; the engine's outputs therefore stay ordinary tensors (the objectness-hint tag keeps working), and NMS of a genuine
@@ -169,3 +198,22 @@ def test_forward_and_nms_under_inference_mode():
         assert torch.equal(a, b) and torch.equal(a, c)
     for a, b in zip(d3, d4):
         assert torch.equal(a, b)
+
+
+def test_nms_apriori_labels_equal_oracle():
+    """utils/general.py:706-712 `labels` (autolabelling, val.py --save-hybrid) through yolov5_amd.non_max_suppression: label rows appended as extra prediction
+    rows; same detections, bit for bit, as the oracle (which is pinned to the live reference for this branch in tests/test_oracle_vs_reference.py),
+    for fp32 and fp16 predictions (fp16: the reference's torch.cat promotes to fp32 -- so does this path)."""
+    from yolov5_amd.general import non_max_suppression
+
+    pred = detgen.synth_predictions(3, 800, 15, obj_pow=3, seed=43)
+    labels = [np.array([[2, 100.0, 120.0, 40.0, 60.0], [7, 300.5, 310.25, 80.0, 20.0]], np.float32), np.zeros((0, 5), np.float32),
+              np.array([[0, 50.0, 60.0, 30.0, 30.0]], np.float32)]
+    for dt in (torch.float32, torch.float16):
+        p = torch.from_numpy(pred).to(dt)
+        for ml in (False, True):
+            exp = yo.non_max_suppression(p.float().numpy(), 0.25, 0.45, labels=labels, multi_label=ml, max_det=300)
+            got = non_max_suppression(p, 0.25, 0.45, labels=[torch.from_numpy(lb) for lb in labels], multi_label=ml, max_det=300)
+            for g, e in zip(got, exp):
+                assert np.array_equal(g.numpy(), e)
+    assert float(got[0][0, 4]) == 1.0

@@ -128,3 +128,32 @@ def test_loss_focal_vs_reference_golden(dev):
         nz = F_[f"grad{i}_nzidx"]
         np.testing.assert_allclose(g[tuple(nz.T)], F_[f"grad{i}_nzrows"], rtol=1e-3, atol=1e-8)
         np.testing.assert_allclose(g[0, 0, :4, :8, 4], F_[f"grad{i}_obj_head"], rtol=1e-3, atol=1e-9)
+
+
+def test_loss_autobalance_vs_oracle(dev):
+    """ComputeLoss(model, autobalance=True) on the GPU (utils/loss.py:127, :173-177): three calls, losses and the drifting balance list against the
+    oracle (pinned to the live reference in tests/test_oracle_vs_reference.py::test_autobalance_matches_live_reference)."""
+    from oracle import detgen
+    from yolov5_amd.loss import ComputeLoss
+    from yolov5_amd.yolo import DetectionModel
+
+    m = DetectionModel("yolov5s.yaml").to(dev)
+    m.hyp = dict(yo.HYP_SCRATCH_LOW)
+    cl = ComputeLoss(m, autobalance=True)
+    assert cl.ssi == 1
+    anchors = yo.model_anchors(yo.model_cfg("yolov5s"))
+    bal = [4.0, 1.0, 0.4]
+    for step in range(3):
+        pn = [detgen.uniform((2, 3, s, s, 85), -3.0, 3.0, name=f"ab{s}", seed=40 + step) for s in (16, 8, 4)]
+        tn = detgen.synth_targets(2, 6, seed=40 + step)
+        p = [torch.from_numpy(a).to(dev).requires_grad_(True) for a in pn]
+        q = [torch.from_numpy(a).clone().requires_grad_(True) for a in pn]
+        loss, items = cl(p, torch.from_numpy(tn).to(dev))
+        loss.backward()
+        lo, io = yo.compute_loss(q, torch.from_numpy(tn), anchors, nc=80, balance=bal, autobalance_ssi=1)
+        lo.backward()
+        np.testing.assert_allclose(loss.item(), lo.item(), rtol=1e-5)
+        np.testing.assert_allclose(items.cpu().numpy(), io.numpy(), rtol=1e-5)
+        np.testing.assert_allclose(cl.balance, bal, rtol=1e-8)
+        for a, b in zip(p, q):
+            np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-3, atol=1e-8)

@@ -47,6 +47,31 @@ def test_build_targets_and_loss_match_live_reference(ns):
         np.testing.assert_allclose(b.grad.numpy(), a.grad.numpy(), rtol=1e-5, atol=1e-10)
 
 
+def test_autobalance_matches_live_reference(ns):
+    """ComputeLoss(autobalance=True) (utils/loss.py:127, :173-177): four calls of the live reference against the oracle's restatement -- losses and
+    the drifting balance list (Python doubles) step by step."""
+    import os
+
+    import yaml
+
+    m = ns.yolo.DetectionModel(os.path.join(ns.root, "models/yolov5s.yaml"), ch=3, nc=80)
+    with open(os.path.join(ns.root, "data/hyps/hyp.scratch-low.yaml")) as f:
+        m.hyp = yaml.safe_load(f)
+    cl = ns.loss.ComputeLoss(m, autobalance=True)
+    assert cl.ssi == 1
+    anchors = m.model[-1].anchors.clone()
+    bal = [4.0, 1.0, 0.4]
+    for step in range(4):
+        p = [torch.from_numpy(detgen.uniform((2, 3, s, s, 85), -3.0, 3.0, name=f"ab{s}", seed=40 + step)) for s in (16, 8, 4)]
+        t = torch.from_numpy(detgen.synth_targets(2, 6, seed=40 + step))
+        loss_r, items_r = cl(p, t)
+        loss_o, items_o = yo.compute_loss(p, t, anchors, nc=80, balance=bal, autobalance_ssi=1)
+        torch.testing.assert_close(loss_o, loss_r, rtol=1e-6, atol=0)
+        torch.testing.assert_close(items_o, items_r, rtol=1e-6, atol=0)
+        assert bal == cl.balance, (step, bal, cl.balance)
+    assert bal[1] == 1.0 and bal[0] != 4.0
+
+
 def test_nms_matches_live_reference(ns):
     pred = detgen.synth_predictions(2, 1500, 85, obj_pow=3, seed=41)
     with ref_shim.oracle_nms_mode():
@@ -54,6 +79,21 @@ def test_nms_matches_live_reference(ns):
     out = yo.non_max_suppression(pred, 0.25, 0.45, max_det=300)
     for r, o in zip(ref, out):
         assert np.array_equal(r.numpy(), o)
+
+
+def test_nms_with_apriori_labels_matches_live_reference(ns):
+    """general.py:706-712 (`labels`, val.py --save-hybrid): the a-priori label rows join the candidates with confidence 1; one image without labels,
+    multi_label on and off."""
+    pred = detgen.synth_predictions(3, 800, 15, obj_pow=3, seed=43)
+    labels = [np.array([[2, 100.0, 120.0, 40.0, 60.0], [7, 300.5, 310.25, 80.0, 20.0]], np.float32), np.zeros((0, 5), np.float32),
+              np.array([[0, 50.0, 60.0, 30.0, 30.0]], np.float32)]
+    for ml in (False, True):
+        with ref_shim.oracle_nms_mode():
+            ref = ns.general.non_max_suppression(torch.from_numpy(pred), 0.25, 0.45, labels=[torch.from_numpy(lb) for lb in labels], multi_label=ml, max_det=300)
+        out = yo.non_max_suppression(pred, 0.25, 0.45, labels=labels, multi_label=ml, max_det=300)
+        for r, o in zip(ref, out):
+            assert np.array_equal(r.numpy(), o)
+        assert (out[0][:2, 4] == 1.0).all() and {int(c) for c in out[0][:2, 5]} == {2, 7}
 
 
 def test_process_batch_and_ap_match_live_reference(ns):

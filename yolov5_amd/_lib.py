@@ -122,6 +122,7 @@ EXPORTS = {
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "y5_channel_sum": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "y5_loss_workspace_bytes": (C.c_size_t, [C.POINTER(LossDesc), C.c_int]),
+    "y5_loss_obji_offset": (C.c_longlong, [C.POINTER(LossDesc), C.c_int]),
     "y5_loss_forward": (C.c_int, [C.POINTER(LossDesc), C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_size_t, C.c_void_p]),
     "y5_loss_backward": (C.c_int, [C.POINTER(LossDesc), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.POINTER(C.c_void_p),

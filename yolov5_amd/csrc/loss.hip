@@ -9,7 +9,7 @@
 namespace {
 
 struct LevelOff { size_t rb, ra, rgj, rgi, rcls, next, tbox, anch, iou, rl_box, rl_cls, G, head, obj_part; };
-struct Layout { size_t n_rows; LevelOff lv[Y5_LOSS_MAX_NL]; long long cap, cells[Y5_LOSS_MAX_NL]; size_t head_begin, head_end, total; };
+struct Layout { size_t n_rows, obji; LevelOff lv[Y5_LOSS_MAX_NL]; long long cap, cells[Y5_LOSS_MAX_NL]; size_t head_begin, head_end, total; };
 
 size_t take(size_t& o, size_t bytes) { const size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; }
 
@@ -33,6 +33,7 @@ Layout layout(const y5_loss_desc* d, int nt) {
   L.cap = cap;
   size_t o = 0;
   L.n_rows = take(o, sizeof(int) * Y5_LOSS_MAX_NL);
+  L.obji = take(o, sizeof(float) * Y5_LOSS_MAX_NL);
   for (int i = 0; i < d->nl; ++i) {
     LevelOff& v = L.lv[i];
     v.rb = take(o, capz * 4); v.ra = take(o, capz * 4); v.rgj = take(o, capz * 4); v.rgi = take(o, capz * 4);
@@ -55,6 +56,7 @@ void fill(Y5LossParams& P, const y5_loss_desc* d, const Layout& L, char* ws, int
   P.hyp_box = d->hyp_box; P.hyp_obj = d->hyp_obj; P.hyp_cls = d->hyp_cls; P.cls_pw = d->cls_pw; P.obj_pw = d->obj_pw; P.fl_gamma = d->fl_gamma;
   P.anchor_t = d->anchor_t; P.cp = d->cp; P.cn = d->cn;
   P.n_rows = reinterpret_cast<int*>(ws + L.n_rows);
+  P.obji = reinterpret_cast<float*>(ws + L.obji);
   for (int i = 0; i < d->nl; ++i) {
     Y5LossLevel& v = P.lv[i];
     const LevelOff& f = L.lv[i];
@@ -74,6 +76,11 @@ void fill(Y5LossParams& P, const y5_loss_desc* d, const Layout& L, char* ws, int
 extern "C" size_t y5_loss_workspace_bytes(const y5_loss_desc* d, int nt) {
   if (validate(d, nt)) return 0;
   return layout(d, nt).total;
+}
+
+extern "C" long long y5_loss_obji_offset(const y5_loss_desc* d, int nt) {
+  if (validate(d, nt)) return -1;
+  return (long long)layout(d, nt).obji;
 }
 
 extern "C" int y5_loss_targets_layout(const y5_loss_desc* d, int nt, int level, size_t offs[10], long long* cap) {

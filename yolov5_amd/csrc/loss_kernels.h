@@ -47,6 +47,7 @@ struct Y5LossParams {
   const float* targets;  // (nt, 6): img, cls, x, y, w, h (normalised)
   int* n_rows;           // [nl]
   float* out;            // [4]: loss, lbox, lobj, lcls
+  float* obji;           // [nl] (workspace): each level's mean objectness BCE BEFORE its balance factor (loss.py:171) -- what autobalance reads (loss.py:173-177)
   const float* gscale;   // device scalar multiplied into the gradient (may be null = 1)
   int nl, na, nc, no, bs, nt;
   float hyp_box, hyp_obj, hyp_cls, cls_pw, obj_pw, anchor_t, cp, cn;
@@ -325,6 +326,7 @@ void y5_loss_finish_kernel(const Y5LossParams p) {
     const long long nblk = (L.cells + 255) / 256;
     const float obji = (float)(y5_block_sum_f(L.obj_part, nblk, s_red) / (double)L.cells);   // loss.py:171
     lobj += obji * L.balance;                                                                // loss.py:172
+    if (threadIdx.x == 0) p.obji[i] = obji;
   }
   if (threadIdx.x == 0) {
     lbox *= p.hyp_box; lobj *= p.hyp_obj; lcls *= p.hyp_cls;                                 // loss.py:178-180

@@ -105,12 +105,25 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     assert 0 <= iou_thres <= 1, f"Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0"
     if isinstance(prediction, (list, tuple)):  # model in validation mode: (inference_out, loss_out)
         prediction = prediction[0]
-    if labels:
-        raise NotImplementedError("autolabelling `labels` (general.py:706-712) is not part of the hot path")
     if not _lib.accepts(prediction):
         raise RuntimeError("yolov5_amd.non_max_suppression needs a GPU tensor (no CPU path)")
     if prediction.dtype not in (torch.float16, torch.float32):
         prediction = prediction.float()
+    if labels and any(len(lb) for lb in labels):
+        # general.py:706-712 (val.py --save-hybrid autolabelling): every image's a-priori labels [cls, x, y, w, h] (pixels) join ITS candidates as
+        # rows with objectness 1 and a one-hot class.  Here they are appended as extra prediction rows behind the model's (image slots without a
+        # label keep objectness 0 and never become candidates): same candidate order as the reference's torch.cat((x, v), 0), so the same tie
+        # rule.  fp32 like the reference's concatenation of a half tensor with the float label rows.
+        bs0, _, no0 = prediction.shape
+        lmax = max(len(lb) for lb in labels)
+        extra = torch.zeros((bs0, lmax, no0), dtype=torch.float32, device=prediction.device)
+        for xi, lb in enumerate(labels):
+            if len(lb):
+                lb = torch.as_tensor(lb, dtype=torch.float32, device=prediction.device)
+                extra[xi, :len(lb), :4] = lb[:, 1:5]
+                extra[xi, :len(lb), 4] = 1.0
+                extra[xi, torch.arange(len(lb), device=prediction.device), lb[:, 0].long() + 5] = 1.0
+        prediction = torch.cat((prediction.float(), extra), 1)
     prediction = prediction.contiguous()
     # objectness plane the engine wrote beside this very tensor (engine.Engine._tag_hint): used only while `prediction` is still the object the
     # engine's LATEST forward returned, unmodified -- any copy, cast, slice, in-place edit or later forward drops it and the filter reads the rows themselves

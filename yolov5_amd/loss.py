@@ -5,8 +5,9 @@ behind `y5_loss_forward` / `y5_loss_backward` (include/yolov5_hip.h).
     loss, loss_items = compute_loss(p, targets)       # p: list of (bs, na, ny, nx, no) GPU tensors, targets (nt, 6)
     loss.backward()                                   # d loss / d p[i] from one fused kernel per level
 
-No host synchronisation happens in either direction (the reference syncs on `if n := b.shape[0]`, loss.py:146).
-Unsupported options raise: focal loss (`fl_gamma > 0`, loss.py:120-122), `autobalance`, `sort_obj_iou`, `gr != 1`.
+No host synchronisation happens in either direction (the reference syncs on `if n := b.shape[0]`, loss.py:146), except with
+`autobalance=True`, whose update rule (loss.py:173-177) is host arithmetic on each level's objectness loss: one read of nl floats per call.
+Unsupported options raise: `sort_obj_iou`, `gr != 1`.
 """
 from __future__ import annotations
 
@@ -80,13 +81,11 @@ class ComputeLoss:
     check_targets = False
 
     def __init__(self, model, autobalance=False):
-        if autobalance:
-            raise NotImplementedError("ComputeLoss(autobalance=True) (loss.py:173-177) needs a per-step host read-back; not supported")
         h = model.hyp
         self.cp, self.cn = smooth_bce(eps=h.get("label_smoothing", 0.0))
         m = de_parallel(model).model[-1]  # Detect()
         self.balance = {3: [4.0, 1.0, 0.4]}.get(m.nl, [4.0, 1.0, 0.25, 0.06, 0.02])
-        self.ssi = 0
+        self.ssi = [float(v) for v in m.stride].index(16.0) if autobalance else 0  # loss.py:127 (ValueError without a stride-16 level, as there)
         self.gr, self.hyp, self.autobalance = 1.0, h, autobalance
         self.na, self.nc, self.nl = m.na, m.nc, m.nl
         self.anchors = m.anchors
@@ -138,7 +137,23 @@ class ComputeLoss:
                 raise IndexError(f"ComputeLoss: target image index {int(hi[0] if hi[0] >= p[0].shape[0] else lo[0])} is out of bounds for batch size {p[0].shape[0]}")
             if lo[1] < 0 or hi[1] >= self.nc:
                 raise IndexError(f"ComputeLoss: target class {int(hi[1] if hi[1] >= self.nc else lo[1])} is out of bounds for nc={self.nc}")
-        return _LossFn.apply(self, targets, *p)
+        out = _LossFn.apply(self, targets, *p)
+        if self.autobalance:
+            self._autobalance(len(p))
+        return out
+
+    def _autobalance(self, nl):
+        """loss.py:173-177: balance[i] <- 0.9999 balance[i] + 0.0001 / obji (Python doubles on the fp32 obji), then / balance[ssi].  The
+        forward that just ran (and its backward, which replays the descriptor captured there) used the OLD factors, like the reference's graph."""
+        d, nt, ws = self._last
+        off = _lib.lib().y5_loss_obji_offset(C.byref(d), nt)
+        if off < 0:
+            _lib.check(-1, _lib.lib())
+        obji = ws[off:off + 4 * nl].view(torch.float32).tolist()  # the one device->host read of this option
+        self.last_obji = obji
+        for i in range(nl):
+            self.balance[i] = self.balance[i] * 0.9999 + 0.0001 / obji[i]
+        self.balance = [x / self.balance[self.ssi] for x in self.balance]
 
     def build_targets(self, p, targets):
         """utils/loss.py:185-247 -> (tcls, tbox, indices, anch) in the reference's format (int64 indices).
