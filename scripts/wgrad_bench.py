@@ -23,15 +23,86 @@ LAYERS = [
 ]
 
 
+def k3_ab(a, dev, lib, st):
+    tot = {1: 0.0, 3: 0.0}  # per family
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for H, C1, C2, k, s, cnt in LAYERS:
+        if cnt == 0 or k != 3:
+            continue
+        if a.only and (str(H) not in a.only.split(",") or s != 1):
+            continue
+        B, OH = a.batch, (H + 2 - 3) // s + 1
+        K = 9 * C1
+        Kpad, Npad = round_up(K, 64), round_up(C2, 32)
+        per = (B * H * H * C1 + B * OH * OH * C2) * 2
+        nrot = max(2, -(-600_000_000 // per))
+        xs = [torch.randn((B, H, H, C1), device=dev).half() for _ in range(nrot)]
+        dzs = [torch.randn((B, OH, OH, C2), device=dev).half() for _ in range(nrot)]
+        dw = torch.zeros((Npad, Kpad), device=dev)
+        line = f"H={H:3d} {C1:4d}->{C2:4d} k3 s{s} x{cnt}: floor {per / 5.8e12 * 1e6:6.1f} us (HBM) "
+        outs = {}
+        cfgs = [int(v) for v in a.cfgs.split(",")]
+        for cfg in cfgs:
+            if cfg == 1:
+                tiles = -(-C2 // (128 if C2 >= 128 else 64)) * -(-K // (128 if K >= 128 else 64))
+                fs = (1.5, 2, 3, 4, 6)
+            else:
+                nt, ct = (4 if C2 > 64 else 2 if C2 > 32 else 1), (2 if C1 > 32 else 1)
+                tiles = -(-C2 // (32 * nt)) * -(-C1 // (32 * ct))
+                fs = (0.75, 1, 1.5, 2, 3, 4)
+            best = (float("inf"), 0)
+            for f in fs:
+                mb = max(1, int(f * 256 + tiles - 1) // tiles)
+                d = _lib.ConvDesc(dtype=_lib.Y5_F16, B=B, H=H, W=H, C1=C1, ldx=C1, OH=OH, OW=OH, C2=C2, ldy=C2, KH=3, KW=3, SH=s, SW=s, PH=1, PW=1,
+                                  act=0, Kpad=Kpad, Npad=Npad, cfg=cfg, max_blocks=mb)
+                dw.zero_()
+                if a.det:
+                    need = lib.y5_conv2d_wgrad_ws_bytes(C.byref(d), C2)
+                    ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+
+                    def call(i):
+                        return lib.y5_conv2d_wgrad_det(C.byref(d), C.c_void_p(xs[i].data_ptr()), C.c_void_p(dzs[i].data_ptr()), C2, C.c_void_p(dw.data_ptr()),
+                                                       C.c_void_p(ws.data_ptr()), need, st)
+                else:
+                    def call(i):
+                        return lib.y5_conv2d_wgrad(C.byref(d), C.c_void_p(xs[i].data_ptr()), C.c_void_p(dzs[i].data_ptr()), C2, C.c_void_p(dw.data_ptr()), st)
+                _lib.check(call(0), lib)
+                if f == fs[0]:
+                    outs[cfg] = dw.clone()
+                n = max(a.iters, nrot)
+                e0.record()
+                for i in range(n):
+                    call(i % nrot)
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) / n * 1e3
+                best = min(best, (us, mb))
+            tot[cfg] += best[0] * cnt
+            line += f" | cfg{cfg}: {best[0]:7.1f} us (splits {best[1]:4d})"
+        if len(cfgs) == 2:
+            err = (outs[1] - outs[3]).abs().max().item() / max(outs[1].abs().max().item(), 1e-9)
+            line += f" | rel diff {err:.1e}"
+        print(line, flush=True)
+        del xs, dzs
+    print(f"TOTAL 3x3 layers: general {tot[1] / 1e3:.3f} ms, patch-staged {tot[3] / 1e3:.3f} ms per step")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--k3-ab", action="store_true", help="3x3 layers only: general gather kernel (cfg 1) against the patch-staged family (cfg 3, csrc/wgrad3.h), "
+                    "each at its best split count, on ROTATING buffers (> 600 MB per layer: no Infinity-Cache residency between launches)")
+    ap.add_argument("--det", action="store_true", help="--k3-ab: time y5_conv2d_wgrad_det (per-split slabs + ordered reduction) instead of the atomic form")
+    ap.add_argument("--only", default="", help="--k3-ab: comma list of input sizes H to keep (stride-1 layers only when given)")
+    ap.add_argument("--cfgs", default="1,3", help="--k3-ab: kernel families to time")
     ap.add_argument("--split-factors", default="", help="comma list f: also time the pixel-range split count f * CUs / tiles (default of the library: 4)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.lib()
     st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    if a.k3_ab:
+        return k3_ab(a, dev, lib, st)
     tot_ms, tot_fl = 0.0, 0.0
     for H, C1, C2, k, s, cnt in LAYERS:
         if cnt == 0:

@@ -151,6 +151,28 @@ inline emu_uint2 __builtin_amdgcn_permlane32_swap(unsigned vdst, unsigned vsrc, 
   return r;
 }
 
+// ds_read_b64_tr_b16 (gfx950 LDS transpose read): within a 16-lane group, lane i receives element i % 4 of the 8 bytes addressed by lanes
+// 4 j + i / 4, j = 0..3 (pinned on the hardware by scripts/ubench/tr_probe.hip, profiles/r02/r02_ubench_tr_probe.log)
+typedef short emu_s4 __attribute__((__vector_size__(4 * sizeof(short))));
+inline emu_s4 emu_ds_read_tr16_b64(const void* addr) {
+  struct P { const void* a; } pl{addr};
+  const void* o[64];
+  emu::wave_exchange(&pl, sizeof(P), o);
+  const int l = emu::lane_id(), i = l & 15;
+  emu_s4 r = {0, 0, 0, 0};
+  for (int j = 0; j < 4; ++j) {
+    const int src = (l & ~15) + 4 * j + (i >> 2);
+    if (o[src]) {
+      short v[4];
+      memcpy(v, ((const P*)o[src])->a, 8);
+      r[j] = v[i & 3];
+    }
+  }
+  return r;
+}
+
+#define __builtin_amdgcn_ds_read_tr16_b64_v4i16(l) emu_ds_read_tr16_b64((const void*)(uintptr_t)(l))
+
 typedef _Float16 emu_half8 __attribute__((ext_vector_type(8)));
 typedef float emu_float16 __attribute__((ext_vector_type(16)));
 // D = A(32x16) * B(16x32) + C ; lane l holds A[i=l&31][k=8*(l>>5)+e], B[k=8*(l>>5)+e][j=l&31];

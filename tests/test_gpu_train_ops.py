@@ -86,6 +86,55 @@ WG = [
 ]
 
 
+# the patch-staged 3x3 family (csrc/wgrad3.h: transpose reads, swizzled tiles, de-interleaved stride-2 patches) on the hardware: (case, cfg, splits, det)
+WG3 = [
+    ((8, 40, 40, 64, 64, (3, 3), (1, 1), (1, 1)), 3, 0, False),       # 64 x 64 tile (NT 2, CT 2), three segments per row (40 = 16 + 16 + 8)
+    ((4, 80, 80, 32, 64, (3, 3), (2, 2), (1, 1)), 3, 37, False),      # stride 2 (33-pixel patch rows, even / odd halves), odd split count
+    ((4, 20, 20, 128, 256, (3, 3), (2, 2), (1, 1)), 3, 0, True),      # 128 x 64 tiles x 2 x 2, OW = 10 < 16, deterministic form
+    ((2, 36, 52, 128, 136, (3, 3), (1, 1), (1, 1)), 341, 5, True),    # capped tile (NT 4, CT 1), n tail, non-square
+    ((2, 33, 47, 40, 72, (3, 3), (2, 2), (1, 1)), 3, 3, False),       # odd sizes, c tail (40 of 64), n tail (72 of 128)
+    ((16, 160, 160, 32, 32, (3, 3), (1, 1), (1, 1)), -1, 0, False),   # automatic choice at a P2 shape of the benchmark (many pixels per filter element)
+]
+
+
+@pytest.mark.parametrize("case,cfg,splits,det", WG3)
+def test_conv_wgrad_patch_staged(case, cfg, splits, det, dev):
+    from yolov5_amd import _lib
+    from yolov5_amd.packing import round_up
+
+    B, H, W, C1, C2, k, s, p = case
+    lib = _lib.lib()
+    OH, OW = (H + 2 - 3) // s[0] + 1, (W + 2 - 3) // s[1] + 1
+    x = torch.from_numpy(detgen.uniform((B, C1, H, W), -1, 1, name="g3x")).half()
+    dz = torch.from_numpy(detgen.uniform((B, C2, OH, OW), -1, 1, name="g3dz")).half() * 0.1
+    ldx, ldz = C1 + 8, C2 + 8
+    xd = torch.full((B, H, W, ldx), 5.0, dtype=torch.float16, device=dev); xd[..., :C1] = x.permute(0, 2, 3, 1).to(dev)
+    dzd = torch.full((B, OH, OW, ldz), 5.0, dtype=torch.float16, device=dev); dzd[..., :C2] = dz.permute(0, 2, 3, 1).to(dev)
+    K = 9 * C1
+    Kpad, Npad = round_up(K, 64), round_up(C2, 32)
+    d = _lib.ConvDesc(dtype=_lib.Y5_F16, B=B, H=H, W=W, C1=C1, ldx=ldx, OH=OH, OW=OW, C2=C2, ldy=ldz, KH=3, KW=3, SH=s[0], SW=s[1],
+                      PH=1, PW=1, act=0, Kpad=Kpad, Npad=Npad, cfg=cfg, max_blocks=splits)
+    outs = []
+    for _ in range(2 if det else 1):
+        dw = torch.zeros((Npad, Kpad), dtype=torch.float32, device=dev)
+        if det:
+            need = lib.y5_conv2d_wgrad_ws_bytes(C.byref(d), ldz)
+            ws = torch.full((need // 4,), float("nan"), dtype=torch.float32, device=dev)   # every slab element that is read must have been written
+            _lib.check(lib.y5_conv2d_wgrad_det(C.byref(d), _p(xd), _p(dzd), ldz, _p(dw), _p(ws), need, _st(dev)), lib)
+        else:
+            _lib.check(lib.y5_conv2d_wgrad(C.byref(d), _p(xd), _p(dzd), ldz, _p(dw), _st(dev)), lib)
+        torch.cuda.synchronize()
+        outs.append(dw)
+    if det:
+        assert torch.equal(outs[0], outs[1])
+    w = torch.zeros((C2, C1, 3, 3), requires_grad=True)
+    F.conv2d(x.float(), w, None, s, 1).backward(dz.float())
+    ref = w.grad.permute(0, 2, 3, 1).reshape(C2, K)
+    scale = float(ref.abs().max())
+    torch.testing.assert_close(outs[0][:C2, :K].cpu(), ref, rtol=2e-3, atol=2e-3 * scale)
+    assert torch.all(outs[0][C2:] == 0) and torch.all(outs[0][:, K:] == 0)
+
+
 @pytest.mark.parametrize("case", WG)
 def test_conv_wgrad(case, dev):
     from yolov5_amd import _lib

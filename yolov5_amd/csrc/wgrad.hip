@@ -12,6 +12,7 @@
 // row advance incrementally (no integer division in the loop).
 #include <hip/hip_runtime.h>
 
+
 #include "../../include/yolov5_hip.h"
 #include "y5_common.h"
 #include "y5_host.h"
@@ -220,6 +221,8 @@ __global__ void y5_wgrad_reduce_kernel(const float* __restrict__ ws, float* __re
   dw[(size_t)n * Kpad + k] += s;
 }
 
+#include "wgrad3.h"
+
 // fp32 weight gradient (TrainEngine's reference-precision mode): one thread per packed filter element, a plain fp32 sum over all output
 // pixels in a fixed order -- deterministic, exact fp32; not a hot path
 __global__ void y5_conv_wgrad_f32_kernel(const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ dw, int B, int H, int W, int C1,
@@ -241,6 +244,19 @@ __global__ void y5_conv_wgrad_f32_kernel(const float* __restrict__ x, const floa
       }
     }
   dw[(size_t)n * Kpad + k] += s;
+}
+
+template <int NT, int CT, int STR, int S, bool DET>
+static void launch_wgrad3(const Y5WgradParams& p, unsigned grid, hipStream_t st) {
+  constexpr int XI = ((2 * 3 * (15 * STR + 3)) * 64 * CT + 1023) / 1024;
+  constexpr size_t bytes = (size_t)S * (32 * 64 * NT + XI * 1024);
+  auto kern = y5_conv_wgrad3_kernel<NT, CT, STR, S, DET>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (bytes > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(576), bytes, st, p);
 }
 
 static int wgrad_impl(const y5_conv_desc* d, const void* x, const void* dz, int ld_dz, float* dw_packed, float* ws, size_t ws_bytes, size_t* need, void* stream_) {
@@ -271,15 +287,66 @@ static int wgrad_impl(const y5_conv_desc* d, const void* x, const void* dz, int 
   p.K = d->KH * d->KW * d->C1; p.Kpad = d->Kpad; p.Npad = d->Npad;
   if (p.Kpad < p.K || p.Npad < p.C2) return y5_fail(Y5_ERR_BAD_ARG, "wgrad: bad packed filter dims");
   p.M = d->B * oh * ow;
-  const int tnb = d->C2 >= 128 ? 2 : 1, tkb = p.K >= 128 ? 2 : 1;
-  p.tiles_n = (d->C2 + 64 * tnb - 1) / (64 * tnb);
-  p.tiles_k = (p.K + 64 * tkb - 1) / (64 * tkb);
   int ncu = 256;
   {
     int dev = 0, n = 0;
     hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ncu = n;
   }
+  const bool det = ws != nullptr;
+  // d->cfg selects the kernel family: -1 / 0 = automatic (by pixels per filter element), 1 = the general im2col-gather kernel, 3 / 3xy = the patch-staged 3x3
+  // kernel (wgrad3.h).  Which one is faster depends on pixels per filter element (measured, profiles/r03/r03_wgrad3_ab.log): TrainEngine times both.
+  const bool can3 = d->KH == 3 && d->KW == 3 && d->PH == 1 && d->PW == 1 && d->SH == d->SW && (d->SH == 1 || d->SH == 2) && d->C2 * 9LL * d->C1 > 0;
+  if (d->cfg >= 3 && !can3) return y5_fail(Y5_ERR_BAD_ARG, "wgrad: cfg 3 (patch-staged kernel) needs k3 p1 and stride 1 or 2");
+  const bool auto3 = d->cfg <= 0 && (long long)p.M >= 10LL * p.K * d->C2;   // many pixels per filter element: P1-P3 of the yolov5 graphs
+  if (can3 && (d->cfg >= 3 || auto3)) {
+    int nt = d->C2 > 64 ? 4 : d->C2 > 32 ? 2 : 1, ct = d->C1 > 32 ? 2 : 1;
+    if (d->cfg >= 300) {  // 300 + 10 NTcap + CTcap: the channel tile is capped (the tuner's alternative shapes, e.g. 341 = up to 128 x 32 per workgroup)
+      const int cn = (d->cfg - 300) / 10, cc = (d->cfg - 300) % 10;
+      if ((cn != 1 && cn != 2 && cn != 4) || (cc != 1 && cc != 2)) return y5_fail(Y5_ERR_BAD_ARG, "wgrad: cfg 3xy needs x in {1,2,4}, y in {1,2}");
+      nt = nt < cn ? nt : cn;
+      ct = ct < cc ? ct : cc;
+    }
+    p.tiles_n = (d->C2 + 32 * nt - 1) / (32 * nt);
+    p.tiles_k = (d->C1 + 32 * ct - 1) / (32 * ct);
+    const int tiles = p.tiles_n * p.tiles_k;
+    const long long segs = (long long)d->B * oh * ((ow + 15) / 16);
+    const long long chunks = (segs + 1) / 2;
+    long long splits = d->max_blocks > 0 ? d->max_blocks : (2 * ncu + tiles - 1) / tiles;
+    const long long max_splits = (chunks + 3) / 4;  // at least 4 chunks per split
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    const long long cps = (chunks + splits - 1) / splits;
+    p.pix_per_split = (int)(2 * cps);                // SEGMENTS per split
+    p.splits = (int)((chunks + cps - 1) / cps);
+    const long long grid = (long long)tiles * p.splits;
+    if (grid > 0x7fffffffLL) return y5_fail(Y5_ERR_UNSUPPORTED, "wgrad: grid too large");
+    const size_t ws_need = (size_t)p.splits * p.Npad * p.Kpad * sizeof(float);
+    if (need) { *need = ws_need; return Y5_OK; }
+    if (det && (ws_bytes < ws_need || ((uintptr_t)ws & 15))) return y5_fail(Y5_ERR_BAD_ARG, "wgrad: workspace too small (y5_conv2d_wgrad_ws_bytes) or misaligned");
+    p.ws = ws;
+    const int key = nt * 100 + ct * 10 + d->SH;
+#define Y5_WG3(NT_, CT_, ST_, S_)                                                                                      \
+  case NT_ * 100 + CT_ * 10 + ST_:                                                                                     \
+    if (det) launch_wgrad3<NT_, CT_, ST_, S_, true>(p, (unsigned)grid, st);                                            \
+    else launch_wgrad3<NT_, CT_, ST_, S_, false>(p, (unsigned)grid, st);                                               \
+    break;
+    switch (key) {
+      Y5_WG3(1, 1, 1, 4) Y5_WG3(1, 1, 2, 4) Y5_WG3(1, 2, 1, 4) Y5_WG3(1, 2, 2, 4)
+      Y5_WG3(2, 1, 1, 4) Y5_WG3(2, 1, 2, 4) Y5_WG3(2, 2, 1, 4) Y5_WG3(2, 2, 2, 3)
+      Y5_WG3(4, 1, 1, 4) Y5_WG3(4, 1, 2, 4) Y5_WG3(4, 2, 1, 4) Y5_WG3(4, 2, 2, 3)
+      default: return y5_fail(Y5_ERR_RUNTIME, "wgrad: no patch-staged instantiation");
+    }
+#undef Y5_WG3
+    if (det) {
+      const long long total = (long long)d->C2 * p.Kpad;
+      hipLaunchKernelGGL(y5_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws, dw_packed, d->C2, p.K, p.Npad, p.Kpad, p.splits);
+    }
+    return y5_check_launch("y5_conv2d_wgrad(k3)");
+  }
+  const int tnb = d->C2 >= 128 ? 2 : 1, tkb = p.K >= 128 ? 2 : 1;
+  p.tiles_n = (d->C2 + 64 * tnb - 1) / (64 * tnb);
+  p.tiles_k = (p.K + 64 * tkb - 1) / (64 * tkb);
   const int tiles = p.tiles_n * p.tiles_k;
   int splits = d->max_blocks > 0 ? d->max_blocks : (4 * ncu + tiles - 1) / tiles;
   const int max_splits = (p.M + 255) / 256;  // at least 8 chunks per split
@@ -291,7 +358,6 @@ static int wgrad_impl(const y5_conv_desc* d, const void* x, const void* dz, int 
   if (grid > 0x7fffffffLL) return y5_fail(Y5_ERR_UNSUPPORTED, "wgrad: grid too large");
   const size_t ws_need = (size_t)p.splits * p.Npad * p.Kpad * sizeof(float);
   if (need) { *need = ws_need; return Y5_OK; }
-  const bool det = ws != nullptr;
   if (det && (ws_bytes < ws_need || ((uintptr_t)ws & 15))) return y5_fail(Y5_ERR_BAD_ARG, "wgrad: workspace too small (y5_conv2d_wgrad_ws_bytes) or misaligned");
   p.ws = ws;
   // ring depth: as many 32-pixel chunks in flight as ~48 KiB of LDS per workgroup allows (3 workgroups per CU)

@@ -186,43 +186,72 @@ class TrainEngine:
             be.zero_(st["zb"])
         st["subs"] = subs
 
-    def _tune_wgrad_splits(self, d, x_ptr, dz_ptr, ld_dz, dw_ptr, dw_bytes, stm):
-        """Pixel-range split count of one weight-gradient launch (csrc/wgrad.hip: grid = filter tiles x splits, partial sums combined by
-        atomics), chosen like the forward tiles -- by timing on the real buffers, once per geometry (persisted with the tile choices).
-        The library default (4 workgroups per CU) suits the P1/P2 layers; at P4/P5, where a filter tile is 128 x 128 and the pixel range
-        short, half as many splits halve the atomic traffic (measured, scripts/wgrad_bench.py --split-factors: 60 -> 37 us for
-        512->256 @20^2, 3.40 -> 2.75 ms over the yolov5s layer set).  Returns max_blocks for the descriptor (0 = library default)."""
+    def _wgrad_launch(self, d, x_ptr, dz_ptr, ld_dz, dw_ptr, stm):
+        """One weight-gradient launch in the form this engine runs: atomics, or (deterministic) per-split slabs + ordered reduction."""
+        lib, be = self.lib, self.be
+        if self.deterministic and self.dt == _lib.Y5_F16:
+            need = int(lib.y5_conv2d_wgrad_ws_bytes(C.byref(d), ld_dz))
+            if need < 0:
+                _lib.check(-1, lib)
+            if self._wg_ws is None or self._wg_ws_bytes < need:
+                self._wg_ws_bytes = max(need, 1 << 20)
+                self._wg_ws = be.empty((self._wg_ws_bytes // 4 + 64,), torch.float32)
+            wsp = be.ptr(self._wg_ws)
+            wsp += (-wsp) % 16
+            return lib.y5_conv2d_wgrad_det(C.byref(d), _vp(x_ptr), _vp(dz_ptr), ld_dz, _vp(dw_ptr), _vp(wsp), need, stm)
+        return lib.y5_conv2d_wgrad(C.byref(d), _vp(x_ptr), _vp(dz_ptr), ld_dz, _vp(dw_ptr), stm)
+
+    def _tune_wgrad(self, d, x_ptr, dz_ptr, ld_dz, dw_ptr, dw_bytes, stm):
+        """(kernel family, pixel-range split count) of one weight-gradient launch (csrc/wgrad.hip, wgrad3.h: grid = filter tiles x splits), chosen
+        like the forward tiles -- by timing on the real buffers, in the form that will run (atomic / deterministic), once per geometry (persisted
+        with the tile choices).  Splits: the library default suits the P1/P2 layers; at P4/P5, where a filter tile is 128 x 128 and the pixel
+        range short, half as many splits halve the atomic traffic (scripts/wgrad_bench.py --split-factors: 60 -> 37 us for 512->256 @20^2).
+        Family (3x3 layers): the patch-staged kernel (cfg 3 / 341) against the general gather kernel (cfg 1) -- 250 -> 164 us for 0->1.Conv's
+        gradient, 209 -> 99 us for 2.C3.m.0.cv2, the general kernel keeps P4/P5 (profiles/r03/r03_wgrad3_ab.log).  Returns (cfg, max_blocks)."""
         mode = os.environ.get("Y5_WGRAD_SPLITS", "auto")  # auto | <n>: fixed split count for every layer (0 = library default)
+        fam = int(os.environ.get("Y5_WGRAD_CFG", "-2"))    # -2 = timed | -1 library heuristic | 1 | 3 | 3xy
+        k3 = d.KH == 3 and d.KW == 3 and d.PH == 1 and d.PW == 1 and d.SH == d.SW and d.SH in (1, 2)
+        if fam >= 3 and not k3:
+            fam = 1
         if mode != "auto":
-            return int(mode)
+            return (fam if fam != -2 else -1), int(mode)
         if not getattr(self.be, "autotune", False) or self.dt != _lib.Y5_F16:
-            return 0
+            return (fam if fam != -2 else -1), 0
         from .engine import _TUNE_CACHE, _load_tune_cache, _save_tune_cache
-        key = (-7001, d.B, d.H, d.W, d.C1, d.ldx, d.OH, d.OW, d.C2, ld_dz, d.KH, d.KW, d.SH, d.SW, d.Kpad, d.Npad)
+        key = (-7002, int(self.deterministic), fam, d.B, d.H, d.W, d.C1, d.ldx, d.OH, d.OW, d.C2, ld_dz, d.KH, d.KW, d.SH, d.SW, d.Kpad, d.Npad)
         _load_tune_cache()
         if key in _TUNE_CACHE:
-            return _TUNE_CACHE[key][0]
+            v = _TUNE_CACHE[key][0]
+            return (v >> 20) - 1, v & 0xFFFFF
         lib = self.lib
         K = d.KH * d.KW * d.C1
-        tiles = -(-d.C2 // (128 if d.C2 >= 128 else 64)) * -(-K // (128 if K >= 128 else 64))
         ncu = torch.cuda.get_device_properties(self.be.device).multi_processor_count
-        cands = sorted({max(1, (int(f * ncu) + tiles - 1) // tiles) for f in (1, 1.5, 2, 3, 4, 6)})
+        fams = []
+        if fam in (-2, -1, 1):
+            fams.append((1, -(-d.C2 // (128 if d.C2 >= 128 else 64)) * -(-K // (128 if K >= 128 else 64)), (1, 1.5, 2, 3, 4, 6)))
+        if k3 and (fam == -2 or fam >= 3):
+            for cfg in ((3, 341) if fam == -2 else (fam,)):
+                cn, cc = ((cfg - 300) // 10, (cfg - 300) % 10) if cfg >= 300 else (4, 2)
+                nt, ct = min(cn, 4 if d.C2 > 64 else 2 if d.C2 > 32 else 1), min(cc, 2 if d.C1 > 32 else 1)
+                if cfg >= 300 and (nt, ct) == (4 if d.C2 > 64 else 2 if d.C2 > 32 else 1, 2 if d.C1 > 32 else 1):
+                    continue   # the cap changes nothing for this layer
+                fams.append((cfg, -(-d.C2 // (32 * nt)) * -(-d.C1 // (32 * ct)), (0.75, 1, 1.5, 2, 3)))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        best, best_ms = 0, float("inf")
-        args = (C.byref(d), _vp(x_ptr), _vp(dz_ptr), ld_dz, _vp(dw_ptr), stm)
-        for mb in cands:
-            d.max_blocks = mb
-            _lib.check(lib.y5_conv2d_wgrad(*args), lib)
-            e0.record()
-            for _ in range(3):
-                lib.y5_conv2d_wgrad(*args)
-            e1.record()
-            e1.synchronize()
-            ms = e0.elapsed_time(e1)
-            if ms < best_ms:
-                best, best_ms = mb, ms
+        best, best_ms = (-1, 0), float("inf")
+        for cfg, tiles, factors in fams:
+            for mb in sorted({max(1, (int(f * ncu) + tiles - 1) // tiles) for f in factors}):
+                d.cfg, d.max_blocks = cfg, mb
+                _lib.check(self._wgrad_launch(d, x_ptr, dz_ptr, ld_dz, dw_ptr, stm), lib)
+                e0.record()
+                for _ in range(3):
+                    self._wgrad_launch(d, x_ptr, dz_ptr, ld_dz, dw_ptr, stm)
+                e1.record()
+                e1.synchronize()
+                ms = e0.elapsed_time(e1)
+                if ms < best_ms:
+                    best, best_ms = (cfg, mb), ms
         _lib.check(lib.y5_memset_zero(_vp(dw_ptr), dw_bytes, stm), lib)  # the timing launches accumulated into this layer's dW
-        _TUNE_CACHE[key] = (best, -1)   # (choice, no runner-up): the cache's value layout (engine.autotune_conv)
+        _TUNE_CACHE[key] = ((best[0] + 1) << 20 | best[1], -1)   # (choice, no runner-up): the cache's value layout (engine.autotune_conv)
         _save_tune_cache()
         return best
 
@@ -481,22 +510,11 @@ class TrainEngine:
                           KH=g["k"][0], KW=g["k"][1], SH=g["s"][0], SW=g["s"][1], PH=g["p"][0], PW=g["p"][1], act=0, Kpad=Kpad, Npad=Npad,
                           cfg=-1, max_blocks=0)
         dw_ptr = be.ptr(self.dwflat) + st["dw_off"] * 4
-        if "wg_splits" not in st:
-            st["wg_splits"] = self._tune_wgrad_splits(d, self._ptr(x), dz_ptr, ld_dz, dw_ptr, Npad * Kpad * 4, stm)
-        d.max_blocks = st["wg_splits"]
-        if self.deterministic and self.dt == _lib.Y5_F16:
-            # fixed-order reduction of the pixel-range splits through a workspace (csrc/wgrad.hip DET): bit-identical gradients run to run
-            need = int(lib.y5_conv2d_wgrad_ws_bytes(C.byref(d), ld_dz))
-            if need < 0:
-                _lib.check(-1, lib)
-            if self._wg_ws is None or self._wg_ws_bytes < need:
-                self._wg_ws_bytes = max(need, 1 << 20)
-                self._wg_ws = be.empty((self._wg_ws_bytes // 4 + 64,), torch.float32)
-            wsp = be.ptr(self._wg_ws)
-            wsp += (-wsp) % 16
-            _lib.check(lib.y5_conv2d_wgrad_det(C.byref(d), _vp(self._ptr(x)), _vp(dz_ptr), ld_dz, _vp(dw_ptr), _vp(wsp), need, stm), lib)
-        else:
-            _lib.check(lib.y5_conv2d_wgrad(C.byref(d), _vp(self._ptr(x)), _vp(dz_ptr), ld_dz, _vp(dw_ptr), stm), lib)
+        if "wg_choice" not in st:
+            st["wg_choice"] = self._tune_wgrad(d, self._ptr(x), dz_ptr, ld_dz, dw_ptr, Npad * Kpad * 4, stm)
+        d.cfg, d.max_blocks = st["wg_choice"]
+        # (deterministic: fixed-order reduction of the pixel-range splits through a workspace, csrc/wgrad.hip DET -- bit-identical gradients run to run)
+        _lib.check(self._wgrad_launch(d, self._ptr(x), dz_ptr, ld_dz, dw_ptr, stm), lib)
         if self.grad_sink is not None:  # a gradient sink (HipDDP) wants every gradient as early as possible: unpack per layer
             _lib.check(lib.y5_unpack_conv_wgrad(_vp(be.ptr(self.dwflat) + st["dw_off"] * 4), Kpad, _vp(self._gptr(cv.weight)), c2, c1, kh, kw,
                                                 st["c1v"], stm), lib)
