@@ -93,15 +93,8 @@ int launch_cfg(const Y5ConvParams& p0, int max_blocks, hipStream_t stream) {
     pieces = p.Kpad / Gm::EPP;
     if (pieces > Y5_CONV_MAXTAB) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: K too large for gather-table mode");
   }
-  size_t lds = y5_conv_lds_bytes<T, WM, WN, TM, TN, RB, NS, ALIAS>(pieces);
+  const size_t lds = y5_conv_lds_bytes<T, WM, WN, TM, TN, RB, NS, ALIAS>(pieces);
   if (lds > 160 * 1024) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: tile configuration exceeds 160 KiB of LDS");
-  {
-    // bias resident in LDS (Npad floats behind the kernel's own layout) whenever it fits; Y5_BIAS_LDS=0 keeps the global-memory reads
-    static const int want = [] { const char* e = getenv("Y5_BIAS_LDS"); return e ? atoi(e) : 1; }();
-    const size_t with_bias = ((lds + 15) & ~(size_t)15) + (size_t)p.Npad * 4;
-    p.bias_lds = want && with_bias <= 160 * 1024;
-    if (p.bias_lds) lds = with_bias;
-  }
   auto kern = y5_conv_igemm_kernel<T, WM, WN, TM, TN, RB, TABLE, NS, PROD, ALIAS, SK>;
   constexpr int NTHREADS = WM * WN * 64 * (PROD ? 2 : 1);
   static bool attr_done = false;  // per instantiation

@@ -40,8 +40,7 @@ struct Y5H3Geom {
   static constexpr int PPS = (APS + 1) / 2;            // ... issued in the first two steps of the previous chunk (seven steps ahead)
   static constexpr int SCR_ROWB = 32 * 2 + 16, SCR_BYTES = 32 * SCR_ROWB;
   // the epilogue's transposition scratch lives in halo stage 1 (idle between a tile's last step and the next tile's step 0)
-  static constexpr size_t LDS = (size_t)2 * A_STAGE + (size_t)NSW * W_STAGE + 1024;  // + one dummy slot (zeros from any wave); + Npad floats of bias
-                                                                                      // behind it when the launch sets p.bias_lds (convh3.hip)
+  static constexpr size_t LDS = (size_t)2 * A_STAGE + (size_t)NSW * W_STAGE + 1024;  // + one dummy slot (zeros from any wave)
   static_assert(NW * SCR_BYTES <= A_STAGE, "epilogue scratch must fit into a halo stage");
   static_assert(NSW == 9 || NSW == 4, "ring depths with bookkeeping: 9 and 4");
   // LDS-DMA instructions (dummies included) a wave has issued for the NEXT chunk's halo (taps 0 and 1) within the WIN steps before tap t
@@ -88,12 +87,6 @@ void y5_conv_h3_kernel(const Y5ConvParams p) {
   const int g = lane >> 5, frow = lane & 31;
   char* const scratch = smem + A_STAGE + wave * Gm::SCR_BYTES;  // halo stage 1
   char* const dummy = smem + 2 * A_STAGE + NSW * W_STAGE;  // shared by all waves: only ever receives zero fill, never read
-  float* const blds = reinterpret_cast<float*>(smem + Gm::LDS);  // p.bias_lds: the layer's bias, copied once (the epilogue's global-memory reads of it
-                                                                 // compiled to sixteen VECTOR loads per 32 x 32 block)
-  if (p.bias_lds) {
-    for (int i = threadIdx.x; i < p.Npad; i += NW * 64) blds[i] = p.bias[i];
-    __syncthreads();
-  }
 
   const int TH = p.h3_th, TW = p.h3_tw, HW = TW + 2;
   const int HP = (TH + 2) * HW;
@@ -208,22 +201,14 @@ void y5_conv_h3_kernel(const Y5ConvParams p) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int nt = n0 + (wn * TN + j) * 32;
-        const int ntc = nt < p.Npad ? nt : 0;
-        const float* pb = p.bias + ntc;
+        const float* pb = p.bias + (nt < p.Npad ? nt : 0);  // scalar-cache loads (wave-uniform address)
         const float keep = nt < p.Npad ? 1.0f : 0.0f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          float4_t bq;
-          if (p.bias_lds) {
-            bq = *reinterpret_cast<const float4_t*>(blds + ntc + q * 8 + g * 4);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bq[e] = g ? pb[q * 8 + 4 + e] : pb[q * 8 + e];
-          }
           half4_t o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float t = acc[i][j][q * 4 + e] + bq[e] * keep;
+            const float t = acc[i][j][q * 4 + e] + (g ? pb[q * 8 + 4 + e] : pb[q * 8 + e]) * keep;
             o[e] = (half_t)(p.act ? y5_silu(t) : t);
           }
           *reinterpret_cast<half4_t*>(scratch + frow * SCR_ROWB + (q * 8 + g * 4) * 2) = o;

@@ -57,8 +57,6 @@ struct Y5ConvParams {
   unsigned pw2_w_bytes;
   int pw2_kpad, pw2_npad, pw2_c2, pw2_act, pw2_split;
   int h3_th, h3_tw, h3_tiles_h, h3_tiles_w;  // conv_h3.h: spatial tile (output rows x columns) and tiles per image
-  int bias_lds; // 1: the launch reserved Npad floats of LDS behind the kernel's own layout; the bias is copied there once and the epilogues read it with
-                // ds_read (0: loaded from global memory in every epilogue -- hipcc makes those VECTOR loads, which queue behind in-flight LDS-DMA)
   int split_n;  // > 0: output channels >= split_n go to y2 (pixel stride ld2, channel n - split_n) instead of y -- C3's cv1 / cv2 halves
                 // of one GEMM landing in two different buffers (y2 is then NOT the upsampled replica)
 };
@@ -145,10 +143,6 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
   const int wm = wave / WN, wn = wave % WN;
   char* scratch = smem + (ALIAS ? 0 : NS * BUF_BYTES + tab_bytes) + wave * Gm::SCR_BYTES;  // ALIAS: re-pointed at every tile boundary
   char* dummy = smem + NS * BUF_BYTES + tab_bytes + NW * Gm::SCR_BYTES + wave * 1024;  // NS > 2 only
-  // bias copy (p.bias_lds): behind everything else -- y5_conv_lds_bytes() of this configuration, rounded to 16
-  float* const blds = reinterpret_cast<float*>(smem + ((NS * BUF_BYTES + tab_bytes + (ALIAS ? 0 : NW * Gm::SCR_BYTES) + (NS > 2 ? NW * 1024 : 0) + 15) & ~15));
-  if (p.bias_lds)
-    for (int i = threadIdx.x; i < p.Npad; i += NW * 64 * (PROD ? 2 : 1)) blds[i] = p.bias[i];
 
   const int G = gridDim.x;
   const int bid = blockIdx.x;
@@ -352,23 +346,15 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
         // bias through the SCALAR cache (nt is wave-uniform; eight consecutive values per s_load, the lane picks its half): a
         // vector load here would sit behind the next tile's in-flight LDS-DMA in the in-order vmcnt queue and stall the epilogue
         // for a full memory round trip
-        const int ntc = nt < p.Npad ? nt : 0;
-        const float* pb = p.bias + ntc;
+        const float* pb = p.bias + (nt < p.Npad ? nt : 0);
         const float keep = nt < p.Npad ? 1.0f : 0.0f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int nl = q * 8 + g * 4;
-          float4_t bq;
-          if (p.bias_lds) {
-            bq = *reinterpret_cast<const float4_t*>(blds + ntc + nl);   // LDS: no entry in the vector-memory queue
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bq[e] = g ? pb[q * 8 + 4 + e] : pb[q * 8 + e];
-          }
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float t = acc[i][j][q * 4 + e] + bq[e] * keep;
+            const float t = acc[i][j][q * 4 + e] + (g ? pb[q * 8 + 4 + e] : pb[q * 8 + e]) * keep;
             v[e] = p.act ? y5_silu(t) : t;
           }
           char* dst = scratch + frow * SCR_ROWB + nl * (int)sizeof(T);
@@ -443,7 +429,7 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
     }
   };
 
-  if (TABLE || p.bias_lds) __syncthreads();  // gather table / bias copy visible to every wave
+  if constexpr (TABLE) __syncthreads();
   if (!PROD || producer) loader_setup(0);
   // multiply the chunk in `lds`; with_loads: the next chunk's LDS-DMA instructions (stage_begin() already called) are issued
   // between the k-steps, so that the vector-memory pipe and the matrix cores work at the same time

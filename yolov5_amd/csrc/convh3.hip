@@ -68,14 +68,6 @@ int launch_h3(const Y5ConvParams& p0, int max_blocks, hipStream_t stream) {
   }
   Y5ConvParams p = p0;
   p.tilesN = (p.Npad + Gm::BN - 1) / Gm::BN;
-  // bias resident in LDS behind the kernel's own layout, unless that would cost a resident workgroup (Y5_BIAS_LDS=0: global-memory reads)
-  static const int want_bias_lds = [] { const char* e = getenv("Y5_BIAS_LDS"); return e ? atoi(e) : 1; }();
-  size_t lds = Gm::LDS;
-  {
-    const size_t with_bias = Gm::LDS + (size_t)p.Npad * 4;
-    p.bias_lds = want_bias_lds && with_bias <= 160 * 1024 && (160 * 1024) / with_bias == (160 * 1024) / Gm::LDS;
-    if (p.bias_lds) lds = with_bias;
-  }
   long long G = max_blocks;
   if (G <= 0) {
     if (!g_num_cu) {
@@ -85,7 +77,7 @@ int launch_h3(const Y5ConvParams& p0, int max_blocks, hipStream_t stream) {
       g_num_cu = n > 0 ? n : 256;
     }
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), Gm::NW * 64, lds) != hipSuccess || occ < 1) occ = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), Gm::NW * 64, Gm::LDS) != hipSuccess || occ < 1) occ = 1;
     G = (long long)g_num_cu * occ;
   }
   int th = 0, tw = 0;
@@ -98,7 +90,7 @@ int launch_h3(const Y5ConvParams& p0, int max_blocks, hipStream_t stream) {
   if (ntiles <= 0 || ntiles > 0x7fffffffLL) return y5_fail(Y5_ERR_BAD_ARG, "conv: grid out of range");
   if (G > ntiles) G = ntiles;
   if (G >= 8) G &= ~7LL;
-  hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(Gm::NW * 64), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(Gm::NW * 64), Gm::LDS, stream, p);
   return y5_check_launch("y5_conv2d_fwd(h3)");
 }
 
