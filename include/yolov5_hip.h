@@ -185,7 +185,8 @@ int y5_nms_batched_hint(const void* pred, int dtype, int bs, int n, int no, int 
  * y5_conv2d_wgrad -- weight gradient of the convolution described by `d` (same descriptor as the forward call; act,
  * ldy, ldr, ld2 ignored; max_blocks > 0 sets the number of pixel-range splits (the train engine times a few per layer
  * geometry and keeps the fastest; 0 = library default); k1 s1 p0 layers take a linear-staging build of the kernel).
- * d->cfg picks the kernel family: -1 / 0 = automatic, 1 = the general im2col-gather kernel, 3 = the patch-staged kernel
+ * d->cfg picks the kernel family: -1 / 0 = automatic, 1 = the general im2col-gather kernel (1xy: its filter tile capped at
+ * 64 x output channels by 64 y k columns, x, y in {1,2} -- more tiles, fewer splits, less atomic traffic), 3 = the patch-staged kernel
  * of the 3x3 layers (k3 p1, stride 1 or 2: one workgroup owns all nine taps of a channel tile and stages spatial patches
  * -- the activation travels to LDS ~3 times instead of 9; wins where a filter element sees many pixels, P1-P3), 3xy = the
  * same with its channel tile capped at 32 x output channels by 32 y input channels (x in {1,2,4}, y in {1,2});

@@ -14,4 +14,4 @@ for k, v in d.items():
         c = v[0] if isinstance(v, list) else v
         print(k, '-> cfg', (c >> 20) - 1, 'splits', c & 0xFFFFF)
 P
-timeout 600 python -m pytest tests/test_gpu_train.py tests/test_gpu_train_ops.py tests/test_gpu_ddp.py -x -q 2>&1 | tail -4
+timeout 600 python -m pytest tests/test_gpu_train.py tests/test_gpu_train_ops.py tests/test_gpu_ddp.py -x -q 2>&1 | grep -E "passed|failed|error" | tail -4

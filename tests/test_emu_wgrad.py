@@ -75,7 +75,7 @@ CASES3 = [
 
 
 @pytest.mark.parametrize("case", CASES3)
-@pytest.mark.parametrize("cfg", [3, 1, 321, -1])
+@pytest.mark.parametrize("cfg", [3, 1, 321, -1, 111, 112])
 def test_emu_wgrad_k3_families_match_torch(case, cfg):
     B, H, W, C1, C2, s, splits = case
     lib = emu()

@@ -297,9 +297,10 @@ static int wgrad_impl(const y5_conv_desc* d, const void* x, const void* dz, int 
   // d->cfg selects the kernel family: -1 / 0 = automatic (by pixels per filter element), 1 = the general im2col-gather kernel, 3 / 3xy = the patch-staged 3x3
   // kernel (wgrad3.h).  Which one is faster depends on pixels per filter element (measured, profiles/r03/r03_wgrad3_ab.log): TrainEngine times both.
   const bool can3 = d->KH == 3 && d->KW == 3 && d->PH == 1 && d->PW == 1 && d->SH == d->SW && (d->SH == 1 || d->SH == 2) && d->C2 * 9LL * d->C1 > 0;
-  if (d->cfg >= 3 && !can3) return y5_fail(Y5_ERR_BAD_ARG, "wgrad: cfg 3 (patch-staged kernel) needs k3 p1 and stride 1 or 2");
+  const bool want3 = d->cfg == 3 || d->cfg >= 300;
+  if (want3 && !can3) return y5_fail(Y5_ERR_BAD_ARG, "wgrad: cfg 3 (patch-staged kernel) needs k3 p1 and stride 1 or 2");
   const bool auto3 = d->cfg <= 0 && (long long)p.M >= 10LL * p.K * d->C2;   // many pixels per filter element: P1-P3 of the yolov5 graphs
-  if (can3 && (d->cfg >= 3 || auto3)) {
+  if (can3 && (want3 || auto3)) {
     int nt = d->C2 > 64 ? 4 : d->C2 > 32 ? 2 : 1, ct = d->C1 > 32 ? 2 : 1;
     if (d->cfg >= 300) {  // 300 + 10 NTcap + CTcap: the channel tile is capped (the tuner's alternative shapes, e.g. 341 = up to 128 x 32 per workgroup)
       const int cn = (d->cfg - 300) / 10, cc = (d->cfg - 300) % 10;
@@ -344,7 +345,16 @@ static int wgrad_impl(const y5_conv_desc* d, const void* x, const void* dz, int 
     }
     return y5_check_launch("y5_conv2d_wgrad(k3)");
   }
-  const int tnb = d->C2 >= 128 ? 2 : 1, tkb = p.K >= 128 ? 2 : 1;
+  int tnb = d->C2 >= 128 ? 2 : 1, tkb = p.K >= 128 ? 2 : 1;
+  // cfg 1xy: the general kernel with its filter tile capped at 64 x output channels by 64 y k columns (x, y in {1, 2}).  Splits x filter elements
+  // is the atomic traffic of a launch; at P4 / P5 (few pixels, large filters) four times as many tiles need a quarter of the splits to fill the chip.
+  if ((d->cfg > 1 && d->cfg < 100 && d->cfg != 3) || (d->cfg >= 200 && d->cfg < 300)) return y5_fail(Y5_ERR_BAD_ARG, "wgrad: unknown cfg");
+  if (d->cfg >= 100 && d->cfg < 200) {
+    const int cn = (d->cfg - 100) / 10, ck = (d->cfg - 100) % 10;
+    if ((cn != 1 && cn != 2) || (ck != 1 && ck != 2)) return y5_fail(Y5_ERR_BAD_ARG, "wgrad: cfg 1xy needs x, y in {1, 2}");
+    tnb = tnb < cn ? tnb : cn;
+    tkb = tkb < ck ? tkb : ck;
+  }
   p.tiles_n = (d->C2 + 64 * tnb - 1) / (64 * tnb);
   p.tiles_k = (p.K + 64 * tkb - 1) / (64 * tkb);
   const int tiles = p.tiles_n * p.tiles_k;

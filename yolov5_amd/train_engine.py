@@ -229,6 +229,13 @@ class TrainEngine:
         fams = []
         if fam in (-2, -1, 1):
             fams.append((1, -(-d.C2 // (128 if d.C2 >= 128 else 64)) * -(-K // (128 if K >= 128 else 64)), (1, 1.5, 2, 3, 4, 6)))
+        if fam == -2 and d.C2 >= 128 and K >= 128 and d.B * d.OH * d.OW <= 64 * 40 * 40:
+            # few pixels, large filter: atomic traffic = splits x filter; the same kernel on 64 x 64 / 64 x 128 tiles fills the chip with fewer splits
+            for cfg, tn, tk in ((111, 64, 64), (112, 64, 128)):
+                fams.append((cfg, -(-d.C2 // tn) * -(-K // tk), (1, 1.5, 2, 3)))
+        elif 100 <= fam < 200:
+            tn, tk = 64 * min((fam - 100) // 10, 2 if d.C2 >= 128 else 1), 64 * min((fam - 100) % 10, 2 if K >= 128 else 1)
+            fams.append((fam, -(-d.C2 // tn) * -(-K // tk), (1, 1.5, 2, 3, 4, 6)))
         if k3 and (fam == -2 or fam >= 3):
             for cfg in ((3, 341) if fam == -2 else (fam,)):
                 cn, cc = ((cfg - 300) // 10, (cfg - 300) % 10) if cfg >= 300 else (4, 2)
