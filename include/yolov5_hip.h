@@ -404,7 +404,8 @@ int y5_bottleneck_cv3_fwd(const void* x, int ldx, const void* w1_packed, const f
 
 /* ---------------------------------------------------------------------------------------------------------
  * y5_mosaic_batch -- the training input pipeline for a whole batch in one launch: utils/dataloaders.py:798-855 `load_mosaic`
- * (four images resized to the training size by `load_image` :770-790 and tiled on a 2s x 2s canvas of 114s), the image half of
+ * (four images resized to the training size by `load_image` :770-790 and tiled on a 2s x 2s canvas of 114s; or, where the hyp['mosaic']
+ * gate of :701 sends a sample down the letterbox branch :710-733, that one image on an s x s canvas -- job.canvas), the image half of
  * utils/augmentations.py:118-166 `random_perspective` (cv2.warpAffine, INTER_LINEAR, border 114, output s x s), :69-83 `augment_hsv`,
  * the flips of dataloaders.py:747-757, `img.transpose((2, 0, 1))[::-1]` (:761) and collate_fn's torch.stack (:862).  Draws, geometry
  * and labels are the host's (yolov5_amd/dataloaders.py); jobs_dev is a DEVICE array of B descriptors.  Source images: uint8 HWC BGR.
@@ -418,7 +419,9 @@ typedef struct {
   int x1b[4], y1b[4];            /* top-left corner of the part of the resized image that lands there */
   double A[6];                   /* INVERSE affine map of cv2.warpAffine: src = A @ (x, y, 1) */
   unsigned char lut[3][256];     /* hue / saturation / value look-up tables of augment_hsv */
-  int hsv, flipud, fliplr, reserved;
+  int hsv, flipud, fliplr;
+  int canvas;                    /* side of the square canvas the tiles sit on; 0 = 2 S (mosaic).  S for the non-mosaic branch of
+                                    dataloaders.py:710-733: load_image + letterbox(auto=False) = ONE tile at (left, top) of an S x S canvas */
 } y5_mosaic_job;
 int y5_mosaic_batch(const y5_mosaic_job* jobs_dev, int B, int S, int pad_value, void* dst, int dst_dtype, int div255, void* stream);
 

@@ -32,18 +32,20 @@ def reference_draws(seed, index, n_images, s, hyp):
     random.seed(seed)
     np.random.seed(seed)
     d = {"mosaic": random.random() < hyp["mosaic"]}
-    assert d["mosaic"], "only the mosaic branch is restated"
-    border = [-s // 2, -s // 2]
-    d["yc"], d["xc"] = (int(random.uniform(-x, 2 * s + x)) for x in border)
-    idx = [index, *random.choices(range(n_images), k=3)]
-    random.shuffle(idx)
-    d["indices"] = idx
+    if d["mosaic"]:
+        border = [-s // 2, -s // 2]
+        d["yc"], d["xc"] = (int(random.uniform(-x, 2 * s + x)) for x in border)
+        idx = [index, *random.choices(range(n_images), k=3)]
+        random.shuffle(idx)
+        d["indices"] = idx
+    else:  # letterbox branch (dataloaders.py:710-733): no draws before random_perspective's, and no mixup gate behind them
+        d["indices"] = [index]
     d["persp"] = (random.uniform(-hyp["perspective"], hyp["perspective"]), random.uniform(-hyp["perspective"], hyp["perspective"]))
     d["angle"] = random.uniform(-hyp["degrees"], hyp["degrees"])
     d["scale"] = random.uniform(1 - hyp["scale"], 1 + hyp["scale"])
     d["shear"] = (random.uniform(-hyp["shear"], hyp["shear"]), random.uniform(-hyp["shear"], hyp["shear"]))
     d["translate"] = (random.uniform(0.5 - hyp["translate"], 0.5 + hyp["translate"]), random.uniform(0.5 - hyp["translate"], 0.5 + hyp["translate"]))
-    d["mixup"] = random.random() < hyp["mixup"]
+    d["mixup"] = d["mosaic"] and random.random() < hyp["mixup"]
     assert not d["mixup"], "mixup is not restated"
     d["hsv"] = np.random.uniform(-1, 1, 3) * [hyp["hsv_h"], hyp["hsv_s"], hyp["hsv_v"]] + 1
     d["flipud"] = random.random() < hyp["flipud"]
@@ -131,6 +133,35 @@ def hsv_luts(r):
     return ((x * r[0]) % 180).astype(np.uint8), np.clip(x * r[1], 0, 255).astype(np.uint8), np.clip(x * r[2], 0, 255).astype(np.uint8)
 
 
+def letterbox_sample(images, labels, d, s, hyp=None):
+    """One training sample of the NON-mosaic branch with augment = True, rect = False (dataloaders.py:710-733): load_image, letterbox to s x s
+    (utils/augmentations.py:85-115, auto=False, scaleup=True: the longest side already is s, so only the 114 border is added), labels to
+    pixels with the FLOAT pad, random_perspective with border (0, 0), then the common tail.  Same return value as mosaic_sample."""
+    i = d["indices"][0]
+    im, _, (h, w) = load_image(images[i], s)
+    r = min(s / h, s / w)                                   # augmentations.py:93 (scaleup=True)
+    nw, nh = int(round(w * r)), int(round(h * r))
+    dw, dh = (s - nw) / 2, (s - nh) / 2                     # :100-106 (auto=False, scaleFill=False)
+    if (w, h) != (nw, nh):
+        im = tp.cv2_resize(im, (nw, nh), interpolation=1)
+    top, bottom = int(round(dh - 0.1)), int(round(dh + 0.1))
+    left, right = int(round(dw - 0.1)), int(round(dw + 0.1))
+    img = tp.cv2_copy_make_border(im, top, bottom, left, right, 0, value=(114, 114, 114))
+    lab = labels[i].copy()
+    if lab.size:
+        lab[:, 1:] = tp.xywhn2xyxy(lab[:, 1:], r * w, r * h, padw=dw, padh=dh)
+    M, width, height = perspective_matrix(d, img.shape[:2], (0, 0))
+    if (M != np.eye(3)).any():
+        img = tp.cv2_warp_affine(img, M[:2], (width, height), borderValue=(114, 114, 114))
+    lab = warp_boxes(lab, M, width, height, d["scale"])
+    return _tail(img, lab, d, hyp)
+
+
+def sample(images, labels, d, s, hyp=None):
+    """dataloaders.py:701: the branch the mosaic gate chose."""
+    return mosaic_sample(images, labels, d, s, hyp) if d.get("mosaic", True) else letterbox_sample(images, labels, d, s, hyp)
+
+
 def mosaic_sample(images, labels, d, s, hyp=None):
     """One training sample.  images: list of HWC uint8 BGR arrays; labels: list of (k, 5) float arrays [cls, xc, yc, w, h] normalised;
     d: draws (reference_draws).  Returns (img (3, s, s) uint8 RGB CHW, labels_out (nl, 6) float32 [0, cls, xc, yc, w, h])."""
@@ -154,6 +185,11 @@ def mosaic_sample(images, labels, d, s, hyp=None):
     M, width, height = perspective_matrix(d, img4.shape[:2], border)
     img = tp.cv2_warp_affine(img4, M[:2], (width, height), borderValue=(114, 114, 114))
     lab = warp_boxes(labels4, M, width, height, d["scale"])
+    return _tail(img, lab, d, hyp)
+
+
+def _tail(img, lab, d, hyp):
+    """dataloaders.py:735-762, common to both branches: normalised clipped xywh, HSV, flips, CHW / RGB."""
     nl = len(lab)
     if nl:
         lab[:, 1:5] = tp.xyxy2xywhn(lab[:, 1:5], w=img.shape[1], h=img.shape[0], clip=True, eps=1e-3)

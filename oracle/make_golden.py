@@ -536,6 +536,24 @@ def gen_augment(ns):
         print("augment", seed, tuple(imb.shape), tuple(labb.shape))
     np.savez_compressed(os.path.join(OUT, "augment.npz"), **out)
 
+    # hyp['mosaic'] = 0.5: the gate of dataloaders.py:701 sends about half of the samples down the letterbox branch (:710-733: load_image,
+    # letterbox(auto=False, scaleup=True), float-pad labels, random_perspective with border (0, 0)); batches of three so that both branches meet
+    ds.hyp = dict(hyp, mosaic=0.5)
+    out = {"s": np.array(s)}
+    for seed in (11, 12, 13, 14):
+        batch, gates = [], []
+        for index in (seed % 6, (seed + 2) % 6, (seed + 4) % 6):
+            random.seed(seed * 10 + index)
+            gates.append(random.random() < 0.5)
+            random.seed(seed * 10 + index)
+            np.random.seed(seed * 10 + index)
+            im, lab, _, _ = cls.__getitem__(ds, index)
+            batch.append((im, lab, "", None))
+        imb, labb, _, _ = cls.collate_fn(batch)
+        out[f"img{seed}"], out[f"lab{seed}"], out[f"mosaic{seed}"] = imb.numpy(), labb.numpy(), np.array(gates)
+        print("augment mixed", seed, gates, tuple(imb.shape), tuple(labb.shape))
+    np.savez_compressed(os.path.join(OUT, "augment_mixed.npz"), **out)
+
 
 TINY_CFG = {  # a 0.13 M-parameter YOLOv5 (reference schema, models/yolov5n.yaml with width 0.125): checkpoint fixtures stay small
     "nc": 80, "depth_multiple": 0.33, "width_multiple": 0.125,

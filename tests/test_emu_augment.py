@@ -49,6 +49,29 @@ def test_mosaic_batch_matches_reference_golden(seed):
     assert torch.equal(half, (imgs.float() / 255).half())
 
 
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_mixed_mosaic_and_letterbox_branches_match_reference_golden(seed):
+    """hyp['mosaic'] = 0.5 (dataloaders.py:701): samples that lose the gate take the letterbox branch (:710-733) -- one tile on an s x s canvas,
+    labels shifted by the float half-borders, random_perspective with border (0, 0) -- inside the same launch as the mosaics of the batch.
+    Against the reference's own __getitem__ / collate_fn (tests/golden/augment_mixed.npz): pixels bit-identical, labels identical."""
+    from yolov5_amd.dataloaders import draw_sample, mosaic_batch
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "augment_mixed.npz"))
+    s = int(g["s"])
+    hyp = dict(HYP, mosaic=0.5)
+    ims_t, labs, _ = _dataset()
+    draws = []
+    for index in (seed % 6, (seed + 2) % 6, (seed + 4) % 6):
+        random.seed(seed * 10 + index)
+        np.random.seed(seed * 10 + index)
+        draws.append(draw_sample(index, 6, s, hyp))
+    assert [d["mosaic"] for d in draws] == list(g[f"mosaic{seed}"])
+    imgs, targets = mosaic_batch(ims_t, labs, draws, s, hyp, dtype=torch.uint8)
+    assert np.array_equal(imgs.numpy(), g[f"img{seed}"])
+    assert targets.shape == g[f"lab{seed}"].shape
+    np.testing.assert_array_equal(targets.numpy(), g[f"lab{seed}"])
+
+
 def test_draws_follow_the_reference_order_and_loader_shapes():
     from yolov5_amd.dataloaders import MosaicLoader, draw_sample
 

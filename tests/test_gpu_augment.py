@@ -35,6 +35,30 @@ def test_mosaic_batch_matches_reference_golden(seed):
     np.testing.assert_array_equal(targets.numpy(), G[f"lab{seed}"])
 
 
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_mixed_mosaic_and_letterbox_branches_match_reference_golden(seed):
+    """hyp['mosaic'] = 0.5: mosaic samples and letterbox-branch samples (dataloaders.py:710-733) in one launch, against the reference's own
+    __getitem__ / collate_fn (tests/golden/augment_mixed.npz) -- the emulator twin is tests/test_emu_augment.py."""
+    from yolov5_amd.dataloaders import draw_sample, mosaic_batch
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "augment_mixed.npz"))
+    dev = torch.device("cuda:0")
+    s = int(g["s"])
+    hyp = dict(HYP, mosaic=0.5)
+    ims, labs = ao.synthetic_dataset(6, seed=3)
+    ims_t = [torch.from_numpy(im).to(dev) for im in ims]
+    labs = [lb.astype(np.float32) for lb in labs]
+    draws = []
+    for index in (seed % 6, (seed + 2) % 6, (seed + 4) % 6):
+        random.seed(seed * 10 + index)
+        np.random.seed(seed * 10 + index)
+        draws.append(draw_sample(index, 6, s, hyp))
+    assert [d["mosaic"] for d in draws] == list(g[f"mosaic{seed}"])
+    imgs, targets = mosaic_batch(ims_t, labs, draws, s, hyp, dtype=torch.uint8)
+    assert np.array_equal(imgs.cpu().numpy(), g[f"img{seed}"])
+    np.testing.assert_array_equal(targets.numpy(), g[f"lab{seed}"])
+
+
 def test_full_size_batch_vs_oracle_and_rate():
     from yolov5_amd.dataloaders import draw_sample, mosaic_batch
 

@@ -210,6 +210,29 @@ def test_training_sample_pipeline_matches_reference_golden(seed):
     assert labb.shape == g[f"lab{seed}"].shape and np.array_equal(labb, g[f"lab{seed}"])
 
 
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_training_sample_pipeline_mixed_branches_match_reference_golden(seed):
+    """hyp['mosaic'] = 0.5: the gate of dataloaders.py:701 sends samples down the letterbox branch (:710-733: load_image, letterbox, float-pad
+    labels, random_perspective with border (0, 0)) or the mosaic branch; oracle restatement of both against the reference's own
+    __getitem__ / collate_fn (tests/golden/augment_mixed.npz), branch by branch as the reference's generator decided."""
+    from oracle import augment_oracle as ao
+
+    g = _load("augment_mixed.npz")
+    s = int(g["s"])
+    ims, labs = ao.synthetic_dataset(6, seed=3)
+    labs = [lb.astype(np.float32) for lb in labs]
+    hyp = dict(ao.HYP_AUG, degrees=5.0, shear=2.0, flipud=0.3, mosaic=0.5)
+    samples, gates = [], []
+    for index in (seed % 6, (seed + 2) % 6, (seed + 4) % 6):
+        d = ao.reference_draws(seed * 10 + index, index, 6, s, hyp)
+        gates.append(d["mosaic"])
+        samples.append(ao.sample(ims, labs, d, s, hyp))
+    assert gates == list(g[f"mosaic{seed}"])
+    imb, labb = ao.collate(samples)
+    assert np.array_equal(imb, g[f"img{seed}"])
+    assert labb.shape == g[f"lab{seed}"].shape and np.array_equal(labb, g[f"lab{seed}"])
+
+
 def test_loss_focal():
     """hyp fl_gamma = 1.5 + label smoothing 0.1 (utils/loss.py:120-122 -> FocalLoss :77-98): the oracle's restatement against the reference's own
     ComputeLoss (tests/golden/loss_focal.npz, oracle/make_golden.py gen_loss)."""

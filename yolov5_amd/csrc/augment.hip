@@ -1,5 +1,6 @@
 // Training input pipeline on the device: one launch renders a whole batch of training images, each of them
 //     load_mosaic            utils/dataloaders.py:798-855   4 images resized to the training size, tiled on a 2s x 2s canvas of 114s
+//       or (hyp['mosaic'] gate lost, :710-733)              1 image, load_image + letterbox = one tile on an s x s canvas of 114s
 //     random_perspective     utils/augmentations.py:118-166 cv2.warpAffine(canvas, M[:2], (s, s), borderValue 114), INTER_LINEAR
 //     augment_hsv            utils/augmentations.py:69-83   BGR -> HSV, three 256-entry LUTs, HSV -> BGR
 //     flipud / fliplr        utils/dataloaders.py:747-757
@@ -32,7 +33,7 @@ __device__ inline long long sat_int(double v) {  // saturate_cast<int>(double): 
   return r < -2147483648.0 ? -2147483648LL : (r > 2147483647.0 ? 2147483647LL : (long long)r);
 }
 
-// pixel (yy, xx) of the virtual 2s x 2s mosaic canvas
+// pixel (yy, xx) of the virtual canvas: 2s x 2s for a mosaic, s x s for the letterboxed single image of the non-mosaic branch (job.canvas)
 __device__ inline void canvas_pixel(const y5_mosaic_job& j, const ResizeGeom* g, int S2, int pad, int yy, int xx, int out[3]) {
   out[0] = out[1] = out[2] = pad;
   if (yy < 0 || xx < 0 || yy >= S2 || xx >= S2) return;
@@ -106,7 +107,7 @@ void y5_mosaic_kernel(const AugParams p) {
   syl = syl < -32768 ? -32768 : (syl > 32767 ? 32767 : syl);
   const int sx = (int)sxl, sy = (int)syl, fx = (int)(X & 31), fy = (int)(Y & 31);
   int p00[3], p01[3], p10[3], p11[3];
-  const int S2 = 2 * S;
+  const int S2 = j.canvas > 0 ? j.canvas : 2 * S;
   canvas_pixel(j, g, S2, p.pad, sy, sx, p00);
   canvas_pixel(j, g, S2, p.pad, sy, sx + 1, p01);
   canvas_pixel(j, g, S2, p.pad, sy + 1, sx, p10);

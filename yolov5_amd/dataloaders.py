@@ -1,4 +1,5 @@
-"""Training input pipeline (utils/dataloaders.py:696-863 mosaic branch of `LoadImagesAndLabels.__getitem__` + `collate_fn`;
+"""Training input pipeline (utils/dataloaders.py:696-863 `LoadImagesAndLabels.__getitem__` with augment = True, rect = False -- the mosaic
+branch and, where the hyp['mosaic'] gate sends a sample there, the letterbox branch :710-733 -- + `collate_fn`;
 utils/augmentations.py:69-83 `augment_hsv`, :118-209 `random_perspective`, :246-258 `box_candidates`) with the pixel work on the
 device: the dataset's uint8 BGR images live in HBM, `MosaicLoader` draws the random numbers and does the geometry + label transform
 of a whole batch on the host (a few hundred floats) and ONE `y5_mosaic_batch` launch renders the (B, 3, s, s) batch -- resized
@@ -7,8 +8,8 @@ rates of this engine (3 k img/s per GPU) the reference's 8 cv2 worker processes 
 
 Random draws follow the reference's ORDER per sample (documented in `draw_sample`), so that a `random.seed()` / `np.random.seed()`-ed
 run consumes the generators exactly as `__getitem__` does; they can also be passed in (parity tests).
-Not covered: rect / non-mosaic branch (letterbox: augmentations.letterbox_batch), mixup, copy_paste, albumentations, perspective != 0,
-segments."""
+Not covered: rect batches / augment = False (the validation loader: augmentations.letterbox_batch), mixup, copy_paste, albumentations,
+perspective != 0, segments."""
 from __future__ import annotations
 
 import ctypes as C
@@ -28,19 +29,20 @@ def draw_sample(index, n_images, s, hyp, rng=random, np_rng=np.random):
     """Random numbers of one sample in the reference's order: mosaic gate (dataloaders.py:701); centre yc, xc (:802); three extra
     indices + shuffle (:803-804); perspective x2, angle, scale, shear x2, translate x2 (augmentations.py:135-156); mixup gate
     (dataloaders.py:707); three HSV gains from numpy (augmentations.py:72); flipud, fliplr gates (dataloaders.py:747,753)."""
-    if not rng.random() < hyp["mosaic"]:
-        raise NotImplementedError("MosaicLoader: hyp['mosaic'] < 1 (letterbox branch) is not implemented")
-    d = {}
-    d["yc"], d["xc"] = (int(rng.uniform(-x, 2 * s + x)) for x in (-s // 2, -s // 2))
-    idx = [index, *rng.choices(range(n_images), k=3)]
-    rng.shuffle(idx)
-    d["indices"] = idx
+    d = {"mosaic": rng.random() < hyp["mosaic"]}
+    if d["mosaic"]:
+        d["yc"], d["xc"] = (int(rng.uniform(-x, 2 * s + x)) for x in (-s // 2, -s // 2))
+        idx = [index, *rng.choices(range(n_images), k=3)]
+        rng.shuffle(idx)
+        d["indices"] = idx
+    else:   # letterbox branch (dataloaders.py:710-733): the next draws are random_perspective's; no mixup gate on this side
+        d["indices"] = [index]
     d["persp"] = (rng.uniform(-hyp["perspective"], hyp["perspective"]), rng.uniform(-hyp["perspective"], hyp["perspective"]))
     d["angle"] = rng.uniform(-hyp["degrees"], hyp["degrees"])
     d["scale"] = rng.uniform(1 - hyp["scale"], 1 + hyp["scale"])
     d["shear"] = (rng.uniform(-hyp["shear"], hyp["shear"]), rng.uniform(-hyp["shear"], hyp["shear"]))
     d["translate"] = (rng.uniform(0.5 - hyp["translate"], 0.5 + hyp["translate"]), rng.uniform(0.5 - hyp["translate"], 0.5 + hyp["translate"]))
-    if rng.random() < hyp["mixup"]:
+    if d["mosaic"] and rng.random() < hyp["mixup"]:
         raise NotImplementedError("MosaicLoader: mixup is not implemented")
     d["hsv"] = np_rng.uniform(-1, 1, 3) * [hyp["hsv_h"], hyp["hsv_s"], hyp["hsv_v"]] + 1
     d["flipud"] = rng.random() < hyp["flipud"]
@@ -69,10 +71,11 @@ def _tile_rects(hw, yc, xc, s):
     return rects
 
 
-def _affine(d, s):
-    """M = T S R P C of random_perspective for the 2s x 2s canvas and border (-s/2, -s/2) (augmentations.py:124-160) -> (M 3x3, out w, h)."""
-    src = 2 * s
-    height = width = src + 2 * (-s // 2)
+def _affine(d, s, mosaic=True):
+    """M = T S R P C of random_perspective (augmentations.py:124-160) -> (M 3x3, out w, h): the 2s x 2s mosaic canvas with border (-s/2, -s/2), or
+    the s x s letterboxed image of the non-mosaic branch with border (0, 0)."""
+    src = 2 * s if mosaic else s
+    height = width = src + (2 * (-s // 2) if mosaic else 0)
     Cm = np.eye(3)
     Cm[0, 2] = Cm[1, 2] = -src / 2
     a = d["angle"] * math.pi / 180.0
@@ -102,22 +105,24 @@ def _invert_affine(M):
     return m
 
 
-def _labels(labels, d, hw, rects, M, width, height, s):
-    """Label half of the sample: tiles -> canvas pixels (xywhn2xyxy, :838), clip to the canvas (:845-846), corners through M + hull +
-    clip + box_candidates (augmentations.py:193-209,246-258), back to normalised xywh with clipping (dataloaders.py:737), flips."""
+def _labels(labels, d, hw, rects, M, width, height, s, pads=None):
+    """Label half of the sample: tiles -> canvas pixels (xywhn2xyxy, :838 / :720), mosaic only: clip to the canvas (:845-846), corners through
+    M + hull + clip + box_candidates (augmentations.py:193-209,246-258), back to normalised xywh with clipping (dataloaders.py:737), flips.
+    pads: the (padw, padh) of each tile when they are not the integer tile offsets (letterbox branch: the FLOAT half-borders dw, dh)."""
     parts = []
-    for i, (h, w), (x1a, y1a, _x2a, _y2a, x1b, y1b) in zip(d["indices"], hw, rects):
+    for k, (i, (h, w), (x1a, y1a, _x2a, _y2a, x1b, y1b)) in enumerate(zip(d["indices"], hw, rects)):
         lb = np.array(labels[i], dtype=np.float32).reshape(-1, 5).copy()
         if lb.size:
             xy, half = lb[:, 1:3].copy(), lb[:, 3:5] / 2
-            padw, padh = x1a - x1b, y1a - y1b
+            padw, padh = (x1a - x1b, y1a - y1b) if pads is None else pads[k]
             lb[:, 1] = w * (xy[:, 0] - half[:, 0]) + padw
             lb[:, 2] = h * (xy[:, 1] - half[:, 1]) + padh
             lb[:, 3] = w * (xy[:, 0] + half[:, 0]) + padw
             lb[:, 4] = h * (xy[:, 1] + half[:, 1]) + padh
         parts.append(lb)
     t = np.concatenate(parts, 0)
-    np.clip(t[:, 1:], 0, 2 * s, out=t[:, 1:])
+    if d.get("mosaic", True):
+        np.clip(t[:, 1:], 0, 2 * s, out=t[:, 1:])
     n = len(t)
     if n:
         pts = np.ones((n * 4, 3))
@@ -176,10 +181,20 @@ def mosaic_batch(images, labels, draws, s, hyp=None, dtype=torch.uint8, normaliz
             rh, rw = _resized_hw(h0, w0, s)
             hw.append((rh, rw))
             j.src[t], j.h0[t], j.w0[t], j.stride[t], j.rh[t], j.rw[t] = im.data_ptr(), h0, w0, int(im.stride(0)), rh, rw
-        rects = _tile_rects(hw, d["yc"], d["xc"], s)
+        mosaic, pads = d.get("mosaic", True), None
+        if mosaic:
+            rects = _tile_rects(hw, d["yc"], d["xc"], s)
+        else:
+            # letterbox(auto=False, scaleup=True) of an image whose longest side already is s (augmentations.py:85-115): r = 1, no second resize;
+            # the image sits at (left, top) = (round(dw - 0.1), round(dh - 0.1)) of an s x s canvas of 114s, the labels move by the FLOAT dw, dh
+            (rh, rw), = hw
+            dw, dh = (s - rw) / 2, (s - rh) / 2
+            left, top = int(round(dw - 0.1)), int(round(dh - 0.1))
+            rects, pads = [(left, top, left + rw, top + rh, 0, 0)], [(dw, dh)]
+            j.canvas = s
         for t, (x1a, y1a, x2a, y2a, x1b, y1b) in enumerate(rects):
             j.x1a[t], j.y1a[t], j.x2a[t], j.y2a[t], j.x1b[t], j.y1b[t] = x1a, y1a, x2a, y2a, x1b, y1b
-        M, width, height = _affine(d, s)
+        M, width, height = _affine(d, s, mosaic)
         A = _invert_affine(M)
         for k in range(6):
             j.A[k] = float(A.reshape(-1)[k])
@@ -188,7 +203,7 @@ def mosaic_batch(images, labels, draws, s, hyp=None, dtype=torch.uint8, normaliz
         for c in range(3):
             C.memmove(j.lut[c], luts[c].ctypes.data, 256)
         j.hsv, j.flipud, j.fliplr = int(use_hsv), int(bool(d["flipud"])), int(bool(d["fliplr"]))
-        lb = _labels(labels, d, hw, rects, M, width, height, s)
+        lb = _labels(labels, d, hw, rects, M, width, height, s, pads)
         lb[:, 0] = b                                             # collate_fn (dataloaders.py:860-862)
         labs.append(lb)
     table = torch.frombuffer(bytearray(jobs), dtype=torch.uint8).to(dev)
