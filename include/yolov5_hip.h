@@ -224,6 +224,22 @@ int y5_bn_silu_bwd(const void* dy, int ld_dy, const void* z, int ldz, int dtype,
                    float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
 int y5_channel_sum(const void* x, int dtype, long long npix, int C, int ld, float* out, void* workspace, size_t workspace_bytes,
                    void* stream);
+/* SyncBatchNorm (train.py:269-271 `torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)` under DDP): the two fused entries above cut at the point
+ * where the ranks exchange per-channel sums -- the exchange (all-reduce SUM) is the host's, there is no collective at the C-ABI.
+ *   forward :  y5_bn_stats (sums[0..C) = sum z, sums[C..2C) = sum z^2, fp64)  ->  all-reduce(sums), count_total = sum of the ranks' npix
+ *              ->  y5_bn_silu_fwd_from_sums (mean / invstd / running statistics from the global sums, then the apply pass)
+ *   backward:  y5_bn_bwd_stats (this rank's dgamma, dbeta: they ARE the parameter gradients, averaged later like every gradient)
+ *              ->  all-reduce(copy of dgamma, dbeta)  ->  y5_bn_silu_bwd_from_sums (dz from the global sums and count_total)
+ * With one rank (count_total = npix, sums untouched) the pairs compute what y5_bn_silu_fwd / y5_bn_silu_bwd compute. */
+int y5_bn_stats(const void* z, int dtype, long long npix, int C, int ldz, double* sums, void* workspace, size_t workspace_bytes, void* stream);
+int y5_bn_silu_fwd_from_sums(const void* z, int dtype, long long npix, int C, int ldz, const float* gamma, const float* beta, float eps,
+                             float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd, const double* sums,
+                             long long count_total, const void* residual, int ldr, void* y, int ldy, void* stream);
+int y5_bn_bwd_stats(const void* dy, int ld_dy, const void* z, int ldz, int dtype, long long npix, int C, const float* gamma, const float* beta,
+                    const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+int y5_bn_silu_bwd_from_sums(const void* dy, int ld_dy, const void* z, int ldz, int dtype, long long npix, int C, const float* gamma,
+                             const float* beta, const float* save_mean, const float* save_invstd, const float* sum_dgamma, const float* sum_dbeta,
+                             long long count_total, void* dz, int ld_dz, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Training-path glue (fp16 NHWC slices; ld = pixel stride in elements, multiples of 8):

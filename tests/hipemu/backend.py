@@ -9,7 +9,7 @@ from yolov5_amd import _lib
 
 from .emu import aligned, emu
 
-_NP = {torch.float16: np.float16, torch.float32: np.float32, torch.uint8: np.uint8}
+_NP = {torch.float16: np.float16, torch.float32: np.float32, torch.uint8: np.uint8, torch.float64: np.float64}
 
 
 class EmuBackend:

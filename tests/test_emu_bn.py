@@ -70,3 +70,63 @@ def test_emu_bn_silu_fwd_bwd_vs_torch(B, H, W, Cc, dtype, use_res):
     np.testing.assert_allclose(rm, trm.numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(rv, trv.numpy(), rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(bs, dy.astype(np.float32).reshape(-1, Cc).sum(0), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", [np.float16, np.float32])
+def test_emu_sync_bn_split_entries_two_shards_equal_full_batch(dtype):
+    """SyncBatchNorm at the C-ABI (train.py:269-271): two 'ranks' with half of the pixels each -- y5_bn_stats per shard, the host adds the sums
+    (what the all-reduce does), y5_bn_silu_fwd_from_sums / y5_bn_bwd_stats + y5_bn_silu_bwd_from_sums with the global count -- against the fused
+    entries on the whole batch: outputs, saved and running statistics, dz; dgamma / dbeta add up."""
+    lib = emu()
+    B, H, W, Cc = 4, 6, 5, 16
+    npix, half, ld = B * H * W, B * H * W // 2, Cc + 8
+    dt = _lib.Y5_F16 if dtype == np.float16 else _lib.Y5_F32
+    zn = detgen.uniform((npix, Cc), -2, 3, name="sz").astype(dtype)
+    dyn = detgen.uniform((npix, Cc), -1, 1, name="sdy").astype(dtype)
+    z = aligned((npix, ld), dtype, 3.0); z[:, :Cc] = zn
+    d = aligned((npix, ld), dtype, 0.0); d[:, :Cc] = dyn
+    g = aligned((Cc,), np.float32); g[...] = detgen.uniform((Cc,), 0.5, 1.5, name="sg")
+    b = aligned((Cc,), np.float32); b[...] = detgen.uniform((Cc,), -0.5, 0.5, name="sb")
+    nws = lib.y5_bn_workspace_bytes(Cc, npix)
+    ws = aligned((nws,), np.uint8)
+
+    def stats():
+        return (aligned((Cc,), np.float32, 0.0), aligned((Cc,), np.float32, 1.0), aligned((Cc,), np.float32), aligned((Cc,), np.float32))
+
+    rm, rv, sm, si = stats()
+    y = aligned((npix, ld), dtype, -7.0); dz = aligned((npix, ld), dtype, -9.0)
+    dg = aligned((Cc,), np.float32); db = aligned((Cc,), np.float32)
+    assert lib.y5_bn_silu_fwd(ptr(z), dt, npix, Cc, ld, ptr(g), ptr(b), 1e-3, 0.03, ptr(rm), ptr(rv), ptr(sm), ptr(si), None, 0, ptr(y), ld, ptr(ws), nws, None) == 0
+    assert lib.y5_bn_silu_bwd(ptr(d), ld, ptr(z), ld, dt, npix, Cc, ptr(g), ptr(b), ptr(sm), ptr(si), ptr(dz), ld, ptr(dg), ptr(db), ptr(ws), nws, None) == 0
+    # two shards
+    es = z.itemsize
+    shard = [(z.ctypes.data + k * half * ld * es, d.ctypes.data + k * half * ld * es) for k in (0, 1)]
+    sums = [aligned((2 * Cc,), np.float64) for _ in (0, 1)]
+    for k, (zp, _) in enumerate(shard):
+        assert lib.y5_bn_stats(C.c_void_p(zp), dt, half, Cc, ld, ptr(sums[k]), ptr(ws), nws, None) == 0
+    tot = aligned((2 * Cc,), np.float64); tot[...] = sums[0] + sums[1]                 # the all-reduce
+    y2 = aligned((npix, ld), dtype, -7.0); dz2 = aligned((npix, ld), dtype, -9.0)
+    per = []
+    for k, (zp, dp) in enumerate(shard):
+        rm2, rv2, sm2, si2 = stats()
+        yo_ = y2.ctypes.data + k * half * ld * es
+        assert lib.y5_bn_silu_fwd_from_sums(C.c_void_p(zp), dt, half, Cc, ld, ptr(g), ptr(b), 1e-3, 0.03, ptr(rm2), ptr(rv2), ptr(sm2), ptr(si2), ptr(tot),
+                                            npix, None, 0, C.c_void_p(yo_), ld, None) == 0, lib.y5_last_error()
+        dgk = aligned((Cc,), np.float32); dbk = aligned((Cc,), np.float32)
+        assert lib.y5_bn_bwd_stats(C.c_void_p(dp), ld, C.c_void_p(zp), ld, dt, half, Cc, ptr(g), ptr(b), ptr(sm2), ptr(si2), ptr(dgk), ptr(dbk), ptr(ws), nws, None) == 0
+        per.append((rm2, rv2, sm2, si2, dgk, dbk))
+    gsum = aligned((2 * Cc,), np.float32)
+    gsum[:Cc] = per[0][4] + per[1][4]; gsum[Cc:] = per[0][5] + per[1][5]                # the all-reduce of the backward
+    for k, (zp, dp) in enumerate(shard):
+        dzo = dz2.ctypes.data + k * half * ld * es
+        assert lib.y5_bn_silu_bwd_from_sums(C.c_void_p(dp), ld, C.c_void_p(zp), ld, dt, half, Cc, ptr(g), ptr(b), ptr(per[k][2]), ptr(per[k][3]), ptr(gsum),
+                                            C.c_void_p(gsum.ctypes.data + 4 * Cc), npix, C.c_void_p(dzo), ld, None) == 0, lib.y5_last_error()
+    tol = dict(rtol=2e-3, atol=2e-3) if dtype == np.float16 else dict(rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(y2[:, :Cc].astype(np.float32), y[:, :Cc].astype(np.float32), **tol)
+    np.testing.assert_allclose(dz2[:, :Cc].astype(np.float32), dz[:, :Cc].astype(np.float32), **tol)
+    for k in (0, 1):
+        for a, ref in zip(per[k][:4], (rm, rv, sm, si)):
+            np.testing.assert_allclose(a, ref, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(gsum[:Cc], dg, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(gsum[Cc:], db, rtol=1e-4, atol=1e-5)
+    assert np.all(y2[:, Cc:] == -7.0) and np.all(dz2[:, Cc:] == -9.0)

@@ -72,6 +72,23 @@ def test_bn_silu_fwd_bwd(B, H, W, Cc, use_res, dev):
     torch.testing.assert_close(rm.cpu(), trm, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(rv.cpu(), trv, rtol=1e-3, atol=1e-5)
     assert torch.all(yd[:, Cc:] == -7.0) and torch.all(dzd[:, Cc:] == -9.0)
+    # SyncBatchNorm's split entries with ONE rank (count_total = npix, sums untouched) are the fused entries, bit for bit (train.py:269-271 path;
+    # the two-rank exchange itself is tests/test_ddp_gloo.py::test_sync_batchnorm_two_ranks_equal_one_process_full_batch)
+    y2, dz2 = slab(None, -7.0), slab(None, -9.0)
+    rm2, rv2 = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
+    sm2, si2, dg2, db2 = (torch.empty(Cc, device=dev) for _ in range(4))
+    sums = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
+    _lib.check(lib.y5_bn_stats(_p(zd), _lib.Y5_F16, npix, Cc, ld, _p(sums), _p(ws), nws, _st(dev)), lib)
+    _lib.check(lib.y5_bn_silu_fwd_from_sums(_p(zd), _lib.Y5_F16, npix, Cc, ld, _p(g), _p(b), 1e-3, 0.03, _p(rm2), _p(rv2), _p(sm2), _p(si2), _p(sums),
+                                            npix, _p(rd), ld, _p(y2), ld, _st(dev)), lib)
+    _lib.check(lib.y5_bn_bwd_stats(_p(dyd), ld, _p(zd), ld, _lib.Y5_F16, npix, Cc, _p(g), _p(b), _p(sm2), _p(si2), _p(dg2), _p(db2), _p(ws), nws,
+                                   _st(dev)), lib)
+    _lib.check(lib.y5_bn_silu_bwd_from_sums(_p(dyd), ld, _p(zd), ld, _lib.Y5_F16, npix, Cc, _p(g), _p(b), _p(sm2), _p(si2), _p(dg2), _p(db2), npix,
+                                            _p(dz2), ld, _st(dev)), lib)
+    torch.cuda.synchronize()
+    for a, bb in ((y2, yd), (dz2, dzd), (sm2, sm), (si2, si), (rm2, rm), (rv2, rv), (dg2, dg), (db2, db)):
+        assert torch.equal(a, bb)
+    np.testing.assert_allclose(sums[:Cc].cpu().numpy() / npix, z.double().reshape(-1, Cc).mean(0).numpy(), rtol=1e-9, atol=1e-9)
 
 
 WG = [

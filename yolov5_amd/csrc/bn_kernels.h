@@ -22,6 +22,8 @@ struct Y5BnParams {
   float* running_mean; float* running_var;  // optional, updated in place by the stats finish
   float* partial;       // [nblk][2][C]
   float* dgamma; float* dbeta;          // [C]
+  double* sums;         // [2][C] raw sums (MODE 3 finish / y5_bn_from_sums_kernel): what SyncBatchNorm exchanges between ranks
+  long long count;      // pixels the statistics cover (npix of this rank, or of all ranks after the exchange)
   long long npix;
   int C, ldz, ldy, ldr, ldo;
   int nblk;
@@ -149,7 +151,10 @@ void y5_bn_finish_kernel(const Y5BnParams p) {
   }
   if (tid != 0) return;
   s0 = s_red[0]; s1 = s_red[128];
-  if constexpr (MODE == 0) {
+  if constexpr (MODE == 3) {   // raw fp64 sums: the cross-rank exchange of SyncBatchNorm adds them before mean / invstd exist
+    p.sums[c] = s0;
+    p.sums[p.C + c] = s1;
+  } else if constexpr (MODE == 0) {
     const double n = (double)p.npix;
     const double mean = s0 / n;
     double var = s1 / n - mean * mean;
@@ -162,6 +167,22 @@ void y5_bn_finish_kernel(const Y5BnParams p) {
     if (p.dbeta) p.dbeta[c] = (float)s0;
     if (p.dgamma) p.dgamma[c] = (float)s1;
   }
+}
+
+// Batch statistics from (possibly cross-rank) sums over p.count pixels: torch.nn.SyncBatchNorm's forward (train.py:269-271 converts the model) reduces
+// to this once sum z and sum z^2 of all ranks have been added; running statistics use the GLOBAL count (unbiased variance), as there.
+__global__ __launch_bounds__(256)
+void y5_bn_from_sums_kernel(const Y5BnParams p) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= p.C) return;
+  const double n = (double)p.count;
+  const double mean = p.sums[c] / n;
+  double var = p.sums[p.C + c] / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  p.mean[c] = (float)mean;
+  p.invstd[c] = (float)(1.0 / sqrt(var + (double)p.eps));
+  if (p.running_mean) p.running_mean[c] = (1.0f - p.momentum) * p.running_mean[c] + p.momentum * (float)mean;
+  if (p.running_var) p.running_var[c] = (1.0f - p.momentum) * p.running_var[c] + p.momentum * (float)(n > 1.0 ? var * n / (n - 1.0) : var);
 }
 
 // Thread mapping of the two apply kernels (as y5_chan_reduce_kernel): thread = (pixel row r of the block, channel vector cl) with cl FIXED for the
@@ -212,7 +233,7 @@ void y5_bn_silu_bwd_apply_kernel(const Y5BnParams p) {
   const int rows = 256 / lanes_c;
   const int r = threadIdx.x / lanes_c, cl = threadIdx.x - r * lanes_c;
   if (r >= rows) return;
-  const float inv_n = 1.0f / (float)p.npix;
+  const float inv_n = 1.0f / (float)(p.count > 0 ? p.count : p.npix);   // SyncBatchNorm: the sums and the count are those of all ranks
   float mu[N], is[N], ga[N], be[N], db[N], dg[N];
 #pragma unroll
   for (int e = 0; e < N; ++e) {

@@ -328,14 +328,37 @@ class TrainEngine:
             npix = B * y.H * y.W
             st["gamma"], st["beta"] = self._f32(bn.weight), self._f32(bn.bias)
             rm, rv = self._running(bn)
-            _lib.check(lib.y5_bn_silu_fwd(_vp(be.ptr(st["z"])), self.dt, npix, c2, c2, _vp(st["gamma"]), _vp(st["beta"]), float(bn.eps),
-                                          float(bn.momentum if bn.momentum is not None else 0.1), rm, rv, _vp(be.ptr(st["mean"])),
-                                          _vp(be.ptr(st["invstd"])), _vp(self._ptr(res)) if res is not None else None,
-                                          self._ld(res) if res is not None else 0, _vp(self._ptr(y)), self._ld(y), _vp(be.ptr(self.ws)),
-                                          self.ws_bytes, stm), lib)
+            world = self._sync_world(bn)
+            if world > 1:
+                # SyncBatchNorm (train.py:269-271): per-channel sum z / sum z^2 of this rank, all-reduce(SUM) over the ranks (2 C doubles; torch's
+                # SyncBatchNorm all-gathers mean / invstd / count per layer at the same point), statistics of the GLOBAL batch, then the apply pass
+                sums = st.get("sums")
+                if sums is None:
+                    sums = st["sums"] = be.empty((2 * c2,), torch.float64)
+                _lib.check(lib.y5_bn_stats(_vp(be.ptr(st["z"])), self.dt, npix, c2, c2, _vp(be.ptr(sums)), _vp(be.ptr(self.ws)), self.ws_bytes, stm), lib)
+                torch.distributed.all_reduce(be.view_torch(sums))
+                _lib.check(lib.y5_bn_silu_fwd_from_sums(_vp(be.ptr(st["z"])), self.dt, npix, c2, c2, _vp(st["gamma"]), _vp(st["beta"]), float(bn.eps),
+                                                        float(bn.momentum if bn.momentum is not None else 0.1), rm, rv, _vp(be.ptr(st["mean"])),
+                                                        _vp(be.ptr(st["invstd"])), _vp(be.ptr(sums)), npix * world,
+                                                        _vp(self._ptr(res)) if res is not None else None, self._ld(res) if res is not None else 0,
+                                                        _vp(self._ptr(y)), self._ld(y), stm), lib)
+            else:
+                _lib.check(lib.y5_bn_silu_fwd(_vp(be.ptr(st["z"])), self.dt, npix, c2, c2, _vp(st["gamma"]), _vp(st["beta"]), float(bn.eps),
+                                              float(bn.momentum if bn.momentum is not None else 0.1), rm, rv, _vp(be.ptr(st["mean"])),
+                                              _vp(be.ptr(st["invstd"])), _vp(self._ptr(res)) if res is not None else None,
+                                              self._ld(res) if res is not None else 0, _vp(self._ptr(y)), self._ld(y), _vp(be.ptr(self.ws)),
+                                              self.ws_bytes, stm), lib)
             self._running_done(bn)
         if y2 is not None:
             _lib.check(lib.y5_upsample2x(_vp(self._ptr(y)), self.dt, _vp(self._ptr(y2)), B, y.H, y.W, y.C, self._ld(y), self._ld(y2), stm), lib)
+
+    @staticmethod
+    def _sync_world(bn):
+        """World size over which a BatchNorm layer's statistics are shared: > 1 only for torch.nn.SyncBatchNorm modules (what
+        `SyncBatchNorm.convert_sync_batchnorm(model)` of train.py:269-271 leaves behind) inside an initialised process group."""
+        if isinstance(bn, torch.nn.SyncBatchNorm) and torch.distributed.is_available() and torch.distributed.is_initialized():
+            return torch.distributed.get_world_size(bn.process_group) if bn.process_group is not None else torch.distributed.get_world_size()
+        return 1
 
     def _running(self, bn):
         """Device pointers of the BatchNorm running statistics (updated in place by the kernel)."""
@@ -497,10 +520,29 @@ class TrainEngine:
                     _lib.check(lib.y5_train_glue_f32(3, _vp(self._ptr(y, True)), _vp(self._ptr(res, True)), npix, 1, 1, y.C, self._ld(y), self._ld(res),
                                                      1 if is_written(res) else 0, stm), lib)
                 mark(res)
-            _lib.check(lib.y5_bn_silu_bwd(_vp(self._ptr(y, True)), self._ld(y), _vp(be.ptr(st["z"])), c2, self.dt, npix, c2,
-                                          _vp(st["gamma"]), _vp(st["beta"]), _vp(be.ptr(st["mean"])), _vp(be.ptr(st["invstd"])),
-                                          _vp(be.ptr(self.dz)), c2, _vp(self._gptr(m.bn.weight)), _vp(self._gptr(m.bn.bias)),
-                                          _vp(be.ptr(self.ws)), self.ws_bytes, stm), lib)
+            world = self._sync_world(m.bn)
+            if world > 1:
+                # SyncBatchNorm backward: this rank's dgamma / dbeta are the parameter gradients (averaged with all the others later); dz needs the
+                # sums over the GLOBAL batch -- all-reduce(SUM) of a copy, as torch's SyncBatchNorm does with (sum_dy, sum_dy_xmu)
+                _lib.check(lib.y5_bn_bwd_stats(_vp(self._ptr(y, True)), self._ld(y), _vp(be.ptr(st["z"])), c2, self.dt, npix, c2, _vp(st["gamma"]),
+                                               _vp(st["beta"]), _vp(be.ptr(st["mean"])), _vp(be.ptr(st["invstd"])), _vp(self._gptr(m.bn.weight)),
+                                               _vp(self._gptr(m.bn.bias)), _vp(be.ptr(self.ws)), self.ws_bytes, stm), lib)
+                gs = st.get("gsum")
+                if gs is None:
+                    gs = st["gsum"] = be.empty((2 * c2,), torch.float32)
+                ow, ob = self.goff[self._pidx[id(m.bn.weight)]], self.goff[self._pidx[id(m.bn.bias)]]
+                gst, gft = be.view_torch(gs), be.view_torch(self.gflat)
+                gst[:c2].copy_(gft[ow:ow + c2])
+                gst[c2:].copy_(gft[ob:ob + c2])
+                torch.distributed.all_reduce(gst)
+                _lib.check(lib.y5_bn_silu_bwd_from_sums(_vp(self._ptr(y, True)), self._ld(y), _vp(be.ptr(st["z"])), c2, self.dt, npix, c2, _vp(st["gamma"]),
+                                                        _vp(st["beta"]), _vp(be.ptr(st["mean"])), _vp(be.ptr(st["invstd"])), _vp(be.ptr(gs)),
+                                                        _vp(be.ptr(gs) + 4 * c2), npix * world, _vp(be.ptr(self.dz)), c2, stm), lib)
+            else:
+                _lib.check(lib.y5_bn_silu_bwd(_vp(self._ptr(y, True)), self._ld(y), _vp(be.ptr(st["z"])), c2, self.dt, npix, c2,
+                                              _vp(st["gamma"]), _vp(st["beta"]), _vp(be.ptr(st["mean"])), _vp(be.ptr(st["invstd"])),
+                                              _vp(be.ptr(self.dz)), c2, _vp(self._gptr(m.bn.weight)), _vp(self._gptr(m.bn.bias)),
+                                              _vp(be.ptr(self.ws)), self.ws_bytes, stm), lib)
             dz_ptr, ld_dz = be.ptr(self.dz), c2
             grads[self._pidx[id(m.bn.weight)]] = True
             grads[self._pidx[id(m.bn.bias)]] = True

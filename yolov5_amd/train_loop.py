@@ -101,12 +101,12 @@ def host_amp_step(optimizer, parameters, scaler, max_norm=10.0):
 
 
 def train(model, loader, hyp=None, epochs=1, device=None, batch_size=None, cos_lr=False, amp=True, ema=True, world_size=1, rank=-1,
-          optimizer_name="SGD", max_norm=10.0, start_epoch=0, on_batch_end=None, nbs=64, val_loader=None, noval=False):
+          optimizer_name="SGD", max_norm=10.0, start_epoch=0, on_batch_end=None, nbs=64, val_loader=None, noval=False, sync_bn=False):
     """Runs `epochs` epochs over `loader` (iterable of (imgs uint8|float BCHW, targets (nt, 6), *rest), re-iterable, len() = batches
     per epoch).  Returns dict(model, ema, optimizer, scheduler, scaler, mloss per epoch, losses per iteration, lr per epoch).
     rank / world_size as train.py's RANK / WORLD_SIZE (-1 / 1: single process; otherwise torch.distributed is initialised and the
     model is wrapped by smart_DDP).  val_loader: validated once per epoch on rank -1 / 0 with the EMA model (train.py:440-455 -> val_loop.run;
-    noval: only after the final epoch); `results` per validated epoch = (P, R, mAP@.5, mAP@.5:.95, val box / obj / cls loss), `fitness` beside it."""
+    noval: only after the final epoch); sync_bn: train.py:269-271 (`--sync-bn` under DDP: BatchNorm statistics over the global batch); `results` per validated epoch = (P, R, mAP@.5, mAP@.5:.95, val box / obj / cls loss), `fitness` beside it."""
     hyp = dict(HYP_SCRATCH_LOW if hyp is None else hyp)
     device = torch.device(device) if device is not None else next(model.parameters()).device
     nb = len(loader)
@@ -119,6 +119,8 @@ def train(model, loader, hyp=None, epochs=1, device=None, batch_size=None, cos_l
     lf = lr_lambda(epochs, hyp["lrf"], cos_lr)
     scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=lf)          # :248
     ema_obj = ModelEMA(model) if (ema and rank in (-1, 0)) else None                # :251
+    if sync_bn and rank != -1:                                                      # :269-271
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model).to(device)
     model.hyp = hyp                                                                 # :331
     ddp = smart_DDP(model) if rank != -1 and world_size > 1 else model              # :322
     compute_loss = ComputeLoss(model)                                               # :352
