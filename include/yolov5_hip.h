@@ -419,6 +419,17 @@ int y5_bottleneck_cv3_fwd(const void* x, int ldx, const void* w1_packed, const f
                           int ldo, int B, int H, int W, int C, int add, int max_blocks, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Test-time augmentation glue (models/yolo.py:269-312 `_forward_augment`; the three forwards in between are ordinary plan runs).
+ * y5_scale_img   -- utils/torch_utils.py `scale_img(img.flip(f), ratio, gs)` of an NCHW batch: optional flip of the source (2 = up-down,
+ *   3 = left-right), F.interpolate(size = (OH, OW), bilinear, align_corners = False), F.pad to (PH, PW) with pad_value (0.447) at the
+ *   right / bottom.  src: u8 (read as x / 255) | f16 | f32; dst: (B, C, PH, PW) f16 | f32.  fp32 weights as torch; tolerance 1e-6 (fp32).
+ * y5_tta_descale -- `_descale_pred` in place on (rows, no) predictions: [..., :4] /= scale; flip 2: y = img_h - y; flip 3: x = img_w - x.
+ * ------------------------------------------------------------------------------------------------------- */
+int y5_scale_img(const void* src, int src_dtype, int B, int C, int H, int W, int flip, int OH, int OW, int PH, int PW, float pad_value,
+                 void* dst, int dst_dtype, void* stream);
+int y5_tta_descale(void* z, int dtype, long long rows, int no, float scale, int flip, float img_h, float img_w, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * y5_mosaic_batch -- the training input pipeline for a whole batch in one launch: utils/dataloaders.py:798-855 `load_mosaic`
  * (four images resized to the training size by `load_image` :770-790 and tiled on a 2s x 2s canvas of 114s; or, where the hyp['mosaic']
  * gate of :701 sends a sample down the letterbox branch :710-733, that one image on an s x s canvas -- job.canvas), the image half of

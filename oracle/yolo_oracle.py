@@ -249,6 +249,39 @@ def model_forward(cfg, sd, x, training=False, bn_batch_stats=False):
         _BN_TRAIN[0] = False
 
 
+def scale_img(img, ratio=1.0, same_shape=False, gs=32):
+    """utils/torch_utils.py scale_img."""
+    if ratio == 1.0:
+        return img
+    h, w = img.shape[2:]
+    s = (int(h * ratio), int(w * ratio))
+    img = F.interpolate(img, size=s, mode="bilinear", align_corners=False)
+    if not same_shape:
+        h, w = (math.ceil(v * ratio / gs) * gs for v in (h, w))
+    return F.pad(img, [0, w - s[1], 0, h - s[0]], value=0.447)
+
+
+def forward_augment(cfg, sd, x):
+    """models/yolo.py:269-312 `_forward_augment` + `_descale_pred` + `_clip_augmented` (eval mode): returns the concatenated z."""
+    img_size = x.shape[-2:]
+    gs = int(max(model_strides(cfg)))
+    y = []
+    for si, fi in zip((1, 0.83, 0.67), (None, 3, None)):
+        xi = scale_img(x.flip(fi) if fi else x, si, gs=gs)
+        p = model_forward(cfg, sd, xi)[0].clone()
+        p[..., :4] /= si
+        if fi == 2:
+            p[..., 1] = img_size[0] - p[..., 1]
+        elif fi == 3:
+            p[..., 0] = img_size[1] - p[..., 0]
+        y.append(p)
+    nl = len(model_strides(cfg))
+    g = sum(4 ** k for k in range(nl))
+    y[0] = y[0][:, :-(y[0].shape[1] // g)]
+    y[-1] = y[-1][:, (y[-1].shape[1] // g) * 4 ** (nl - 1):]
+    return torch.cat(y, 1)
+
+
 def _model_forward(cfg, sd, x, training=False):
     layers, save = parse_graph(cfg, x.shape[1])
     y = []

@@ -171,6 +171,46 @@ def test_autobalance_follows_oracle():
         ComputeLoss(m, autobalance=True)
 
 
+def test_scale_img_kernel_equals_torch_interpolate_and_pad():
+    """utils/torch_utils.py scale_img (F.interpolate bilinear align_corners=False + F.pad 0.447) and the x.flip(3) in front of it (yolo.py:276)."""
+    import math
+
+    import torch.nn.functional as F
+
+    from yolov5_amd.torch_utils import scale_img
+
+    x = torch.from_numpy(detgen.uniform((2, 3, 50, 70), 0.0, 1.0, name="si", seed=1))
+    for ratio, flip in ((0.83, 3), (0.67, None), (1.0, 3), (0.5, 2), (1.0, None)):
+        src = x.flip(flip) if flip else x
+        if ratio == 1.0:
+            ref = src
+        else:
+            s = (int(50 * ratio), int(70 * ratio))
+            ref = F.interpolate(src, size=s, mode="bilinear", align_corners=False)
+            h, w = (math.ceil(v * ratio / 32) * 32 for v in (50, 70))
+            ref = F.pad(ref, [0, w - s[1], 0, h - s[0]], value=0.447)
+        out = scale_img(x, ratio, gs=32, flip=flip)
+        assert out.shape == ref.shape
+        torch.testing.assert_close(out, ref, rtol=1e-5, atol=2e-6)
+        outh = scale_img(x.half(), ratio, gs=32, flip=flip)
+        torch.testing.assert_close(outh.float(), ref, rtol=2e-3, atol=1e-3)
+
+
+def test_forward_augment_equals_oracle():
+    """model(x, augment=True) (models/yolo.py:269-312) on the kernels: three plan runs + y5_scale_img / y5_tta_descale against oracle.forward_augment
+    (pinned to the live reference in tests/test_oracle_vs_reference.py)."""
+    m = _model().eval()
+    x = torch.from_numpy(detgen.uniform((2, 3, 64, 96), 0.0, 1.0, name="tta", seed=5))
+    with torch.no_grad():
+        z, none = m(x, augment=True)
+        zo = yo.forward_augment(yo.model_cfg("yolov5n"), yo.det_state_dict(yo.model_cfg("yolov5n"), 0, fused=False), x)
+    assert none is None and z.shape == zo.shape
+    np.testing.assert_allclose(z.numpy(), zo.numpy(), rtol=2e-4, atol=5e-4)
+    zs = m(x)[0]                                             # the plain forward is untouched by the in-place de-scaling
+    np.testing.assert_allclose(zs.numpy(), yo.model_forward(yo.model_cfg("yolov5n"), yo.det_state_dict(yo.model_cfg("yolov5n"), 0, fused=False), x)[0].numpy(),
+                               rtol=1e-4, atol=2e-4)
+
+
 def test_forward_and_nms_under_inference_mode():
     """detect.py / val.py run under `smart_inference_mode` (utils/torch_utils.py:34-43 -> torch.inference_mode).  Inference tensors
     have no version counter; the engine's outputs therefore stay ordinary tensors (the objectness-hint tag keeps working), and NMS of a genuine

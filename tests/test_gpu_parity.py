@@ -269,6 +269,23 @@ def test_uint8_input_scaling(dev):
     torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
 
 
+def test_forward_augment_on_gpu_vs_oracle(dev):
+    """model(x, augment=True) (models/yolo.py:269-312: scales 1 / 0.83 / 0.67 + left-right flip, _descale_pred, _clip_augmented) on the MI355X:
+    y5_scale_img + three plan runs + y5_tta_descale against oracle.forward_augment (pinned to the live reference on CPU); fp32 input tight,
+    fp16 input inside the fp16 envelope of the plain forward."""
+    m = _det_model("yolov5n", 0).to(dev).eval()
+    cfg = yo.model_cfg("yolov5n")
+    x = torch.from_numpy(detgen.uniform((2, 3, 96, 128), 0.0, 1.0, name="tta", seed=5))
+    with torch.no_grad():
+        zo = yo.forward_augment(cfg, yo.det_state_dict(cfg, 0, fused=False), x).numpy()
+        z, none = m(x.to(dev), augment=True)
+        z16 = m(x.half().to(dev), augment=True)[0]
+    assert none is None and tuple(z.shape) == zo.shape
+    np.testing.assert_allclose(z.float().cpu().numpy(), zo, rtol=1e-3, atol=2e-3)
+    d = np.abs(z16.float().cpu().numpy() - zo)
+    assert d[..., :4].max() < 1.0 and d[..., 4:].max() < 3e-2
+
+
 def test_single_layer_forward_api(dev):
     from yolov5_amd.common import C3, SPPF, Conv
 

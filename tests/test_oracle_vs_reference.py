@@ -72,6 +72,25 @@ def test_autobalance_matches_live_reference(ns):
     assert bal[1] == 1.0 and bal[0] != 4.0
 
 
+def test_forward_augment_matches_live_reference(ns):
+    """models/yolo.py:269-312 (TTA: scales 1 / 0.83 / 0.67 + left-right flip, _descale_pred, _clip_augmented): the live reference's
+    model(x, augment=True) against oracle.forward_augment on the same weights."""
+    import os
+
+    torch.manual_seed(0)
+    m = ns.yolo.DetectionModel(os.path.join(ns.root, "models/yolov5n.yaml"))
+    cfg = yo.model_cfg("yolov5n")
+    sd = yo.det_state_dict(cfg, 3, fused=False)
+    m.load_state_dict(sd)
+    m.eval()
+    x = torch.from_numpy(detgen.uniform((2, 3, 96, 128), 0.0, 1.0, name="tta", seed=5))
+    with torch.no_grad():
+        zr = m(x, augment=True)[0]
+        zo = yo.forward_augment(cfg, sd, x)
+    assert zr.shape == zo.shape
+    torch.testing.assert_close(zo, zr, rtol=1e-5, atol=1e-5)
+
+
 def test_nms_matches_live_reference(ns):
     pred = detgen.synth_predictions(2, 1500, 85, obj_pow=3, seed=41)
     with ref_shim.oracle_nms_mode():

@@ -136,3 +136,96 @@ extern "C" int y5_letterbox_batch(const y5_letterbox_job* jobs_dev, int B, int H
   hipLaunchKernelGGL(y5_letterbox_kernel, dim3((unsigned)((lanes + 255) / 256), B), dim3(256), 0, static_cast<hipStream_t>(stream_), p);
   return y5_check_launch("y5_letterbox_batch");
 }
+
+// ---- test-time augmentation glue (models/yolo.py:269-312 `_forward_augment`) ---------------------------------------------------------------
+// y5_scale_img: utils/torch_utils.py `scale_img(img.flip(f), ratio, gs)` for a whole NCHW batch in one launch: optional flip of the SOURCE (2 = up-down,
+// 3 = left-right, as torch's dim index), F.interpolate(size = (OH, OW), mode = "bilinear", align_corners = False) -- source index
+// (dst + 0.5) * (in / out) - 0.5 clamped at 0, the +1 neighbour clamped at the border, weights in fp32 -- and F.pad to (PH, PW) with `pad_value`
+// (0.447, the ImageNet mean) on the right / bottom.  src u8 is read as x / 255 (the `im.half() / 255` of val.py:262 folded in).
+namespace {
+struct ScaleParams {
+  const void* src; void* dst;
+  int src_dtype, dst_dtype, B, C, H, W, OH, OW, PH, PW, flip;
+  float pad, sh, sw;
+};
+template <typename T> __device__ inline float load_px(const void* p, size_t i);
+template <> __device__ inline float load_px<unsigned char>(const void* p, size_t i) { return (float)static_cast<const unsigned char*>(p)[i] / 255.0f; }
+template <> __device__ inline float load_px<_Float16>(const void* p, size_t i) { return (float)static_cast<const _Float16*>(p)[i]; }
+template <> __device__ inline float load_px<float>(const void* p, size_t i) { return static_cast<const float*>(p)[i]; }
+
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256)
+void y5_scale_img_kernel(const ScaleParams p) {
+  const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long per = (long long)p.PH * p.PW;
+  if (id >= per) return;
+  const int plane = blockIdx.y;                     // b * C + c
+  const int oy = (int)(id / p.PW), ox = (int)(id - (long long)oy * p.PW);
+  float v = p.pad;
+  if (oy < p.OH && ox < p.OW) {
+    float fy = p.sh * ((float)oy + 0.5f) - 0.5f, fx = p.sw * ((float)ox + 0.5f) - 0.5f;   // area_pixel_compute_source_index, align_corners = False
+    fy = fy < 0.f ? 0.f : fy;
+    fx = fx < 0.f ? 0.f : fx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < p.H - 1 ? 1 : 0), x1 = x0 + (x0 < p.W - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    auto at = [&](int y, int x) {
+      if (p.flip == 2) y = p.H - 1 - y;
+      if (p.flip == 3) x = p.W - 1 - x;
+      return load_px<TS>(p.src, ((size_t)plane * p.H + y) * p.W + x);
+    };
+    v = (1.f - ly) * ((1.f - lx) * at(y0, x0) + lx * at(y0, x1)) + ly * ((1.f - lx) * at(y1, x0) + lx * at(y1, x1));
+  }
+  static_cast<TD*>(p.dst)[(size_t)plane * per + id] = (TD)v;
+}
+
+struct DescaleParams { void* z; long long rows; int no; float inv_scale, img_h, img_w; int flip; };
+// models/yolo.py:283-299 `_descale_pred` (inplace): p[..., :4] /= scale; flip 2: y = img_h - y; flip 3: x = img_w - x
+template <typename T>
+__global__ __launch_bounds__(256)
+void y5_tta_descale_kernel(const DescaleParams p) {
+  const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= p.rows) return;
+  T* q = static_cast<T*>(p.z) + r * p.no;
+  float x = (float)q[0] / p.inv_scale, y = (float)q[1] / p.inv_scale;   // (inv_scale holds the scale: a division, like the reference)
+  const float w = (float)q[2] / p.inv_scale, h = (float)q[3] / p.inv_scale;
+  if (p.flip == 2) y = p.img_h - y;
+  if (p.flip == 3) x = p.img_w - x;
+  q[0] = (T)x; q[1] = (T)y; q[2] = (T)w; q[3] = (T)h;
+}
+}  // namespace
+
+extern "C" int y5_scale_img(const void* src, int src_dtype, int B, int Cn, int H, int W, int flip, int OH, int OW, int PH, int PW, float pad_value,
+                            void* dst, int dst_dtype, void* stream_) {
+  if (!src || !dst) return y5_fail(Y5_ERR_BAD_ARG, "scale_img: null pointer");
+  if (B < 1 || Cn < 1 || H < 1 || W < 1 || OH < 1 || OW < 1 || PH < OH || PW < OW || (long long)B * Cn > 65535)
+    return y5_fail(Y5_ERR_BAD_ARG, "scale_img: bad sizes (need PH >= OH, PW >= OW, B * C <= 65535)");
+  if (flip != 0 && flip != 2 && flip != 3) return y5_fail(Y5_ERR_BAD_ARG, "scale_img: flip must be 0, 2 (up-down) or 3 (left-right)");
+  if ((src_dtype != Y5_U8 && src_dtype != Y5_F16 && src_dtype != Y5_F32) || (dst_dtype != Y5_F16 && dst_dtype != Y5_F32))
+    return y5_fail(Y5_ERR_BAD_ARG, "scale_img: src u8 / f16 / f32, dst f16 / f32");
+  ScaleParams p{};
+  p.src = src; p.dst = dst; p.src_dtype = src_dtype; p.dst_dtype = dst_dtype; p.B = B; p.C = Cn; p.H = H; p.W = W; p.OH = OH; p.OW = OW;
+  p.PH = PH; p.PW = PW; p.flip = flip; p.pad = pad_value; p.sh = (float)H / (float)OH; p.sw = (float)W / (float)OW;
+  const dim3 g((unsigned)(((long long)PH * PW + 255) / 256), (unsigned)(B * Cn));
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+#define Y5_SI(TS, TD) hipLaunchKernelGGL((y5_scale_img_kernel<TS, TD>), g, dim3(256), 0, st, p)
+  if (dst_dtype == Y5_F16) {
+    if (src_dtype == Y5_U8) Y5_SI(unsigned char, _Float16); else if (src_dtype == Y5_F16) Y5_SI(_Float16, _Float16); else Y5_SI(float, _Float16);
+  } else {
+    if (src_dtype == Y5_U8) Y5_SI(unsigned char, float); else if (src_dtype == Y5_F16) Y5_SI(_Float16, float); else Y5_SI(float, float);
+  }
+#undef Y5_SI
+  return y5_check_launch("y5_scale_img");
+}
+
+extern "C" int y5_tta_descale(void* z, int dtype, long long rows, int no, float scale, int flip, float img_h, float img_w, void* stream_) {
+  if (!z || rows < 1 || no < 4 || !(scale > 0.f)) return y5_fail(Y5_ERR_BAD_ARG, "tta_descale: bad args");
+  if (flip != 0 && flip != 2 && flip != 3) return y5_fail(Y5_ERR_BAD_ARG, "tta_descale: flip must be 0, 2 or 3");
+  if (dtype != Y5_F16 && dtype != Y5_F32) return y5_fail(Y5_ERR_BAD_ARG, "tta_descale: dtype must be f16 or f32");
+  DescaleParams p{z, rows, no, scale, img_h, img_w, flip};
+  const dim3 g((unsigned)((rows + 255) / 256));
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (dtype == Y5_F16) hipLaunchKernelGGL(y5_tta_descale_kernel<_Float16>, g, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(y5_tta_descale_kernel<float>, g, dim3(256), 0, st, p);
+  return y5_check_launch("y5_tta_descale");
+}

@@ -124,6 +124,32 @@ class HipDDP(nn.Module):
         return grads
 
 
+def scale_img(img, ratio=1.0, same_shape=False, gs=32, flip=None):
+    """utils/torch_utils.py `scale_img` (+ the `x.flip(fi)` of models/yolo.py:276 folded in as `flip` = 2 | 3): bilinear resize of an NCHW float
+    batch by `ratio` and padding with 0.447 to a multiple of `gs`, one `y5_scale_img` launch.  ratio == 1: the (flipped) image, unpadded, like
+    the reference."""
+    import ctypes as C
+
+    from . import _lib
+    if img.dtype not in (torch.float16, torch.float32) or img.dim() != 4 or not _lib.accepts(img):
+        raise TypeError("scale_img: a float16 / float32 NCHW GPU batch is expected")
+    img = img.contiguous()
+    B, Cn, h, w = (int(v) for v in img.shape)
+    if ratio == 1.0:
+        s, (ph, pw) = (h, w), (h, w)
+        if flip is None:
+            return img
+    else:
+        s = (int(h * ratio), int(w * ratio))
+        ph, pw = s if same_shape else tuple(math.ceil(v * ratio / gs) * gs for v in (h, w))
+    out = torch.empty((B, Cn, ph, pw), dtype=img.dtype, device=img.device)
+    code = _lib.Y5_F16 if img.dtype == torch.float16 else _lib.Y5_F32
+    lib = _lib.lib()
+    _lib.check(lib.y5_scale_img(C.c_void_p(img.data_ptr()), code, B, Cn, h, w, int(flip or 0), s[0], s[1], ph, pw, 0.447,
+                                C.c_void_p(out.data_ptr()), code, _lib.stream(img.device)), lib)
+    return out
+
+
 def smart_DDP(model):
     """utils/torch_utils.py:61-70 (one process per GPU under torchrun; `nccl` = RCCL on ROCm)."""
     return HipDDP(model)

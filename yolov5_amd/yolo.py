@@ -243,8 +243,41 @@ class DetectionModel(BaseModel):
 
     def forward(self, x, augment=False, profile=False):
         if augment:
-            raise NotImplementedError("test-time augmentation (_forward_augment, yolo.py:269-312) is outside the hot path")
+            return self._forward_augment(x)
         return self._forward_once(x, profile)
+
+    def _forward_augment(self, x):
+        """models/yolo.py:269-282: three forwards (scales 1 / 0.83 / 0.67, the middle one left-right flipped), predictions de-scaled / de-flipped
+        (`_descale_pred`, :283-299, one in-place launch each) and concatenated without the overlapping tails (`_clip_augmented`, :301-312)."""
+        import ctypes as C
+
+        from . import _lib
+        from .torch_utils import scale_img
+        if self.training:
+            raise RuntimeError("augmented inference runs in eval mode")
+        img_size = x.shape[-2:]
+        gs = int(self.stride.max())
+        lib, y = _lib.lib(), []
+        for si, fi in zip((1, 0.83, 0.67), (None, 3, None)):
+            xi = scale_img(x, si, gs=gs, flip=fi)
+            yi = self._forward_once(xi)[0].clone()      # (the plan owns its z; the de-scaling below is in place)
+            code = _lib.Y5_F16 if yi.dtype == torch.float16 else _lib.Y5_F32
+            _lib.check(lib.y5_tta_descale(C.c_void_p(yi.data_ptr()), code, yi.shape[0] * yi.shape[1], yi.shape[2], float(si), int(fi or 0),
+                                          float(img_size[0]), float(img_size[1]), _lib.stream(yi.device)), lib)
+            y.append(yi)
+        y = self._clip_augmented(y)
+        return torch.cat(y, 1), None
+
+    def _clip_augmented(self, y):
+        """models/yolo.py:301-312."""
+        nl = self.model[-1].nl
+        g = sum(4 ** k for k in range(nl))
+        e = 1
+        i = (y[0].shape[1] // g) * sum(4 ** k for k in range(e))
+        y[0] = y[0][:, :-i]
+        i = (y[-1].shape[1] // g) * sum(4 ** (nl - 1 - k) for k in range(e))
+        y[-1] = y[-1][:, i:]
+        return y
 
     def _initialize_biases(self, cf=None):
         """models/yolo.py:314-327."""
