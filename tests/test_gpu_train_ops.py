@@ -88,7 +88,7 @@ def test_bn_silu_fwd_bwd(B, H, W, Cc, use_res, dev):
     torch.cuda.synchronize()
     for a, bb in ((y2, yd), (dz2, dzd), (sm2, sm), (si2, si), (rm2, rm), (rv2, rv), (dg2, dg), (db2, db)):
         assert torch.equal(a, bb)
-    np.testing.assert_allclose(sums[:Cc].cpu().numpy() / npix, z.double().reshape(-1, Cc).mean(0).numpy(), rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(sums[:Cc].cpu().numpy() / npix, z.double().reshape(-1, Cc).mean(0).numpy(), rtol=1e-6, atol=1e-7)   # (the per-block partial sums are fp32)
 
 
 WG = [
