@@ -3,8 +3,8 @@
 
     python scripts/rocprof_frac.py <..._kernel_trace.csv> [--gbytes G] [--out f.json]
 
-A forward is the run of dispatches from one stem launch (y5_conv_stem_kernel) to the next; the conv launches inside it
-(igemm / h3 / pw / k3 / stem / bneck / pw_head) are summed per forward from the trace's own begin/end timestamps (pure kernel
+A forward is the run of dispatches from one launch of the network's first kernel (y5_conv_front_kernel where the fused front is the plan's
+choice, else y5_conv_stem_kernel) to the next; the conv launches inside it (front / igemm / h3 / pw / k3 / stem / bneck / pw_head) are summed per forward from the trace's own begin/end timestamps (pure kernel
 durations: no dispatch gaps, so this sum is a lower bound of the in-situ event-to-event figure bench.py uses).  Groups that
 are not whole forwards (autotune bursts, isolated per-op timing) have a different launch count and are dropped by keeping the
 most common count only.  mfma_frac = algorithmic GFLOP / median sum / 2500 TFLOP/s (bench.py roofline.frac);
@@ -12,7 +12,7 @@ hbm frac = algorithmic GB (bench.py's `algorithmic_gbytes_per_step`) / median su
 """
 import argparse, collections, csv, json, statistics, sys
 
-CONV = ("conv_igemm", "conv_h3", "conv_pw", "conv_k3", "conv_stem", "conv_bneck")
+CONV = ("conv_igemm", "conv_h3", "conv_pw", "conv_k3", "conv_stem", "conv_bneck", "conv_front")
 
 
 def main():
@@ -29,9 +29,14 @@ def main():
             continue
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), k))
     rows.sort()
+    # the kernel that opens a forward: the fused front if the trace has MORE launches of it than of the stand-alone stem (whose remaining launches
+    # are then the plan builder's timing of the alternative), else the stem
+    n_front = sum("conv_front" in k for _, _, k in rows)
+    n_stem = sum("conv_stem" in k for _, _, k in rows)
+    first = "conv_front" if n_front > n_stem else "conv_stem"
     groups, cur = [], None
     for s, e, k in rows:
-        if "conv_stem" in k:
+        if first in k:
             if cur:
                 groups.append(cur)
             cur = []
