@@ -5,7 +5,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp Y5_TUNE_CACHE=/tmp/tc_fwd.json Y5_GRAPH=0
 # fusion decisions forced on (what the timing at plan build picks on this part): the profiled process launches no fused-vs-unfused timing kernels
-export Y5_FUSED_K3PW=1 Y5_FUSED_CV3=1 Y5_FUSED_HEAD=1
+export Y5_FUSED_K3PW=1 Y5_FUSED_CV3=1 Y5_FUSED_HEAD=1 Y5_FUSED_FRONT=1
 N=10
 python scripts/forward_only.py 2 > /dev/null 2>&1   # fills the tile-choice cache: the profiled runs launch no timing kernels
 for C in FETCH_SIZE WRITE_SIZE; do
@@ -23,7 +23,7 @@ for f in glob.glob('gpurun_out/pmcf_*/**/*counter_collection.csv', recursive=Tru
         if 'y5_' not in k: continue
         tot[k][r['Counter_Name']] += float(r['Counter_Value'])
         if r['Counter_Name'] == 'FETCH_SIZE': cnt[k] += 1
-conv = lambda k: any(s in k for s in ('conv_igemm', 'conv_h3', 'conv_pw', 'conv_k3', 'conv_stem', 'conv_bneck'))
+conv = lambda k: any(s in k for s in ('conv_igemm', 'conv_h3', 'conv_pw', 'conv_k3', 'conv_stem', 'conv_bneck', 'conv_front'))
 def gb(keys, name, mult): return sum(tot[k][name] for k in keys) * 1024 * mult / N / 1e9   # counters are in KiB
 ck = [k for k in tot if conv(k)]; ok = [k for k in tot if not conv(k)]
 out = {"forwards": N, "conv_launches_per_forward": sum(cnt[k] for k in ck) / N,
