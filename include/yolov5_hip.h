@@ -189,7 +189,8 @@ int y5_nms_batched_hint(const void* pred, int dtype, int bs, int n, int no, int 
  * 64 x output channels by 64 y k columns, x, y in {1,2} -- more tiles, fewer splits, less atomic traffic), 3 = the patch-staged kernel
  * of the 3x3 layers (k3 p1, stride 1 or 2: one workgroup owns all nine taps of a channel tile and stages spatial patches
  * -- the activation travels to LDS ~3 times instead of 9; wins where a filter element sees many pixels, P1-P3), 3xy = the
- * same with its channel tile capped at 32 x output channels by 32 y input channels (x in {1,2,4}, y in {1,2});
+ * same with its channel tile capped at 32 x output channels by 32 y input channels (x in {1,2,4}, y in {1,2}), 6 = the stem
+ * kernel (0.Conv on the paired-pixel view: k(6,3) s(2,1) p(2,1), C1 = 8, ldx = 8; the automatic choice for that geometry);
  * Y5_ERR_BAD_ARG if cfg >= 3 is asked for another geometry:
  *   dw_packed[n][k] += sum_pixels dz[pixel][n] * im2col(x)[pixel][k]     fp32, layout [Npad][Kpad] of w_packed.
  * The caller zero-fills dw_packed; accumulation uses fp32 atomics (split over the pixel range).  x, dz: fp16 NHWC

@@ -87,12 +87,43 @@ def k3_ab(a, dev, lib, st):
     print(f"TOTAL 3x3 layers: general {tot[1] / 1e3:.3f} ms, patch-staged {tot[3] / 1e3:.3f} ms per step")
 
 
+def stem_ab(a, dev, lib, st):
+    B, H, W, C2 = a.batch, 640, 320, 32
+    OH, OW = 320, 320
+    per = (B * H * W * 8 + B * OH * OW * C2) * 2
+    nrot = 2
+    xs = [torch.randn((B, H, W, 8), device=dev).half() for _ in range(nrot)]
+    dzs = [torch.randn((B, OH, OW, C2), device=dev).half() for _ in range(nrot)]
+    dw = torch.zeros((32, 192), device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    outs = {}
+    for cfg, fs in ((1, (1.5, 2, 3, 4, 6)), (6, (1, 2, 3, 4, 6, 8))):
+        best = (float("inf"), 0)
+        for f in fs:
+            mb = int(f * 256) // (2 if cfg == 1 else 1)
+            d = _lib.ConvDesc(dtype=_lib.Y5_F16, B=B, H=H, W=W, C1=8, ldx=8, OH=OH, OW=OW, C2=C2, ldy=C2, KH=6, KW=3, SH=2, SW=1, PH=2, PW=1, act=0,
+                              Kpad=192, Npad=32, cfg=cfg, max_blocks=mb)
+            dw.zero_()
+            _lib.check(lib.y5_conv2d_wgrad(C.byref(d), C.c_void_p(xs[0].data_ptr()), C.c_void_p(dzs[0].data_ptr()), C2, C.c_void_p(dw.data_ptr()), st), lib)
+            if f == fs[0]:
+                outs[cfg] = dw.clone()
+            e0.record()
+            for i in range(a.iters):
+                lib.y5_conv2d_wgrad(C.byref(d), C.c_void_p(xs[i % nrot].data_ptr()), C.c_void_p(dzs[i % nrot].data_ptr()), C2, C.c_void_p(dw.data_ptr()), st)
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, (e0.elapsed_time(e1) / a.iters * 1e3, mb))
+        print(f"stem wgrad cfg {cfg}: {best[0]:7.1f} us (splits {best[1]}), HBM time {per / 5.8e12 * 1e6:.1f} us", flush=True)
+    print("rel diff", ((outs[1] - outs[6]).abs().max() / outs[1].abs().max()).item())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--k3-ab", action="store_true", help="3x3 layers only: general gather kernel (cfg 1) against the patch-staged family (cfg 3, csrc/wgrad3.h), "
                     "each at its best split count, on ROTATING buffers (> 600 MB per layer: no Infinity-Cache residency between launches)")
+    ap.add_argument("--stem", action="store_true", help="0.Conv's weight gradient (paired-pixel view, 64 x 640 x 320 x 8 -> 32 channels): general kernel (cfg 1) vs the stem kernel (cfg 6)")
     ap.add_argument("--det", action="store_true", help="--k3-ab: time y5_conv2d_wgrad_det (per-split slabs + ordered reduction) instead of the atomic form")
     ap.add_argument("--only", default="", help="--k3-ab: comma list of input sizes H to keep (stride-1 layers only when given)")
     ap.add_argument("--cfgs", default="1,3", help="--k3-ab: kernel families to time")
@@ -101,6 +132,8 @@ def main():
     dev = torch.device("cuda:0")
     lib = _lib.lib()
     st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    if a.stem:
+        return stem_ab(a, dev, lib, st)
     if a.k3_ab:
         return k3_ab(a, dev, lib, st)
     tot_ms, tot_fl = 0.0, 0.0

@@ -90,6 +90,23 @@ def test_emu_wgrad_k3_families_match_torch(case, cfg):
     assert np.all(dw[C2:] == 0) and np.all(dw[:, K:] == 0)
 
 
+@pytest.mark.parametrize("B,H,W,C2,splits,cfg", [(1, 24, 40, 32, 0, 6), (2, 10, 17, 32, 3, 6), (1, 12, 36, 24, 2, -1), (2, 8, 16, 40, 0, 6), (1, 24, 40, 32, 0, 1)])
+def test_emu_wgrad_stem_kernel_matches_torch(B, H, W, C2, splits, cfg):
+    """cfg 6 (csrc/wgrad3.h y5_conv_wgrad_stem_kernel): 0.Conv's weight gradient on the paired-pixel view -- k(6,3) s(2,1) p(2,1), 8 channels, pixels
+    contiguous (ldx = 8) -- against torch's conv2d weight gradient of the same geometry; -1 = the library's automatic choice (the stem kernel), 1 = the
+    general gather kernel on the same buffers."""
+    lib = emu()
+    x = torch.from_numpy(detgen.uniform((B, 8, H, W), -1, 1, name="stx")).half()
+    OH, OW = (H + 4 - 6) // 2 + 1, W
+    dz = torch.from_numpy(detgen.uniform((B, C2, OH, OW), -1, 1, name="stdz")).half()
+    dw, K, Kpad = run_wgrad(lib, x, dz, (6, 3), (2, 1), (2, 1), splits, ldx_extra=0, cfg=cfg)
+    w = torch.zeros((C2, 8, 6, 3), requires_grad=True)
+    F.conv2d(x.float(), w, None, (2, 1), (2, 1)).backward(dz.float())
+    ref = w.grad.permute(0, 2, 3, 1).reshape(C2, K).numpy()
+    np.testing.assert_allclose(dw[:C2, :K], ref, rtol=2e-3, atol=2e-3)
+    assert np.all(dw[C2:] == 0) and np.all(dw[:, K:] == 0)
+
+
 def test_emu_wgrad_cfg3_refuses_other_geometries():
     lib = emu()
     x = torch.zeros((1, 32, 6, 6)).half()

@@ -152,6 +152,43 @@ def test_conv_wgrad_patch_staged(case, cfg, splits, det, dev):
     assert torch.all(outs[0][C2:] == 0) and torch.all(outs[0][:, K:] == 0)
 
 
+@pytest.mark.parametrize("B,H,W,C2,splits,det", [(4, 128, 64, 32, 0, False), (2, 66, 41, 32, 7, True), (8, 640, 320, 32, 0, False)])
+def test_conv_wgrad_stem_kernel(B, H, W, C2, splits, det, dev):
+    """cfg 6 (y5_conv_wgrad_stem_kernel): 0.Conv's weight gradient on the paired-pixel view (k(6,3) s(2,1) p(2,1), 8 channels, ldx = 8) on the MI355X
+    vs torch-CPU; the last case is the benchmark's geometry at bs = 8; also == the general kernel (cfg 1) within fp32 association."""
+    from yolov5_amd import _lib
+    from yolov5_amd.packing import round_up
+
+    lib = _lib.lib()
+    OH, OW = (H + 4 - 6) // 2 + 1, W
+    x = torch.from_numpy(detgen.uniform((B, 8, H, W), -1, 1, name="gsx")).half()
+    dz = torch.from_numpy(detgen.uniform((B, C2, OH, OW), -1, 1, name="gsdz")).half() * 0.1
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    dzd = dz.permute(0, 2, 3, 1).contiguous().to(dev)
+    K, Kpad, Npad = 144, 192, round_up(C2, 32)
+    outs = {}
+    for cfg in (6, 1):
+        d = _lib.ConvDesc(dtype=_lib.Y5_F16, B=B, H=H, W=W, C1=8, ldx=8, OH=OH, OW=OW, C2=C2, ldy=C2, KH=6, KW=3, SH=2, SW=1, PH=2, PW=1, act=0,
+                          Kpad=Kpad, Npad=Npad, cfg=cfg, max_blocks=splits)
+        dw = torch.zeros((Npad, Kpad), dtype=torch.float32, device=dev)
+        if det and cfg == 6:
+            need = lib.y5_conv2d_wgrad_ws_bytes(C.byref(d), C2)
+            ws = torch.full((need // 4,), float("nan"), dtype=torch.float32, device=dev)
+            _lib.check(lib.y5_conv2d_wgrad_det(C.byref(d), _p(xd), _p(dzd), C2, _p(dw), _p(ws), need, _st(dev)), lib)
+        else:
+            _lib.check(lib.y5_conv2d_wgrad(C.byref(d), _p(xd), _p(dzd), C2, _p(dw), _st(dev)), lib)
+        torch.cuda.synchronize()
+        outs[cfg] = dw.cpu()
+    scale = float(outs[1].abs().max())
+    torch.testing.assert_close(outs[6], outs[1], rtol=1e-4, atol=1e-4 * scale)
+    if B * H * W <= 4 * 128 * 64:
+        w = torch.zeros((C2, 8, 6, 3), requires_grad=True)
+        F.conv2d(x.float(), w, None, (2, 1), (2, 1)).backward(dz.float())
+        ref = w.grad.permute(0, 2, 3, 1).reshape(C2, K)
+        torch.testing.assert_close(outs[6][:C2, :K], ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
+    assert torch.all(outs[6][C2:] == 0) and torch.all(outs[6][:, K:] == 0)
+
+
 @pytest.mark.parametrize("case", WG)
 def test_conv_wgrad(case, dev):
     from yolov5_amd import _lib

@@ -12,6 +12,8 @@
 // row advance incrementally (no integer division in the loop).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 
 #include "../../include/yolov5_hip.h"
 #include "y5_common.h"
@@ -297,6 +299,51 @@ static int wgrad_impl(const y5_conv_desc* d, const void* x, const void* dz, int 
   // d->cfg selects the kernel family: -1 / 0 = automatic (by pixels per filter element), 1 = the general im2col-gather kernel, 3 / 3xy = the patch-staged 3x3
   // kernel (wgrad3.h).  Which one is faster depends on pixels per filter element (measured, profiles/r03/r03_wgrad3_ab.log): TrainEngine times both.
   const bool can3 = d->KH == 3 && d->KW == 3 && d->PH == 1 && d->PW == 1 && d->SH == d->SW && (d->SH == 1 || d->SH == 2) && d->C2 * 9LL * d->C1 > 0;
+  // cfg 6: the stem kernel (wgrad3.h): k(6,3) s(2,1) p(2,1) on the 8-channel paired-pixel view of the 3-channel image, contiguous pixels (ldx == 8)
+  const bool can6 = d->KH == 6 && d->KW == 3 && d->SH == 2 && d->SW == 1 && d->PH == 2 && d->PW == 1 && d->C1 == 8 && d->ldx == 8 && p.Kpad >= 144;
+  if (d->cfg == 6 && !can6) return y5_fail(Y5_ERR_BAD_ARG, "wgrad: cfg 6 (stem kernel) needs the paired-pixel stem geometry");
+  if (can6 && (d->cfg == 6 || d->cfg <= 0)) {
+    static const int variant = [] { const char* e = getenv("Y5_WG_STEM"); return e ? atoi(e) : 26; }();   // experiment knob: <segments per chunk><ring depth>
+    const int NSEG = variant / 10;
+    p.tiles_n = (d->C2 + 31) / 32;
+    p.tiles_k = 1;
+    const long long segs = (long long)d->B * oh * ((ow + 15) / 16);
+    const long long chunks = (segs + NSEG - 1) / NSEG;
+    long long splits = d->max_blocks > 0 ? d->max_blocks : (3 * ncu + p.tiles_n - 1) / p.tiles_n;
+    const long long max_splits = (chunks + 3) / 4;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    const long long cps = (chunks + splits - 1) / splits;
+    p.pix_per_split = (int)(NSEG * cps);
+    p.splits = (int)((chunks + cps - 1) / cps);
+    const long long grid = (long long)p.tiles_n * p.splits;
+    const size_t ws_need = (size_t)p.splits * p.Npad * p.Kpad * sizeof(float);
+    if (need) { *need = ws_need; return Y5_OK; }
+    if (det && (ws_bytes < ws_need || ((uintptr_t)ws & 15))) return y5_fail(Y5_ERR_BAD_ARG, "wgrad: workspace too small (y5_conv2d_wgrad_ws_bytes) or misaligned");
+    p.ws = ws;
+#define Y5_STEM(NS, SS)                                                                                                            \
+  case NS * 10 + SS: {                                                                                                             \
+    constexpr size_t bytes = (size_t)SS * (NS * 16 * 64 + ((NS * 6 * 20 * 16 + 1023) / 1024) * 1024 + 64);                         \
+    static bool attr = false;                                                                                                      \
+    if (!attr) {                                                                                                                   \
+      hipFuncSetAttribute(reinterpret_cast<const void*>(y5_conv_wgrad_stem_kernel<NS, SS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      hipFuncSetAttribute(reinterpret_cast<const void*>(y5_conv_wgrad_stem_kernel<NS, SS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+      attr = true;                                                                                                                 \
+    }                                                                                                                              \
+    if (det) hipLaunchKernelGGL((y5_conv_wgrad_stem_kernel<NS, SS, true>), dim3((unsigned)grid), dim3(384), bytes, st, p);         \
+    else hipLaunchKernelGGL((y5_conv_wgrad_stem_kernel<NS, SS, false>), dim3((unsigned)grid), dim3(384), bytes, st, p);            \
+  } break;
+    switch (variant) {
+      Y5_STEM(2, 6) Y5_STEM(4, 4) Y5_STEM(4, 6) Y5_STEM(8, 3) Y5_STEM(8, 4)
+      default: return y5_fail(Y5_ERR_BAD_ARG, "wgrad: unknown Y5_WG_STEM variant");
+    }
+#undef Y5_STEM
+    if (det) {
+      const long long total = (long long)d->C2 * p.Kpad;
+      hipLaunchKernelGGL(y5_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws, dw_packed, d->C2, p.K, p.Npad, p.Kpad, p.splits);
+    }
+    return y5_check_launch("y5_conv2d_wgrad(stem)");
+  }
   const bool want3 = d->cfg == 3 || d->cfg >= 300;
   if (want3 && !can3) return y5_fail(Y5_ERR_BAD_ARG, "wgrad: cfg 3 (patch-staged kernel) needs k3 p1 and stride 1 or 2");
   const bool auto3 = d->cfg <= 0 && (long long)p.M >= 10LL * p.K * d->C2;   // many pixels per filter element: P1-P3 of the yolov5 graphs
@@ -348,7 +395,7 @@ static int wgrad_impl(const y5_conv_desc* d, const void* x, const void* dz, int 
   int tnb = d->C2 >= 128 ? 2 : 1, tkb = p.K >= 128 ? 2 : 1;
   // cfg 1xy: the general kernel with its filter tile capped at 64 x output channels by 64 y k columns (x, y in {1, 2}).  Splits x filter elements
   // is the atomic traffic of a launch; at P4 / P5 (few pixels, large filters) four times as many tiles need a quarter of the splits to fill the chip.
-  if ((d->cfg > 1 && d->cfg < 100 && d->cfg != 3) || (d->cfg >= 200 && d->cfg < 300)) return y5_fail(Y5_ERR_BAD_ARG, "wgrad: unknown cfg");
+  if ((d->cfg > 1 && d->cfg < 100 && d->cfg != 3 && d->cfg != 6) || (d->cfg >= 200 && d->cfg < 300)) return y5_fail(Y5_ERR_BAD_ARG, "wgrad: unknown cfg");
   if (d->cfg >= 100 && d->cfg < 200) {
     const int cn = (d->cfg - 100) / 10, ck = (d->cfg - 100) % 10;
     if ((cn != 1 && cn != 2) || (ck != 1 && ck != 2)) return y5_fail(Y5_ERR_BAD_ARG, "wgrad: cfg 1xy needs x, y in {1, 2}");

@@ -233,3 +233,146 @@ void y5_conv_wgrad3_kernel(const Y5WgradParams p) {
       }
   }
 }
+
+// ---- weight gradient of the STEM (0.Conv: k6 s2 p2 on 3 channels, run as k(6,3) s(2,1) p(2,1) on the paired-pixel view with 8 channels) ----------------
+// The general kernel gathers 18 taps x 8 channels per pixel for this layer: 533 us per step against 108 us of HBM time (420 MB of dz, 210 MB of x) --
+// one seventh of the whole weight-gradient time (profiles/r03/r03_train_kernel_stats_v1.csv).  Here one workgroup of SIX waves owns the filter
+// (32 x 144): wave kh multiplies filter row kh.  In the paired view the 24 k columns (kw, c) of a filter row are 48 contiguous bytes of x starting at
+// pixel ow - 1, so the B tile of output pixel p is the 64-byte window at patch pixel p (columns 24..31 are dead and masked at the end): a transposed
+// fragment is two ds_read_b64_tr_b16 over rows that are 16 bytes apart.  A chunk is NSEG segments of 16 output pixels of one output row:
+// dz[NSEG][16][32] + patch[NSEG][6 rows][20 px][8], staged by LDS-DMA through an S-deep ring exactly like the kernel above.
+template <int NSEG, int S, bool DET>
+__global__ __launch_bounds__(384)
+void y5_conv_wgrad_stem_kernel(const Y5WgradParams p) {
+  static_assert(NSEG <= 8, "segment index: 3 bits of the staging meta word");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int PWs = 20;                            // patch pixels per row: ow0 - 1 .. ow0 + 18 (16 windows of 4 pixels)
+  constexpr int ZT = NSEG * 16 * 64;
+  constexpr int XPIX = NSEG * 6 * PWs;
+  constexpr int ZI = ZT / 1024, XI = (XPIX * 16 + 1023) / 1024;
+  constexpr int XT = XI * 1024 + 64, BUF = ZT + XT;   // (+64: the last window of the last row reads 48 bytes past its 16)
+  constexpr int NI = (ZI + XI + 5) / 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = kh
+  const int bid = blockIdx.x;
+  const int tn = bid % p.tiles_n, sp = bid / p.tiles_n;
+  const int n0 = tn * 32;
+  const int spr = (p.OW + 15) >> 4;
+  const int total_segs = p.B * p.OH * spr;
+  const int seg_begin = sp * p.pix_per_split;                  // segments per split, a multiple of NSEG
+  const int seg_end = seg_begin + p.pix_per_split < total_segs ? seg_begin + p.pix_per_split : total_segs;
+  if (seg_begin >= seg_end) return;
+  const int nchunks = (seg_end - seg_begin + NSEG - 1) / NSEG;
+  const y5_rsrc_t xrs = y5_make_rsrc(p.x, p.x_bytes);
+  const y5_rsrc_t zrs = y5_make_rsrc(p.dz, p.dz_bytes);
+
+  // (uniform) first segment of the chunk staged next
+  int c_idx = seg_begin;
+  int c_row = c_idx / spr, c_sg = c_idx - c_row * spr;
+  int c_b = c_row / p.OH, c_oh = c_row - c_b * p.OH;
+
+  // per-lane constants: meta = seg (3 bits) | r << 3 | u << 6 | ok << 11 | real << 12
+  bool i_isx[NI];
+  int i_dst[NI], i_meta[NI], i_const[NI];
+#pragma unroll
+  for (int q = 0; q < NI; ++q) {
+    const int I = q * 6 + wave;
+    i_isx[q] = I >= ZI;
+    i_dst[q] = I < ZI ? I * 1024 : ZT + (I - ZI) * 1024;
+    i_meta[q] = 0; i_const[q] = 0;
+    if (I < ZI) {
+      const int pr = I * 16 + (lane >> 2), cg = lane & 3;      // 64-byte rows: 16 pixels per instruction; no swizzle needed (y5_wg3_swz<64>)
+      const int px = pr & 15;
+      i_meta[q] = (pr >> 4) | px << 6 | (n0 + 8 * cg < p.C2 ? 1 << 11 : 0) | 1 << 12;
+      i_const[q] = (px * p.ldz + n0 + 8 * cg) * 2;
+    } else if (I < ZI + XI) {
+      const int t = (I - ZI) * 64 + lane;                      // one 16-byte patch pixel per lane
+      if (t < XPIX) {
+        const int sg = t / (6 * PWs), rem = t - sg * (6 * PWs);
+        const int r = rem / PWs, u = rem - r * PWs;
+        i_meta[q] = sg | r << 3 | u << 6 | 1 << 11 | 1 << 12;
+        i_const[q] = ((r * p.W + u) * p.ldx) * 2;
+      }
+    }
+  }
+  const bool short_wave = (NI - 1) * 6 + wave >= ZI + XI;
+
+  auto stage = [&](int buf) {
+    char* base = smem + buf * BUF;
+    int zb[NSEG], xb[NSEG], ih0[NSEG], iw0[NSEG], ow0[NSEG];
+    bool live[NSEG];
+    {
+      int b = c_b, oh = c_oh, sg = c_sg;
+#pragma unroll
+      for (int t = 0; t < NSEG; ++t) {
+        live[t] = c_idx + t < seg_end;
+        ow0[t] = sg << 4;
+        zb[t] = (((b * p.OH + oh) * p.OW + ow0[t]) * p.ldz) * 2;
+        ih0[t] = oh * 2 - 2;
+        iw0[t] = ow0[t] - 1;
+        xb[t] = (((b * p.H + ih0[t]) * p.W + iw0[t]) * p.ldx) * 2;
+        if (++sg == spr) { sg = 0; if (++oh == p.OH) { oh = 0; ++b; } }
+      }
+      c_idx += NSEG; c_b = b; c_oh = oh; c_sg = sg;            // the state after NSEG single steps = the next chunk's first segment
+    }
+#pragma unroll
+    for (int q = 0; q < NI; ++q) {
+      const int m = i_meta[q];
+      const int t = m & 7, u = (m >> 6) & 31;
+      bool lv = live[0]; int zbt = zb[0], xbt = xb[0], ih = ih0[0], iw = iw0[0], owt = ow0[0];
+#pragma unroll
+      for (int k = 1; k < NSEG; ++k)
+        if (t == k) { lv = live[k]; zbt = zb[k]; xbt = xb[k]; ih = ih0[k]; iw = iw0[k]; owt = ow0[k]; }
+      bool ok = ((m >> 11) == 3) & lv;
+      int off;
+      if (!i_isx[q]) {
+        ok &= owt + u < p.OW;
+        off = zbt + i_const[q];
+      } else {
+        ih += (m >> 3) & 7; iw += u;
+        ok &= ((unsigned)ih < (unsigned)p.H) & ((unsigned)iw < (unsigned)p.W);
+        off = xbt + i_const[q];
+      }
+      if (q < NI - 1 || !short_wave) y5_bglds16(i_isx[q] ? xrs : zrs, ok ? (unsigned)off : Y5_OOB, base + i_dst[q]);
+    }
+  };
+
+  const int fi = lane & 31, g = lane >> 5;
+  const int q4 = (lane & 15) >> 2;
+  const int tr_col = 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+  const int tr_z = (8 * g + q4) * 64 + tr_col;                 // dz tile: 64-byte rows
+  const int tr_x = (8 * g + q4) * 16 + tr_col;                 // patch: the window of pixel p starts 16 p bytes into the row
+  float16_t acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s) stage(s);
+  int cur = 0, nxt = S - 1;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    if (short_wave) y5_wait_vm<(S - 2) * (NI - 1)>();
+    else y5_wait_vm<(S - 2) * NI>();
+    __builtin_amdgcn_s_barrier();
+    stage(nxt);
+    const char* zt = smem + cur * BUF + tr_z;
+    const char* xt = smem + cur * BUF + ZT + wave * (PWs * 16) + tr_x;
+    nxt = cur;
+    cur = cur + 1 == S ? 0 : cur + 1;
+#pragma unroll
+    for (int ks = 0; ks < NSEG; ++ks) {
+      const half8_t bf = y5_tr_frag(xt + ks * (6 * PWs * 16), 4 * 16);
+      const half8_t af = y5_tr_frag(zt + ks * (16 * 64), 4 * 64);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0);
+    }
+  }
+  y5_wait_vm<0>();
+  if (fi >= 24) return;                                        // dead columns of the 64-byte window
+  const int kcol = wave * 24 + fi;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * g;
+    if (n >= p.C2) continue;
+    if constexpr (DET) p.ws[((size_t)sp * p.Npad + n) * p.Kpad + kcol] = acc[r];
+    else atomicAdd(p.dw + (size_t)n * p.Kpad + kcol, acc[r]);
+  }
+}

@@ -211,8 +211,10 @@ class TrainEngine:
         mode = os.environ.get("Y5_WGRAD_SPLITS", "auto")  # auto | <n>: fixed split count for every layer (0 = library default)
         fam = int(os.environ.get("Y5_WGRAD_CFG", "-2"))    # -2 = timed | -1 library heuristic | 1 | 3 | 3xy
         k3 = d.KH == 3 and d.KW == 3 and d.PH == 1 and d.PW == 1 and d.SH == d.SW and d.SH in (1, 2)
-        if fam >= 3 and not k3:
+        if fam >= 3 and fam != 6 and not k3:
             fam = 1
+        if fam == 6:
+            fam = -1   # (the library picks the stem kernel by geometry)
         if mode != "auto":
             return (fam if fam != -2 else -1), int(mode)
         if not getattr(self.be, "autotune", False) or self.dt != _lib.Y5_F16:
@@ -236,6 +238,8 @@ class TrainEngine:
         elif 100 <= fam < 200:
             tn, tk = 64 * min((fam - 100) // 10, 2 if d.C2 >= 128 else 1), 64 * min((fam - 100) % 10, 2 if K >= 128 else 1)
             fams.append((fam, -(-d.C2 // tn) * -(-K // tk), (1, 1.5, 2, 3, 4, 6)))
+        if fam == -2 and d.KH == 6 and d.KW == 3 and d.SH == 2 and d.SW == 1 and d.PH == 2 and d.PW == 1 and d.C1 == 8 and d.ldx == 8:
+            fams.append((6, -(-d.C2 // 32), (1, 2, 3, 4)))   # 0.Conv on the paired-pixel view: the stem kernel (517 -> 252 us, scripts/wgrad_bench.py --stem)
         if k3 and (fam == -2 or fam >= 3):
             for cfg in ((3, 341) if fam == -2 else (fam,)):
                 cn, cc = ((cfg - 300) // 10, (cfg - 300) % 10) if cfg >= 300 else (4, 2)
