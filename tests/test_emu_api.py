@@ -257,3 +257,35 @@ def test_nms_apriori_labels_equal_oracle():
             for g, e in zip(got, exp):
                 assert np.array_equal(g.numpy(), e)
     assert float(got[0][0, 4]) == 1.0
+
+
+def test_tune_cache_is_bound_to_the_kernel_library(tmp_path, monkeypatch):
+    """Tile / split choices are properties of the kernel binary: a cache file written with another build of libyolov5_hip.so is ignored."""
+    import json
+
+    from yolov5_amd import engine as eng
+
+    path = tmp_path / "tune.json"
+    monkeypatch.setenv("Y5_TUNE_CACHE", str(path))
+    saved, state = dict(eng._TUNE_CACHE), dict(eng._TUNE_FILE_STATE)
+    try:
+        eng._TUNE_CACHE.clear()
+        eng._TUNE_FILE_STATE.update(loaded=False)
+        eng._TUNE_FILE_STATE.pop("stamp", None)
+        eng._TUNE_CACHE[(1, 2, 3)] = (43, 2)
+        eng._save_tune_cache()
+        d = json.load(open(path))
+        assert d["__lib_sha16__"] == eng._lib_stamp() and d["1,2,3"] == [43, 2]
+        eng._TUNE_CACHE.clear()
+        eng._TUNE_FILE_STATE["loaded"] = False
+        eng._load_tune_cache()
+        assert eng._TUNE_CACHE == {(1, 2, 3): (43, 2)}
+        d["__lib_sha16__"] = "0123456789abcdef"                      # another build
+        json.dump(d, open(path, "w"))
+        eng._TUNE_CACHE.clear()
+        eng._TUNE_FILE_STATE["loaded"] = False
+        eng._load_tune_cache()
+        assert eng._TUNE_CACHE == {}
+    finally:
+        eng._TUNE_CACHE.clear(); eng._TUNE_CACHE.update(saved)
+        eng._TUNE_FILE_STATE.clear(); eng._TUNE_FILE_STATE.update(state)

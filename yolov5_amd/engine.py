@@ -447,6 +447,20 @@ def _tune_cache_path():
     return os.path.join(os.path.expanduser("~"), ".cache", "yolov5_amd", f"tune_{tag}.json")
 
 
+def _lib_stamp():
+    """sha256 (16 hex digits) of the kernel library the choices were timed with: a cache written by another build of the kernels is ignored (a tile
+    choice is a property of the binary -- this round's bias-in-LDS episode changed which configuration wins three layers without changing any id)."""
+    if "stamp" not in _TUNE_FILE_STATE:
+        import hashlib
+
+        try:
+            with open(_lib.LIB_PATH, "rb") as f:
+                _TUNE_FILE_STATE["stamp"] = hashlib.sha256(f.read()).hexdigest()[:16]
+        except OSError:
+            _TUNE_FILE_STATE["stamp"] = "unknown"
+    return _TUNE_FILE_STATE["stamp"]
+
+
 def _load_tune_cache():
     path = _tune_cache_path()
     if not path or _TUNE_FILE_STATE["loaded"]:
@@ -456,7 +470,10 @@ def _load_tune_cache():
         import json
 
         with open(path) as f:
-            for k, v in json.load(f).items():
+            d = json.load(f)
+            if d.pop("__lib_sha16__", None) != _lib_stamp():
+                return
+            for k, v in d.items():
                 v = (int(v), -1) if not isinstance(v, (list, tuple)) else (int(v[0]), int(v[1]))  # (best, runner-up); older files: best only
                 _TUNE_CACHE[tuple(int(x) if x not in ("True", "False") else x == "True" for x in k.split(","))] = v
     except (OSError, ValueError):
@@ -473,7 +490,7 @@ def _save_tune_cache():
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
         tmp = f"{path}.{os.getpid()}.tmp"
         with open(tmp, "w") as f:
-            json.dump({",".join(str(x) for x in k): list(v) for k, v in _TUNE_CACHE.items()}, f)
+            json.dump({"__lib_sha16__": _lib_stamp(), **{",".join(str(x) for x in k): list(v) for k, v in _TUNE_CACHE.items()}}, f)
         os.replace(tmp, path)  # atomic: several ranks tune at once
     except OSError:
         pass
