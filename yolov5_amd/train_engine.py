@@ -230,7 +230,7 @@ class TrainEngine:
         ncu = torch.cuda.get_device_properties(self.be.device).multi_processor_count
         fams = []
         if fam in (-2, -1, 1):
-            fams.append((1, -(-d.C2 // (128 if d.C2 >= 128 else 64)) * -(-K // (128 if K >= 128 else 64)), (1, 1.5, 2, 3, 4, 6)))
+            fams.append((-1 if fam == -1 else 1, -(-d.C2 // (128 if d.C2 >= 128 else 64)) * -(-K // (128 if K >= 128 else 64)), (1, 1.5, 2, 3, 4, 6)))
         if fam == -2 and d.C2 >= 128 and K >= 128 and d.B * d.OH * d.OW <= 64 * 40 * 40:
             # few pixels, large filter: atomic traffic = splits x filter; the same kernel on 64 x 64 / 64 x 128 tiles fills the chip with fewer splits
             for cfg, tn, tk in ((111, 64, 64), (112, 64, 128)):
