@@ -63,6 +63,27 @@ def test_nms_large_candidate_set_global_sort_path():
     assert len(ref[0]) == 100 and np.array_equal(res[0], ref[0])
 
 
+def test_nms_pruning_stage_short_lists_ties_and_overflow():
+    """K1c (csrc/nms_kernels.h): lists longer than max_nms are cut to the confidence bins that can hold the max_nms best keys before the sort.
+    One call, three images: a long random list (pruned), a list shorter than max_nms (left alone), and a list whose candidates all share ONE
+    confidence (every key in the same bin: the compaction buffer overflows and the image falls back to sorting everything) -- each bit-identical
+    to the oracle, whose order among equal confidences is the candidate index (the contract of the keys' low word)."""
+    p = detgen.synth_predictions(3, 3000, 9, obj_pow=1, seed=23)
+    p[1, 150:, 4] = 0.0                                   # image 1: few rows survive the objectness threshold
+    p[2, :, 4] = 0.5; p[2, :, 5:] = 0.5                   # image 2: every (row, class) has confidence 0.25
+    kw = dict(conf_thres=0.01, iou_thres=0.5, multi_label=True, max_det=60, max_nms=500)
+    res = run_nms(emu(), p, **kw)
+    ref = yo.non_max_suppression(p, **kw)
+    for i in range(3):
+        assert len(ref[i]) > 0 and np.array_equal(res[i], ref[i]), i
+    # exactly max_nms candidates at the boundary, and max_nms larger than the list
+    for mx in (499, 501, 11990, 40000):
+        kw["max_nms"] = mx
+        res = run_nms(emu(), p[:1], **kw)
+        ref = yo.non_max_suppression(p[:1], **kw)
+        assert np.array_equal(res[0], ref[0]), mx
+
+
 def test_detect_decode_emulated():
     lib = emu()
     B, ny, nx, na, no = 2, 5, 7, 3, 85

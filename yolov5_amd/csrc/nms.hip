@@ -6,7 +6,7 @@
 #include "y5_host.h"
 
 namespace {
-struct Layout { size_t off_count, off_keys, off_cls, off_gbox, off_rows, total; long long cap, cap_pad, gcap; };
+struct Layout { size_t off_count, off_keys, off_cls, off_gbox, off_rows, off_hist, off_thr, off_keys2, total; long long cap, cap_pad, gcap, cap2; };
 Layout layout(int bs, int n, int no, int nm, int flags, int max_nms) {
   Layout L{};
   const int nc = no - 5 - nm;
@@ -23,6 +23,12 @@ Layout layout(int bs, int n, int no, int nm, int flags, int max_nms) {
   if (L.gcap < 64) L.gcap = 64;
   L.off_gbox = o; o += ((size_t)bs * L.gcap * Y5_NMS_REC * 4 + 255) & ~(size_t)255;
   L.off_rows = o; o += ((size_t)bs * n * 4 + 255) & ~(size_t)255;  // hint path: rows the objectness plane could not exclude
+  // pruning stage (nms_kernels.h K1c), only where a candidate list can exceed max_nms: histogram, thresholds + counts, compaction buffer of 4 x max_nms keys
+  L.cap2 = L.cap > max_nms ? (4LL * max_nms + 63) / 64 * 64 : 0;
+  if (L.cap2 > L.cap) L.cap2 = L.cap;
+  L.off_hist = o; o += L.cap2 ? ((size_t)bs * Y5_NMS_BINS * 4 + 255) & ~(size_t)255 : 0;
+  L.off_thr = o; o += L.cap2 ? ((size_t)bs * 8 + 255) & ~(size_t)255 : 0;
+  L.off_keys2 = o; o += ((size_t)bs * L.cap2 * 8 + 255) & ~(size_t)255;
   L.total = o;
   return L;
 }
@@ -62,12 +68,15 @@ extern "C" int y5_nms_batched_hint(const void* pred, int dt, int bs, int n, int 
   p.best_cls = reinterpret_cast<unsigned char*>(w + L.off_cls);
   p.gbox = reinterpret_cast<float*>(w + L.off_gbox);
   p.cap = L.cap; p.cap_pad = L.cap_pad; p.gcap = L.gcap;
+  p.hist = reinterpret_cast<int*>(w + L.off_hist); p.thr = reinterpret_cast<int*>(w + L.off_thr);
+  p.keys2 = reinterpret_cast<unsigned long long*>(w + L.off_keys2); p.cap2 = L.cap2;
 
   if (hipMemsetAsync(p.count, 0, (size_t)bs * 8, st) != hipSuccess) return y5_fail(Y5_ERR_RUNTIME, "nms: memset failed");
   const dim3 fg((unsigned)((n + 255) / 256), (unsigned)bs), fb(256);
   static bool attr = false;
   if (!attr) {
     hipFuncSetAttribute((const void*)y5_nms_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Y5_NMS_SORT_LDS_KEYS * 8);
+    hipFuncSetAttribute((const void*)y5_nms_sort_windows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Y5_NMS_SORT_LDS_KEYS * 8);
     hipFuncSetAttribute((const void*)y5_nms_greedy_kernel<half_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipFuncSetAttribute((const void*)y5_nms_greedy_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     attr = true;
@@ -111,6 +120,21 @@ extern "C" int y5_nms_batched_hint(const void* pred, int dt, int bs, int n, int 
     } else {
       hipLaunchKernelGGL((y5_nms_filter_kernel<float, false>), fg, fb, 0, st, p);
     }
+  }
+  if (L.cap2 > 0) {  // a list can be longer than max_nms: keep only the keys that can be among the max_nms best before sorting
+    if (hipMemsetAsync(p.hist, 0, (size_t)bs * Y5_NMS_BINS * 4, st) != hipSuccess) return y5_fail(Y5_ERR_RUNTIME, "nms: memset failed");
+    const dim3 hg(64, (unsigned)bs);
+    hipLaunchKernelGGL(y5_nms_hist_kernel, hg, dim3(256), Y5_NMS_BINS * 4, st, p);
+    hipLaunchKernelGGL(y5_nms_select_kernel, dim3((unsigned)bs), dim3(256), 256 * 4, st, p);
+    hipLaunchKernelGGL(y5_nms_compact_kernel, hg, dim3(256), 16, st, p);
+    hipLaunchKernelGGL(y5_nms_adopt_kernel, dim3(16, (unsigned)bs), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(y5_nms_adopt_count_kernel, dim3((unsigned)((bs + 255) / 256)), dim3(256), 0, st, p);
+  }
+  if (L.cap_pad > Y5_NMS_SORT_LDS_KEYS) {  // lists that can exceed one LDS window: the window-local merge sizes in parallel (early exit per image otherwise)
+    const long long most = L.cap2 > 0 ? (L.cap2 > max_nms ? L.cap2 : max_nms) : L.cap;   // longest list the sort can see (pruned, or the overflow fallback)
+    long long wp2 = 64;
+    while (wp2 < (L.cap2 > 0 ? L.cap : most)) wp2 <<= 1;
+    hipLaunchKernelGGL(y5_nms_sort_windows_kernel, dim3((unsigned)(wp2 / Y5_NMS_SORT_LDS_KEYS), (unsigned)bs), dim3(1024), Y5_NMS_SORT_LDS_KEYS * 8, st, p);
   }
   hipLaunchKernelGGL(y5_nms_sort_kernel, dim3((unsigned)bs), dim3(1024), Y5_NMS_SORT_LDS_KEYS * 8, st, p);
   {

@@ -35,6 +35,11 @@ struct Y5NmsParams {
   float* gbox;                // [bs][gcap / 64][12][64] (chunk-major, field planes of 64 candidates): bx1,by1,bx2,by2,area, x1,y1,x2,y2,conf,cls,
                               // row index (as int bits); gcap is a multiple of 64
   long long cap, cap_pad, gcap;
+  // pruning of over-long candidate lists (K1c): only the max_nms best keys are ever looked at (general.py:735 `x[...argsort...][:max_nms]`)
+  int* hist;                  // [bs][Y5_NMS_BINS] histogram of the keys' confidence bins
+  int* thr;                   // [bs] lowest bin that is kept (-1: the list is short enough / pruning failed, sort everything), [bs..2bs): count2
+  unsigned long long* keys2;  // [bs][cap2] the keys of the kept bins
+  long long cap2;
   int cls_lists;              // greedy kernel: per-(class, wave) linked lists of the kept boxes live in LDS (host: they fit and NMS is per class)
 };
 
@@ -67,16 +72,32 @@ __device__ __forceinline__ void y5_nms_eval_row(const Y5NmsParams& p, int b, int
   };
   if (p.flags & 1) {  // multi_label: every (row, class) with obj*cls > thres (general.py:726-728)
     if (__ballot(live) == 0ull) return;  // wave-uniform
-    for (int j = 0; j < p.nc; ++j) {
-      bool hit = false;
-      float conf = 0.f;
-      if (live) {
-        conf = (float)row[5 + j] * obj;
-        hit = conf > p.conf_thres && class_ok(j);
-      }
-      const unsigned idx = (unsigned)r * (unsigned)p.nc + (unsigned)j;
-      append(hit, ((unsigned long long)__float_as_uint(conf) << 32) | (unsigned long long)(0xFFFFFFFFu - idx));
+    // ONE reservation per wave for all classes: count the lane's hits, exclusive wave scan, one atomicAdd of the wave total, then every lane writes its
+    // keys behind its prefix.  (A ballot + atomicAdd per CLASS was 31.5 k same-address returning atomics per image with val.py's thresholds --
+    // ~650 ns each under contention: 20.5 of the 26.8 ms a 64-image batch took, profiles/r03/r03_nms_val_breakdown.txt.)
+    int cnt = 0;
+    if (live)
+      for (int j = 0; j < p.nc; ++j) cnt += ((float)row[5 + j] * obj > p.conf_thres && class_ok(j)) ? 1 : 0;
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl(incl, lane >= d ? lane - d : lane);
+      if (lane >= d) incl += up;
     }
+    const int total = __shfl(incl, 63);
+    if (total == 0) return;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(p.count + b, total);
+    base = __shfl(base, 0);
+    long long slot = (long long)base + incl - cnt;
+    if (live)
+      for (int j = 0; j < p.nc; ++j) {
+        const float conf = (float)row[5 + j] * obj;
+        if (conf > p.conf_thres && class_ok(j)) {
+          const unsigned idx = (unsigned)r * (unsigned)p.nc + (unsigned)j;
+          keys[slot++] = ((unsigned long long)__float_as_uint(conf) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+        }
+      }
   } else {  // best class only: first maximal class (general.py:730)
     bool hit = false;
     float best = 0.f;
@@ -198,9 +219,161 @@ __global__ __launch_bounds__(256) void y5_nms_hint_rows_kernel(const Y5NmsParams
   }
 }
 
+// ---- K1c: prune an over-long candidate list to the keys that can be among the max_nms best ------------------------------------------------
+// With val.py's thresholds (conf 0.001, multi_label) an image can produce n * nc = 2 M candidates, of which only the max_nms = 30 000 most
+// confident survive general.py:735.  Sorting them all was a one-workgroup bitonic network over global memory: 1.5 ms per image.  Instead:
+// histogram of the confidence's top 16 float bits (128 bins per octave, LDS-private per workgroup), the lowest bin T whose tail holds >= max_nms
+// keys, and a wave-aggregated compaction of the keys in bins >= T -- exactly a superset of the max_nms best, normally a few hundred keys more --
+// which the sort below then orders.  A list that does not fit the compaction buffer (a million ties) keeps the old path.
+#define Y5_NMS_BINS 2048
+#define Y5_NMS_BIN0 0x3800   // top 16 bits of 2^-15: everything below shares bin 0
+__device__ __forceinline__ int y5_nms_bin(unsigned long long key) {
+  const int b = (int)(key >> 48) - Y5_NMS_BIN0;
+  return b < 0 ? 0 : (b > Y5_NMS_BINS - 1 ? Y5_NMS_BINS - 1 : b);
+}
+__global__ __launch_bounds__(256) void y5_nms_hist_kernel(const Y5NmsParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* h = reinterpret_cast<int*>(smem);   // [Y5_NMS_BINS]
+  const int b = blockIdx.y;
+  long long n = p.count[b];
+  if (n > p.cap) n = p.cap;
+  if (n <= p.max_nms) return;
+  for (int i = threadIdx.x; i < Y5_NMS_BINS; i += 256) h[i] = 0;
+  __syncthreads();
+  const unsigned long long* keys = p.keys + (long long)b * p.cap_pad;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) atomicAdd(&h[y5_nms_bin(keys[i])], 1);
+  __syncthreads();
+  for (int i = threadIdx.x; i < Y5_NMS_BINS; i += 256)
+    if (h[i]) atomicAdd(&p.hist[(long long)b * Y5_NMS_BINS + i], h[i]);
+}
+__global__ __launch_bounds__(256) void y5_nms_select_kernel(const Y5NmsParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* part = reinterpret_cast<int*>(smem);   // [256]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  long long n = p.count[b];
+  if (n > p.cap) n = p.cap;
+  if (tid == 0) { p.thr[b] = -1; p.thr[p.bs + b] = 0; }
+  if (n <= p.max_nms) return;
+  const int* h = p.hist + (long long)b * Y5_NMS_BINS;
+  constexpr int PER = Y5_NMS_BINS / 256;
+  int s = 0;
+  for (int q = 0; q < PER; ++q) s += h[tid * PER + q];
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0, t = 255;
+    for (; t >= 0; --t) {               // the 8-bin group in which the tail reaches max_nms, then the bin inside it
+      if (acc + part[t] >= p.max_nms) break;
+      acc += part[t];
+    }
+    int T = 0;
+    if (t >= 0) {
+      T = t * PER + PER - 1;
+      for (; T > t * PER; --T) {
+        if (acc + h[T] >= p.max_nms) break;
+        acc += h[T];
+      }
+    }
+    p.thr[b] = T;
+  }
+}
+__global__ __launch_bounds__(256) void y5_nms_compact_kernel(const Y5NmsParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* s_cnt = reinterpret_cast<int*>(smem);   // [0] takes of this workgroup, [1] its base in keys2, [2] running offset
+  const int b = blockIdx.y;
+  const int T = p.thr[b];
+  if (T < 0) return;
+  long long n = p.count[b];
+  if (n > p.cap) n = p.cap;
+  const unsigned long long* keys = p.keys + (long long)b * p.cap_pad;
+  unsigned long long* dst = p.keys2 + (long long)b * p.cap2;
+  const int lane = threadIdx.x & 63;
+  // a contiguous slice per workgroup, ONE global reservation for it (a wave-aggregated atomicAdd per 64 keys was 17 k same-address atomics per image)
+  const long long per = ((n + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+  const long long i_begin = per * blockIdx.x, i_end = i_begin + per < n ? i_begin + per : n;
+  if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  int mine = 0;
+  for (long long i = i_begin + threadIdx.x; i < i_end; i += 256) mine += y5_nms_bin(keys[i]) >= T ? 1 : 0;
+  if (mine) atomicAdd(&s_cnt[0], mine);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_cnt[0] > 0) s_cnt[1] = atomicAdd(&p.thr[p.bs + b], s_cnt[0]);
+  __syncthreads();
+  if (s_cnt[0] == 0) return;
+  const long long base = s_cnt[1];
+  for (long long i0 = i_begin; i0 < i_end; i0 += 256) {                      // (whole waves iterate together: the ballot needs every lane)
+    const long long i = i0 + threadIdx.x;
+    const unsigned long long k = i < i_end ? keys[i] : 0ull;
+    const bool take = i < i_end && y5_nms_bin(k) >= T;
+    const unsigned long long m = __ballot(take);
+    if (m == 0ull) continue;
+    int off = 0;
+    if (lane == 0) off = atomicAdd(&s_cnt[2], __popcll(m));                  // LDS counter: order inside the slice is irrelevant (the keys are sorted next)
+    off = __shfl(off, 0);
+    const long long slot = base + off + __popcll(m & ((1ull << lane) - 1ull));
+    if (take && slot < p.cap2) dst[slot] = k;
+  }
+}
+// the pruned list replaces the image's candidate list (keys, count) -- unless it overflowed the buffer, in which case everything is sorted as before
+__global__ __launch_bounds__(256) void y5_nms_adopt_kernel(const Y5NmsParams p) {
+  const int b = blockIdx.y;
+  if (p.thr[b] < 0) return;
+  const long long n2 = p.thr[p.bs + b];
+  if (n2 > p.cap2) return;
+  unsigned long long* keys = p.keys + (long long)b * p.cap_pad;
+  const unsigned long long* src = p.keys2 + (long long)b * p.cap2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long long)gridDim.x * 256) keys[i] = src[i];
+}
+__global__ void y5_nms_adopt_count_kernel(const Y5NmsParams p) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= p.bs || p.thr[b] < 0) return;
+  const int n2 = p.thr[p.bs + b];
+  if (n2 <= p.cap2) p.count[b] = n2;
+}
+
 // ---- K2: per-image bitonic sort, descending ----------------------------------------------------------
 __device__ __forceinline__ void y5_cmpswap_desc(unsigned long long& a, unsigned long long& b2, bool desc) {
   if ((a < b2) == desc) { const unsigned long long t = a; a = b2; b2 = t; }
+}
+
+// Large lists (more keys than one LDS window): the merge sizes k <= WIN of the bitonic network only touch aligned windows of WIN keys, so they run as
+// (windows x images) independent workgroups, each sorting its window in LDS in the direction the network wants there; the one-workgroup-per-image
+// kernel below then starts at k = 2 WIN -- for the 32 768 keys a pruned val.py list has, 2 of the 15 merge sizes are left to the serial kernel.
+__global__ __launch_bounds__(1024) void y5_nms_sort_windows_kernel(const Y5NmsParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* sk = reinterpret_cast<unsigned long long*>(smem);
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  unsigned long long* keys = p.keys + (long long)b * p.cap_pad;
+  long long n = p.count[b];
+  if (n > p.cap) n = p.cap;
+  long long np2 = 64;
+  while (np2 < n) np2 <<= 1;
+  constexpr int WIN = Y5_NMS_SORT_LDS_KEYS;
+  const long long w0 = (long long)blockIdx.x * WIN;
+  if (np2 <= WIN || w0 >= np2) return;
+  for (int i = tid; i < WIN; i += nt) sk[i] = w0 + i < n ? keys[w0 + i] : 0ull;
+  __syncthreads();
+  for (int k = 2; k <= WIN; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < WIN / 2; t += nt) {
+        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int hi = lo | j;
+        const bool desc = ((w0 + lo) & k) == 0;
+        const unsigned long long a = sk[lo], c = sk[hi];
+        if ((a < c) == desc) { sk[lo] = c; sk[hi] = a; }
+      }
+      const int next_j = j > 1 ? j >> 1 : k;
+      if (j > 64 || next_j > 64) {
+        __syncthreads();
+      } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
+  }
+  for (int i = tid; i < WIN; i += nt) keys[w0 + i] = sk[i];   // (padding zeros included: the serial kernel continues on np2 keys)
 }
 
 __global__ void y5_nms_sort_kernel(const Y5NmsParams p) {
@@ -245,11 +418,10 @@ __global__ void y5_nms_sort_kernel(const Y5NmsParams p) {
   } else {
     // large candidate sets (val-style thresholds): bitonic network over global memory; strides that fit a
     // Y5_NMS_SORT_LDS_KEYS window are finished inside LDS
-    for (long long i = n + tid; i < np2; i += nt) keys[i] = 0ull;
-    __syncthreads();
+    // (the windows are sorted and zero-padded already: y5_nms_sort_windows_kernel)
     const long long half = np2 >> 1;
     constexpr int WIN = Y5_NMS_SORT_LDS_KEYS;
-    for (long long k = 2; k <= np2; k <<= 1) {
+    for (long long k = 2 * WIN; k <= np2; k <<= 1) {
       long long j = k >> 1;
       for (; j >= WIN; j >>= 1) {
         for (long long t = tid; t < half; t += nt) {
