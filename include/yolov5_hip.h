@@ -436,7 +436,7 @@ int y5_tta_descale(void* z, int dtype, long long rows, int no, float scale, int 
  * gate of :701 sends a sample down the letterbox branch :710-733, that one image on an s x s canvas -- job.canvas), the image half of
  * utils/augmentations.py:118-166 `random_perspective` (cv2.warpAffine, INTER_LINEAR, border 114, output s x s), :69-83 `augment_hsv`,
  * the flips of dataloaders.py:747-757, `img.transpose((2, 0, 1))[::-1]` (:761) and collate_fn's torch.stack (:862).  Draws, geometry
- * and labels are the host's (yolov5_amd/dataloaders.py); jobs_dev is a DEVICE array of B descriptors.  Source images: uint8 HWC BGR.
+ * and labels are the host's (yolov5_amd/dataloaders.py); jobs_dev is a DEVICE array of B descriptors (+ the mixup partners behind them).  Source images: uint8 HWC BGR.
  * dst: (B, 3, S, S) RGB planes, uint8 / fp16 / fp32 (div255: divide by 255 like train.py:375).
  * ------------------------------------------------------------------------------------------------------- */
 typedef struct {
@@ -450,6 +450,10 @@ typedef struct {
   int hsv, flipud, fliplr;
   int canvas;                    /* side of the square canvas the tiles sit on; 0 = 2 S (mosaic).  S for the non-mosaic branch of
                                     dataloaders.py:710-733: load_image + letterbox(auto=False) = ONE tile at (left, top) of an S x S canvas */
+  double mix_r;                  /* mixup (utils/augmentations.py:225-233, dataloaders.py:707-708): out = uint8(this * mix_r + partner * (1 - mix_r)) */
+  int mix_job;                   /* 1 + index of the partner job in the table (partners sit behind the B rendered jobs), 0 = no mixup; of the partner
+                                    only the tiles, rectangles, A and canvas are used */
+  int reserved;
 } y5_mosaic_job;
 int y5_mosaic_batch(const y5_mosaic_job* jobs_dev, int B, int S, int pad_value, void* dst, int dst_dtype, int div255, void* stream);
 

@@ -46,7 +46,21 @@ def reference_draws(seed, index, n_images, s, hyp):
     d["shear"] = (random.uniform(-hyp["shear"], hyp["shear"]), random.uniform(-hyp["shear"], hyp["shear"]))
     d["translate"] = (random.uniform(0.5 - hyp["translate"], 0.5 + hyp["translate"]), random.uniform(0.5 - hyp["translate"], 0.5 + hyp["translate"]))
     d["mixup"] = d["mosaic"] and random.random() < hyp["mixup"]
-    assert not d["mixup"], "mixup is not restated"
+    if d["mixup"]:  # dataloaders.py:707-708: random.choice(indices), the partner mosaic's own draws (load_mosaic), then np.random.beta inside mixup()
+        i2 = random.choice(range(n_images))
+        m = {"mosaic": True}
+        border = [-s // 2, -s // 2]
+        m["yc"], m["xc"] = (int(random.uniform(-x, 2 * s + x)) for x in border)
+        idx = [i2, *random.choices(range(n_images), k=3)]
+        random.shuffle(idx)
+        m["indices"] = idx
+        m["persp"] = (random.uniform(-hyp["perspective"], hyp["perspective"]), random.uniform(-hyp["perspective"], hyp["perspective"]))
+        m["angle"] = random.uniform(-hyp["degrees"], hyp["degrees"])
+        m["scale"] = random.uniform(1 - hyp["scale"], 1 + hyp["scale"])
+        m["shear"] = (random.uniform(-hyp["shear"], hyp["shear"]), random.uniform(-hyp["shear"], hyp["shear"]))
+        m["translate"] = (random.uniform(0.5 - hyp["translate"], 0.5 + hyp["translate"]), random.uniform(0.5 - hyp["translate"], 0.5 + hyp["translate"]))
+        d["partner"] = m
+        d["mix_r"] = np.random.beta(32.0, 32.0)
     d["hsv"] = np.random.uniform(-1, 1, 3) * [hyp["hsv_h"], hyp["hsv_s"], hyp["hsv_v"]] + 1
     d["flipud"] = random.random() < hyp["flipud"]
     d["fliplr"] = random.random() < hyp["fliplr"]
@@ -162,7 +176,7 @@ def sample(images, labels, d, s, hyp=None):
     return mosaic_sample(images, labels, d, s, hyp) if d.get("mosaic", True) else letterbox_sample(images, labels, d, s, hyp)
 
 
-def mosaic_sample(images, labels, d, s, hyp=None):
+def mosaic_sample(images, labels, d, s, hyp=None, _partner=False):
     """One training sample.  images: list of HWC uint8 BGR arrays; labels: list of (k, 5) float arrays [cls, xc, yc, w, h] normalised;
     d: draws (reference_draws).  Returns (img (3, s, s) uint8 RGB CHW, labels_out (nl, 6) float32 [0, cls, xc, yc, w, h])."""
     tiles_im, shapes = [], []
@@ -185,6 +199,12 @@ def mosaic_sample(images, labels, d, s, hyp=None):
     M, width, height = perspective_matrix(d, img4.shape[:2], border)
     img = tp.cv2_warp_affine(img4, M[:2], (width, height), borderValue=(114, 114, 114))
     lab = warp_boxes(labels4, M, width, height, d["scale"])
+    if d.get("mixup") and not _partner:   # utils/augmentations.py:225-233 on the two warped mosaics, before the common tail
+        img2, lab2 = mosaic_sample(images, labels, d["partner"], s, hyp, _partner=True)
+        img = (img * d["mix_r"] + img2 * (1 - d["mix_r"])).astype(np.uint8)
+        lab = np.concatenate((lab, lab2), 0)
+    if _partner:
+        return img, lab
     return _tail(img, lab, d, hyp)
 
 

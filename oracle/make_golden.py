@@ -554,6 +554,21 @@ def gen_augment(ns):
         print("augment mixed", seed, gates, tuple(imb.shape), tuple(labb.shape))
     np.savez_compressed(os.path.join(OUT, "augment_mixed.npz"), **out)
 
+    # hyp['mixup'] = 0.5 (data/hyps/hyp.scratch-med.yaml has 0.1): dataloaders.py:707-708 blends a second mosaic into about half of the samples
+    ds.hyp = dict(hyp, mixup=0.5)
+    out = {"s": np.array(s)}
+    for seed in (21, 22, 23, 24):
+        batch = []
+        for index in (seed % 6, (seed + 2) % 6, (seed + 4) % 6):
+            random.seed(seed * 10 + index)
+            np.random.seed(seed * 10 + index)
+            im, lab, _, _ = cls.__getitem__(ds, index)
+            batch.append((im, lab, "", None))
+        imb, labb, _, _ = cls.collate_fn(batch)
+        out[f"img{seed}"], out[f"lab{seed}"] = imb.numpy(), labb.numpy()
+        print("augment mixup", seed, tuple(imb.shape), tuple(labb.shape))
+    np.savez_compressed(os.path.join(OUT, "augment_mixup.npz"), **out)
+
 
 TINY_CFG = {  # a 0.13 M-parameter YOLOv5 (reference schema, models/yolov5n.yaml with width 0.125): checkpoint fixtures stay small
     "nc": 80, "depth_multiple": 0.33, "width_multiple": 0.125,

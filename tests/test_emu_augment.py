@@ -72,6 +72,29 @@ def test_mixed_mosaic_and_letterbox_branches_match_reference_golden(seed):
     np.testing.assert_array_equal(targets.numpy(), g[f"lab{seed}"])
 
 
+@pytest.mark.parametrize("seed", [21, 22, 23, 24])
+def test_mixup_matches_reference_golden(seed):
+    """hyp['mixup'] = 0.5 (dataloaders.py:707-708, utils/augmentations.py:225-233): a second mosaic -- its own draws, its own random_perspective --
+    blended into the first in uint8 inside the same launch (job.mix_job / mix_r), labels concatenated; the Beta(32, 32) ratio is drawn from numpy's
+    generator right after the partner's draws.  Against the reference's own __getitem__ / collate_fn (tests/golden/augment_mixup.npz)."""
+    from yolov5_amd.dataloaders import draw_sample, mosaic_batch
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "augment_mixup.npz"))
+    s = int(g["s"])
+    hyp = dict(HYP, mixup=0.5)
+    ims_t, labs, _ = _dataset()
+    draws = []
+    for index in (seed % 6, (seed + 2) % 6, (seed + 4) % 6):
+        random.seed(seed * 10 + index)
+        np.random.seed(seed * 10 + index)
+        draws.append(draw_sample(index, 6, s, hyp))
+    assert any(d.get("partner") is not None for d in draws)
+    imgs, targets = mosaic_batch(ims_t, labs, draws, s, hyp, dtype=torch.uint8)
+    assert np.array_equal(imgs.numpy(), g[f"img{seed}"])
+    assert targets.shape == g[f"lab{seed}"].shape
+    np.testing.assert_array_equal(targets.numpy(), g[f"lab{seed}"])
+
+
 def test_draws_follow_the_reference_order_and_loader_shapes():
     from yolov5_amd.dataloaders import MosaicLoader, draw_sample
 

@@ -59,6 +59,29 @@ def test_mixed_mosaic_and_letterbox_branches_match_reference_golden(seed):
     np.testing.assert_array_equal(targets.numpy(), g[f"lab{seed}"])
 
 
+@pytest.mark.parametrize("seed", [21, 22, 23, 24])
+def test_mixup_matches_reference_golden(seed):
+    """hyp['mixup'] = 0.5 on the MI355X (the double-precision blend + uint8 truncation of utils/augmentations.py:231 inside the kernel) against the
+    reference's own __getitem__ / collate_fn (tests/golden/augment_mixup.npz); emulator twin: tests/test_emu_augment.py."""
+    from yolov5_amd.dataloaders import draw_sample, mosaic_batch
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "augment_mixup.npz"))
+    dev = torch.device("cuda:0")
+    s = int(g["s"])
+    hyp = dict(HYP, mixup=0.5)
+    ims, labs = ao.synthetic_dataset(6, seed=3)
+    ims_t = [torch.from_numpy(im).to(dev) for im in ims]
+    labs = [lb.astype(np.float32) for lb in labs]
+    draws = []
+    for index in (seed % 6, (seed + 2) % 6, (seed + 4) % 6):
+        random.seed(seed * 10 + index)
+        np.random.seed(seed * 10 + index)
+        draws.append(draw_sample(index, 6, s, hyp))
+    imgs, targets = mosaic_batch(ims_t, labs, draws, s, hyp, dtype=torch.uint8)
+    assert np.array_equal(imgs.cpu().numpy(), g[f"img{seed}"])
+    np.testing.assert_array_equal(targets.numpy(), g[f"lab{seed}"])
+
+
 def test_full_size_batch_vs_oracle_and_rate():
     from yolov5_amd.dataloaders import draw_sample, mosaic_batch
 

@@ -233,6 +233,23 @@ def test_training_sample_pipeline_mixed_branches_match_reference_golden(seed):
     assert labb.shape == g[f"lab{seed}"].shape and np.array_equal(labb, g[f"lab{seed}"])
 
 
+@pytest.mark.parametrize("seed", [21, 22, 23, 24])
+def test_training_sample_pipeline_mixup_matches_reference_golden(seed):
+    """hyp['mixup'] = 0.5 (dataloaders.py:707-708 -> utils/augmentations.py:225-233): the oracle's restatement -- partner mosaic with its own draws,
+    float64 blend truncated to uint8, labels concatenated -- against the reference's own __getitem__ / collate_fn (tests/golden/augment_mixup.npz)."""
+    from oracle import augment_oracle as ao
+
+    g = _load("augment_mixup.npz")
+    s = int(g["s"])
+    ims, labs = ao.synthetic_dataset(6, seed=3)
+    labs = [lb.astype(np.float32) for lb in labs]
+    hyp = dict(ao.HYP_AUG, degrees=5.0, shear=2.0, flipud=0.3, mixup=0.5)
+    samples = [ao.sample(ims, labs, ao.reference_draws(seed * 10 + index, index, 6, s, hyp), s, hyp) for index in (seed % 6, (seed + 2) % 6, (seed + 4) % 6)]
+    imb, labb = ao.collate(samples)
+    assert np.array_equal(imb, g[f"img{seed}"])
+    assert labb.shape == g[f"lab{seed}"].shape and np.array_equal(labb, g[f"lab{seed}"])
+
+
 def test_loss_focal():
     """hyp fl_gamma = 1.5 + label smoothing 0.1 (utils/loss.py:120-122 -> FocalLoss :77-98): the oracle's restatement against the reference's own
     ComputeLoss (tests/golden/loss_focal.npz, oracle/make_golden.py gen_loss)."""

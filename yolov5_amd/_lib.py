@@ -48,7 +48,8 @@ class LetterboxJob(C.Structure):
 class MosaicJob(C.Structure):
     """include/yolov5_hip.h: y5_mosaic_job (one output image of a y5_mosaic_batch launch)."""
     _fields_ = [("src", C.c_void_p * 4)] + [(n, C.c_int * 4) for n in ("h0", "w0", "stride", "rh", "rw", "x1a", "y1a", "x2a", "y2a", "x1b", "y1b")] + \
-               [("A", C.c_double * 6), ("lut", (C.c_ubyte * 256) * 3), ("hsv", C.c_int), ("flipud", C.c_int), ("fliplr", C.c_int), ("canvas", C.c_int)]
+               [("A", C.c_double * 6), ("lut", (C.c_ubyte * 256) * 3), ("hsv", C.c_int), ("flipud", C.c_int), ("fliplr", C.c_int), ("canvas", C.c_int),
+                ("mix_r", C.c_double), ("mix_job", C.c_int), ("reserved", C.c_int)]
 
 
 class MtTensor(C.Structure):

@@ -2,6 +2,7 @@
 //     load_mosaic            utils/dataloaders.py:798-855   4 images resized to the training size, tiled on a 2s x 2s canvas of 114s
 //       or (hyp['mosaic'] gate lost, :710-733)              1 image, load_image + letterbox = one tile on an s x s canvas of 114s
 //     random_perspective     utils/augmentations.py:118-166 cv2.warpAffine(canvas, M[:2], (s, s), borderValue 114), INTER_LINEAR
+//     mixup                  utils/augmentations.py:225-233 (dataloaders.py:707-708) a second warped mosaic blended in, uint8 truncation
 //     augment_hsv            utils/augmentations.py:69-83   BGR -> HSV, three 256-entry LUTs, HSV -> BGR
 //     flipud / fliplr        utils/dataloaders.py:747-757
 //     img.transpose((2, 0, 1))[::-1]  + collate's torch.stack   :761-762, :858-863   -> (B, 3, s, s) RGB planes, uint8 or fp16 / 255
@@ -86,19 +87,11 @@ __device__ inline void hsv2bgr_u8(int h8, int s8, int v8, int out[3]) {  // HSV2
 }
 }  // namespace
 
-__global__ __launch_bounds__(256)
-void y5_mosaic_kernel(const AugParams p) {
-  const int b = blockIdx.y;
-  const int id = blockIdx.x * 256 + threadIdx.x;
-  const int S = p.S;
-  if (id >= S * S) return;
-  const int oy = id / S, ox = id - oy * S;
-  const y5_mosaic_job& j = p.jobs[b];
-  const int y = j.flipud ? S - 1 - oy : oy, x = j.fliplr ? S - 1 - ox : ox;   // np.flipud / np.fliplr of the warped image
+// the warped canvas of job j at output pixel (x, y): WarpAffineInvoker's fixed-point source position (5 fractional bits) and 15-bit bilinear weights
+__device__ inline void warp_pixel(const y5_mosaic_job& j, int S, int pad, int x, int y, int bgr[3]) {
   ResizeGeom g[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) g[t] = resize_geom(j.h0[t], j.w0[t], j.rh[t], j.rw[t]);
-  // WarpAffineInvoker: fixed-point source position with 5 fractional bits
   const long long adelta = sat_int(j.A[0] * (double)x * 1024.0), bdelta = sat_int(j.A[3] * (double)x * 1024.0);
   const long long X0 = sat_int((j.A[1] * (double)y + j.A[2]) * 1024.0) + 16, Y0 = sat_int((j.A[4] * (double)y + j.A[5]) * 1024.0) + 16;
   const long long X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
@@ -108,16 +101,34 @@ void y5_mosaic_kernel(const AugParams p) {
   const int sx = (int)sxl, sy = (int)syl, fx = (int)(X & 31), fy = (int)(Y & 31);
   int p00[3], p01[3], p10[3], p11[3];
   const int S2 = j.canvas > 0 ? j.canvas : 2 * S;
-  canvas_pixel(j, g, S2, p.pad, sy, sx, p00);
-  canvas_pixel(j, g, S2, p.pad, sy, sx + 1, p01);
-  canvas_pixel(j, g, S2, p.pad, sy + 1, sx, p10);
-  canvas_pixel(j, g, S2, p.pad, sy + 1, sx + 1, p11);
+  canvas_pixel(j, g, S2, pad, sy, sx, p00);
+  canvas_pixel(j, g, S2, pad, sy, sx + 1, p01);
+  canvas_pixel(j, g, S2, pad, sy + 1, sx, p10);
+  canvas_pixel(j, g, S2, pad, sy + 1, sx + 1, p11);
   const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
-  int bgr[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const int q = (p00[c] * w00 + p01[c] * w01 + p10[c] * w10 + p11[c] * w11 + (1 << 14)) >> 15;
     bgr[c] = q < 0 ? 0 : (q > 255 ? 255 : q);
+  }
+}
+
+__global__ __launch_bounds__(256)
+void y5_mosaic_kernel(const AugParams p) {
+  const int b = blockIdx.y;
+  const int id = blockIdx.x * 256 + threadIdx.x;
+  const int S = p.S;
+  if (id >= S * S) return;
+  const int oy = id / S, ox = id - oy * S;
+  const y5_mosaic_job& j = p.jobs[b];
+  const int y = j.flipud ? S - 1 - oy : oy, x = j.fliplr ? S - 1 - ox : ox;   // np.flipud / np.fliplr of the warped image
+  int bgr[3];
+  warp_pixel(j, S, p.pad, x, y, bgr);
+  if (j.mix_job > 0) {   // utils/augmentations.py:225-233 mixup: (im * r + im2 * (1 - r)).astype(np.uint8) on the two warped mosaics, in double
+    int b2[3];
+    warp_pixel(p.jobs[j.mix_job - 1], S, p.pad, x, y, b2);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) bgr[c] = (int)((double)bgr[c] * j.mix_r + (double)b2[c] * (1.0 - j.mix_r));
   }
   if (j.hsv) {
     int h, s, v;

@@ -8,7 +8,7 @@ rates of this engine (3 k img/s per GPU) the reference's 8 cv2 worker processes 
 
 Random draws follow the reference's ORDER per sample (documented in `draw_sample`), so that a `random.seed()` / `np.random.seed()`-ed
 run consumes the generators exactly as `__getitem__` does; they can also be passed in (parity tests).
-Not covered: rect batches / augment = False (the validation loader: augmentations.letterbox_batch), mixup, copy_paste, albumentations,
+Not covered: rect batches / augment = False (the validation loader: augmentations.letterbox_batch), copy_paste, albumentations,
 perspective != 0, segments."""
 from __future__ import annotations
 
@@ -43,7 +43,19 @@ def draw_sample(index, n_images, s, hyp, rng=random, np_rng=np.random):
     d["shear"] = (rng.uniform(-hyp["shear"], hyp["shear"]), rng.uniform(-hyp["shear"], hyp["shear"]))
     d["translate"] = (rng.uniform(0.5 - hyp["translate"], 0.5 + hyp["translate"]), rng.uniform(0.5 - hyp["translate"], 0.5 + hyp["translate"]))
     if d["mosaic"] and rng.random() < hyp["mixup"]:
-        raise NotImplementedError("MosaicLoader: mixup is not implemented")
+        # dataloaders.py:707-708: random.choice(indices), the partner mosaic's own draws (load_mosaic -> random_perspective), np.random.beta in mixup()
+        m = {"mosaic": True}
+        i2 = rng.choice(range(n_images))
+        m["yc"], m["xc"] = (int(rng.uniform(-x, 2 * s + x)) for x in (-s // 2, -s // 2))
+        idx = [i2, *rng.choices(range(n_images), k=3)]
+        rng.shuffle(idx)
+        m["indices"] = idx
+        m["persp"] = (rng.uniform(-hyp["perspective"], hyp["perspective"]), rng.uniform(-hyp["perspective"], hyp["perspective"]))
+        m["angle"] = rng.uniform(-hyp["degrees"], hyp["degrees"])
+        m["scale"] = rng.uniform(1 - hyp["scale"], 1 + hyp["scale"])
+        m["shear"] = (rng.uniform(-hyp["shear"], hyp["shear"]), rng.uniform(-hyp["shear"], hyp["shear"]))
+        m["translate"] = (rng.uniform(0.5 - hyp["translate"], 0.5 + hyp["translate"]), rng.uniform(0.5 - hyp["translate"], 0.5 + hyp["translate"]))
+        d["partner"], d["mix_r"] = m, float(np_rng.beta(32.0, 32.0))
     d["hsv"] = np_rng.uniform(-1, 1, 3) * [hyp["hsv_h"], hyp["hsv_s"], hyp["hsv_v"]] + 1
     d["flipud"] = rng.random() < hyp["flipud"]
     d["fliplr"] = rng.random() < hyp["fliplr"]
@@ -106,8 +118,8 @@ def _invert_affine(M):
 
 
 def _labels(labels, d, hw, rects, M, width, height, s, pads=None):
-    """Label half of the sample: tiles -> canvas pixels (xywhn2xyxy, :838 / :720), mosaic only: clip to the canvas (:845-846), corners through
-    M + hull + clip + box_candidates (augmentations.py:193-209,246-258), back to normalised xywh with clipping (dataloaders.py:737), flips.
+    """Label half of the sample up to random_perspective: tiles -> canvas pixels (xywhn2xyxy, :838 / :720), mosaic only: clip to the canvas
+    (:845-846), corners through M + hull + clip + box_candidates (augmentations.py:193-209,246-258) -> (k, 5) [cls, x1, y1, x2, y2] in output pixels.
     pads: the (padw, padh) of each tile when they are not the integer tile offsets (letterbox branch: the FLOAT half-borders dw, dh)."""
     parts = []
     for k, (i, (h, w), (x1a, y1a, _x2a, _y2a, x1b, y1b)) in enumerate(zip(d["indices"], hw, rects)):
@@ -139,6 +151,11 @@ def _labels(labels, d, hw, rects, M, width, height, s, pads=None):
         keep = (w2 > 2) & (h2 > 2) & (w2 * h2 / (w1 * h1 + 1e-16) > 0.10) & (ar < 100)
         t = t[keep]
         t[:, 1:5] = new[keep]
+    return t
+
+
+def _finish_labels(t, d, width, height):
+    """dataloaders.py:735-757 on the (possibly mixup-concatenated) pixel boxes: normalised xywh with clipping (:737), flips."""
     if len(t):
         b = t[:, 1:5]
         b[:, [0, 2]] = b[:, [0, 2]].clip(0, width - 1e-3)
@@ -166,12 +183,11 @@ def mosaic_batch(images, labels, draws, s, hyp=None, dtype=torch.uint8, normaliz
     hyp = HYP_AUG if hyp is None else hyp
     dev = images[0].device
     B = len(draws)
-    jobs = (_lib.MosaicJob * B)()
     labs = []
     use_hsv = bool(hyp["hsv_h"] or hyp["hsv_s"] or hyp["hsv_v"])
     x = np.arange(0, 256, dtype=np.float64)
-    for b, d in enumerate(draws):
-        j = jobs[b]
+    def fill(j, d):
+        """Geometry half of one job (tiles, rectangles, inverse affine map) -> the pixel boxes of its labels after random_perspective."""
         hw = []
         for t, i in enumerate(d["indices"]):
             im = images[i]
@@ -198,12 +214,25 @@ def mosaic_batch(images, labels, draws, s, hyp=None, dtype=torch.uint8, normaliz
         A = _invert_affine(M)
         for k in range(6):
             j.A[k] = float(A.reshape(-1)[k])
+        return _labels(labels, d, hw, rects, M, width, height, s, pads), width, height
+
+    partners = [d for d in draws if d.get("partner") is not None]
+    jobs = (_lib.MosaicJob * (B + len(partners)))()
+    npart = 0
+    for b, d in enumerate(draws):
+        j = jobs[b]
+        t, width, height = fill(j, d)
+        if d.get("partner") is not None:   # mixup (dataloaders.py:707-708): the partner mosaic is a job of its own behind the B rendered ones
+            t2, _, _ = fill(jobs[B + npart], d["partner"])
+            j.mix_job, j.mix_r = B + npart + 1, float(d["mix_r"])
+            npart += 1
+            t = np.concatenate((t, t2), 0)
         r = np.asarray(d["hsv"], dtype=np.float64)
         luts = (((x * r[0]) % 180).astype(np.uint8), np.clip(x * r[1], 0, 255).astype(np.uint8), np.clip(x * r[2], 0, 255).astype(np.uint8))
         for c in range(3):
             C.memmove(j.lut[c], luts[c].ctypes.data, 256)
         j.hsv, j.flipud, j.fliplr = int(use_hsv), int(bool(d["flipud"])), int(bool(d["fliplr"]))
-        lb = _labels(labels, d, hw, rects, M, width, height, s, pads)
+        lb = _finish_labels(t, d, width, height)
         lb[:, 0] = b                                             # collate_fn (dataloaders.py:860-862)
         labs.append(lb)
     table = torch.frombuffer(bytearray(jobs), dtype=torch.uint8).to(dev)
