@@ -104,6 +104,8 @@ int y5_conv2d_time(const y5_conv_desc* d, const void* x, const void* w_packed, c
  * ------------------------------------------------------------------------------------------------------- */
 int y5_conv_stem_fwd(const void* x_nchw, int B, int H, int W, const void* w_stem, const float* bias, int C2, int Npad,
                      void* y, int ldy, int max_blocks, void* stream);
+/* The same launch WITHOUT bias and activation (train mode: BatchNorm with batch statistics follows as its own passes, models/common.py:86-88). */
+int y5_conv_stem_fwd_raw(const void* x_nchw, int B, int H, int W, const void* w_stem, int C2, int Npad, void* y, int ldy, int max_blocks, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * y5_nchw_to_nhwc -- input contract (train.py:379, val.py:259-262, detect.py:206-210, common.py:926):
@@ -273,7 +275,8 @@ int y5_pack_dgrad_weight(const float* w, int C2, int C1, int KH, int KW, const i
 int y5_unpack_conv_wgrad(const float* dw_packed, int Kpad, float* gw, int C2, int C1, int KH, int KW, int C1_view, void* stream);
 /* The same three transforms over many filters in ONE launch: `jobs_dev` is a DEVICE array of njobs descriptors, max_total the
  * largest `total` among them.  kind 0 = y5_pack_conv_weight, 1 = y5_pack_dgrad_weight, 2 = y5_unpack_conv_wgrad (total = output
- * elements: Npad*Kpad for the packs, C2*C1*KH*KW for the unpack). */
+ * elements: Npad*Kpad for the packs, C2*C1*KH*KW for the unpack), 3 = the stem filter (C2, 3, 6, 6) fp32 -> [Npad][144] fp16 of
+ * y5_conv_stem_fwd / _raw (total = Npad * 144). */
 typedef struct {
   const void* src; void* dst;
   long long total;

@@ -186,3 +186,32 @@ def test_conv_stem_direct_nchw(B, H, W, C2, max_blocks):
     ref = F.silu(F.conv2d(x.float(), w, b, 2, 2)).permute(0, 2, 3, 1).numpy()
     np.testing.assert_allclose(y[..., :C2].astype(np.float32), ref, rtol=2e-2, atol=2e-2)
     assert np.all(y[..., C2:] == -3.0)
+
+
+@pytest.mark.parametrize("B,H,W,C2", [(1, 8, 64, 32), (2, 6, 128, 16), (1, 4, 64, 64)])
+def test_conv_stem_raw_and_device_filter_pack(B, H, W, C2):
+    """y5_conv_stem_fwd_raw (train mode: no bias, no activation) on a filter packed by the y5_filter_jobs kind-3 job (fp32 (C2, 3, 6, 6) master weights ->
+    [Npad][144] fp16, the layout of packing.pack_stem_weight) against torch's conv2d."""
+    from yolov5_amd.packing import pack_stem_weight, round_up
+
+    lib = emu()
+    x = torch.from_numpy(detgen.uniform((B, 3, H, W), 0, 1, name="xr")).half()
+    w = torch.from_numpy(detgen.uniform((C2, 3, 6, 6), -0.3, 0.3, name="wr"))
+    npad = round_up(C2, 32)
+    w32 = aligned(w.shape, np.float32); w32[...] = w.numpy()
+    wa = aligned((npad * 144,), np.float16, 7.0)
+    job = (_lib.FilterJob * 1)()
+    j = job[0]
+    j.src, j.dst, j.total, j.kind, j.C2, j.C1, j.KH, j.KW, j.Kpad, j.Npad = w32.ctypes.data, wa.ctypes.data, npad * 144, 3, C2, 3, 6, 6, 144, npad
+    tab = aligned((C.sizeof(job),), np.uint8); tab[...] = np.frombuffer(job, dtype=np.uint8)
+    assert lib.y5_filter_jobs(ptr(tab), 1, npad * 144, None) == 0, lib.y5_last_error()
+    ref_w, _, _ = pack_stem_weight(w, None)
+    assert np.array_equal(wa.reshape(npad, 144), ref_w.numpy())
+    xa = aligned(x.shape, np.float16); xa[...] = x.numpy()
+    ldy = C2 + 8
+    y = aligned((B, H // 2, W // 2, ldy), np.float16, -3.0)
+    rc = lib.y5_conv_stem_fwd_raw(ptr(xa), B, H, W, ptr(wa), C2, npad, ptr(y), ldy, 0, None)
+    assert rc == 0, lib.y5_last_error()
+    ref = F.conv2d(x.float(), w.half().float(), None, 2, 2).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(y[..., :C2].astype(np.float32), ref, rtol=5e-3, atol=5e-3)
+    assert np.all(y[..., C2:] == -3.0)

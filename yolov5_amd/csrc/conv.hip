@@ -590,10 +590,10 @@ extern "C" int y5_conv_k3pw_fwd(const y5_conv_desc* d, const void* x, const void
 
 // ---- stem (conv_stem.h) -----------------------------------------------------------------------------------
 namespace {
-template <int NT, int S>
+template <int NT, int S, bool RAW = false>
 int launch_stem(const Y5StemParams& p, int max_blocks, hipStream_t stream) {
   const size_t lds = y5_conv_stem_lds_bytes<NT, S>();
-  auto kern = y5_conv_stem_kernel<NT, S>;
+  auto kern = y5_conv_stem_kernel<NT, S, RAW>;
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -635,6 +635,27 @@ extern "C" int y5_conv_stem_fwd(const void* x_nchw, int B, int H, int W, const v
   p.tiles_per_row = p.OW / 32;
   p.nwt = B * p.OH * p.tiles_per_row;
   return Npad == 32 ? launch_stem<1, 4>(p, max_blocks, stream) : launch_stem<2, 3>(p, max_blocks, stream);
+}
+
+// The same launch without bias and activation: the train-mode forward of 0.Conv (models/common.py:86-88 with BatchNorm in training mode: the
+// convolution's own output is what the statistics pass reads).  Replaces a layout pass + a table-gather launch of the general kernel (369 us at bs 64).
+extern "C" int y5_conv_stem_fwd_raw(const void* x_nchw, int B, int H, int W, const void* w_stem, int C2, int Npad, void* y, int ldy, int max_blocks,
+                                    void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (!x_nchw || !w_stem || !y) return y5_fail(Y5_ERR_BAD_ARG, "conv_stem_raw: null pointer");
+  if (B < 1 || H < 2 || (H & 1) || W < 64 || (W & 63)) return y5_fail(Y5_ERR_UNSUPPORTED, "conv_stem_raw: needs even H and W % 64 == 0");
+  if (C2 < 8 || (C2 & 7) || C2 > Npad || (Npad != 32 && Npad != 64) || (ldy & 7) || ldy < C2)
+    return y5_fail(Y5_ERR_UNSUPPORTED, "conv_stem_raw: C2 must be a multiple of 8, <= 64 (Npad 32 or 64)");
+  if (((uintptr_t)x_nchw | (uintptr_t)w_stem | (uintptr_t)y) & 15) return y5_fail(Y5_ERR_BAD_ARG, "conv_stem_raw: pointers must be 16-byte aligned");
+  if ((long long)B * 3 * H * W >= 0x3fffffffLL) return y5_fail(Y5_ERR_UNSUPPORTED, "conv_stem_raw: input exceeds 2^30 elements");
+  Y5StemParams p{};
+  p.x = x_nchw; p.w = w_stem; p.y = y; p.zero = y5_zero_page();
+  if (!p.zero) return y5_fail(Y5_ERR_RUNTIME, "conv_stem_raw: zero page allocation failed");
+  p.bias = static_cast<const float*>(p.zero);   // (the kernel stages Npad floats of bias it never uses)
+  p.B = B; p.H = H; p.W = W; p.OH = H / 2; p.OW = W / 2; p.C2 = C2; p.ldy = ldy;
+  p.tiles_per_row = p.OW / 32;
+  p.nwt = B * p.OH * p.tiles_per_row;
+  return Npad == 32 ? launch_stem<1, 4, true>(p, max_blocks, stream) : launch_stem<2, 3, true>(p, max_blocks, stream);
 }
 
 #ifdef Y5_K3_TIMING

@@ -32,7 +32,8 @@ constexpr size_t y5_conv_stem_lds_bytes() {
 
 // (launch bound 2: with a 256-register budget the compiler keeps the accumulators in VGPRs -- at a 512 budget it parks them in AGPRs and the epilogue,
 // which is this kernel's issue bound, pays 16 v_accvgpr_read per tile; LDS still limits a CU to three workgroups)
-template <int NT, int S>
+// RAW: the convolution's plain output (no bias, no activation) -- the train-mode forward, whose BatchNorm + SiLU follow as their own passes
+template <int NT, int S, bool RAW = false>
 __global__ __launch_bounds__(256, 2)
 void y5_conv_stem_kernel(const Y5StemParams p) {
   typedef half_t T;
@@ -158,7 +159,7 @@ void y5_conv_stem_kernel(const Y5StemParams p) {
         const float4_t bv = *reinterpret_cast<const float4_t*>(blds + j * 32 + q * 8 + g * 4);
         half4_t o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (half_t)y5_silu(acc[j][q * 4 + e] + bv[e]);
+        for (int e = 0; e < 4; ++e) o[e] = RAW ? (half_t)acc[j][q * 4 + e] : (half_t)y5_silu(acc[j][q * 4 + e] + bv[e]);
         const int slot = j * 4 + q;
         *reinterpret_cast<half4_t*>(st + frow * (NPAD * 2) + ((slot ^ (frow & SWM)) * 16) + g * 8) = o;
       }

@@ -431,6 +431,14 @@ void y5_filter_jobs_kernel(const y5_filter_job* __restrict__ jobs, int njobs) {
     const long long end = base + MT_CH < j.total ? base + MT_CH : j.total;
   // element indices fit 32 bits (y5_filter_jobs checks): unsigned 32-bit divisions instead of the ~100-instruction 64-bit sequences
   for (unsigned i = (unsigned)base + threadIdx.x; i < (unsigned)end; i += 256) {
+    if (j.kind == 3) {  // stem filter (C2, 3, 6, 6) fp32 -> [Npad][144] fp16 of y5_conv_stem_fwd: k = (c*6 + kh)*8 + kw, taps kw = 6, 7 zero
+      const unsigned k = i % 144u, n = i / 144u;
+      const unsigned kw = k & 7u, kh = (k >> 3) % 6u, c = k / 48u;
+      float v = 0.f;
+      if ((int)n < j.C2 && kw < 6u) v = static_cast<const float*>(j.src)[((n * 3u + c) * 6u + kh) * 6u + kw];
+      static_cast<half_t*>(j.dst)[i] = (half_t)v;
+      continue;
+    }
     if (j.kind == 2) {  // packed fp32 dW -> (C2, C1, KH, KW)
       const unsigned kw = i % (unsigned)j.KW;
       unsigned t = i / (unsigned)j.KW;

@@ -169,6 +169,16 @@ class TrainEngine:
         self._dw_total += round_up(st["Npad"] * st["Kpad"], 64)
         st["c2s"] = c2 if st["has_bn"] else op["c2_store"]
         st["fcfg"] = -1
+        # 0.Conv (k6 s2 p2 on the 3-channel image): the forward runs in the NCHW stem kernel without bias / activation (y5_conv_stem_fwd_raw) instead of
+        # a table-gather launch of the general kernel on the NHWC copy (369 -> ~185 us at bs 64); the NHWC copy stays for the weight gradient.
+        # Y5_TRAIN_STEM=0 keeps the general kernel.  (fp16 plan, fp16 NCHW input, even H, W % 64 == 0, <= 64 output channels.)
+        _, _, Hi, Wi = self.x_shape
+        st["stem_w"] = None
+        if (op["view"] == "first" and self.dtype == torch.float16 and os.environ.get("Y5_TRAIN_STEM", "1") != "0" and st["has_bn"]
+                and (c1, kh, kw) == (3, 6, 6) and tuple(op["s"]) == (2, 2) and tuple(op["p"]) == (2, 2) and c2 % 8 == 0 and c2 <= 64
+                and Hi % 2 == 0 and Wi % 64 == 0):
+            st["stem_np"] = round_up(c2, 32)
+            st["stem_w"] = be.empty((st["stem_np"] * 144,), torch.float16)
         subs = []
         if op["view"] != "first":
             (sh, sw), (ph, pw) = op["s"], op["p"]
@@ -277,6 +287,7 @@ class TrainEngine:
         self._fwd_seq = getattr(self, "_fwd_seq", 0) + 1  # backward checks that its saved activations are still this forward's
         _state.bump_weights_epoch()  # BatchNorm running statistics are updated through raw pointers below
         x, xptr, src_dt = be.input(x)
+        self._x_nchw = (xptr, src_dt)
         self._run_jobs(0, stm)  # every forward filter: fp32 master weights -> packed fp16, one launch
         for op in self.spec.ops:
             kind = op["op"]
@@ -326,7 +337,12 @@ class TrainEngine:
         ptrs = (_vp(self._ptr(x)), _vp(be.ptr(st["wp"])), _vp(be.ptr(st["bp"])), None, _vp(out_ptr), None)
         if st["fcfg"] < 0 and getattr(be, "autotune", False):
             st["fcfg"] = d.cfg = autotune_conv(lib, d, ptrs, stm)
-        _lib.check(lib.y5_conv2d_fwd(C.byref(d), *ptrs, stm), lib)
+        xp, xdt = getattr(self, "_x_nchw", (0, -1))
+        if st["stem_w"] is not None and xdt == _lib.Y5_F16 and xp % 16 == 0:
+            _lib.check(lib.y5_conv_stem_fwd_raw(_vp(xp), B, self.x_shape[2], self.x_shape[3], _vp(be.ptr(st["stem_w"])), c2, st["stem_np"], _vp(out_ptr), ldo,
+                                                0, stm), lib)
+        else:
+            _lib.check(lib.y5_conv2d_fwd(C.byref(d), *ptrs, stm), lib)
         if st["has_bn"]:
             bn = st["mod"].bn
             npix = B * y.H * y.W
@@ -476,6 +492,8 @@ class TrainEngine:
                 c2, c1, kh, kw = cv.weight.shape
                 if kind == 0:
                     rows.append((wptr, be.ptr(st["wp"]), st["Npad"] * st["Kpad"], 0, c2, c1, kh, kw, st["c1v"], 0, st["Kpad"], st["Npad"], 0, 0, (), ()))
+                    if st["stem_w"] is not None:   # the stem kernel's own filter layout ([Npad][144], y5_filter_jobs kind 3)
+                        rows.append((wptr, be.ptr(st["stem_w"]), st["stem_np"] * 144, 3, c2, c1, kh, kw, 0, 0, 144, st["stem_np"], 0, 0, (), ()))
                 elif kind == 2:
                     rows.append((be.ptr(self.dwflat) + st["dw_off"] * 4, self._gptr(cv.weight), c2 * c1 * kh * kw, 2, c2, c1, kh, kw, st["c1v"], 0,
                                  st["Kpad"], st["Npad"], 0, 0, (), ()))
