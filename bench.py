@@ -159,6 +159,47 @@ def pmc_traffic(a, conv_by):
     return {"gbytes_per_step": round(gb, 3), "vs_algorithmic": round(gb * 1e9 / conv_by, 3) if conv_by else None, "kernel_src_sha16": have, "source": src}
 
 
+def pmc_mfma_busy(a):
+    """Counter-based matrix-core utilisation of the conv launches of one forward: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles),
+    collected by scripts/pmc_issue_mix.sh (rocprofv3 --kernel-trace --pmc, two SQ passes) and committed under profiles/pmc/ -- the figure
+    north_star asks for beside the FLOP-derived fraction.  Same validity rule as `traffic`: only for the configuration and the kernel sources
+    (kernel_src_hash) it was measured with; otherwise reported as stale with a null value."""
+    import glob
+
+    cands = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc", "r*_pmc_issue_mix.json")))
+    if not (a.model == "yolov5s" and a.batch == 64 and a.imgsz == 640 and cands):
+        return None, {}
+    path = cands[-1]
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        frac = float(d["stack"]["mfma_busy_frac"])
+    except (OSError, ValueError, KeyError, TypeError):
+        return None, {}
+    src = f"profiles/pmc/{os.path.basename(path)} (scripts/pmc_issue_mix.sh: rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE, ...)"
+    have, want = d.get("kernel_src_sha16"), kernel_src_hash()
+    per_kernel = {r["kernel"]: r.get("mfma_busy_frac") for r in d.get("kernels", []) if r.get("conv")}
+    if have != want:
+        return {"value": None, "stale": True, "stale_value": round(frac, 4), "measured_with_kernel_src_sha16": have, "current_kernel_src_sha16": want, "source": src}, {}
+    return {"value": round(frac, 4), "kernel_src_sha16": have, "source": src,
+            "definition": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles) over the conv launches of one forward (inside the kernels: no launch gaps)"}, per_kernel
+
+
+def conv_family(cfg):
+    """Kernel family a convolution configuration id launches (csrc/conv.hip id space)."""
+    if isinstance(cfg, str):
+        return {"front": "y5_conv_front_kernel", "bneck": "y5_conv_bneck_kernel"}.get(cfg, "y5_conv_" + cfg + "_kernel")
+    if cfg is None or cfg < 0:
+        return None
+    if cfg >= 84 or cfg == 56 or 14 <= cfg < 22:
+        return "y5_conv_pw_kernel"
+    if 78 <= cfg < 84 or 30 <= cfg < 35:
+        return "y5_conv_k3_kernel"
+    if 61 <= cfg < 78:
+        return "y5_conv_h3_kernel"
+    return "y5_conv_igemm_kernel"
+
+
 def usable_cores():
     """Host cores this process may really use: affinity mask and cgroup CPU quota, capped at 64 threads (oneDNN/OpenMP
     stop scaling -- and thrash -- far below the 256 logical CPUs the GPU box advertises)."""
@@ -337,10 +378,12 @@ def gpu_state_probe(fn, dev, seconds=1.6):
 TRAIN_GFLOP_PER_IMG = {"yolov5s": 49.3}  # forward + data gradient + weight gradient = 3 x 16.43 GFLOP at 640^2
 
 
-def train_probe(name, batch, imgsz, dev, world, steps=20, warmup=5):
+def train_probe(name, batch, imgsz, dev, world, steps=20, warmup=5, exchange_group=False):
     """BASELINE config 3 per-GPU shape: one training step = train-mode forward (batch-statistics BN) + ComputeLoss + backward
     (+ bucketed RCCL gradient all-reduce overlapped with backward when world > 1, loss * WORLD_SIZE as train.py:404-405) +
-    unscale / clip / SGD-Nesterov / EMA (fused), fp16 compute with fp32 master weights, synthetic data."""
+    unscale / clip / SGD-Nesterov / EMA (fused), fp16 compute with fp32 master weights, synthetic data.
+    exchange_group (N = 1 on a GPU): the model is wrapped by smart_DDP over a ONE-rank `nccl` group, so every bucket of the
+    gradient arena really goes through RCCL's launch / wait path (AVG over one rank = identity); reported beside the plain step."""
     from yolov5_amd.loss import ComputeLoss
     from yolov5_amd.torch_utils import ModelEMA, smart_DDP, smart_optimizer
     from yolov5_amd.yolo import DetectionModel
@@ -349,7 +392,8 @@ def train_probe(name, batch, imgsz, dev, world, steps=20, warmup=5):
     m = DetectionModel(name + ".yaml").to(dev).train()
     m.hyp = {"box": 0.05, "cls": 0.5, "cls_pw": 1.0, "obj": 1.0, "obj_pw": 1.0, "anchor_t": 4.0, "fl_gamma": 0.0, "label_smoothing": 0.0}
     compute_loss = ComputeLoss(m)
-    model = smart_DDP(m) if world > 1 else m
+    ddp = world > 1 or exchange_group
+    model = smart_DDP(m) if ddp else m
     opt = smart_optimizer(m, "SGD", lr=0.01, momentum=0.937, decay=5e-4)  # HipSGD: 3 groups, fused multi-tensor step
     ema = ModelEMA(m)
     g = torch.Generator(device="cpu").manual_seed(1 + int(os.environ.get("RANK", 0)))
@@ -384,7 +428,7 @@ def train_probe(name, batch, imgsz, dev, world, steps=20, warmup=5):
     per = clk.ms()
     dt = reduce_max([dt], dev, world)[0]
     ar_bytes = nbuckets = None
-    if world > 1:
+    if ddp:
         ar_bytes = sum((b.hi - b.lo) * 4 for b in model.buckets)
         nbuckets = len(model.buckets)
     del m, model, opt
@@ -392,10 +436,10 @@ def train_probe(name, batch, imgsz, dev, world, steps=20, warmup=5):
         torch.cuda.empty_cache()
     ips = batch * world * steps / dt
     out = {"images_per_sec": round(ips, 1), "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps, "warmup": warmup,
-           "step_ms": stats(per), "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+           "step_ms": stats(per), "rccl_ranks": dist.get_world_size() if ddp else 1,
            "allreduce_bytes_per_step": ar_bytes, "allreduce_buckets": nbuckets,
            "workload": f"{name} train step, {batch} img/GPU 3x{imgsz}x{imgsz}, {nt} targets: forward(train BN) + ComputeLoss + backward"
-                       f"{' + RCCL all-reduce (overlapped)' if world > 1 else ''} + clip + SGD + EMA; fp16 compute / fp32 masters",
+                       f"{' + RCCL all-reduce (overlapped)' if ddp else ''} + clip + SGD + EMA; fp16 compute / fp32 masters",
            "loss": round(float(loss.detach()), 4)}
     gf = TRAIN_GFLOP_PER_IMG.get(name)
     if gf and imgsz == 640:
@@ -404,6 +448,36 @@ def train_probe(name, batch, imgsz, dev, world, steps=20, warmup=5):
                            "traffic": None, "algorithmic_gflop_per_img": gf,
                            "note": "whole training step (all kernels + host), per GPU: 3 x forward conv FLOPs / step time"}
     return out
+
+
+def train_with_exchange(name, batch, imgsz, dev, steps=20, warmup=5):
+    """N = 1 on a GPU: the plain training step (the figure `train.ms_per_step` has always meant: train.py without DDP at one GPU) and the SAME step
+    through smart_DDP over a one-rank RCCL group -- the exchange step of the data-parallel path (bucketed all-reduce of the flat gradient arena
+    launched from inside the backward plan, utils/torch_utils.py:61-70) with everything but the wire: bucket bookkeeping, RCCL kernel launches on
+    its own stream, the event hand-over to the compute stream.  `exposed_us` = step with the exchange - plain step (BASELINE.md section 4 "us exposed")."""
+    plain = train_probe(name, batch, imgsz, dev, 1, steps, warmup)
+    own_group = False
+    try:
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            own_group = True
+        ex = train_probe(name, batch, imgsz, dev, 1, steps, warmup, exchange_group=True)
+        plain["rccl_ranks"] = ex["rccl_ranks"]
+        plain["allreduce_bytes_per_step"] = ex["allreduce_bytes_per_step"]
+        plain["allreduce_buckets"] = ex["allreduce_buckets"]
+        plain["exchange"] = {"backend": "nccl (RCCL), one rank", "ms_per_step": ex["ms_per_step"], "step_ms": ex["step_ms"],
+                             "exposed_us": round((ex["step_ms"]["median"] - plain["step_ms"]["median"]) * 1e3, 1),
+                             "loss": ex["loss"],
+                             "note": "same step through smart_DDP over a 1-rank RCCL group: real bucket launches / waits, no wire; no 1->8 curve has been "
+                                     "measured (the driver's 8-GPU tier was unavailable in rounds 1-3)"}
+    except Exception as e:  # the plain figure stands; say why the exchange leg is missing
+        plain["exchange"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    finally:
+        if own_group and dist.is_initialized():
+            dist.destroy_process_group()
+    return plain
 
 
 def pipeline_probe(model, batch, dev, nm, iters=10):
@@ -616,6 +690,15 @@ def dry_run_tail(a, model, x, step, nm, dev, rank, world):
     if not a.no_train:
         del model
         train = train_probe(a.model, a.batch, a.imgsz, dev, world, steps=1, warmup=1)
+    mfma_busy = pmc_mfma_busy(a) if rank == 0 else (None, {})
+    dom_busy = None
+    if rank == 0 and dominant and mfma_busy[1]:
+        # the PMC file names kernels by their (mangled or demangled) symbol: match family + the instantiation's share of launches
+        fam_rows = {k: v for k, v in mfma_busy[1].items() if dominant["family"].replace("_kernel", "") in k}
+        if len(fam_rows) == 1:
+            dom_busy = next(iter(fam_rows.values()))
+        elif fam_rows:
+            dom_busy = {"per_instantiation_of_family": fam_rows}
     if rank == 0:
         imgs = a.batch * world * a.steps
         print(json.dumps({"metric": "images/sec at 640px (yolov5s bs=64), forward+NMS", "value": round(imgs / dt, 3), "unit": "images/sec", "n_gpus": world,
@@ -796,6 +879,33 @@ def main():
     backbone = {"ms": round(bb_ms * parts, 4), "gflop": round(bb_fl * parts / 1e9, 1), "mfma_tflops": round(bb_fl / (bb_ms * 1e-3) / 1e12, 1) if bb_ms > 0 else None,
                 "mfma_frac": round(bb_fl / (bb_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4) if bb_ms > 0 else None,
                 "target_mfma_frac": 0.70, "note": "layers 0-9 (stem .. SPPF), in-situ per-op times incl. the pooling launch"} if bb_done else None
+    # the DOMINANT kernel: conv launches grouped by (family, configuration id) = one kernel instantiation; the one with the
+    # largest in-situ time per forward is named in roofline.kernel with ITS OWN achieved / frac, the stack-wide figure stays beside it as stack_frac
+    cfg_of_all = {i: c for i, (_n, c) in enumerate(eng.plan_table())}
+    groups = {}
+    for i, o, s_ in timed:
+        if i not in fl or fl[i] <= 0 or s_[1] <= 0.002:   # (fused-away ops keep a ~0 ms placeholder row)
+            continue
+        key = (conv_family(cfg_of_all.get(i)), cfg_of_all.get(i))
+        gsum = groups.setdefault(key, [0.0, 0.0, 0.0, 0])
+        gsum[0] += s_[1]; gsum[1] += fl[i]; gsum[2] += by.get(i, 0); gsum[3] += 1
+    dominant = None
+    if groups:
+        (fam, cid), (gms, gfl, gby, gn) = max(groups.items(), key=lambda kv: kv[1][0])
+        tile = ""
+        if isinstance(cid, int):
+            try:
+                import ctypes as _C
+                from yolov5_amd import _lib as _l
+                bm, bn, bk = _C.c_int(0), _C.c_int(0), _C.c_int(0)
+                _l.lib().y5_conv_cfg_info(cid, _C.byref(bm), _C.byref(bn), _C.byref(bk))
+                tile = f", {bm.value}x{bn.value} tile, {bk.value}-byte K rows"
+            except Exception:
+                tile = ""
+        dominant = {"name": f"{fam} (configuration {cid}{tile})", "family": fam, "cfg": cid, "launches_per_step": gn * parts, "ms_per_step": round(gms * parts, 4),
+                    "share_of_conv_time": round(gms / conv_ms_in_situ, 3) if conv_ms_in_situ > 0 else None,
+                    "achieved_tflops": round(gfl / (gms * 1e-3) / 1e12, 1), "frac": round(gfl / (gms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                    "hbm_gbytes_per_s": round(gby / (gms * 1e-3) / 1e9, 1)}
     # practical per-layer floor: every conv launch at the ceilings this box just showed (copy bandwidth, sustained MFMA rate)
     ceil = None
     if rank == 0:
@@ -860,7 +970,10 @@ def main():
         try:
             del model, eng, eng_top
             torch.cuda.empty_cache()
-            train = train_probe(a.model, a.batch, a.imgsz, dev, world)
+            if world == 1 and not emu and torch.device(dev).type == "cuda":
+                train = train_with_exchange(a.model, a.batch, a.imgsz, dev)   # + the exchange step through a one-rank RCCL group
+            else:
+                train = train_probe(a.model, a.batch, a.imgsz, dev, world)
         except Exception as e:  # the headline metric must not depend on the secondary probe
             if world > 1:
                 raise  # (a rank that fails alone would leave the others in a collective)
@@ -892,9 +1005,18 @@ def main():
             # fp16 MFMA peak.  The HBM view of the same launches (per-layer algorithmic bytes / the same time / 8 TB/s) is kept beside it: with
             # per-layer execution the stack's arithmetic intensity (144 flop/B for yolov5s bs=64 640^2) is below the ridge (312 flop/B), so
             # per-layer it is the HBM figure that says how close each launch is to ITS bound -- but the contract prices the stack against MFMA.
-            "roofline": {"bound": "mfma", "kernel": "y5_conv_{igemm,h3,pw,k3,stem,bneck}_kernel (all conv launches of one forward)",
-                         "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(a, conv_by * parts),
+            # roofline.kernel / achieved / frac: the DOMINANT kernel instantiation (largest time per forward) with its own figure; stack_* : all conv
+            # launches of one forward (the number rounds 1-3 reported as `frac`); mfma_busy_frac: the counter-based utilisation of the same launches
+            "roofline": {"bound": "mfma", "kernel": dominant["name"] if dominant else "y5_conv_*_kernel (all conv launches of one forward)",
+                         "achieved": dominant["achieved_tflops"] if dominant else round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": dominant["frac"] if dominant else round(achieved / MFMA_PEAK_TFLOPS, 4),
+                         "frac_definition": "conv FLOPs of the dominant kernel's launches / their in-situ time / 2500 TFLOP/s; stack_frac = the same over ALL conv "
+                                            "launches of one forward (rounds 1-3 reported that one as frac)",
+                         "dominant_kernel": dominant,
+                         "stack_kernels": "y5_conv_{front,igemm,h3,pw,k3,stem,bneck}_kernel (all conv launches of one forward)",
+                         "stack_achieved": round(achieved, 2), "stack_frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                         "mfma_busy_frac": mfma_busy[0], "mfma_busy_frac_dominant_kernel": dom_busy,
+                         "traffic": pmc_traffic(a, conv_by * parts),
                          "whole_step_frac": round(a.batch * world * a.steps / dt / world * conv_fl * parts / a.batch / 1e12 / MFMA_PEAK_TFLOPS, 4),
                          "backbone_l0_9": backbone,
                          "hbm_achieved_gbytes_per_s": round(achieved_bw, 1), "hbm_peak_gbytes_per_s": HBM_PEAK_GBS, "hbm_frac": round(achieved_bw / HBM_PEAK_GBS, 4),
@@ -909,6 +1031,12 @@ def main():
                          "launches_per_step": nconv * parts, "other_kernels_ms_per_step": round(other_ms * parts, 4),
                          "measured_ceilings": ceil},
         }
+        try:  # which plan the tuner built on this box: two lines are comparable only when this hash agrees
+            import hashlib
+            res["config"]["plan_sha16"] = hashlib.sha256(json.dumps([[n, c] for n, c in eng.plan_table()]).encode()).hexdigest()[:16]
+            res["config"]["kernel_src_sha16"] = kernel_src_hash()
+        except Exception:
+            pass
         if selfcheck is not None:
             res["selfcheck"] = selfcheck
         if nms_dist is not None:

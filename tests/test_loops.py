@@ -315,3 +315,34 @@ def test_detect_on_reference_sample_images_C1():
         assert (got[:, 2] <= im.shape[1]).all() and (got[:, 3] <= im.shape[0]).all() and len(e) > 3
         a = detset.agreement(e, got.numpy(), 0.25, box_atol=1.0, conf_atol=1e-3, margin=1e-3)
         assert a["unmatched_ref"] + a["unmatched_got"] <= 1, a
+
+
+def test_ema_bn_buffers_keep_tracking_after_a_validation():
+    """val.py:187,388 converts the EMA model `.half()` / `.float()` IN PLACE once per epoch; `nn.Module._apply` re-creates
+    buffer tensors, so a fused EMA update that cached (model buffer, EMA buffer) tensor pairs kept writing into orphans and the EMA's
+    BatchNorm running statistics froze after the first validation.  Two epochs with a validation after each: the EMA's running statistics must
+    follow the model's at the LAST optimizer step (ni = 3, in the second epoch), not those of the first epoch."""
+    from yolov5_amd.train_loop import TensorLoader, train
+
+    m, cfg, sd = _tiny(seed=2)
+    imgs, tpi = to.synthetic_set(6, 64, per_img=2, seed=4)
+    vimgs, vtpi, vshapes = _val_set(4, 64, seed=9)
+    snaps = {}
+
+    def grab(ni, li, opt):
+        snaps[ni] = {k: b.detach().clone() for k, b in m.named_buffers() if k.endswith(("running_mean", "running_var"))}
+
+    res = train(m, TensorLoader(imgs, tpi, 2), hyp=dict(to.HYP), epochs=2, device="cpu", amp=True, on_batch_end=grab,
+                val_loader=_ValLoader(vimgs, vtpi, vshapes, 2))
+    assert hasattr(res["optimizer"], "step_fused") and res["ema"].updates == 3 and len(res["results"]) == 2
+    e_b = dict(res["ema"].ema.named_buffers())
+    d = 0.9999 * (1 - np.exp(-3 / 2000))                     # decay of the third update: the EMA is (1 - d) of the model's tensors at ni = 3
+    worst_new, worst_old = 0.0, 0.0
+    for k, at3 in snaps[3].items():
+        scale = float((at3 - snaps[1][k]).abs().max())        # how far the statistics moved between the second and the third optimizer step
+        if scale < 1e-6:
+            continue
+        worst_new = max(worst_new, float((e_b[k].float() - at3).abs().max()) / scale)
+        worst_old = max(worst_old, float((e_b[k].float() - snaps[1][k]).abs().max()) / scale)
+    assert worst_old > 0.5, worst_old                         # the test can tell the two apart
+    assert worst_new < 0.05 + 2 * d, (worst_new, worst_old)   # EMA follows step 3 (one fp16 round trip of the validation allowed for)

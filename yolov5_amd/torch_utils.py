@@ -340,13 +340,30 @@ class ModelEMA:
         params = {id(p): e_p[k] for k, p in m.named_parameters() if p.dtype.is_floating_point}
         rest = [(p, e_p[k]) for k, p in m.named_parameters() if p.dtype.is_floating_point]
         rest += [(b, e_b[k]) for k, b in m.named_buffers() if b.dtype.is_floating_point and k in e_b]
-        self._pairs = (m, params, rest, {})
+        # `nn.Module._apply` (`.half()`, `.float()`, `.to()`: val.py:187,388 does that to the EMA model once per epoch) REPLACES buffer
+        # tensors while parameters keep their identity: remember where every cached buffer hangs so that a stale cache is noticed
+        owners = []
+        for root in (m, self.ema):
+            for mod in root.modules():
+                for name, b in mod._buffers.items():
+                    if b is not None and b.dtype.is_floating_point:
+                        owners.append((mod._buffers, name, b))
+        self._pairs = (m, params, rest, {}, owners)
         return self._pairs
+
+    def _current_pairs(self, model):
+        pr = self._pairs
+        if pr is None or pr[0] is not de_parallel(model) or any(d.get(k) is not t for d, k, t in pr[4]):
+            pr = self._build_pairs(model)
+        return pr
+
+    def invalidate(self):
+        """Drop the cached (model tensor, EMA tensor) pairs (after anything that re-creates tensors of either module)."""
+        self._pairs = None
 
     def param_pairs(self, model):
         """id(model parameter) -> EMA parameter tensor."""
-        pr = self._pairs if self._pairs is not None and self._pairs[0] is de_parallel(model) else self._build_pairs(model)
-        return pr[1]
+        return self._current_pairs(model)[1]
 
     def lerp_rest(self, model, d, lib, stream, skip=()):
         """EMA of every float tensor of the state_dict that the optimizer kernel did not already update (buffers: BatchNorm
@@ -357,7 +374,7 @@ class ModelEMA:
 
         from . import _lib
 
-        pr = self._pairs if self._pairs is not None and self._pairs[0] is de_parallel(model) else self._build_pairs(model)
+        pr = self._current_pairs(model)
         todo = [(s, e) for s, e in pr[2] if s.data_ptr() not in skip]
         if not todo:
             return

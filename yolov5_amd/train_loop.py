@@ -17,6 +17,8 @@ from __future__ import annotations
 
 import math
 
+from copy import deepcopy
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -183,8 +185,12 @@ def train(model, loader, hyp=None, epochs=1, device=None, batch_size=None, cos_l
                 from . import val_loop
                 from .metrics import fitness
 
-                vm = ema_obj.ema if ema_obj is not None else de_parallel(ddp)
+                # train.py:443 validates `ema.ema`; val.py:187,388 converts that copy to fp16 and back IN PLACE.  Without an EMA the live
+                # model must not take that round trip (fp16 rounding of the fp32 master weights every epoch): validate a copy of it.
+                vm = ema_obj.ema if ema_obj is not None else deepcopy(de_parallel(ddp))
                 results, _maps, _ = val_loop.run(vm, val_loader, half=amp, compute_loss=compute_loss)
+                if ema_obj is not None:
+                    ema_obj.invalidate()   # `.half()` / `.float()` re-created the EMA's buffer tensors (ModelEMA also checks by itself)
                 fi = float(fitness(np.array(results).reshape(1, -1))[0])            # :457 weighted [P, R, mAP@.5, mAP@.5:.95]
                 best_fitness = max(best_fitness, fi)
                 hist["results"].append(tuple(float(v) for v in results))
