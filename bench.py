@@ -690,15 +690,6 @@ def dry_run_tail(a, model, x, step, nm, dev, rank, world):
     if not a.no_train:
         del model
         train = train_probe(a.model, a.batch, a.imgsz, dev, world, steps=1, warmup=1)
-    mfma_busy = pmc_mfma_busy(a) if rank == 0 else (None, {})
-    dom_busy = None
-    if rank == 0 and dominant and mfma_busy[1]:
-        # the PMC file names kernels by their (mangled or demangled) symbol: match family + the instantiation's share of launches
-        fam_rows = {k: v for k, v in mfma_busy[1].items() if dominant["family"].replace("_kernel", "") in k}
-        if len(fam_rows) == 1:
-            dom_busy = next(iter(fam_rows.values()))
-        elif fam_rows:
-            dom_busy = {"per_instantiation_of_family": fam_rows}
     if rank == 0:
         imgs = a.batch * world * a.steps
         print(json.dumps({"metric": "images/sec at 640px (yolov5s bs=64), forward+NMS", "value": round(imgs / dt, 3), "unit": "images/sec", "n_gpus": world,
@@ -978,6 +969,15 @@ def main():
             if world > 1:
                 raise  # (a rank that fails alone would leave the others in a collective)
             train = {"error": f"{type(e).__name__}: {e}"}
+    mfma_busy = pmc_mfma_busy(a) if rank == 0 else (None, {})
+    dom_busy = None
+    if rank == 0 and dominant and mfma_busy[1]:
+        # the PMC file names kernels by their (mangled or demangled) symbol: match family + the instantiation's share of launches
+        fam_rows = {k: v for k, v in mfma_busy[1].items() if dominant["family"].replace("_kernel", "") in k}
+        if len(fam_rows) == 1:
+            dom_busy = next(iter(fam_rows.values()))
+        elif fam_rows:
+            dom_busy = {"per_instantiation_of_family": fam_rows}
     if rank == 0:
         imgs = a.batch * world * a.steps
         res = {
