@@ -58,9 +58,14 @@ typedef struct {
   int split_n;  /* > 0: channels [0, split_n) are stored to y (pixel stride ldy), channels [split_n, C2) to the y_up2 ARGUMENT (pixel stride
                  * ld2, channel n - split_n) -- one GEMM for C3's cv1 + cv2 (models/common.py:246) whose halves land in different buffers;
                  * no upsampled replica, residual or output placement in that mode */
+  int up_c, ld_up;  /* up_c > 0 (configurations 88 / 89, 1x1 s1 fp16 layers): `nn.Upsample(None, 2, 'nearest')` + `Concat` (models/yolov5s.yaml:36-37,
+                 * 41-42; models/common.py:443-453) consumed VIRTUALLY -- input channels [0, up_c) of output pixel (b, oh, ow) are read from a
+                 * LOW-resolution tensor (B, H/2, W/2, pixel stride ld_up) at (b, oh >> 1, ow >> 1), channels [up_c, C1) from x as usual (x = the
+                 * concat buffer, whose first up_c channels are then never written: no 2x replica exists).  The low-resolution tensor is passed in
+                 * the `residual` argument (such a layer has no residual); every other configuration rejects up_c > 0. */
 } y5_conv_desc;
 
-#define Y5_CONV_NUM_CFGS 88   /* 0..13 implicit-GEMM tiles (2 LDS stages), 14..21 streaming pointwise (1x1 s1, fp16),
+#define Y5_CONV_NUM_CFGS 90   /* 0..13 implicit-GEMM tiles (2 LDS stages), 14..21 streaming pointwise (1x1 s1, fp16),
                                 22..29 implicit-GEMM tiles with a 3-stage LDS ring (fp16), 30..34 streaming 3x3 (small C, fp16),
                                 35..39 256-row implicit-GEMM tiles with 2-4 stage rings, 4 or 8 waves (fp16, deep layers),
                                 40..45 producer/consumer implicit GEMM: 4 MFMA waves + 4 LDS-DMA waves per workgroup (fp16),
@@ -73,7 +78,9 @@ typedef struct {
                                 staged once per 32-channel chunk and serves all nine taps, only the filter streams per tap,
                                 78..79 streaming 3x3 s1 64 -> 64 with the filter's MFMA fragments in registers (3 / 4 LDS stages),
                                 80..83 streaming 3x3 with EIGHT waves per workgroup and one (two) stage(s) per wave: 64->64 s1, 32->64 s2, 32->32 s1,
-                                84..87 streaming pointwise with eight waves per workgroup, one stage per wave: 128->128, 64->64, 128->64, 128->256 */
+                                84..87 streaming pointwise with eight waves per workgroup, one stage per wave: 128->128, 64->64, 128->64, 128->256,
+                                88..89 implicit GEMM (128x128 tile: producer / consumer BK32 ring, plain 2-stage BK64) for 1x1 layers whose input is
+                                Upsample(2) + Concat, read virtually from the low-resolution tensor (y5_conv_desc.up_c > 0 only) */
 /* Scratch for the stream-K configurations (57..60): `bytes` of device memory (256-byte aligned; bytes >= y5_conv_sk_workspace_bytes())
  * that the CALLER owns and keeps alive; registered per device, used by every later y5_conv2d_fwd with such a configuration on ANY
  * stream -- so launches that may overlap in time must not both use stream-K (the engine keeps it off its side-stream ops).  The

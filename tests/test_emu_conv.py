@@ -215,3 +215,44 @@ def test_conv_stem_raw_and_device_filter_pack(B, H, W, C2):
     ref = F.conv2d(x.float(), w.half().float(), None, 2, 2).permute(0, 2, 3, 1).numpy()
     np.testing.assert_allclose(y[..., :C2].astype(np.float32), ref, rtol=5e-3, atol=5e-3)
     assert np.all(y[..., C2:] == -3.0)
+
+
+@pytest.mark.parametrize("B,H,W,c_up,c_hi,C2,cfg,max_blocks", [
+    (2, 8, 12, 64, 64, 128, 88, 0),     # producer / consumer ring, one chunk boundary at the source switch
+    (1, 10, 6, 128, 64, 96, 88, 2),     # 4 low-resolution chunks + 2 plain ones, N tail, several tiles per workgroup
+    (2, 6, 10, 64, 128, 160, 89, 0),    # 2-stage BK64 tile, two N tiles
+    (3, 4, 4, 128, 128, 64, -1, 1),     # cfg -1 resolves to 89 for up_c > 0; one workgroup walks every tile
+])
+def test_conv_virtual_upsample_concat(B, H, W, c_up, c_hi, C2, cfg, max_blocks):
+    """Configurations 88 / 89 (conv_igemm.h UP2): the 1x1 convolution behind `nn.Upsample(2, 'nearest')` + `Concat` (models/yolov5s.yaml:36-38,41-43)
+    reading the low-resolution tensor for input channels [0, c_up) -- against torch on the materialised concat.  The concat buffer's first c_up
+    channels hold garbage (NaN) to prove they are never read."""
+    lib = emu()
+    lo = torch.from_numpy(detgen.uniform((B, c_up, H // 2, W // 2), -1, 1, name="lo")).half().float()
+    hi = torch.from_numpy(detgen.uniform((B, c_hi, H, W), -1, 1, name="hi")).half().float()
+    C1 = c_up + c_hi
+    w = torch.from_numpy(detgen.uniform((C2, C1, 1, 1), -0.2, 0.2, name="wu")).half().float()
+    b = torch.from_numpy(detgen.uniform((C2,), -0.5, 0.5, name="bu"))
+    ld_lo, ldx, ldy = c_up + 16, C1 + 8, C2 + 8
+    lo_a = aligned((B, H // 2, W // 2, ld_lo), np.float16, 9.0)
+    lo_a[..., :c_up] = lo.permute(0, 2, 3, 1).numpy().astype(np.float16)
+    x = aligned((B, H, W, ldx), np.float16, 7.0)
+    x[..., :c_up] = np.nan
+    x[..., c_up:C1] = hi.permute(0, 2, 3, 1).numpy().astype(np.float16)
+    wp, bp, K, Kpad, Npad = pack_conv_weight(w, b, torch.float16)
+    wp_a = aligned(wp.shape, np.float16); wp_a[...] = wp.numpy()
+    bp_a = aligned(bp.shape, np.float32); bp_a[...] = bp.numpy()
+    y = aligned((B, H, W, ldy), np.float16, -3.0)
+    d = _lib.ConvDesc(dtype=_lib.Y5_F16, B=B, H=H, W=W, C1=C1, ldx=ldx, OH=H, OW=W, C2=C2, ldy=ldy, KH=1, KW=1, SH=1, SW=1, PH=0, PW=0, act=1,
+                      Kpad=Kpad, Npad=Npad, ldr=0, ld2=0, cfg=cfg, max_blocks=max_blocks, up_c=c_up, ld_up=ld_lo)
+    rc = lib.y5_conv2d_fwd(C.byref(d), ptr(x), ptr(wp_a), ptr(bp_a), ptr(lo_a), ptr(y), None, None)
+    assert rc == 0, lib.y5_last_error()
+    cat = torch.cat((F.interpolate(lo, scale_factor=2, mode="nearest"), hi), 1)
+    ref = F.silu(F.conv2d(cat, w, b)).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(y[..., :C2].astype(np.float32), ref, rtol=3e-2, atol=3e-2)
+    assert np.all(y[..., C2:] == -3.0)
+    # every other configuration refuses such a layer, and 88 / 89 refuse layers without one
+    d.cfg = 43
+    assert lib.y5_conv2d_fwd(C.byref(d), ptr(x), ptr(wp_a), ptr(bp_a), ptr(lo_a), ptr(y), None, None) != 0
+    d.cfg, d.up_c = 88, 0
+    assert lib.y5_conv2d_fwd(C.byref(d), ptr(x), ptr(wp_a), ptr(bp_a), None, ptr(y), None, None) != 0

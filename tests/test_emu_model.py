@@ -114,3 +114,23 @@ def test_fused_bottleneck_plan_same_outputs(monkeypatch):
         u, v = np.asarray(a[k]).astype(np.float32), np.asarray(b[k]).astype(np.float32)
         assert np.abs(u - v).max() <= 4e-3 * max(1.0, np.abs(u).max()), (k, np.abs(u - v).max())
         assert (u != v).mean() < 0.2, k
+
+
+def test_virtual_upsample_concat_plan_same_outputs(monkeypatch):
+    """fp16 plans read `nn.Upsample(2) -> Concat -> C3` (models/yolov5s.yaml:36-38,41-43) without the 2x replica: the C3's cv1+cv2 GEMM takes its first
+    input channels from the low-resolution tensor (engine._Planner.run `virt`, conv configurations 88 / 89).  Same function as the plan that
+    materialises the replica (another tile configuration, hence another fp32 summation order: a few fp16 ulps), and one replicated store less."""
+    m = det_model("yolov5s", 0, True).half()
+    x = torch.from_numpy(detgen.uniform((2, 3, 64, 64), 0.0, 1.0, name="img", seed=0)).half()
+    monkeypatch.setenv("Y5_VIRTUAL_UP", "0")
+    plain = Engine(m, (2, 3, 64, 64), torch.float16, "cpu", want_raw=True, backend=EmuBackend())
+    monkeypatch.setenv("Y5_VIRTUAL_UP", "1")
+    virt = Engine(m, (2, 3, 64, 64), torch.float16, "cpu", want_raw=True, backend=EmuBackend())
+    ups = [o["name"] for o in virt.spec.ops if o.get("op") == "conv" and o.get("up") is not None]
+    assert ups == ["13.C3.cv1+cv2", "17.C3.cv1+cv2"] and not any(o.get("up") for o in plain.spec.ops if o.get("op") == "conv")
+    rep = lambda e: [o["name"] for o in e.spec.ops if o.get("op") == "conv" and o.get("y2") is not None and not o.get("split_n")]  # noqa: E731
+    assert rep(plain) == ["10.Conv", "14.Conv"] and rep(virt) == []
+    a, b = plain(x), virt(x)
+    for k in a:
+        u, v = np.asarray(a[k]).astype(np.float32), np.asarray(b[k]).astype(np.float32)
+        assert np.abs(u - v).max() <= 4e-3 * max(1.0, np.abs(u).max()), (k, np.abs(u - v).max())

@@ -172,6 +172,49 @@ def test_conv_matches_torch_fp32_reference(case, dev):
         assert torch.equal(up, y2)
 
 
+@pytest.mark.parametrize("B,H,W,c_up,c_hi,C2,cfg,max_blocks", [
+    (16, 40, 40, 256, 256, 256, 88, 0),    # yolov5s 13.C3.cv1+cv2 (producer / consumer ring): many tiles per workgroup
+    (8, 80, 80, 128, 128, 128, 88, 0),     # yolov5s 17.C3.cv1+cv2
+    (8, 80, 80, 128, 128, 128, 89, 0),     # 2-stage BK64 tile
+    (4, 38, 42, 64, 192, 96, 88, 16),      # odd tile counts, N tail, source switch after one chunk
+    (4, 38, 42, 320, 64, 160, 89, 24),
+])
+def test_conv_virtual_upsample_concat_matches_torch(B, H, W, c_up, c_hi, C2, cfg, max_blocks, dev):
+    """Configurations 88 / 89 (conv_igemm.h UP2): the 1x1 convolution behind `nn.Upsample(2, 'nearest')` + `Concat` (models/yolov5s.yaml:36-38,41-43,
+    common.py:443-453) reads input channels [0, c_up) from the LOW-resolution tensor; torch on the materialised concat is the reference.  The concat
+    buffer's first c_up channels hold NaN: they must never be read."""
+    from yolov5_amd import _lib
+    from yolov5_amd.packing import pack_conv_weight
+
+    lib = _lib.lib()
+    lo = torch.from_numpy(detgen.uniform((B, c_up, H // 2, W // 2), -1, 1, name="lo")).half().float()
+    hi = torch.from_numpy(detgen.uniform((B, c_hi, H, W), -1, 1, name="hi")).half().float()
+    C1 = c_up + c_hi
+    w = (torch.from_numpy(detgen.uniform((C2, C1, 1, 1), -1, 1, name="wu")) * (2.0 / C1) ** 0.5).half().float()
+    b = torch.from_numpy(detgen.uniform((C2,), -0.5, 0.5, name="bu"))
+    ld_lo, ldx, ldy = c_up + 16, C1 + 8, C2 + 8
+    lo_d = torch.full((B, H // 2, W // 2, ld_lo), 9.0, dtype=torch.float16, device=dev)
+    lo_d[..., :c_up] = lo.permute(0, 2, 3, 1).to(dev, torch.float16)
+    xd = torch.full((B, H, W, ldx), 7.0, dtype=torch.float16, device=dev)
+    xd[..., :c_up] = float("nan")
+    xd[..., c_up:C1] = hi.permute(0, 2, 3, 1).to(dev, torch.float16)
+    wp, bp, K, Kpad, Npad = pack_conv_weight(w, b, torch.float16)
+    wp, bp = wp.to(dev), bp.to(dev)
+    y = torch.full((B, H, W, ldy), -3.0, dtype=torch.float16, device=dev)
+    d = _lib.ConvDesc(dtype=_lib.Y5_F16, B=B, H=H, W=W, C1=C1, ldx=ldx, OH=H, OW=W, C2=C2, ldy=ldy, KH=1, KW=1, SH=1, SW=1, PH=0, PW=0, act=1,
+                      Kpad=Kpad, Npad=Npad, ldr=0, ld2=0, cfg=cfg, max_blocks=max_blocks, up_c=c_up, ld_up=ld_lo)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    rc = lib.y5_conv2d_fwd(C.byref(d), C.c_void_p(xd.data_ptr()), C.c_void_p(wp.data_ptr()), C.c_void_p(bp.data_ptr()), C.c_void_p(lo_d.data_ptr()),
+                           C.c_void_p(y.data_ptr()), None, st)
+    assert rc == 0, lib.y5_last_error()
+    torch.cuda.synchronize()
+    cat = torch.cat((F.interpolate(lo, scale_factor=2, mode="nearest"), hi), 1)
+    ref = F.silu(F.conv2d(cat, w, b)).permute(0, 2, 3, 1)
+    torch.testing.assert_close(y[..., :C2].float().cpu(), ref, rtol=2e-2, atol=2e-2)
+    pad = y[..., C2:].float().cpu()
+    assert torch.equal(pad, torch.full_like(pad, -3.0))
+
+
 # ---- whole model ------------------------------------------------------------------------------------------
 def _det_model(name, seed):
     from yolov5_amd.yolo import DetectionModel, SegmentationModel

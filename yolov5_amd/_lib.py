@@ -21,7 +21,7 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "dtype", "B", "H", "W", "C1", "ldx", "OH", "OW", "C2", "ldy", "KH", "KW", "SH", "SW", "PH", "PW",
         "act", "Kpad", "Npad", "ldr", "ld2", "cfg", "max_blocks",
-        "out_mul_h", "out_mul_w", "out_off_h", "out_off_w", "out_H", "out_W", "split_n")]
+        "out_mul_h", "out_mul_w", "out_off_h", "out_off_w", "out_H", "out_W", "split_n", "up_c", "ld_up")]
 
 
 class LossDesc(C.Structure):

@@ -79,7 +79,7 @@ constexpr size_t kSkFlagBytes = kSkMaxGrid * 4;
 struct SkWs { void* ws; size_t bytes; };
 SkWs g_sk[64] = {};
 
-template <typename T, int WM, int WN, int TM, int TN, int RB, bool TABLE, int NS = 2, bool PROD = false, bool ALIAS = false, bool SK = false>
+template <typename T, int WM, int WN, int TM, int TN, int RB, bool TABLE, int NS = 2, bool PROD = false, bool ALIAS = false, bool SK = false, bool UP2 = false>
 int launch_cfg(const Y5ConvParams& p0, int max_blocks, hipStream_t stream) {
   using Gm = Y5ConvGeom<T, RB>;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -95,7 +95,7 @@ int launch_cfg(const Y5ConvParams& p0, int max_blocks, hipStream_t stream) {
   }
   const size_t lds = y5_conv_lds_bytes<T, WM, WN, TM, TN, RB, NS, ALIAS>(pieces);
   if (lds > 160 * 1024) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: tile configuration exceeds 160 KiB of LDS");
-  auto kern = y5_conv_igemm_kernel<T, WM, WN, TM, TN, RB, TABLE, NS, PROD, ALIAS, SK>;
+  auto kern = y5_conv_igemm_kernel<T, WM, WN, TM, TN, RB, TABLE, NS, PROD, ALIAS, SK, UP2>;
   constexpr int NTHREADS = WM * WN * 64 * (PROD ? 2 : 1);
   static bool attr_done = false;  // per instantiation
   if (!attr_done) {
@@ -208,6 +208,10 @@ int launch_by_cfg(const Y5ConvParams& p, int cfg, int mb, hipStream_t s) {
 struct PwCfg { int kc, rb, nt, s; };
 constexpr int kNumPw = 13;
 constexpr int kPw8_0 = 84;  // ids 84.. = kPwCfgs[9..]: eight waves per workgroup, one stage per wave
+// ids 88, 89: implicit GEMM whose loader reads `nn.Upsample(2) + Concat` virtually (conv_igemm.h UP2; 1x1 s1 layers with d->up_c > 0 ONLY):
+// 88 = the producer / consumer 128 x 128 BK32 ring of id 43, 89 = the plain 2-stage 128 x 128 BK64 tile of id 8
+constexpr int kUp0 = 88, kNumUp = 2;
+constexpr TileCfg kUpCfgs[kNumUp] = {{2, 2, 2, 2, 64}, {2, 2, 2, 2, 128}};
 constexpr int kPw2_0 = 56;  // pointwise configurations added after the id space was laid out: ids 56.. = kPwCfgs[8..]
 constexpr PwCfg kPwCfgs[kNumPw] = {
     {1, 64, 1, 4},   // 14:  32 ->  32, 4 stages
@@ -386,6 +390,13 @@ extern "C" int y5_conv_set_sk_workspace(void* ws, size_t bytes, void* stream_) {
 
 extern "C" int y5_conv_cfg_info(int cfg, int* bm, int* bn, int* bk_bytes) {
   if (cfg < 0 || cfg >= Y5_CONV_NUM_CFGS) return y5_fail(Y5_ERR_BAD_ARG, "conv_cfg_info: bad id");
+  if (cfg >= kUp0) {
+    const TileCfg& c = kUpCfgs[cfg - kUp0];
+    if (bm) *bm = c.wm * c.tm * 32;
+    if (bn) *bn = c.wn * c.tn * 32;
+    if (bk_bytes) *bk_bytes = c.rb;
+    return Y5_OK;
+  }
   if (cfg >= kPw8_0) {
     const PwCfg& c = kPwCfgs[9 + cfg - kPw8_0];
     if (bm) *bm = 256;
@@ -457,19 +468,29 @@ extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w
   const int es = d->dtype == Y5_F16 ? 2 : d->dtype == Y5_F32 ? 4 : 0;
   if (!es) return y5_fail(Y5_ERR_BAD_ARG, "conv: dtype must be Y5_F16 or Y5_F32");
   const int epp = 16 / es;
-  int cfg = d->cfg < 0 ? default_cfg(d) : d->cfg;
+  int cfg = d->cfg < 0 ? (d->up_c > 0 ? kUp0 + 1 : default_cfg(d)) : d->cfg;
   if (cfg >= Y5_CONV_NUM_CFGS) return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown tile config");
-  const bool pw8 = cfg >= kPw8_0;                 // streaming pointwise with eight waves per workgroup (ids 84..)
-  const bool k3w = cfg >= kK3W_0 && !pw8;         // streaming 3x3 added after the id space was laid out (ids 78..83)
-  const bool h3 = cfg >= kH3_0 && !k3w && !pw8;
-  const bool sk = cfg >= kSk0 && !h3 && !k3w && !pw8;
-  const bool pw = (cfg >= kNumIgemm && cfg < kRing0) || (cfg >= kPw2_0 && !sk && !h3 && !k3w);
-  const int pwi = pw8 ? 9 + cfg - kPw8_0 : cfg >= kPw2_0 ? 8 + cfg - kPw2_0 : cfg - kNumIgemm;
-  const bool big = cfg >= kBig0 && cfg < kPw2_0;
-  const bool k3 = (cfg >= kK3_0 && cfg < kBig0) || k3w;
-  const int k3i = k3w ? 5 + cfg - kK3W_0 : cfg - kK3_0;
-  const int bk = (pw || k3 || h3) ? 8 : (sk ? kSkCfgs[cfg - kSk0].rb : big ? kBigCfgs[cfg - kBig0].rb : kCfgs[cfg >= kRing0 ? kRingBase[cfg - kRing0] : cfg].rb) / es;
-  if (cfg >= kRing0 && d->dtype != Y5_F16) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: ring configurations are fp16 only");
+  const bool up2 = cfg >= kUp0;                   // virtual upsample + concat loader (ids 88, 89)
+  if (up2 != (d->up_c > 0)) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: configurations 88 / 89 serve exactly the layers with up_c > 0 (virtual upsample + concat)");
+  if (up2) {
+    const int bkb = kUpCfgs[cfg - kUp0].rb / 2;
+    if (d->dtype != Y5_F16 || d->KH != 1 || d->KW != 1 || d->SH != 1 || d->SW != 1 || d->PH || d->PW || !residual || !y || y_up2 || d->split_n ||
+        d->out_mul_h || (d->H & 1) || (d->W & 1) || d->up_c % bkb || d->up_c >= d->C1 || d->C1 % bkb || d->ld_up < d->up_c || (d->ld_up & 7))
+      return y5_fail(Y5_ERR_UNSUPPORTED, "conv: virtual upsample + concat needs a 1x1 s1 fp16 layer on an even H x W grid, up_c and C1 multiples of the K chunk, "
+                                         "the low-resolution tensor in the `residual` argument");
+  }
+  const int fam = up2 ? 2 : cfg;   // (88 / 89 are implicit-GEMM tiles: none of the family tests below applies to them)
+  const bool pw8 = fam >= kPw8_0;         // streaming pointwise with eight waves per workgroup (ids 84..)
+  const bool k3w = fam >= kK3W_0 && !pw8;         // streaming 3x3 added after the id space was laid out (ids 78..83)
+  const bool h3 = fam >= kH3_0 && !k3w && !pw8;
+  const bool sk = fam >= kSk0 && !h3 && !k3w && !pw8;
+  const bool pw = (fam >= kNumIgemm && fam < kRing0) || (fam >= kPw2_0 && !sk && !h3 && !k3w);
+  const int pwi = pw8 ? 9 + fam - kPw8_0 : fam >= kPw2_0 ? 8 + fam - kPw2_0 : fam - kNumIgemm;
+  const bool big = fam >= kBig0 && fam < kPw2_0;
+  const bool k3 = (fam >= kK3_0 && fam < kBig0) || k3w;
+  const int k3i = k3w ? 5 + fam - kK3W_0 : fam - kK3_0;
+  const int bk = up2 ? kUpCfgs[cfg - kUp0].rb / es : (pw || k3 || h3) ? 8 : (sk ? kSkCfgs[fam - kSk0].rb : big ? kBigCfgs[fam - kBig0].rb : kCfgs[fam >= kRing0 ? kRingBase[fam - kRing0] : fam].rb) / es;
+  if (fam >= kRing0 && d->dtype != Y5_F16) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: ring configurations are fp16 only");
   if (d->C1 % epp || d->ldx % epp) return y5_fail(Y5_ERR_BAD_ARG, "conv: C1 and ldx must be multiples of 16 bytes");
   if (d->C2 % epp || (y && d->ldy % epp) || (residual && d->ldr % epp) || (y_up2 && d->ld2 % epp))
     return y5_fail(Y5_ERR_BAD_ARG, "conv: C2/ldy/ldr/ld2 must be multiples of 16 bytes");
@@ -488,7 +509,13 @@ extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w
     return y5_fail(Y5_ERR_UNSUPPORTED, "conv: tensor exceeds 2^31 bytes (32-bit buffer offsets)");
 
   Y5ConvParams p{};
-  p.x = x; p.w = w_packed; p.bias = bias; p.res = residual; p.y = y; p.y2 = y_up2;
+  p.x = x; p.w = w_packed; p.bias = bias; p.res = up2 ? nullptr : residual; p.y = y; p.y2 = y_up2;
+  if (up2) {   // (the low-resolution source travels in the `residual` argument: a layer of this kind has no residual)
+    p.x2 = residual; p.ldx2 = d->ld_up; p.up_c = d->up_c;
+    const long long b2 = (((long long)d->B * (d->H / 2) * (d->W / 2) - 1) * d->ld_up + d->up_c) * 2;
+    if (b2 >= 0x7fffffffLL) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: low-resolution tensor exceeds 2^31 bytes");
+    p.x2_bytes = (unsigned)b2;
+  }
   p.zero = y5_zero_page();
   if (!p.zero) return y5_fail(Y5_ERR_RUNTIME, "conv: zero page allocation failed");
   p.B = d->B; p.H = d->H; p.W = d->W; p.C1 = d->C1; p.ldx = d->ldx;
@@ -528,6 +555,10 @@ extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w
         d->C1 != c.kc * c.rb / 2 || d->Npad != c.nt * 32 || (p.M & 31) || d->Kpad * 2 < c.kc * c.rb)
       return y5_fail(Y5_ERR_UNSUPPORTED, "conv: pointwise configuration does not match this layer");
     return launch_pw_by_cfg(p, pwi, d->max_blocks, stream);
+  }
+  if (up2) {
+    if (cfg == kUp0) return launch_cfg<half_t, 2, 2, 2, 2, 64, false, 4, true, false, false, true>(p, d->max_blocks, stream);
+    return launch_cfg<half_t, 2, 2, 2, 2, 128, false, 2, false, false, false, true>(p, d->max_blocks, stream);
   }
   const bool table = (d->C1 % bk) != 0 || d->KH * d->KW > 32;  // uniform mode keeps a 32-bit tap-validity mask per row
   if (d->dtype == Y5_F16)

@@ -59,6 +59,12 @@ struct Y5ConvParams {
   int h3_th, h3_tw, h3_tiles_h, h3_tiles_w;  // conv_h3.h: spatial tile (output rows x columns) and tiles per image
   int split_n;  // > 0: output channels >= split_n go to y2 (pixel stride ld2, channel n - split_n) instead of y -- C3's cv1 / cv2 halves
                 // of one GEMM landing in two different buffers (y2 is then NOT the upsampled replica)
+  // UP2 kernels (1x1 s1 p0 only): `nn.Upsample(2, 'nearest')` + `Concat` consumed VIRTUALLY (models/yolov5s.yaml:36-37,41-42, common.py:443-453).
+  // Input channels [0, up_c) of output pixel (b, oh, ow) are read from the LOW-resolution tensor x2 (B, H/2, W/2, >= up_c channels, pixel
+  // stride ldx2) at (b, oh >> 1, ow >> 1); channels [up_c, C1) from x as usual (x = the concat buffer whose first up_c channels are never written).
+  const void* x2;
+  unsigned x2_bytes;
+  int ldx2, up_c;
 };
 
 #define Y5_CONV_MAXTAB 4096   // max k-pieces in TABLE mode (LDS: 8 B each)
@@ -109,9 +115,10 @@ constexpr int y5_conv_min_waves(int tm, int tn) { return tm * tn <= 1 ? 5 : tm *
 // clears the flags for the next launch and runs the ordinary epilogue.  Dependencies only point
 // from a workgroup to higher-numbered ones that started at the same time (or are dispatched as lower-numbered ones retire), so there
 // is nothing to deadlock on; the poll is bounded all the same.
-template <typename T, int WM, int WN, int TM, int TN, int RB, bool TABLE, int NS = 2, bool PROD = false, bool ALIAS = false, bool SK = false>
+template <typename T, int WM, int WN, int TM, int TN, int RB, bool TABLE, int NS = 2, bool PROD = false, bool ALIAS = false, bool SK = false, bool UP2 = false>
 __global__ __launch_bounds__(WM * WN * 64 * (PROD ? 2 : 1), y5_conv_min_waves(TM, TN) + (ALIAS ? 1 : 0))
 void y5_conv_igemm_kernel(const Y5ConvParams p) {
+  static_assert(!UP2 || (!TABLE && !SK && sizeof(T) == 2), "the virtual upsample + concat loader is built for the uniform fp16 loader");
   static_assert(!PROD || NS >= 3, "producer/consumer needs a ring");
   static_assert(!SK || (NS == 2 && !PROD && !ALIAS), "stream-K is implemented for the plain 2-stage kernel");
   static_assert(!ALIAS || (NS == 2 && !PROD), "scratch aliasing is implemented for the 2-stage kernel");
@@ -164,6 +171,7 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
 
   const y5_rsrc_t xrs = y5_make_rsrc(p.x, p.x_bytes);
   const y5_rsrc_t wrs = y5_make_rsrc(p.w, p.w_bytes);
+  const y5_rsrc_t xrs2 = UP2 ? y5_make_rsrc(p.x2, p.x2_bytes) : xrs;
   constexpr int ES = (int)sizeof(T);
 
   if constexpr (TABLE) {
@@ -189,6 +197,7 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
   const int lrow = lane / NSLOT;   // row inside one LDS-DMA instruction
   const int lslot = lane % NSLOT;  // destination 16-byte slot
   int a_base[ACT_PER_WAVE];        // BYTE offset of (b, ih0, iw0) + source slot (may be negative for padded origins)
+  int a_base2[UP2 ? ACT_PER_WAVE : 1];  // UP2: byte offset of the low-resolution pixel (b, oh >> 1, ow >> 1) in x2 + source slot
   int a_ih0[ACT_PER_WAVE], a_iw0[ACT_PER_WAVE], a_slot[ACT_PER_WAVE];  // TABLE mode
   unsigned a_mask[ACT_PER_WAVE];   // UNIFORM mode: bit (kh*KW + kw) CLEAR <=> that tap of this row lies inside the image
   unsigned w_off[WGT_PER_WAVE];    // byte offset of the filter row + source slot, Y5_OOB for rows beyond the tile / Npad
@@ -217,6 +226,7 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
       const int oh = r / p.OW, ow = r - oh * p.OW;
       const int ih0 = oh * p.SH - p.PH, iw0 = ow * p.SW - p.PW;
       a_base[i] = (((b * p.H + ih0) * p.W + iw0) * p.ldx + sslot * EPP) * ES;
+      if constexpr (UP2) a_base2[i] = (((b * (p.H >> 1) + (oh >> 1)) * (p.W >> 1) + (ow >> 1)) * p.ldx2 + sslot * EPP) * ES;
       if constexpr (TABLE) {
         a_ih0[i] = m < p.M ? ih0 : -0x40000000;  // pixel rows past M: every tap reads zeros
         a_iw0[i] = iw0;
@@ -259,12 +269,14 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
   constexpr int LPC = ACT_PER_WAVE + WGT_PER_WAVE;  // LDS-DMA instructions per chunk per wave (NS > 2: uniform)
   char* st_lds = smem;
   int st_tap_off = 0, st_tap_bit = 0;
+  bool st_up = false;
   unsigned st_kcb = 0;
   auto stage_begin = [&](int buf) {
     st_lds = smem + buf * BUF_BYTES;
     if constexpr (!TABLE) {
       st_tap_off = ((u_kh * p.W + u_kw) * p.ldx + u_c0) * ES;
       st_tap_bit = u_kh * p.KW + u_kw;
+      if constexpr (UP2) st_up = u_c0 < p.up_c;
     }
     st_kcb = (unsigned)(s_kc * BK * ES);
   };
@@ -281,6 +293,14 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
       } else {
         // outside-the-image taps get bit 31 (= out of range = zero fill): shift, shift-or, add -- no compare / select
         voff = (unsigned)(a_base[i] + st_tap_off) | ((a_mask[i] >> st_tap_bit) << 31);
+      }
+      if constexpr (UP2) {
+        // 1x1 layer: st_tap_off is the chunk's channel offset in bytes; the first up_c channels come from the low-resolution tensor
+        // (wave-uniform choice: a chunk never straddles the boundary, up_c % BK == 0)
+        if (st_up) {
+          y5_bglds16(xrs2, (unsigned)(a_base2[i] + st_tap_off) | (a_mask[i] << 31), st_lds + (wave + i * NW) * 1024);
+          return;
+        }
       }
       y5_bglds16(xrs, voff, st_lds + (wave + i * NW) * 1024);
     } else {

@@ -80,7 +80,7 @@ def _pair(v):
 class _Planner:
     """Walks the module tree once and emits PlanSpec ops."""
 
-    def __init__(self, model, B, ch, H, W, want_raw=False, fuse_bneck=False):
+    def __init__(self, model, B, ch, H, W, want_raw=False, fuse_bneck=False, virtual_up=False):
         from . import common, yolo
 
         self.cm, self.yo = common, yolo
@@ -88,10 +88,13 @@ class _Planner:
         self.spec = PlanSpec(B, ch, (H, W))
         self.want_raw = want_raw
         self.fuse_bneck = fuse_bneck  # fp16 plans: Bottlenecks of 32-channel C3 blocks as one launch (csrc/conv_bneck.h)
+        # fp16 plans: `nn.Upsample(2) -> Concat -> C3` (models/yolov5s.yaml:36-38,41-43) without the 2x replica -- the C3's cv1+cv2 GEMM reads the
+        # low-resolution tensor for the first half of K (csrc/conv_igemm.h UP2, configuration ids 88 / 89)
+        self.virtual_up = virtual_up
 
     # ---- leaf emitters ----------------------------------------------------------------------------
     def conv(self, mods, x: TRef, dest: TRef | None = None, res: TRef | None = None, up2: TRef | None = None,
-             act=True, name="", view=None, c2_store=None, split=None, emit=True):
+             act=True, name="", view=None, c2_store=None, split=None, emit=True, x_up=None):
         """mods: list of Conv-like modules stacked along output channels (same input, same k/s/p).
         split = (n, hi): output channels [0, n) go to `dest` (n channels wide), channels [n, c2) to the slice `hi`."""
         m0 = mods[0]
@@ -109,6 +112,9 @@ class _Planner:
             up2 = split[1]
         op = dict(op="conv", mods=mods, x=x, y=dest, res=res, y2=up2, k=k, s=s, p=p, act=act, c2=c2, c2_store=cst, name=name, view=view,
                   split_n=0 if split is None else split[0])
+        if x_up is not None:   # (low-resolution TRef, channels): input channels [0, c_up) are read from it at (oh >> 1, ow >> 1)
+            assert k == (1, 1) and s == (1, 1) and p == (0, 0) and res is None and split is None and up2 is None, name
+            op["up"] = x_up
         if emit:
             self.spec.ops.append(op)
             return dest
@@ -129,10 +135,11 @@ class _Planner:
                 return False
         return True
 
-    def c3(self, m, x: TRef, dest: TRef | None, up2=None, name="C3"):
+    def c3(self, m, x: TRef, dest: TRef | None, up2=None, name="C3", x_up=None):
         c_ = m.cv1.conv.out_channels
         cat = self.spec.new_buf(x.H, x.W, 2 * c_, name + ".cat")
         if self._bneck_fusable(m, c_, x):
+            assert x_up is None
             # cv1's half of the GEMM lands in a buffer of its own (split store), every Bottleneck is ONE launch that reads one buffer
             # and writes another (a tile needs its neighbours' input pixels: not in place), the last one writes its slice of `cat`
             ping = [self.spec.new_buf(x.H, x.W, c_, name + ".a0")]
@@ -147,7 +154,7 @@ class _Planner:
                                           cv2=self.conv([b.cv2], src, dst, name="b.cv2", emit=False)))
                 src = dst
             return self.conv([m.cv3], cat, dest, up2=up2, name=name + ".cv3")
-        self.conv([m.cv1, m.cv2], x, cat, name=name + ".cv1+cv2")  # one GEMM, N = 2*c_
+        self.conv([m.cv1, m.cv2], x, cat, name=name + ".cv1+cv2", x_up=x_up)  # one GEMM, N = 2*c_
         a = _slice(cat, 0, c_)
         if len(m.m):
             tmp = self.spec.new_buf(x.H, x.W, c_, name + ".tmp")
@@ -232,6 +239,27 @@ class _Planner:
                 if isinstance(layers[j], (cm.Conv, cm.C3, cm.SPPF)):
                     fused_up[j] = i
 
+        # virtual upsample: Upsample u (fused into producer j) -> first source of Concat c -> only reader of c is a C3 k that is not the fused-Bottleneck form
+        virt = {}      # upsample layer u -> (concat layer c, C3 layer k)
+        virt_cat = {}  # C3 layer k -> (producer layer j, channels)
+        if self.virtual_up:
+            for j, u in fused_up.items():
+                cu, hu, wu = shp[u]
+                if len(consumers[u]) != 1 or cu % 64 or hu % 2 or wu % 2:
+                    continue
+                c = consumers[u][0]
+                if not isinstance(layers[c], cm.Concat) or src_ids(c, layers[c])[0] != u or len(consumers[c]) != 1:
+                    continue
+                k = consumers[c][0]
+                mk = layers[k]
+                if not isinstance(mk, cm.C3) or src_ids(k, mk) != [c] or shp[c][0] <= cu or (shp[c][0] - cu) % 64:
+                    continue
+                c_k = mk.cv1.conv.out_channels
+                if self.fuse_bneck and c_k == 32:   # that C3 stores its cv1 / cv2 halves separately (split store): keep the replica
+                    continue
+                virt[u] = (c, k)
+                virt_cat[k] = (j, cu)
+
         # pass 3: emit
         out = {}
         x0 = spec.new_buf(H, W, 4 if spec.in_ch <= 4 else (spec.in_ch + 7) // 8 * 8, "input_nhwc")
@@ -243,15 +271,23 @@ class _Planner:
             if i in fused_up:
                 u = fused_up[i]
                 c, h, w = shp[u]
-                up2 = home.get(u) or spec.new_buf(h, w, c, f"up{u}")
-                out[u] = up2
+                if u in virt:
+                    out[u] = "virtual"   # no replica: the C3 behind the Concat reads this layer's own output (emitted below)
+                else:
+                    up2 = home.get(u) or spec.new_buf(h, w, c, f"up{u}")
+                    out[u] = up2
             if isinstance(m, cm.Conv):
                 view = None
                 if i == 0:
                     view = "first"
                 out[i] = self.conv([m], ins[0], dest, up2=up2, name=f"{i}.Conv", view=view)
             elif isinstance(m, cm.C3):
-                out[i] = self.c3(m, ins[0], dest, up2, name=f"{i}.C3")
+                x_up = None
+                if i in virt_cat:
+                    j, cu = virt_cat[i]
+                    x_up = (out[j], cu)
+                kw = {} if x_up is None else {"x_up": x_up}   # (subclassed planners without the virtual form never see the keyword)
+                out[i] = self.c3(m, ins[0], dest, up2, name=f"{i}.C3", **kw)
             elif isinstance(m, cm.SPPF):
                 out[i] = self.sppf(m, ins[0], dest, up2, name=f"{i}.SPPF")
             elif isinstance(m, nn.Upsample):
@@ -263,7 +299,10 @@ class _Planner:
             elif isinstance(m, cm.Concat):
                 buf = cat_bufs[i]
                 off = 0
-                for t in ins:
+                for t, j in zip(ins, src_ids(i, m)):
+                    if isinstance(t, str):   # "virtual": the upsampled replica is never materialised (its slice of the buffer stays unwritten)
+                        off += shp[j][0]
+                        continue
                     want = _slice(buf, off, t.C)
                     if t != want:
                         spec.ops.append(dict(op="copy", src=t, dst=want))
@@ -351,9 +390,9 @@ class _Planner:
             row_off += na * x.H * x.W
 
 
-def build_plan_spec(model, B, ch, H, W, want_raw=False, fuse_bneck=False) -> PlanSpec:
+def build_plan_spec(model, B, ch, H, W, want_raw=False, fuse_bneck=False, virtual_up=False) -> PlanSpec:
     """Device-independent kernel schedule for `model` (a yolov5_amd.yolo.BaseModel) at input (B,ch,H,W)."""
-    return _Planner(model, B, ch, H, W, want_raw, fuse_bneck).run()
+    return _Planner(model, B, ch, H, W, want_raw, fuse_bneck, virtual_up).run()
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -589,7 +628,8 @@ class Engine:
         B, ch, H, W = x_shape
         self.x_shape = tuple(x_shape)
         self.spec = spec if spec is not None else build_plan_spec(
-            model, B, ch, H, W, want_raw, fuse_bneck=dtype == torch.float16 and os.environ.get("Y5_FUSED_BNECK", "1") != "0")
+            model, B, ch, H, W, want_raw, fuse_bneck=dtype == torch.float16 and os.environ.get("Y5_FUSED_BNECK", "1") != "0",
+            virtual_up=dtype == torch.float16 and os.environ.get("Y5_VIRTUAL_UP", "1") != "0")
         det = getattr(model, "model", [None])[-1] if model is not None else None
         self._det = det if det is not None and hasattr(det, "anchors") else None
         self._anchor_ops = []  # (plan op index, pyramid level) of every op that holds anchor sizes
@@ -892,6 +932,11 @@ class Engine:
         if d.split_n:
             d.ldy = self._ld(y)
         assert Npad >= c2s
+        if op.get("up") is not None:   # virtual Upsample + Concat: the low-resolution tensor rides in the residual slot (include/yolov5_hip.h, up_c)
+            lo, c_up = op["up"]
+            assert res is None and lo.H * 2 == H and lo.W * 2 == W and lo.C >= c_up
+            d.up_c, d.ld_up = c_up, self._ld(lo)
+            res = lo
         ptrs = (self._ptr(x), C.c_void_p(self.be.ptr(wp)), C.c_void_p(self.be.ptr(bp)), self._ptr(res), self._ptr(y), self._ptr(y2))
         if getattr(self.be, "autotune", False):
             # stream-K kernels combine split tiles through ONE registered workspace: not for ops that run beside others (side stream)
