@@ -553,13 +553,56 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
       }
       return;
     }
+    // Consumer loop, software-pipelined ACROSS the chunk boundary (round 4).  The barrier that says "chunk c+1 has landed" is taken before the
+    // LAST k-step of chunk c instead of after it, and that k-step's MFMAs run behind the fragment reads of (c+1, k-step 0): a chunk no longer
+    // opens with an LDS round trip during which the wave's matrix-core slot idles (8 reads, ~130 cycles, then 8 MFMAs = 256 cycles per BK32
+    // chunk before).  The ring makes it legal: the producers run NS-1 chunks ahead, so chunk c+1 is normally in LDS long before it is asked for.
+    // Hand-over of the slot of chunk c to the producers happens at that same barrier, so every read of chunk c must have RETURNED by then
+    // (lgkmcnt(0): the last reads were issued a k-step = 4+ MFMAs earlier).  Same number of barriers in the same order as before: the
+    // producer side is unchanged.  At a tile boundary the first chunk is read after the barrier as before (the epilogue sits in between).
+    constexpr int KS = RB / 32;
+    static_assert(KS % 2 == 0, "two fragment register sets alternate per k-step: a chunk must hold an even number of k-steps");
     int cur = 0;
+    half8_t af[2][TM], wf[2][TN];
+    auto rd = [&](const char* lds, auto ksc, auto bc) {
+      constexpr int ks = decltype(ksc)::value, b = decltype(bc)::value;
+      const int so = ((ks * 2 + g) ^ fsw) * 16;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[b][i] = *reinterpret_cast<const half8_t*>(lds + a_rd[i] + so);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) wf[b][j] = *reinterpret_cast<const half8_t*>(lds + w_rd[j] + so);
+    };
     for (int ti = 0; ti < nmine; ++ti) {
+      __builtin_amdgcn_s_barrier();
+      tile_begin(ti, pm0, pn0);
+      rd(smem + cur * BUF_BYTES, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
       for (int kc = 0; kc < nk; ++kc) {
-        __builtin_amdgcn_s_barrier();
-        if (kc == 0) tile_begin(ti, pm0, pn0);
-        compute(smem + cur * BUF_BYTES, false);
-        cur = cur + 1 == NS ? 0 : cur + 1;
+        const char* lds = smem + cur * BUF_BYTES;
+        const int nxt_buf = cur + 1 == NS ? 0 : cur + 1;
+        y5_static_for<0, KS>([&](auto ksc) {
+          constexpr int ks = decltype(ksc)::value, b = ks & 1;
+          if constexpr (ks + 1 < KS) {
+            rd(lds, std::integral_constant<int, ks + 1>{}, std::integral_constant<int, b ^ 1>{});
+          } else {
+            if (kc + 1 < nk) {
+              __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): every fragment of chunk kc is in registers before its slot is handed back
+              __builtin_amdgcn_s_barrier();        // chunk kc + 1 has landed
+              rd(smem + nxt_buf * BUF_BYTES, std::integral_constant<int, 0>{}, std::integral_constant<int, b ^ 1>{});
+            }
+          }
+#ifndef Y5_EMU
+          __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[b][j], af[b][i], acc[i][j], 0, 0, 0);
+#ifndef Y5_EMU
+          __builtin_amdgcn_sched_barrier(0);
+#endif
+        });
+        cur = nxt_buf;
       }
     }
   } else if constexpr (SK) {
