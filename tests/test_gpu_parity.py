@@ -215,6 +215,42 @@ def test_conv_virtual_upsample_concat_matches_torch(B, H, W, c_up, c_hi, C2, cfg
     assert torch.equal(pad, torch.full_like(pad, -3.0))
 
 
+@pytest.mark.parametrize("H,C1,C2,k,s,cfg", [(40, 128, 128, 3, 1, 76), (40, 256, 256, 1, 1, 43), (80, 64, 64, 3, 1, 80), (80, 128, 128, 1, 1, 84), (20, 512, 512, 1, 1, 39),
+                                             (80, 128, 256, 3, 2, 43), (40, 128, 128, 3, 1, 40)])
+def test_conv_unit_scale_and_saturating_activations(H, C1, C2, k, s, cfg, dev):
+    """the full-resolution detection-set fixtures are conditioned to small pre-activations (SiLU almost linear).  The per-layer check at
+    REALISTIC and LARGE magnitudes lives here: the configurations the yolov5s plan actually selects, pre-activation standard deviation ~1 and ~6
+    (SiLU well into both of its asymptotes, fp16 outputs up to ~30), against torch fp32 on the same fp16-rounded operands -- error budget = one fp16
+    rounding of the result (2^-10 relative) plus the fp32 accumulation-order noise."""
+    from yolov5_amd import _lib
+    from yolov5_amd.packing import pack_conv_weight
+
+    lib = _lib.lib()
+    B, p = 4, k // 2
+    OH = (H + 2 * p - k) // s + 1
+    for gain in (1.0, 6.0):
+        x = torch.from_numpy(detgen.uniform((B, C1, H, H), -3 ** 0.5, 3 ** 0.5, name="xs", seed=int(gain))).half().float()   # unit variance
+        w = (torch.from_numpy(detgen.uniform((C2, C1, k, k), -3 ** 0.5, 3 ** 0.5, name="ws", seed=cfg)) * gain / (C1 * k * k) ** 0.5).half().float()
+        b = torch.from_numpy(detgen.uniform((C2,), -0.5, 0.5, name="bs"))
+        xd = x.permute(0, 2, 3, 1).contiguous().to(dev, torch.float16)
+        wp, bp, K, Kpad, Npad = pack_conv_weight(w, b, torch.float16)
+        wp, bp = wp.to(dev), bp.to(dev)
+        y = torch.zeros((B, OH, OH, C2), dtype=torch.float16, device=dev)
+        d = _lib.ConvDesc(dtype=_lib.Y5_F16, B=B, H=H, W=H, C1=C1, ldx=C1, OH=OH, OW=OH, C2=C2, ldy=C2, KH=k, KW=k, SH=s, SW=s, PH=p, PW=p, act=1,
+                          Kpad=Kpad, Npad=Npad, ldr=0, ld2=0, cfg=cfg, max_blocks=0)
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        rc = lib.y5_conv2d_fwd(C.byref(d), C.c_void_p(xd.data_ptr()), C.c_void_p(wp.data_ptr()), C.c_void_p(bp.data_ptr()), None, C.c_void_p(y.data_ptr()), None, st)
+        assert rc == 0, lib.y5_last_error()
+        torch.cuda.synchronize()
+        pre = F.conv2d(x, w, b, s, p)
+        ref = F.silu(pre).permute(0, 2, 3, 1)
+        assert 0.6 * gain < float(pre.std()) < 1.6 * gain
+        got = y.float().cpu()
+        err = (got - ref).abs()
+        tol = 2.0 ** -10 * ref.abs() + 2e-3 * gain   # one fp16 rounding + accumulation noise / the tanh-like knee of SiLU' <= 1.1
+        assert bool((err <= tol).all()), (gain, float(err.max()), float((err / (ref.abs() + 1e-3)).max()))
+
+
 # ---- whole model ------------------------------------------------------------------------------------------
 def _det_model(name, seed):
     from yolov5_amd.yolo import DetectionModel, SegmentationModel

@@ -4,6 +4,8 @@ un-vendored helpers the reference imports from `ultralytics.utils.ops` (xywh2xyx
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 import logging
 import math
@@ -148,7 +150,10 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     ws = _nms_ws.get(key)
     if ws is None:
         nbytes = lib.y5_nms_workspace_bytes(bs, n, no, nm, flags, max_nms)
-        while len(_nms_ws) >= 4:
+        # bounded by BYTES as well as by count: a val.py-shaped call (bs 64, n * nc ~ 2 M keys) needs > 1 GiB of scratch, a few of
+        # those beside detect-shaped ones must not pin several GiB -- oldest entries go until the cache fits the budget (the newest always stays)
+        budget = int(os.environ.get("Y5_NMS_WS_CACHE_MB", "1536")) << 20
+        while _nms_ws and (len(_nms_ws) >= 4 or sum(v[1] for v in _nms_ws.values()) + nbytes > budget):
             _nms_ws.pop(next(iter(_nms_ws)))
         ws = _nms_ws[key] = (_lib.workspace(nbytes, dev), nbytes)
     out = torch.empty((bs, max_det, 6 + nm), dtype=torch.float32, device=dev)

@@ -359,7 +359,7 @@ class TrainEngine:
                 torch.distributed.all_reduce(be.view_torch(sums))
                 _lib.check(lib.y5_bn_silu_fwd_from_sums(_vp(be.ptr(st["z"])), self.dt, npix, c2, c2, _vp(st["gamma"]), _vp(st["beta"]), float(bn.eps),
                                                         float(bn.momentum if bn.momentum is not None else 0.1), rm, rv, _vp(be.ptr(st["mean"])),
-                                                        _vp(be.ptr(st["invstd"])), _vp(be.ptr(sums)), npix * world,
+                                                        _vp(be.ptr(st["invstd"])), _vp(be.ptr(sums)), y.H * y.W * self._sync_images(bn, world),
                                                         _vp(self._ptr(res)) if res is not None else None, self._ld(res) if res is not None else 0,
                                                         _vp(self._ptr(y)), self._ld(y), stm), lib)
             else:
@@ -379,6 +379,17 @@ class TrainEngine:
         if isinstance(bn, torch.nn.SyncBatchNorm) and torch.distributed.is_available() and torch.distributed.is_initialized():
             return torch.distributed.get_world_size(bn.process_group) if bn.process_group is not None else torch.distributed.get_world_size()
         return 1
+
+    def _sync_images(self, bn, world):
+        """Images over which a SyncBatchNorm layer's statistics run: the sum of the ranks' batch sizes, exchanged ONCE per forward (torch's
+        SyncBatchNorm all-gathers the per-rank counts; `npix * world` was only right while every rank held the same number of images, which a
+        loader without padding does not guarantee).  The backward of the same step reuses the forward's figure."""
+        tot = getattr(self, "_sync_total", None)
+        if tot is None or tot[0] != self._fwd_seq:
+            t = torch.tensor([float(self.spec.B)], dtype=torch.float64, device=self.be.view_torch(self.gflat).device)
+            torch.distributed.all_reduce(t, group=bn.process_group)
+            tot = self._sync_total = (self._fwd_seq, int(round(float(t.item()))))
+        return tot[1]
 
     def _running(self, bn):
         """Device pointers of the BatchNorm running statistics (updated in place by the kernel)."""
@@ -559,7 +570,7 @@ class TrainEngine:
                 torch.distributed.all_reduce(gst)
                 _lib.check(lib.y5_bn_silu_bwd_from_sums(_vp(self._ptr(y, True)), self._ld(y), _vp(be.ptr(st["z"])), c2, self.dt, npix, c2, _vp(st["gamma"]),
                                                         _vp(st["beta"]), _vp(be.ptr(st["mean"])), _vp(be.ptr(st["invstd"])), _vp(be.ptr(gs)),
-                                                        _vp(be.ptr(gs) + 4 * c2), npix * world, _vp(be.ptr(self.dz)), c2, stm), lib)
+                                                        _vp(be.ptr(gs) + 4 * c2), y.H * y.W * self._sync_images(m.bn, world), _vp(be.ptr(self.dz)), c2, stm), lib)
             else:
                 _lib.check(lib.y5_bn_silu_bwd(_vp(self._ptr(y, True)), self._ld(y), _vp(be.ptr(st["z"])), c2, self.dt, npix, c2,
                                               _vp(st["gamma"]), _vp(st["beta"]), _vp(be.ptr(st["mean"])), _vp(be.ptr(st["invstd"])),
