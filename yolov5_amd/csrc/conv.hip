@@ -87,6 +87,7 @@ int launch_cfg(const Y5ConvParams& p0, int max_blocks, hipStream_t stream) {
   p.tilesM = (p.M + BM - 1) / BM;
   p.tilesN = (p.Npad + BN - 1) / BN;
   p.nk = (p.K + Gm::BK - 1) / Gm::BK;
+  y5_conv_set_fastdiv(p);
   if (p.nk * Gm::BK > p.Kpad) return y5_fail(Y5_ERR_BAD_ARG, "conv: Kpad smaller than K rounded up to the tile config's K per stage");
   int pieces = 0;
   if (TABLE) {

@@ -65,7 +65,30 @@ struct Y5ConvParams {
   const void* x2;
   unsigned x2_bytes;
   int ldx2, up_c;
+  // exact unsigned division by OH*OW and by OW as multiply-high + shifts (Granlund-Montgomery, filled by y5_conv_set_fastdiv on the host): the
+  // loader decomposes every staged row's pixel index once per tile -- two ~40-instruction division sequences per row otherwise
+  unsigned dv_ohw_m, dv_ow_m;
+  int dv_ohw_s, dv_ow_s;   // sh1 | sh2 << 8
 };
+
+__host__ __device__ inline void y5_fastdiv_make(unsigned d, unsigned* m, int* s) {
+  int l = 0;
+  while (l < 32 && (1ull << l) < d) ++l;   // ceil(log2 d)
+  *m = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+  *s = (l < 1 ? l : 1) | ((l > 0 ? l - 1 : 0) << 8);
+}
+__device__ __forceinline__ unsigned y5_fastdiv(unsigned n, unsigned m, int s) {
+#ifdef Y5_EMU
+  const unsigned t = (unsigned)(((unsigned long long)m * n) >> 32);
+#else
+  const unsigned t = __umulhi(m, n);
+#endif
+  return (t + ((n - t) >> (s & 0xff))) >> (s >> 8);
+}
+inline void y5_conv_set_fastdiv(Y5ConvParams& p) {
+  y5_fastdiv_make((unsigned)(p.OH * p.OW), &p.dv_ohw_m, &p.dv_ohw_s);
+  y5_fastdiv_make((unsigned)p.OW, &p.dv_ow_m, &p.dv_ow_s);
+}
 
 #define Y5_CONV_MAXTAB 4096   // max k-pieces in TABLE mode (LDS: 8 B each)
 
@@ -211,7 +234,7 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
     n0 = tn * BN;
   };
 
-  auto loader_setup = [&](int j) {
+  auto loader_setup = [&](int j) __attribute__((always_inline)) {   // (outlined as a real call -- 600 B of stack per wave -- in the 256-row kernels otherwise)
     int m0, n0;
     tile_coords(j, m0, n0);
 #pragma unroll
@@ -221,9 +244,9 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
       const int m = m0 + row;
       const int mm = m < p.M ? m : 0;
       const int ohw = p.OH * p.OW;
-      const int b = mm / ohw;
+      const int b = (int)y5_fastdiv((unsigned)mm, p.dv_ohw_m, p.dv_ohw_s);
       const int r = mm - b * ohw;
-      const int oh = r / p.OW, ow = r - oh * p.OW;
+      const int oh = (int)y5_fastdiv((unsigned)r, p.dv_ow_m, p.dv_ow_s), ow = r - oh * p.OW;
       const int ih0 = oh * p.SH - p.PH, iw0 = ow * p.SW - p.PW;
       a_base[i] = (((b * p.H + ih0) * p.W + iw0) * p.ldx + sslot * EPP) * ES;
       if constexpr (UP2) a_base2[i] = (((b * (p.H >> 1) + (oh >> 1)) * (p.W >> 1) + (ow >> 1)) * p.ldx2 + sslot * EPP) * ES;
@@ -232,12 +255,20 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
         a_iw0[i] = iw0;
         a_slot[i] = sslot;
       } else {
+        // taps inside the image: kh in [max(0, -ih0), min(KH, H - ih0)), kw likewise -- two bit ranges and one shift-or per filter ROW instead
+        // of two compares per TAP (round 4: this runs once per tile in the waves that feed the ring; a 1x1 layer's tile is only 8 chunks long)
         unsigned mk = 0;
         if (m < p.M) {
-          unsigned bit = 1;
+          auto range_bits = [](int lo, int hi) __attribute__((always_inline)) -> unsigned {   // bits [lo, hi), 0 <= lo, hi <= 32
+            if (hi <= lo) return 0u;
+            const unsigned top = hi >= 32 ? ~0u : (1u << hi) - 1u;
+            return top & ~((1u << lo) - 1u);
+          };
+          const int lo_h = ih0 < 0 ? -ih0 : 0, hi_h = p.H - ih0 < p.KH ? p.H - ih0 : p.KH;
+          const int lo_w = iw0 < 0 ? -iw0 : 0, hi_w = p.W - iw0 < p.KW ? p.W - iw0 : p.KW;
+          const unsigned bh = range_bits(lo_h < 32 ? lo_h : 32, hi_h), bw = range_bits(lo_w < 32 ? lo_w : 32, hi_w);
           for (int kh = 0; kh < p.KH; ++kh)
-            for (int kw = 0; kw < p.KW; ++kw, bit <<= 1)
-              if ((unsigned)(ih0 + kh) < (unsigned)p.H && (unsigned)(iw0 + kw) < (unsigned)p.W) mk |= bit;
+            if ((bh >> kh) & 1u) mk |= bw << (kh * p.KW);
         }
         a_mask[i] = ~mk;  // stored inverted: bit set <=> tap outside the image
       }
@@ -271,7 +302,7 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
   int st_tap_off = 0, st_tap_bit = 0;
   bool st_up = false;
   unsigned st_kcb = 0;
-  auto stage_begin = [&](int buf) {
+  auto stage_begin = [&](int buf) __attribute__((always_inline)) {
     st_lds = smem + buf * BUF_BYTES;
     if constexpr (!TABLE) {
       st_tap_off = ((u_kh * p.W + u_kw) * p.ldx + u_c0) * ES;
@@ -313,7 +344,7 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
       }
     }
   };
-  auto stage_end = [&]() {  // advance to the next (tile, chunk)
+  auto stage_end = [&]() __attribute__((always_inline)) {  // advance to the next (tile, chunk)
     if constexpr (!TABLE) {
       u_c0 += BK;
       if (u_c0 >= p.C1) {
@@ -326,7 +357,7 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
       if (++s_t < nmine) loader_setup(s_t);
     }
   };
-  auto stage = [&](int buf) {
+  auto stage = [&](int buf) __attribute__((always_inline)) {
 #ifdef Y5_DBG_NOLOAD
     if (s_t > 0 || s_kc > 0) { stage_end(); return; }
 #endif
