@@ -897,6 +897,11 @@ def main():
                     "share_of_conv_time": round(gms / conv_ms_in_situ, 3) if conv_ms_in_situ > 0 else None,
                     "achieved_tflops": round(gfl / (gms * 1e-3) / 1e12, 1), "frac": round(gfl / (gms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
                     "hbm_gbytes_per_s": round(gby / (gms * 1e-3) / 1e9, 1)}
+    try:  # which plan the tuner built on this box: two lines are comparable only when this hash agrees
+        import hashlib
+        plan_sha16 = hashlib.sha256(json.dumps([[n, c] for n, c in eng.plan_table()]).encode()).hexdigest()[:16]
+    except Exception:
+        plan_sha16 = None
     # practical per-layer floor: every conv launch at the ceilings this box just showed (copy bandwidth, sustained MFMA rate)
     ceil = None
     if rank == 0:
@@ -1032,8 +1037,7 @@ def main():
                          "measured_ceilings": ceil},
         }
         try:  # which plan the tuner built on this box: two lines are comparable only when this hash agrees
-            import hashlib
-            res["config"]["plan_sha16"] = hashlib.sha256(json.dumps([[n, c] for n, c in eng.plan_table()]).encode()).hexdigest()[:16]
+            res["config"]["plan_sha16"] = plan_sha16
             res["config"]["kernel_src_sha16"] = kernel_src_hash()
         except Exception:
             pass

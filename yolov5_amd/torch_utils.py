@@ -13,6 +13,7 @@ parameters and buffers are broadcast from rank 0 at construction; BatchNorm stat
 from __future__ import annotations
 
 import math
+import os
 from contextlib import contextmanager
 from copy import deepcopy
 
@@ -47,8 +48,10 @@ class HipDDP(nn.Module):
     25 MB default would give 2); a 6 MB ring all-reduce is ~70 us on one xGMI link, still far above the per-collective latency.
     The mean over ranks is ReduceOp.AVG inside the collective on RCCL (`nccl`), a per-bucket division after the wait elsewhere."""
 
-    def __init__(self, module, bucket_cap_mb=6.0, process_group=None):
+    def __init__(self, module, bucket_cap_mb=None, process_group=None):
         super().__init__()
+        if bucket_cap_mb is None:
+            bucket_cap_mb = float(os.environ.get("Y5_DDP_BUCKET_MB", "6"))
         self.module = module
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
