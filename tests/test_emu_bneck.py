@@ -27,7 +27,8 @@ def _ref_bneck(x, w1, b1, w2, b2, add):
                                                       (64, 2, 4, 24, True, 64, 72, 0), (32, 3, 4, 8, True, 32, 32, 0),
                                                       # many tiles per wave (grid capped at 1-2 workgroups) for every ring depth: ramp, steady state, drain
                                                       (32, 1, 24, 32, True, 32, 32, 1 | (1 << 16)), (32, 1, 24, 32, True, 64, 32, 1 | (2 << 16)),
-                                                      (32, 2, 16, 40, False, 32, 32, 2 | (3 << 16)), (64, 1, 16, 32, True, 64, 64, 1 | (1 << 16))])
+                                                      (32, 2, 16, 40, False, 32, 32, 2 | (3 << 16)), (64, 1, 16, 32, True, 64, 64, 1 | (1 << 16)),
+                                                      (64, 2, 16, 32, True, 64, 64, 1), (64, 3, 8, 40, False, 128, 64, 2)])   # C = 64 default: eight waves, t aliased onto the stage; 3-4 tiles per wave
 def test_fused_bottleneck_matches_torch(Cc, B, H, W, add, ldx, ldy, mb):
     lib = emu()
     rng = np.random.default_rng(Cc + H + W)

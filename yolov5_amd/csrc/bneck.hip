@@ -7,18 +7,18 @@
 #include "y5_host.h"
 
 namespace {
-template <int C, int S, bool ADD, bool CV3 = false>
+template <int C, int S, bool ADD, bool CV3 = false, int NWV = 4, bool ALIAS = false>
 int launch_bneck(const Y5BneckParams& p, int max_blocks, hipStream_t stream) {
-  const size_t lds = y5_conv_bneck_lds_bytes<C, S, CV3>();
+  const size_t lds = y5_conv_bneck_lds_bytes<C, S, CV3, NWV, ALIAS>();
   if (lds > 160 * 1024) return y5_fail(Y5_ERR_UNSUPPORTED, "bottleneck: exceeds 160 KiB of LDS");
-  auto kern = y5_conv_bneck_kernel<C, S, ADD, CV3>;
+  auto kern = y5_conv_bneck_kernel<C, S, ADD, CV3, NWV, ALIAS>;
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   const long long nwt = (long long)p.B * (p.H / 4) * (p.W / 8);
-  const long long nbt = (nwt + 3) >> 2;
+  const long long nbt = (nwt + NWV - 1) / NWV;
   long long G = max_blocks;
   if (G <= 0) {
     static int num_cu = 0;
@@ -36,7 +36,7 @@ int launch_bneck(const Y5BneckParams& p, int max_blocks, hipStream_t stream) {
   }
   if (G > nbt) G = nbt;
   if (G >= 8) G &= ~7LL;
-  hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(NWV * 64), lds, stream, p);
   return y5_check_launch("y5_bottleneck_fwd");
 }
 }  // namespace
@@ -71,7 +71,9 @@ extern "C" int y5_bottleneck_fwd(const void* x, int ldx, const void* w1_packed, 
     if (S == 1) return add ? launch_bneck<32, 1, true>(p, max_blocks, st) : launch_bneck<32, 1, false>(p, max_blocks, st);
     if (S == 2) return add ? launch_bneck<32, 2, true>(p, max_blocks, st) : launch_bneck<32, 2, false>(p, max_blocks, st);
     if (S == 3) return add ? launch_bneck<32, 3, true>(p, max_blocks, st) : launch_bneck<32, 3, false>(p, max_blocks, st);
-  } else if (S == 1) {
+  } else if (stages == 0) {   // C = 64 default (round 4): eight waves, t aliased onto the single stage
+    return add ? launch_bneck<64, 1, true, false, 8, true>(p, max_blocks, st) : launch_bneck<64, 1, false, false, 8, true>(p, max_blocks, st);
+  } else if (S == 1) {        // stages = 1 asked for explicitly: the four-wave form with stage and t apart
     return add ? launch_bneck<64, 1, true>(p, max_blocks, st) : launch_bneck<64, 1, false>(p, max_blocks, st);
   }
   return y5_fail(Y5_ERR_UNSUPPORTED, "bottleneck: unsupported number of stages");

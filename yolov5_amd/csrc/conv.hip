@@ -475,7 +475,7 @@ extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w
   if (up2 != (d->up_c > 0)) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: configurations 88 / 89 serve exactly the layers with up_c > 0 (virtual upsample + concat)");
   if (up2) {
     const int bkb = kUpCfgs[cfg - kUp0].rb / 2;
-    if (d->dtype != Y5_F16 || d->KH != 1 || d->KW != 1 || d->SH != 1 || d->SW != 1 || d->PH || d->PW || !residual || !y || y_up2 || d->split_n ||
+    if (d->dtype != Y5_F16 || d->KH != 1 || d->KW != 1 || d->SH != 1 || d->SW != 1 || d->PH || d->PW || !residual || !y || (y_up2 != nullptr) != (d->split_n > 0) ||
         d->out_mul_h || (d->H & 1) || (d->W & 1) || d->up_c % bkb || d->up_c >= d->C1 || d->C1 % bkb || d->ld_up < d->up_c || (d->ld_up & 7))
       return y5_fail(Y5_ERR_UNSUPPORTED, "conv: virtual upsample + concat needs a 1x1 s1 fp16 layer on an even H x W grid, up_c and C1 multiples of the K chunk, "
                                          "the low-resolution tensor in the `residual` argument");
@@ -527,7 +527,7 @@ extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w
   p.split_n = d->split_n;
   if (d->split_n) {
     if (d->split_n < 0 || d->split_n % epp || d->split_n >= d->C2 || !y || !y_up2 || d->ld2 % epp || d->ld2 < d->C2 - d->split_n || d->ldy < d->split_n ||
-        placed || residual)
+        placed || (residual && !up2))
       return y5_fail(Y5_ERR_BAD_ARG, "conv: bad split store (split_n multiple of 16 bytes inside C2, both destinations, no residual / placement)");
     if (k3 || h3) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: split store needs a pointwise / implicit-GEMM configuration");
   }

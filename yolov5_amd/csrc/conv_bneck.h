@@ -25,11 +25,13 @@
 #endif
 __device__ __forceinline__ float y5_bneck_act(float v) { return (Y5_BNECK_ABL & 1) ? v : y5_silu(v); }
 
-template <int C, int S, bool CV3 = false>
+template <int C, int S, bool CV3 = false, int NWV = 4, bool ALIAS = false>
 constexpr size_t y5_conv_bneck_lds_bytes() {
   constexpr int NSL = C / 8, NI = (60 * NSL + 63) / 64;
   // CV3: + the third bias (the third filter lives in registers, the cv2 half of its input comes straight from global memory)
-  return (size_t)C * C * 2 + (size_t)C * 9 * C * 2 + (size_t)2 * C * 4 + (size_t)4 * (S * NI * 1024 + 64 * C * 2) + (CV3 ? (size_t)2 * C * 4 : 0);
+  // ALIAS: the t buffer IS the (single) stage -- see the kernel
+  return (size_t)C * C * 2 + (size_t)C * 9 * C * 2 + (size_t)2 * C * 4 +
+         (size_t)NWV * (ALIAS ? (NI * 1024 > 64 * C * 2 ? NI * 1024 : 64 * C * 2) : S * NI * 1024 + 64 * C * 2) + (CV3 ? (size_t)2 * C * 4 : 0);
 }
 
 struct Y5BneckParams {
@@ -51,9 +53,14 @@ struct Y5BneckParams {
   int ld2, Kpad3, C3, act3;
 };
 
-template <int C, int S, bool ADD, bool CV3 = false>
-__global__ __launch_bounds__(256, CV3 ? 3 : 1)  // CV3: three waves per SIMD as without it (the third filter's 32 registers must not cost a workgroup per CU)
+// NWV = 8 + ALIAS (round 4, C = 64): eight waves share the one copy of the filters (8 + 72 KB at C = 64) and each wave's t buffer IS its single
+// stage -- GEMM 1 reads every fragment of the receptive field and the residual is lifted to registers BEFORE t is written over it, and the next tile's
+// receptive field is requested only when the tile's last scratch read has returned (no prefetch inside a wave: the other wave of the SIMD covers the
+// round trip, the "resident waves beat prefetch depth" finding of conv_k3.h / conv_pw.h).  Four waves with stage + t apart fill the LDS at C = 64.
+template <int C, int S, bool ADD, bool CV3 = false, int NWV = 4, bool ALIAS = false>
+__global__ __launch_bounds__(NWV * 64, CV3 ? 3 : 1)  // CV3: three waves per SIMD as without it (the third filter's 32 registers must not cost a workgroup per CU)
 void y5_conv_bneck_kernel(const Y5BneckParams p) {
+  static_assert(!ALIAS || (S == 1 && !CV3), "the aliased form has one stage and no third GEMM");
   typedef half_t T;
   constexpr int NT = C / 32;
   constexpr int TR = 4, TC = 8, RH = TR + 2, RW = TC + 2;   // wave tile / receptive field
@@ -81,8 +88,9 @@ void y5_conv_bneck_kernel(const Y5BneckParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* b3l = reinterpret_cast<float*>(smem + W1_BYTES + W2_BYTES + 2 * C * 4);
-  char* ring = smem + W1_BYTES + W2_BYTES + 2 * C * 4 + (CV3 ? C3P * 4 : 0) + wave * (S * STAGE2 + TBYTES);
-  char* ts = ring + S * STAGE2;
+  constexpr int PERWAVE = ALIAS ? (STAGE2 > TBYTES ? STAGE2 : TBYTES) : S * STAGE2 + TBYTES;
+  char* ring = smem + W1_BYTES + W2_BYTES + 2 * C * 4 + (CV3 ? C3P * 4 : 0) + wave * PERWAVE;
+  char* ts = ALIAS ? ring : ring + S * STAGE2;
 
   const y5_rsrc_t xrs = y5_make_rsrc(p.x, p.x_bytes);
   const y5_rsrc_t w1rs = y5_make_rsrc(p.w1, p.w1_bytes);
@@ -95,21 +103,21 @@ void y5_conv_bneck_kernel(const Y5BneckParams p) {
   // ---- prologue: both filters (rows swizzled like the activation rows) + biases into LDS -----------------------------
   {
     constexpr int WI1 = C * NSL / 64;
-    for (int I = wave; I < WI1; I += 4) {
+    for (int I = wave; I < WI1; I += NWV) {
       const int pidx = I * 64 + lane;
       const int n = pidx / NSL, ps = pidx - n * NSL;
       y5_bglds16(w1rs, (unsigned)(n * p.Kpad1 * 2 + ((ps ^ fsw(n)) * 16)), w1l + I * 1024);
     }
     constexpr int WSL = 9 * NSL, WI2 = C * WSL / 64;
-    for (int I = wave; I < WI2; I += 4) {
+    for (int I = wave; I < WI2; I += NWV) {
       const int pidx = I * 64 + lane;
       const int n = pidx / WSL, ps = pidx - n * WSL;
       const int src_slot = (ps & ~(NSL - 1)) | ((ps & (NSL - 1)) ^ fsw(n));
       y5_bglds16(w2rs, (unsigned)(n * p.Kpad2 * 2 + src_slot * 16), w2l + I * 1024);
     }
-    for (int i = tid; i < C; i += 256) { b1l[i] = p.b1[i]; b2l[i] = p.b2[i]; }
+    for (int i = tid; i < C; i += NWV * 64) { b1l[i] = p.b1[i]; b2l[i] = p.b2[i]; }
     if constexpr (CV3) {
-      for (int i = tid; i < C3P; i += 256) b3l[i] = p.b3[i];
+      for (int i = tid; i < C3P; i += NWV * 64) b3l[i] = p.b3[i];
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
@@ -165,9 +173,9 @@ void y5_conv_bneck_kernel(const Y5BneckParams p) {
   const int tw = p.W / TC, th = p.H / TR;
   const int nwt = p.B * th * tw;
   const int G = gridDim.x, bid = blockIdx.x;
-  const int nbt = (nwt + 3) >> 2;
+  const int nbt = (nwt + NWV - 1) / NWV;
   const int nmine = (nbt - bid + G - 1) / G;
-  auto tile_id = [&](int j) { return y5_xcd_remap(bid + j * G, nbt) * 4 + wave; };
+  auto tile_id = [&](int j) { return y5_xcd_remap(bid + j * G, nbt) * NWV + wave; };
   int nw = nmine;
   if (nw > 0 && tile_id(nw - 1) >= nwt) --nw;
   auto tile_origin = [&](int j, int& b, int& oh0, int& ow0) {
@@ -198,8 +206,8 @@ void y5_conv_bneck_kernel(const Y5BneckParams p) {
     if (s0 < nw) issue(s0, s0);
   int buf = 0;
   for (int i = 0; i < nw; ++i) {
-    if (i + S - 1 >= nw) {
-      y5_wait_vm<0>();
+    if (ALIAS || i + S - 1 >= nw) {
+      y5_wait_vm<0>();   // ALIAS: the stage's loads are the NEWEST operations of the queue (issued behind the previous tile's stores)
     } else if (i < S) {
       switch (i) {
         case 0: y5_wait_vm<(S - 1) * LP>(); break;
@@ -221,6 +229,7 @@ void y5_conv_bneck_kernel(const Y5BneckParams p) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) y2f[ks] = y5_buffer_load16(y2rs, poff + (ks * 2 + g) * 16, 0);
     }
+    uint4_t resv[NPASS];
     // ---- GEMM 1: t = SiLU(W1 x + b1) on the receptive field, zero outside the image -------------------------------------
     {
       float16_t acc1[2][NT];
@@ -242,6 +251,18 @@ void y5_conv_bneck_kernel(const Y5BneckParams p) {
           for (int f = 0; f < 2; ++f) acc1[f][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, af[f], acc1[f][j], 0, 0, 0);
         }
       }
+      if constexpr (ALIAS && ADD) {   // t is about to overwrite the stage: the tile's own pixels of x go to registers first
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+          const int row = ps * RPP + orow;
+          const int q = ((row >> 3) + 1) * RW + (row & 7) + 1;
+          resv[ps] = *reinterpret_cast<const uint4_t*>(xs + q * ROWB + ((oslot ^ fsw(q)) * 16));
+        }
+      }
+      if constexpr (ALIAS) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): every fragment / residual read of the stage has returned
+        __builtin_amdgcn_wave_barrier();
+      }
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
         const int q = f * 32 + pl;
@@ -261,8 +282,7 @@ void y5_conv_bneck_kernel(const Y5BneckParams p) {
       }
     }
     // ---- residual: the tile's own pixels of x, stage -> registers; then the stage is free for the next tile --------------
-    uint4_t resv[NPASS];
-    if constexpr (ADD) {
+    if constexpr (ADD && !ALIAS) {
 #pragma unroll
       for (int ps = 0; ps < NPASS; ++ps) {
         const int row = ps * RPP + orow;
@@ -273,8 +293,10 @@ void y5_conv_bneck_kernel(const Y5BneckParams p) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // t is written, every LDS read of the stage has returned (lgkmcnt 0)
     __builtin_amdgcn_s_waitcnt(0xC07F);                       // lgkmcnt(0)
     __builtin_amdgcn_wave_barrier();
-    if (i + S < nw && !(Y5_BNECK_ABL & 4)) issue(i + S, buf);
-    buf = buf + 1 == S ? 0 : buf + 1;
+    if constexpr (!ALIAS) {
+      if (i + S < nw && !(Y5_BNECK_ABL & 4)) issue(i + S, buf);
+      buf = buf + 1 == S ? 0 : buf + 1;
+    }
     // ---- GEMM 2: 3x3 over t ---------------------------------------------------------------------------------------------------
     float16_t acc[NT];  // one accumulation chain per block, as conv_k3.h
 #pragma unroll
@@ -383,5 +405,10 @@ void y5_conv_bneck_kernel(const Y5BneckParams p) {
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // the scratch is rewritten by the next tile's GEMM 1
+    if constexpr (ALIAS) {
+      __builtin_amdgcn_s_waitcnt(0xC07F);   // the last scratch reads have returned: the buffer takes the next receptive field
+      __builtin_amdgcn_wave_barrier();
+      if (i + 1 < nw && !(Y5_BNECK_ABL & 4)) issue(i + 1, 0);
+    }
   }
 }

@@ -113,7 +113,7 @@ class _Planner:
         op = dict(op="conv", mods=mods, x=x, y=dest, res=res, y2=up2, k=k, s=s, p=p, act=act, c2=c2, c2_store=cst, name=name, view=view,
                   split_n=0 if split is None else split[0])
         if x_up is not None:   # (low-resolution TRef, channels): input channels [0, c_up) are read from it at (oh >> 1, ow >> 1)
-            assert k == (1, 1) and s == (1, 1) and p == (0, 0) and res is None and split is None and up2 is None, name
+            assert k == (1, 1) and s == (1, 1) and p == (0, 0) and res is None and (up2 is None or split is not None), name
             op["up"] = x_up
         if emit:
             self.spec.ops.append(op)
@@ -126,7 +126,10 @@ class _Planner:
         return self.conv([m.cv2], t, dest, res=x if m.add else None, name="b.cv2")
 
     def _bneck_fusable(self, m, c_, x):
-        if not self.fuse_bneck or c_ != 32 or x.H % 4 or x.W % 8 or not len(m.m):
+        # c_ = 32: four waves, stage + t (conv_bneck.h); c_ = 64 (round 4): eight waves with t aliased onto the stage -- Y5_FUSED_BNECK64 = 0 keeps
+        # the two-launch form there
+        ok_c = c_ == 32 or (c_ == 64 and os.environ.get("Y5_FUSED_BNECK64", "1") != "0")
+        if not self.fuse_bneck or not ok_c or x.H % 4 or x.W % 8 or not len(m.m):
             return False
         for b in m.m:
             c1, c2 = b.cv1.conv, b.cv2.conv
@@ -139,13 +142,12 @@ class _Planner:
         c_ = m.cv1.conv.out_channels
         cat = self.spec.new_buf(x.H, x.W, 2 * c_, name + ".cat")
         if self._bneck_fusable(m, c_, x):
-            assert x_up is None
             # cv1's half of the GEMM lands in a buffer of its own (split store), every Bottleneck is ONE launch that reads one buffer
             # and writes another (a tile needs its neighbours' input pixels: not in place), the last one writes its slice of `cat`
             ping = [self.spec.new_buf(x.H, x.W, c_, name + ".a0")]
             if len(m.m) > 1:
                 ping.append(self.spec.new_buf(x.H, x.W, c_, name + ".a1"))
-            self.conv([m.cv1, m.cv2], x, ping[0], name=name + ".cv1+cv2", split=(c_, _slice(cat, c_, c_)))
+            self.conv([m.cv1, m.cv2], x, ping[0], name=name + ".cv1+cv2", split=(c_, _slice(cat, c_, c_)), x_up=x_up)
             src = ping[0]
             for i, b in enumerate(m.m):
                 dst = _slice(cat, 0, c_) if i == len(m.m) - 1 else ping[(i + 1) % 2]
