@@ -178,7 +178,7 @@ def pmc_mfma_busy(a):
         return None, {}
     src = f"profiles/pmc/{os.path.basename(path)} (scripts/pmc_issue_mix.sh: rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE, ...)"
     have, want = d.get("kernel_src_sha16"), kernel_src_hash()
-    per_kernel = {r["kernel"]: r.get("mfma_busy_frac") for r in d.get("kernels", []) if r.get("conv")}
+    per_kernel = {r["kernel"]: (r.get("mfma_busy_frac"), r.get("launches_per_forward")) for r in d.get("kernels", []) if r.get("conv")}
     if have != want:
         return {"value": None, "stale": True, "stale_value": round(frac, 4), "measured_with_kernel_src_sha16": have, "current_kernel_src_sha16": want, "source": src}, {}
     return {"value": round(frac, 4), "kernel_src_sha16": have, "source": src,
@@ -978,11 +978,11 @@ def main():
     dom_busy = None
     if rank == 0 and dominant and mfma_busy[1]:
         # the PMC file names kernels by their (mangled or demangled) symbol: match family + the instantiation's share of launches
+        # several instantiations of the family were profiled: the dominant one is the one with (nearly) the same number of launches per forward
         fam_rows = {k: v for k, v in mfma_busy[1].items() if dominant["family"].replace("_kernel", "") in k}
-        if len(fam_rows) == 1:
-            dom_busy = next(iter(fam_rows.values()))
-        elif fam_rows:
-            dom_busy = {"per_instantiation_of_family": fam_rows}
+        if fam_rows:
+            k_best = min(fam_rows, key=lambda k: abs((fam_rows[k][1] or 0) - dominant["launches_per_step"] / max(parts, 1)))
+            dom_busy = {"value": fam_rows[k_best][0], "kernel": k_best[:120], "launches_per_forward": fam_rows[k_best][1]}
     if rank == 0:
         imgs = a.batch * world * a.steps
         res = {
