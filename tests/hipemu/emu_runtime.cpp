@@ -7,11 +7,13 @@ alignas(256) char smem[160 * 1024];  // the kernels' `extern __shared__ char sme
 
 namespace emu {
 enum { RUN = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
+struct Dma { void* dst; int size; unsigned char data[16]; };
 struct Lane {
   ucontext_t ctx;
   dim3 tid;
   int linear, state;
   unsigned seq;
+  std::vector<Dma> dma;   // pieces in flight (Y5_EMU_ASYNC=1), oldest first
 };
 struct Slot { unsigned char data[64][64]; unsigned tag[64]; };
 static std::vector<Lane> lanes;
@@ -46,8 +48,28 @@ void wave_exchange(const void* payload, int bytes, const void* out[64]) {
   for (int k = 0; k < 64; ++k) out[k] = s.tag[k] == seq ? s.data[k] : nullptr;
 }
 
+static int g_async = -1;
+void dma_issue(void* dst, const void* src, int size) {
+  if (g_async < 0) { const char* e = getenv("Y5_EMU_ASYNC"); g_async = e && e[0] == '1'; }
+  if (!g_async || size > 16) {
+    if (src) memcpy(dst, src, size); else memset(dst, 0, size);
+    return;
+  }
+  Dma d{dst, size, {}};
+  if (src) memcpy(d.data, src, size);
+  cur->dma.push_back(d);
+}
+void dma_wait(int keep) {
+  std::vector<Dma>& q = cur->dma;
+  const int n = (int)q.size() - (keep < 0 ? 0 : keep);
+  if (n <= 0) return;
+  for (int i = 0; i < n; ++i) memcpy(q[i].dst, q[i].data, q[i].size);
+  q.erase(q.begin(), q.begin() + n);
+}
+
 static void trampoline() {
   (*g_fn)();
+  dma_wait(0);
   cur->state = DONE;
   swapcontext(&cur->ctx, &sched);
 }

@@ -37,6 +37,11 @@ void barrier_block();
 // wave collective: every live lane of the wave deposits `bytes` of payload; returns after all arrived.
 // out[l] points at lane l's payload (nullptr if lane l did not participate).
 void wave_exchange(const void* payload, int bytes, const void* out[64]);
+// LDS-DMA model (Y5_EMU_ASYNC=1): a `buffer_load ... lds` lands only when a covering s_waitcnt vmcnt(N) of the issuing lane retires it (or at kernel
+// end) -- the LATEST moment the hardware allows, so a wait that is one piece too loose reads poison instead of passing by luck.  Default (0): lands
+// at issue, the EARLIEST moment (write-after-read hazards of a ring show up in this mode).  Tests of the counted-vmcnt kernels run both.
+void dma_issue(void* dst, const void* src, int size);   // src == nullptr: zero fill
+void dma_wait(int keep);                                // retire all but the `keep` youngest pieces of the calling lane
 }  // namespace emu
 
 #define threadIdx (emu::lane_tid())
@@ -90,7 +95,7 @@ inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorN
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_readlane(v, l) __shfl((v), (l))
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
-#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(x) emu::dma_wait((int)(((x) & 15) | ((((x) >> 14) & 3) << 4)))
 #define __builtin_amdgcn_s_barrier() emu::barrier_block()
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_amdgcn_sched_barrier(a) ((void)0)
@@ -115,10 +120,10 @@ struct __amdgpu_buffer_rsrc_t { const char* base; unsigned num_records; };
 inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, int, int n, int) { return {(const char*)p, (unsigned)n}; }
 inline void emu_bglds(__amdgpu_buffer_rsrc_t r, void* l, int size, unsigned voff) {
   char* d = (char*)l + (size_t)emu::lane_id() * size;
-  if ((unsigned long long)voff + size > r.num_records) memset(d, 0, size); else memcpy(d, r.base + voff, size);
+  emu::dma_issue(d, (unsigned long long)voff + size > r.num_records ? nullptr : r.base + voff, size);
 }
 #define __builtin_amdgcn_raw_ptr_buffer_load_lds(r, l, size, voff, soff, ioff, aux) emu_bglds((r), (void*)(uintptr_t)(l), (size), (unsigned)(voff))
-inline void emu_glds(const void* g, void* l, int size) { memcpy((char*)l + (size_t)emu::lane_id() * size, g, size); }
+inline void emu_glds(const void* g, void* l, int size) { emu::dma_issue((char*)l + (size_t)emu::lane_id() * size, g, size); }
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu_glds((const void*)(uintptr_t)(g), (void*)(uintptr_t)(l), (size))
 
 inline unsigned long long __ballot(int pred) {

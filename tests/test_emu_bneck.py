@@ -55,6 +55,55 @@ def test_fused_bottleneck_matches_torch(Cc, B, H, W, add, ldx, ldy, mb):
     assert np.all(ybuf[..., Cc:] == 7)                               # nothing written outside the slice
 
 
+# c_ = 128 (conv_h3b.h): GEMM-1 phase + halo-resident 3x3.  Shapes: one tile per image; images cut into several row / column tiles with ragged
+# edges (the in-image test of the t store); several tiles per workgroup (next-tile halo prefetch into dead planes, ring re-prologue); 5-stage ring.
+# Each case runs with LDS-DMA landing at issue (write-after-read hazards) and at the covering vmcnt wait (counted-wait bookkeeping).
+H3B_CASES = [(1, 6, 7, True, 128, 128, 0), (2, 9, 20, False, 256, 136, 0), (1, 23, 40, True, 128, 128, 2), (3, 12, 10, True, 128, 256, 1),
+             (1, 40, 40, True, 128, 128, 3), (2, 17, 33, False, 128, 128, 2 | (5 << 16)), (5, 5, 5, True, 128, 128, 1 | (5 << 16))]
+
+
+@pytest.mark.parametrize("async_dma", ["0", "1"])
+@pytest.mark.parametrize("B,H,W,add,ldx,ldy,mb", H3B_CASES)
+def test_fused_bottleneck_c128_matches_torch(B, H, W, add, ldx, ldy, mb, async_dma):
+    import subprocess
+    import sys
+
+    if async_dma == "1":   # the DMA model is latched per process (getenv once): run the same case in a child with the switch set
+        code = f"import tests.test_emu_bneck as t; t._run_c128({B}, {H}, {W}, {add}, {ldx}, {ldy}, {mb})"
+        import os
+        env = dict(os.environ, Y5_EMU_ASYNC="1")
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        return
+    _run_c128(B, H, W, add, ldx, ldy, mb)
+
+
+def _run_c128(B, H, W, add, ldx, ldy, mb):
+    lib = emu()
+    Cc = 128
+    rng = np.random.default_rng(B * 1000 + H * 10 + W)
+    w1 = torch.from_numpy(rng.standard_normal((Cc, Cc, 1, 1)).astype(np.float32) * (2.0 / Cc) ** 0.5)
+    w2 = torch.from_numpy(rng.standard_normal((Cc, Cc, 3, 3)).astype(np.float32) * (2.0 / (9 * Cc)) ** 0.5)
+    b1 = torch.from_numpy(rng.standard_normal(Cc).astype(np.float32) * 0.3)
+    b2 = torch.from_numpy(rng.standard_normal(Cc).astype(np.float32) * 0.3)
+    w1p, b1p, _, K1, _ = pack_conv_weight(w1, b1, torch.float16)
+    w2p, b2p, _, K2, _ = pack_conv_weight(w2, b2, torch.float16)
+    xbuf = aligned((B, H, W, ldx), np.float16)
+    xbuf[...] = rng.standard_normal(xbuf.shape).astype(np.float16)
+    x = xbuf[..., ldx - Cc:]
+    ybuf = aligned((B, H, W, ldy), np.float16, 7)
+    W1, B1, W2, B2 = (aligned(t.shape, t.numpy().dtype) for t in (w1p, b1p, w2p, b2p))
+    for dst, src in ((W1, w1p), (B1, b1p), (W2, w2p), (B2, b2p)):
+        dst[...] = src.numpy()
+    rc = lib.y5_bottleneck_fwd(C.c_void_p(xbuf.ctypes.data + (ldx - Cc) * 2), ldx, ptr(W1), ptr(B1), K1, ptr(W2), ptr(B2), K2, ptr(ybuf), ldy, B, H, W, Cc,
+                               int(add), mb, None)
+    assert rc == 0, lib.y5_last_error()
+    ref = _ref_bneck(np.ascontiguousarray(x), w1, b1, w2, b2, add)
+    got = ybuf[..., :Cc].astype(np.float32)
+    np.testing.assert_allclose(got, ref, rtol=4e-3, atol=4e-3)
+    assert np.all(ybuf[..., Cc:] == 7)
+
+
 def test_fused_bottleneck_rejects_overlap_and_bad_shapes():
     lib = emu()
     buf = aligned((1, 8, 8, 64), np.float16)
@@ -147,5 +196,28 @@ def test_plan_fuses_cv3_into_the_last_bottleneck(monkeypatch):
         eng = Engine(m, (1, 3, 64, 64), torch.float16, "cpu", want_raw=False, backend=EmuBackend())
         outs[mode] = np.asarray(eng(x)["z"]).astype(np.float32).copy()
         assert any(n.startswith("bneck+cv3:") for n in eng.op_names) == (mode == "1"), eng.op_names
+    u, v = outs["0"], outs["1"]
+    assert np.abs(u - v).max() <= 4e-3 * max(1.0, np.abs(u).max()), np.abs(u - v).max()
+
+
+def test_plan_fuses_the_128_channel_bottlenecks(monkeypatch):
+    """yolov5s 6.C3 / 13.C3 / 20.C3 (c_ = 128): the plan whose Bottlenecks are conv_h3b.h launches (default) against the two-launch plan
+    (Y5_FUSED_BNECK128=0) on the emulator; 13.C3's cv1+cv2 GEMM carries the split store on top of the virtual Upsample + Concat read."""
+    from oracle import detgen
+    from tests.hipemu.backend import EmuBackend
+    from tests.test_emu_model import det_model
+    from yolov5_amd.engine import Engine
+
+    m = det_model("yolov5s", 0, True).half()
+    x = torch.from_numpy(detgen.uniform((1, 3, 64, 96), 0.0, 1.0, name="img", seed=0)).half()
+    outs, names = {}, {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("Y5_FUSED_BNECK128", mode)
+        eng = Engine(m, (1, 3, 64, 96), torch.float16, "cpu", want_raw=False, backend=EmuBackend())
+        outs[mode] = np.asarray(eng(x)["z"]).astype(np.float32).copy()
+        names[mode] = list(eng.op_names)
+    n128 = [n for n in names["1"] if n.startswith("bneck:") and n.split(":")[1].split(".")[0] in ("6", "13", "20")]
+    assert len(n128) == 5 and not any(n.startswith("bneck:6.") for n in names["0"]), (names["0"], names["1"])
+    assert len(names["1"]) == len(names["0"]) - 5 + 0 or len([n for n in names["1"] if n == "conv:b.cv1"]) == len([n for n in names["0"] if n == "conv:b.cv1"]) - 5
     u, v = outs["0"], outs["1"]
     assert np.abs(u - v).max() <= 4e-3 * max(1.0, np.abs(u).max()), np.abs(u - v).max()

@@ -4,6 +4,7 @@
 
 #include "../../include/yolov5_hip.h"
 #include "conv_bneck.h"
+#include "conv_h3b.h"
 #include "y5_host.h"
 
 namespace {
@@ -39,14 +40,71 @@ int launch_bneck(const Y5BneckParams& p, int max_blocks, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(NWV * 64), lds, stream, p);
   return y5_check_launch("y5_bottleneck_fwd");
 }
+
+// ---- c_ = 128: GEMM-1 phase in front of the halo-resident 3x3 (conv_h3b.h) ------------------------------------------------------------------
+// spatial tile for an H x W image: TW = ceil(W / d), TH as tall as the 256-pixel MFMA tile and the 320-pixel LDS halo allow, evened out over the
+// image height; fewest rounds of `slots` concurrent workgroups wins, ties go to the smaller staged halo (= fewer GEMM-1 rows)
+bool h3b_pick_tile(int B, int H, int W, long long slots, int* th, int* tw) {
+  constexpr int BM = 256, HPMAX = 320;
+  long long best = -1;
+  for (int d = 1; d <= 16 && d <= W; ++d) {
+    const int TW = (W + d - 1) / d;
+    if (TW > BM || TW + 2 > 255) continue;
+    int thm = BM / TW < H ? BM / TW : H;
+    while (thm >= 1 && (thm + 2) * (TW + 2) > HPMAX) --thm;
+    if (thm < 1) continue;
+    if (thm + 2 > 255) thm = 253;
+    const int nth = (H + thm - 1) / thm;
+    const int TH = (H + nth - 1) / nth;
+    const int ntw = (W + TW - 1) / TW;
+    const long long tiles = (long long)B * nth * ntw;
+    const long long rounds = (tiles + slots - 1) / slots;
+    const long long cost = rounds * (1LL << 32) + (long long)(TH + 2) * (TW + 2) * nth * ntw;
+    if (best < 0 || cost < best) { best = cost; *th = TH; *tw = TW; }
+  }
+  return best >= 0;
+}
+
+template <int NSW>
+int launch_h3b(Y5H3bParams p, int max_blocks, hipStream_t stream) {
+  using Gm = Y5H3bGeom<NSW>;
+  auto kern = y5_conv_h3b_kernel<NSW>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  long long G = max_blocks;
+  if (G <= 0) {
+    static int num_cu = 0;
+    if (!num_cu) {
+      int dev = 0, n = 0;
+      hipGetDevice(&dev);
+      hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+      num_cu = n > 0 ? n : 256;
+    }
+    G = num_cu;   // 145 KB of LDS: one workgroup per CU
+  }
+  if (!h3b_pick_tile(p.B, p.H, p.W, G, &p.th, &p.tw)) return y5_fail(Y5_ERR_UNSUPPORTED, "bottleneck: no spatial tile fits the 320-pixel halo");
+  p.tiles_h = (p.H + p.th - 1) / p.th;
+  p.tiles_w = (p.W + p.tw - 1) / p.tw;
+  const long long ntiles = (long long)p.B * p.tiles_h * p.tiles_w;
+  if (ntiles <= 0 || ntiles > 0x7fffffffLL) return y5_fail(Y5_ERR_BAD_ARG, "bottleneck: grid out of range");
+  if (G > ntiles) G = ntiles;
+  if (G >= 8) G &= ~7LL;
+  hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(Gm::NW * 64), Gm::LDS, stream, p);
+  return y5_check_launch("y5_bottleneck_fwd(h3b)");
+}
 }  // namespace
 
 extern "C" int y5_bottleneck_fwd(const void* x, int ldx, const void* w1_packed, const float* bias1, int Kpad1, const void* w2_packed,
                                  const float* bias2, int Kpad2, void* y, int ldy, int B, int H, int W, int C, int add, int max_blocks,
                                  void* stream_) {
   if (!x || !w1_packed || !bias1 || !w2_packed || !bias2 || !y) return y5_fail(Y5_ERR_BAD_ARG, "bottleneck: null pointer");
-  if (C != 32 && C != 64) return y5_fail(Y5_ERR_UNSUPPORTED, "bottleneck: fused kernel exists for 32 and 64 channels");
-  if (B < 1 || H < 4 || W < 8 || (H & 3) || (W & 7) || H > 255 * 4 || W > 65535) return y5_fail(Y5_ERR_UNSUPPORTED, "bottleneck: needs H % 4 == 0 and W % 8 == 0");
+  if (C != 32 && C != 64 && C != 128) return y5_fail(Y5_ERR_UNSUPPORTED, "bottleneck: fused kernel exists for 32, 64 and 128 channels");
+  if (C != 128 && (B < 1 || H < 4 || W < 8 || (H & 3) || (W & 7) || H > 255 * 4 || W > 65535))
+    return y5_fail(Y5_ERR_UNSUPPORTED, "bottleneck: needs H % 4 == 0 and W % 8 == 0");
+  if (C == 128 && (B < 1 || H < 1 || W < 1 || H > 65535 || W > 65535)) return y5_fail(Y5_ERR_UNSUPPORTED, "bottleneck: bad image size");
   if ((ldx & 7) || (ldy & 7) || ldx < C || ldy < C || Kpad1 < C || (Kpad1 & 7) || Kpad2 < 9 * C || (Kpad2 & 7))
     return y5_fail(Y5_ERR_BAD_ARG, "bottleneck: bad strides / packed filter dims");
   if (((uintptr_t)x | (uintptr_t)w1_packed | (uintptr_t)bias1 | (uintptr_t)w2_packed | (uintptr_t)bias2 | (uintptr_t)y) & 15)
@@ -66,6 +124,15 @@ extern "C" int y5_bottleneck_fwd(const void* x, int ldx, const void* w1_packed, 
   hipStream_t st = static_cast<hipStream_t>(stream_);
   const int stages = max_blocks >> 16;      // bits 16.. of max_blocks select the ring depth (0 = default for C), bits 0..15 the grid cap
   max_blocks &= 0xffff;
+  if (C == 128) {   // conv_h3b.h: 1x1 as a GEMM-1 phase of the halo-resident 3x3; stages = depth of the 3x3 filter ring (4 default, 5)
+    Y5H3bParams q{};
+    q.x = x; q.w1 = w1_packed; q.w2 = w2_packed; q.b1 = bias1; q.b2 = bias2; q.y = y;
+    q.x_bytes = p.x_bytes; q.w1_bytes = p.w1_bytes; q.w2_bytes = p.w2_bytes;
+    q.B = B; q.H = H; q.W = W; q.ldx = ldx; q.ldy = ldy; q.Kpad1 = Kpad1; q.Kpad2 = Kpad2; q.add = add;
+    if (stages == 0 || stages == 4) return launch_h3b<4>(q, max_blocks, st);
+    if (stages == 5) return launch_h3b<5>(q, max_blocks, st);
+    return y5_fail(Y5_ERR_UNSUPPORTED, "bottleneck: unsupported number of stages");
+  }
   const int S = stages > 0 ? stages : 1;  // measured (scripts/bneck_bench.py): resident waves beat prefetch depth -- 1 stage, 3 workgroups per CU
   if (C == 32) {
     if (S == 1) return add ? launch_bneck<32, 1, true>(p, max_blocks, st) : launch_bneck<32, 1, false>(p, max_blocks, st);

@@ -1,0 +1,396 @@
+// Fused Bottleneck at c_ = 128 (models/common.py:164-181 inside C3, :230-246; yolov5s: 6.C3.m0-2, 13.C3.m0, 20.C3.m0 at 40 x 40):
+//     y = [x +] SiLU(W2 (*) SiLU(W1 x + b1) + b2),   cv1 = 1x1 128 -> 128, cv2 = 3x3 pad 1 128 -> 128 (BN folded)
+// as ONE launch built on the halo-resident 3x3 kernel (conv_h3.h).  What the two-launch form pays for -- the 1x1's output t written to HBM
+// and read back 1.3x (halo), one kernel boundary -- becomes a GEMM-1 phase in front of the 3x3 loop:
+//   * a workgroup owns a TH x TW spatial tile of one image; the (TH+2) x (TW+2) halo of ALL 128 channels lives in LDS as four 32-channel
+//     planes (HPMAX = 320 halo pixels x 64 B = 20 KB each; conv_h3.h layout: 16-byte slots XOR-swizzled on the source side);
+//   * phase 1: the planes hold the x halo (LDS-DMA straight from the NHWC tensor, out-of-image pixels zero-filled); t = W1 x for every halo pixel
+//     (<= 10 row blocks x 4 channel blocks of 32 x 32, K = 128: 5-6 accumulator blocks per wave) with W1 resident in LDS for the whole launch
+//     (32 KB, loaded once per workgroup); after a barrier SiLU(t + b1) is written OVER the x halo as fp16 -- exactly the bytes the unfused 1x1 would
+//     have stored -- with out-of-image halo pixels forced to 0 (the 3x3's zero padding applies to t, not to x);
+//   * phase 2: conv_h3.h's software-pipelined tap loop over the resident planes -- only the 3x3 filter streams (NSW-stage ring of 8 KB slices,
+//     counted vmcnt, one barrier per (tap, chunk) step);
+//   * the NEXT tile's x halo streams into a plane as soon as the loop has finished with it (plane cc-1 during chunk cc, the last plane behind the
+//     loop), so phase 1 of the next tile never waits for HBM; the residual is re-read from x (L2-hot: this workgroup fetched it one tile ago) in the
+//     epilogue, whose transposition scratch aliases the idle filter ring.
+// LDS: 80 KB planes + NSW x 8 KB ring + 32 KB W1 + 1 KB dummy = 145 KB (NSW = 4): one workgroup of eight waves per CU.
+// Halo recompute of the 1x1: (TH+2)(TW+2) / (TH TW) = 1.32x of a GEMM that is 1/9 of the 3x3's work.
+#pragma once
+#include "conv_h3.h"
+
+struct Y5H3bParams {
+  const void* x;            // (B, H, W, >= 128 channels) NHWC slice, pixel stride ldx
+  const void* w1;           // [128][Kpad1] fp16, k = c
+  const void* w2;           // [128][Kpad2] fp16, k = (kh, kw, c)
+  const float* b1; const float* b2;
+  void* y;                  // NHWC slice, pixel stride ldy; must not overlap x
+  unsigned x_bytes, w1_bytes, w2_bytes;
+  int B, H, W, ldx, ldy, Kpad1, Kpad2, add;
+  int th, tw, tiles_h, tiles_w;
+};
+
+template <int NSW_>
+struct Y5H3bGeom {
+  static constexpr int C = 128, NCC = 4, NW = 8, WN = 2, TM = 2, TN = 2, HPMAX = 320;
+  static constexpr int NAI_MAX = HPMAX / 16, PLANE = NAI_MAX * 1024;   // 20 pieces of 16 halo pixels x 64 B
+  static constexpr int W_STAGE = C * 64, NSW = NSW_, WIN = NSW - 3;
+  static constexpr int APS = (NAI_MAX + NW - 1) / NW, PPS = (APS + 1) / 2;   // halo pieces per wave per plane; issued in tap 0 / tap 1
+  static constexpr int NSTEP = NCC * 9;
+  static constexpr int NRB1 = 3;                                        // GEMM-1 row blocks per wave (rows wm + 4 i)
+  static constexpr int SCR_ROWB = 32 * 2 + 16, SCR_BYTES = 32 * SCR_ROWB;
+  static constexpr size_t OFF_RING = (size_t)NCC * PLANE, OFF_W1 = OFF_RING + (size_t)NSW * W_STAGE, OFF_DUMMY = OFF_W1 + (size_t)C * C * 2;
+  static constexpr size_t LDS = OFF_DUMMY + 1024;
+  static_assert(NW * SCR_BYTES <= NSW * W_STAGE, "epilogue scratch must fit into the filter ring");
+  static_assert(NSW >= 4 && NSW <= 9 && LDS <= 160 * 1024, "ring depth");
+  // pieces of the next tile's halo a wave issues in tap t of any chunk
+  static constexpr int xi(int t) { return t == 0 ? PPS : t == 1 ? APS - PPS : 0; }
+  // LDS-DMA instructions a wave may still have in flight at the barrier of (chunk, tap t): everything issued in the WIN steps before it.
+  // Filter slices: one per step while a slice NSW-1 steps ahead exists (always before the last chunk; taps <= 9 - NSW inside it; the ring prologue
+  // counts as the NSW-1 steps in front of the loop); halo pieces: taps 0 and 1 of the current chunk.
+  static constexpr int allowed(int t, bool last) {
+    int n = 0;
+    for (int u = t - WIN; u <= t - 1; ++u) {
+      n += (!last || u <= 9 - NSW) ? 1 : 0;
+      if (u >= 0) n += xi(u);
+    }
+    return n;
+  }
+};
+
+template <int NSW_>
+__global__ __launch_bounds__(512, 1)
+void y5_conv_h3b_kernel(const Y5H3bParams p) {
+  typedef half_t T;
+  using Gm = Y5H3bGeom<NSW_>;
+  constexpr int NW = Gm::NW, TM = Gm::TM, TN = Gm::TN, NSW = Gm::NSW, APS = Gm::APS, PLANE = Gm::PLANE, W_STAGE = Gm::W_STAGE;
+  constexpr int SCR_ROWB = Gm::SCR_ROWB, NRB1 = Gm::NRB1;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const a_lds = smem;                    // four planes: x halo, then t halo
+  char* const w_lds = smem + Gm::OFF_RING;     // 3x3 filter ring; the epilogue's transposition scratch between two tiles
+  char* const w1_lds = smem + Gm::OFF_W1;      // 1x1 filter, four 32-channel slices of [128 rows][64 B]
+  char* const dummy = smem + Gm::OFF_DUMMY;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int g = lane >> 5, frow = lane & 31;
+  char* const scratch = w_lds + wave * Gm::SCR_BYTES;
+
+  const int TH = p.th, TW = p.tw, HW = TW + 2;
+  const int HP = (TH + 2) * HW;
+  const int NAI = (HP + 15) >> 4;
+  const int NRB = (HP + 31) >> 5;
+
+  const y5_rsrc_t xrs = y5_make_rsrc(p.x, p.x_bytes);
+  const y5_rsrc_t w1rs = y5_make_rsrc(p.w1, p.w1_bytes);
+  const y5_rsrc_t w2rs = y5_make_rsrc(p.w2, p.w2_bytes);
+
+  // ---- per-lane constants ------------------------------------------------------------------------------------------------------
+  // (a) halo pieces this wave stages per plane: instruction I = k * NW + wave covers 16 halo pixels x 4 slots
+  int a_rel[APS], a_rc[APS];
+#pragma unroll
+  for (int k = 0; k < APS; ++k) {
+    const int idx = (k * NW + wave) * 64 + lane;
+    const int hp = idx >> 2, ds = idx & 3;
+    const int ss = ds ^ ((hp >> 2) & 3);
+    const int hr = hp / HW, hc = hp - hr * HW;
+    a_rel[k] = ((hr * p.W + hc) * p.ldx) * 2 + ss * 16;
+    a_rc[k] = hr | (hc << 8) | ((hp < HP ? 1 : 0) << 16);
+  }
+  // (b) 3x3 fragment reads: lane (pixel row frow of block i, k-half g) -> halo pixel of tap (0, 0); filter row of block j
+  int hp0[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = (wm * TM + i) * 32 + frow;
+    const int r = m / TW, c = m - r * TW;
+    hp0[i] = r < TH ? r * HW + c : 0;
+  }
+  const int fsw = (frow >> 2) & 3;
+  int w_rd[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) w_rd[j] = ((wn * TN + j) * 32 + frow) * 64 + ((g ^ fsw) << 4);
+  // (c) epilogue store rows: lane -> tile pixel (pass ps, row ps*16 + lane/4), 16-byte vector lane%4 of the 32 channels
+  int o_rc[TM][2];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int m = (wm * TM + i) * 32 + ps * 16 + (lane >> 2);
+      const int r = m / TW, c = m - r * TW;
+      o_rc[i][ps] = r < TH ? (r | (c << 16)) : -1;
+    }
+  // (d) GEMM 1: this wave's halo-pixel row blocks wm + 4 i; lane -> halo pixel (row, column) for the in-image test of the t store
+  int g1_rc[NRB1];
+#pragma unroll
+  for (int i = 0; i < NRB1; ++i) {
+    const int hp = (wm + 4 * i) * 32 + frow;
+    const int hr = hp / HW, hc = hp - hr * HW;
+    g1_rc[i] = hr | (hc << 8) | ((hp < HP ? 1 : 0) << 16);
+  }
+  // (e) filter pieces: one 16-row piece per wave per slice (3x3 ring) / per 32-channel slice of W1
+  unsigned w2_off, w1_off;
+  {
+    const int row = wave * 16 + (lane >> 2);
+    const int ss = (lane & 3) ^ ((row >> 2) & 3);
+    w2_off = (unsigned)(row * p.Kpad2 * 2 + ss * 16);
+    w1_off = (unsigned)(row * p.Kpad1 * 2 + ss * 16);
+  }
+
+  // ---- tile schedule -----------------------------------------------------------------------------------------------------------
+  const int G = gridDim.x, bid = blockIdx.x;
+  const int ntiles = p.B * p.tiles_h * p.tiles_w;
+  const int nmine = (ntiles - bid + G - 1) / G;
+  if (nmine <= 0) return;
+  auto tile_coords = [&](int j, int& b, int& oh0, int& ow0) {
+    const int t = y5_xcd_remap(bid + j * G, ntiles);
+    const int tx = t % p.tiles_w, q = t / p.tiles_w;
+    const int ty = q % p.tiles_h;
+    b = q / p.tiles_h;
+    oh0 = ty * TH;
+    ow0 = tx * TW;
+  };
+
+  // ---- loader state of the tile whose x halo is being staged -----------------------------------------------------------------------
+  int s_base = 0, s_ih0 = 0, s_iw0 = 0;
+  bool s_valid = false;
+  auto x_setup = [&](int j) {
+    s_valid = j < nmine;
+    if (s_valid) {
+      int b, oh0, ow0;
+      tile_coords(j, b, oh0, ow0);
+      s_ih0 = oh0 - 1;
+      s_iw0 = ow0 - 1;
+      s_base = ((b * p.H + s_ih0) * p.W + s_iw0) * p.ldx * 2;
+    }
+  };
+  auto issue_x = [&](auto kc, int cc, bool real) {  // piece k of plane cc of the staged tile; a wave without that piece issues a dummy (uniform counts)
+    constexpr int k = decltype(kc)::value;
+    const int I = k * NW + wave;
+    if (real && s_valid && I < NAI) {
+      const int ih = s_ih0 + (a_rc[k] & 0xff), iw = s_iw0 + ((a_rc[k] >> 8) & 0xff);
+      const bool ok = (a_rc[k] >> 16) != 0 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      y5_bglds16(xrs, ok ? (unsigned)(s_base + a_rel[k] + cc * 64) : Y5_OOB, a_lds + cc * PLANE + I * 1024);
+    } else {
+      y5_bglds16(xrs, Y5_OOB, dummy);
+    }
+  };
+  auto issue_w2 = [&](int stage, int s) {  // slice s = chunk * 9 + tap
+    const int cc = s / 9, tap = s - cc * 9;
+    y5_bglds16(w2rs, w2_off + (unsigned)((tap * Gm::C + cc * 32) * 2), w_lds + stage * W_STAGE + wave * 1024);
+  };
+
+  float16_t acc[TM][TN];
+  T* yg = static_cast<T*>(p.y);
+  const T* rg = p.add ? static_cast<const T*>(p.x) : nullptr;
+
+  // ---- epilogue: bias + SiLU -> per-wave LDS transpose -> (+ x) -> 16-byte row-contiguous stores ---------------------------------------
+  auto epilogue = [&](int b, int oh0, int ow0) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int nt = (wn * TN + j) * 32;
+        const float* pb = p.b2 + nt;  // scalar-cache loads (wave-uniform address)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          half4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float t = acc[i][j][q * 4 + e] + (g ? pb[q * 8 + 4 + e] : pb[q * 8 + e]);
+            o[e] = (half_t)y5_silu(t);
+          }
+          *reinterpret_cast<half4_t*>(scratch + frow * SCR_ROWB + (q * 8 + g * 4) * 2) = o;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+          const int rc = o_rc[i][ps];
+          const int oh = oh0 + (rc & 0xffff), ow = ow0 + (rc >> 16);
+          const int vs = lane & 3;
+          const int n = nt + vs * 8;
+          if (rc >= 0 && oh < p.H && ow < p.W) {
+            uint4_t raw = *reinterpret_cast<const uint4_t*>(scratch + (ps * 16 + (lane >> 2)) * SCR_ROWB + vs * 16);
+            const size_t mo = ((size_t)b * p.H + oh) * p.W + ow;
+            if (rg) {
+              const uint4_t rr = *reinterpret_cast<const uint4_t*>(rg + mo * p.ldx + n);
+              half8_t a = __builtin_bit_cast(half8_t, raw), r8 = __builtin_bit_cast(half8_t, rr), c;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) c[e] = (half_t)((float)a[e] + (float)r8[e]);
+              raw = __builtin_bit_cast(uint4_t, c);
+            }
+            *reinterpret_cast<uint4_t*>(yg + mo * p.ldy + n) = raw;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  };
+
+  // ---- launch prologue: W1 (once per workgroup) and the first tile's x halo ------------------------------------------------------------------
+#pragma unroll
+  for (int cc = 0; cc < Gm::NCC; ++cc) y5_bglds16(w1rs, w1_off + (unsigned)(cc * 64), w1_lds + cc * W_STAGE + wave * 1024);
+  x_setup(0);
+#pragma unroll
+  for (int cc = 0; cc < Gm::NCC; ++cc) y5_static_for<0, APS>([&](auto kc) { issue_x(kc, cc, true); });
+
+  for (int ti = 0; ti < nmine; ++ti) {
+    int tb, toh0, tow0;
+    tile_coords(ti, tb, toh0, tow0);
+
+    // ---- phase 1: t = SiLU(W1 x + b1) over the halo ---------------------------------------------------------------------------------------
+    y5_wait_vm<0>();      // this tile's x halo (and W1) landed
+    __syncthreads();      // ... for every wave; the previous tile's epilogue is done with the ring
+    y5_static_for<0, NSW - 1>([&](auto uc) { issue_w2(decltype(uc)::value, decltype(uc)::value); });  // 3x3 slices 0..NSW-2 fly behind GEMM 1
+    {
+      float16_t acc1[NRB1][TN];
+#pragma unroll
+      for (int i = 0; i < NRB1; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc1[i][j][r] = 0.f;
+      int a1[NRB1];
+#pragma unroll
+      for (int i = 0; i < NRB1; ++i) {
+        const int hp = (wm + 4 * i) * 32 + frow;
+        a1[i] = (hp << 6) | ((g ^ ((hp >> 2) & 3)) << 4);
+      }
+      // all three row blocks are multiplied unconditionally (a block beyond the halo reads whatever LDS holds behind it and is never stored: the
+      // barrier below waits for the waves that own three real blocks anyway); fragments of k-step s+1 are fetched while step s multiplies
+      half8_t wf1[2][TN], af1[2][NRB1];
+      auto rd1 = [&](auto sc) {
+        constexpr int s1 = decltype(sc)::value, cc = s1 >> 1, ks = s1 & 1, bf = s1 & 1;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wf1[bf][j] = *reinterpret_cast<const half8_t*>(w1_lds + cc * W_STAGE + (w_rd[j] ^ (ks * 32)));
+#pragma unroll
+        for (int i = 0; i < NRB1; ++i) af1[bf][i] = *reinterpret_cast<const half8_t*>(a_lds + cc * PLANE + (a1[i] ^ (ks * 32)));
+      };
+      rd1(std::integral_constant<int, 0>{});
+      y5_static_for<0, Gm::NCC * 2>([&](auto sc) {
+        constexpr int s1 = decltype(sc)::value, bf = s1 & 1;
+        if constexpr (s1 + 1 < Gm::NCC * 2) rd1(std::integral_constant<int, s1 + 1>{});
+#ifndef Y5_EMU
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+        for (int i = 0; i < NRB1; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf1[bf][j], af1[bf][i], acc1[i][j], 0, 0, 0);
+#ifndef Y5_EMU
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+      });
+      __syncthreads();    // every wave has read its x fragments: the planes may now take t
+#pragma unroll
+      for (int i = 0; i < NRB1; ++i) {
+        if (wm + 4 * i < NRB) {
+          const int hp = (wm + 4 * i) * 32 + frow;
+          const int ih = toh0 - 1 + (g1_rc[i] & 0xff), iw = tow0 - 1 + ((g1_rc[i] >> 8) & 0xff);
+          const bool ok = (g1_rc[i] >> 16) != 0 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+          const int sw = (hp >> 2) & 3;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int cb = wn * TN + j;
+            const float* pb = p.b1 + cb * 32;
+            char* row = a_lds + cb * PLANE + (hp << 6) + g * 8;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              half4_t o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float t = acc1[i][j][q * 4 + e] + (g ? pb[q * 8 + 4 + e] : pb[q * 8 + e]);
+                o[e] = ok ? (half_t)y5_silu(t) : (half_t)0.f;
+              }
+              *reinterpret_cast<half4_t*>(row + ((q ^ sw) << 4)) = o;
+            }
+          }
+        }
+      }
+    }
+    x_setup(ti + 1);   // from here on the loader stages the NEXT tile's x halo
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- phase 2: the 3x3 over the resident t halo (conv_h3.h's software-pipelined tap loop) ---------------------------------------------
+    half8_t af[2][TM], wf[2][TN];
+    auto frag_addr = [&](int tap, int cc_, int (&a0)[TM]) {
+      int hoff = (tap / 3) * HW + (tap % 3) + cc_ * (PLANE / 64);  // plane base in halo-pixel units (a multiple of 16: swizzle unchanged)
+#ifndef Y5_EMU
+      asm volatile("" : "+s"(hoff));
+#endif
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int hp = hp0[i] + hoff;
+        a0[i] = (hp << 6) | ((g ^ ((hp >> 2) & 3)) << 4);
+      }
+    };
+    auto read_frags = [&](auto ksc, const int (&a0)[TM], const char* wst) {
+      constexpr int ks = decltype(ksc)::value;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) wf[ks][j] = *reinterpret_cast<const half8_t*>(wst + (w_rd[j] ^ (ks * 32)));
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[ks][i] = *reinterpret_cast<const half8_t*>(a_lds + (a0[i] ^ (ks * 32)));
+    };
+    {
+      y5_wait_vm<(NSW - 2)>();   // filter slice 0 landed (slices 1..NSW-2 may still be in flight)
+      __syncthreads();           // ... and every wave's t rows are visible
+      int a0[TM];
+      frag_addr(0, 0, a0);
+      read_frags(std::integral_constant<int, 0>{}, a0, w_lds);
+      read_frags(std::integral_constant<int, 1>{}, a0, w_lds);
+    }
+    int st_cur = 0;   // ring stage of the current step's slice (step index mod NSW)
+    for (int cc = 0; cc < Gm::NCC; ++cc) {
+      const bool last = cc + 1 == Gm::NCC;
+      y5_static_for<0, 9>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int tn = (t + 1) % 9;
+        if (last) y5_wait_vm<Gm::allowed(t, true)>();
+        else y5_wait_vm<Gm::allowed(t, false)>();
+        __builtin_amdgcn_s_barrier();
+        // plane cc-1 is dead (its last fragments were consumed in the step before this chunk's tap 0): it takes the next tile's x halo
+        if constexpr (t < 2)
+          y5_static_for<t * Gm::PPS, (t + 1) * Gm::PPS < APS ? (t + 1) * Gm::PPS : APS>([&](auto kc) { issue_x(kc, cc - 1, cc > 0); });
+        // slice s + NSW - 1 goes into the stage slice s - 1 occupied (every wave finished reading it before this barrier)
+        const int st_prev = st_cur == 0 ? NSW - 1 : st_cur - 1;
+        if (!last || t <= 9 - NSW) issue_w2(st_prev, cc * 9 + t + NSW - 1);
+        const int st_next = st_cur == NSW - 1 ? 0 : st_cur + 1;
+        const bool more = t < 8 || !last;  // a step s+1 exists in this tile
+        int a0[TM];
+        if (more) frag_addr(tn, t == 8 ? cc + 1 : cc, a0);
+        const char* wst = w_lds + st_next * W_STAGE;
+        y5_static_for<0, 2>([&](auto ksc) {
+          constexpr int ks = decltype(ksc)::value;
+#ifndef Y5_EMU
+          __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+#ifndef Y5_EMU
+          __builtin_amdgcn_sched_barrier(0);
+#endif
+          if (more) read_frags(ksc, a0, wst);
+        });
+#ifndef Y5_EMU
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        st_cur = st_next;
+      });
+    }
+    __syncthreads();  // every wave is done with the ring and with the last plane
+    y5_static_for<0, APS>([&](auto kc) { issue_x(kc, Gm::NCC - 1, true); });  // the next tile's last plane flies during the epilogue
+    epilogue(tb, toh0, tow0);
+  }
+}

@@ -100,7 +100,7 @@ template <int N> __device__ __forceinline__ void y5_wait_vm() {
 // drain the vector-memory queue with an instruction the compiler can neither drop nor merge (the guide's split-K recipe: hipcc's
 // scoreboard removes a builtin wait it believes redundant, e.g. behind a fence)
 #ifdef Y5_EMU
-#define Y5_DRAIN_VM() ((void)0)
+#define Y5_DRAIN_VM() emu::dma_wait(0)
 #else
 #define Y5_DRAIN_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif

@@ -128,8 +128,10 @@ class _Planner:
     def _bneck_fusable(self, m, c_, x):
         # c_ = 32: four waves, stage + t (conv_bneck.h); c_ = 64 (round 4): eight waves with t aliased onto the stage -- Y5_FUSED_BNECK64 = 0 keeps
         # the two-launch form there
-        ok_c = c_ == 32 or (c_ == 64 and os.environ.get("Y5_FUSED_BNECK64", "1") != "0")
-        if not self.fuse_bneck or not ok_c or x.H % 4 or x.W % 8 or not len(m.m):
+        # c_ = 128 (round 5): the 1x1 as a GEMM-1 phase of the halo-resident 3x3 (conv_h3b.h), any H x W -- Y5_FUSED_BNECK128 = 0 keeps two launches
+        ok_c = (c_ == 32 or (c_ == 64 and os.environ.get("Y5_FUSED_BNECK64", "1") != "0")
+                or (c_ == 128 and os.environ.get("Y5_FUSED_BNECK128", "1") != "0"))
+        if not self.fuse_bneck or not ok_c or (c_ != 128 and (x.H % 4 or x.W % 8)) or not len(m.m):
             return False
         for b in m.m:
             c1, c2 = b.cv1.conv, b.cv2.conv
