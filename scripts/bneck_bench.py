@@ -20,7 +20,9 @@ def timeit(fn, iters=30):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 
-for (Cc, HW, B) in ((32, 160, 64), (64, 80, 64)):
+import os as _os
+SHAPES = ((128, 40, 64),) if _os.environ.get("BNECK_ONLY128") else ((32, 160, 64), (64, 80, 64), (128, 40, 64))
+for (Cc, HW, B) in SHAPES:
     torch.manual_seed(0)
     w1 = torch.randn(Cc, Cc, 1, 1) * (2.0 / Cc) ** 0.5; b1 = torch.randn(Cc) * 0.1
     w2 = torch.randn(Cc, Cc, 3, 3) * (2.0 / (9 * Cc)) ** 0.5; b2 = torch.randn(Cc) * 0.1
@@ -50,7 +52,8 @@ for (Cc, HW, B) in ((32, 160, 64), (64, 80, 64)):
     _lib.check(lib.y5_conv2d_fwd(C.byref(d2o), vp(tmp), vp(w2p), vp(b2p), vp(cat), vp(ref), None, st), lib)
     torch.cuda.synchronize()
     err = (out.float() - ref.float()).abs().max().item()
-    for mb in (0,) + tuple(g | (S << 16) for S in ((1, 2, 3) if Cc == 32 else (1,)) for g in (256, 512, 768)):
+    mbs = (0, 4 << 16, 5 << 16, 128) if Cc == 128 else (0,) + tuple(g | (S << 16) for S in ((1, 2, 3) if Cc == 32 else (1,)) for g in (256, 512, 768))
+    for mb in mbs:
         f2 = lambda: _lib.check(lib.y5_bottleneck_fwd(vp(cat), 2 * Cc, vp(w1p), vp(b1p), K1, vp(w2p), vp(b2p), K2, vp(out), Cc, B, HW, HW, Cc, 1, mb, st), lib)
         print(f"C={Cc} {HW}^2 bs={B}: fused (stages {mb >> 16}, grid cap {mb & 0xffff}) {timeit(f2):.1f} us")
     print(f"C={Cc} {HW}^2 bs={B}: two launches (cfg {d1.cfg} + {d2.cfg}) {timeit(two):.1f} us; max|fused - two-op| = {err:.4f}")

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Round 5, GPU call 1: fused Bottleneck at c_ = 128 (conv_h3b.h) -- C-ABI parity at the benchmarked shape, isolated timing against the two launches it
+# replaces, same-box bench A/B (Y5_FUSED_BNECK128 = 0 / 1, alternating arms, shared tune cache per arm).
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
+O=gpurun_out/r05_run2; rm -rf $O; mkdir -p $O
+timeout 600 python -m pytest tests/test_gpu_parity.py -q -x -k "c128 or bneck128" > $O/pytest_h3b.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_h3b.log; tail -5 $O/pytest_h3b.log
+BNECK_ONLY128=1 timeout 300 python scripts/bneck_bench.py > $O/bneck_bench.log 2>&1; tail -6 $O/bneck_bench.log
+run() { tag=$1; shift; env "$@" timeout 400 python bench.py --no-cpu-baseline --no-train --no-configs --no-pipeline --no-selfcheck --op-table $O/op_$tag.json 2>$O/bench_$tag.err | grep '^{' > $O/bench_$tag.json; python -c "
+import json,sys
+d=json.loads(open('$O/bench_$tag.json').read()); print('$tag', d['value'], d['ms_per_step'], d['forward_ms'], d['roofline'].get('stack_frac'))"; }
+run off1 Y5_FUSED_BNECK128=0 Y5_TUNE_CACHE=/tmp/tc_off.json
+run on1 Y5_FUSED_BNECK128=1 Y5_TUNE_CACHE=/tmp/tc_on.json
+run off2 Y5_FUSED_BNECK128=0 Y5_TUNE_CACHE=/tmp/tc_off.json
+run on2 Y5_FUSED_BNECK128=1 Y5_TUNE_CACHE=/tmp/tc_on.json
+timeout 900 python -m pytest tests/test_gpu_train.py -q -x -s -k benchmarked_train_plan > $O/pytest_trainplan.log 2>&1; echo "trainplan rc=$?"; grep -E "train plan parity|passed|failed|Error|assert" $O/pytest_trainplan.log | cut -c1-600 | head -20

@@ -624,3 +624,68 @@ def test_plan_bneck_cv3_fused_equals_unfused_on_gpu(dev, monkeypatch):
         assert any(n.startswith("bneck+cv3:") for n in eng.op_names) == (mode == "1"), eng.op_names
     u, v = outs["0"], outs["1"]
     assert float((u - v).abs().max()) <= 4e-3 * max(1.0, float(u.abs().max()))
+
+
+@pytest.mark.parametrize("B,H,W,add,ldx,ldy,mb", [(8, 40, 40, True, 256, 128, 0), (8, 40, 40, False, 128, 256, 5 << 16), (3, 23, 37, True, 128, 128, 8),
+                                                  (64, 40, 40, True, 256, 256, 0), (2, 80, 80, True, 128, 128, 16 | (5 << 16))])
+def test_fused_bottleneck_c128_matches_torch(B, H, W, add, ldx, ldy, mb, dev):
+    """y5_bottleneck_fwd at C = 128 (csrc/conv_h3b.h: GEMM-1 phase + halo-resident 3x3 + residual, models/common.py:164-181) through the C-ABI against
+    torch fp32 on the same fp16 operands (t rounded to fp16 as the two-launch form stores it); bs = 64 at 40 x 40 is the benchmarked shape
+    (two tiles per workgroup: next-tile halo prefetch into dead planes), mb caps the grid so that workgroups walk many tiles."""
+    import ctypes as C
+
+    import torch.nn.functional as F
+
+    from yolov5_amd import _lib
+    from yolov5_amd.packing import pack_conv_weight
+
+    lib = _lib.lib()
+    Cc = 128
+    g = torch.Generator().manual_seed(B * 100 + H)
+    w1 = torch.randn((Cc, Cc, 1, 1), generator=g) * (2.0 / Cc) ** 0.5
+    w2 = torch.randn((Cc, Cc, 3, 3), generator=g) * (2.0 / (9 * Cc)) ** 0.5
+    b1, b2 = torch.randn(Cc, generator=g) * 0.3, torch.randn(Cc, generator=g) * 0.3
+    w1p, b1p, _, K1, _ = pack_conv_weight(w1, b1, torch.float16)
+    w2p, b2p, _, K2, _ = pack_conv_weight(w2, b2, torch.float16)
+    w1p, b1p, w2p, b2p = (t.to(dev) for t in (w1p, b1p, w2p, b2p))
+    xbuf = torch.randn((B, H, W, ldx), generator=g).half().to(dev)
+    ybuf = torch.full((B, H, W, ldy), 7.0, dtype=torch.float16, device=dev)
+    st = _lib.stream(dev)
+    vp = lambda t, off=0: C.c_void_p(t.data_ptr() + off)  # noqa: E731
+    rc = lib.y5_bottleneck_fwd(vp(xbuf, (ldx - Cc) * 2), ldx, vp(w1p), vp(b1p), K1, vp(w2p), vp(b2p), K2, vp(ybuf), ldy, B, H, W, Cc, int(add), mb, st)
+    _lib.check(rc, lib)
+    torch.cuda.synchronize()
+    xf = xbuf[..., ldx - Cc:].float().permute(0, 3, 1, 2)
+    t = F.silu(F.conv2d(xf, w1.half().float().to(dev), b1.to(dev))).half().float()
+    ref = F.silu(F.conv2d(t, w2.half().float().to(dev), b2.to(dev), padding=1)).half().float()
+    if add:
+        ref = (ref + xf).half().float()
+    ref = ref.permute(0, 2, 3, 1)
+    got = ybuf[..., :Cc].float()
+    # torch's GPU conv is a second implementation, not the truth: spot-check a slab against torch-CPU fp32 as well
+    cpu = F.silu(F.conv2d(F.silu(F.conv2d(xf[:1].cpu(), w1.half().float(), b1)).half().float(), w2.half().float(), b2, padding=1)).half().float()
+    if add:
+        cpu = (cpu + xf[:1].cpu()).half().float()
+    assert float((got[:1].cpu() - cpu.permute(0, 2, 3, 1)).abs().max()) <= 8e-3
+    assert float((got - ref).abs().max()) <= 8e-3, float((got - ref).abs().max())
+    assert bool((ybuf[..., Cc:] == 7).all())
+
+
+def test_plan_bneck128_fused_equals_unfused_on_gpu(dev, monkeypatch):
+    """yolov5s 8 x 3 x 640 x 640 fp16: the 128-channel Bottlenecks of 6 / 13 / 20.C3 as conv_h3b.h launches against the two-launch plan."""
+    from yolov5_amd.yolo import DetectionModel
+
+    cfg = yo.model_cfg("yolov5s")
+    sd = yo.det_state_dict(cfg, 0, fused=False)
+    x = torch.from_numpy(detgen.uniform((8, 3, 640, 640), 0.0, 1.0, name="img", seed=1)).half().to(dev)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("Y5_FUSED_BNECK128", mode)
+        m = DetectionModel("yolov5s.yaml")
+        m.load_state_dict(sd)
+        m = m.eval().fuse().half().to(dev)
+        outs[mode] = m(x)[0].float().cpu()
+        eng = next(iter(m._engines.values()))
+        assert sum(n.startswith(("bneck:6.", "bneck:13.", "bneck:20.")) for n in eng.op_names) == (5 if mode == "1" else 0), eng.op_names
+    u, v = outs["0"], outs["1"]
+    assert float((u - v).abs().max()) <= 4e-3 * max(1.0, float(u.abs().max()))

@@ -13,7 +13,8 @@
 //   * the NEXT tile's x halo streams into a plane as soon as the loop has finished with it (plane cc-1 during chunk cc, the last plane behind the
 //     loop), so phase 1 of the next tile never waits for HBM; the residual is re-read from x (L2-hot: this workgroup fetched it one tile ago) in the
 //     epilogue, whose transposition scratch aliases the idle filter ring.
-// LDS: 80 KB planes + NSW x 8 KB ring + 32 KB W1 + 1 KB dummy = 145 KB (NSW = 4): one workgroup of eight waves per CU.
+// LDS: 80 KB planes + 9 x 8 KB ring (W1 streamed through four of its stages between tiles) + 1 KB dummy = 153 KB; with a resident W1 (32 KB) the
+// ring has 4-5 stages (145 / 153 KB).  One workgroup of eight waves per CU.
 // Halo recompute of the 1x1: (TH+2)(TW+2) / (TH TW) = 1.32x of a GEMM that is 1/9 of the 3x3's work.
 #pragma once
 #include "conv_h3.h"
@@ -38,10 +39,19 @@ struct Y5H3bGeom {
   static constexpr int NSTEP = NCC * 9;
   static constexpr int NRB1 = 3;                                        // GEMM-1 row blocks per wave (rows wm + 4 i)
   static constexpr int SCR_ROWB = 32 * 2 + 16, SCR_BYTES = 32 * SCR_ROWB;
-  static constexpr size_t OFF_RING = (size_t)NCC * PLANE, OFF_W1 = OFF_RING + (size_t)NSW * W_STAGE, OFF_DUMMY = OFF_W1 + (size_t)C * C * 2;
-  static constexpr size_t LDS = OFF_DUMMY + 1024;
-  static_assert(NW * SCR_BYTES <= NSW * W_STAGE, "epilogue scratch must fit into the filter ring");
-  static_assert(NSW >= 4 && NSW <= 9 && LDS <= 160 * 1024, "ring depth");
+  // W1 (32 KB): resident behind a short ring (NSW <= 5), or -- so that the ring can be as deep as conv_h3.h's (NSW = 9: slices issued eight steps
+  // ahead; with two steps of lead a one-workgroup-per-CU loop waits on L2 latency, profiles/r05/r05_ab_h3b_v1.log) -- STREAMED per tile into ring
+  // stages W1_ST0..W1_ST0+3, which are idle between the last tap of a tile and the end of the next tile's GEMM 1; the epilogue's scratch keeps
+  // stages 0..W1_ST0-1
+  static constexpr bool W1RES = NSW <= 5;
+  static constexpr int W1_ST0 = 3, PRE0 = W1RES ? NSW - 1 : W1_ST0;      // ring slices issued in front of GEMM 1 (the rest of the first NSW-1 behind it)
+  static constexpr size_t OFF_RING = (size_t)NCC * PLANE;
+  static constexpr size_t OFF_W1 = W1RES ? OFF_RING + (size_t)NSW * W_STAGE : OFF_RING + (size_t)W1_ST0 * W_STAGE;
+  static constexpr size_t OFF_DUMMY = OFF_RING + (size_t)NSW * W_STAGE + (W1RES ? (size_t)C * C * 2 : 0);
+  static constexpr size_t OFF_BIAS = OFF_DUMMY + 1024;   // b1, b2 as fp32 (1 KB): per-lane ds_read_b128 instead of 16 global loads per accumulator block
+  static constexpr size_t LDS = OFF_BIAS + 2 * C * 4;
+  static_assert(NW * SCR_BYTES <= (W1RES ? NSW : W1_ST0) * W_STAGE, "epilogue scratch must fit into the filter ring (in front of the streamed W1)");
+  static_assert(NSW >= 4 && NSW <= 9 && (W1RES || NSW >= W1_ST0 + 5) && LDS <= 160 * 1024, "ring depth");
   // pieces of the next tile's halo a wave issues in tap t of any chunk
   static constexpr int xi(int t) { return t == 0 ? PPS : t == 1 ? APS - PPS : 0; }
   // LDS-DMA instructions a wave may still have in flight at the barrier of (chunk, tap t): everything issued in the WIN steps before it.
@@ -57,6 +67,13 @@ struct Y5H3bGeom {
   }
 };
 
+#ifdef Y5_H3B_TIMING   // kernel-experiment builds only (scripts/h3b_timing.py): s_memrealtime (100 MHz) at the phase boundaries of the first four tiles
+__device__ unsigned long long y5_h3b_stamps[512 * 4 * 8];
+#define Y5_H3B_STAMP(k) do { if (tid == 0 && blockIdx.x < 512 && ti < 4) y5_h3b_stamps[(blockIdx.x * 4 + ti) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define Y5_H3B_STAMP(k) ((void)0)
+#endif
+
 template <int NSW_>
 __global__ __launch_bounds__(512, 1)
 void y5_conv_h3b_kernel(const Y5H3bParams p) {
@@ -70,6 +87,7 @@ void y5_conv_h3b_kernel(const Y5H3bParams p) {
   char* const w_lds = smem + Gm::OFF_RING;     // 3x3 filter ring; the epilogue's transposition scratch between two tiles
   char* const w1_lds = smem + Gm::OFF_W1;      // 1x1 filter, four 32-channel slices of [128 rows][64 B]
   char* const dummy = smem + Gm::OFF_DUMMY;
+  float* const bias_lds = reinterpret_cast<float*>(smem + Gm::OFF_BIAS);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -192,15 +210,12 @@ void y5_conv_h3b_kernel(const Y5H3bParams p) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int nt = (wn * TN + j) * 32;
-        const float* pb = p.b2 + nt;  // scalar-cache loads (wave-uniform address)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+          const float4_t bq = *reinterpret_cast<const float4_t*>(bias_lds + Gm::C + nt + q * 8 + g * 4);
           half4_t o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float t = acc[i][j][q * 4 + e] + (g ? pb[q * 8 + 4 + e] : pb[q * 8 + e]);
-            o[e] = (half_t)y5_silu(t);
-          }
+          for (int e = 0; e < 4; ++e) o[e] = (half_t)y5_silu(acc[i][j][q * 4 + e] + bq[e]);
           *reinterpret_cast<half4_t*>(scratch + frow * SCR_ROWB + (q * 8 + g * 4) * 2) = o;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -231,8 +246,15 @@ void y5_conv_h3b_kernel(const Y5H3bParams p) {
   };
 
   // ---- launch prologue: W1 (once per workgroup) and the first tile's x halo ------------------------------------------------------------------
+  auto issue_w1 = [&]() {
 #pragma unroll
-  for (int cc = 0; cc < Gm::NCC; ++cc) y5_bglds16(w1rs, w1_off + (unsigned)(cc * 64), w1_lds + cc * W_STAGE + wave * 1024);
+    for (int cc = 0; cc < Gm::NCC; ++cc) y5_bglds16(w1rs, w1_off + (unsigned)(cc * 64), w1_lds + cc * W_STAGE + wave * 1024);
+  };
+  if (tid < Gm::C) {   // (visible to every wave behind the first tile's barrier)
+    bias_lds[tid] = p.b1[tid];
+    bias_lds[Gm::C + tid] = p.b2[tid];
+  }
+  issue_w1();
   x_setup(0);
 #pragma unroll
   for (int cc = 0; cc < Gm::NCC; ++cc) y5_static_for<0, APS>([&](auto kc) { issue_x(kc, cc, true); });
@@ -242,9 +264,11 @@ void y5_conv_h3b_kernel(const Y5H3bParams p) {
     tile_coords(ti, tb, toh0, tow0);
 
     // ---- phase 1: t = SiLU(W1 x + b1) over the halo ---------------------------------------------------------------------------------------
+    Y5_H3B_STAMP(0);
     y5_wait_vm<0>();      // this tile's x halo (and W1) landed
     __syncthreads();      // ... for every wave; the previous tile's epilogue is done with the ring
-    y5_static_for<0, NSW - 1>([&](auto uc) { issue_w2(decltype(uc)::value, decltype(uc)::value); });  // 3x3 slices 0..NSW-2 fly behind GEMM 1
+    Y5_H3B_STAMP(1);
+    y5_static_for<0, Gm::PRE0>([&](auto uc) { issue_w2(decltype(uc)::value, decltype(uc)::value); });  // the first 3x3 slices fly behind GEMM 1
     {
       float16_t acc1[NRB1][TN];
 #pragma unroll
@@ -284,7 +308,9 @@ void y5_conv_h3b_kernel(const Y5H3bParams p) {
         __builtin_amdgcn_sched_barrier(0);
 #endif
       });
-      __syncthreads();    // every wave has read its x fragments: the planes may now take t
+      __syncthreads();    // every wave has read its x fragments: the planes may now take t (and the ring stages of a streamed W1 their slices)
+      Y5_H3B_STAMP(2);
+      y5_static_for<Gm::PRE0, NSW - 1>([&](auto uc) { issue_w2(decltype(uc)::value, decltype(uc)::value); });
 #pragma unroll
       for (int i = 0; i < NRB1; ++i) {
         if (wm + 4 * i < NRB) {
@@ -292,20 +318,18 @@ void y5_conv_h3b_kernel(const Y5H3bParams p) {
           const int ih = toh0 - 1 + (g1_rc[i] & 0xff), iw = tow0 - 1 + ((g1_rc[i] >> 8) & 0xff);
           const bool ok = (g1_rc[i] >> 16) != 0 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
           const int sw = (hp >> 2) & 3;
+          const uint32_t keep = ok ? 0xffffffffu : 0u;   // branch-free: the zero padding of the 3x3 is a bit mask on the packed pair
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
             const int cb = wn * TN + j;
-            const float* pb = p.b1 + cb * 32;
             char* row = a_lds + cb * PLANE + (hp << 6) + g * 8;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              half4_t o;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float t = acc1[i][j][q * 4 + e] + (g ? pb[q * 8 + 4 + e] : pb[q * 8 + e]);
-                o[e] = ok ? (half_t)y5_silu(t) : (half_t)0.f;
-              }
-              *reinterpret_cast<half4_t*>(row + ((q ^ sw) << 4)) = o;
+              const float4_t bq = *reinterpret_cast<const float4_t*>(bias_lds + cb * 32 + q * 8 + g * 4);
+              uint2_t o;
+              o[0] = y5_pack_h2(y5_silu(acc1[i][j][q * 4 + 0] + bq[0]), y5_silu(acc1[i][j][q * 4 + 1] + bq[1])) & keep;
+              o[1] = y5_pack_h2(y5_silu(acc1[i][j][q * 4 + 2] + bq[2]), y5_silu(acc1[i][j][q * 4 + 3] + bq[3])) & keep;
+              *reinterpret_cast<uint2_t*>(row + ((q ^ sw) << 4)) = o;
             }
           }
         }
@@ -343,6 +367,7 @@ void y5_conv_h3b_kernel(const Y5H3bParams p) {
     {
       y5_wait_vm<(NSW - 2)>();   // filter slice 0 landed (slices 1..NSW-2 may still be in flight)
       __syncthreads();           // ... and every wave's t rows are visible
+      Y5_H3B_STAMP(3);
       int a0[TM];
       frag_addr(0, 0, a0);
       read_frags(std::integral_constant<int, 0>{}, a0, w_lds);
@@ -390,7 +415,12 @@ void y5_conv_h3b_kernel(const Y5H3bParams p) {
       });
     }
     __syncthreads();  // every wave is done with the ring and with the last plane
+    Y5_H3B_STAMP(4);
     y5_static_for<0, APS>([&](auto kc) { issue_x(kc, Gm::NCC - 1, true); });  // the next tile's last plane flies during the epilogue
+    if constexpr (!Gm::W1RES) {
+      if (ti + 1 < nmine) issue_w1();   // ... and so does its W1, into the ring stages behind the scratch
+    }
     epilogue(tb, toh0, tow0);
+    Y5_H3B_STAMP(5);
   }
 }
