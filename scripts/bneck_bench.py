@@ -52,7 +52,7 @@ for (Cc, HW, B) in SHAPES:
     _lib.check(lib.y5_conv2d_fwd(C.byref(d2o), vp(tmp), vp(w2p), vp(b2p), vp(cat), vp(ref), None, st), lib)
     torch.cuda.synchronize()
     err = (out.float() - ref.float()).abs().max().item()
-    mbs = (0, 4 << 16, 5 << 16, 128) if Cc == 128 else (0,) + tuple(g | (S << 16) for S in ((1, 2, 3) if Cc == 32 else (1,)) for g in (256, 512, 768))
+    mbs = (0, 18 << 16, 4 << 16, 5 << 16) if Cc == 128 else (0,) + tuple(g | (S << 16) for S in ((1, 2, 3) if Cc == 32 else (1,)) for g in (256, 512, 768))
     for mb in mbs:
         f2 = lambda: _lib.check(lib.y5_bottleneck_fwd(vp(cat), 2 * Cc, vp(w1p), vp(b1p), K1, vp(w2p), vp(b2p), K2, vp(out), Cc, B, HW, HW, Cc, 1, mb, st), lib)
         print(f"C={Cc} {HW}^2 bs={B}: fused (stages {mb >> 16}, grid cap {mb & 0xffff}) {timeit(f2):.1f} us")

@@ -28,7 +28,7 @@ w2p, b2p, _, K2, N2 = pack_conv_weight(w2, b2, torch.float16)
 w1p, b1p, w2p, b2p = (t.to(dev) for t in (w1p, b1p, w2p, b2p))
 cat = torch.randn(B, HW, HW, 2 * Cc, device=dev).half()
 out = torch.empty(B, HW, HW, Cc, device=dev, dtype=torch.float16)
-for mb in [int(a, 0) for a in (sys.argv[1:] or ["0", str(4 << 16), str(5 << 16)])]:
+for mb in [int(a, 0) for a in (sys.argv[1:] or ["0", str(18 << 16), str(5 << 16)])]:
     f = lambda: _lib.check(lib.y5_bottleneck_fwd(vp(cat), 2 * Cc, vp(w1p), vp(b1p), K1, vp(w2p), vp(b2p), K2, vp(out), Cc, B, HW, HW, Cc, 1, mb, st), lib)
     for _ in range(3):
         f()

@@ -60,7 +60,8 @@ def test_fused_bottleneck_matches_torch(Cc, B, H, W, add, ldx, ldy, mb):
 # Each case runs with LDS-DMA landing at issue (write-after-read hazards) and at the covering vmcnt wait (counted-wait bookkeeping).
 H3B_CASES = [(1, 6, 7, True, 128, 128, 0), (2, 9, 20, False, 256, 136, 0), (1, 23, 40, True, 128, 128, 2), (3, 12, 10, True, 128, 256, 1),
              (1, 40, 40, True, 128, 128, 3), (2, 17, 33, False, 128, 128, 2 | (5 << 16)), (5, 5, 5, True, 128, 128, 1 | (5 << 16)),
-             (1, 23, 40, True, 128, 128, 2 | (4 << 16)), (3, 12, 10, False, 128, 256, 1 | (4 << 16))]
+             (1, 23, 40, True, 128, 128, 2 | (4 << 16)), (3, 12, 10, False, 128, 256, 1 | (4 << 16)),
+             (1, 23, 40, True, 128, 128, 2 | (18 << 16)), (3, 12, 10, False, 128, 256, 1 | (18 << 16)), (2, 17, 33, True, 128, 128, 2 | (18 << 16))]
 
 
 @pytest.mark.parametrize("async_dma", ["0", "1"])

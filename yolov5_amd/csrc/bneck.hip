@@ -65,10 +65,10 @@ bool h3b_pick_tile(int B, int H, int W, long long slots, int* th, int* tw) {
   return best >= 0;
 }
 
-template <int NSW>
+template <int NSW, bool K64 = false>
 int launch_h3b(Y5H3bParams p, int max_blocks, hipStream_t stream) {
-  using Gm = Y5H3bGeom<NSW>;
-  auto kern = y5_conv_h3b_kernel<NSW>;
+  using Gm = Y5H3bGeom<NSW, K64>;
+  auto kern = y5_conv_h3b_kernel<NSW, K64>;
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -124,12 +124,13 @@ extern "C" int y5_bottleneck_fwd(const void* x, int ldx, const void* w1_packed, 
   hipStream_t st = static_cast<hipStream_t>(stream_);
   const int stages = max_blocks >> 16;      // bits 16.. of max_blocks select the ring depth (0 = default for C), bits 0..15 the grid cap
   max_blocks &= 0xffff;
-  if (C == 128) {   // conv_h3b.h: 1x1 as a GEMM-1 phase of the halo-resident 3x3; stages = depth of the 3x3 filter ring (9 default, 4, 5)
+  if (C == 128) {   // conv_h3b.h: 1x1 as a GEMM-1 phase of the halo-resident 3x3; stages = depth of the 3x3 filter ring (9 default; 18 = 9 stages with double steps; 4, 5)
     Y5H3bParams q{};
     q.x = x; q.w1 = w1_packed; q.w2 = w2_packed; q.b1 = bias1; q.b2 = bias2; q.y = y;
     q.x_bytes = p.x_bytes; q.w1_bytes = p.w1_bytes; q.w2_bytes = p.w2_bytes;
     q.B = B; q.H = H; q.W = W; q.ldx = ldx; q.ldy = ldy; q.Kpad1 = Kpad1; q.Kpad2 = Kpad2; q.add = add;
-    if (stages == 0 || stages == 9) return launch_h3b<9>(q, max_blocks, st);   // W1 streamed per tile through the ring
+    if (stages == 0 || stages == 9) return launch_h3b<9>(q, max_blocks, st);      // W1 streamed through the ring, one barrier per slice
+    if (stages == 18) return launch_h3b<9, true>(q, max_blocks, st);               // ... one barrier per TWO slices (profiles/r05/r05_h3b_v3_k64.log: not faster)
     if (stages == 4) return launch_h3b<4>(q, max_blocks, st);                    // W1 resident behind a short ring
     if (stages == 5) return launch_h3b<5>(q, max_blocks, st);
     return y5_fail(Y5_ERR_UNSUPPORTED, "bottleneck: unsupported number of stages");

@@ -40,7 +40,9 @@ struct Y5H3Geom {
   static constexpr int PPS = (APS + 1) / 2;            // ... issued in the first two steps of the previous chunk (seven steps ahead)
   static constexpr int SCR_ROWB = 32 * 2 + 16, SCR_BYTES = 32 * SCR_ROWB;
   // the epilogue's transposition scratch lives in halo stage 1 (idle between a tile's last step and the next tile's step 0)
-  static constexpr size_t LDS = (size_t)2 * A_STAGE + (size_t)NSW * W_STAGE + 1024;  // + one dummy slot (zeros from any wave)
+  static constexpr int BIAS_MAX = 1024;               // output channels whose fp32 bias is staged in LDS (4 KB) once per workgroup
+  static constexpr size_t OFF_BIAS = (size_t)2 * A_STAGE + (size_t)NSW * W_STAGE + 1024;  // behind one dummy slot (zeros from any wave)
+  static constexpr size_t LDS = OFF_BIAS + (size_t)BIAS_MAX * 4;
   static_assert(NW * SCR_BYTES <= A_STAGE, "epilogue scratch must fit into a halo stage");
   static_assert(NSW == 9 || NSW == 4, "ring depths with bookkeeping: 9 and 4");
   // LDS-DMA instructions (dummies included) a wave has issued for the NEXT chunk's halo (taps 0 and 1) within the WIN steps before tap t
@@ -87,6 +89,11 @@ void y5_conv_h3_kernel(const Y5ConvParams p) {
   const int g = lane >> 5, frow = lane & 31;
   char* const scratch = smem + A_STAGE + wave * Gm::SCR_BYTES;  // halo stage 1
   char* const dummy = smem + 2 * A_STAGE + NSW * W_STAGE;  // shared by all waves: only ever receives zero fill, never read
+  // fp32 bias of every (padded) output channel, staged once: the epilogue reads it with one ds_read_b128 per four channels.  (Round 5: the
+  // `g ? pb[q*8+4+e] : pb[q*8+e]` form meant for the scalar cache had been compiled into 16 SERIALIZED per-lane global loads per accumulator
+  // block, each behind an s_waitcnt vmcnt(0) that also drained the next tile's in-flight LDS-DMA.)
+  float* const bias_lds = reinterpret_cast<float*>(smem + Gm::OFF_BIAS);
+  for (int i = tid; i < p.Npad; i += NW * 64) bias_lds[i] = p.bias[i];
 
   const int TH = p.h3_th, TW = p.h3_tw, HW = TW + 2;
   const int HP = (TH + 2) * HW;
@@ -201,14 +208,15 @@ void y5_conv_h3_kernel(const Y5ConvParams p) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int nt = n0 + (wn * TN + j) * 32;
-        const float* pb = p.bias + (nt < p.Npad ? nt : 0);  // scalar-cache loads (wave-uniform address)
+        const float* pb = bias_lds + (nt < p.Npad ? nt : 0) + g * 4;
         const float keep = nt < p.Npad ? 1.0f : 0.0f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+          const float4_t bq = *reinterpret_cast<const float4_t*>(pb + q * 8);
           half4_t o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float t = acc[i][j][q * 4 + e] + (g ? pb[q * 8 + 4 + e] : pb[q * 8 + e]) * keep;
+            const float t = acc[i][j][q * 4 + e] + bq[e] * keep;
             o[e] = (half_t)(p.act ? y5_silu(t) : t);
           }
           *reinterpret_cast<half4_t*>(scratch + frow * SCR_ROWB + (q * 8 + g * 4) * 2) = o;

@@ -5,8 +5,7 @@
 //   * a workgroup owns a TH x TW spatial tile of one image; the (TH+2) x (TW+2) halo of ALL 128 channels lives in LDS as four 32-channel
 //     planes (HPMAX = 320 halo pixels x 64 B = 20 KB each; conv_h3.h layout: 16-byte slots XOR-swizzled on the source side);
 //   * phase 1: the planes hold the x halo (LDS-DMA straight from the NHWC tensor, out-of-image pixels zero-filled); t = W1 x for every halo pixel
-//     (<= 10 row blocks x 4 channel blocks of 32 x 32, K = 128: 5-6 accumulator blocks per wave) with W1 resident in LDS for the whole launch
-//     (32 KB, loaded once per workgroup); after a barrier SiLU(t + b1) is written OVER the x halo as fp16 -- exactly the bytes the unfused 1x1 would
+//     (<= 10 row blocks x 4 channel blocks of 32 x 32, K = 128, dealt round-robin: 4-5 accumulator blocks per wave); after a barrier SiLU(t + b1) is written OVER the x halo as fp16 -- exactly the bytes the unfused 1x1 would
 //     have stored -- with out-of-image halo pixels forced to 0 (the 3x3's zero padding applies to t, not to x);
 //   * phase 2: conv_h3.h's software-pipelined tap loop over the resident planes -- only the 3x3 filter streams (NSW-stage ring of 8 KB slices,
 //     counted vmcnt, one barrier per (tap, chunk) step);
@@ -30,21 +29,24 @@ struct Y5H3bParams {
   int th, tw, tiles_h, tiles_w;
 };
 
-template <int NSW_>
+template <int NSW_, bool K64_ = false>
 struct Y5H3bGeom {
+  static constexpr bool K64 = K64_;   // one barrier per TWO (tap, chunk) slices = 16 MFMAs per wave (needs the deep ring: two double-steps of lead)
   static constexpr int C = 128, NCC = 4, NW = 8, WN = 2, TM = 2, TN = 2, HPMAX = 320;
   static constexpr int NAI_MAX = HPMAX / 16, PLANE = NAI_MAX * 1024;   // 20 pieces of 16 halo pixels x 64 B
   static constexpr int W_STAGE = C * 64, NSW = NSW_, WIN = NSW - 3;
   static constexpr int APS = (NAI_MAX + NW - 1) / NW, PPS = (APS + 1) / 2;   // halo pieces per wave per plane; issued in tap 0 / tap 1
   static constexpr int NSTEP = NCC * 9;
-  static constexpr int NRB1 = 3;                                        // GEMM-1 row blocks per wave (rows wm + 4 i)
+  static constexpr int NRB1 = 5;                                        // GEMM-1: wave w owns channel block w & 3 of the halo row blocks (w >> 2) + 2 i
   static constexpr int SCR_ROWB = 32 * 2 + 16, SCR_BYTES = 32 * SCR_ROWB;
   // W1 (32 KB): resident behind a short ring (NSW <= 5), or -- so that the ring can be as deep as conv_h3.h's (NSW = 9: slices issued eight steps
   // ahead; with two steps of lead a one-workgroup-per-CU loop waits on L2 latency, profiles/r05/r05_ab_h3b_v1.log) -- STREAMED per tile into ring
   // stages W1_ST0..W1_ST0+3, which are idle between the last tap of a tile and the end of the next tile's GEMM 1; the epilogue's scratch keeps
   // stages 0..W1_ST0-1
   static constexpr bool W1RES = NSW <= 5;
-  static constexpr int W1_ST0 = 3, PRE0 = W1RES ? NSW - 1 : W1_ST0;      // ring slices issued in front of GEMM 1 (the rest of the first NSW-1 behind it)
+  static constexpr int NPRO = K64 ? NSW - 2 : NSW - 1;                  // ring slices issued before the tap loop
+  static constexpr int W1_ST0 = 3, PRE0 = W1RES ? NPRO : W1_ST0;        // ... of which in front of GEMM 1 (the rest behind it)
+  static_assert(!K64 || (NSW == 9 && !W1RES), "double steps: 9-stage ring");
   static constexpr size_t OFF_RING = (size_t)NCC * PLANE;
   static constexpr size_t OFF_W1 = W1RES ? OFF_RING + (size_t)NSW * W_STAGE : OFF_RING + (size_t)W1_ST0 * W_STAGE;
   static constexpr size_t OFF_DUMMY = OFF_RING + (size_t)NSW * W_STAGE + (W1RES ? (size_t)C * C * 2 : 0);
@@ -65,6 +67,19 @@ struct Y5H3bGeom {
     }
     return n;
   }
+  // ---- K64: double-step k = 0..8 of a chunk PAIR (18 slices); double-step d = 9 P + k multiplies slices 2d, 2d+1, issues slices 2d+7, 2d+8 (while
+  // they exist: d <= 13 both, d = 14 one) and, at k = 0, 1 (plane 1, second pair only) and k = 5, 6 (plane 2 P), the next tile's halo pieces.
+  static constexpr int xi2(int k) { return (k == 0 || k == 5) ? PPS : (k == 1 || k == 6) ? APS - PPS : 0; }
+  static constexpr int wi2(int k, bool last) { return !last || k <= 4 ? 2 : k == 5 ? 1 : 0; }   // (last: d = 9 + k)
+  // in flight at the barrier of double-step k: what the two double-steps before it issued (the ring prologue counts as those in front of the loop)
+  static constexpr int allowed2(int k, bool last) {
+    int n = 0;
+    for (int u = k - 2; u <= k - 1; ++u) {
+      n += u < 0 ? 2 : wi2(u, last);   // u < 0: the previous pair (never the last) or the prologue (slices 3..6)
+      if (u >= 0) n += xi2(u);
+    }
+    return n;
+  }
 };
 
 #ifdef Y5_H3B_TIMING   // kernel-experiment builds only (scripts/h3b_timing.py): s_memrealtime (100 MHz) at the phase boundaries of the first four tiles
@@ -74,11 +89,11 @@ __device__ unsigned long long y5_h3b_stamps[512 * 4 * 8];
 #define Y5_H3B_STAMP(k) ((void)0)
 #endif
 
-template <int NSW_>
+template <int NSW_, bool K64_ = false>
 __global__ __launch_bounds__(512, 1)
 void y5_conv_h3b_kernel(const Y5H3bParams p) {
   typedef half_t T;
-  using Gm = Y5H3bGeom<NSW_>;
+  using Gm = Y5H3bGeom<NSW_, K64_>;
   constexpr int NW = Gm::NW, TM = Gm::TM, TN = Gm::TN, NSW = Gm::NSW, APS = Gm::APS, PLANE = Gm::PLANE, W_STAGE = Gm::W_STAGE;
   constexpr int SCR_ROWB = Gm::SCR_ROWB, NRB1 = Gm::NRB1;
 
@@ -139,11 +154,15 @@ void y5_conv_h3b_kernel(const Y5H3bParams p) {
       const int r = m / TW, c = m - r * TW;
       o_rc[i][ps] = r < TH ? (r | (c << 16)) : -1;
     }
-  // (d) GEMM 1: this wave's halo-pixel row blocks wm + 4 i; lane -> halo pixel (row, column) for the in-image test of the t store
+  // (d) GEMM 1: the <= 40 blocks of 32 halo pixels x 32 channels are dealt round-robin (block b = w + 8 i -> channel block b & 3 = w & 3, row block
+  // b >> 2 = (w >> 2) + 2 i): 4-5 blocks per wave at 9 row blocks instead of 4-6 with a 2 x 3 grid; lane -> halo pixel (row, column) for the
+  // in-image test of the t store
+  const int cb1 = wave & 3, rb1 = wave >> 2;
+  const int w1_rd = (cb1 * 32 + frow) * 64 + ((g ^ ((frow >> 2) & 3)) << 4);
   int g1_rc[NRB1];
 #pragma unroll
   for (int i = 0; i < NRB1; ++i) {
-    const int hp = (wm + 4 * i) * 32 + frow;
+    const int hp = (rb1 + 2 * i) * 32 + frow;
     const int hr = hp / HW, hc = hp - hr * HW;
     g1_rc[i] = hr | (hc << 8) | ((hp < HP ? 1 : 0) << 16);
   }
@@ -270,26 +289,23 @@ void y5_conv_h3b_kernel(const Y5H3bParams p) {
     Y5_H3B_STAMP(1);
     y5_static_for<0, Gm::PRE0>([&](auto uc) { issue_w2(decltype(uc)::value, decltype(uc)::value); });  // the first 3x3 slices fly behind GEMM 1
     {
-      float16_t acc1[NRB1][TN];
+      float16_t acc1[NRB1];
 #pragma unroll
       for (int i = 0; i < NRB1; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc1[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc1[i][r] = 0.f;
       int a1[NRB1];
 #pragma unroll
       for (int i = 0; i < NRB1; ++i) {
-        const int hp = (wm + 4 * i) * 32 + frow;
+        const int hp = (rb1 + 2 * i) * 32 + frow;
         a1[i] = (hp << 6) | ((g ^ ((hp >> 2) & 3)) << 4);
       }
-      // all three row blocks are multiplied unconditionally (a block beyond the halo reads whatever LDS holds behind it and is never stored: the
-      // barrier below waits for the waves that own three real blocks anyway); fragments of k-step s+1 are fetched while step s multiplies
-      half8_t wf1[2][TN], af1[2][NRB1];
+      // all five row blocks are multiplied unconditionally (a block beyond the halo reads whatever the plane holds there and is never stored: the
+      // barrier below waits for the waves that own five real blocks anyway); fragments of k-step s+1 are fetched while step s multiplies
+      half8_t wf1[2], af1[2][NRB1];
       auto rd1 = [&](auto sc) {
         constexpr int s1 = decltype(sc)::value, cc = s1 >> 1, ks = s1 & 1, bf = s1 & 1;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) wf1[bf][j] = *reinterpret_cast<const half8_t*>(w1_lds + cc * W_STAGE + (w_rd[j] ^ (ks * 32)));
+        wf1[bf] = *reinterpret_cast<const half8_t*>(w1_lds + cc * W_STAGE + (w1_rd ^ (ks * 32)));
 #pragma unroll
         for (int i = 0; i < NRB1; ++i) af1[bf][i] = *reinterpret_cast<const half8_t*>(a_lds + cc * PLANE + (a1[i] ^ (ks * 32)));
       };
@@ -301,36 +317,30 @@ void y5_conv_h3b_kernel(const Y5H3bParams p) {
         __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
-        for (int i = 0; i < NRB1; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf1[bf][j], af1[bf][i], acc1[i][j], 0, 0, 0);
+        for (int i = 0; i < NRB1; ++i) acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf1[bf], af1[bf][i], acc1[i], 0, 0, 0);
 #ifndef Y5_EMU
         __builtin_amdgcn_sched_barrier(0);
 #endif
       });
       __syncthreads();    // every wave has read its x fragments: the planes may now take t (and the ring stages of a streamed W1 their slices)
       Y5_H3B_STAMP(2);
-      y5_static_for<Gm::PRE0, NSW - 1>([&](auto uc) { issue_w2(decltype(uc)::value, decltype(uc)::value); });
+      y5_static_for<Gm::PRE0, Gm::NPRO>([&](auto uc) { issue_w2(decltype(uc)::value, decltype(uc)::value); });
 #pragma unroll
       for (int i = 0; i < NRB1; ++i) {
-        if (wm + 4 * i < NRB) {
-          const int hp = (wm + 4 * i) * 32 + frow;
+        if (rb1 + 2 * i < NRB) {
+          const int hp = (rb1 + 2 * i) * 32 + frow;
           const int ih = toh0 - 1 + (g1_rc[i] & 0xff), iw = tow0 - 1 + ((g1_rc[i] >> 8) & 0xff);
           const bool ok = (g1_rc[i] >> 16) != 0 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
           const int sw = (hp >> 2) & 3;
           const uint32_t keep = ok ? 0xffffffffu : 0u;   // branch-free: the zero padding of the 3x3 is a bit mask on the packed pair
+          char* row = a_lds + cb1 * PLANE + (hp << 6) + g * 8;
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const int cb = wn * TN + j;
-            char* row = a_lds + cb * PLANE + (hp << 6) + g * 8;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float4_t bq = *reinterpret_cast<const float4_t*>(bias_lds + cb * 32 + q * 8 + g * 4);
-              uint2_t o;
-              o[0] = y5_pack_h2(y5_silu(acc1[i][j][q * 4 + 0] + bq[0]), y5_silu(acc1[i][j][q * 4 + 1] + bq[1])) & keep;
-              o[1] = y5_pack_h2(y5_silu(acc1[i][j][q * 4 + 2] + bq[2]), y5_silu(acc1[i][j][q * 4 + 3] + bq[3])) & keep;
-              *reinterpret_cast<uint2_t*>(row + ((q ^ sw) << 4)) = o;
-            }
+          for (int q = 0; q < 4; ++q) {
+            const float4_t bq = *reinterpret_cast<const float4_t*>(bias_lds + cb1 * 32 + q * 8 + g * 4);
+            uint2_t o;
+            o[0] = y5_pack_h2(y5_silu(acc1[i][q * 4 + 0] + bq[0]), y5_silu(acc1[i][q * 4 + 1] + bq[1])) & keep;
+            o[1] = y5_pack_h2(y5_silu(acc1[i][q * 4 + 2] + bq[2]), y5_silu(acc1[i][q * 4 + 3] + bq[3])) & keep;
+            *reinterpret_cast<uint2_t*>(row + ((q ^ sw) << 4)) = o;
           }
         }
       }
@@ -365,7 +375,7 @@ void y5_conv_h3b_kernel(const Y5H3bParams p) {
       for (int i = 0; i < TM; ++i) af[ks][i] = *reinterpret_cast<const half8_t*>(a_lds + (a0[i] ^ (ks * 32)));
     };
     {
-      y5_wait_vm<(NSW - 2)>();   // filter slice 0 landed (slices 1..NSW-2 may still be in flight)
+      y5_wait_vm<Gm::NPRO - 1>();   // filter slice 0 landed (the rest of the ring prologue may still be in flight)
       __syncthreads();           // ... and every wave's t rows are visible
       Y5_H3B_STAMP(3);
       int a0[TM];
@@ -373,26 +383,9 @@ void y5_conv_h3b_kernel(const Y5H3bParams p) {
       read_frags(std::integral_constant<int, 0>{}, a0, w_lds);
       read_frags(std::integral_constant<int, 1>{}, a0, w_lds);
     }
-    int st_cur = 0;   // ring stage of the current step's slice (step index mod NSW)
-    for (int cc = 0; cc < Gm::NCC; ++cc) {
-      const bool last = cc + 1 == Gm::NCC;
-      y5_static_for<0, 9>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        constexpr int tn = (t + 1) % 9;
-        if (last) y5_wait_vm<Gm::allowed(t, true)>();
-        else y5_wait_vm<Gm::allowed(t, false)>();
-        __builtin_amdgcn_s_barrier();
-        // plane cc-1 is dead (its last fragments were consumed in the step before this chunk's tap 0): it takes the next tile's x halo
-        if constexpr (t < 2)
-          y5_static_for<t * Gm::PPS, (t + 1) * Gm::PPS < APS ? (t + 1) * Gm::PPS : APS>([&](auto kc) { issue_x(kc, cc - 1, cc > 0); });
-        // slice s + NSW - 1 goes into the stage slice s - 1 occupied (every wave finished reading it before this barrier)
-        const int st_prev = st_cur == 0 ? NSW - 1 : st_cur - 1;
-        if (!last || t <= 9 - NSW) issue_w2(st_prev, cc * 9 + t + NSW - 1);
-        const int st_next = st_cur == NSW - 1 ? 0 : st_cur + 1;
-        const bool more = t < 8 || !last;  // a step s+1 exists in this tile
-        int a0[TM];
-        if (more) frag_addr(tn, t == 8 ? cc + 1 : cc, a0);
-        const char* wst = w_lds + st_next * W_STAGE;
+    int st_cur = 0;   // ring stage of the current (first) slice of the step (slice index mod NSW)
+    if constexpr (Gm::K64) {
+      auto half_step = [&](const int (&a0)[TM], const char* wst, bool more) {
         y5_static_for<0, 2>([&](auto ksc) {
           constexpr int ks = decltype(ksc)::value;
 #ifndef Y5_EMU
@@ -411,8 +404,76 @@ void y5_conv_h3b_kernel(const Y5H3bParams p) {
 #ifndef Y5_EMU
         __builtin_amdgcn_sched_barrier(0);
 #endif
-        st_cur = st_next;
-      });
+      };
+      auto wrap = [](int v) { return v >= NSW ? v - NSW : v; };
+      for (int P = 0; P < Gm::NCC / 2; ++P) {
+        const bool last = P + 1 == Gm::NCC / 2;
+        y5_static_for<0, 9>([&](auto kc_) {
+          constexpr int k = decltype(kc_)::value;
+          constexpr int uB = 2 * k + 1, uN = 2 * k + 2;           // second slice of this double-step / first slice of the next (pair-relative)
+          // slices <= 2 d + 2 have landed: the second slice of this double-step and the first of the next, whose fragments are read below
+          if (last) y5_wait_vm<Gm::allowed2(k, true)>();
+          else y5_wait_vm<Gm::allowed2(k, false)>();
+          __builtin_amdgcn_s_barrier();
+          // dead planes take the next tile's x halo: plane 2 P once slice 9 (2 P) + 8 has been read (k >= 4), plane 1 at the top of the second pair
+          if constexpr (k == 0 || k == 1)
+            y5_static_for<k * Gm::PPS, (k + 1) * Gm::PPS < APS ? (k + 1) * Gm::PPS : APS>([&](auto kc) { issue_x(kc, 1, P > 0); });
+          if constexpr (k == 5 || k == 6)
+            y5_static_for<(k - 5) * Gm::PPS, (k - 4) * Gm::PPS < APS ? (k - 4) * Gm::PPS : APS>([&](auto kc) { issue_x(kc, 2 * P, true); });
+          // slices 2 d + 7, 2 d + 8 go into the stages slices 2 d - 2, 2 d - 1 occupied (every wave finished reading them before this barrier)
+          const int s0 = 18 * P + 2 * k + NSW - 2;
+          if (!last || k <= 4) { issue_w2(wrap(st_cur + NSW - 2), s0); issue_w2(wrap(st_cur + NSW - 1), s0 + 1); }
+          else if (k == 5) issue_w2(wrap(st_cur + NSW - 2), s0);
+          int a0[TM];
+          frag_addr(uB % 9, 2 * P + uB / 9, a0);
+          half_step(a0, w_lds + wrap(st_cur + 1) * W_STAGE, true);
+          const bool more = k < 8 || !last;
+          if (more) frag_addr(uN % 9, 2 * P + uN / 9, a0);
+          half_step(a0, w_lds + wrap(st_cur + 2) * W_STAGE, more);
+          st_cur = wrap(st_cur + 2);
+        });
+      }
+    } else {
+      for (int cc = 0; cc < Gm::NCC; ++cc) {
+        const bool last = cc + 1 == Gm::NCC;
+        y5_static_for<0, 9>([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          constexpr int tn = (t + 1) % 9;
+          if (last) y5_wait_vm<Gm::allowed(t, true)>();
+          else y5_wait_vm<Gm::allowed(t, false)>();
+          __builtin_amdgcn_s_barrier();
+          // plane cc-1 is dead (its last fragments were consumed in the step before this chunk's tap 0): it takes the next tile's x halo
+          if constexpr (t < 2)
+            y5_static_for<t * Gm::PPS, (t + 1) * Gm::PPS < APS ? (t + 1) * Gm::PPS : APS>([&](auto kc) { issue_x(kc, cc - 1, cc > 0); });
+          // slice s + NSW - 1 goes into the stage slice s - 1 occupied (every wave finished reading it before this barrier)
+          const int st_prev = st_cur == 0 ? NSW - 1 : st_cur - 1;
+          if (!last || t <= 9 - NSW) issue_w2(st_prev, cc * 9 + t + NSW - 1);
+          const int st_next = st_cur == NSW - 1 ? 0 : st_cur + 1;
+          const bool more = t < 8 || !last;  // a step s+1 exists in this tile
+          int a0[TM];
+          if (more) frag_addr(tn, t == 8 ? cc + 1 : cc, a0);
+          const char* wst = w_lds + st_next * W_STAGE;
+          y5_static_for<0, 2>([&](auto ksc) {
+            constexpr int ks = decltype(ksc)::value;
+#ifndef Y5_EMU
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+#ifndef Y5_EMU
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            if (more) read_frags(ksc, a0, wst);
+          });
+#ifndef Y5_EMU
+          __builtin_amdgcn_sched_barrier(0);
+#endif
+          st_cur = st_next;
+        });
+      }
     }
     __syncthreads();  // every wave is done with the ring and with the last plane
     Y5_H3B_STAMP(4);

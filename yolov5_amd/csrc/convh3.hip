@@ -67,6 +67,7 @@ int launch_h3(const Y5ConvParams& p0, int max_blocks, hipStream_t stream) {
     attr_done = true;
   }
   Y5ConvParams p = p0;
+  if (p.Npad > Gm::BIAS_MAX) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: halo 3x3 configurations stage at most 1024 output channels of bias");
   p.tilesN = (p.Npad + Gm::BN - 1) / Gm::BN;
   long long G = max_blocks;
   if (G <= 0) {
