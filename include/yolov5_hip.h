@@ -93,6 +93,11 @@ int y5_conv_num_cfgs(void);
  * eight MFMAs per wave; reports the TFLOP/s the device sustains and the shader clock it held meanwhile (s_memtime against the 100 MHz
  * s_memrealtime).  scratch: >= 2 * CUs * 1024 + 64 bytes of device memory.  bench.py prints it beside the data-sheet peak. */
 int y5_probe_mfma(void* scratch, size_t scratch_bytes, int iters, float* tflops, float* shader_ghz, void* stream);
+/* CU budget of the persistent kernels (grids = budget x occupancy instead of CUs x occupancy).  utils/torch_utils.py:61-70 `smart_DDP` + train.py:404-410:
+ * the reference overlaps the gradient all-reduce with backward; here the collective's kernels (RCCL, on the process group's stream) need workgroup slots
+ * beside the backward plan's persistent workgroups, so yolov5_amd.torch_utils.HipDDP reserves r CUs (budget = CUs - r) while a process group exists.
+ * n_cus = 0 restores the device's full count.  Process-global; takes effect at the next launch / plan build. */
+int y5_set_cu_budget(int n_cus);
 int y5_conv_cfg_info(int cfg, int* bm_pixels, int* bn_channels, int* k_bytes_per_stage);
 
 int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w_packed, const float* bias,

@@ -71,6 +71,7 @@ EXPORTS = {
     "y5_conv_stem_fwd_raw": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "y5_conv_num_cfgs": (C.c_int, []),
     "y5_probe_mfma": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p]),
+    "y5_set_cu_budget": (C.c_int, [C.c_int]),
     "y5_conv_sk_workspace_bytes": (C.c_size_t, []),
     "y5_conv_set_sk_workspace": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "y5_conv_cfg_info": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -13,3 +13,16 @@ def bump_weights_epoch():
     global weights_epoch
     weights_epoch += 1
     return weights_epoch
+
+
+cu_budget = 0  # CUs the persistent kernels currently size their grids for (0 = all); mirrors csrc/core.hip's value for host-side grid arithmetic
+
+
+def set_cu_budget(lib, n):
+    global cu_budget
+    n = max(int(n), 0)
+    if n != cu_budget:
+        rc = lib.y5_set_cu_budget(n)
+        if rc != 0:
+            raise RuntimeError("y5_set_cu_budget failed")
+        cu_budget = n

@@ -28,6 +28,8 @@ struct Y5BnParams {
   int C, ldz, ldy, ldr, ldo;
   int nblk;
   float eps, momentum;
+  int rev;              // statistics passes walk the tensor from its END: the producer (conv / dgrad) wrote it front to back, so the tail is what the
+                        // memory-side cache still holds; the apply pass that follows runs front to back again and meets what this pass read last
 };
 
 template <typename T> struct Y5Vec;
@@ -70,7 +72,8 @@ void y5_chan_reduce_kernel(const Y5BnParams p) {
     }
     // pixels of this block: a contiguous range split evenly over the grid, rows of the block stride through it
     const long long per = (p.npix + gridDim.x - 1) / gridDim.x;
-    const long long p0 = per * blockIdx.x, p1 = p0 + per < p.npix ? p0 + per : p.npix;
+    const long long bx = p.rev ? (long long)gridDim.x - 1 - blockIdx.x : blockIdx.x;   // (partials stay indexed by blockIdx: the finish order is fixed either way)
+    const long long p0 = per * bx, p1 = p0 + per < p.npix ? p0 + per : p.npix;
     // U independent 16-byte loads per thread and iteration: the pass is a pure stream, its speed is the number of bytes in flight
     constexpr int U = 4;
     auto accumulate = [&](const V& zv, const V& gv) {

@@ -22,13 +22,7 @@ int launch_bneck(const Y5BneckParams& p, int max_blocks, hipStream_t stream) {
   const long long nbt = (nwt + NWV - 1) / NWV;
   long long G = max_blocks;
   if (G <= 0) {
-    static int num_cu = 0;
-    if (!num_cu) {
-      int dev = 0, n = 0;
-      hipGetDevice(&dev);
-      hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-      num_cu = n > 0 ? n : 256;
-    }
+    const int num_cu = y5_num_cu();
     // resident workgroups per CU: LDS is the limit (52.5 KB at C = 32, one stage: three fit in 160 KB; the occupancy query answers two)
     int occ = (int)((160 * 1024) / lds);
     if (occ < 1) occ = 1;
@@ -76,13 +70,7 @@ int launch_h3b(Y5H3bParams p, int max_blocks, hipStream_t stream) {
   }
   long long G = max_blocks;
   if (G <= 0) {
-    static int num_cu = 0;
-    if (!num_cu) {
-      int dev = 0, n = 0;
-      hipGetDevice(&dev);
-      hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-      num_cu = n > 0 ? n : 256;
-    }
+    const int num_cu = y5_num_cu();
     G = num_cu;   // 145 KB of LDS: one workgroup per CU
   }
   if (!h3b_pick_tile(p.B, p.H, p.W, G, &p.th, &p.tw)) return y5_fail(Y5_ERR_UNSUPPORTED, "bottleneck: no spatial tile fits the 320-pixel halo");

@@ -63,7 +63,6 @@ constexpr TileCfg kCfgs[kNumIgemm] = {
     {4, 1, 2, 1, 128},  // 13: 256 x  32, BK64
 };
 
-int g_num_cu = 0;
 
 // stream-K configurations (conv_igemm.h SK): ids kSk0 + index; (wm, wn, tm, tn), 128-byte LDS rows (BK64), 2 stages
 constexpr int kSk0 = 57, kNumSk = 4;
@@ -108,12 +107,7 @@ int launch_cfg(const Y5ConvParams& p0, int max_blocks, hipStream_t stream) {
   // persistent grid: as many workgroups as stay resident (CUs x occupancy), each walking ntiles/G tiles
   long long G = max_blocks;
   if (G <= 0) {
-    if (!g_num_cu) {
-      int dev = 0, n = 0;
-      hipGetDevice(&dev);
-      hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-      g_num_cu = n > 0 ? n : 256;
-    }
+    const int g_num_cu = y5_num_cu();
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), NTHREADS, lds) != hipSuccess || occ < 1)
       occ = 1;
@@ -243,12 +237,7 @@ int launch_pw_v(const Y5ConvParams& p, int max_blocks, hipStream_t stream) {
   const long long nbt = ((long long)(p.M >> 5) + NWV - 1) / NWV;
   long long G = max_blocks;
   if (G <= 0) {
-    if (!g_num_cu) {
-      int dev = 0, n = 0;
-      hipGetDevice(&dev);
-      hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-      g_num_cu = n > 0 ? n : 256;
-    }
+    const int g_num_cu = y5_num_cu();
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), NWV * 64, lds) != hipSuccess || occ < 1) occ = 1;
     G = (long long)g_num_cu * occ;
@@ -319,12 +308,7 @@ int launch_k3_v(const Y5ConvParams& p, int max_blocks, hipStream_t stream) {
   const long long nbt = (nwt + NWV - 1) / NWV;
   long long G = max_blocks;
   if (G <= 0) {
-    if (!g_num_cu) {
-      int dev = 0, n = 0;
-      hipGetDevice(&dev);
-      hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-      g_num_cu = n > 0 ? n : 256;
-    }
+    const int g_num_cu = y5_num_cu();
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), NWV * 64, lds) != hipSuccess || occ < 1) occ = 1;
     G = (long long)g_num_cu * occ;
@@ -634,12 +618,7 @@ int launch_stem(const Y5StemParams& p, int max_blocks, hipStream_t stream) {
   const long long nbt = ((long long)p.nwt + 3) >> 2;
   long long G = max_blocks;
   if (G <= 0) {
-    if (!g_num_cu) {
-      int dev = 0, n = 0;
-      hipGetDevice(&dev);
-      hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-      g_num_cu = n > 0 ? n : 256;
-    }
+    const int g_num_cu = y5_num_cu();
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), 256, lds) != hipSuccess || occ < 1) occ = 1;
     G = (long long)g_num_cu * occ;

@@ -6,7 +6,6 @@
 #include "y5_host.h"
 
 namespace {
-int g_num_cu = 0;
 
 // ---- halo-resident 3x3 configurations (conv_h3.h): ids kH3_0 + index ------------------------------------------------------------
 struct H3Cfg { int wm, wn, tm, tn, hpmax; };
@@ -71,12 +70,7 @@ int launch_h3(const Y5ConvParams& p0, int max_blocks, hipStream_t stream) {
   p.tilesN = (p.Npad + Gm::BN - 1) / Gm::BN;
   long long G = max_blocks;
   if (G <= 0) {
-    if (!g_num_cu) {
-      int dev = 0, n = 0;
-      hipGetDevice(&dev);
-      hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-      g_num_cu = n > 0 ? n : 256;
-    }
+    const int g_num_cu = y5_num_cu();
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), Gm::NW * 64, Gm::LDS) != hipSuccess || occ < 1) occ = 1;
     G = (long long)g_num_cu * occ;

@@ -6,7 +6,6 @@
 #include "y5_host.h"
 
 namespace {
-int g_front_cu = 0;
 
 template <int TH, int TW, int NT1, int NT2>
 int launch_front(const Y5FrontParams& p, int max_blocks, hipStream_t stream) {
@@ -17,12 +16,7 @@ int launch_front(const Y5FrontParams& p, int max_blocks, hipStream_t stream) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  if (!g_front_cu) {
-    int dev = 0, n = 0;
-    hipGetDevice(&dev);
-    hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    g_front_cu = n > 0 ? n : 256;
-  }
+  const int g_front_cu = y5_num_cu();
   const long long ntiles = (long long)p.B * p.tiles_h * p.tiles_w;
   long long G = max_blocks > 0 ? max_blocks : g_front_cu;  // one workgroup (eight waves, ~153 KB of LDS) per CU
   if (G > ntiles) G = ntiles;

@@ -57,13 +57,7 @@ extern "C" int y5_detect_head_fwd_hint(const y5_conv_desc* d, const void* x, con
   const long long nbt = ((long long)(p.M >> 5) + nwv - 1) / nwv;
   long long G = d->max_blocks;
   if (G <= 0) {
-    static int num_cu = 0;
-    if (!num_cu) {
-      int dev = 0, n = 0;
-      hipGetDevice(&dev);
-      hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-      num_cu = n > 0 ? n : 256;
-    }
+    const int num_cu = y5_num_cu();
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), nwv * 64, lds) != hipSuccess || occ < 1) occ = 1;
     G = (long long)num_cu * occ;

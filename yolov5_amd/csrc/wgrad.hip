@@ -289,12 +289,7 @@ static int wgrad_impl(const y5_conv_desc* d, const void* x, const void* dz, int 
   p.K = d->KH * d->KW * d->C1; p.Kpad = d->Kpad; p.Npad = d->Npad;
   if (p.Kpad < p.K || p.Npad < p.C2) return y5_fail(Y5_ERR_BAD_ARG, "wgrad: bad packed filter dims");
   p.M = d->B * oh * ow;
-  int ncu = 256;
-  {
-    int dev = 0, n = 0;
-    hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ncu = n;
-  }
+  const int ncu = y5_num_cu();
   const bool det = ws != nullptr;
   // d->cfg selects the kernel family: -1 / 0 = automatic (by pixels per filter element), 1 = the general im2col-gather kernel, 3 / 3xy = the patch-staged 3x3
   // kernel (wgrad3.h).  Which one is faster depends on pixels per filter element (measured, profiles/r03/r03_wgrad3_ab.log): TrainEngine times both.

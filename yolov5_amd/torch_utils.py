@@ -62,6 +62,12 @@ class HipDDP(nn.Module):
                 for t in list(module.parameters()) + [b for b in module.buffers() if b.dtype.is_floating_point or b.dtype == torch.long]:
                     dist.broadcast(t.data, 0, group=process_group)
         self.cap = int(bucket_cap_mb * 1024 * 1024 / 4)
+        # CUs left to the collective while the backward plan runs (csrc/core.hip y5_set_cu_budget): the plan's persistent kernels size their grids for
+        # CUs - reserve.  Default 0: swept on one rank through a real RCCL group (scripts/r5_ddp_reserve.py, profiles/r05/r05_ddp_exchange.log) a
+        # reservation only slows the backward (exposed 0.60 / 0.62 / 0.73 / 0.90 / 1.64 ms at 0 / 8 / 16 / 32 / 64 CUs) -- a one-rank group launches NO
+        # RCCL kernel (rocprofv3: 0 nccl dispatches), so its "exposed exchange" never was CU starvation.  What it is: see _launch.  The knob stays for
+        # N > 1, where RCCL's ring kernels do need workgroup slots beside the plan's persistent workgroups.
+        self.reserve_cus = int(os.environ.get("Y5_DDP_RESERVE_CUS", "0")) if self.avg_in_collective else 0
         self.buckets, self.p2b, self._eng, self._flat = [], {}, None, None
         module.__dict__["_ddp_sink"] = self
         for k in ("stride", "names", "hyp", "nc", "yaml"):
@@ -92,15 +98,35 @@ class HipDDP(nn.Module):
     def begin(self, eng):
         if eng is not self._eng:
             self._attach(eng)
+        if self.reserve_cus > 0:
+            _state.set_cu_budget(eng.lib, self._ncu(eng) - self.reserve_cus)
         for b in self.buckets:
             b.pending = len(b.idxs)
             b.work = None
 
     def _launch(self, b):
+        if os.environ.get("Y5_DDP_DRY") == "1":   # measurement aid (scripts/r5_ddp_reserve.py): bookkeeping only, no collective
+            b.pending = -1
+            return
         if self.world > 1 or self.avg_in_collective:  # (a 1-rank RCCL group still runs the collective: exercises the launch / wait path)
             op = dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM
-            b.work = dist.all_reduce(self._flat[b.lo:b.hi], op=op, group=self.pg, async_op=True)
+            # Y5_DDP_SYNC = none (default): asynchronous collectives on the process group's stream, overlapped with the rest of the backward plan (the
+            # reference's DDP behaviour).  = all: issued synchronously, which this torch enqueues on the CURRENT stream -- no overlap, but no second
+            # hardware queue either.  Measured through a one-rank group (profiles/r05/r05_ddp_exchange.log): bookkeeping alone 0 us, async collectives
+            # 0.43-0.55 ms of step time whether 1 or 6 buckets (a fixed cost of bringing the second queue into play, not per collective and not the
+            # last bucket's hand-over: `last` = 0.45-0.55 ms), synchronous 0.00-0.01 ms.  On N ranks the choice is that fixed cost against the un-overlapped
+            # ring time of 28.9 MB (~0.3-0.5 ms estimated at 8 ranks): unmeasured here, so the overlapping form stays the default.
+            mode = os.environ.get("Y5_DDP_SYNC", "none")   # none | last | all
+            sync = self.avg_in_collective and (mode == "all" or (mode == "last" and b is self.buckets[-1]))
+            w = dist.all_reduce(self._flat[b.lo:b.hi], op=op, group=self.pg, async_op=not sync)
+            b.work = None if sync else w
+            if sync and not self.avg_in_collective:
+                self._flat[b.lo:b.hi].div_(self.world)
         b.pending = -1
+
+    def bucket_of(self, idx):
+        """The bucket a parameter's gradient travels in (the engine batches its per-layer gradient unpacking by bucket)."""
+        return self.p2b[idx]
 
     def grad_ready(self, idx):
         """The kernels producing parameter `idx`'s gradient are queued on the compute stream; a complete bucket goes on the
@@ -119,12 +145,19 @@ class HipDDP(nn.Module):
                         o = self._eng.goff[i]
                         self._flat[o:o + self.params[i].numel()].zero_()
                 self._launch(b)
+        if self.reserve_cus > 0:
+            _state.set_cu_budget(self._eng.lib, 0)   # the forward / validation / optimizer launches that follow use every CU again
         for b in self.buckets:
             if b.work is not None:
                 b.work.wait()  # orders the compute stream behind the collective; no host block on RCCL
                 if not self.avg_in_collective:
                     self._flat[b.lo:b.hi].div_(self.world)
         return grads
+
+    @staticmethod
+    def _ncu(eng):
+        dev = getattr(eng.be, "device", None)
+        return torch.cuda.get_device_properties(dev).multi_processor_count if dev is not None and torch.cuda.is_available() else 256
 
 
 def scale_img(img, ratio=1.0, same_shape=False, gs=32, flip=None):

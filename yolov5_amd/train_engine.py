@@ -230,7 +230,7 @@ class TrainEngine:
         if not getattr(self.be, "autotune", False) or self.dt != _lib.Y5_F16:
             return (fam if fam != -2 else -1), 0
         from .engine import _TUNE_CACHE, _load_tune_cache, _save_tune_cache
-        key = (-7002, int(self.deterministic), fam, d.B, d.H, d.W, d.C1, d.ldx, d.OH, d.OW, d.C2, ld_dz, d.KH, d.KW, d.SH, d.SW, d.Kpad, d.Npad)
+        key = (-7002 - 1000 * _state.cu_budget, int(self.deterministic), fam, d.B, d.H, d.W, d.C1, d.ldx, d.OH, d.OW, d.C2, ld_dz, d.KH, d.KW, d.SH, d.SW, d.Kpad, d.Npad)
         _load_tune_cache()
         if key in _TUNE_CACHE:
             v = _TUNE_CACHE[key][0]
@@ -238,6 +238,8 @@ class TrainEngine:
         lib = self.lib
         K = d.KH * d.KW * d.C1
         ncu = torch.cuda.get_device_properties(self.be.device).multi_processor_count
+        if 0 < _state.cu_budget < ncu:
+            ncu = _state.cu_budget   # (HipDDP reserves CUs for the collective during backward: split counts are chosen for the CUs the plan may fill)
         fams = []
         if fam in (-2, -1, 1):
             fams.append((-1 if fam == -1 else 1, -(-d.C2 // (128 if d.C2 >= 128 else 64)) * -(-K // (128 if K >= 128 else 64)), (1, 1.5, 2, 3, 4, 6)))
@@ -453,6 +455,7 @@ class TrainEngine:
         grads = _G([None] * len(params))
         hold = []
         self._unpack_later = []
+        self._unpack_pending, self._unpack_bucket = [], None
         for op in reversed(self.spec.ops):
             kind = op["op"]
             if kind == "decode":
@@ -478,6 +481,8 @@ class TrainEngine:
                 pass
             else:
                 raise NotImplementedError(kind)
+        if self._unpack_pending:
+            self._flush_unpack(stm, grads)
         if self._unpack_later:
             self._run_jobs(2, stm)  # packed fp32 dW of every conv -> parameter layout in the gradient arena, one launch
             for i in self._unpack_later:
@@ -487,18 +492,28 @@ class TrainEngine:
         flat = be.view_torch(self.gflat)  # (fresh view tensors: autograd's AccumulateGrad can adopt them without a copy)
         return [None if g is None else flat[self.goff[i]:self.goff[i] + p.numel()].view(p.shape) for i, (p, g) in enumerate(zip(params, grads))]
 
-    def _run_jobs(self, kind, stm):
+    def _flush_unpack(self, stm, grads):
+        """Unpack the packed weight gradients of the layers collected for one gradient bucket (one launch), then report them to the sink."""
+        sts, self._unpack_pending, self._unpack_bucket = self._unpack_pending, [], None
+        self._run_jobs(2, stm, convs=sts)
+        for st in sts:
+            grads[self._pidx[id(st["cv"].weight)]] = True
+
+    def _run_jobs(self, kind, stm, convs=None):
         """One y5_filter_jobs launch: kind 0 = pack every forward filter, 1 = pack every data-gradient sub-filter, 2 = unpack every
-        weight gradient.  The device-resident job table is rebuilt only when a pointer changed."""
+        weight gradient (convs: only those of these layers -- one launch per gradient bucket under HipDDP).  The device-resident job table is
+        rebuilt only when a pointer changed."""
         import numpy as np
 
         lib, be = self.lib, self.be
         cache = self.__dict__.setdefault("_job_tables", {})
-        ent = cache.get(kind)
-        wkey = tuple(self._f32(st["cv"].weight) for st in self.convs)  # (all other pointers are engine-owned buffers)
+        sel = self.convs if convs is None else convs
+        ckey = kind if convs is None else (kind, tuple(id(st) for st in convs))
+        ent = cache.get(ckey)
+        wkey = tuple(self._f32(st["cv"].weight) for st in sel)  # (all other pointers are engine-owned buffers)
         if ent is None or ent[0] != wkey:
             rows = []
-            for st, wptr in zip(self.convs, wkey):
+            for st, wptr in zip(sel, wkey):
                 cv = st["cv"]
                 c2, c1, kh, kw = cv.weight.shape
                 if kind == 0:
@@ -524,7 +539,7 @@ class TrainEngine:
                 j.reserved = 1 if (self.dtype == torch.float32 and j.kind != 2) else 0  # fp32 plan: packed filters are fp32
             tab = be.from_torch(torch.from_numpy(np.frombuffer(arr, dtype=np.uint8).copy()))
             ent = (wkey, tab, len(rows), max(r[2] for r in rows))
-            cache[kind] = ent
+            cache[ckey] = ent
         _lib.check(lib.y5_filter_jobs(_vp(be.ptr(ent[1])), ent[2], ent[3], stm), lib)
 
     def _bwd_conv(self, st, stm, is_written, mark, grads, hold):
@@ -597,10 +612,16 @@ class TrainEngine:
         d.cfg, d.max_blocks = st["wg_choice"]
         # (deterministic: fixed-order reduction of the pixel-range splits through a workspace, csrc/wgrad.hip DET -- bit-identical gradients run to run)
         _lib.check(self._wgrad_launch(d, self._ptr(x), dz_ptr, ld_dz, dw_ptr, stm), lib)
-        if self.grad_sink is not None:  # a gradient sink (HipDDP) wants every gradient as early as possible: unpack per layer
-            _lib.check(lib.y5_unpack_conv_wgrad(_vp(be.ptr(self.dwflat) + st["dw_off"] * 4), Kpad, _vp(self._gptr(cv.weight)), c2, c1, kh, kw,
-                                                st["c1v"], stm), lib)
-            grads[self._pidx[id(cv.weight)]] = True
+        if self.grad_sink is not None:
+            # a gradient sink (HipDDP) wants every gradient as early as possible -- but one unpack launch per LAYER was 56 extra launches per step
+            # (most of the "exposed exchange" of a one-rank group, profiles/r05/r05_ddp_exchange_trace.log): the packed gradients of the layers whose
+            # weights share a bucket are unpacked by ONE job launch when the bucket's last layer has queued its weight gradient
+            widx = self._pidx[id(cv.weight)]
+            bk = self.grad_sink.bucket_of(widx)
+            if self._unpack_bucket is not None and bk is not self._unpack_bucket:
+                self._flush_unpack(stm, grads)
+            self._unpack_bucket = bk
+            self._unpack_pending.append(st)
         else:
             self._unpack_later.append(self._pidx[id(cv.weight)])
         # data gradient: one forward launch per parity class on the re-packed sub-filter
