@@ -247,6 +247,20 @@ int y5_channel_sum(const void* x, int dtype, long long npix, int C, int ld, floa
  *              ->  all-reduce(copy of dgamma, dbeta)  ->  y5_bn_silu_bwd_from_sums (dz from the global sums and count_total)
  * With one rank (count_total = npix, sums untouched) the pairs compute what y5_bn_silu_fwd / y5_bn_silu_bwd compute. */
 int y5_bn_stats(const void* z, int dtype, long long npix, int C, int ldz, double* sums, void* workspace, size_t workspace_bytes, void* stream);
+/* Batch statistics from the EPILOGUE of the convolution that produces z (round 5; models/common.py:82-88 `Conv.forward` in train mode: the BatchNorm's
+ * batch mean / variance are a function of the convolution's output alone).
+ *   y5_conv2d_fwd_stats          = y5_conv2d_fwd (act = 0, no residual, one destination y = the z buffer) that also writes one row [2][C2] of fp32
+ *                                  (sum z, sum z^2) per workgroup into `partial` -- sums of the fp16-ROUNDED outputs, added in a fixed order (deterministic);
+ *                                  *rows = number of rows written (= grid size, <= 8 x CUs); partial_bytes >= rows * 2 * C2 * 4.
+ *                                  Y5_ERR_UNSUPPORTED unless the chosen configuration is a streaming pointwise / 3x3 kernel (conv_pw.h / conv_k3.h: the
+ *                                  HBM-bound layers of P1-P3), fp16: the caller then runs y5_conv2d_fwd + y5_bn_silu_fwd.
+ *   y5_bn_silu_fwd_from_partials = y5_bn_silu_fwd without its statistics pass over z: fixed-order finish of the `rows` partial rows (mean / invstd / running
+ *                                  statistics exactly as y5_bn_silu_fwd), then the apply pass. */
+int y5_conv2d_fwd_stats(const y5_conv_desc* d, const void* x, const void* w_packed, const float* bias, void* y, float* partial, size_t partial_bytes,
+                        int* rows, void* stream);
+int y5_bn_silu_fwd_from_partials(const void* z, int dtype, long long npix, int C, int ldz, const float* gamma, const float* beta, float eps,
+                                 float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                                 const float* partial, int rows, const void* residual, int ldr, void* y, int ldy, void* stream);
 int y5_bn_silu_fwd_from_sums(const void* z, int dtype, long long npix, int C, int ldz, const float* gamma, const float* beta, float eps,
                              float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd, const double* sums,
                              long long count_total, const void* residual, int ldr, void* y, int ldy, void* stream);

@@ -130,3 +130,61 @@ def test_emu_sync_bn_split_entries_two_shards_equal_full_batch(dtype):
     np.testing.assert_allclose(gsum[:Cc], dg, rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(gsum[Cc:], db, rtol=1e-4, atol=1e-5)
     assert np.all(y2[:, Cc:] == -7.0) and np.all(dz2[:, Cc:] == -9.0)
+
+
+@pytest.mark.parametrize("B,H,W,C1,C2,k,cfg,mb", [(7, 8, 16, 32, 32, 1, 14, 1), (5, 8, 16, 128, 64, 1, 18, 2), (5, 8, 16, 128, 128, 1, 84, 1),
+                                                  (3, 8, 16, 128, 248, 1, 87, 2), (2, 8, 16, 32, 32, 3, 30, 1), (3, 8, 16, 64, 64, 3, 80, 1),
+                                                  (1, 12, 24, 64, 56, 3, 79, 2)])
+def test_conv_fwd_stats_equals_the_separate_statistics_pass(B, H, W, C1, C2, k, cfg, mb):
+    """y5_conv2d_fwd_stats (streaming pointwise / 3x3 kernels, act = 0): z identical to y5_conv2d_fwd's, and y5_bn_silu_fwd_from_partials on its
+    per-workgroup partial rows gives the mean / invstd / running statistics / y of y5_bn_silu_fwd on that z (models/common.py:82-88 train mode)."""
+    from tests.test_emu_conv import run_conv  # noqa: F401  (same packing helpers)
+    from yolov5_amd.packing import pack_conv_weight
+
+    lib = emu()
+    x = torch.from_numpy(detgen.uniform((B, C1, H, W), -1, 1, name="sx")).half().float()
+    w = torch.from_numpy(detgen.uniform((C2, C1, k, k), -0.3, 0.3, name="sw")).half().float()
+    b = torch.zeros(C2)
+    p = k // 2
+    xa = aligned((B, H, W, C1), np.float16); xa[...] = x.permute(0, 2, 3, 1).numpy().astype(np.float16)
+    wp, bp, K, Kpad, Npad = pack_conv_weight(w, b, torch.float16)
+    wa = aligned(wp.shape, np.float16); wa[...] = wp.numpy()
+    ba = aligned(bp.shape, np.float32); ba[...] = bp.numpy()
+    npix = B * H * W
+    d = _lib.ConvDesc(dtype=_lib.Y5_F16, B=B, H=H, W=W, C1=C1, ldx=C1, OH=H, OW=W, C2=C2, ldy=C2, KH=k, KW=k, SH=1, SW=1, PH=p, PW=p, act=0,
+                      Kpad=Kpad, Npad=Npad, ldr=0, ld2=0, cfg=cfg, max_blocks=mb)
+    z0 = aligned((npix, C2), np.float16, 5.0)
+    assert lib.y5_conv2d_fwd(C.byref(d), ptr(xa), ptr(wa), ptr(ba), None, ptr(z0), None, None) == 0, lib.y5_last_error()
+    z1 = aligned((npix, C2), np.float16, 5.0)
+    part = aligned((64 * 2 * C2,), np.float32, np.nan)
+    rows = C.c_int(0)
+    rc = lib.y5_conv2d_fwd_stats(C.byref(d), ptr(xa), ptr(wa), ptr(ba), ptr(z1), ptr(part), part.nbytes, C.byref(rows), None)
+    assert rc == 0, lib.y5_last_error()
+    assert np.array_equal(z0, z1) and 1 <= rows.value <= 64
+    pr = part[:rows.value * 2 * C2].reshape(rows.value, 2, C2).astype(np.float64)
+    zf = z1.astype(np.float64)
+    np.testing.assert_allclose(pr[:, 0].sum(0), zf.sum(0), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(pr[:, 1].sum(0), (zf * zf).sum(0), rtol=1e-5, atol=1e-3)
+    g = aligned((C2,), np.float32); g[...] = detgen.uniform((C2,), 0.5, 1.5, name="sg")
+    be = aligned((C2,), np.float32); be[...] = detgen.uniform((C2,), -0.5, 0.5, name="sb")
+    outs = []
+    for fused in (False, True):
+        rm = aligned((C2,), np.float32, 0.0); rv = aligned((C2,), np.float32, 1.0)
+        sm = aligned((C2,), np.float32); si = aligned((C2,), np.float32)
+        y = aligned((npix, C2), np.float16, -7.0)
+        if fused:
+            rc = lib.y5_bn_silu_fwd_from_partials(ptr(z1), _lib.Y5_F16, npix, C2, C2, ptr(g), ptr(be), 1e-3, 0.03, ptr(rm), ptr(rv), ptr(sm), ptr(si),
+                                                  ptr(part), rows.value, None, 0, ptr(y), C2, None)
+        else:
+            nws = lib.y5_bn_workspace_bytes(C2, npix)
+            ws = aligned((nws,), np.uint8)
+            rc = lib.y5_bn_silu_fwd(ptr(z1), _lib.Y5_F16, npix, C2, C2, ptr(g), ptr(be), 1e-3, 0.03, ptr(rm), ptr(rv), ptr(sm), ptr(si), None, 0,
+                                    ptr(y), C2, ptr(ws), nws, None)
+        assert rc == 0, lib.y5_last_error()
+        outs.append((sm.copy(), si.copy(), rm.copy(), rv.copy(), y.astype(np.float32)))
+    for u, v in zip(outs[0][:4], outs[1][:4]):
+        np.testing.assert_allclose(u, v, rtol=2e-6, atol=1e-7)
+    assert np.abs(outs[0][4] - outs[1][4]).max() <= 2e-3   # (y in fp16: one ulp where the statistics differ in their last bit)
+    # configurations that cannot carry the statistics say so instead of silently skipping them
+    d2 = _lib.ConvDesc.from_buffer_copy(d); d2.cfg = 2
+    assert lib.y5_conv2d_fwd_stats(C.byref(d2), ptr(xa), ptr(wa), ptr(ba), ptr(z1), ptr(part), part.nbytes, C.byref(rows), None) == _lib.Y5_ERR_UNSUPPORTED

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("Y5_LIB_PATH") or os.path.join(_HERE, "libyolov5_hip.so")  # override: kernel experiments only
 
 Y5_F16, Y5_F32, Y5_U8 = 0, 1, 2
+Y5_OK, Y5_ERR_BAD_ARG, Y5_ERR_UNSUPPORTED, Y5_ERR_RUNTIME, Y5_ERR_WORKSPACE = 0, -1, -2, -3, -4   # y5_status (include/yolov5_hip.h)
 NMS_MULTI_LABEL, NMS_AGNOSTIC = 1, 2
 
 
@@ -128,6 +129,11 @@ EXPORTS = {
                                C.c_void_p, C.c_int, C.c_void_p]),
     "y5_tta_descale": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     "y5_bn_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "y5_conv2d_fwd_stats": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int),
+                                     C.c_void_p]),
+    "y5_bn_silu_fwd_from_partials": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                               C.c_int, C.c_void_p]),
     "y5_bn_silu_fwd_from_sums": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_void_p,
                                            C.c_int, C.c_void_p]),

@@ -120,6 +120,32 @@ extern "C" int y5_bn_silu_fwd_from_sums(const void* z, int dt, long long npix, i
   return y5_check_launch("y5_bn_silu_fwd_from_sums");
 }
 
+// Forward of BatchNorm + SiLU when the convolution that produced z already left the per-workgroup partial sums (y5_conv2d_fwd_stats): the fixed-order
+// finish over `rows` partial rows [2][C], then the apply pass -- the statistics pass over z is gone.
+extern "C" int y5_bn_silu_fwd_from_partials(const void* z, int dt, long long npix, int C, int ldz, const float* gamma, const float* beta, float eps,
+                                            float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                                            const float* partial, int rows, const void* residual, int ldr, void* y, int ldy, void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (dt != Y5_F16 && dt != Y5_F32) return y5_fail(Y5_ERR_BAD_ARG, "bn: dtype must be Y5_F16 or Y5_F32");
+  const int vec = dt == Y5_F16 ? 8 : 4;
+  if (npix < 1 || rows < 1 || C < vec || C % vec || C / vec > 256) return y5_fail(Y5_ERR_BAD_ARG, "bn_silu_fwd_from_partials: bad npix / rows / C");
+  if (!z || !gamma || !beta || !save_mean || !save_invstd || !partial || !y) return y5_fail(Y5_ERR_BAD_ARG, "bn_silu_fwd_from_partials: null pointer");
+  Y5BnParams p{};
+  p.z = z; p.res = residual; p.out = y; p.gamma = gamma; p.beta = beta; p.mean = save_mean; p.invstd = save_invstd;
+  p.running_mean = running_mean; p.running_var = running_var; p.partial = const_cast<float*>(partial);
+  p.npix = npix; p.C = C; p.ldz = ldz; p.ldr = ldr; p.ldo = ldy; p.nblk = rows; p.eps = eps; p.momentum = momentum;
+  hipLaunchKernelGGL(y5_bn_finish_kernel<0>, dim3((unsigned)C), dim3(128), 2 * 128 * 8, st, p);
+  const dim3 g(apply_grid(npix, C, dt));
+  if (dt == Y5_F16) {
+    if (residual) hipLaunchKernelGGL((y5_bn_silu_apply_kernel<half_t, true>), g, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((y5_bn_silu_apply_kernel<half_t, false>), g, dim3(256), 0, st, p);
+  } else {
+    if (residual) hipLaunchKernelGGL((y5_bn_silu_apply_kernel<float, true>), g, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((y5_bn_silu_apply_kernel<float, false>), g, dim3(256), 0, st, p);
+  }
+  return y5_check_launch("y5_bn_silu_fwd_from_partials");
+}
+
 extern "C" int y5_bn_bwd_stats(const void* dy, int ld_dy, const void* z, int ldz, int dt, long long npix, int C, const float* gamma, const float* beta,
                                const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t st = static_cast<hipStream_t>(stream_);

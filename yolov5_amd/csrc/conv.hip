@@ -244,6 +244,10 @@ int launch_pw_v(const Y5ConvParams& p, int max_blocks, hipStream_t stream) {
   }
   if (G > nbt) G = nbt;
   if (G >= 8) G &= ~7LL;
+  if (p.bn_partial) {
+    if ((size_t)G * 2 * p.C2 * 4 > p.bn_bytes) return y5_fail(Y5_ERR_WORKSPACE, "conv_fwd_stats: partial buffer too small for this grid");
+    *p.bn_rows = (int)G;
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(NWV * 64), lds, stream, p);
   return y5_check_launch("y5_conv2d_fwd(pw)");
 }
@@ -315,6 +319,10 @@ int launch_k3_v(const Y5ConvParams& p, int max_blocks, hipStream_t stream) {
   }
   if (G > nbt) G = nbt;
   if (G >= 8) G &= ~7LL;
+  if (p.bn_partial) {
+    if ((size_t)G * 2 * p.C2 * 4 > p.bn_bytes) return y5_fail(Y5_ERR_WORKSPACE, "conv_fwd_stats: partial buffer too small for this grid");
+    *p.bn_rows = (int)G;
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(NWV * 64), lds, stream, p);
   return y5_check_launch("y5_conv2d_fwd(k3)");
 }
@@ -446,8 +454,25 @@ extern "C" int y5_conv_cfg_info(int cfg, int* bm, int* bn, int* bk_bytes) {
   return Y5_OK;
 }
 
+static int conv2d_fwd_impl(const y5_conv_desc* d, const void* x, const void* w_packed, const float* bias, const void* residual, void* y, void* y_up2,
+                           float* stats_partial, size_t stats_bytes, int* stats_rows, void* stream_);
+
 extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                              const void* residual, void* y, void* y_up2, void* stream_) {
+  return conv2d_fwd_impl(d, x, w_packed, bias, residual, y, y_up2, nullptr, 0, nullptr, stream_);
+}
+
+// Train-mode forward of a Conv block's convolution (models/common.py:82-88: act(bn(conv(x))), conv without bias / activation) that ALSO leaves the
+// per-channel batch statistics of its output as per-workgroup partials -- see include/yolov5_hip.h
+extern "C" int y5_conv2d_fwd_stats(const y5_conv_desc* d, const void* x, const void* w_packed, const float* bias, void* y, float* partial,
+                                   size_t partial_bytes, int* rows, void* stream_) {
+  if (!partial || !rows || ((uintptr_t)partial & 15)) return y5_fail(Y5_ERR_BAD_ARG, "conv_fwd_stats: partial / rows must be given (partial 16-byte aligned)");
+  *rows = 0;
+  return conv2d_fwd_impl(d, x, w_packed, bias, nullptr, y, nullptr, partial, partial_bytes, rows, stream_);
+}
+
+static int conv2d_fwd_impl(const y5_conv_desc* d, const void* x, const void* w_packed, const float* bias, const void* residual, void* y, void* y_up2,
+                           float* stats_partial, size_t stats_bytes, int* stats_rows, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (!d || !x || !w_packed || !bias || (!y && !y_up2)) return y5_fail(Y5_ERR_BAD_ARG, "conv: null pointer");
   const int es = d->dtype == Y5_F16 ? 2 : d->dtype == Y5_F32 ? 4 : 0;
@@ -520,6 +545,11 @@ extern "C" int y5_conv2d_fwd(const y5_conv_desc* d, const void* x, const void* w
   if (placed && (pw || k3 || h3)) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: output placement needs a general implicit-GEMM configuration");
   p.x_bytes = (unsigned)((((long long)d->B * d->H * d->W - 1) * d->ldx + d->C1) * es);
   p.w_bytes = (unsigned)((long long)d->Npad * d->Kpad * es);
+  if (stats_partial) {   // fused BatchNorm statistics: the act = 0 instantiations of the streaming kernels carry them
+    if (!(pw || k3) || d->act || d->dtype != Y5_F16 || d->split_n || placed || !y)
+      return y5_fail(Y5_ERR_UNSUPPORTED, "conv_fwd_stats: needs a streaming pointwise / 3x3 configuration, fp16, act = 0, one destination");
+    p.bn_partial = stats_partial; p.bn_bytes = stats_bytes; p.bn_rows = stats_rows;
+  }
 
   if (h3) {
     if (d->dtype != Y5_F16 || d->KH != 3 || d->KW != 3 || d->SH != 1 || d->SW != 1 || d->PH != 1 || d->PW != 1 || !y || y_up2 || d->C1 % 32 ||

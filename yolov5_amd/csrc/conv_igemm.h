@@ -69,6 +69,10 @@ struct Y5ConvParams {
   // loader decomposes every staged row's pixel index once per tile -- two ~40-instruction division sequences per row otherwise
   unsigned dv_ohw_m, dv_ow_m;
   int dv_ohw_s, dv_ow_s;   // sh1 | sh2 << 8
+  // y5_conv2d_fwd_stats (train-mode forward, act = 0, streaming kernels): one row [2][C2] of per-channel (sum z, sum z^2) per workgroup (y5_common.h Y5StatAcc)
+  float* bn_partial;
+  size_t bn_bytes;         // host side: capacity of bn_partial
+  int* bn_rows;            // host side: receives the number of rows (= grid size) of this launch
 };
 
 __host__ __device__ inline void y5_fastdiv_make(unsigned d, unsigned* m, int* s) {

@@ -141,6 +141,9 @@ void y5_conv_k3_kernel(const Y5ConvParams p) {
     y5_wait_vm<0>();  // retired here, ahead of the counted-vmcnt ring: none of these loads may sit in the queue the tile loop counts
   }
   const int orow = lane / SPR, oslot = lane % SPR;
+  constexpr bool STATS = !ACT && !RES && NT2 == 0;   // act = 0 instantiations: optional BatchNorm statistics of the train-mode forward (p.bn_partial)
+  Y5StatAcc stat[1];
+  if constexpr (STATS) stat[0].clear();
   const int orow2 = lane / SPR2, oslot2 = lane % SPR2;
   T* __restrict__ y2g = static_cast<T*>(p.y2);
 
@@ -316,6 +319,9 @@ void y5_conv_k3_kernel(const Y5ConvParams p) {
       }
       const size_t m = ((size_t)b * p.OH + oh0 + (row >> 3)) * p.OW + ow0 + (row & 7);
       const int n = oslot * 8;
+      if constexpr (STATS) {
+        if (p.bn_partial) stat[0].add(raw);   // (a wave tile is 4 x 8 real pixels: H % 4 == 0, W % 8 == 0)
+      }
       if (n < p.C2) *reinterpret_cast<uint4_t*>(yg + m * p.ldy + n) = raw;
     }
     }
@@ -330,6 +336,12 @@ void y5_conv_k3_kernel(const Y5ConvParams p) {
     const unsigned long long k_t5 = __builtin_amdgcn_s_memtime();
     d_wait += k_t1 - k_t0; d_res += k_t2 - k_t1; d_mfma += k_t3 - k_t2; d_epi += k_t4 - k_t3; d_issue += k_t5 - k_t4;
 #endif
+  }
+  if constexpr (STATS) {
+    if (p.bn_partial) {   // (kernel-uniform) every wave's ring is idle: its first stage carries the wave's sums to the cross-wave addition
+      y5_wait_vm<0>();
+      y5_stat_flush<SPR, 1, NWV>(stat, lane, tid, ring, smem + W_BYTES + NPAD * 4 + NPAD2 * (K2B + 4), S * STAGE, p.bn_partial + (size_t)blockIdx.x * 2 * p.C2, p.C2);
+    }
   }
 #ifdef Y5_K3_TIMING
   if (lane == 0 && blockIdx.x == 0) {

@@ -110,6 +110,12 @@ __device__ __forceinline__ void y5_conv_pw_body(const Y5ConvParams& p, const Y5H
   const int g = lane >> 5, frow = lane & 31;
   const int fsw = Y5ConvGeom<T, RB>::swz(frow);
   const int orow = lane / SPR, oslot = lane % SPR;
+  constexpr bool STATS = !ACT && !DEC && !UP2;   // the act = 0 instantiations serve the train-mode forward: optional BatchNorm statistics (p.bn_partial)
+  Y5StatAcc stat[STATS ? OS : 1];
+  if constexpr (STATS) {
+#pragma unroll
+    for (int h = 0; h < OS; ++h) stat[h].clear();
+  }
 
   for (int s = 0; s < S; ++s)
     if (s < nw) issue(s, s);
@@ -246,6 +252,9 @@ __device__ __forceinline__ void y5_conv_pw_body(const Y5ConvParams& p, const Y5H
         const int row = ps * RPP + orow;
         const uint4_t raw = *reinterpret_cast<const uint4_t*>(st + row * (NPH * 2) + ((oslot ^ (row & SWM)) * 16));
         const int m = m0 + row, n = h * NPH + oslot * 8;
+        if constexpr (STATS) {
+          if (p.bn_partial) stat[h].add(raw);   // (rows are always real pixels: M % 32 == 0; padded channels are dropped at the flush)
+        }
         if (n < p.C2) {
           if (!UP2 && p.split_n) {
             T* d = n < p.split_n ? yg + (size_t)m * p.ldy + n : y2g + (size_t)m * p.ld2 + (n - p.split_n);
@@ -273,6 +282,12 @@ __device__ __forceinline__ void y5_conv_pw_body(const Y5ConvParams& p, const Y5H
     // ---- refill the vacated stage with tile i+S ----
     if (i + S < nw) issue(i + S, buf);
     buf = buf + 1 == S ? 0 : buf + 1;
+  }
+  if constexpr (STATS) {
+    if (p.bn_partial) {   // (kernel-uniform) every wave's ring is idle: its first stage carries the wave's sums to the cross-wave addition
+      y5_wait_vm<0>();
+      y5_stat_flush<SPR, OS, NWV>(stat, lane, tid, ring, smem + W_BYTES + NPAD * 4, S * STAGE, p.bn_partial + (size_t)blockIdx.x * 2 * p.C2, p.C2);
+    }
   }
 }
 

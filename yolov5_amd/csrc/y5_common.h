@@ -113,3 +113,48 @@ __device__ __forceinline__ void y5_static_for(F&& f) {
     y5_static_for<B + 1, E>(f);
   }
 }
+
+// ---- BatchNorm batch statistics in the epilogue of the convolution that produces z (models/common.py:82-88 train mode: act(bn(conv(x)))) ----------------
+// The separate statistics pass (bn_kernels.h y5_chan_reduce_kernel<0>) re-reads every z the convolution has just written; the streaming kernels of the
+// high-resolution levels (conv_pw.h, conv_k3.h) are HBM-bound with idle vector pipes, and after their LDS-transposed epilogue every lane holds eight
+// consecutive channels of one pixel -- the SAME eight channels for every store pass and every tile it ever processes.  So a lane keeps sum z and sum z^2
+// of its channel octet in registers over the whole launch (16 FMAs per 16-byte store, on the fp16-ROUNDED values: what the statistics pass would read),
+// and at kernel end the lanes sharing an octet, then the waves, are added in a fixed order: one row [2][C] of partials per workgroup -- deterministic, and
+// exactly the input format of y5_bn_finish_kernel.
+struct Y5StatAcc {
+  float s0[8], s1[8];
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
+  }
+  __device__ __forceinline__ void add(uint4_t raw) {
+    const half8_t h = __builtin_bit_cast(half8_t, raw);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float z = (float)h[e]; s0[e] += z; s1[e] += z * z; }
+  }
+};
+// SPR lanes (lane % SPR = octet index) x 64 / SPR rows; G groups of SPR octets (channels g * SPR * 8 + ...).  wave_slot: >= 2 * NCH floats of LDS owned by
+// this wave (NCH = G * SPR * 8), slot_stride: bytes between the slots of consecutive waves.  Must be reached by EVERY wave of the workgroup.
+template <int SPR, int G, int NWV>
+__device__ __forceinline__ void y5_stat_flush(Y5StatAcc (&acc)[G], int lane, int tid, char* wave_slot, const char* slot0, int slot_stride, float* partial_row, int C) {
+  constexpr int NCH = G * SPR * 8;
+  float* mine = reinterpret_cast<float*>(wave_slot);
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = acc[g].s0[e], b = acc[g].s1[e];
+#pragma unroll
+      for (int m = SPR; m < 64; m <<= 1) { a += __shfl(a, lane ^ m); b += __shfl(b, lane ^ m); }   // (xor butterfly: every lane ends with the same sum)
+      if (lane < SPR) { mine[(g * SPR + lane) * 8 + e] = a; mine[NCH + (g * SPR + lane) * 8 + e] = b; }
+    }
+  }
+  __syncthreads();
+  for (int o = tid; o < 2 * NCH; o += NWV * 64) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) s += reinterpret_cast<const float*>(slot0 + w * slot_stride)[o];
+    const int which = o / NCH, c = o - which * NCH;
+    if (c < C) partial_row[which * C + c] = s;
+  }
+}

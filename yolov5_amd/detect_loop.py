@@ -75,7 +75,10 @@ class DetectPipeline:
         host wake-up gap came back -- profiles/r02/r02_pipeline_ab.log.)  Forward i+1 writes a different z block and the engine's other
         objectness plane, and forward i+2 is only enqueued after batch i has been collected, so nothing the NMS reads is overwritten under it."""
 
-    def __init__(self, model, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, max_det=1000, nm=0, overlap=True):
+    def __init__(self, model, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, max_det=1000, nm=0, overlap=None):
+        import os
+        if overlap is None:
+            overlap = os.environ.get("Y5_PIPE_OVERLAP", "1") != "0"   # A/B switch: 0 = the NMS chain stays on the caller's stream
         self.model = model
         self.kw = dict(conf_thres=conf_thres, iou_thres=iou_thres, classes=classes, agnostic=agnostic, max_det=max_det, nm=nm)
         self.overlap = overlap

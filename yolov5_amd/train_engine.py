@@ -119,6 +119,11 @@ class TrainEngine:
         self.dwflat = self.be.empty((max(self._dw_total, 64),), torch.float32)  # packed fp32 dW accumulators of all convs
         self.ws = self.be.empty((max(max_ws, 256),), torch.uint8)
         self.ws_bytes = max(max_ws, 256)
+        # BatchNorm statistics from the convolution's epilogue (y5_conv2d_fwd_stats: one partial row per workgroup, <= 8 workgroups per CU x 256 channels);
+        # Y5_BN_FUSED_STATS=0 keeps the separate statistics pass everywhere
+        self.fused_stats = self.dtype == torch.float16 and os.environ.get("Y5_BN_FUSED_STATS", "1") != "0"
+        self.stats_ws_bytes = 8 * 256 * 8 * 2 * 256 * 4 // 8
+        self.stats_ws = self.be.empty((self.stats_ws_bytes,), torch.uint8) if self.fused_stats else None
 
     # ---- helpers ---------------------------------------------------------------------------------------------------
     def _ptr(self, t: TRef, grad=False):
@@ -340,18 +345,37 @@ class TrainEngine:
         if st["fcfg"] < 0 and getattr(be, "autotune", False):
             st["fcfg"] = d.cfg = autotune_conv(lib, d, ptrs, stm)
         xp, xdt = getattr(self, "_x_nchw", (0, -1))
+        stats_rows = 0
         if st["stem_w"] is not None and xdt == _lib.Y5_F16 and xp % 16 == 0:
             _lib.check(lib.y5_conv_stem_fwd_raw(_vp(xp), B, self.x_shape[2], self.x_shape[3], _vp(be.ptr(st["stem_w"])), c2, st["stem_np"], _vp(out_ptr), ldo,
                                                 0, stm), lib)
         else:
-            _lib.check(lib.y5_conv2d_fwd(C.byref(d), *ptrs, stm), lib)
+            if self.fused_stats and st["has_bn"] and st.get("stats_ok", True) and self._sync_world(st["mod"].bn) == 1:
+                # the streaming kernels of P1-P3 leave sum z / sum z^2 per workgroup beside z: no statistics pass over z (models/common.py:82-88)
+                rows = C.c_int(0)
+                rc = lib.y5_conv2d_fwd_stats(C.byref(d), ptrs[0], ptrs[1], ptrs[2], ptrs[4], _vp(be.ptr(self.stats_ws)), self.stats_ws_bytes, C.byref(rows), stm)
+                if os.environ.get("Y5_STATS_DEBUG") == "1" and "stats_ok" not in st:
+                    print(f"[stats] {op['name']:16s} cfg {d.cfg:3d} {'fused' if rc == 0 else 'separate pass'}  z {B * y.H * y.W * c2 * 2 / 1e6:.0f} MB", flush=True)
+                if rc == _lib.Y5_ERR_UNSUPPORTED:
+                    st["stats_ok"] = False   # this layer's configuration is not a streaming kernel: separate pass, decided once
+                else:
+                    _lib.check(rc, lib)
+                    st["stats_ok"], stats_rows = True, rows.value
+            if not stats_rows:
+                _lib.check(lib.y5_conv2d_fwd(C.byref(d), *ptrs, stm), lib)
         if st["has_bn"]:
             bn = st["mod"].bn
             npix = B * y.H * y.W
             st["gamma"], st["beta"] = self._f32(bn.weight), self._f32(bn.bias)
             rm, rv = self._running(bn)
             world = self._sync_world(bn)
-            if world > 1:
+            if stats_rows:
+                _lib.check(lib.y5_bn_silu_fwd_from_partials(_vp(be.ptr(st["z"])), self.dt, npix, c2, c2, _vp(st["gamma"]), _vp(st["beta"]), float(bn.eps),
+                                                            float(bn.momentum if bn.momentum is not None else 0.1), rm, rv, _vp(be.ptr(st["mean"])),
+                                                            _vp(be.ptr(st["invstd"])), _vp(be.ptr(self.stats_ws)), stats_rows,
+                                                            _vp(self._ptr(res)) if res is not None else None, self._ld(res) if res is not None else 0,
+                                                            _vp(self._ptr(y)), self._ld(y), stm), lib)
+            elif world > 1:
                 # SyncBatchNorm (train.py:269-271): per-channel sum z / sum z^2 of this rank, all-reduce(SUM) over the ranks (2 C doubles; torch's
                 # SyncBatchNorm all-gathers mean / invstd / count per layer at the same point), statistics of the GLOBAL batch, then the apply pass
                 sums = st.get("sums")
