@@ -191,7 +191,7 @@ def conv_family(cfg):
         return {"front": "y5_conv_front_kernel", "bneck": "y5_conv_bneck_kernel"}.get(cfg, "y5_conv_" + cfg + "_kernel")
     if cfg is None or cfg < 0:
         return None
-    if cfg >= 84 or cfg == 56 or 14 <= cfg < 22:
+    if 84 <= cfg < 88 or cfg == 56 or 14 <= cfg < 22:   # (88 / 89 = the virtual Upsample + Concat loader: implicit-GEMM instantiations)
         return "y5_conv_pw_kernel"
     if 78 <= cfg < 84 or 30 <= cfg < 35:
         return "y5_conv_k3_kernel"

@@ -37,6 +37,7 @@ for f in glob.glob('gpurun_out/pmcm_*/**/*counter_collection.csv', recursive=Tru
             dur[k] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-3   # us, pass 1 (the pass the busy counters come from)
 conv = lambda k: any(s in k for s in ('conv_igemm', 'conv_h3', 'conv_pw', 'conv_k3', 'conv_stem', 'conv_bneck', 'conv_front', 'conv_c3'))
 NSIMD = 1024.0
+MAX_GHZ = 2.4   # data-sheet shader clock of the part: no kernel can have had more cycles than duration x this
 def util(d):
     gui = d.get('GRBM_GUI_ACTIVE', 0.0)
     cyc = d.get('SQ_BUSY_CYCLES', 0.0) / 32.0          # SQ_BUSY_CYCLES is summed over the 32 shader engines
@@ -51,9 +52,19 @@ for k, d in tot.items():
     wc = d.get('SQ_WAVE_CYCLES', 0) or 1
     mf = d.get('SQ_INSTS_MFMA', 0)
     u, cyc = util(d)
+    #  the cycle denominator is only trusted while it implies a clock the part can run at; otherwise -- and always as a second
+    # figure -- utilisation against the cycles the kernel's DURATION allows at the maximum clock (a lower bound on the true busy fraction)
+    ghz = cyc / max(dur[k], 1e-9) * 1e-3 if cyc else None
+    cyc_time = dur[k] * 1e-6 * MAX_GHZ * 1e9
+    u_time = d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (NSIMD * cyc_time) if cyc_time > 0 else None
+    plausible = ghz is not None and ghz <= 2.45
+    if not plausible:
+        u, cyc = u_time, cyc_time
     out.append({"kernel": k[:140], "conv": conv(k), "launches_per_forward": round(cnt[k] / N, 1), "us_per_forward_under_pmc": round(dur[k] / N, 1),
                 "waves_per_launch": round(w / max(cnt[k], 1)), "mfma_busy_frac": round(u, 4) if u is not None else None,
-                "effective_clock_ghz": round(cyc / max(dur[k], 1e-9) * 1e-3, 3) if cyc else None,
+                "mfma_busy_frac_vs_duration_at_max_clock": round(u_time, 4) if u_time is not None else None,
+                "effective_clock_ghz": round(ghz, 3) if ghz else None, "cycle_counter_plausible": plausible,
+                "lds_busy_frac": round(d.get('SQ_LDS_IDX_ACTIVE', 0.0) / (256.0 * cyc), 4) if cyc else None,
                 "valu_per_wave": round(d.get('SQ_INSTS_VALU', 0) / w), "mfma_per_wave": round(mf / w), "lds_per_wave": round(d.get('SQ_INSTS_LDS', 0) / w),
                 "vmem_per_wave": round(d.get('SQ_INSTS_VMEM', 0) / w), "salu_per_wave": round(d.get('SQ_INSTS_SALU', 0) / w),
                 "valu_per_mfma": round(d.get('SQ_INSTS_VALU', 0) / mf, 2) if mf else None, "salu_per_mfma": round(d.get('SQ_INSTS_SALU', 0) / mf, 2) if mf else None,
@@ -64,16 +75,21 @@ for k, d in tot.items():
 out.sort(key=lambda r: -r["us_per_forward_under_pmc"])
 ck = [k for k in tot if conv(k)]
 busy = sum(tot[k].get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) for k in ck)
-cycles = sum(util(tot[k])[1] for k in ck)
+def kcycles(k):   # per kernel: the counter's cycles where they imply a possible clock, the duration at the maximum clock otherwise
+    c = util(tot[k])[1]
+    return c if c and c / max(dur[k], 1e-9) * 1e-3 <= 2.45 else dur[k] * 1e-6 * MAX_GHZ * 1e9
+cycles = sum(kcycles(k) for k in ck)
 import bench
 res = {"forwards": N, "kernel_src_sha16": bench.kernel_src_hash(),
-       "stack": {"mfma_busy_frac": round(busy / (NSIMD * cycles), 4) if cycles else None, "conv_us_per_forward_under_pmc": round(sum(dur[k] for k in ck) / N, 1),
+       "stack": {"mfma_busy_frac": round(busy / (NSIMD * cycles), 4) if cycles else None,
+                 "mfma_busy_frac_vs_duration_at_max_clock": round(busy / (NSIMD * sum(dur[k] for k in ck) * 1e-6 * MAX_GHZ * 1e9), 4) if ck else None, "conv_us_per_forward_under_pmc": round(sum(dur[k] for k in ck) / N, 1),
                  "mfma_busy_cycles_per_forward": busy / N, "kernel_cycles_per_forward": cycles / N,
                  "definition": "sum over the conv launches of one forward of SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x sum of their kernel cycles); profiled passes "
                                "serialise the launches, so this is the utilisation INSIDE the kernels (no launch gaps)"},
        "kernels": out}
 json.dump(res, open('gpurun_out/pmc_issue_mix.json', 'w'), indent=1)
 print(json.dumps(res["stack"]))
-for r in out[:16]: print({k: r[k] for k in ("kernel", "launches_per_forward", "us_per_forward_under_pmc", "mfma_busy_frac", "effective_clock_ghz", "valu_per_mfma", "salu_per_mfma", "lds_per_mfma", "wait_inst_over_wave_cycles", "lds_bank_conflict_over_lds_active")})
+assert all(r["effective_clock_ghz"] is None or r["effective_clock_ghz"] <= 2.45 or not r["cycle_counter_plausible"] for r in out)
+for r in out[:16]: print({k: r[k] for k in ("kernel", "launches_per_forward", "us_per_forward_under_pmc", "mfma_busy_frac", "mfma_busy_frac_vs_duration_at_max_clock", "lds_busy_frac", "effective_clock_ghz", "valu_per_mfma", "salu_per_mfma", "lds_per_mfma", "wait_inst_over_wave_cycles", "lds_bank_conflict_over_lds_active")})
 PY
 find gpurun_out/pmcm_* -name "*.csv" -size +5M -delete

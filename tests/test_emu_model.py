@@ -126,8 +126,8 @@ def test_virtual_upsample_concat_plan_same_outputs(monkeypatch):
     plain = Engine(m, (2, 3, 64, 64), torch.float16, "cpu", want_raw=True, backend=EmuBackend())
     monkeypatch.setenv("Y5_VIRTUAL_UP", "1")
     virt = Engine(m, (2, 3, 64, 64), torch.float16, "cpu", want_raw=True, backend=EmuBackend())
-    ups = [o["name"] for o in virt.spec.ops if o.get("op") == "conv" and o.get("up") is not None]
-    assert ups == ["13.C3.cv1+cv2", "17.C3.cv1+cv2"] and not any(o.get("up") for o in plain.spec.ops if o.get("op") == "conv")
+    ups = [o["name"] for o in virt.spec.ops if o.get("op") == "conv" and o.get("x_up") is not None]
+    assert ups == ["13.C3.cv1+cv2", "17.C3.cv1+cv2"] and not any(o.get("x_up") for o in plain.spec.ops if o.get("op") == "conv")
     rep = lambda e: [o["name"] for o in e.spec.ops if o.get("op") == "conv" and o.get("y2") is not None and not o.get("split_n")]  # noqa: E731
     assert rep(plain) == ["10.Conv", "14.Conv"] and rep(virt) == []
     a, b = plain(x), virt(x)

@@ -61,8 +61,12 @@ def test_fp32_forward_matches_reference_at_full_resolution(name, dev):
     # that noise is far below the north-star bound (the round-4 yolov5x fixture: 8.7e-6 of the box size at its worst row), another summation order
     # of a 200-layer network may land at 2e-5 without being any less a correct fp32 forward; the floor is a quarter of the 1e-4 contract for the
     # worst row and a tenth of it for the mean
-    assert hb.max() <= max(2.0 * rb.max(), 2.5e-5) + 1e-6 and hc.max() <= max(2.0 * rc.max(), 2.5e-5) + 1e-6, (name, hb.max(), rb.max(), hc.max(), rc.max())
-    assert hb.mean() <= max(2.0 * rb.mean(), 1e-5) + 1e-8 and hc.mean() <= max(2.0 * rc.mean(), 1e-5) + 1e-8, (name, hb.mean(), rb.mean(), hc.mean(), rc.mean())
+    # (the floor applies to the yolov5x fixture only -- the other fixtures keep the plain "2x the reference's own noise" criterion -- and the
+    # measured ratio rides on the assert message)
+    fmax, fmean = (2.5e-5, 1e-5) if name.startswith("yolov5x") else (0.0, 0.0)
+    ratios = f"{name}: box max {hb.max():.3g} = {hb.max() / max(rb.max(), 1e-30):.2f}x reference fp32 noise {rb.max():.3g}; score max {hc.max():.3g} = {hc.max() / max(rc.max(), 1e-30):.2f}x {rc.max():.3g}"
+    assert hb.max() <= max(2.0 * rb.max(), fmax) + 1e-6 and hc.max() <= max(2.0 * rc.max(), fmax) + 1e-6, ratios
+    assert hb.mean() <= max(2.0 * rb.mean(), fmean) + 1e-8 and hc.mean() <= max(2.0 * rc.mean(), fmean) + 1e-8, (ratios, hb.mean(), rb.mean(), hc.mean(), rc.mean())
     # against the reference's fp32 output itself: the north-star 1e-4 (boxes relative to box size, scores absolute) wherever the
     # reference's own fp32 noise is below it, 3x that noise otherwise (|hip - ref32| <= |hip - ref64| + |ref32 - ref64|)
     eb, ec = _errs(rows, ref32)

@@ -31,6 +31,9 @@ int launch_bneck(const Y5BneckParams& p, int max_blocks, hipStream_t stream) {
   }
   if (G > nbt) G = nbt;
   if (G >= 8) G &= ~7LL;
+  //  the kernel assumes that only a workgroup's LAST tile can be the partial one; with the XCD remap that holds for grids that are a multiple
+  // of eight or cover every tile -- an explicit cap of 1..7 below the tile count would put the partial block-tile mid-sequence
+  if (G < 8 && G < nbt && nbt >= 8 && nwt % NWV != 0) return y5_fail(Y5_ERR_UNSUPPORTED, "bottleneck: a grid cap below 8 needs a wave-tile count that is a multiple of the waves per workgroup");
   hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(NWV * 64), lds, stream, p);
   return y5_check_launch("y5_bottleneck_fwd");
 }

@@ -114,7 +114,7 @@ class _Planner:
                   split_n=0 if split is None else split[0])
         if x_up is not None:   # (low-resolution TRef, channels): input channels [0, c_up) are read from it at (oh >> 1, ow >> 1)
             assert k == (1, 1) and s == (1, 1) and p == (0, 0) and res is None and (up2 is None or split is not None), name
-            op["up"] = x_up
+            op["x_up"], op["up_c"] = x_up   # (TRef at the top level of the op: the "no other reader of this buffer" scans of the fusion races see it)
         if emit:
             self.spec.ops.append(op)
             return dest
@@ -448,6 +448,7 @@ def autotune_conv(lib, d, ptrs, st, exclude=()):
         if part:
             lo, _, hi = part.partition("-")
             skip.update(range(int(lo), int(hi or lo) + 1))
+    timed = []
     for cfg in range(ncfg):
         if cfg in skip or cfg in exclude:
             continue
@@ -458,13 +459,29 @@ def autotune_conv(lib, d, ptrs, st, exclude=()):
         rc = lib.y5_conv2d_time(C.byref(d), *ptrs, iters, st, C.byref(ms))
         if rc != 0:
             continue  # configuration not applicable to this shape
-        if ms.value < best_ms:
-            second, second_ms = best, best_ms
-            best, best_ms = cfg, ms.value
-        elif ms.value < second_ms:
-            second, second_ms = cfg, ms.value
-    if best < 0:
+        timed.append((ms.value, cfg))
+    if not timed:
         _lib.check(-2, lib)
+    # Reproducible choices at near ties (three runs of one build gave three plans): the front-runners of the coarse pass are timed
+    # again with 4x the iterations, in ascending id order, and a configuration only displaces one with a LOWER id when it is faster by more than the
+    # hysteresis (Y5_TUNE_HYST, 2 %) -- launch-to-launch noise of these timings is about 1 %
+    hyst = float(os.environ.get("Y5_TUNE_HYST", "0.02"))
+    timed.sort()
+    finals = sorted(cfg for t, cfg in timed[:4] if t <= timed[0][0] * 1.10)
+    for cfg in finals:
+        d.cfg = cfg
+        if lib.y5_conv2d_time(C.byref(d), *ptrs, 4 * iters, st, C.byref(ms)) != 0:
+            continue
+        t = ms.value
+        if t < best_ms * (1.0 - hyst):
+            second, second_ms = best, best_ms
+            best, best_ms = cfg, t
+        elif t < second_ms:
+            second, second_ms = cfg, t
+    if best < 0:
+        best = timed[0][1]
+    if second < 0 and len(timed) > 1:
+        second = next(cfg for t, cfg in timed if cfg != best)
     if second < 0:
         second = best  # a single applicable configuration: the runner-up plan keeps it
     _TUNE_CACHE[key] = (best, second)
@@ -936,8 +953,8 @@ class Engine:
         if d.split_n:
             d.ldy = self._ld(y)
         assert Npad >= c2s
-        if op.get("up") is not None:   # virtual Upsample + Concat: the low-resolution tensor rides in the residual slot (include/yolov5_hip.h, up_c)
-            lo, c_up = op["up"]
+        if op.get("x_up") is not None:   # virtual Upsample + Concat: the low-resolution tensor rides in the residual slot (include/yolov5_hip.h, up_c)
+            lo, c_up = op["x_up"], op["up_c"]
             assert res is None and lo.H * 2 == H and lo.W * 2 == W and lo.C >= c_up
             d.up_c, d.ld_up = c_up, self._ld(lo)
             res = lo
@@ -982,7 +999,7 @@ class Engine:
                 and d.C1 == 32 and d.C2 == 64 and d.Npad == 64 and y.H % 4 == 0 and y.W % 8 == 0):
             return None
         if not (nxt["op"] == "conv" and _pair(nxt["k"]) == (1, 1) and _pair(nxt["s"]) == (1, 1) and _pair(nxt["p"]) == (0, 0) and nxt["res"] is None and nxt["c2_store"] <= 64
-                and nxt["c2_store"] % 8 == 0 and not nxt.get("side") and nxt["x"].buf == y.buf and nxt["x"].c_off == y.c_off and nxt["x"].C == d.C2):
+                and nxt["c2_store"] % 8 == 0 and not nxt.get("side") and nxt.get("x_up") is None and nxt["x"].buf == y.buf and nxt["x"].c_off == y.c_off and nxt["x"].C == d.C2):
             return None
         if nxt["y2"] is not None and not nxt.get("split_n"):
             return None  # an upsampled replica behind the pointwise layer: not built

@@ -382,7 +382,7 @@ class TrainEngine:
                 if sums is None:
                     sums = st["sums"] = be.empty((2 * c2,), torch.float64)
                 _lib.check(lib.y5_bn_stats(_vp(be.ptr(st["z"])), self.dt, npix, c2, c2, _vp(be.ptr(sums)), _vp(be.ptr(self.ws)), self.ws_bytes, stm), lib)
-                torch.distributed.all_reduce(be.view_torch(sums))
+                torch.distributed.all_reduce(be.view_torch(sums), group=bn.process_group)   # (the same rank set as the image count)
                 _lib.check(lib.y5_bn_silu_fwd_from_sums(_vp(be.ptr(st["z"])), self.dt, npix, c2, c2, _vp(st["gamma"]), _vp(st["beta"]), float(bn.eps),
                                                         float(bn.momentum if bn.momentum is not None else 0.1), rm, rv, _vp(be.ptr(st["mean"])),
                                                         _vp(be.ptr(st["invstd"])), _vp(be.ptr(sums)), y.H * y.W * self._sync_images(bn, world),
@@ -606,7 +606,7 @@ class TrainEngine:
                 gst, gft = be.view_torch(gs), be.view_torch(self.gflat)
                 gst[:c2].copy_(gft[ow:ow + c2])
                 gst[c2:].copy_(gft[ob:ob + c2])
-                torch.distributed.all_reduce(gst)
+                torch.distributed.all_reduce(gst, group=m.bn.process_group)
                 _lib.check(lib.y5_bn_silu_bwd_from_sums(_vp(self._ptr(y, True)), self._ld(y), _vp(be.ptr(st["z"])), c2, self.dt, npix, c2, _vp(st["gamma"]),
                                                         _vp(st["beta"]), _vp(be.ptr(st["mean"])), _vp(be.ptr(st["invstd"])), _vp(be.ptr(gs)),
                                                         _vp(be.ptr(gs) + 4 * c2), y.H * y.W * self._sync_images(m.bn, world), _vp(be.ptr(self.dz)), c2, stm), lib)
