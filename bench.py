@@ -195,7 +195,7 @@ def conv_family(cfg):
         return "y5_conv_pw_kernel"
     if 78 <= cfg < 84 or 30 <= cfg < 35:
         return "y5_conv_k3_kernel"
-    if 61 <= cfg < 78:
+    if 61 <= cfg < 78 or 90 <= cfg < 93:
         return "y5_conv_h3_kernel"
     return "y5_conv_igemm_kernel"
 

@@ -76,6 +76,16 @@ CASES = [
     (2, 9, 33, 32, 144, 3, 1, 1, 0, True, False, 75, 0, "f16"),
     (2, 13, 40, 96, 128, 3, 1, 1, 1, True, False, 76, 2, "f16"),
     (1, 10, 40, 64, 48, 3, 1, 1, 1, False, False, 77, 1, "f16"),
+    # ... at STRIDE 2 (round 5: 3 / 5 / 7 / 18 / 21.Conv): odd and even input sizes, several tiles per image and per workgroup, the small-tile ids 90..92
+    (2, 16, 32, 32, 64, 3, 2, 1, 1, False, False, 61, 0, "f16"),
+    (1, 23, 41, 64, 128, 3, 2, 1, 1, False, False, 64, 2, "f16"),
+    (2, 20, 20, 96, 160, 3, 2, 1, 0, False, False, 73, 1, "f16"),
+    (1, 40, 24, 64, 128, 3, 2, 1, 1, False, False, 76, 2, "f16"),
+    (2, 32, 64, 64, 128, 3, 2, 1, 1, False, False, 90, 2, "f16"),
+    (1, 33, 65, 32, 96, 3, 2, 1, 1, False, False, 91, 1, "f16"),
+    (3, 16, 16, 64, 128, 3, 2, 1, 1, False, False, 92, 0, "f16"),
+    (2, 13, 40, 96, 128, 3, 1, 1, 1, True, False, 90, 2, "f16"),      # (and the new ids at stride 1)
+    (1, 20, 20, 64, 64, 3, 1, 1, 1, False, False, 91, 1, "f16"),
 ] + [
     # every fp16 tile configuration on one shape with M, N tails and K = 9*64 (uniform) / 9*48 (table for BK64)
     (2, 9, 9, c1, 160, 3, 1, 1, 1, True, False, cfg, 2, "f16") for cfg in list(range(14)) + list(range(22, 30)) + list(range(35, 56)) for c1 in (64, 48)

@@ -119,6 +119,13 @@ CONV_CASES = [
     (8, 20, 20, 256, 256, 3, 1, 1, 1, True, False, 75, 16, "f16"),
     (8, 40, 40, 128, 128, 3, 1, 1, 1, True, False, 76, 0, "f16"),
     (8, 80, 80, 64, 64, 3, 1, 1, 1, True, False, 77, 16, "f16"),
+    # halo-resident 3x3 at STRIDE 2 (round 5: the down-sampling layers 3 / 5 / 7 / 18 / 21.Conv at their real shapes, small batch) and the small-tile ids 90..92
+    (4, 160, 160, 64, 128, 3, 2, 1, 1, False, False, 90, 0, "f16"),
+    (4, 160, 160, 64, 128, 3, 2, 1, 1, False, False, 91, 16, "f16"),
+    (8, 80, 80, 128, 256, 3, 2, 1, 1, False, False, 76, 0, "f16"),
+    (8, 40, 40, 256, 512, 3, 2, 1, 1, False, False, 92, 8, "f16"),
+    (8, 80, 80, 128, 128, 3, 2, 1, 0, False, False, 73, 0, "f16"),
+    (3, 41, 37, 64, 96, 3, 2, 1, 1, False, False, 64, 0, "f16"),
 ]
 
 

@@ -95,8 +95,12 @@ void y5_conv_h3_kernel(const Y5ConvParams p) {
   float* const bias_lds = reinterpret_cast<float*>(smem + Gm::OFF_BIAS);
   for (int i = tid; i < p.Npad; i += NW * 64) bias_lds[i] = p.bias[i];
 
-  const int TH = p.h3_th, TW = p.h3_tw, HW = TW + 2;
-  const int HP = (TH + 2) * HW;
+  // stride 1 or 2 (round 5: the 3x3 s2 down-sampling layers -- 3 / 5 / 7 / 18 / 21.Conv -- through the same kernel): output pixel (r, c) of the tile reads
+  // halo pixel (r S + kh, c S + kw) of a ((TH-1) S + 3) x ((TW-1) S + 3) input halo; only the fragment base addresses and the halo extent know about S.
+  // The input crosses L2 -> LDS ((TH-1) S + 3)((TW-1) S + 3) / (S^2 TH TW) = 1.1-1.2x instead of the implicit GEMM's 9 / S^2 = 2.25x.
+  const int SD = p.SH;
+  const int TH = p.h3_th, TW = p.h3_tw, HW = (TW - 1) * SD + 3;
+  const int HP = ((TH - 1) * SD + 3) * HW;
   const int NAI = (HP + 15) >> 4;
   const int NCC = p.C1 >> 5;
   const int total = NCC * 9;
@@ -122,7 +126,7 @@ void y5_conv_h3_kernel(const Y5ConvParams p) {
   for (int i = 0; i < TM; ++i) {
     const int m = (wm * TM + i) * 32 + frow;
     const int r = m / TW, c = m - r * TW;
-    hp0[i] = r < TH ? r * HW + c : 0;
+    hp0[i] = r < TH ? r * SD * HW + c * SD : 0;
   }
   const int fsw = (frow >> 2) & 3;
   int w_rd[TN];
@@ -161,8 +165,8 @@ void y5_conv_h3_kernel(const Y5ConvParams p) {
   auto loader_setup = [&](int j) {
     int b, oh0, ow0, n0;
     tile_coords(j, b, oh0, ow0, n0);
-    s_ih0 = oh0 - 1;
-    s_iw0 = ow0 - 1;
+    s_ih0 = oh0 * SD - 1;
+    s_iw0 = ow0 * SD - 1;
     s_base = ((b * p.H + s_ih0) * p.W + s_iw0) * p.ldx * 2;
 #pragma unroll
     for (int q = 0; q < WPW; ++q) {

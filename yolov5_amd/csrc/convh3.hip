@@ -9,7 +9,7 @@ namespace {
 
 // ---- halo-resident 3x3 configurations (conv_h3.h): ids kH3_0 + index ------------------------------------------------------------
 struct H3Cfg { int wm, wn, tm, tn, hpmax; };
-constexpr int kNumH3 = 17;
+constexpr int kNumH3 = 20;
 constexpr H3Cfg kH3Cfgs[kNumH3] = {
     {2, 2, 5, 2, 496},  // 61: 320 pixels x 128 channels (8 x 40, 4 x 80, 16 x 20 output tiles)
     {2, 2, 5, 1, 496},  // 62: 320 x  64
@@ -31,25 +31,29 @@ constexpr H3Cfg kH3Cfgs[kNumH3] = {
     {2, 2, 3, 2, 320},  // 75: 192 x 128
     {4, 2, 2, 2, 320},  // 76: 256 x 128, eight waves, two workgroups per CU
     {4, 2, 2, 1, 320},  // 77: 256 x  64, eight waves, two workgroups per CU
+    // round 5 (ids 90..92): small pixel tiles for the STRIDE-2 layers, whose halo is ~4.6x the output tile (4 x 16 outputs <- 9 x 33 inputs)
+    {2, 2, 1, 2, 320},  // 90:  64 x 128, four waves, 4-stage ring: two workgroups per CU
+    {4, 2, 1, 2, 592},  // 91: 128 x 128, eight waves, 4-stage ring (8 x 16 outputs <- 17 x 33 inputs)
+    {2, 2, 2, 2, 592},  // 92: 128 x 128, four waves, 4-stage ring
 };
 
 // spatial tile for an H x W output: TW = ceil(W / d), TH as tall as the pixel budget and the LDS halo allow, then evened out over the
 // image height; the candidate that needs the fewest rounds of `slots` concurrent workgroups wins, ties go to the smaller staged halo
-bool h3_pick_tile(int B, int H, int W, int BM, int hpmax, long long tiles_n, long long slots, int* th, int* tw) {
+bool h3_pick_tile(int B, int H, int W, int BM, int hpmax, long long tiles_n, long long slots, int S, int* th, int* tw) {
   long long best = -1;
   for (int d = 1; d <= 16 && d <= W; ++d) {
     const int TW = (W + d - 1) / d;
-    if (TW > BM || TW + 2 > 255) continue;
+    if (TW > BM || (TW - 1) * S + 3 > 255) continue;
     int thm = BM / TW < H ? BM / TW : H;
-    while (thm >= 1 && (thm + 2) * (TW + 2) > hpmax) --thm;
+    while (thm >= 1 && ((thm - 1) * S + 3) * ((TW - 1) * S + 3) > hpmax) --thm;
     if (thm < 1) continue;
-    if (thm + 2 > 255) thm = 253;
+    while ((thm - 1) * S + 3 > 255) --thm;
     const int nth = (H + thm - 1) / thm;
     const int TH = (H + nth - 1) / nth;
     const int ntw = (W + TW - 1) / TW;
     const long long tiles = (long long)B * nth * ntw * tiles_n;
     const long long rounds = (tiles + slots - 1) / slots;
-    const long long cost = rounds * (1LL << 32) + (long long)(TH + 2) * (TW + 2) * nth * ntw;
+    const long long cost = rounds * (1LL << 32) + (long long)((TH - 1) * S + 3) * ((TW - 1) * S + 3) * nth * ntw;
     if (best < 0 || cost < best) { best = cost; *th = TH; *tw = TW; }
   }
   return best >= 0;
@@ -76,7 +80,7 @@ int launch_h3(const Y5ConvParams& p0, int max_blocks, hipStream_t stream) {
     G = (long long)g_num_cu * occ;
   }
   int th = 0, tw = 0;
-  if (!h3_pick_tile(p.B, p.OH, p.OW, Gm::BM, HPMAX, p.tilesN, G, &th, &tw))
+  if (!h3_pick_tile(p.B, p.OH, p.OW, Gm::BM, HPMAX, p.tilesN, G, p.SH, &th, &tw))
     return y5_fail(Y5_ERR_UNSUPPORTED, "conv: no spatial tile of this halo configuration fits the layer");
   p.h3_th = th; p.h3_tw = tw;
   p.h3_tiles_h = (p.OH + th - 1) / th;
@@ -116,6 +120,9 @@ int y5_launch_h3_by_cfg(const Y5ConvParams& p, int idx, int mb, hipStream_t s) {
     case 14: return launch_h3<2, 2, 3, 2, 320, 4>(p, mb, s);
     case 15: return launch_h3<4, 2, 2, 2, 320, 4>(p, mb, s);
     case 16: return launch_h3<4, 2, 2, 1, 320, 4>(p, mb, s);
+    case 17: return launch_h3<2, 2, 1, 2, 320, 4>(p, mb, s);
+    case 18: return launch_h3<4, 2, 1, 2, 592, 4>(p, mb, s);
+    case 19: return launch_h3<2, 2, 2, 2, 592, 4>(p, mb, s);
   }
   return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown halo 3x3 config");
 }
