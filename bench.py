@@ -77,7 +77,7 @@ def conv_flops(engine):
     out = []
     B = engine.spec.B
     for i, op in enumerate(engine.spec.ops):
-        subs = [op] if op["op"] == "conv" else [op["cv1"], op["cv2"]] if op["op"] == "bneck" else []
+        subs = [op] if op["op"] == "conv" else [op["cv1"], op["cv2"]] if op["op"] == "bneck" else [op["cv1"]] if op["op"] == "sppf_front" else []
         if not subs:
             continue
         fl = 0
@@ -115,6 +115,8 @@ def conv_bytes(engine, esize=2):
             out.append((i, one(op, op.get("res") is not None) * esize))
         elif op["op"] == "bneck":
             out.append((i, (one(op["cv1"], False) + one(op["cv2"], op["add"])) * esize))
+        elif op["op"] == "sppf_front":   # (charged as the cv1 layer it contains: the pools were never part of the conv figure)
+            out.append((i, one(op["cv1"], False) * esize))
     return out
 
 
@@ -188,7 +190,7 @@ def pmc_mfma_busy(a):
 def conv_family(cfg):
     """Kernel family a convolution configuration id launches (csrc/conv.hip id space)."""
     if isinstance(cfg, str):
-        return {"front": "y5_conv_front_kernel", "bneck": "y5_conv_bneck_kernel"}.get(cfg, "y5_conv_" + cfg + "_kernel")
+        return {"front": "y5_conv_front_kernel", "bneck": "y5_conv_bneck_kernel", "h3b": "y5_conv_h3b_kernel", "sppf": "y5_sppf_cv1_pool_kernel"}.get(cfg, "y5_conv_" + cfg + "_kernel")
     if cfg is None or cfg < 0:
         return None
     if 84 <= cfg < 88 or cfg == 56 or 14 <= cfg < 22:   # (88 / 89 = the virtual Upsample + Concat loader: implicit-GEMM instantiations, ADVICE r4)
@@ -1018,7 +1020,7 @@ def main():
                          "frac_definition": "conv FLOPs of the dominant kernel's launches / their in-situ time / 2500 TFLOP/s; stack_frac = the same over ALL conv "
                                             "launches of one forward (rounds 1-3 reported that one as frac)",
                          "dominant_kernel": dominant,
-                         "stack_kernels": "y5_conv_{front,igemm,h3,pw,k3,stem,bneck}_kernel (all conv launches of one forward)",
+                         "stack_kernels": "y5_conv_{front,igemm,h3,h3b,pw,k3,stem,bneck}_kernel (all conv launches of one forward)",
                          "stack_achieved": round(achieved, 2), "stack_frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                          "mfma_busy_frac": mfma_busy[0], "mfma_busy_frac_dominant_kernel": dom_busy,
                          "traffic": pmc_traffic(a, conv_by * parts),

@@ -436,6 +436,17 @@ int y5_conv_front_fwd(const void* x_nchw, int B, int H, int W, const void* w_ste
                       int Kpad2, int act2, void* y, int ldy, void* y2, int ld2, int split_n, int max_blocks, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * y5_sppf_cv1_pool_fwd -- models/common.py:318-340 `SPPF.forward` up to the concat: x1 = cv1(x) (1x1 C1 -> c_, BN folded, bias + SiLU), y1 = m(x1),
+ * y2 = m(y1), y3 = m(y2) with m = MaxPool2d(k, 1, k // 2), as ONE launch (csrc/conv_sppf.h): a workgroup owns all H x W pixels of one image for 64
+ * output channels, so the pools run on the LDS copy of what the GEMM just produced.  The four results land in channel slices [s c_, (s + 1) c_),
+ * s = 0..3, of `buf` (NHWC, pixel stride ld >= 4 c_): the concat of :340 is never materialised separately -- cv2 reads `buf`.
+ * fp16; H * W <= 416 (P5 of a 640 x 640 input: 20 x 20), C1 % 32 == 0, c_ % 64 == 0, odd k; w_packed [c_][Kpad] (k = c) as y5_conv2d_fwd.
+ * Y5_ERR_UNSUPPORTED otherwise: y5_conv2d_fwd + y5_sppf_pool.
+ * ------------------------------------------------------------------------------------------------------- */
+int y5_sppf_cv1_pool_fwd(const void* x, int ldx, const void* w_packed, const float* bias, int Kpad, void* buf, int ld, int B, int H, int W, int C1,
+                         int c_, int k, int act, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * y5_bottleneck_fwd -- models/common.py:164-181 `Bottleneck.forward` inside C3 (e = 1.0, :242): y = [x +] cv2(cv1(x)) with cv1 = 1x1
  * C->C and cv2 = 3x3 pad 1 C->C (BN folded, bias + SiLU each), fp16, as ONE pass: the 1x1 output stays in LDS (csrc/conv_bneck.h).
  * x / y: NHWC channel slices with pixel strides ldx / ldy (elements); y must NOT overlap x.  C = 32 or 64, H % 4 == 0, W % 8 == 0.
@@ -523,6 +534,8 @@ int y5_plan_set_anchors(y5_plan*, int op_index, const float* anchors_px, int n);
 int y5_plan_add_nchw_to_nhwc(y5_plan*, const void* src, int src_dtype, void* dst, int dst_dtype, int B, int C, int H,
                              int W, int ld, float scale);
 int y5_plan_add_sppf_pool(y5_plan*, void* buf, int dtype, int B, int H, int W, int C, int ld, int k);
+int y5_plan_add_sppf_cv1_pool(y5_plan* plan, const void* x, int ldx, const void* w_packed, const float* bias, int Kpad, void* buf, int ld, int B, int H, int W,
+                              int C1, int c_, int k, int act);
 int y5_plan_add_upsample2x(y5_plan*, const void* src, int dtype, void* dst, int B, int H, int W, int C, int lds, int ldd);
 int y5_plan_add_copy_slice(y5_plan*, const void* src, int dtype, void* dst, int npix, int C, int lds, int ldd);
 int y5_plan_add_detect_decode(y5_plan*, const void* logits, int dtype, int B, int ny, int nx, int na, int no, int nm,

@@ -218,8 +218,8 @@ def test_plan_fuses_the_128_channel_bottlenecks(monkeypatch):
         eng = Engine(m, (1, 3, 64, 96), torch.float16, "cpu", want_raw=False, backend=EmuBackend())
         outs[mode] = np.asarray(eng(x)["z"]).astype(np.float32).copy()
         names[mode] = list(eng.op_names)
-    n128 = [n for n in names["1"] if n.startswith("bneck:") and n.split(":")[1].split(".")[0] in ("6", "13", "20")]
-    assert len(n128) == 5 and not any(n.startswith("bneck:6.") for n in names["0"]), (names["0"], names["1"])
+    n128 = [n for n in names["1"] if n.startswith("bneck128:") and n.split(":")[1].split(".")[0] in ("6", "13", "20")]
+    assert len(n128) == 5 and not any(n.startswith("bneck128:") for n in names["0"]), (names["0"], names["1"])
     assert len(names["1"]) == len(names["0"]) - 5 + 0 or len([n for n in names["1"] if n == "conv:b.cv1"]) == len([n for n in names["0"] if n == "conv:b.cv1"]) - 5
     u, v = outs["0"], outs["1"]
     assert np.abs(u - v).max() <= 4e-3 * max(1.0, np.abs(u).max()), np.abs(u - v).max()

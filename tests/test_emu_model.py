@@ -107,8 +107,9 @@ def test_fused_bottleneck_plan_same_outputs(monkeypatch):
     monkeypatch.setenv("Y5_FUSED_BNECK", "1")
     fused = Engine(m, (2, 3, 64, 64), torch.float16, "cpu", want_raw=True, backend=EmuBackend())
     kinds = [o["op"] for o in fused.spec.ops]
-    assert kinds.count("bneck") == 3 and "bneck" not in [o["op"] for o in plain.spec.ops]
-    assert sum(1 for o in fused.spec.ops if o.get("split_n")) == 2
+    # 4.C3.m0 / m1, 17.C3.m0 (c_ = 32) and -- round 5 -- 8.C3.m0, 23.C3.m0 (c_ = 128: conv_h3b.h, here on 2 x 2 images)
+    assert [o["x"].C for o in fused.spec.ops if o["op"] == "bneck"] == [32, 32, 128, 32, 128] and "bneck" not in [o["op"] for o in plain.spec.ops]
+    assert sum(1 for o in fused.spec.ops if o.get("split_n")) == 4
     a, b = plain(x), fused(x)
     for k in a:  # same arithmetic, another fp32 summation order inside the 3x3 (two accumulators): a few fp16 ulps
         u, v = np.asarray(a[k]).astype(np.float32), np.asarray(b[k]).astype(np.float32)

@@ -693,6 +693,60 @@ def test_plan_bneck128_fused_equals_unfused_on_gpu(dev, monkeypatch):
         m = m.eval().fuse().half().to(dev)
         outs[mode] = m(x)[0].float().cpu()
         eng = next(iter(m._engines.values()))
-        assert sum(n.startswith(("bneck:6.", "bneck:13.", "bneck:20.")) for n in eng.op_names) == (5 if mode == "1" else 0), eng.op_names
+        assert sum(n.startswith("bneck128:") for n in eng.op_names) == (5 if mode == "1" else 0), eng.op_names
+    u, v = outs["0"], outs["1"]
+    assert float((u - v).abs().max()) <= 4e-3 * max(1.0, float(u.abs().max()))
+
+
+@pytest.mark.parametrize("B,H,W,C1,c_,k", [(64, 20, 20, 512, 256, 5), (3, 13, 17, 96, 64, 5), (16, 20, 20, 1280, 640, 5), (2, 16, 16, 64, 128, 3)])
+def test_sppf_cv1_pool_matches_torch(B, H, W, C1, c_, k, dev):
+    """y5_sppf_cv1_pool_fwd (csrc/conv_sppf.h: SPPF.cv1 + the three cascaded max pools in one launch, models/common.py:318-340) through the C-ABI: slice 0
+    against torch fp32 on the same fp16 operands, slices 1..3 EXACTLY torch's pools of slice 0; bs 64 x 20 x 20 x 512 -> 256 is yolov5s' 9.SPPF, 1280 -> 640
+    yolov5x'."""
+    import ctypes as C
+
+    import torch.nn.functional as F
+
+    from yolov5_amd import _lib
+    from yolov5_amd.packing import pack_conv_weight
+
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(B + H + C1)
+    w = torch.randn((c_, C1, 1, 1), generator=g) * (2.0 / C1) ** 0.5
+    b = torch.randn(c_, generator=g) * 0.3
+    wp, bp, _, Kpad, _ = pack_conv_weight(w, b, torch.float16)
+    wp, bp = wp.to(dev), bp.to(dev)
+    x = torch.randn((B, H, W, C1), generator=g).half().to(dev)
+    buf = torch.full((B, H, W, 4 * c_ + 8), 7.0, dtype=torch.float16, device=dev)
+    vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    _lib.check(lib.y5_sppf_cv1_pool_fwd(vp(x), C1, vp(wp), vp(bp), Kpad, vp(buf), 4 * c_ + 8, B, H, W, C1, c_, k, 1, _lib.stream(dev)), lib)
+    torch.cuda.synchronize()
+    xf = x[:2].float().cpu().permute(0, 3, 1, 2)
+    ref0 = F.silu(F.conv2d(xf, w.half().float(), b)).half().float().permute(0, 2, 3, 1)
+    got = buf[..., :4 * c_].float().cpu()
+    assert float((got[:2, ..., :c_] - ref0).abs().max()) <= 8e-3
+    cur = got[..., :c_].permute(0, 3, 1, 2)
+    for s in range(1, 4):
+        cur = F.max_pool2d(cur, k, 1, k // 2)
+        assert torch.equal(got[..., s * c_:(s + 1) * c_], cur.permute(0, 2, 3, 1)), s
+    assert bool((buf[..., 4 * c_:] == 7).all())
+
+
+def test_plan_sppf_front_fused_equals_unfused_on_gpu(dev, monkeypatch):
+    """yolov5s 8 x 3 x 640 x 640 fp16: 9.SPPF's cv1 + pools as one launch against cv1 + y5_sppf_pool."""
+    from yolov5_amd.yolo import DetectionModel
+
+    cfg = yo.model_cfg("yolov5s")
+    sd = yo.det_state_dict(cfg, 0, fused=False)
+    x = torch.from_numpy(detgen.uniform((8, 3, 640, 640), 0.0, 1.0, name="img", seed=1)).half().to(dev)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("Y5_FUSED_SPPF", mode)
+        m = DetectionModel("yolov5s.yaml")
+        m.load_state_dict(sd)
+        m = m.eval().fuse().half().to(dev)
+        outs[mode] = m(x)[0].float().cpu()
+        eng = next(iter(m._engines.values()))
+        assert any(n.startswith("sppf_front:") for n in eng.op_names) == (mode == "1") and ("sppf_pool" in eng.op_names) == (mode == "0"), eng.op_names
     u, v = outs["0"], outs["1"]
     assert float((u - v).abs().max()) <= 4e-3 * max(1.0, float(u.abs().max()))

@@ -129,6 +129,10 @@ EXPORTS = {
                                C.c_void_p, C.c_int, C.c_void_p]),
     "y5_tta_descale": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     "y5_bn_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "y5_sppf_cv1_pool_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_void_p]),
+    "y5_plan_add_sppf_cv1_pool": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, C.c_int, C.c_int]),
     "y5_conv2d_fwd_stats": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int),
                                      C.c_void_p]),
     "y5_bn_silu_fwd_from_partials": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float,

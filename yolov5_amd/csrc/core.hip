@@ -68,7 +68,7 @@ int y5_num_cu() {
 // ---------------------------------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------------------------------
-enum OpKind { OP_CONV, OP_TO_NHWC, OP_SPPF, OP_UPS, OP_COPY, OP_DECODE, OP_TO_NCHW, OP_STEM, OP_HEAD, OP_NOP, OP_BNECK, OP_K3PW, OP_BNECK_CV3, OP_FRONT };
+enum OpKind { OP_CONV, OP_TO_NHWC, OP_SPPF, OP_UPS, OP_COPY, OP_DECODE, OP_TO_NCHW, OP_STEM, OP_HEAD, OP_NOP, OP_BNECK, OP_K3PW, OP_BNECK_CV3, OP_FRONT, OP_SPPF_FRONT };
 
 struct Op {
   OpKind kind;
@@ -127,6 +127,14 @@ extern "C" int y5_plan_add_nhwc_to_nchw(y5_plan* pl, const void* src, int dt, vo
   if (!pl) return y5_fail(Y5_ERR_BAD_ARG, "plan: null");
   Op o{}; o.kind = OP_TO_NCHW; o.p0 = src; o.q0 = dst;
   o.i[0] = dt; o.i[1] = B; o.i[2] = C; o.i[3] = H; o.i[4] = W; o.i[5] = ld;
+  pl->ops.push_back(o);
+  return Y5_OK;
+}
+extern "C" int y5_plan_add_sppf_cv1_pool(y5_plan* pl, const void* x, int ldx, const void* w, const float* bias, int Kpad, void* buf, int ld, int B, int H, int W,
+                                         int C1, int c_, int k, int act) {
+  if (!pl) return y5_fail(Y5_ERR_BAD_ARG, "plan: null");
+  Op o{}; o.kind = OP_SPPF_FRONT; o.p0 = x; o.p1 = w; o.p2 = bias; o.q0 = buf;
+  o.i[0] = ldx; o.i[1] = Kpad; o.i[2] = ld; o.i[3] = B; o.i[4] = H; o.i[5] = W; o.i[6] = C1; o.i[7] = c_; o.i[8] = k; o.i[9] = act;
   pl->ops.push_back(o);
   return Y5_OK;
 }
@@ -295,6 +303,8 @@ static int run_op(const Op& o, void* st) {
     case OP_HEAD:
       return y5_detect_head_fwd_hint(&o.conv, o.p0, o.p1, (const float*)o.p2, o.i[0], o.i[1], o.f[0], o.anchors, o.q0, o.l[0], o.l[1], const_cast<void*>(o.p3), st);
     case OP_NOP: return Y5_OK;
+    case OP_SPPF_FRONT:
+      return y5_sppf_cv1_pool_fwd(o.p0, o.i[0], o.p1, (const float*)o.p2, o.i[1], o.q0, o.i[2], o.i[3], o.i[4], o.i[5], o.i[6], o.i[7], o.i[8], o.i[9], st);
     case OP_BNECK_CV3:
       return y5_bottleneck_cv3_fwd(o.p0, o.i[0], o.p1, (const float*)o.p2, o.i[1], o.p3, (const float*)o.q1, o.i[2], o.r0, o.i[9], o.r1, (const float*)o.r2,
                                    o.i[10], o.i[11] & 0xffff, o.i[11] >> 16, o.q0, o.i[3], o.i[4], o.i[5], o.i[6], o.i[7], o.i[8], 0, st);

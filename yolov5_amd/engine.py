@@ -170,8 +170,16 @@ class _Planner:
         c_ = m.cv1.conv.out_channels
         k = m.m.kernel_size if isinstance(m.m.kernel_size, int) else m.m.kernel_size[0]
         cat = self.spec.new_buf(x.H, x.W, 4 * c_, name + ".cat")
-        self.conv([m.cv1], x, _slice(cat, 0, c_), name=name + ".cv1")
-        self.spec.ops.append(dict(op="sppf_pool", buf=cat, C=c_, k=k))
+        cv1 = m.cv1.conv
+        # fp16 inference plans (round 5): cv1 + the three pools as ONE launch (csrc/conv_sppf.h: a workgroup owns an image's H x W pixels for 64 output
+        # channels and pools its own GEMM result in LDS) -- Y5_FUSED_SPPF = 0 keeps cv1 and y5_sppf_pool apart
+        if (self.fuse_bneck and os.environ.get("Y5_FUSED_SPPF", "1") != "0" and x.H * x.W <= 416 and c_ % 64 == 0 and cv1.in_channels % 32 == 0
+                and _pair(cv1.kernel_size) == (1, 1) and _pair(cv1.stride) == (1, 1) and _pair(cv1.padding) == (0, 0) and k % 2 == 1):
+            self.spec.ops.append(dict(op="sppf_front", x=x, y=_slice(cat, 0, c_), buf=cat, C=c_, k=k, name=name + ".cv1+pool",
+                                      cv1=self.conv([m.cv1], x, _slice(cat, 0, c_), name=name + ".cv1", emit=False)))
+        else:
+            self.conv([m.cv1], x, _slice(cat, 0, c_), name=name + ".cv1")
+            self.spec.ops.append(dict(op="sppf_pool", buf=cat, C=c_, k=k))
         return self.conv([m.cv2], cat, dest, up2=up2, name=name + ".cv2")
 
     def proto(self, m, x: TRef):
@@ -760,6 +768,8 @@ class Engine:
             rc = self._add_conv(op)
         elif kind == "bneck":
             rc = self._add_bneck(op)
+        elif kind == "sppf_front":
+            rc = self._add_sppf_front(op)
         elif kind == "sppf_pool":
             b = op["buf"]
             rc = lib.y5_plan_add_sppf_pool(self.plan, self._ptr(b), self.dt, B, b.H, b.W, op["C"], self._ld(b), op["k"])
@@ -849,6 +859,17 @@ class Engine:
                 self._graph = False
                 self._graph_gen = getattr(self, "_graph_gen", 0) + 1
 
+    def _add_sppf_front(self, op):
+        """SPPF.cv1 + the three max pools as one launch (y5_sppf_cv1_pool_fwd); the filter is packed like any conv's and re-packed by refresh_weights()."""
+        sub, x, cat = op["cv1"], op["x"], op["buf"]
+        _, (wp, bp, _K, Kpad, _Npad), _ = self._conv_weights(sub)
+        wp, bp = self.be.from_torch(wp), self.be.from_torch(bp)
+        self._keep += [wp, bp]
+        self._conv_bufs.append((sub, wp, bp, None, None))
+        self.op_names.append("sppf_front:" + op["name"])
+        return self.lib.y5_plan_add_sppf_cv1_pool(self.plan, self._ptr(x), self._ld(x), C.c_void_p(self.be.ptr(wp)), C.c_void_p(self.be.ptr(bp)), Kpad,
+                                                  self._ptr(cat), self._ld(cat), self.spec.B, x.H, x.W, x.C, op["C"], op["k"], 1 if sub["act"] else 0)
+
     def _add_bneck(self, op):
         """Fused Bottleneck (y5_bottleneck_fwd): both filters packed like ordinary convs; refresh_weights() re-packs them too.  When it is the last
         Bottleneck of a C3 and the op behind it is that C3's cv3, both can run as ONE launch (y5_bottleneck_cv3_fwd): the Bottleneck's result
@@ -869,7 +890,7 @@ class Engine:
             self._k3pw_skip = self._cur + 1
             self.op_names.append("bneck+cv3:" + op["name"] + "+" + cv3["name"])
             return self.lib.y5_plan_add_bottleneck_cv3(self.plan, *base, *cv3["args"], *tail)
-        self.op_names.append("bneck:" + op["name"])
+        self.op_names.append(("bneck128:" if x.C == 128 else "bneck:") + op["name"])
         return self.lib.y5_plan_add_bottleneck(self.plan, *base, self._ptr(y), self._ld(y), *tail)
 
     def _fused_cv3_args(self, op, base, tail):
@@ -1257,6 +1278,10 @@ class Engine:
                 out.append((n, "front"))
             elif n.startswith(("conv:", "conv+pw:", "conv+decode:")):
                 out.append((n, next(ci, None)))
+            elif n.startswith("sppf_front:"):
+                out.append((n, "sppf"))     # csrc/conv_sppf.h
+            elif n.startswith("bneck128:"):
+                out.append((n, "h3b"))      # csrc/conv_h3b.h (the 128-channel Bottleneck: GEMM-1 phase + halo-resident 3x3)
             elif n.startswith("bneck"):
                 out.append((n, "bneck"))
             else:
