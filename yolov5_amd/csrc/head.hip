@@ -7,6 +7,7 @@
 
 #include "../../include/yolov5_hip.h"
 #include "conv_pw.h"
+#include "conv_headk.h"
 #include "y5_host.h"
 
 extern "C" int y5_detect_head_fwd_hint(const y5_conv_desc* d, const void* x, const void* w_packed, const float* bias, int ny, int nx, float stride,
@@ -14,6 +15,38 @@ extern "C" int y5_detect_head_fwd_hint(const y5_conv_desc* d, const void* x, con
   if (!d || !x || !w_packed || !bias || !anchors_px || !z) return y5_fail(Y5_ERR_BAD_ARG, "detect_head: null pointer");
   constexpr int KC = 2, RB = 128, NT = 8, S = 2, OS = 2;
   const long long npix = (long long)ny * nx;
+  if (d->C1 > KC * RB / 2) {   // deep levels (P4 / P5: 256 / 512 input channels): the K-streamed kernel of conv_headk.h
+    using Gm = Y5HeadkGeom<4>;
+    if (d->dtype != Y5_F16 || d->KH != 1 || d->KW != 1 || d->SH != 1 || d->SW != 1 || d->PH || d->PW || d->act || (d->C1 & 31) || d->Npad != Gm::NPAD || d->C2 < 255 ||
+        d->C2 > 256 || d->Kpad < d->C1 || (d->Kpad & 7) || d->H != ny || d->W != nx || d->OH != ny || d->OW != nx || d->ldx % 8 || d->out_mul_h != 0)
+      return y5_fail(Y5_ERR_UNSUPPORTED, "detect_head: needs a 1x1 fp16 convolution C1 (multiple of 32) -> 3 x 85 channels without activation");
+    const long long M = (long long)d->B * npix;
+    if ((M & 31) || (npix & 7) || npix < 32 || npix >= 65536 || (nrows_total & 7) || (row_off & 7) || nrows_total < row_off + 3 * npix)
+      return y5_fail(Y5_ERR_UNSUPPORTED, "detect_head: B * pixels must be a multiple of 32, pixels per image a multiple of 8 (32 .. 65535), z rows 8-row aligned");
+    if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)bias | (uintptr_t)z | (uintptr_t)obj_hint) & 15) return y5_fail(Y5_ERR_BAD_ARG, "detect_head: pointers must be 16-byte aligned");
+    if (M * d->ldx * 2 >= 0x7fffffffLL || M >= 0x7fffffffLL) return y5_fail(Y5_ERR_UNSUPPORTED, "detect_head: tensor exceeds 2^31 bytes");
+    Y5ConvParams p{};
+    p.x = x; p.w = w_packed; p.bias = bias;
+    p.B = d->B; p.H = ny; p.W = nx; p.C1 = d->C1; p.ldx = d->ldx; p.C2 = d->C2; p.Kpad = d->Kpad; p.Npad = d->Npad; p.M = (int)M;
+    p.x_bytes = (unsigned)(((M - 1) * d->ldx + d->C1) * 2);
+    p.w_bytes = (unsigned)((long long)d->Npad * d->Kpad * 2);
+    Y5HeadParams h{};
+    h.z = z; h.nrows_total = nrows_total; h.row_off = row_off; h.npix = (int)npix; h.nx = nx;
+    h.inv_nx = (unsigned)((0x100000000ULL + (unsigned)nx - 1) / (unsigned)nx);
+    h.stride = stride;
+    for (int i = 0; i < 6; ++i) h.anchors_px[i] = anchors_px[i];
+    h.obj_hint = obj_hint;
+    static bool attr_k = false;
+    if (!attr_k) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(y5_conv_headk_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(y5_conv_headk_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_k = true;
+    }
+    const unsigned G = (unsigned)((M + Gm::BM - 1) / Gm::BM);
+    if (obj_hint) hipLaunchKernelGGL((y5_conv_headk_kernel<4, true>), dim3(G), dim3(Gm::NW * 64), Gm::LDS, static_cast<hipStream_t>(stream_), p, h);
+    else hipLaunchKernelGGL((y5_conv_headk_kernel<4, false>), dim3(G), dim3(Gm::NW * 64), Gm::LDS, static_cast<hipStream_t>(stream_), p, h);
+    return y5_check_launch("y5_detect_head_fwd(headk)");
+  }
   if (d->dtype != Y5_F16 || d->KH != 1 || d->KW != 1 || d->SH != 1 || d->SW != 1 || d->PH || d->PW || d->act || d->C1 != KC * RB / 2 ||
       d->Npad != NT * 32 || d->C2 < 255 || d->C2 > 256 || d->Kpad * 2 < KC * RB || d->H != ny || d->W != nx || d->OH != ny || d->OW != nx ||
       d->ldx % 8 || d->out_mul_h != 0)

@@ -1139,6 +1139,8 @@ class Engine:
             return None
         if mode != "1" and not getattr(self.be, "autotune", False):
             return None
+        if d.C1 > 128 and os.environ.get("Y5_FUSED_HEAD_DEEP", "1") == "0":
+            return None   # A/B switch: the K-streamed fused head of the deep levels (csrc/conv_headk.h) off
         lvl = dec["level"]
         apx = (self.anchors[lvl] * self.stride_t[lvl]).reshape(-1).tolist()
         arr = (C.c_float * 6)(*apx)
