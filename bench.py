@@ -199,6 +199,8 @@ def conv_family(cfg):
         return "y5_conv_k3_kernel"
     if 61 <= cfg < 78 or 90 <= cfg < 93:
         return "y5_conv_h3_kernel"
+    if 93 <= cfg < 95:
+        return "y5_conv_pwk_kernel"
     return "y5_conv_igemm_kernel"
 
 

@@ -86,6 +86,13 @@ CASES = [
     (3, 16, 16, 64, 128, 3, 2, 1, 1, False, False, 92, 0, "f16"),
     (2, 13, 40, 96, 128, 3, 1, 1, 1, True, False, 90, 2, "f16"),      # (and the new ids at stride 1)
     (1, 20, 20, 64, 64, 3, 1, 1, 1, False, False, 91, 1, "f16"),
+    # K-streamed pointwise kernel (conv_pwk.h, ids 93 / 94): pixel tails, N tails, several N tiles, K from one to many chunks, no activation
+    (1, 6, 7, 32, 32, 1, 1, 0, 1, False, False, 93, 0, "f16"),
+    (2, 20, 20, 256, 256, 1, 1, 0, 1, False, False, 93, 0, "f16"),
+    (3, 9, 11, 96, 248, 1, 1, 0, 0, False, False, 93, 0, "f16"),
+    (1, 16, 16, 160, 512, 1, 1, 0, 1, False, False, 93, 0, "f16"),
+    (2, 13, 10, 256, 128, 1, 1, 0, 1, False, False, 94, 0, "f16"),
+    (1, 8, 8, 64, 320, 1, 1, 0, 1, False, False, 94, 0, "f16"),
 ] + [
     # every fp16 tile configuration on one shape with M, N tails and K = 9*64 (uniform) / 9*48 (table for BK64)
     (2, 9, 9, c1, 160, 3, 1, 1, 1, True, False, cfg, 2, "f16") for cfg in list(range(14)) + list(range(22, 30)) + list(range(35, 56)) for c1 in (64, 48)

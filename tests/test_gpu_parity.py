@@ -126,6 +126,12 @@ CONV_CASES = [
     (8, 40, 40, 256, 512, 3, 2, 1, 1, False, False, 92, 8, "f16"),
     (8, 80, 80, 128, 128, 3, 2, 1, 0, False, False, 73, 0, "f16"),
     (3, 41, 37, 64, 96, 3, 2, 1, 1, False, False, 64, 0, "f16"),
+    # K-streamed pointwise kernel (conv_pwk.h, ids 93 / 94) at the P4 / P5 shapes of yolov5s and with tails
+    (8, 40, 40, 256, 256, 1, 1, 0, 1, False, False, 93, 0, "f16"),
+    (8, 20, 20, 1024, 512, 1, 1, 0, 1, False, False, 93, 0, "f16"),
+    (8, 40, 40, 256, 128, 1, 1, 0, 1, False, False, 94, 0, "f16"),
+    (3, 21, 19, 96, 248, 1, 1, 0, 0, False, False, 93, 0, "f16"),
+    (2, 20, 20, 512, 320, 1, 1, 0, 1, False, False, 94, 0, "f16"),
 ]
 
 

@@ -3,6 +3,7 @@
 
 #include "../../include/yolov5_hip.h"
 #include "conv_h3.h"
+#include "conv_pwk.h"
 #include "y5_host.h"
 
 namespace {
@@ -125,6 +126,29 @@ int y5_launch_h3_by_cfg(const Y5ConvParams& p, int idx, int mb, hipStream_t s) {
     case 19: return launch_h3<2, 2, 2, 2, 592, 4>(p, mb, s);
   }
   return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown halo 3x3 config");
+}
+
+// ---- K-streamed pointwise kernel (conv_pwk.h): ids 93 (256-channel N tile), 94 (128) -----------------------------------------------------------
+template <int NT>
+static int launch_pwk(const Y5ConvParams& p, hipStream_t stream) {
+  using Gm = Y5PwkGeom<4, NT>;
+  auto kern = y5_conv_pwk_kernel<4, NT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const long long gx = ((long long)p.M + Gm::BM - 1) / Gm::BM, gy = (p.Npad + Gm::BN - 1) / Gm::BN;
+  if (gx < 1 || gx > 0x7fffffffLL || gy > 65535) return y5_fail(Y5_ERR_BAD_ARG, "conv: grid out of range");
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)gy), dim3(Gm::NW * 64), Gm::LDS, stream, p);
+  return y5_check_launch("y5_conv2d_fwd(pwk)");
+}
+int y5_launch_pwk_by_cfg(const Y5ConvParams& p, int idx, hipStream_t s) {
+  switch (idx) {
+    case 0: return launch_pwk<8>(p, s);
+    case 1: return launch_pwk<4>(p, s);
+  }
+  return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown K-streamed pointwise config");
 }
 
 #ifdef Y5_H3_TIMING
