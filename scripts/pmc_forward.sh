@@ -23,7 +23,7 @@ for f in glob.glob('gpurun_out/pmcf_*/**/*counter_collection.csv', recursive=Tru
         if 'y5_' not in k: continue
         tot[k][r['Counter_Name']] += float(r['Counter_Value'])
         if r['Counter_Name'] == 'FETCH_SIZE': cnt[k] += 1
-conv = lambda k: any(s in k for s in ('conv_igemm', 'conv_h3', 'conv_pw', 'conv_k3', 'conv_stem', 'conv_bneck', 'conv_front'))
+conv = lambda k: any(s in k for s in ('conv_igemm', 'conv_h3', 'conv_pw', 'conv_k3', 'conv_stem', 'conv_bneck', 'conv_front', 'sppf_cv1_pool', 'conv_headk'))
 def gb(keys, name, mult): return sum(tot[k][name] for k in keys) * 1024 * mult / N / 1e9   # counters are in KiB
 ck = [k for k in tot if conv(k)]; ok = [k for k in tot if not conv(k)]
 out = {"forwards": N, "conv_launches_per_forward": sum(cnt[k] for k in ck) / N,

@@ -35,7 +35,7 @@ for f in glob.glob('gpurun_out/pmcm_*/**/*counter_collection.csv', recursive=Tru
         if first and r['Dispatch_Id'] not in seen:
             seen.add(r['Dispatch_Id']); cnt[k] += 1
             dur[k] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-3   # us, pass 1 (the pass the busy counters come from)
-conv = lambda k: any(s in k for s in ('conv_igemm', 'conv_h3', 'conv_pw', 'conv_k3', 'conv_stem', 'conv_bneck', 'conv_front', 'conv_c3', 'sppf_cv1_pool'))
+conv = lambda k: any(s in k for s in ('conv_igemm', 'conv_h3', 'conv_pw', 'conv_k3', 'conv_stem', 'conv_bneck', 'conv_front', 'conv_c3', 'sppf_cv1_pool', 'conv_headk'))
 NSIMD = 1024.0
 MAX_GHZ = 2.4   # data-sheet shader clock of the part: no kernel can have had more cycles than duration x this
 def util(d):
