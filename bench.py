@@ -474,8 +474,10 @@ def train_with_exchange(name, batch, imgsz, dev, steps=20, warmup=5):
         plain["exchange"] = {"backend": "nccl (RCCL), one rank", "ms_per_step": ex["ms_per_step"], "step_ms": ex["step_ms"],
                              "exposed_us": round((ex["step_ms"]["median"] - plain["step_ms"]["median"]) * 1e3, 1),
                              "loss": ex["loss"],
-                             "note": "same step through smart_DDP over a 1-rank RCCL group: real bucket launches / waits, no wire; no 1->8 curve has been "
-                                     "measured (the driver's 8-GPU tier was unavailable in rounds 1-3)"}
+                             "note": "same step through smart_DDP over a 1-rank RCCL group: real bucket launches / waits, no wire.  A one-rank all-reduce launches NO "
+                                     "kernel (rocprofv3): the exposed time is the fixed cost of bringing a second hardware queue into play, not CU starvation "
+                                     "(DESIGN.md section 6; Y5_DDP_SYNC=all issues the collectives on the compute stream: 0.00-0.02 ms).  No 1->8 curve has been "
+                                     "measured (the driver's 8-GPU tier was unavailable in rounds 1-4)"}
     except Exception as e:  # the plain figure stands; say why the exchange leg is missing
         plain["exchange"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     finally:
