@@ -102,8 +102,10 @@ def test_engine_fused_head_same_outputs(monkeypatch):
     assert not c._fused_heads
 
 
-@pytest.mark.parametrize("async_dma", ["0", "1"])
-@pytest.mark.parametrize("B,ny,nx,C1,row_off,extra", [(2, 8, 8, 256, 0, 0), (4, 5, 8, 512, 8, 16), (2, 20, 20, 256, 0, 8), (3, 8, 12, 160, 16, 0), (16, 2, 20, 512, 0, 0)])
+DEEP_CASES = [(2, 8, 8, 256, 0, 0), (4, 5, 8, 512, 8, 16), (2, 20, 20, 256, 0, 8), (3, 8, 12, 160, 16, 0), (16, 2, 20, 512, 0, 0)]
+
+
+@pytest.mark.parametrize("B,ny,nx,C1,row_off,extra,async_dma", [c + ("0",) for c in DEEP_CASES] + [DEEP_CASES[i] + ("1",) for i in (1, 2)])
 def test_fused_head_deep_levels_bit_identical(B, ny, nx, C1, row_off, extra, async_dma):
     """y5_detect_head_fwd for C1 > 128 (csrc/conv_headk.h: K streamed through an LDS ring; P4 / P5 of yolov5s): bit-identical to y5_conv2d_fwd(act = 0) +
     y5_detect_decode; 5 x 8 = 40 and 20 x 20 = 400 pixels per image put image boundaries INSIDE 32-pixel wave tiles (two store segments)."""

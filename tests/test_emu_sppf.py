@@ -47,8 +47,7 @@ def _run(B, H, W, C1, c_, k, ld_extra):
     assert np.all(buf[..., 4 * c_:] == 7)
 
 
-@pytest.mark.parametrize("async_dma", ["0", "1"])
-@pytest.mark.parametrize("B,H,W,C1,c_,k,ld_extra", CASES)
+@pytest.mark.parametrize("B,H,W,C1,c_,k,ld_extra,async_dma", [c + ("0",) for c in CASES] + [CASES[i] + ("1",) for i in (1, 3)])
 def test_sppf_cv1_pool_matches_torch(B, H, W, C1, c_, k, ld_extra, async_dma):
     if async_dma == "1":
         code = f"import tests.test_emu_sppf as t; t._run({B}, {H}, {W}, {C1}, {c_}, {k}, {ld_extra})"
