@@ -183,6 +183,60 @@ def test_fused_bottleneck_cv3_matches_torch(B, H, W, add, c3, ldx, ld2, ldo, act
     assert np.all(out[..., c3:] == 7)
 
 
+# c_ = 128 (conv_h3b.h CV3): Bottleneck + cv3 (256 -> <= 256) in one launch; image tails, several tiles per workgroup (the next tile's halo and W1 are issued
+# behind GEMM 3), C3 with a channel tail, no activation; both LDS-DMA landing models
+CV3_128_CASES = [(1, 6, 7, True, 256, 128, 128, 256, 1, 0), (2, 12, 20, False, 256, 136, 256, 264, 1, 2), (1, 23, 40, True, 248, 128, 128, 256, 0, 2),
+                 (3, 9, 10, True, 256, 256, 128, 256, 1, 1)]
+
+
+def _run_cv3_128(B, H, W, add, c3, ldx, ld2, ldo, act3, mb):
+    lib = emu()
+    Cc = 128
+    rng = np.random.default_rng(H * W + c3 + B)
+    w1 = torch.from_numpy(rng.standard_normal((Cc, Cc, 1, 1)).astype(np.float32) * (2.0 / Cc) ** 0.5)
+    w2 = torch.from_numpy(rng.standard_normal((Cc, Cc, 3, 3)).astype(np.float32) * (2.0 / (9 * Cc)) ** 0.5)
+    w3 = torch.from_numpy(rng.standard_normal((c3, 2 * Cc, 1, 1)).astype(np.float32) * (2.0 / (2 * Cc)) ** 0.5)
+    b1, b2 = (torch.from_numpy(rng.standard_normal(Cc).astype(np.float32) * 0.3) for _ in range(2))
+    b3 = torch.from_numpy(rng.standard_normal(c3).astype(np.float32) * 0.3)
+    w1p, b1p, _, K1, _ = pack_conv_weight(w1, b1, torch.float16)
+    w2p, b2p, _, K2, _ = pack_conv_weight(w2, b2, torch.float16)
+    w3p, b3p, _, K3, N3 = pack_conv_weight(w3, b3, torch.float16)
+    xbuf = aligned((B, H, W, ldx), np.float16)
+    xbuf[...] = rng.standard_normal(xbuf.shape).astype(np.float16)
+    y2buf = aligned((B, H, W, ld2), np.float16)
+    y2buf[...] = rng.standard_normal(y2buf.shape).astype(np.float16)
+    x, y2 = xbuf[..., ldx - Cc:], y2buf[..., ld2 - Cc:]
+    out = aligned((B, H, W, ldo), np.float16, 7)
+    bufs = [aligned(t.shape, t.numpy().dtype) for t in (w1p, b1p, w2p, b2p, w3p, b3p)]
+    for dst, src in zip(bufs, (w1p, b1p, w2p, b2p, w3p, b3p)):
+        dst[...] = src.numpy()
+    W1, B1, W2, B2, W3, B3 = bufs
+    rc = lib.y5_bottleneck_cv3_fwd(C.c_void_p(xbuf.ctypes.data + (ldx - Cc) * 2), ldx, ptr(W1), ptr(B1), K1, ptr(W2), ptr(B2), K2,
+                                   C.c_void_p(y2buf.ctypes.data + (ld2 - Cc) * 2), ld2, ptr(W3), ptr(B3), K3, c3, act3, ptr(out), ldo, B, H, W, Cc, int(add), mb, None)
+    assert rc == 0, lib.y5_last_error()
+    m = torch.from_numpy(_ref_bneck(np.ascontiguousarray(x), w1, b1, w2, b2, add)).permute(0, 3, 1, 2)
+    cat = torch.cat((m, torch.from_numpy(np.ascontiguousarray(y2).astype(np.float32)).permute(0, 3, 1, 2)), 1)
+    ref = F.conv2d(cat, w3.half().float(), b3)
+    ref = (F.silu(ref) if act3 else ref).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(out[..., :c3].astype(np.float32), ref, rtol=6e-3, atol=6e-3)
+    assert np.all(out[..., c3:] == 7)
+
+
+@pytest.mark.parametrize("B,H,W,add,c3,ldx,ld2,ldo,act3,mb,async_dma", [c + ("0",) for c in CV3_128_CASES] + [CV3_128_CASES[i] + ("1",) for i in (1, 2)])
+def test_fused_bottleneck_cv3_c128_matches_torch(B, H, W, add, c3, ldx, ld2, ldo, act3, mb, async_dma):
+    import os
+    import subprocess
+    import sys
+
+    if async_dma == "1":
+        code = f"import tests.test_emu_bneck as t; t._run_cv3_128({B}, {H}, {W}, {add}, {c3}, {ldx}, {ld2}, {ldo}, {act3}, {mb})"
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, Y5_EMU_ASYNC="1"), capture_output=True, text=True,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        return
+    _run_cv3_128(B, H, W, add, c3, ldx, ld2, ldo, act3, mb)
+
+
 def test_plan_fuses_cv3_into_the_last_bottleneck(monkeypatch):
     """yolov5s 2.C3 (c_ = 32): the plan with Bottleneck + cv3 as one launch (Y5_FUSED_CV3=1) against the two-launch plan on the emulator."""
     from oracle import detgen
@@ -198,6 +252,28 @@ def test_plan_fuses_cv3_into_the_last_bottleneck(monkeypatch):
         eng = Engine(m, (1, 3, 64, 64), torch.float16, "cpu", want_raw=False, backend=EmuBackend())
         outs[mode] = np.asarray(eng(x)["z"]).astype(np.float32).copy()
         assert any(n.startswith("bneck+cv3:") for n in eng.op_names) == (mode == "1"), eng.op_names
+    u, v = outs["0"], outs["1"]
+    assert np.abs(u - v).max() <= 4e-3 * max(1.0, np.abs(u).max()), np.abs(u - v).max()
+
+
+def test_plan_fuses_cv3_into_the_last_128_channel_bottleneck(monkeypatch):
+    """yolov5s 6 / 13 / 20.C3 (c_ = 128): the C3 tail (last Bottleneck + cv3) as one conv_h3b.h launch (Y5_FUSED_CV3_128=1) against the plan with cv3 as
+    its own launch, on the emulator (1 x 3 x 64 x 96: 8 x 12, 4 x 6 and 2 x 3 images)."""
+    from oracle import detgen
+    from tests.hipemu.backend import EmuBackend
+    from tests.test_emu_model import det_model
+    from yolov5_amd.engine import Engine
+
+    m = det_model("yolov5s", 0, True).half()
+    x = torch.from_numpy(detgen.uniform((1, 3, 64, 96), 0.0, 1.0, name="img", seed=0)).half()
+    outs = {}
+    monkeypatch.setenv("Y5_FUSED_CV3", "0")
+    for mode in ("0", "1"):
+        monkeypatch.setenv("Y5_FUSED_CV3_128", mode)
+        eng = Engine(m, (1, 3, 64, 96), torch.float16, "cpu", want_raw=False, backend=EmuBackend())
+        outs[mode] = np.asarray(eng(x)["z"]).astype(np.float32).copy()
+        fused = [n for n in eng.op_names if n.startswith("bneck128+cv3:")]
+        assert len(fused) == (3 if mode == "1" else 0), eng.op_names
     u, v = outs["0"], outs["1"]
     assert np.abs(u - v).max() <= 4e-3 * max(1.0, np.abs(u).max()), np.abs(u - v).max()
 
@@ -218,8 +294,8 @@ def test_plan_fuses_the_128_channel_bottlenecks(monkeypatch):
         eng = Engine(m, (1, 3, 64, 96), torch.float16, "cpu", want_raw=False, backend=EmuBackend())
         outs[mode] = np.asarray(eng(x)["z"]).astype(np.float32).copy()
         names[mode] = list(eng.op_names)
-    n128 = [n for n in names["1"] if n.startswith("bneck128:") and n.split(":")[1].split(".")[0] in ("6", "13", "20")]
-    assert len(n128) == 5 and not any(n.startswith("bneck128:") for n in names["0"]), (names["0"], names["1"])
+    n128 = [n for n in names["1"] if n.startswith("bneck128") and n.split(":")[1].split(".")[0] in ("6", "13", "20")]
+    assert len(n128) == 5 and not any(n.startswith("bneck128") for n in names["0"]), (names["0"], names["1"])
     assert len(names["1"]) == len(names["0"]) - 5 + 0 or len([n for n in names["1"] if n == "conv:b.cv1"]) == len([n for n in names["0"] if n == "conv:b.cv1"]) - 5
     u, v = outs["0"], outs["1"]
     assert np.abs(u - v).max() <= 4e-3 * max(1.0, np.abs(u).max()), np.abs(u - v).max()

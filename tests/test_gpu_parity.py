@@ -699,7 +699,81 @@ def test_plan_bneck128_fused_equals_unfused_on_gpu(dev, monkeypatch):
         m = m.eval().fuse().half().to(dev)
         outs[mode] = m(x)[0].float().cpu()
         eng = next(iter(m._engines.values()))
-        assert sum(n.startswith("bneck128:") for n in eng.op_names) == (5 if mode == "1" else 0), eng.op_names
+        assert sum(n.startswith("bneck128") for n in eng.op_names) == (5 if mode == "1" else 0), eng.op_names   # ("bneck128+cv3:" = the C3-tail form)
+    u, v = outs["0"], outs["1"]
+    assert float((u - v).abs().max()) <= 4e-3 * max(1.0, float(u.abs().max()))
+
+
+@pytest.mark.parametrize("B,H,W,add,c3,ldx,ld2,ldo,act3,mb", [(8, 40, 40, True, 256, 256, 256, 256, 1, 0), (64, 40, 40, True, 256, 256, 256, 256, 1, 0),
+                                                             (3, 23, 37, False, 248, 128, 136, 264, 0, 8), (2, 80, 80, True, 128, 128, 128, 128, 1, 16)])
+def test_fused_bottleneck_cv3_c128_matches_torch(B, H, W, add, c3, ldx, ld2, ldo, act3, mb, dev):
+    """y5_bottleneck_cv3_fwd at C = 128 (csrc/conv_h3b.h CV3 form: the last Bottleneck of a C3 + the C3's cv3, models/common.py:232-246, in one launch; the
+    Bottleneck's result goes to LDS as fp16 -- the rounding the two-launch form applies when it stores it) through the C-ABI against torch fp32 on the same
+    fp16 operands; bs = 64 at 40 x 40 with 256 -> 256 is yolov5s' 6.C3 tail."""
+    import ctypes as C
+
+    import torch.nn.functional as F
+
+    from yolov5_amd import _lib
+    from yolov5_amd.packing import pack_conv_weight
+
+    lib = _lib.lib()
+    Cc = 128
+    g = torch.Generator().manual_seed(B * 100 + H + c3)
+    w1 = torch.randn((Cc, Cc, 1, 1), generator=g) * (2.0 / Cc) ** 0.5
+    w2 = torch.randn((Cc, Cc, 3, 3), generator=g) * (2.0 / (9 * Cc)) ** 0.5
+    w3 = torch.randn((c3, 2 * Cc, 1, 1), generator=g) * (2.0 / (2 * Cc)) ** 0.5
+    b1, b2, b3 = torch.randn(Cc, generator=g) * 0.3, torch.randn(Cc, generator=g) * 0.3, torch.randn(c3, generator=g) * 0.3
+    w1p, b1p, _, K1, _ = pack_conv_weight(w1, b1, torch.float16)
+    w2p, b2p, _, K2, _ = pack_conv_weight(w2, b2, torch.float16)
+    w3p, b3p, _, K3, _ = pack_conv_weight(w3, b3, torch.float16)
+    w1p, b1p, w2p, b2p, w3p, b3p = (t.to(dev) for t in (w1p, b1p, w2p, b2p, w3p, b3p))
+    xbuf = torch.randn((B, H, W, ldx), generator=g).half().to(dev)
+    y2buf = torch.randn((B, H, W, ld2), generator=g).half().to(dev)
+    obuf = torch.full((B, H, W, ldo), 7.0, dtype=torch.float16, device=dev)
+    st = _lib.stream(dev)
+    vp = lambda t, off=0: C.c_void_p(t.data_ptr() + off)  # noqa: E731
+    rc = lib.y5_bottleneck_cv3_fwd(vp(xbuf, (ldx - Cc) * 2), ldx, vp(w1p), vp(b1p), K1, vp(w2p), vp(b2p), K2, vp(y2buf, (ld2 - Cc) * 2), ld2, vp(w3p), vp(b3p), K3,
+                                   c3, act3, vp(obuf), ldo, B, H, W, Cc, int(add), mb, st)
+    _lib.check(rc, lib)
+    torch.cuda.synchronize()
+
+    def ref_of(xf, y2f, d):
+        t = F.silu(F.conv2d(xf, w1.half().float().to(d), b1.to(d))).half().float()
+        m = F.silu(F.conv2d(t, w2.half().float().to(d), b2.to(d), padding=1)).half().float()
+        if add:
+            m = (m + xf).half().float()
+        o = F.conv2d(torch.cat((m, y2f), 1), w3.half().float().to(d), b3.to(d))
+        return (F.silu(o) if act3 else o).half().float().permute(0, 2, 3, 1)
+
+    xf = xbuf[..., ldx - Cc:].float().permute(0, 3, 1, 2)
+    y2f = y2buf[..., ld2 - Cc:].float().permute(0, 3, 1, 2)
+    got = obuf[..., :c3].float()
+    ref = ref_of(xf, y2f, dev)
+    cpu = ref_of(xf[:1].cpu(), y2f[:1].cpu(), "cpu")  # torch's GPU conv is a second implementation, not the truth
+    tol = 1.2e-2  # one fp16 ulp of the intermediate moves the 256-term sum by a few 1e-3
+    assert float((got[:1].cpu() - cpu).abs().max()) <= tol
+    assert float((got - ref).abs().max()) <= tol, float((got - ref).abs().max())
+    assert bool((obuf[..., c3:] == 7).all())
+
+
+def test_plan_bneck128_cv3_fused_equals_unfused_on_gpu(dev, monkeypatch):
+    """yolov5s 8 x 3 x 640 x 640 fp16: the C3 tails of layers 6 / 13 / 20 (last Bottleneck + cv3) as one conv_h3b.h launch each (Y5_FUSED_CV3_128=1) against
+    the plan that keeps cv3 its own launch."""
+    from yolov5_amd.yolo import DetectionModel
+
+    cfg = yo.model_cfg("yolov5s")
+    sd = yo.det_state_dict(cfg, 0, fused=False)
+    x = torch.from_numpy(detgen.uniform((8, 3, 640, 640), 0.0, 1.0, name="img", seed=1)).half().to(dev)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("Y5_FUSED_CV3_128", mode)
+        m = DetectionModel("yolov5s.yaml")
+        m.load_state_dict(sd)
+        m = m.eval().fuse().half().to(dev)
+        outs[mode] = m(x)[0].float().cpu()
+        eng = next(iter(m._engines.values()))
+        assert sum(n.startswith("bneck128+cv3:") for n in eng.op_names) == (3 if mode == "1" else 0), eng.op_names
     u, v = outs["0"], outs["1"]
     assert float((u - v).abs().max()) <= 4e-3 * max(1.0, float(u.abs().max()))
 

@@ -1,0 +1,47 @@
+"""CPU (no GPU): the compiled gfx950 ISA keeps every "dummy" LDS-DMA (y5_common.h y5_bglds16_dummy) as its own instruction.
+
+Counted `s_waitcnt vmcnt(N)` waits are only right when every wave issues exactly the number of loads the count assumes; identical dummies in a row were
+once merged into one by the compiler (profiles/r05/r05_dummy_dma_merge.log), which no host-side emulation of the kernels can see.  Two checks: no kernel
+source issues a dummy without the helper, and conv_headk.h's ring (three prologue stages + the loop body, each a real path of 4 loads and a dummy path
+of 4) compiles to 32 LDS-DMA instructions per instantiation."""
+import glob
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "yolov5_amd", "csrc")
+
+
+def test_every_dummy_goes_through_the_helper():
+    pat = re.compile(r"y5_bglds16\([^;]*Y5_OOB\s*,\s*dummy\s*\)")
+    bad = []
+    for f in glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hip")):
+        for n, line in enumerate(open(f), 1):
+            if pat.search(line):
+                bad.append(f"{os.path.basename(f)}:{n}")
+    assert not bad, bad
+
+
+def test_headk_ring_keeps_its_dummy_loads(tmp_path):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    out = tmp_path / "head.s"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only", "-I" + os.path.join(ROOT, "include"),
+                        "-o", str(out), os.path.join(CSRC, "head.hip")], capture_output=True, text=True, cwd=CSRC)
+    assert r.returncode == 0, r.stderr[-3000:]
+    counts, cur = {}, None
+    for line in open(out):
+        m = re.match(r"^(_Z\w*y5_conv_headk_kernel\w*):", line)
+        if m:
+            cur = m.group(1)
+            counts[cur] = 0
+        elif cur and "s_endpgm" in line:
+            cur = None
+        elif cur and re.search(r"buffer_load_dwordx4 .* lds", line):
+            counts[cur] += 1
+    assert len(counts) == 2 and all(v == 32 for v in counts.values()), counts

@@ -62,10 +62,10 @@ bool h3b_pick_tile(int B, int H, int W, long long slots, int* th, int* tw) {
   return best >= 0;
 }
 
-template <int NSW, bool K64 = false>
+template <int NSW, bool K64 = false, bool CV3 = false>
 int launch_h3b(Y5H3bParams p, int max_blocks, hipStream_t stream) {
-  using Gm = Y5H3bGeom<NSW, K64>;
-  auto kern = y5_conv_h3b_kernel<NSW, K64>;
+  using Gm = Y5H3bGeom<NSW, K64, CV3>;
+  auto kern = y5_conv_h3b_kernel<NSW, K64, CV3>;
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -145,8 +145,9 @@ extern "C" int y5_bottleneck_cv3_fwd(const void* x, int ldx, const void* w1_pack
                                      const float* bias2, int Kpad2, const void* y2, int ld2, const void* w3_packed, const float* bias3, int Kpad3,
                                      int C3, int act3, void* out, int ldo, int B, int H, int W, int C, int add, int max_blocks, void* stream_) {
   if (!x || !w1_packed || !bias1 || !w2_packed || !bias2 || !y2 || !w3_packed || !bias3 || !out) return y5_fail(Y5_ERR_BAD_ARG, "bottleneck_cv3: null pointer");
-  if (C != 32) return y5_fail(Y5_ERR_UNSUPPORTED, "bottleneck_cv3: built for 32-channel Bottlenecks (cv3: 64 -> <= 64 channels)");
-  if (B < 1 || H < 4 || W < 8 || (H & 3) || (W & 7) || H > 255 * 4 || W > 65535) return y5_fail(Y5_ERR_UNSUPPORTED, "bottleneck_cv3: needs H % 4 == 0 and W % 8 == 0");
+  if (C != 32 && C != 128) return y5_fail(Y5_ERR_UNSUPPORTED, "bottleneck_cv3: built for 32-channel (cv3: 64 -> <= 64) and 128-channel (cv3: 256 -> <= 256) Bottlenecks");
+  if (C == 32 && (B < 1 || H < 4 || W < 8 || (H & 3) || (W & 7) || H > 255 * 4 || W > 65535)) return y5_fail(Y5_ERR_UNSUPPORTED, "bottleneck_cv3: needs H % 4 == 0 and W % 8 == 0");
+  if (C == 128 && (B < 1 || H < 1 || W < 1 || H > 65535 || W > 65535)) return y5_fail(Y5_ERR_UNSUPPORTED, "bottleneck_cv3: bad image size");
   if ((ldx & 7) || (ld2 & 7) || (ldo & 7) || ldx < C || ld2 < C || Kpad1 < C || (Kpad1 & 7) || Kpad2 < 9 * C || (Kpad2 & 7) || Kpad3 < 2 * C || (Kpad3 & 7) ||
       C3 < 8 || C3 > 2 * C || (C3 & 7) || ldo < C3)
     return y5_fail(Y5_ERR_BAD_ARG, "bottleneck_cv3: bad strides / packed filter dims / output channels");
@@ -175,6 +176,15 @@ extern "C" int y5_bottleneck_cv3_fwd(const void* x, int ldx, const void* w1_pack
   p.w3 = w3_packed; p.b3 = bias3; p.Kpad3 = Kpad3; p.C3 = C3; p.act3 = act3; p.w3_bytes = (unsigned)((long long)2 * C * Kpad3 * 2);
   hipStream_t st = static_cast<hipStream_t>(stream_);
   max_blocks &= 0xffff;
+  if (C == 128) {   // conv_h3b.h CV3: GEMM-1 phase + halo-resident 3x3 + cv3 as a GEMM-3 phase (the Bottleneck's result stays in LDS)
+    Y5H3bParams q{};
+    q.x = x; q.w1 = w1_packed; q.w2 = w2_packed; q.b1 = bias1; q.b2 = bias2; q.y = out;
+    q.x_bytes = p.x_bytes; q.w1_bytes = p.w1_bytes; q.w2_bytes = p.w2_bytes;
+    q.B = B; q.H = H; q.W = W; q.ldx = ldx; q.ldy = ldo; q.Kpad1 = Kpad1; q.Kpad2 = Kpad2; q.add = add;
+    q.y2 = y2; q.ld2 = ld2; q.y2_bytes = p.y2_bytes; q.w3 = w3_packed; q.b3 = bias3; q.Kpad3 = Kpad3; q.C3 = C3; q.act3 = act3;
+    q.w3_bytes = (unsigned)((long long)((C3 + 31) / 32 * 32) * Kpad3 * 2);
+    return launch_h3b<9, false, true>(q, max_blocks, st);
+  }
   return add ? launch_bneck<32, 1, true, true>(p, max_blocks, st) : launch_bneck<32, 1, false, true>(p, max_blocks, st);
 }
 

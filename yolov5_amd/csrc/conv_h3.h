@@ -184,7 +184,7 @@ void y5_conv_h3_kernel(const Y5ConvParams p) {
       const bool ok = (a_rc[k] >> 16) != 0 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
       y5_bglds16(xrs, ok ? (unsigned)(s_base + a_rel[k] + cc * 64) : Y5_OOB, a_lds + (cc & 1) * A_STAGE + I * 1024);
     } else if (with_dummy) {
-      y5_bglds16(xrs, Y5_OOB, dummy);
+      y5_bglds16_dummy(xrs, dummy);
     }
   };
   auto issue_w = [&](int stage, int tap, int cc) {
@@ -192,7 +192,7 @@ void y5_conv_h3_kernel(const Y5ConvParams p) {
 #pragma unroll
     for (int q = 0; q < WPW; ++q) {
       if (Gm::W_INSTR % NW == 0 || q * NW + wave < Gm::W_INSTR) y5_bglds16(wrs, w_off[q] + koff, w_lds + stage * W_STAGE + (q * NW + wave) * 1024);
-      else y5_bglds16(wrs, Y5_OOB, dummy);
+      else y5_bglds16_dummy(wrs, dummy);
     }
   };
   auto prologue = [&](int j) {  // first halo chunk + the filter slices of steps 0..NSW-2 (a tile has at least nine steps)

@@ -27,10 +27,18 @@ struct Y5H3bParams {
   unsigned x_bytes, w1_bytes, w2_bytes;
   int B, H, W, ldx, ldy, Kpad1, Kpad2, add;
   int th, tw, tiles_h, tiles_w;
+  // CV3 kernels: C3's cv3 in the same launch (models/common.py:246: cv3(cat(m(cv1(x)), cv2(x)))): out = act3(W3 [y ; y2] + b3); y (the Bottleneck's
+  // result) never leaves LDS, `y` above is then the destination `out` (pixel stride ldy, C3 <= 256 channels)
+  const void* y2;           // C3.cv2's output: NHWC slice of 128 channels, pixel stride ld2
+  const void* w3;           // [256][Kpad3] fp16, k = (y's 128 channels, then y2's)
+  const float* b3;
+  unsigned y2_bytes, w3_bytes;
+  int ld2, Kpad3, C3, act3;
 };
 
-template <int NSW_, bool K64_ = false>
+template <int NSW_, bool K64_ = false, bool CV3_ = false>
 struct Y5H3bGeom {
+  static constexpr bool CV3 = CV3_;   // + C3's cv3 as a GEMM-3 phase behind the tap loop (the planes hold the Bottleneck's result as its A operand)
   static constexpr bool K64 = K64_;   // one barrier per TWO (tap, chunk) slices = 16 MFMAs per wave (needs the deep ring: two double-steps of lead)
   static constexpr int C = 128, NCC = 4, NW = 8, WN = 2, TM = 2, TN = 2, HPMAX = 320;
   static constexpr int NAI_MAX = HPMAX / 16, PLANE = NAI_MAX * 1024;   // 20 pieces of 16 halo pixels x 64 B
@@ -50,8 +58,13 @@ struct Y5H3bGeom {
   static constexpr size_t OFF_RING = (size_t)NCC * PLANE;
   static constexpr size_t OFF_W1 = W1RES ? OFF_RING + (size_t)NSW * W_STAGE : OFF_RING + (size_t)W1_ST0 * W_STAGE;
   static constexpr size_t OFF_DUMMY = OFF_RING + (size_t)NSW * W_STAGE + (W1RES ? (size_t)C * C * 2 : 0);
-  static constexpr size_t OFF_BIAS = OFF_DUMMY + 1024;   // b1, b2 as fp32 (1 KB): per-lane ds_read_b128 instead of 16 global loads per accumulator block
-  static constexpr size_t LDS = OFF_BIAS + 2 * C * 4;
+  static constexpr size_t OFF_BIAS = OFF_DUMMY + 1024;   // b1, b2 (, b3) as fp32: per-lane ds_read_b128 instead of 16 global loads per accumulator block
+  static constexpr size_t LDS = OFF_BIAS + (CV3 ? 4 : 2) * C * 4;
+  // GEMM 3 (CV3): K = 256 in eight 32-channel chunks; chunks 0..3 take their A operand from the planes (the Bottleneck's result), chunks 4..7 stream y2
+  // (256 rows x 64 B) beside the filter chunk (256 rows x 64 B): two 32 KB stages inside the ring, B = [40 KB, 72 KB) (filled while the first epilogue still
+  // uses the scratch at [0, 20 KB)) and A = [8 KB, 40 KB)
+  static constexpr int G3_STAGE = 2 * 256 * 64, G3_OFF_B = 5 * W_STAGE, G3_OFF_A = W_STAGE, G3_PPW = 4;
+  static_assert(!CV3 || (NSW == 9 && !K64_), "cv3 phase: 9-stage ring, single-step loop");
   static_assert(NW * SCR_BYTES <= (W1RES ? NSW : W1_ST0) * W_STAGE, "epilogue scratch must fit into the filter ring (in front of the streamed W1)");
   static_assert(NSW >= 4 && NSW <= 9 && (W1RES || NSW >= W1_ST0 + 5) && LDS <= 160 * 1024, "ring depth");
   // pieces of the next tile's halo a wave issues in tap t of any chunk
@@ -89,11 +102,12 @@ __device__ unsigned long long y5_h3b_stamps[512 * 4 * 8];
 #define Y5_H3B_STAMP(k) ((void)0)
 #endif
 
-template <int NSW_, bool K64_ = false>
+template <int NSW_, bool K64_ = false, bool CV3_ = false>
 __global__ __launch_bounds__(512, 1)
 void y5_conv_h3b_kernel(const Y5H3bParams p) {
   typedef half_t T;
-  using Gm = Y5H3bGeom<NSW_, K64_>;
+  using Gm = Y5H3bGeom<NSW_, K64_, CV3_>;
+  constexpr bool CV3 = CV3_;
   constexpr int NW = Gm::NW, TM = Gm::TM, TN = Gm::TN, NSW = Gm::NSW, APS = Gm::APS, PLANE = Gm::PLANE, W_STAGE = Gm::W_STAGE;
   constexpr int SCR_ROWB = Gm::SCR_ROWB, NRB1 = Gm::NRB1;
 
@@ -210,7 +224,7 @@ void y5_conv_h3b_kernel(const Y5H3bParams p) {
       const bool ok = (a_rc[k] >> 16) != 0 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
       y5_bglds16(xrs, ok ? (unsigned)(s_base + a_rel[k] + cc * 64) : Y5_OOB, a_lds + cc * PLANE + I * 1024);
     } else {
-      y5_bglds16(xrs, Y5_OOB, dummy);
+      y5_bglds16_dummy(xrs, dummy);
     }
   };
   auto issue_w2 = [&](int stage, int s) {  // slice s = chunk * 9 + tap
@@ -255,7 +269,11 @@ void y5_conv_h3b_kernel(const Y5H3bParams p) {
               for (int e = 0; e < 8; ++e) c[e] = (half_t)((float)a[e] + (float)r8[e]);
               raw = __builtin_bit_cast(uint4_t, c);
             }
-            *reinterpret_cast<uint4_t*>(yg + mo * p.ldy + n) = raw;
+            if constexpr (!CV3) *reinterpret_cast<uint4_t*>(yg + mo * p.ldy + n) = raw;
+            else {   // the Bottleneck's result as the A operand of GEMM 3: plane n / 32, row = tile pixel m, 16-byte slot swizzled like every operand tile
+              const int m = (wm * TM + i) * 32 + ps * 16 + (lane >> 2);
+              *reinterpret_cast<uint4_t*>(a_lds + (n >> 5) * PLANE + (m << 6) + ((vs ^ ((m >> 2) & 3)) << 4)) = raw;
+            }
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -272,6 +290,10 @@ void y5_conv_h3b_kernel(const Y5H3bParams p) {
   if (tid < Gm::C) {   // (visible to every wave behind the first tile's barrier)
     bias_lds[tid] = p.b1[tid];
     bias_lds[Gm::C + tid] = p.b2[tid];
+    if constexpr (CV3) {
+      bias_lds[2 * Gm::C + tid] = tid < p.C3 ? p.b3[tid] : 0.f;
+      bias_lds[3 * Gm::C + tid] = Gm::C + tid < p.C3 ? p.b3[Gm::C + tid] : 0.f;
+    }
   }
   issue_w1();
   x_setup(0);
@@ -443,8 +465,8 @@ void y5_conv_h3b_kernel(const Y5H3bParams p) {
           else y5_wait_vm<Gm::allowed(t, false)>();
           __builtin_amdgcn_s_barrier();
           // plane cc-1 is dead (its last fragments were consumed in the step before this chunk's tap 0): it takes the next tile's x halo
-          if constexpr (t < 2)
-            y5_static_for<t * Gm::PPS, (t + 1) * Gm::PPS < APS ? (t + 1) * Gm::PPS : APS>([&](auto kc) { issue_x(kc, cc - 1, cc > 0); });
+          if constexpr (t < 2)   // (CV3: the planes are needed for GEMM 3 -- dummies keep the counts; the halo is issued behind GEMM 3)
+            y5_static_for<t * Gm::PPS, (t + 1) * Gm::PPS < APS ? (t + 1) * Gm::PPS : APS>([&](auto kc) { issue_x(kc, cc - 1, cc > 0 && !CV3); });
           // slice s + NSW - 1 goes into the stage slice s - 1 occupied (every wave finished reading it before this barrier)
           const int st_prev = st_cur == 0 ? NSW - 1 : st_cur - 1;
           if (!last || t <= 9 - NSW) issue_w2(st_prev, cc * 9 + t + NSW - 1);
@@ -477,11 +499,118 @@ void y5_conv_h3b_kernel(const Y5H3bParams p) {
     }
     __syncthreads();  // every wave is done with the ring and with the last plane
     Y5_H3B_STAMP(4);
-    y5_static_for<0, APS>([&](auto kc) { issue_x(kc, Gm::NCC - 1, true); });  // the next tile's last plane flies during the epilogue
-    if constexpr (!Gm::W1RES) {
-      if (ti + 1 < nmine) issue_w1();   // ... and so does its W1, into the ring stages behind the scratch
+    if constexpr (!CV3) {
+      y5_static_for<0, APS>([&](auto kc) { issue_x(kc, Gm::NCC - 1, true); });  // the next tile's last plane flies during the epilogue
+      if constexpr (!Gm::W1RES) {
+        if (ti + 1 < nmine) issue_w1();   // ... and so does its W1, into the ring stages behind the scratch
+      }
+      epilogue(tb, toh0, tow0);
+    } else {
+      // ---- phase 3: out = act3(W3 [y ; y2] + b3) ---------------------------------------------------------------------------------------------
+      const y5_rsrc_t y2rs = y5_make_rsrc(p.y2, p.y2_bytes);
+      const y5_rsrc_t w3rs = y5_make_rsrc(p.w3, p.w3_bytes);
+      // loader: per chunk a wave issues two 16-row pieces of the filter chunk and (chunks 4..7) two of y2's rows = tile pixels
+      unsigned w3_off[2], y2_off[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int row = (q * NW + wave) * 16 + (lane >> 2);
+        const int ss = (lane & 3) ^ ((row >> 2) & 3);
+        w3_off[q] = row < p.C3 ? (unsigned)(row * p.Kpad3 * 2 + ss * 16) : Y5_OOB;
+        const int r = row / TW, c = row - r * TW;
+        const bool ok = r < TH && toh0 + r < p.H && tow0 + c < p.W;
+        y2_off[q] = ok ? (unsigned)((((tb * p.H + toh0 + r) * p.W + tow0 + c) * p.ld2) * 2 + ss * 16) : Y5_OOB;
+      }
+      // (no dummies here: chunks 0..3 are two loads per wave, chunks 4..7 four, and the waits below count exactly that.  The first version padded
+      // with pairs of plain out-of-range loads into the dummy region, which the compiler merged into ONE load -- every counted wait behind them one short, wrong results at
+      // slow y2 pitches: profiles/r05/r05_dummy_dma_merge.log, y5_common.h y5_bglds16_dummy)
+      auto issue3 = [&](int c) {
+        char* st = w_lds + ((c & 1) ? Gm::G3_OFF_A : Gm::G3_OFF_B);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) y5_bglds16(w3rs, w3_off[q] == Y5_OOB ? Y5_OOB : w3_off[q] + (unsigned)(c * 64), st + (q * NW + wave) * 1024);
+        if (c >= 4) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q) y5_bglds16(y2rs, y2_off[q] == Y5_OOB ? Y5_OOB : y2_off[q] + (unsigned)((c - 4) * 64), st + 256 * 64 + (q * NW + wave) * 1024);
+        }
+      };
+      issue3(0);                       // into stage B: flies during the first epilogue (whose scratch is below it)
+      epilogue(tb, toh0, tow0);        // y = [x +] SiLU(acc + b2) -> planes (fp16, exactly what the two-launch form stores)
+      __syncthreads();
+      float16_t acc3[2][4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc3[i][j][r] = 0.f;
+      int a3[2], w3_rd[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = (wm * 2 + i) * 32 + frow;
+        a3[i] = (m << 6) | ((g ^ ((m >> 2) & 3)) << 4);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w3_rd[j] = ((wn * 4 + j) * 32 + frow) * 64 + ((g ^ fsw) << 4);
+      for (int c = 0; c < 8; ++c) {
+        if (c + 1 < 8) issue3(c + 1);
+        // chunk c landed (chunk c + 1 may be in flight: two loads per wave up to chunk 3, four from chunk 4 on)
+        if (c + 1 < 4) y5_wait_vm<2>();
+        else if (c + 1 < 8) y5_wait_vm<4>();
+        else y5_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        const char* st = w_lds + ((c & 1) ? Gm::G3_OFF_A : Gm::G3_OFF_B);
+        const char* ab = c < 4 ? a_lds + c * PLANE : st + 256 * 64;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          half8_t af3[2], wf3[4];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) af3[i] = *reinterpret_cast<const half8_t*>(ab + (a3[i] ^ (ks * 32)));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) wf3[j] = *reinterpret_cast<const half8_t*>(st + (w3_rd[j] ^ (ks * 32)));
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc3[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf3[j], af3[i], acc3[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_barrier();   // every wave is done with this stage before chunk c + 2 lands in it
+      }
+      // planes and ring are idle: the next tile's x halo and W1 fly during the second epilogue
+#pragma unroll
+      for (int cc = 0; cc < Gm::NCC; ++cc) y5_static_for<0, APS>([&](auto kc) { issue_x(kc, cc, true); });
+      if (ti + 1 < nmine) issue_w1();
+      // second epilogue: bias + act3 -> scratch -> 16-byte row-contiguous stores of the 256-channel result
+      T* og = static_cast<T*>(p.y);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int nt = (wn * 4 + j) * 32;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4_t bq = *reinterpret_cast<const float4_t*>(bias_lds + 2 * Gm::C + nt + q * 8 + g * 4);
+            half4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float t = acc3[i][j][q * 4 + e] + bq[e]; o[e] = (half_t)(p.act3 ? y5_silu(t) : t); }
+            *reinterpret_cast<half4_t*>(scratch + frow * SCR_ROWB + (q * 8 + g * 4) * 2) = o;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int ps = 0; ps < 2; ++ps) {
+            const int rc = o_rc[i][ps];
+            const int oh = toh0 + (rc & 0xffff), ow = tow0 + (rc >> 16);
+            const int vs = lane & 3;
+            const int n = nt + vs * 8;
+            if (rc >= 0 && oh < p.H && ow < p.W && n < p.C3) {
+              const uint4_t raw = *reinterpret_cast<const uint4_t*>(scratch + (ps * 16 + (lane >> 2)) * SCR_ROWB + vs * 16);
+              const size_t mo = ((size_t)tb * p.H + oh) * p.W + ow;
+              *reinterpret_cast<uint4_t*>(og + mo * p.ldy + n) = raw;
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
     }
-    epilogue(tb, toh0, tow0);
     Y5_H3B_STAMP(5);
   }
 }

@@ -63,7 +63,7 @@ void y5_conv_headk_kernel(const Y5ConvParams p, const Y5HeadParams hd) {
   };
   auto issue_dummy = [&]() {
 #pragma unroll
-    for (int q = 0; q < PPW; ++q) y5_bglds16(xrs, Y5_OOB, dummy);
+    for (int q = 0; q < PPW; ++q) y5_bglds16_dummy(xrs, dummy);
   };
 
   const int hp = wave * 32 + frow;

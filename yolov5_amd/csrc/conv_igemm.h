@@ -344,7 +344,7 @@ void y5_conv_igemm_kernel(const Y5ConvParams p) {
       if (WGT_INSTR % NW == 0 || idx < WGT_INSTR) {
         y5_bglds16(wrs, w_off[i] + st_kcb, st_lds + BM * RB + idx * 1024);
       } else if (NS > 2) {
-        y5_bglds16(wrs, Y5_OOB, dummy);  // keeps the per-chunk LDS-DMA count identical in every wave (counted vmcnt)
+        y5_bglds16_dummy(wrs, dummy);  // keeps the per-chunk LDS-DMA count identical in every wave (counted vmcnt)
       }
     }
   };

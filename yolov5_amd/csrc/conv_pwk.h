@@ -61,12 +61,12 @@ void y5_conv_pwk_kernel(const Y5ConvParams p) {
 #pragma unroll
     for (int q = 0; q < WPW; ++q) {
       if ((q * NW + wave) * 16 < Gm::BN) y5_bglds16(wrs, w_off[q] == Y5_OOB ? Y5_OOB : w_off[q] + (unsigned)(c * 64), st + XS + (q * NW + wave) * 1024);
-      else y5_bglds16(wrs, Y5_OOB, dummy);
+      else y5_bglds16_dummy(wrs, dummy);
     }
   };
   auto issue_dummy = [&]() {
 #pragma unroll
-    for (int q = 0; q < PPW; ++q) y5_bglds16(xrs, Y5_OOB, dummy);
+    for (int q = 0; q < PPW; ++q) y5_bglds16_dummy(xrs, dummy);
   };
 
   const int hp = wave * 32 + frow;

@@ -78,10 +78,10 @@ void y5_sppf_cv1_pool_kernel(const Y5SppfParams p) {
     for (int q = 0; q < XPW; ++q) {
       const int I = q * NW + wave;
       if (I < Gm::NAIX) y5_bglds16(xrs, x_off[q] == Y5_OOB ? Y5_OOB : x_off[q] + (unsigned)(c * 64), st + I * 1024);
-      else y5_bglds16(xrs, Y5_OOB, dummy);
+      else y5_bglds16_dummy(xrs, dummy);
     }
     if (wave < 4) y5_bglds16(wrs, w_off + (unsigned)(c * 64), st + XS + wave * 1024);
-    else y5_bglds16(wrs, Y5_OOB, dummy);
+    else y5_bglds16_dummy(wrs, dummy);
   };
 
   // ---- GEMM ----------------------------------------------------------------------------------------------------------------------------------------
@@ -102,14 +102,14 @@ void y5_sppf_cv1_pool_kernel(const Y5SppfParams p) {
 #pragma unroll
   for (int c = 0; c < NS - 1; ++c)
     if (c < NK) issue(c);
-    else { for (int q = 0; q < PPW; ++q) y5_bglds16(xrs, Y5_OOB, dummy); }
+    else { for (int q = 0; q < PPW; ++q) y5_bglds16_dummy(xrs, dummy); }
   for (int c = 0; c < NK; ++c) {
     // chunk c has landed: everything but the chunks issued after it (c+1 .. c+NS-2, PPW instructions each; dummies past the end keep this a constant)
     y5_wait_vm<(NS - 2) * PPW>();
     __builtin_amdgcn_s_barrier();
     // chunk c + NS - 1 goes into the stage chunk c - 1 occupied (every wave finished reading it before this barrier)
     if (c + NS - 1 < NK) issue(c + NS - 1);
-    else { for (int q = 0; q < PPW; ++q) y5_bglds16(xrs, Y5_OOB, dummy); }
+    else { for (int q = 0; q < PPW; ++q) y5_bglds16_dummy(xrs, dummy); }
     const char* st = smem + (c % NS) * STAGE;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {

@@ -34,6 +34,17 @@ __device__ __forceinline__ void y5_bglds16(y5_rsrc_t r, unsigned voff, void* lds
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, Y5_LDS_PTR(lds_wave_base), 16, (int)voff, 0, 0, 0);
 }
 
+// A load that moves nothing (every lane out of range -> zeros into a 1 KB dummy region): waves that have no piece of a stage issue it so that the
+// counted vmcnt waits see the same number of loads in every wave.  The compiler barrier behind it is REQUIRED: two identical dummies in a row are
+// otherwise merged into one (dead-store elimination on the intrinsic -- measured on conv_headk.h's ring tail, profiles/r05/r05_dummy_dma_merge.log),
+// which silently makes every counted wait behind them too lenient.
+__device__ __forceinline__ void y5_bglds16_dummy(y5_rsrc_t r, void* dummy_lds) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, Y5_LDS_PTR(dummy_lds), 16, (int)Y5_OOB, 0, 0, 0);
+#if !defined(Y5_EMU) && !defined(Y5_DUMMY_MERGEABLE)   // (Y5_DUMMY_MERGEABLE: the A/B build of scripts/build_dummy_ab.sh only)
+  asm volatile("" ::: "memory");
+#endif
+}
+
 // 16-byte buffer store / load with an explicit cache policy (aux: 16 = sc1, write-through / bypass of the non-coherent levels): the
 // transport of data that another workgroup -- possibly on another XCD -- reads within the same launch (stream-K slabs)
 __device__ __forceinline__ void y5_buffer_store16(uint4_t v, y5_rsrc_t r, int voff, int aux) {

@@ -888,7 +888,7 @@ class Engine:
         cv3 = self._fused_cv3_args(op, base, tail)
         if cv3 is not None:
             self._k3pw_skip = self._cur + 1
-            self.op_names.append("bneck+cv3:" + op["name"] + "+" + cv3["name"])
+            self.op_names.append(("bneck128+cv3:" if x.C == 128 else "bneck+cv3:") + op["name"] + "+" + cv3["name"])
             return self.lib.y5_plan_add_bottleneck_cv3(self.plan, *base, *cv3["args"], *tail)
         self.op_names.append(("bneck128:" if x.C == 128 else "bneck:") + op["name"])
         return self.lib.y5_plan_add_bottleneck(self.plan, *base, self._ptr(y), self._ld(y), *tail)
@@ -897,14 +897,16 @@ class Engine:
         mode = os.environ.get("Y5_FUSED_CV3", "auto")
         nxt_i = self._cur + 1
         x, y = op["x"], op["y"]
-        if mode == "0" or self.dt != _lib.Y5_F16 or x.C != 32 or nxt_i >= len(self.spec.ops):
+        if x.C == 128:   # c_ = 128 (conv_h3b.h, CV3 form): its own switch, same meaning
+            mode = os.environ.get("Y5_FUSED_CV3_128", "auto")
+        if mode == "0" or self.dt != _lib.Y5_F16 or x.C not in (32, 128) or nxt_i >= len(self.spec.ops):
             return None
         nxt = self.spec.ops[nxt_i]
         if not (nxt["op"] == "conv" and _pair(nxt["k"]) == (1, 1) and _pair(nxt["s"]) == (1, 1) and _pair(nxt["p"]) == (0, 0) and nxt["res"] is None
-                and nxt["y2"] is None and not nxt.get("split_n") and not nxt.get("side") and nxt["c2_store"] <= 64 and nxt["c2_store"] % 8 == 0):
+                and nxt["y2"] is None and not nxt.get("split_n") and not nxt.get("side") and nxt["c2_store"] <= 2 * x.C and nxt["c2_store"] % 8 == 0):
             return None
         cat = nxt["x"]
-        if not (cat.buf == y.buf and cat.c_off == y.c_off and cat.C == 2 * y.C and y.C == 32):  # this Bottleneck writes the first half of cv3's input
+        if not (cat.buf == y.buf and cat.c_off == y.c_off and cat.C == 2 * y.C and y.C == x.C):  # this Bottleneck writes the first half of cv3's input
             return None
         for k, o in enumerate(self.spec.ops):  # the Bottleneck's own output must have no other reader
             if k in (self._cur, nxt_i):
@@ -915,7 +917,7 @@ class Engine:
         if mode != "1" and not getattr(self.be, "autotune", False):
             return None
         (_g, (wp3, bp3, _K3, Kpad3, Npad3), stem3) = self._conv_weights(nxt)
-        if stem3 is not None or Npad3 != 64:
+        if stem3 is not None or Npad3 > 2 * x.C:
             return None
         wp3, bp3 = self.be.from_torch(wp3), self.be.from_torch(bp3)
         y2 = _slice(cat, y.C, y.C)
@@ -1282,7 +1284,7 @@ class Engine:
                 out.append((n, next(ci, None)))
             elif n.startswith("sppf_front:"):
                 out.append((n, "sppf"))     # csrc/conv_sppf.h
-            elif n.startswith("bneck128:"):
+            elif n.startswith("bneck128"):
                 out.append((n, "h3b"))      # csrc/conv_h3b.h (the 128-channel Bottleneck: GEMM-1 phase + halo-resident 3x3)
             elif n.startswith("bneck"):
                 out.append((n, "bneck"))
