@@ -270,3 +270,33 @@ def test_head_layout_roundtrip(B, npix, na, no, ld, dev):
     want = torch.zeros_like(dlg)
     want[..., : na * no] = draw.permute(0, 2, 1, 3).reshape(B, npix, na * no)
     assert torch.equal(dlg, want)
+
+
+@pytest.mark.parametrize("B,H,W,Cc", [(64, 20, 20, 256), (3, 13, 17, 24), (2, 40, 40, 64)])
+def test_sppf_pool_bwd_matches_autograd_and_repeats(B, H, W, Cc, dev):
+    """y5_sppf_pool_bwd (csrc/train_misc.hip; SPPF's three chained max_pool2d(5, 1, 2), models/common.py:338-340) against torch autograd on the CPU --
+    fp16 activations quantised to a coarse grid so that windows hold many equal maxima (the first-in-scan-order tie rule decides) -- and bit-identical
+    across repeated launches: the gather form has no atomics (bs 64 x 20 x 20 x 256 is yolov5s' 9.SPPF at 640^2)."""
+    from yolov5_amd import _lib
+
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(B + H + Cc)
+    x = ((torch.rand((B, Cc, H, W), generator=g) * 8).round() / 4 - 1).half().float().requires_grad_(True)   # 9 distinct values: ties everywhere
+    y1 = F.max_pool2d(x, 5, 1, 2)
+    y2 = F.max_pool2d(y1, 5, 1, 2)
+    y3 = F.max_pool2d(y2, 5, 1, 2)
+    gs = [(torch.rand((B, Cc, H, W), generator=g) * 2 - 1).half().float() for _ in range(4)]
+    (x * gs[0] + y1 * gs[1] + y2 * gs[2] + y3 * gs[3]).sum().backward()
+    act = torch.cat([t.detach().permute(0, 2, 3, 1) for t in (x, y1, y2, y3)], -1).half().contiguous().to(dev)
+    grad0 = torch.cat([t.permute(0, 2, 3, 1) for t in gs], -1).half().contiguous().to(dev)
+    outs = []
+    for _ in range(3):
+        grad = grad0.clone()
+        _lib.check(lib.y5_sppf_pool_bwd(C.c_void_p(act.data_ptr()), C.c_void_p(grad.data_ptr()), B, H, W, Cc, 4 * Cc, 4 * Cc, 5, _lib.stream(dev)), lib)
+        torch.cuda.synchronize()
+        outs.append(grad[..., :Cc].clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    ref = x.grad.permute(0, 2, 3, 1)
+    got = outs[0].float().cpu()
+    # sums of up to 1 + 25 + 25^2 ... fp16-rounded terms in fp32, rounded to fp16 once: a few fp16 ulps of the largest sums
+    assert float((got - ref).abs().max()) <= 4e-3 * max(1.0, float(ref.abs().max())), float((got - ref).abs().max())

@@ -91,8 +91,11 @@ __global__ void y5_add_slice_kernel(const char* __restrict__ src, char* __restri
 
 // SPPF backward.  act: NHWC buffer [x | y1 | y2 | y3] (4*C channels), grad: same geometry holding d/d[x|y1|y2|y3] as left by
 // the consumer's data-gradient; on return grad[..., 0:C] holds the total gradient w.r.t. x (slices 1..3 are consumed).
-// One workgroup per (image, 8-channel group); fp32 accumulators in LDS; argmax = first maximum in (kh, kw) scan order
-// (torch's max_pool2d_with_indices tie rule).
+// One workgroup per (image, 8-channel group); fp32 planes in LDS; argmax = first maximum in (kh, kw) scan order
+// (torch's max_pool2d_with_indices tie rule).  Deterministic: every pool output records the position of its maximum, then every INPUT position
+// gathers -- in scan order -- the output gradients of the windows whose maximum it is (as torch's max_pool2d backward does; the first version
+// scattered with LDS atomics, whose order, hence fp32 rounding, changed from run to run: tests/test_gpu_train.py deterministic check,
+// profiles/r05/r05_sppf_bwd_deterministic.log).
 // GV = 16-byte channel groups (8 channels each) a workgroup owns: 4 = 64 contiguous bytes per pixel (half a cache line per access
 // instead of 16 bytes out of every 2 KiB row), 1 when the H*W planes of four groups do not fit LDS.
 template <int GV>
@@ -102,10 +105,11 @@ void y5_sppf_pool_bwd_kernel(const char* __restrict__ act, char* __restrict__ gr
   const int HW = H * W;
   const int n = HW * GV;                                               // vector index v = pixel * GV + group-in-workgroup
   half8_t* a_in = reinterpret_cast<half8_t*>(smem);                 // [n] activation of the pool input
-  // component-major planes [8][n]: consecutive lanes hit consecutive LDS banks (the [n][8] layout put a wave's scatter-adds 32 bytes apart: a
-  // 16-way bank conflict on every one of the eight ds_add_f32 per vector -- 246 us for a 26 MB tensor)
+  // component-major planes [8][n]: consecutive lanes hit consecutive LDS banks (the [n][8] layout put a wave's accesses 32 bytes apart: a
+  // 16-way bank conflict on every one of the eight accesses per vector -- 246 us for a 26 MB tensor)
   float* g_out = reinterpret_cast<float*>(a_in + n);                // [8][n] gradient of the pool output
-  float* g_in = g_out + (size_t)n * 8;                              // [8][n] gradient accumulated for the pool input
+  float* g_in = g_out + (size_t)n * 8;                              // [8][n] gradient of the pool input (direct part, then the total)
+  unsigned char* amax = reinterpret_cast<unsigned char*>(g_in + (size_t)n * 8);   // [8][n] window-relative position (dy * k + dx, k <= 15) of the maximum of output v's window
   const int groups = C_bytes / (16 * GV);
   const int b = blockIdx.x / groups, cg = blockIdx.x - b * groups;
   const char* abase = act + (size_t)b * HW * lda_b + (size_t)cg * 16 * GV;
@@ -126,6 +130,7 @@ void y5_sppf_pool_bwd_kernel(const char* __restrict__ act, char* __restrict__ gr
       for (int e = 0; e < 8; ++e) g_in[e * n + v] = (float)q[e];  // direct gradient of that slice (from cv2's data-gradient)
     }
     __syncthreads();
+    // (a) where is the maximum of output v's window
     for (int v = threadIdx.x; v < n; v += blockDim.x) {
       const int i = v / GV, gl = v % GV;
       const int y = i / W, x = i - y * W;
@@ -137,20 +142,41 @@ void y5_sppf_pool_bwd_kernel(const char* __restrict__ act, char* __restrict__ gr
       {
         const half8_t q = a_in[(y0 * W + x0) * GV + gl];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { best[e] = (float)q[e]; bi[e] = y0 * W + x0; }
+        for (int e = 0; e < 8; ++e) { best[e] = (float)q[e]; bi[e] = (y0 - y + r) * k + (x0 - x + r); }
       }
       for (int yy = y0; yy <= y1; ++yy)
         for (int xx = x0; xx <= x1; ++xx) {
-          const int pos = yy * W + xx;
+          const int pos = yy * W + xx, code = (yy - y + r) * k + (xx - x + r);   // window-relative position: what phase (b) compares with
           const half8_t q = a_in[pos * GV + gl];
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const float t = (float)q[e];
-            if (t > best[e]) { best[e] = t; bi[e] = pos; }
+            if (t > best[e]) { best[e] = t; bi[e] = code; }
           }
         }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) atomicAdd(&g_in[e * n + bi[e] * GV + gl], g_out[e * n + v]);
+      for (int e = 0; e < 8; ++e) amax[e * n + v] = (unsigned char)bi[e];
+    }
+    __syncthreads();
+    // (b) input position i collects, in scan order, the gradients of the outputs whose window contains it and whose maximum it is
+    for (int v = threadIdx.x; v < n; v += blockDim.x) {
+      const int i = v / GV, gl = v % GV;
+      const int y = i / W, x = i - y * W;
+      const int y0 = y - r < 0 ? 0 : y - r, y1 = y + r >= H ? H - 1 : y + r;
+      const int x0 = x - r < 0 ? 0 : x - r, x1 = x + r >= W ? W - 1 : x + r;
+      float s[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] = g_in[e * n + v];
+      for (int yy = y0; yy <= y1; ++yy)
+        for (int xx = x0; xx <= x1; ++xx) {
+          const int ov = (yy * W + xx) * GV + gl;
+          const unsigned char me = (unsigned char)((y - yy + r) * k + (x - xx + r));   // this input position as seen from output (yy, xx)
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (amax[e * n + ov] == me) s[e] += g_out[e * n + ov];
+        }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g_in[e * n + v] = s[e];   // (nobody else reads or writes this slot in this phase)
     }
     __syncthreads();
     // the accumulated input gradient is the next pass's output gradient
@@ -311,10 +337,11 @@ extern "C" int y5_sppf_pool_bwd(const void* act, void* grad, int B, int H, int W
   // 16-byte channel groups per workgroup: 2 = whole 32-byte sectors per pixel access AND two or more workgroups per CU (the kernel is a chain of
   // load -> barrier -> scatter-add -> barrier phases: with four groups one 128 KB workgroup per CU sat through every memory latency alone)
   static const int force_gv = getenv("Y5_SPPF_BWD_GV") ? atoi(getenv("Y5_SPPF_BWD_GV")) : 0;
-  int gv = (C % 16 == 0 && (size_t)H * W * 2 * (16 + 32 + 32) <= 150 * 1024) ? 2 : 1;
-  if (force_gv == 4 && C % 32 == 0 && (size_t)H * W * 4 * (16 + 32 + 32) <= 150 * 1024) gv = 4;
+  int gv = (C % 16 == 0 && (size_t)H * W * 2 * (16 + 32 + 32 + 8) <= 150 * 1024) ? 2 : 1;
+  if (force_gv == 4 && C % 32 == 0 && (size_t)H * W * 4 * (16 + 32 + 32 + 8) <= 150 * 1024) gv = 4;
   if (force_gv == 1) gv = 1;
-  const size_t lds = (size_t)H * W * gv * (16 + 32 + 32);
+  const size_t lds = (size_t)H * W * gv * (16 + 32 + 32 + 8);   // a_in, g_out, g_in, amax
+  if (k > 15) return y5_fail(Y5_ERR_UNSUPPORTED, "sppf_pool_bwd: kernel size above 15");
   if (lds > 150 * 1024) return y5_fail(Y5_ERR_UNSUPPORTED, "sppf_pool_bwd: H*W plane does not fit in LDS");
   static bool a = false;
   if (!a) {

@@ -897,8 +897,10 @@ class Engine:
         mode = os.environ.get("Y5_FUSED_CV3", "auto")
         nxt_i = self._cur + 1
         x, y = op["x"], op["y"]
-        if x.C == 128:   # c_ = 128 (conv_h3b.h, CV3 form): its own switch, same meaning
-            mode = os.environ.get("Y5_FUSED_CV3_128", "auto")
+        if x.C == 128:   # c_ = 128 (conv_h3b.h, CV3 form): its own switch, same meaning.  Default OFF: measured slower than the two-launch form on every box
+            # (97-100 us against 54 + 36, profiles/r05/r05_ab_cv3_128.log), and under a profiler's serialised launches the plan-build race picked
+            # it anyway -- a PMC pass must measure the plan the bench runs
+            mode = os.environ.get("Y5_FUSED_CV3_128", "0")
         if mode == "0" or self.dt != _lib.Y5_F16 or x.C not in (32, 128) or nxt_i >= len(self.spec.ops):
             return None
         nxt = self.spec.ops[nxt_i]
