@@ -114,6 +114,7 @@ inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f;
 inline int atomicAdd(int* p, int v) { int o = *p; *p += v; return o; }
 inline int atomicExch(int* p, int v) { int o = *p; *p = v; return o; }
 inline float atomicAdd(float* p, float v) { float o = *p; *p += v; return o; }
+inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
 inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 
 struct __amdgpu_buffer_rsrc_t { const char* base; unsigned num_records; };

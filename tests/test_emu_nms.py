@@ -155,6 +155,19 @@ def test_sppf_pool_emulated(dt, Cc, H, W):
         assert np.array_equal(buf[..., i * Cc:(i + 1) * Cc].astype(np.float32), t.permute(0, 2, 3, 1).numpy())
 
 
+def test_sppf_pool_bwd_gather_form_emulated():
+    """The gather fallback of y5_sppf_pool_bwd (planes too large for the fixed-point scatter; forced here with Y5_SPPF_BWD_GATHER=1, which the library
+    latches per process)."""
+    import os
+    import subprocess
+    import sys
+
+    code = "import tests.test_emu_nms as t; [t.test_sppf_pool_bwd_emulated(c) for c in (8, 32)]"
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, Y5_SPPF_BWD_GATHER="1"), capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 @pytest.mark.parametrize("Cc", [8, 32, 64])   # 32 / 64: four 16-byte groups per workgroup
 def test_sppf_pool_bwd_emulated(Cc):
     """y5_sppf_pool_bwd against torch autograd through three chained max_pool2d(5, 1, 2) (models/common.py:338-340)."""

@@ -91,16 +91,90 @@ __global__ void y5_add_slice_kernel(const char* __restrict__ src, char* __restri
 
 // SPPF backward.  act: NHWC buffer [x | y1 | y2 | y3] (4*C channels), grad: same geometry holding d/d[x|y1|y2|y3] as left by
 // the consumer's data-gradient; on return grad[..., 0:C] holds the total gradient w.r.t. x (slices 1..3 are consumed).
-// One workgroup per (image, 8-channel group); fp32 planes in LDS; argmax = first maximum in (kh, kw) scan order
-// (torch's max_pool2d_with_indices tie rule).  Deterministic: every pool output records the position of its maximum, then every INPUT position
-// gathers -- in scan order -- the output gradients of the windows whose maximum it is (as torch's max_pool2d backward does; the first version
-// scattered with LDS atomics, whose order, hence fp32 rounding, changed from run to run: tests/test_gpu_train.py deterministic check,
-// profiles/r05/r05_sppf_bwd_deterministic.log).
-// GV = 16-byte channel groups (8 channels each) a workgroup owns: 4 = 64 contiguous bytes per pixel (half a cache line per access
-// instead of 16 bytes out of every 2 KiB row), 1 when the H*W planes of four groups do not fit LDS.
+// One workgroup per (image, 8-channel group); planes in LDS; argmax = first maximum in (kh, kw) scan order (torch's max_pool2d_with_indices tie rule).
+// DETERMINISTIC, two forms (the first version scattered with fp32 LDS atomics, whose order -- hence rounding -- changed from run to run:
+// profiles/r05/r05_sppf_bwd_deterministic.log):
+//   y5_sppf_pool_bwd_kernel        every pool output scatters its gradient to the position of its maximum with 64-bit INTEGER LDS atomics on a 2^-24
+//                                  fixed-point grid.  Every fp16 value is a multiple of 2^-24, so are the sums: the accumulation is exact, hence independent
+//                                  of the order of the adds; between passes the total is rounded to fp32 once.  112 bytes of LDS per 8-channel vector.
+//   y5_sppf_pool_bwd_gather_kernel fallback for planes that do not fit (88 bytes per vector): every output records the window-relative position of its
+//                                  maximum (one byte), every INPUT position sums, in scan order, the outputs whose maximum it is.  2.4x slower.
+// GV = 16-byte channel groups (8 channels each) a workgroup owns.
+__device__ __forceinline__ long long y5_fix24(float x) { return (long long)(x * 16777216.0f); }   // exact: x is a multiple of 2^-24, |x| < 2^38
+__device__ __forceinline__ float y5_unfix24(long long s) { return (float)s * (1.0f / 16777216.0f); }   // one rounding (to nearest) of the exact sum
+
 template <int GV>
 __global__ __launch_bounds__(256)
 void y5_sppf_pool_bwd_kernel(const char* __restrict__ act, char* __restrict__ grad, int H, int W, int C_bytes, int lda_b, int ldg_b, int k) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int HW = H * W;
+  const int n = HW * GV;                                               // vector index v = pixel * GV + group-in-workgroup
+  half8_t* a_in = reinterpret_cast<half8_t*>(smem);                 // [n] activation of the pool input
+  // component-major planes [8][n]: consecutive lanes hit consecutive LDS banks
+  float* g_out = reinterpret_cast<float*>(a_in + n);                // [8][n] gradient of the pool output (fp32: a multiple of 2^-24)
+  unsigned long long* g_in = reinterpret_cast<unsigned long long*>(g_out + (size_t)n * 8);   // [8][n] gradient of the pool input, 2^-24 fixed point
+  const int groups = C_bytes / (16 * GV);
+  const int b = blockIdx.x / groups, cg = blockIdx.x - b * groups;
+  const char* abase = act + (size_t)b * HW * lda_b + (size_t)cg * 16 * GV;
+  char* gbase = grad + (size_t)b * HW * ldg_b + (size_t)cg * 16 * GV;
+  const int r = k / 2;
+  // g_out <- d/dy3
+  for (int v = threadIdx.x; v < n; v += blockDim.x) {
+    const half8_t q = *reinterpret_cast<const half8_t*>(gbase + (size_t)(v / GV) * ldg_b + 3 * (size_t)C_bytes + (v % GV) * 16);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g_out[e * n + v] = (float)q[e];
+  }
+  for (int pass = 3; pass >= 1; --pass) {  // pool `pass`: input slice pass-1 -> output slice pass
+    for (int v = threadIdx.x; v < n; v += blockDim.x) {
+      const size_t po = (size_t)(pass - 1) * C_bytes + (v % GV) * 16;
+      a_in[v] = *reinterpret_cast<const half8_t*>(abase + (size_t)(v / GV) * lda_b + po);
+      const half8_t q = *reinterpret_cast<const half8_t*>(gbase + (size_t)(v / GV) * ldg_b + po);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g_in[e * n + v] = (unsigned long long)y5_fix24((float)q[e]);  // direct gradient of that slice (from cv2's data-gradient)
+    }
+    __syncthreads();
+    for (int v = threadIdx.x; v < n; v += blockDim.x) {
+      const int i = v / GV, gl = v % GV;
+      const int y = i / W, x = i - y * W;
+      const int y0 = y - r < 0 ? 0 : y - r, y1 = y + r >= H ? H - 1 : y + r;
+      const int x0 = x - r < 0 ? 0 : x - r, x1 = x + r >= W ? W - 1 : x + r;
+      // one LDS read per window position, eight running (maximum, position) pairs; strict > keeps the FIRST maximum in scan order
+      float best[8];
+      int bi[8];
+      {
+        const half8_t q = a_in[(y0 * W + x0) * GV + gl];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { best[e] = (float)q[e]; bi[e] = y0 * W + x0; }
+      }
+      for (int yy = y0; yy <= y1; ++yy)
+        for (int xx = x0; xx <= x1; ++xx) {
+          const int pos = yy * W + xx;
+          const half8_t q = a_in[pos * GV + gl];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float t = (float)q[e];
+            if (t > best[e]) { best[e] = t; bi[e] = pos; }
+          }
+        }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) atomicAdd(&g_in[e * n + bi[e] * GV + gl], (unsigned long long)y5_fix24(g_out[e * n + v]));   // integer: any order, same sum
+    }
+    __syncthreads();
+    // the accumulated input gradient is the next pass's output gradient
+    for (int q = threadIdx.x; q < n * 8; q += blockDim.x) g_out[q] = y5_unfix24((long long)g_in[q]);
+    __syncthreads();
+  }
+  for (int v = threadIdx.x; v < n; v += blockDim.x) {
+    half8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)g_out[e * n + v];
+    *reinterpret_cast<half8_t*>(gbase + (size_t)(v / GV) * ldg_b + (v % GV) * 16) = o;
+  }
+}
+
+template <int GV>
+__global__ __launch_bounds__(256)
+void y5_sppf_pool_bwd_gather_kernel(const char* __restrict__ act, char* __restrict__ grad, int H, int W, int C_bytes, int lda_b, int ldg_b, int k) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int HW = H * W;
   const int n = HW * GV;                                               // vector index v = pixel * GV + group-in-workgroup
@@ -334,29 +408,43 @@ extern "C" int y5_add_slice(const void* src, void* dst, long long npix, int C, i
 }
 extern "C" int y5_sppf_pool_bwd(const void* act, void* grad, int B, int H, int W, int C, int ld_act, int ld_grad, int k, void* stream_) {
   if (!act || !grad || C % 8 || ld_act % 8 || ld_grad % 8 || ld_act < 4 * C || ld_grad < 4 * C || !(k & 1)) return y5_fail(Y5_ERR_BAD_ARG, "sppf_pool_bwd: bad args");
-  // 16-byte channel groups per workgroup: 2 = whole 32-byte sectors per pixel access AND two or more workgroups per CU (the kernel is a chain of
-  // load -> barrier -> scatter-add -> barrier phases: with four groups one 128 KB workgroup per CU sat through every memory latency alone)
+  // 16-byte channel groups per workgroup: 2 = whole 32-byte sectors per pixel access, but only while two workgroups still fit a CU (the kernel is a chain
+  // of load -> barrier -> scatter -> barrier phases: one big workgroup per CU sat through every memory latency alone); Y5_SPPF_BWD_GV forces 1 / 2 / 4
   static const int force_gv = getenv("Y5_SPPF_BWD_GV") ? atoi(getenv("Y5_SPPF_BWD_GV")) : 0;
-  int gv = (C % 16 == 0 && (size_t)H * W * 2 * (16 + 32 + 32 + 8) <= 150 * 1024) ? 2 : 1;
-  if (force_gv == 4 && C % 32 == 0 && (size_t)H * W * 4 * (16 + 32 + 32 + 8) <= 150 * 1024) gv = 4;
-  if (force_gv == 1) gv = 1;
-  const size_t lds = (size_t)H * W * gv * (16 + 32 + 32 + 8);   // a_in, g_out, g_in, amax
+  static const int force_gather = getenv("Y5_SPPF_BWD_GATHER") ? atoi(getenv("Y5_SPPF_BWD_GATHER")) : 0;
   if (k > 15) return y5_fail(Y5_ERR_UNSUPPORTED, "sppf_pool_bwd: kernel size above 15");
-  if (lds > 150 * 1024) return y5_fail(Y5_ERR_UNSUPPORTED, "sppf_pool_bwd: H*W plane does not fit in LDS");
+  constexpr size_t kFix = 16 + 32 + 64, kGather = 16 + 32 + 32 + 8, kMax = 150 * 1024;   // LDS bytes per vector: a_in, g_out, g_in (, amax)
+  const size_t hw = (size_t)H * W;
+  const bool gather = force_gather || hw * kFix > kMax;
+  const size_t per = gather ? kGather : kFix;
+  if (hw * per > kMax) return y5_fail(Y5_ERR_UNSUPPORTED, "sppf_pool_bwd: H*W plane does not fit in LDS");
+  int gv = (C % 16 == 0 && hw * 2 * per <= 75 * 1024) ? 2 : 1;
+  if ((force_gv == 2 || force_gv == 4) && C % (8 * force_gv) == 0 && hw * force_gv * per <= kMax) gv = force_gv;
+  if (force_gv == 1) gv = 1;
+  const size_t lds = hw * gv * per;
   static bool a = false;
   if (!a) {
     hipFuncSetAttribute((const void*)y5_sppf_pool_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     hipFuncSetAttribute((const void*)y5_sppf_pool_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     hipFuncSetAttribute((const void*)y5_sppf_pool_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute((const void*)y5_sppf_pool_bwd_gather_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute((const void*)y5_sppf_pool_bwd_gather_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute((const void*)y5_sppf_pool_bwd_gather_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     a = true;
   }
   const dim3 g((unsigned)(B * (C / (8 * gv))));
-  if (gv == 2) hipLaunchKernelGGL(y5_sppf_pool_bwd_kernel<2>, g, dim3(256), lds, static_cast<hipStream_t>(stream_), (const char*)act, (char*)grad, H, W,
-                                  C * 2, ld_act * 2, ld_grad * 2, k);
-  else if (gv == 4) hipLaunchKernelGGL(y5_sppf_pool_bwd_kernel<4>, g, dim3(256), lds, static_cast<hipStream_t>(stream_), (const char*)act, (char*)grad, H, W,
-                                  C * 2, ld_act * 2, ld_grad * 2, k);
-  else hipLaunchKernelGGL(y5_sppf_pool_bwd_kernel<1>, g, dim3(256), lds, static_cast<hipStream_t>(stream_), (const char*)act, (char*)grad, H, W, C * 2,
-                          ld_act * 2, ld_grad * 2, k);
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+#define Y5_PB_LAUNCH(KERN) hipLaunchKernelGGL(KERN, g, dim3(256), lds, st, (const char*)act, (char*)grad, H, W, C * 2, ld_act * 2, ld_grad * 2, k)
+  if (gather) {
+    if (gv == 2) Y5_PB_LAUNCH(y5_sppf_pool_bwd_gather_kernel<2>);
+    else if (gv == 4) Y5_PB_LAUNCH(y5_sppf_pool_bwd_gather_kernel<4>);
+    else Y5_PB_LAUNCH(y5_sppf_pool_bwd_gather_kernel<1>);
+  } else {
+    if (gv == 2) Y5_PB_LAUNCH(y5_sppf_pool_bwd_kernel<2>);
+    else if (gv == 4) Y5_PB_LAUNCH(y5_sppf_pool_bwd_kernel<4>);
+    else Y5_PB_LAUNCH(y5_sppf_pool_bwd_kernel<1>);
+  }
+#undef Y5_PB_LAUNCH
   return y5_check_launch("y5_sppf_pool_bwd");
 }
 
