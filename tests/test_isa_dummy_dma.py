@@ -26,17 +26,17 @@ def test_every_dummy_goes_through_the_helper():
     assert not bad, bad
 
 
-def test_headk_ring_keeps_its_dummy_loads(tmp_path):
+def _lds_dma_counts(tmp_path, src, pattern):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
-    out = tmp_path / "head.s"
+    out = tmp_path / (src + ".s")
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only", "-I" + os.path.join(ROOT, "include"),
-                        "-o", str(out), os.path.join(CSRC, "head.hip")], capture_output=True, text=True, cwd=CSRC)
+                        "-o", str(out), os.path.join(CSRC, src)], capture_output=True, text=True, cwd=CSRC)
     assert r.returncode == 0, r.stderr[-3000:]
     counts, cur = {}, None
     for line in open(out):
-        m = re.match(r"^(_Z\w*y5_conv_headk_kernel\w*):", line)
+        m = re.match(pattern, line)
         if m:
             cur = m.group(1)
             counts[cur] = 0
@@ -44,4 +44,15 @@ def test_headk_ring_keeps_its_dummy_loads(tmp_path):
             cur = None
         elif cur and re.search(r"buffer_load_dwordx4 .* lds", line):
             counts[cur] += 1
+    return counts
+
+
+def test_sppf_front_ring_keeps_its_dummy_loads(tmp_path):
+    """conv_sppf.h (one instantiation): 33 LDS-DMA instructions with every dummy kept, 17 when the compiler merges them (-DY5_DUMMY_MERGEABLE, the pre-fix build)."""
+    counts = _lds_dma_counts(tmp_path, "sppf.hip", r"^(_Z\w*y5_sppf_cv1_pool_kernel\w*):")
+    assert list(counts.values()) == [33], counts
+
+
+def test_headk_ring_keeps_its_dummy_loads(tmp_path):
+    counts = _lds_dma_counts(tmp_path, "head.hip", r"^(_Z\w*y5_conv_headk_kernel\w*):")
     assert len(counts) == 2 and all(v == 32 for v in counts.values()), counts
