@@ -281,7 +281,8 @@ int y5_bn_silu_bwd_from_sums(const void* dy, int ld_dy, const void* z, int ldz, 
  * y5_upsample2x_bwd  -- backward of nn.Upsample(2,'nearest'): gsrc(b,h,w,:) (+)= sum of the 2x2 block of gup.
  * y5_add_slice       -- dst (+)= src over npix pixels x C channels (Bottleneck shortcut / Concat fan-out gradients).
  * y5_sppf_pool_bwd   -- backward of SPPF's three chained max-pools (common.py:338-340) in the [x|y1|y2|y3] buffers:
- *   on entry grad holds the per-slice gradients left by cv2's data-gradient, on return grad[..., 0:C] = d/dx.
+ *   on entry grad holds the per-slice gradients left by cv2's data-gradient, on return grad[..., 0:C] = d/dx.  Bit-reproducible: the scatter to the
+ *   window maxima accumulates on an exact 2^-24 fixed-point grid (integer LDS atomics), k <= 15, H*W <= ~1700 (LDS).
  * ------------------------------------------------------------------------------------------------------- */
 int y5_nhwc_to_raw(const void* logits, void* raw, int B, int npix, int na, int no, int ld, void* stream);
 int y5_raw_to_nhwc(const void* draw, void* dlogits, int B, int npix, int na, int no, int ld, void* stream);
@@ -451,14 +452,16 @@ int y5_sppf_cv1_pool_fwd(const void* x, int ldx, const void* w_packed, const flo
 /* ---------------------------------------------------------------------------------------------------------
  * y5_bottleneck_fwd -- models/common.py:164-181 `Bottleneck.forward` inside C3 (e = 1.0, :242): y = [x +] cv2(cv1(x)) with cv1 = 1x1
  * C->C and cv2 = 3x3 pad 1 C->C (BN folded, bias + SiLU each), fp16, as ONE pass: the 1x1 output stays in LDS (csrc/conv_bneck.h).
- * x / y: NHWC channel slices with pixel strides ldx / ldy (elements); y must NOT overlap x.  C = 32 or 64, H % 4 == 0, W % 8 == 0.
+ * x / y: NHWC channel slices with pixel strides ldx / ldy (elements); y must NOT overlap x.  C = 32 or 64 (H % 4 == 0, W % 8 == 0), or
+ * C = 128 (csrc/conv_h3b.h: GEMM-1 phase in front of the halo-resident 3x3; any H, W; max_blocks bits 16.. select the ring form, 0 = default).
  * Filters packed like y5_conv2d_fwd's ([32-padded C][Kpad], k = (kh, kw, c)), biases fp32 [C].
  * ------------------------------------------------------------------------------------------------------- */
 int y5_bottleneck_fwd(const void* x, int ldx, const void* w1_packed, const float* bias1, int Kpad1, const void* w2_packed, const float* bias2,
                       int Kpad2, void* y, int ldy, int B, int H, int W, int C, int add, int max_blocks, void* stream);
 /* The last Bottleneck of a C3 + the C3's cv3 (models/common.py:246: cv3(cat(m(cv1(x)), cv2(x)))) as ONE launch: the Bottleneck's result
  * stays in LDS and is the first half of the 1x1's input, y2 (C3's cv2 output: NHWC slice, pixel stride ld2) the second; out (pixel stride
- * ldo, C3 <= 2 C channels) = act3(W3 [y ; y2] + b3) with W3 packed [2 C padded][Kpad3], k = (y's C channels, then y2's).  C = 32. */
+ * ldo, C3 <= 2 C channels) = act3(W3 [y ; y2] + b3) with W3 packed [2 C padded][Kpad3], k = (y's C channels, then y2's).  C = 32 (csrc/conv_bneck.h)
+ * or C = 128 (csrc/conv_h3b.h CV3 form: cv3 as a GEMM-3 phase on the LDS-resident result; measured slower than two launches). */
 int y5_bottleneck_cv3_fwd(const void* x, int ldx, const void* w1_packed, const float* bias1, int Kpad1, const void* w2_packed, const float* bias2,
                           int Kpad2, const void* y2, int ld2, const void* w3_packed, const float* bias3, int Kpad3, int C3, int act3, void* out,
                           int ldo, int B, int H, int W, int C, int add, int max_blocks, void* stream);
