@@ -155,6 +155,39 @@ def test_sppf_pool_emulated(dt, Cc, H, W):
         assert np.array_equal(buf[..., i * Cc:(i + 1) * Cc].astype(np.float32), t.permute(0, 2, 3, 1).numpy())
 
 
+def test_sppf_pool_bwd_exact_and_nonfinite_emulated():
+    """The fixed-point scatter of y5_sppf_pool_bwd is EXACT: gradients spanning fp16's whole range (subnormals 6e-8 ... 6e4, both signs) sum to the correctly
+    rounded value of the float64 sum (one fp32 rounding per pass, one fp16 rounding at the end -- never further than 1.01 fp16 ulp from the float64 result);
+    an Inf or NaN in ANY incoming gradient slice comes out non-finite (the loss scaler has to see the overflow), in the gather fallback as in the scatter form."""
+    lib = emu()
+    B, H, W, Cc = 1, 6, 7, 8
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy((rng.integers(0, 6, (B, Cc, H, W)) / 2.0).astype(np.float32)).double().requires_grad_(True)
+    y1 = torch.nn.functional.max_pool2d(x, 5, 1, 2)
+    y2 = torch.nn.functional.max_pool2d(y1, 5, 1, 2)
+    y3 = torch.nn.functional.max_pool2d(y2, 5, 1, 2)
+    mag = 2.0 ** rng.integers(-24, 14, (4, B, Cc, H, W))
+    gs = [torch.from_numpy((mag[i] * rng.choice([-1.0, 1.0, 1.5], (B, Cc, H, W))).astype(np.float16).astype(np.float64)) for i in range(4)]
+    (x * gs[0] + y1 * gs[1] + y2 * gs[2] + y3 * gs[3]).sum().backward()
+    act = aligned((B, H, W, 4 * Cc), np.float16, 0.0)
+    grad = aligned((B, H, W, 4 * Cc), np.float16, 0.0)
+    for i, t in enumerate((x, y1, y2, y3)):
+        act[..., i * Cc:(i + 1) * Cc] = t.detach().permute(0, 2, 3, 1).numpy()
+        grad[..., i * Cc:(i + 1) * Cc] = gs[i].permute(0, 2, 3, 1).numpy()
+    g0 = grad.copy()
+    assert lib.y5_sppf_pool_bwd(ptr(act), ptr(grad), B, H, W, Cc, 4 * Cc, 4 * Cc, 5, None) == 0, lib.y5_last_error()
+    ref = x.grad.permute(0, 2, 3, 1).numpy()
+    got = grad[..., :Cc].astype(np.float64)
+    fin = np.abs(ref) < 65000
+    ulp = np.maximum(2.0 ** (np.floor(np.log2(np.maximum(np.abs(ref), 2.0 ** -14))) - 10), 2.0 ** -24)
+    assert np.all(np.abs(got - ref)[fin] <= 1.01 * ulp[fin]), float(np.max((np.abs(got - ref) / ulp)[fin]))
+    for bad in (np.inf, np.nan):
+        grad[...] = g0
+        grad[0, 2, 3, 2 * Cc + 1] = bad        # one element of the d/dy2 slice
+        assert lib.y5_sppf_pool_bwd(ptr(act), ptr(grad), B, H, W, Cc, 4 * Cc, 4 * Cc, 5, None) == 0
+        assert not np.isfinite(grad[..., :Cc].astype(np.float32)).all()   # (NaN from the scatter form, Inf / NaN from the gather form)
+
+
 def test_sppf_pool_bwd_gather_form_emulated():
     """The gather fallback of y5_sppf_pool_bwd (planes too large for the fixed-point scatter; forced here with Y5_SPPF_BWD_GATHER=1, which the library
     latches per process)."""
@@ -162,7 +195,7 @@ def test_sppf_pool_bwd_gather_form_emulated():
     import subprocess
     import sys
 
-    code = "import tests.test_emu_nms as t; [t.test_sppf_pool_bwd_emulated(c) for c in (8, 32)]"
+    code = "import tests.test_emu_nms as t; [t.test_sppf_pool_bwd_emulated(c) for c in (8, 32)]; t.test_sppf_pool_bwd_exact_and_nonfinite_emulated()"
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, Y5_SPPF_BWD_GATHER="1"), capture_output=True, text=True,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]

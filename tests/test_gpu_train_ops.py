@@ -300,3 +300,10 @@ def test_sppf_pool_bwd_matches_autograd_and_repeats(B, H, W, Cc, dev):
     got = outs[0].float().cpu()
     # sums of up to 1 + 25 + 25^2 ... fp16-rounded terms in fp32, rounded to fp16 once: a few fp16 ulps of the largest sums
     assert float((got - ref).abs().max()) <= 4e-3 * max(1.0, float(ref.abs().max())), float((got - ref).abs().max())
+    # an fp16 overflow in an incoming slice must stay visible to the loss scaler (the integer grid of the scatter form has no Inf: the workgroup's output is poisoned)
+    grad = grad0.clone()
+    grad[0, H // 2, W // 2, 2 * Cc + 1] = float("inf")
+    _lib.check(lib.y5_sppf_pool_bwd(C.c_void_p(act.data_ptr()), C.c_void_p(grad.data_ptr()), B, H, W, Cc, 4 * Cc, 4 * Cc, 5, _lib.stream(dev)), lib)
+    torch.cuda.synchronize()
+    assert not bool(torch.isfinite(grad[0, ..., :Cc].float()).all())
+    assert bool(torch.isfinite(grad[1:, ..., :Cc].float()).all())

@@ -113,6 +113,11 @@ void y5_sppf_pool_bwd_kernel(const char* __restrict__ act, char* __restrict__ gr
   // component-major planes [8][n]: consecutive lanes hit consecutive LDS banks
   float* g_out = reinterpret_cast<float*>(a_in + n);                // [8][n] gradient of the pool output (fp32: a multiple of 2^-24)
   unsigned long long* g_in = reinterpret_cast<unsigned long long*>(g_out + (size_t)n * 8);   // [8][n] gradient of the pool input, 2^-24 fixed point
+  // Inf / NaN cannot live on the integer grid: a non-finite incoming gradient (an fp16 overflow that the loss scaler must SEE in order to skip the step)
+  // poisons the workgroup's whole output with NaN instead of turning into a large finite number
+  __shared__ int s_bad;
+  if (threadIdx.x == 0) s_bad = 0;
+  int bad = 0;
   const int groups = C_bytes / (16 * GV);
   const int b = blockIdx.x / groups, cg = blockIdx.x - b * groups;
   const char* abase = act + (size_t)b * HW * lda_b + (size_t)cg * 16 * GV;
@@ -122,7 +127,7 @@ void y5_sppf_pool_bwd_kernel(const char* __restrict__ act, char* __restrict__ gr
   for (int v = threadIdx.x; v < n; v += blockDim.x) {
     const half8_t q = *reinterpret_cast<const half8_t*>(gbase + (size_t)(v / GV) * ldg_b + 3 * (size_t)C_bytes + (v % GV) * 16);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) g_out[e * n + v] = (float)q[e];
+    for (int e = 0; e < 8; ++e) { float f = (float)q[e]; if (!(fabsf(f) <= 65504.0f)) { bad = 1; f = 0.f; } g_out[e * n + v] = f; }
   }
   for (int pass = 3; pass >= 1; --pass) {  // pool `pass`: input slice pass-1 -> output slice pass
     for (int v = threadIdx.x; v < n; v += blockDim.x) {
@@ -130,7 +135,11 @@ void y5_sppf_pool_bwd_kernel(const char* __restrict__ act, char* __restrict__ gr
       a_in[v] = *reinterpret_cast<const half8_t*>(abase + (size_t)(v / GV) * lda_b + po);
       const half8_t q = *reinterpret_cast<const half8_t*>(gbase + (size_t)(v / GV) * ldg_b + po);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) g_in[e * n + v] = (unsigned long long)y5_fix24((float)q[e]);  // direct gradient of that slice (from cv2's data-gradient)
+      for (int e = 0; e < 8; ++e) {   // direct gradient of that slice (from cv2's data-gradient)
+        float f = (float)q[e];
+        if (!(fabsf(f) <= 65504.0f)) { bad = 1; f = 0.f; }
+        g_in[e * n + v] = (unsigned long long)y5_fix24(f);
+      }
     }
     __syncthreads();
     for (int v = threadIdx.x; v < n; v += blockDim.x) {
@@ -164,10 +173,13 @@ void y5_sppf_pool_bwd_kernel(const char* __restrict__ act, char* __restrict__ gr
     for (int q = threadIdx.x; q < n * 8; q += blockDim.x) g_out[q] = y5_unfix24((long long)g_in[q]);
     __syncthreads();
   }
+  if (bad) s_bad = 1;   // (benign race: every writer stores the same value)
+  __syncthreads();
+  const bool poison = s_bad != 0;
   for (int v = threadIdx.x; v < n; v += blockDim.x) {
     half8_t o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (half_t)g_out[e * n + v];
+    for (int e = 0; e < 8; ++e) o[e] = poison ? (half_t)__builtin_nanf("") : (half_t)g_out[e * n + v];
     *reinterpret_cast<half8_t*>(gbase + (size_t)(v / GV) * ldg_b + (v % GV) * 16) = o;
   }
 }
