@@ -93,6 +93,14 @@ CASES = [
     (1, 16, 16, 160, 512, 1, 1, 0, 1, False, False, 93, 0, "f16"),
     (2, 13, 10, 256, 128, 1, 1, 0, 1, False, False, 94, 0, "f16"),
     (1, 8, 8, 64, 320, 1, 1, 0, 1, False, False, 94, 0, "f16"),
+    # 256-row / 8-phase implicit GEMM (conv_g8.h, id 95): one K tile, odd / even K-tile counts (the LDS buffer parity flips per output tile), pixel and
+    # channel tails, several N tiles, several output tiles per workgroup (the schedule runs across tile boundaries), residual in place, stride 2, no activation
+    (1, 6, 7, 64, 32, 1, 1, 0, 1, False, False, 95, 0, "f16"),
+    (2, 9, 8, 64, 64, 3, 1, 1, 1, True, False, 95, 0, "f16"),
+    (1, 20, 20, 64, 320, 3, 2, 1, 1, False, False, 95, 0, "f16"),
+    (3, 12, 12, 128, 264, 1, 1, 0, 0, False, False, 95, 2, "f16"),
+    (2, 13, 11, 64, 512, 3, 1, 1, 1, True, False, 95, 1, "f16"),
+    (1, 16, 16, 192, 256, 1, 1, 0, 1, False, False, 95, 0, "f16"),
 ] + [
     # every fp16 tile configuration on one shape with M, N tails and K = 9*64 (uniform) / 9*48 (table for BK64)
     (2, 9, 9, c1, 160, 3, 1, 1, 1, True, False, cfg, 2, "f16") for cfg in list(range(14)) + list(range(22, 30)) + list(range(35, 56)) for c1 in (64, 48)

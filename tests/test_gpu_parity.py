@@ -132,6 +132,16 @@ CONV_CASES = [
     (8, 40, 40, 256, 128, 1, 1, 0, 1, False, False, 94, 0, "f16"),
     (3, 21, 19, 96, 248, 1, 1, 0, 0, False, False, 93, 0, "f16"),
     (2, 20, 20, 512, 320, 1, 1, 0, 1, False, False, 94, 0, "f16"),
+    # 256-row / 8-phase implicit GEMM (conv_g8.h, id 95) at the MFMA-bound shapes of yolov5s (5 / 7 / 21.Conv, SPPF.cv2, Bottleneck.cv2 with residual) at a
+    # smaller batch: long K rings across many tiles per workgroup, one tile per workgroup, odd K-tile counts, tails in M and N, a yolov5x channel count
+    (8, 80, 80, 128, 256, 3, 2, 1, 1, False, False, 95, 0, "f16"),
+    (16, 40, 40, 256, 512, 3, 2, 1, 1, False, False, 95, 0, "f16"),
+    (16, 40, 40, 256, 256, 3, 2, 1, 1, False, False, 95, 16, "f16"),
+    (16, 20, 20, 1024, 512, 1, 1, 0, 1, False, False, 95, 0, "f16"),
+    (16, 20, 20, 256, 256, 3, 1, 1, 1, True, False, 95, 8, "f16"),
+    (3, 41, 37, 192, 328, 3, 1, 1, 0, False, False, 95, 24, "f16"),
+    (2, 40, 40, 320, 320, 3, 1, 1, 1, True, False, 95, 0, "f16"),
+    (4, 40, 40, 64, 256, 1, 1, 0, 1, False, False, 95, 8, "f16"),
 ]
 
 

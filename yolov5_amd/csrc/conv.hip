@@ -208,6 +208,7 @@ constexpr int kPw8_0 = 84;  // ids 84.. = kPwCfgs[9..]: eight waves per workgrou
 // 88 = the producer / consumer 128 x 128 BK32 ring of id 43, 89 = the plain 2-stage 128 x 128 BK64 tile of id 8
 constexpr int kUp0 = 88, kNumUp = 2;
 constexpr int kPwk0 = 93;                  // ids 93, 94 = K-streamed pointwise kernel of conv_pwk.h (256- / 128-channel N tile)
+constexpr int kG8_0 = 95;                  // ids 95.. = 256-row / 8-phase implicit GEMM of conv_g8.h (convg8.hip)
 constexpr int kH3S_0 = 90, kNumH3a = 17;   // ids 90.. = halo-resident 3x3 configurations 17.. of convh3.hip (small tiles for the stride-2 layers)
 constexpr TileCfg kUpCfgs[kNumUp] = {{2, 2, 2, 2, 64}, {2, 2, 2, 2, 128}};
 constexpr int kPw2_0 = 56;  // pointwise configurations added after the id space was laid out: ids 56.. = kPwCfgs[8..]
@@ -355,6 +356,7 @@ int launch_k3_by_cfg(const Y5ConvParams& p, int idx, int mb, hipStream_t s) {
 }  // namespace
 int y5_launch_h3_by_cfg(const Y5ConvParams& p, int idx, int mb, hipStream_t s);
 int y5_launch_pwk_by_cfg(const Y5ConvParams& p, int idx, hipStream_t s);
+int y5_launch_g8_by_cfg(const Y5ConvParams& p, int idx, int mb, hipStream_t s);
 void y5_h3_cfg_info(int idx, int* bm, int* bn);
 namespace {
 constexpr int kH3_0 = 61;
@@ -387,6 +389,12 @@ extern "C" int y5_conv_set_sk_workspace(void* ws, size_t bytes, void* stream_) {
 
 extern "C" int y5_conv_cfg_info(int cfg, int* bm, int* bn, int* bk_bytes) {
   if (cfg < 0 || cfg >= Y5_CONV_NUM_CFGS) return y5_fail(Y5_ERR_BAD_ARG, "conv_cfg_info: bad id");
+  if (cfg >= kG8_0) {
+    if (bm) *bm = 256;
+    if (bn) *bn = 256;
+    if (bk_bytes) *bk_bytes = 128;
+    return Y5_OK;
+  }
   if (cfg >= kPwk0) {
     if (bm) *bm = 256;
     if (bn) *bn = cfg == kPwk0 ? 256 : 128;
@@ -498,9 +506,10 @@ static int conv2d_fwd_impl(const y5_conv_desc* d, const void* x, const void* w_p
   const int epp = 16 / es;
   int cfg = d->cfg < 0 ? (d->up_c > 0 ? kUp0 + 1 : default_cfg(d)) : d->cfg;
   if (cfg >= Y5_CONV_NUM_CFGS) return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown tile config");
-  const bool pwk = cfg >= kPwk0;          // K-streamed pointwise kernel (ids 93, 94)
-  const bool h3s = cfg >= kH3S_0 && !pwk; // halo-resident 3x3 configurations added in round 5 (ids 90..92)
-  const bool up2 = cfg >= kUp0 && !h3s && !pwk;   // virtual upsample + concat loader (ids 88, 89)
+  const bool g8 = cfg >= kG8_0;           // 256-row / 8-phase implicit GEMM (ids 95..)
+  const bool pwk = cfg >= kPwk0 && !g8;   // K-streamed pointwise kernel (ids 93, 94)
+  const bool h3s = cfg >= kH3S_0 && !pwk && !g8; // halo-resident 3x3 configurations added in round 5 (ids 90..92)
+  const bool up2 = cfg >= kUp0 && !h3s && !pwk && !g8;   // virtual upsample + concat loader (ids 88, 89)
   if (up2 != (d->up_c > 0)) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: configurations 88 / 89 serve exactly the layers with up_c > 0 (virtual upsample + concat)");
   if (up2) {
     const int bkb = kUpCfgs[cfg - kUp0].rb / 2;
@@ -509,7 +518,7 @@ static int conv2d_fwd_impl(const y5_conv_desc* d, const void* x, const void* w_p
       return y5_fail(Y5_ERR_UNSUPPORTED, "conv: virtual upsample + concat needs a 1x1 s1 fp16 layer on an even H x W grid, up_c and C1 multiples of the K chunk, "
                                          "the low-resolution tensor in the `residual` argument");
   }
-  const int fam = up2 || pwk ? 2 : h3s ? kH3_0 : cfg;   // (88 / 89 are implicit-GEMM tiles; 90.. belong to the halo family: none of the id-range tests below applies to them)
+  const int fam = up2 || pwk || g8 ? 2 : h3s ? kH3_0 : cfg;   // (88 / 89 are implicit-GEMM tiles; 90.. belong to the halo family: none of the id-range tests below applies to them)
   const bool pw8 = fam >= kPw8_0;         // streaming pointwise with eight waves per workgroup (ids 84..)
   const bool k3w = fam >= kK3W_0 && !pw8;         // streaming 3x3 added after the id space was laid out (ids 78..83)
   const bool h3 = fam >= kH3_0 && !k3w && !pw8;
@@ -571,6 +580,11 @@ static int conv2d_fwd_impl(const y5_conv_desc* d, const void* x, const void* w_p
     p.bn_partial = stats_partial; p.bn_bytes = stats_bytes; p.bn_rows = stats_rows;
   }
 
+  if (g8) {
+    if (d->dtype != Y5_F16 || !y || (y_up2 && !d->split_n) || placed || (d->C1 & 63) || (d->Kpad & 63) || d->KH * d->KW > 32 || d->Npad > 2048)
+      return y5_fail(Y5_ERR_UNSUPPORTED, "conv: the 8-phase configurations need an fp16 layer with C1 % 64 == 0, Kpad % 64 == 0, at most 32 taps, Npad <= 2048, no replica / placement");
+    return y5_launch_g8_by_cfg(p, cfg - kG8_0, d->max_blocks, stream);
+  }
   if (pwk) {
     if (d->dtype != Y5_F16 || d->KH != 1 || d->KW != 1 || d->SH != 1 || d->SW != 1 || d->PH || d->PW || residual || !y || (y_up2 && !d->split_n) || placed ||
         (d->C1 & 31) || d->Kpad < d->C1)

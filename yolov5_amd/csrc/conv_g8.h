@@ -1,0 +1,315 @@
+// NHWC implicit-GEMM convolution for the MFMA-bound layers on the 256-row / 8-phase "ping-pong" structure (round 6; configuration ids 95 ..).
+//
+// Replaces `Conv.forward_fuse` (models/common.py:90-92: act(conv(x)), BN folded by utils/torch_utils.py:224-254) for layers with C1 % 64 == 0 and a long K
+// (3x3 s1 / s2 and deep 1x1: 5 / 7 / 21.Conv, SPPF.cv2, Bottleneck.cv2 of yolov5s; the 3x3 320 -> 320 / 640 -> 640 layers of yolov5x), the residual add of
+// `Bottleneck.forward` (common.py:181) and the concat-free channel-slice / split stores of conv_igemm.h.
+//
+// Every other convolution kernel of this library shares one loop scheme: 128-row tiles, ONE barrier per K chunk, 4-8 MFMAs per wave between barriers, every
+// wave loading and multiplying in lock step.  None of them gets past 0.34 of the MFMA peak.  This kernel is built the other way round:
+//   * workgroup tile 256 pixels x 256 channels, K tile 64 (128-byte LDS rows), eight waves as 2 (pixels) x 4 (channels): a wave owns 128 pixels x 64 channels
+//     = 4 x 2 accumulator blocks of mfma_f32_32x32x16_f16 (128 accumulator registers), 32 MFMAs per K tile;
+//   * a K tile is FOUR half-tiles of 128 rows x 128 B = 16 KiB (two LDS-DMA instructions per wave each): Act-h0 / Act-h1 = pixel rows {0-63, 128-191} /
+//     {64-127, 192-255} (the first / second 64 pixels of BOTH wave rows), Wgt-h0 / Wgt-h1 = the first / second 32 channels of all four wave columns;
+//     two K tiles are resident (2 x 64 KiB);
+//   * a K tile is multiplied in FOUR phases, one 64-pixel x 32-channel quadrant x K = 64 each (8 MFMAs = 256 matrix-pipe cycles):
+//         q1: read Wgt-h0 (4 ds_read_b128) then Act-h0 (8)   stage Act-h1 of K tile t+1      MFMA act0 x wgt0
+//         q2: read Wgt-h1 (4)                                stage Wgt-h0 of K tile t+2      MFMA act0 x wgt1
+//         q3: read Act-h1 (8)                                stage Act-h0 of K tile t+2      MFMA act1 x wgt1
+//         q4: --                                             stage Wgt-h1 of K tile t+2      MFMA act1 x wgt0        + s_waitcnt vmcnt(6)
+//     every phase is  { ds_reads ; 2 LDS-DMA ; s_barrier ; lgkmcnt(0) ; s_setprio 1 ; 8 MFMAs ; s_setprio 0 ; s_barrier };
+//   * the two wave ROWS run staggered by one barrier (wave row 1 takes one extra s_barrier before the loop): on every SIMD one wave multiplies while its
+//     partner reads fragments and issues LDS-DMA -- the matrix pipe sees MFMAs back to back, and s_setprio has something to arbitrate;
+//   * vmcnt is NEVER 0 in the loop: the one counted wait per K tile (q4, vmcnt(6)) leaves the three youngest half-tiles in flight across every barrier.
+//
+// Hazard bookkeeping (cdna_hip_programming.md "The 256^2 8-phase template"; intervals between consecutive s_barriers are numbered I0, I1, ...; wave row 0 reads
+// in I(2p-2) and multiplies in I(2p-1), wave row 1 reads in I(2p-1) and multiplies in I(2p)):
+//   RAW  the q4 wait of K tile t retires everything older than the three half-tiles staged in q2..q4 of t, i.e. ALL of K tile t+1 (staged q2..q4 of t-1 and
+//        q1 of t); both wave rows have executed it before the barrier that opens the first read of t+1 (q1 of t+1): "read one phase after the wait".
+//   WAR  a half-tile is restaged two phases after the phase that read it (q3 restages what q1 read, q4 what q2 read, q1 what q3 read): the reads of the LATER wave
+//        row (issued in I(2p-1), returned by the lgkmcnt(0) inside I(2p)) are complete before the EARLIER row's LDS-DMA of phase p+2 (I(2p+2)).  One exception,
+//        as in the template: Wgt-h0 is read first in q1 (four reads, then a scheduling barrier, then the eight activation reads) and retired by lgkmcnt(8)
+//        BEFORE q1's first barrier, so q2 may restage it one phase later.
+// The schedule runs seamlessly across the output tiles of a persistent workgroup (the K tiles of all its tiles form one sequence; the next tile's first K tiles
+// fly during the epilogue); past the last K tile every lane's offsets are out of range (zero fill, no traffic), so the counted wait means the same thing in every
+// iteration.  Global stores of the epilogue also count in vmcnt: loads retire in order among themselves, so a younger store can only make the counted wait
+// stricter, never too lenient.
+//
+// Epilogue WITHOUT an LDS transpose: the filter rows of a 32-channel fragment are staged in a permuted order (row i = 8q + 4g + e of the MFMA holds channel
+// (q >> 1) * 16 + g * 8 + (q & 1) * 4 + e), so that after the MFMA lane (pixel = lane & 31, g = lane >> 5) owns accumulator register r = channel
+// (r >> 3) * 16 + g * 8 + (r & 7): two runs of eight CONSECUTIVE channels = two 16-byte stores per fragment, bias (fp32, staged once in LDS) read as float4.
+//
+// LDS row swizzle and the im2col loader are conv_igemm.h's: 16-byte slot s of row r is stored at slot s ^ ((r >> 1) & 7), applied on the per-lane GLOBAL
+// source (LDS-DMA destinations are lane-linear); padding taps / pixel tails / channel tails carry bit 31 in their buffer offset = zero fill.
+#pragma once
+#include "conv_igemm.h"
+
+struct Y5G8Geom {
+  static constexpr int NW = 8, BM = 256, BN = 256, BK = 64;
+  static constexpr int HT = 128 * 128;              // one half-tile: 128 LDS rows of 128 B
+  static constexpr int BUF = 4 * HT;                // one K tile: [Act-h0][Act-h1][Wgt-h0][Wgt-h1]
+  static constexpr int MAXN = 2048;                 // bias staged for the whole layer
+  static constexpr int OFF_BIAS = 2 * BUF;
+  static constexpr size_t LDS = OFF_BIAS + MAXN * 4;
+  static constexpr int LPH = 2;                     // LDS-DMA instructions per wave per half-tile
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  // MFMA row i (0..31) of a filter fragment <-> channel inside its 32-channel group
+  __host__ __device__ static constexpr int chan_of_row(int i) { return ((i >> 4) & 1) * 16 + ((i >> 2) & 1) * 8 + ((i >> 3) & 1) * 4 + (i & 3); }
+};
+
+#ifdef Y5_G8_TIMING
+__device__ unsigned long long y5_g8_dbg[64];
+#endif
+
+__global__ __launch_bounds__(512, 2)
+void y5_conv_g8_kernel(const Y5ConvParams p) {
+  typedef half_t T;
+  using Gm = Y5G8Geom;
+  constexpr int HT = Gm::HT, BUF = Gm::BUF;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* const blds = reinterpret_cast<float*>(smem + Gm::OFF_BIAS);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int g = lane >> 5, l31 = lane & 31;
+
+  const int G = gridDim.x, bid = blockIdx.x;
+  const int ntiles = p.tilesM * p.tilesN, nk = p.nk;
+  const int nmine = (ntiles - bid + G - 1) / G;   // host guarantees G <= ntiles
+
+  const y5_rsrc_t xrs = y5_make_rsrc(p.x, p.x_bytes);
+  const y5_rsrc_t wrs = y5_make_rsrc(p.w, p.w_bytes);
+
+  for (int i = tid; i < p.Npad; i += 512) blds[i] = p.bias[i];
+  __syncthreads();   // (before the first LDS-DMA is issued: a fenced barrier with LDS-DMA in flight drains it)
+
+  // ---- loader: the K tile being staged is (output tile s_t of this workgroup, chunk s_kc); per lane TWO rows (one per LDS-DMA instruction) of each half-tile ----
+  const int lrow = lane >> 3, lslot = lane & 7;
+  int a_base[2][2];        // [half][instruction]: byte offset of the pixel's (b, ih0, iw0) + source slot
+  unsigned a_mask[2][2];   // bit (kh * KW + kw) SET <=> that tap of this pixel lies outside the image (or the pixel is past M)
+  unsigned w_off[2][2];    // byte offset of the filter row + source slot; bit 31 for rows past Npad
+  int u_kh = 0, u_kw = 0, u_c0 = 0, s_t = 0, s_kc = 0;
+  int st_tap_off = 0, st_tap_bit = 0;
+  unsigned st_kcb = 0;
+
+  auto tile_coords = [&](int j, int& m0, int& n0) {
+    const int t = y5_xcd_remap(bid + j * G, ntiles);
+    const int tn = t % p.tilesN, tm = t / p.tilesN;
+    m0 = tm * Gm::BM;
+    n0 = tn * Gm::BN;
+  };
+  auto loader_setup = [&](int j) __attribute__((always_inline)) {
+    int m0, n0;
+    tile_coords(j, m0, n0);
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int rr = (wave * 2 + jj) * 8 + lrow;             // LDS row inside the half-tile
+      const int sslot = lslot ^ ((rr >> 1) & 7);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int m = m0 + (rr >> 6) * 128 + s * 64 + (rr & 63);
+        const int mm = m < p.M ? m : 0;
+        const int b = (int)y5_fastdiv((unsigned)mm, p.dv_ohw_m, p.dv_ohw_s);
+        const int r = mm - b * ohw;
+        const int oh = (int)y5_fastdiv((unsigned)r, p.dv_ow_m, p.dv_ow_s), ow = r - oh * p.OW;
+        const int ih0 = oh * p.SH - p.PH, iw0 = ow * p.SW - p.PW;
+        a_base[s][jj] = (((b * p.H + ih0) * p.W + iw0) * p.ldx + sslot * 8) * 2;
+        unsigned mk = 0;
+        if (m < p.M) {
+          auto range_bits = [](int lo, int hi) __attribute__((always_inline)) -> unsigned {   // bits [lo, hi), 0 <= lo, hi <= 32
+            if (hi <= lo) return 0u;
+            const unsigned top = hi >= 32 ? ~0u : (1u << hi) - 1u;
+            return top & ~((1u << lo) - 1u);
+          };
+          const int lo_h = ih0 < 0 ? -ih0 : 0, hi_h = p.H - ih0 < p.KH ? p.H - ih0 : p.KH;
+          const int lo_w = iw0 < 0 ? -iw0 : 0, hi_w = p.W - iw0 < p.KW ? p.W - iw0 : p.KW;
+          const unsigned bh = range_bits(lo_h < 32 ? lo_h : 32, hi_h), bw = range_bits(lo_w < 32 ? lo_w : 32, hi_w);
+          for (int kh = 0; kh < p.KH; ++kh)
+            if ((bh >> kh) & 1u) mk |= bw << (kh * p.KW);
+        }
+        a_mask[s][jj] = ~mk;
+        const int n = n0 + (rr >> 5) * 64 + s * 32 + Gm::chan_of_row(rr & 31);
+        w_off[s][jj] = n < p.Npad ? (unsigned)((n * p.Kpad + sslot * 8) * 2) : 0x80000000u;
+      }
+    }
+  };
+  auto loader_kill = [&]() {   // past the last K tile: every offset out of range (zero fill, no traffic) -- the counted waits keep their meaning
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) { a_mask[s][jj] = ~0u; w_off[s][jj] = 0x80000000u; }
+  };
+  auto tap_update = [&]() {
+    st_tap_off = ((u_kh * p.W + u_kw) * p.ldx + u_c0) * 2;
+    st_tap_bit = u_kh * p.KW + u_kw;
+    st_kcb = (unsigned)(s_kc * 128);
+  };
+  auto advance = [&]() __attribute__((always_inline)) {   // next K tile of this workgroup's sequence
+    u_c0 += 64;
+    if (u_c0 >= p.C1) {
+      u_c0 = 0;
+      if (++u_kw == p.KW) { u_kw = 0; ++u_kh; }
+    }
+    if (++s_kc == nk) {
+      s_kc = 0; u_kh = 0; u_kw = 0; u_c0 = 0;
+      if (++s_t < nmine) loader_setup(s_t);
+      else loader_kill();
+    }
+    tap_update();
+  };
+  auto stage_act = [&](auto sc, char* buf) __attribute__((always_inline)) {
+    constexpr int s = decltype(sc)::value;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const unsigned voff = (unsigned)(a_base[s][jj] + st_tap_off) | ((a_mask[s][jj] >> st_tap_bit) << 31);
+      y5_bglds16(xrs, voff, buf + s * HT + (wave * 2 + jj) * 1024);
+    }
+  };
+  auto stage_wgt = [&](auto sc, char* buf) __attribute__((always_inline)) {
+    constexpr int s = decltype(sc)::value;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) y5_bglds16(wrs, w_off[s][jj] + st_kcb, buf + 2 * HT + s * HT + (wave * 2 + jj) * 1024);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  // ---- fragment reads: lane -> row (lane & 31), 16-byte slot (2 ks + g) ^ swz(row); swz depends on lane & 31 only (fragment bases are multiples of 32) ----
+  const int fsw = (l31 >> 1) & 7;
+  const int a_rd = (wr * 64 + l31) * 128 + ((g ^ fsw) << 4);            // + pf * 4096 + half * HT ; ^ (ks * 32)
+  const int w_rd = 2 * HT + (wc * 32 + l31) * 128 + ((g ^ fsw) << 4);   // + half * HT ; ^ (ks * 32)
+  half8_t af[2][4], wf[2][4];
+  float16_t acc[4][2];   // [half * 2 + pixel fragment][channel half]
+
+  auto rd_act = [&](auto sc, const char* buf) __attribute__((always_inline)) {
+    constexpr int s = decltype(sc)::value;
+#pragma unroll
+    for (int pf = 0; pf < 2; ++pf)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) af[pf][ks] = *reinterpret_cast<const half8_t*>(buf + s * HT + pf * 4096 + (a_rd ^ (ks * 32)));
+  };
+  auto rd_wgt = [&](auto sc, const char* buf) __attribute__((always_inline)) {
+    constexpr int s = decltype(sc)::value;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) wf[s][ks] = *reinterpret_cast<const half8_t*>(buf + s * HT + (w_rd ^ (ks * 32)));
+  };
+  auto mma = [&](auto sc, auto cc) __attribute__((always_inline)) {
+    constexpr int s = decltype(sc)::value, c = decltype(cc)::value;
+#ifndef Y5_EMU
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int pf = 0; pf < 2; ++pf)
+        acc[s * 2 + pf][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[c][ks], af[pf][ks], acc[s * 2 + pf][c], 0, 0, 0);
+#ifndef Y5_EMU
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+  };
+  auto lgkm0 = [&]() __attribute__((always_inline)) { __builtin_amdgcn_s_waitcnt(0xC07F); };   // lgkmcnt(0), vmcnt untouched
+
+  // ---- epilogue of the finished output tile j: bias + act (+ residual) -> two 16-byte stores per accumulator block, no LDS transpose ----
+  T* yg = static_cast<T*>(p.y);   // may alias p.res
+  const T* rg = static_cast<const T*>(p.res);
+  T* y2g = static_cast<T*>(p.y2);
+  auto epilogue = [&](int j) __attribute__((always_inline)) {
+    int m0, n0;
+    tile_coords(j, m0, n0);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int n = n0 + wc * 64 + c * 32 + h * 16 + g * 8;
+        const int nb = n < p.Npad ? n : 0;
+        const float4_t b0 = *reinterpret_cast<const float4_t*>(blds + nb), b1 = *reinterpret_cast<const float4_t*>(blds + nb + 4);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const int m = m0 + wr * 128 + (f >> 1) * 64 + (f & 1) * 32 + l31;
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float t = acc[f][c][h * 8 + e] + (e < 4 ? b0[e] : b1[e - 4]);
+            v[e] = p.act ? y5_silu(t) : t;
+          }
+          uint4_t raw;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) raw[e] = y5_pack_h2(v[2 * e], v[2 * e + 1]);
+          if (m < p.M && n < p.C2) {
+            if (rg) {
+              const uint4_t rr = *reinterpret_cast<const uint4_t*>(rg + (size_t)m * p.ldr + n);
+              half8_t a = __builtin_bit_cast(half8_t, raw), b = __builtin_bit_cast(half8_t, rr), o;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)a[e] + (float)b[e]);
+              raw = __builtin_bit_cast(uint4_t, o);
+            }
+            T* d = (p.split_n && n >= p.split_n) ? y2g + (size_t)m * p.ld2 + (n - p.split_n) : yg + (size_t)m * p.ldy + n;
+            *reinterpret_cast<uint4_t*>(d) = raw;
+          }
+        }
+      }
+    }
+  };
+
+  // ---- prologue: all of K tile 0, three half-tiles of K tile 1 ----
+  loader_setup(0);
+  tap_update();
+  stage_wgt(I0{}, smem); stage_act(I0{}, smem); stage_wgt(I1{}, smem); stage_act(I1{}, smem);
+  advance();
+  stage_wgt(I0{}, smem + BUF); stage_act(I0{}, smem + BUF); stage_wgt(I1{}, smem + BUF);
+  y5_wait_vm<3 * Gm::LPH>();
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();   // the stagger: wave row 1 runs one barrier interval behind wave row 0
+
+  int t = 0;
+  for (int ti = 0; ti < nmine; ++ti) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][c][r] = 0.f;
+    for (int kc = 0; kc < nk; ++kc, ++t) {
+      char* cur = smem + (t & 1) * BUF;
+      char* oth = smem + ((t & 1) ^ 1) * BUF;
+      // q1
+      rd_wgt(I0{}, cur);
+#ifndef Y5_EMU
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      rd_act(I0{}, cur);
+      stage_act(I1{}, oth);          // Act-h1 of K tile t+1
+      advance();                     // the loader moves on to K tile t+2
+      __builtin_amdgcn_s_waitcnt(0xC87F);   // lgkmcnt(8): the four filter reads have returned -- q2 restages Wgt-h0
+      __builtin_amdgcn_s_barrier();
+      lgkm0();
+      mma(I0{}, I0{});
+      __builtin_amdgcn_s_barrier();
+      // q2
+      rd_wgt(I1{}, cur);
+      stage_wgt(I0{}, cur);          // Wgt-h0 of K tile t+2
+      __builtin_amdgcn_s_barrier();
+      lgkm0();
+      mma(I0{}, I1{});
+      __builtin_amdgcn_s_barrier();
+      // q3
+      rd_act(I1{}, cur);
+      stage_act(I0{}, cur);          // Act-h0 of K tile t+2
+      __builtin_amdgcn_s_barrier();
+      lgkm0();
+      mma(I1{}, I1{});
+      __builtin_amdgcn_s_barrier();
+      // q4
+      stage_wgt(I1{}, cur);          // Wgt-h1 of K tile t+2
+      y5_wait_vm<3 * Gm::LPH>();     // everything but the three youngest half-tiles has landed: K tile t+1 is complete
+      __builtin_amdgcn_s_barrier();
+      mma(I1{}, I0{});
+      __builtin_amdgcn_s_barrier();
+    }
+    epilogue(ti);
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
+  Y5_DRAIN_VM();                                // the zero-fill LDS-DMA past the end must not outlive the wave
+}

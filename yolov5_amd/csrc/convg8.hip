@@ -1,0 +1,32 @@
+// Host-side launcher of the 256-row / 8-phase implicit-GEMM family (conv_g8.h); reached through y5_conv2d_fwd (conv.hip), configuration ids 95 ..
+#include <hip/hip_runtime.h>
+
+#include "../../include/yolov5_hip.h"
+#include "conv_g8.h"
+#include "y5_host.h"
+
+// idx 0 (id 95): 256 pixels x 256 channels, K tile 64, mfma_f32_32x32x16_f16
+int y5_launch_g8_by_cfg(const Y5ConvParams& p0, int idx, int max_blocks, hipStream_t stream) {
+  using Gm = Y5G8Geom;
+  if (idx != 0) return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown 8-phase config");
+  Y5ConvParams p = p0;
+  if (p.C1 % Gm::BK || p.KH * p.KW > 32 || p.Kpad % Gm::BK || p.Npad > Gm::MAXN)
+    return y5_fail(Y5_ERR_UNSUPPORTED, "conv: the 8-phase configurations need C1 % 64 == 0, Kpad % 64 == 0, KH * KW <= 32 and Npad <= 2048");
+  p.tilesM = (p.M + Gm::BM - 1) / Gm::BM;
+  p.tilesN = (p.Npad + Gm::BN - 1) / Gm::BN;
+  p.nk = p.K / Gm::BK;
+  y5_conv_set_fastdiv(p);
+  auto kern = y5_conv_g8_kernel;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const long long ntiles = (long long)p.tilesM * p.tilesN;
+  if (ntiles <= 0 || ntiles > 0x7fffffffLL) return y5_fail(Y5_ERR_BAD_ARG, "conv: grid out of range");
+  long long G = max_blocks > 0 ? max_blocks : y5_num_cu();   // 136 KiB of LDS: one workgroup per CU
+  if (G >= ntiles) G = ntiles;        // one tile each: no constraint from the XCD remap
+  else if (G >= 8) G &= ~7LL;         // several tiles per workgroup: bid % 8 must stay the XCD of every virtual id bid + j * G
+  hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(Gm::NW * 64), Gm::LDS, stream, p);
+  return y5_check_launch("y5_conv2d_fwd(g8)");
+}
