@@ -65,7 +65,7 @@ typedef struct {
                  * the `residual` argument (such a layer has no residual); every other configuration rejects up_c > 0. */
 } y5_conv_desc;
 
-#define Y5_CONV_NUM_CFGS 96   /* 0..13 implicit-GEMM tiles (2 LDS stages), 14..21 streaming pointwise (1x1 s1, fp16),
+#define Y5_CONV_NUM_CFGS 97   /* 0..13 implicit-GEMM tiles (2 LDS stages), 14..21 streaming pointwise (1x1 s1, fp16),
                                 22..29 implicit-GEMM tiles with a 3-stage LDS ring (fp16), 30..34 streaming 3x3 (small C, fp16),
                                 35..39 256-row implicit-GEMM tiles with 2-4 stage rings, 4 or 8 waves (fp16, deep layers),
                                 40..45 producer/consumer implicit GEMM: 4 MFMA waves + 4 LDS-DMA waves per workgroup (fp16),
@@ -85,9 +85,10 @@ typedef struct {
                                 9 x 33 input halo),
                                 93..94 pointwise (1x1 s1, fp16, C1 % 32 == 0) with K streamed through an LDS ring and the whole 256- / 128-channel N tile
                                 owned by one workgroup of eight waves (256 pixels): the deep 1x1 layers of P4 / P5,
-                                95 implicit GEMM on the 256-row / 8-phase ping-pong structure (conv_g8.h; fp16, C1 % 64 == 0, <= 32 taps, Npad <= 2048):
+                                95..96 implicit GEMM on the 256-row / 8-phase ping-pong structure (conv_g8.h; fp16, C1 % 64 == 0, <= 32 taps, Npad <= 2048):
                                 256 pixels x 256 channels per workgroup, K tile 64 in four half-tiles, two wave rows staggered by one barrier, counted
-                                vmcnt(6) once per K tile -- the MFMA-bound 3x3 / deep 1x1 layers */
+                                vmcnt(6) once per K tile -- the MFMA-bound 3x3 / deep 1x1 layers; 96: 256 pixels x 128 channels (three half-tiles per K
+                                tile, three K tiles resident) */
 /* Scratch for the stream-K configurations (57..60): `bytes` of device memory (256-byte aligned; bytes >= y5_conv_sk_workspace_bytes())
  * that the CALLER owns and keeps alive; registered per device, used by every later y5_conv2d_fwd with such a configuration on ANY
  * stream -- so launches that may overlap in time must not both use stream-K (the engine keeps it off its side-stream ops).  The

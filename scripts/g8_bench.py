@@ -24,6 +24,9 @@ LAYERS = [
     ("8.b.cv2 3x3 256->256 @20 +res", 64, 20, 256, 256, 3, 1, True),
     ("8.cv3 1x1 512->512 @20", 64, 20, 512, 512, 1, 1, False),
     ("6.cv1+cv2 1x1 256->256 @40", 64, 40, 256, 256, 1, 1, False),
+    ("18.Conv 3x3s2 128->128 @80", 64, 80, 128, 128, 3, 2, False),
+    ("3.Conv 3x3s2 64->128 @160", 64, 160, 64, 128, 3, 2, False),
+    ("6.b.cv2 3x3 128->128 @40 +res", 64, 40, 128, 128, 3, 1, True),
     ("x:3x3 320->320 @80 +res", 16, 80, 320, 320, 3, 1, True),
     ("x:3x3s2 320->640 @80", 16, 80, 320, 640, 3, 2, False),
     ("x:3x3 640->640 @40 +res", 16, 40, 640, 640, 3, 1, True),
@@ -37,7 +40,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--only", default="")
-    ap.add_argument("--cfgs", default="95", help="the new ids to race")
+    ap.add_argument("--cfgs", default="95,96", help="the new ids to race")
     ap.add_argument("--base", default="8,12,37,38,39,40,41,42,43,44,64,69,70,73,76,93,94", help="ids of the round-5 library to race against")
     ap.add_argument("--out", default="")
     a = ap.parse_args()

@@ -101,6 +101,15 @@ CASES = [
     (3, 12, 12, 128, 264, 1, 1, 0, 0, False, False, 95, 2, "f16"),
     (2, 13, 11, 64, 512, 3, 1, 1, 1, True, False, 95, 1, "f16"),
     (1, 16, 16, 192, 256, 1, 1, 0, 1, False, False, 95, 0, "f16"),
+    # ... 256 x 128 tiles (id 96): three resident K tiles, the filter walker one K tile ahead of the activation walker -- K-tile counts 1, 2, 3, 9 (every
+    # residue of the buffer rotation across an output-tile boundary), N tiles with a padded tail, several tiles per workgroup
+    (1, 6, 7, 64, 32, 1, 1, 0, 1, False, False, 96, 0, "f16"),
+    (2, 9, 8, 64, 64, 3, 1, 1, 1, True, False, 96, 0, "f16"),
+    (1, 20, 20, 64, 160, 3, 2, 1, 1, False, False, 96, 0, "f16"),
+    (3, 12, 12, 128, 264, 1, 1, 0, 0, False, False, 96, 2, "f16"),
+    (2, 13, 11, 64, 256, 3, 1, 1, 1, True, False, 96, 1, "f16"),
+    (2, 16, 16, 192, 320, 1, 1, 0, 1, False, False, 96, 3, "f16"),
+    (3, 10, 10, 64, 384, 1, 1, 0, 1, True, False, 96, 1, "f16"),
 ] + [
     # every fp16 tile configuration on one shape with M, N tails and K = 9*64 (uniform) / 9*48 (table for BK64)
     (2, 9, 9, c1, 160, 3, 1, 1, 1, True, False, cfg, 2, "f16") for cfg in list(range(14)) + list(range(22, 30)) + list(range(35, 56)) for c1 in (64, 48)

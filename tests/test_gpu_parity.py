@@ -142,6 +142,16 @@ CONV_CASES = [
     (3, 41, 37, 192, 328, 3, 1, 1, 0, False, False, 95, 24, "f16"),
     (2, 40, 40, 320, 320, 3, 1, 1, 1, True, False, 95, 0, "f16"),
     (4, 40, 40, 64, 256, 1, 1, 0, 1, False, False, 95, 8, "f16"),
+    # ... 256 x 128 tiles (id 96): 18 / 21.Conv, Bottleneck.cv2 at P4 / P5, yolov5x channel counts (320, 640: 2.5 and 5 N tiles), tails, short K
+    (8, 80, 80, 128, 128, 3, 2, 1, 1, False, False, 96, 0, "f16"),
+    (16, 40, 40, 256, 256, 3, 2, 1, 1, False, False, 96, 0, "f16"),
+    (16, 20, 20, 256, 256, 3, 1, 1, 1, True, False, 96, 8, "f16"),
+    (8, 40, 40, 128, 128, 3, 1, 1, 1, True, False, 96, 16, "f16"),
+    (2, 40, 40, 320, 320, 3, 1, 1, 1, True, False, 96, 0, "f16"),
+    (2, 20, 20, 640, 640, 3, 1, 1, 1, False, False, 96, 0, "f16"),
+    (3, 41, 37, 192, 328, 3, 1, 1, 0, False, False, 96, 24, "f16"),
+    (4, 40, 40, 64, 384, 1, 1, 0, 1, False, False, 96, 8, "f16"),
+    (8, 20, 20, 128, 136, 1, 1, 0, 1, False, False, 96, 1, "f16"),
 ]
 
 

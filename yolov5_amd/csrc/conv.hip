@@ -391,7 +391,7 @@ extern "C" int y5_conv_cfg_info(int cfg, int* bm, int* bn, int* bk_bytes) {
   if (cfg < 0 || cfg >= Y5_CONV_NUM_CFGS) return y5_fail(Y5_ERR_BAD_ARG, "conv_cfg_info: bad id");
   if (cfg >= kG8_0) {
     if (bm) *bm = 256;
-    if (bn) *bn = 256;
+    if (bn) *bn = cfg == kG8_0 ? 256 : 128;
     if (bk_bytes) *bk_bytes = 128;
     return Y5_OK;
   }

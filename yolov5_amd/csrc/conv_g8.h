@@ -56,8 +56,40 @@ struct Y5G8Geom {
   __host__ __device__ static constexpr int chan_of_row(int i) { return ((i >> 4) & 1) * 16 + ((i >> 2) & 1) * 8 + ((i >> 3) & 1) * 4 + (i & 3); }
 };
 
+
+// One staged activation row of the im2col loader: output pixel m -> byte offset of its (b, ih0, iw0) origin + the lane's source slot, and the tap mask (bit
+// kh * KW + kw SET <=> that tap lies outside the image, or the pixel is past M): conv_igemm.h's scheme (exact multiply-high division, two bit ranges)
+__device__ __forceinline__ void y5_g8_act_row(const Y5ConvParams& p, int m, int sslot, int& base, unsigned& mask) {
+  const int ohw = p.OH * p.OW;
+  const int mm = m < p.M ? m : 0;
+  const int b = (int)y5_fastdiv((unsigned)mm, p.dv_ohw_m, p.dv_ohw_s);
+  const int r = mm - b * ohw;
+  const int oh = (int)y5_fastdiv((unsigned)r, p.dv_ow_m, p.dv_ow_s), ow = r - oh * p.OW;
+  const int ih0 = oh * p.SH - p.PH, iw0 = ow * p.SW - p.PW;
+  base = (((b * p.H + ih0) * p.W + iw0) * p.ldx + sslot * 8) * 2;
+  unsigned mk = 0;
+  if (m < p.M) {
+    auto range_bits = [](int lo, int hi) __attribute__((always_inline)) -> unsigned {   // bits [lo, hi), 0 <= lo, hi <= 32
+      if (hi <= lo) return 0u;
+      const unsigned top = hi >= 32 ? ~0u : (1u << hi) - 1u;
+      return top & ~((1u << lo) - 1u);
+    };
+    const int lo_h = ih0 < 0 ? -ih0 : 0, hi_h = p.H - ih0 < p.KH ? p.H - ih0 : p.KH;
+    const int lo_w = iw0 < 0 ? -iw0 : 0, hi_w = p.W - iw0 < p.KW ? p.W - iw0 : p.KW;
+    const unsigned bh = range_bits(lo_h < 32 ? lo_h : 32, hi_h), bw = range_bits(lo_w < 32 ? lo_w : 32, hi_w);
+    for (int kh = 0; kh < p.KH; ++kh)
+      if ((bh >> kh) & 1u) mk |= bw << (kh * p.KW);
+  }
+  mask = ~mk;
+}
+
 #ifdef Y5_G8_TIMING
-__device__ unsigned long long y5_g8_dbg[64];
+// kernel-experiment builds only: per workgroup (< 512) and wave row, stamps of the FIRST output tile -- s_memrealtime (100 MHz) at kernel entry / bias staged /
+// K tile 0 landed / K loop done / epilogue done, and the shader-clock length of the K loop (s_memtime)
+__device__ unsigned long long y5_g8_dbg[512 * 2 * 8];
+#define Y5_G8_STAMP(i) do { if (dbg_on) dbg[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define Y5_G8_STAMP(i) ((void)0)
 #endif
 
 __global__ __launch_bounds__(512, 2)
@@ -76,12 +108,20 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
   const int G = gridDim.x, bid = blockIdx.x;
   const int ntiles = p.tilesM * p.tilesN, nk = p.nk;
   const int nmine = (ntiles - bid + G - 1) / G;   // host guarantees G <= ntiles
+#ifdef Y5_G8_TIMING
+  const bool dbg_on = (tid & 255) == 0 && bid < 512;
+  unsigned long long* const dbg = y5_g8_dbg + (bid < 512 ? bid : 0) * 16 + wr * 8;
+  unsigned long long dbg_c0 = 0;
+  Y5_G8_STAMP(0);
+#endif
 
   const y5_rsrc_t xrs = y5_make_rsrc(p.x, p.x_bytes);
   const y5_rsrc_t wrs = y5_make_rsrc(p.w, p.w_bytes);
 
-  for (int i = tid; i < p.Npad; i += 512) blds[i] = p.bias[i];
-  __syncthreads();   // (before the first LDS-DMA is issued: a fenced barrier with LDS-DMA in flight drains it)
+  float bv[Gm::MAXN / 512];   // the bias loads are issued ahead of the prologue's LDS-DMA and written to LDS behind it (older loads retire first)
+#pragma unroll
+  for (int q = 0; q < Gm::MAXN / 512; ++q) bv[q] = tid + q * 512 < p.Npad ? p.bias[tid + q * 512] : 0.f;
+  Y5_G8_STAMP(1);
 
   // ---- loader: the K tile being staged is (output tile s_t of this workgroup, chunk s_kc); per lane TWO rows (one per LDS-DMA instruction) of each half-tile ----
   const int lrow = lane >> 3, lslot = lane & 7;
@@ -91,6 +131,9 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
   int u_kh = 0, u_kw = 0, u_c0 = 0, s_t = 0, s_kc = 0;
   int st_tap_off = 0, st_tap_bit = 0;
   unsigned st_kcb = 0;
+#ifdef Y5_G8_ABL_NODMA
+  bool t_loop = false;   // ablation build: no LDS-DMA inside the K loop (the prologue's tiles are multiplied over and over)
+#endif
 
   auto tile_coords = [&](int j, int& m0, int& n0) {
     const int t = y5_xcd_remap(bid + j * G, ntiles);
@@ -101,34 +144,13 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
   auto loader_setup = [&](int j) __attribute__((always_inline)) {
     int m0, n0;
     tile_coords(j, m0, n0);
-    const int ohw = p.OH * p.OW;
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       const int rr = (wave * 2 + jj) * 8 + lrow;             // LDS row inside the half-tile
       const int sslot = lslot ^ ((rr >> 1) & 7);
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const int m = m0 + (rr >> 6) * 128 + s * 64 + (rr & 63);
-        const int mm = m < p.M ? m : 0;
-        const int b = (int)y5_fastdiv((unsigned)mm, p.dv_ohw_m, p.dv_ohw_s);
-        const int r = mm - b * ohw;
-        const int oh = (int)y5_fastdiv((unsigned)r, p.dv_ow_m, p.dv_ow_s), ow = r - oh * p.OW;
-        const int ih0 = oh * p.SH - p.PH, iw0 = ow * p.SW - p.PW;
-        a_base[s][jj] = (((b * p.H + ih0) * p.W + iw0) * p.ldx + sslot * 8) * 2;
-        unsigned mk = 0;
-        if (m < p.M) {
-          auto range_bits = [](int lo, int hi) __attribute__((always_inline)) -> unsigned {   // bits [lo, hi), 0 <= lo, hi <= 32
-            if (hi <= lo) return 0u;
-            const unsigned top = hi >= 32 ? ~0u : (1u << hi) - 1u;
-            return top & ~((1u << lo) - 1u);
-          };
-          const int lo_h = ih0 < 0 ? -ih0 : 0, hi_h = p.H - ih0 < p.KH ? p.H - ih0 : p.KH;
-          const int lo_w = iw0 < 0 ? -iw0 : 0, hi_w = p.W - iw0 < p.KW ? p.W - iw0 : p.KW;
-          const unsigned bh = range_bits(lo_h < 32 ? lo_h : 32, hi_h), bw = range_bits(lo_w < 32 ? lo_w : 32, hi_w);
-          for (int kh = 0; kh < p.KH; ++kh)
-            if ((bh >> kh) & 1u) mk |= bw << (kh * p.KW);
-        }
-        a_mask[s][jj] = ~mk;
+        y5_g8_act_row(p, m0 + (rr >> 6) * 128 + s * 64 + (rr & 63), sslot, a_base[s][jj], a_mask[s][jj]);
         const int n = n0 + (rr >> 5) * 64 + s * 32 + Gm::chan_of_row(rr & 31);
         w_off[s][jj] = n < p.Npad ? (unsigned)((n * p.Kpad + sslot * 8) * 2) : 0x80000000u;
       }
@@ -160,6 +182,9 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
   };
   auto stage_act = [&](auto sc, char* buf) __attribute__((always_inline)) {
     constexpr int s = decltype(sc)::value;
+#ifdef Y5_G8_ABL_NODMA
+    if (t_loop) return;
+#endif
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       const unsigned voff = (unsigned)(a_base[s][jj] + st_tap_off) | ((a_mask[s][jj] >> st_tap_bit) << 31);
@@ -168,6 +193,9 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
   };
   auto stage_wgt = [&](auto sc, char* buf) __attribute__((always_inline)) {
     constexpr int s = decltype(sc)::value;
+#ifdef Y5_G8_ABL_NODMA
+    if (t_loop) return;
+#endif
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) y5_bglds16(wrs, w_off[s][jj] + st_kcb, buf + 2 * HT + s * HT + (wave * 2 + jj) * 1024);
   };
@@ -180,9 +208,15 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
   const int w_rd = 2 * HT + (wc * 32 + l31) * 128 + ((g ^ fsw) << 4);   // + half * HT ; ^ (ks * 32)
   half8_t af[2][4], wf[2][4];
   float16_t acc[4][2];   // [half * 2 + pixel fragment][channel half]
+#ifdef Y5_G8_ABL_NORD
+  bool t_rd = false;     // ablation build: fragments are read in the first K tile only
+#endif
 
   auto rd_act = [&](auto sc, const char* buf) __attribute__((always_inline)) {
     constexpr int s = decltype(sc)::value;
+#ifdef Y5_G8_ABL_NORD
+    if (t_rd) return;
+#endif
 #pragma unroll
     for (int pf = 0; pf < 2; ++pf)
 #pragma unroll
@@ -190,6 +224,9 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
   };
   auto rd_wgt = [&](auto sc, const char* buf) __attribute__((always_inline)) {
     constexpr int s = decltype(sc)::value;
+#ifdef Y5_G8_ABL_NORD
+    if (t_rd) return;
+#endif
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) wf[s][ks] = *reinterpret_cast<const half8_t*>(buf + s * HT + (w_rd ^ (ks * 32)));
   };
@@ -197,15 +234,28 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
     constexpr int s = decltype(sc)::value, c = decltype(cc)::value;
 #ifndef Y5_EMU
     __builtin_amdgcn_sched_barrier(0);
+#ifndef Y5_G8_NOPRIO
     __builtin_amdgcn_s_setprio(1);
 #endif
+#endif
+#ifdef Y5_G8_ABL_NOMMA
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      asm volatile("" :: "v"(wf[c][ks]));
+#pragma unroll
+      for (int pf = 0; pf < 2; ++pf) asm volatile("" :: "v"(af[pf][ks]));
+    }
+#else
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int pf = 0; pf < 2; ++pf)
         acc[s * 2 + pf][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[c][ks], af[pf][ks], acc[s * 2 + pf][c], 0, 0, 0);
+#endif
 #ifndef Y5_EMU
+#ifndef Y5_G8_NOPRIO
     __builtin_amdgcn_s_setprio(0);
+#endif
     __builtin_amdgcn_sched_barrier(0);
 #endif
   };
@@ -259,10 +309,20 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
   stage_wgt(I0{}, smem); stage_act(I0{}, smem); stage_wgt(I1{}, smem); stage_act(I1{}, smem);
   advance();
   stage_wgt(I0{}, smem + BUF); stage_act(I0{}, smem + BUF); stage_wgt(I1{}, smem + BUF);
+#pragma unroll
+  for (int q = 0; q < Gm::MAXN / 512; ++q) blds[tid + q * 512] = bv[q];
   y5_wait_vm<3 * Gm::LPH>();
+  __builtin_amdgcn_s_waitcnt(0xC07F);          // the bias table is written before the barrier that publishes it
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();   // the stagger: wave row 1 runs one barrier interval behind wave row 0
+  Y5_G8_STAMP(2);
+#ifdef Y5_G8_TIMING
+  dbg_c0 = __builtin_amdgcn_s_memtime();
+#endif
 
+#ifdef Y5_G8_ABL_NODMA
+  t_loop = true;
+#endif
   int t = 0;
   for (int ti = 0; ti < nmine; ++ti) {
 #pragma unroll
@@ -301,6 +361,9 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
       lgkm0();
       mma(I1{}, I1{});
       __builtin_amdgcn_s_barrier();
+#ifdef Y5_G8_ABL_NORD
+      t_rd = true;
+#endif
       // q4
       stage_wgt(I1{}, cur);          // Wgt-h1 of K tile t+2
       y5_wait_vm<3 * Gm::LPH>();     // everything but the three youngest half-tiles has landed: K tile t+1 is complete
@@ -308,8 +371,278 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
       mma(I1{}, I0{});
       __builtin_amdgcn_s_barrier();
     }
+#ifdef Y5_G8_TIMING
+    if (ti == 0) { Y5_G8_STAMP(3); if (dbg_on) dbg[5] = __builtin_amdgcn_s_memtime() - dbg_c0; }
+#endif
+    // Tile boundary: the stagger is taken out for the epilogue and put back behind it.  Left in, wave row 1 sits at the barrier behind its last MFMAs until
+    // wave row 0 has finished its WHOLE epilogue (wave row 0's next barrier is behind it), and wave row 0 then waits through wave row 1's: two epilogues
+    // (3.9 us each at 7.Conv, profiles/r06/r06_g8_timing_v1.log) one after the other with the matrix pipe idle.  Wave row 0 takes its balancing barrier HERE
+    // (it pairs with the barrier behind wave row 1's last MFMAs), both rows run their epilogues at the same time, and wave row 1 takes the extra barrier again
+    // before the next tile's q1 (it pairs with the barrier behind wave row 0's q1 reads).  No LDS hazard moves: the epilogue touches only the bias table.
+#ifndef Y5_G8_SERIAL_EPILOGUE
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+#endif
     epilogue(ti);
+#ifndef Y5_G8_SERIAL_EPILOGUE
+    if (wr == 1 && ti + 1 < nmine) __builtin_amdgcn_s_barrier();
+#endif
+#ifdef Y5_G8_TIMING
+    if (ti == 0) { Y5_G8_STAMP(4); if (dbg_on) { dbg[6] = nk; dbg[7] = nmine; } }
+#endif
   }
+#ifdef Y5_G8_SERIAL_EPILOGUE
   if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger
+#endif
   Y5_DRAIN_VM();                                // the zero-fill LDS-DMA past the end must not outlive the wave
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------------------------
+// 256 pixels x 128 channels (id 96): the same structure for layers whose channel count / tile count does not fit 256-wide tiles (C2 = 128, 320, 640; M x N
+// grids that leave the second round of 256 x 256 tiles half empty).  A wave owns 128 pixels x 32 channels (four accumulator blocks, 16 MFMAs per K tile);
+// a K tile is THREE half-tiles (Act-h0, Act-h1, Wgt: all 128 filter rows = the 32 channels of the four wave columns) = 48 KiB, THREE K tiles are resident:
+//         p1: read Wgt (4) then Act-h0 (8)      stage Act-h0 of K tile t+2                          MFMA act0 x wgt
+//         p2: read Act-h1 (8)                   stage Act-h1 of K tile t+2, Wgt of K tile t+3       MFMA act1 x wgt        + s_waitcnt vmcnt(6)
+// RAW: the p2 wait of K tile t leaves the three half-tiles staged in p1 / p2 of t in flight; K tile t+1 (Act staged in p1 / p2 of t-1, Wgt in p2 of t-2) is older.
+// WAR: Act-h0 / Act-h1 of t+2 replace those of t-1 (buffer (t+2) % 3), read two phases earlier; Wgt of t+3 replaces Wgt of t, read first in p1 of t and retired
+// by lgkmcnt(8) before p1's first barrier.  The filter walker therefore runs one K tile ahead of the activation walker.
+struct Y5G8nGeom {
+  static constexpr int NW = 8, BM = 256, BN = 128, BK = 64;
+  static constexpr int HT = 128 * 128;
+  static constexpr int BUF = 3 * HT;                // [Act-h0][Act-h1][Wgt]
+  static constexpr int NB = 3;
+  static constexpr int MAXN = 2048;
+  static constexpr int OFF_BIAS = NB * BUF;
+  static constexpr size_t LDS = OFF_BIAS + MAXN * 4;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+};
+
+__global__ __launch_bounds__(512, 2)
+void y5_conv_g8n_kernel(const Y5ConvParams p) {
+  typedef half_t T;
+  using Gm = Y5G8nGeom;
+  constexpr int HT = Gm::HT, BUF = Gm::BUF;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* const blds = reinterpret_cast<float*>(smem + Gm::OFF_BIAS);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int g = lane >> 5, l31 = lane & 31;
+
+  const int G = gridDim.x, bid = blockIdx.x;
+  const int ntiles = p.tilesM * p.tilesN, nk = p.nk;
+  const int nmine = (ntiles - bid + G - 1) / G;
+
+  const y5_rsrc_t xrs = y5_make_rsrc(p.x, p.x_bytes);
+  const y5_rsrc_t wrs = y5_make_rsrc(p.w, p.w_bytes);
+
+  float bv[Gm::MAXN / 512];
+#pragma unroll
+  for (int q = 0; q < Gm::MAXN / 512; ++q) bv[q] = tid + q * 512 < p.Npad ? p.bias[tid + q * 512] : 0.f;
+
+  // ---- loaders: the activation walker (output tile a_t, chunk a_kc) and the filter walker (w_t, w_kc), the latter one K tile ahead ----
+  const int lrow = lane >> 3, lslot = lane & 7;
+  int a_base[2][2];
+  unsigned a_mask[2][2];
+  unsigned w_off[2];
+  int u_kh = 0, u_kw = 0, u_c0 = 0, a_t = 0, a_kc = 0, w_t = 0, w_kc = 0;
+  int st_tap_off = 0, st_tap_bit = 0;
+
+  auto tile_coords = [&](int j, int& m0, int& n0) {
+    const int t = y5_xcd_remap(bid + j * G, ntiles);
+    const int tn = t % p.tilesN, tm = t / p.tilesN;
+    m0 = tm * Gm::BM;
+    n0 = tn * Gm::BN;
+  };
+  auto act_setup = [&](int j) __attribute__((always_inline)) {
+    int m0, n0;
+    tile_coords(j, m0, n0);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int rr = (wave * 2 + jj) * 8 + lrow;
+      const int sslot = lslot ^ ((rr >> 1) & 7);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) y5_g8_act_row(p, m0 + (rr >> 6) * 128 + s * 64 + (rr & 63), sslot, a_base[s][jj], a_mask[s][jj]);
+    }
+  };
+  auto wgt_setup = [&](int j) __attribute__((always_inline)) {
+    int m0, n0;
+    tile_coords(j, m0, n0);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int rr = (wave * 2 + jj) * 8 + lrow;
+      const int sslot = lslot ^ ((rr >> 1) & 7);
+      const int n = n0 + (rr >> 5) * 32 + Y5G8Geom::chan_of_row(rr & 31);
+      w_off[jj] = n < p.Npad ? (unsigned)((n * p.Kpad + sslot * 8) * 2) : 0x80000000u;
+    }
+  };
+  auto tap_update = [&]() {
+    st_tap_off = ((u_kh * p.W + u_kw) * p.ldx + u_c0) * 2;
+    st_tap_bit = u_kh * p.KW + u_kw;
+  };
+  auto adv_act = [&]() __attribute__((always_inline)) {
+    u_c0 += 64;
+    if (u_c0 >= p.C1) {
+      u_c0 = 0;
+      if (++u_kw == p.KW) { u_kw = 0; ++u_kh; }
+    }
+    if (++a_kc == nk) {
+      a_kc = 0; u_kh = 0; u_kw = 0; u_c0 = 0;
+      if (++a_t < nmine) act_setup(a_t);
+      else {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) a_mask[s][jj] = ~0u;
+      }
+    }
+    tap_update();
+  };
+  auto adv_wgt = [&]() __attribute__((always_inline)) {
+    if (++w_kc == nk) {
+      w_kc = 0;
+      if (++w_t < nmine) wgt_setup(w_t);
+      else { w_off[0] = 0x80000000u; w_off[1] = 0x80000000u; }
+    }
+  };
+  auto stage_act = [&](auto sc, char* buf) __attribute__((always_inline)) {
+    constexpr int s = decltype(sc)::value;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const unsigned voff = (unsigned)(a_base[s][jj] + st_tap_off) | ((a_mask[s][jj] >> st_tap_bit) << 31);
+      y5_bglds16(xrs, voff, buf + s * HT + (wave * 2 + jj) * 1024);
+    }
+  };
+  auto stage_wgt = [&](char* buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) y5_bglds16(wrs, w_off[jj] + (unsigned)(w_kc * 128), buf + 2 * HT + (wave * 2 + jj) * 1024);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  const int fsw = (l31 >> 1) & 7;
+  const int a_rd = (wr * 64 + l31) * 128 + ((g ^ fsw) << 4);
+  const int w_rd = 2 * HT + (wc * 32 + l31) * 128 + ((g ^ fsw) << 4);
+  half8_t af[2][4], wf[4];
+  float16_t acc[4];
+
+  auto rd_act = [&](auto sc, const char* buf) __attribute__((always_inline)) {
+    constexpr int s = decltype(sc)::value;
+#pragma unroll
+    for (int pf = 0; pf < 2; ++pf)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) af[pf][ks] = *reinterpret_cast<const half8_t*>(buf + s * HT + pf * 4096 + (a_rd ^ (ks * 32)));
+  };
+  auto rd_wgt = [&](const char* buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) wf[ks] = *reinterpret_cast<const half8_t*>(buf + (w_rd ^ (ks * 32)));
+  };
+  auto mma = [&](auto sc) __attribute__((always_inline)) {
+    constexpr int s = decltype(sc)::value;
+#ifndef Y5_EMU
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int pf = 0; pf < 2; ++pf) acc[s * 2 + pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], af[pf][ks], acc[s * 2 + pf], 0, 0, 0);
+#ifndef Y5_EMU
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+  };
+  auto lgkm0 = [&]() __attribute__((always_inline)) { __builtin_amdgcn_s_waitcnt(0xC07F); };
+
+  T* yg = static_cast<T*>(p.y);
+  const T* rg = static_cast<const T*>(p.res);
+  T* y2g = static_cast<T*>(p.y2);
+  auto epilogue = [&](int j) __attribute__((always_inline)) {
+    int m0, n0;
+    tile_coords(j, m0, n0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int n = n0 + wc * 32 + h * 16 + g * 8;
+      const int nb = n < p.Npad ? n : 0;
+      const float4_t b0 = *reinterpret_cast<const float4_t*>(blds + nb), b1 = *reinterpret_cast<const float4_t*>(blds + nb + 4);
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const int m = m0 + wr * 128 + (f >> 1) * 64 + (f & 1) * 32 + l31;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float t = acc[f][h * 8 + e] + (e < 4 ? b0[e] : b1[e - 4]);
+          v[e] = p.act ? y5_silu(t) : t;
+        }
+        uint4_t raw;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) raw[e] = y5_pack_h2(v[2 * e], v[2 * e + 1]);
+        if (m < p.M && n < p.C2) {
+          if (rg) {
+            const uint4_t rr = *reinterpret_cast<const uint4_t*>(rg + (size_t)m * p.ldr + n);
+            half8_t a = __builtin_bit_cast(half8_t, raw), b = __builtin_bit_cast(half8_t, rr), o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)a[e] + (float)b[e]);
+            raw = __builtin_bit_cast(uint4_t, o);
+          }
+          T* d = (p.split_n && n >= p.split_n) ? y2g + (size_t)m * p.ld2 + (n - p.split_n) : yg + (size_t)m * p.ldy + n;
+          *reinterpret_cast<uint4_t*>(d) = raw;
+        }
+      }
+    }
+  };
+
+  // ---- prologue: K tiles 0 and 1 complete, the filter half-tile of K tile 2 ----
+  act_setup(0);
+  wgt_setup(0);
+  tap_update();
+  stage_wgt(smem); adv_wgt(); stage_act(I0{}, smem); stage_act(I1{}, smem); adv_act();
+  stage_wgt(smem + BUF); adv_wgt(); stage_act(I0{}, smem + BUF); stage_act(I1{}, smem + BUF); adv_act();
+  stage_wgt(smem + 2 * BUF); adv_wgt();
+#pragma unroll
+  for (int q = 0; q < Gm::MAXN / 512; ++q) blds[tid + q * 512] = bv[q];
+  y5_wait_vm<8>();   // K tile 0 (the six oldest loads) has landed
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();
+
+  char* b_cur = smem;             // buffer of K tile t
+  char* b_nx1 = smem + BUF;       // t + 1
+  char* b_nx2 = smem + 2 * BUF;   // t + 2
+  for (int ti = 0; ti < nmine; ++ti) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+    for (int kc = 0; kc < nk; ++kc) {
+      // p1
+      rd_wgt(b_cur);
+#ifndef Y5_EMU
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      rd_act(I0{}, b_cur);
+      stage_act(I0{}, b_nx2);        // Act-h0 of K tile t+2
+      __builtin_amdgcn_s_waitcnt(0xC87F);   // lgkmcnt(8): the four filter reads have returned -- p2 restages Wgt
+      __builtin_amdgcn_s_barrier();
+      lgkm0();
+      mma(I0{});
+      __builtin_amdgcn_s_barrier();
+      // p2
+      rd_act(I1{}, b_cur);
+      stage_act(I1{}, b_nx2);        // Act-h1 of K tile t+2
+      adv_act();
+      stage_wgt(b_cur);              // Wgt of K tile t+3 (buffer t % 3)
+      adv_wgt();
+      y5_wait_vm<6>();               // K tile t+1 is complete
+      __builtin_amdgcn_s_barrier();
+      lgkm0();
+      mma(I1{});
+      __builtin_amdgcn_s_barrier();
+      char* const b = b_cur; b_cur = b_nx1; b_nx1 = b_nx2; b_nx2 = b;
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // (tile boundary: see y5_conv_g8_kernel)
+    epilogue(ti);
+    if (wr == 1 && ti + 1 < nmine) __builtin_amdgcn_s_barrier();
+  }
+  Y5_DRAIN_VM();
 }

@@ -5,28 +5,40 @@
 #include "conv_g8.h"
 #include "y5_host.h"
 
-// idx 0 (id 95): 256 pixels x 256 channels, K tile 64, mfma_f32_32x32x16_f16
-int y5_launch_g8_by_cfg(const Y5ConvParams& p0, int idx, int max_blocks, hipStream_t stream) {
-  using Gm = Y5G8Geom;
-  if (idx != 0) return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown 8-phase config");
+// idx 0 (id 95): 256 pixels x 256 channels; idx 1 (id 96): 256 pixels x 128 channels; K tile 64, mfma_f32_32x32x16_f16
+template <typename Gm, typename K>
+static int launch_g8(K kern, const Y5ConvParams& p0, int max_blocks, hipStream_t stream) {
   Y5ConvParams p = p0;
-  if (p.C1 % Gm::BK || p.KH * p.KW > 32 || p.Kpad % Gm::BK || p.Npad > Gm::MAXN)
-    return y5_fail(Y5_ERR_UNSUPPORTED, "conv: the 8-phase configurations need C1 % 64 == 0, Kpad % 64 == 0, KH * KW <= 32 and Npad <= 2048");
   p.tilesM = (p.M + Gm::BM - 1) / Gm::BM;
   p.tilesN = (p.Npad + Gm::BN - 1) / Gm::BN;
   p.nk = p.K / Gm::BK;
   y5_conv_set_fastdiv(p);
-  auto kern = y5_conv_g8_kernel;
-  static bool attr_done = false;
+  static bool attr_done = false;   // per instantiation
   if (!attr_done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   const long long ntiles = (long long)p.tilesM * p.tilesN;
   if (ntiles <= 0 || ntiles > 0x7fffffffLL) return y5_fail(Y5_ERR_BAD_ARG, "conv: grid out of range");
-  long long G = max_blocks > 0 ? max_blocks : y5_num_cu();   // 136 KiB of LDS: one workgroup per CU
+  long long G = max_blocks > 0 ? max_blocks : y5_num_cu();   // > 80 KiB of LDS: one workgroup per CU
   if (G >= ntiles) G = ntiles;        // one tile each: no constraint from the XCD remap
   else if (G >= 8) G &= ~7LL;         // several tiles per workgroup: bid % 8 must stay the XCD of every virtual id bid + j * G
   hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(Gm::NW * 64), Gm::LDS, stream, p);
   return y5_check_launch("y5_conv2d_fwd(g8)");
 }
+
+int y5_launch_g8_by_cfg(const Y5ConvParams& p, int idx, int max_blocks, hipStream_t stream) {
+  if (p.C1 % 64 || p.KH * p.KW > 32 || p.Kpad % 64 || p.Npad > Y5G8Geom::MAXN)
+    return y5_fail(Y5_ERR_UNSUPPORTED, "conv: the 8-phase configurations need C1 % 64 == 0, Kpad % 64 == 0, KH * KW <= 32 and Npad <= 2048");
+  switch (idx) {
+    case 0: return launch_g8<Y5G8Geom>(y5_conv_g8_kernel, p, max_blocks, stream);
+    case 1: return launch_g8<Y5G8nGeom>(y5_conv_g8n_kernel, p, max_blocks, stream);
+  }
+  return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown 8-phase config");
+}
+
+#ifdef Y5_G8_TIMING
+extern "C" int y5_g8_dbg_read(unsigned long long* out) {  // kernel-experiment builds only (not part of the ABI)
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(y5_g8_dbg), sizeof(unsigned long long) * 512 * 2 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
