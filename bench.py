@@ -135,7 +135,18 @@ def kernel_src_hash():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(a, conv_by):
+def _pmc_plan_mismatch(d, timed_families):
+    """None when the counter file was measured on a plan with the kernel families x launches of the timed plan; else what differs."""
+    have = d.get("plan_families")
+    if have is None:
+        return {"reason": "the counter file carries no plan (measured before round 6)"}
+    if timed_families is None or have == timed_families:
+        return None
+    keys = sorted(set(have) | set(timed_families))
+    return {"reason": "the counters were collected on another plan", "family: [profiled, timed] launches": {k: [have.get(k, 0), timed_families.get(k, 0)] for k in keys if have.get(k, 0) != timed_families.get(k, 0)}}
+
+
+def pmc_traffic(a, conv_by, timed_families=None):
     """HBM bytes of the conv launches of one forward from the memory-side L2 counters.  They cannot be collected from inside this
     process: scripts/pmc_forward.sh runs the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same forward and the
     result is committed under profiles/pmc/ (FETCH_SIZE doubled: gfx950 correction of MI355X_MICROARCH.md "HBM").  Only
@@ -158,10 +169,14 @@ def pmc_traffic(a, conv_by):
     if have != want:
         return {"gbytes_per_step": None, "vs_algorithmic": None, "stale": True, "measured_with_kernel_src_sha16": have, "current_kernel_src_sha16": want,
                 "stale_gbytes_per_step": round(gb, 3), "source": src}
-    return {"gbytes_per_step": round(gb, 3), "vs_algorithmic": round(gb * 1e9 / conv_by, 3) if conv_by else None, "kernel_src_sha16": have, "source": src}
+    mis = _pmc_plan_mismatch(d, timed_families)
+    if mis is not None:
+        return {"gbytes_per_step": None, "vs_algorithmic": None, "other_plan": mis, "other_plan_gbytes_per_step": round(gb, 3), "source": src}
+    return {"gbytes_per_step": round(gb, 3), "vs_algorithmic": round(gb * 1e9 / conv_by, 3) if conv_by else None, "kernel_src_sha16": have,
+            "plan_families": d.get("plan_families"), "source": src}
 
 
-def pmc_mfma_busy(a):
+def pmc_mfma_busy(a, timed_families=None):
     """Counter-based matrix-core utilisation of the conv launches of one forward: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles),
     collected by scripts/pmc_issue_mix.sh (rocprofv3 --kernel-trace --pmc, two SQ passes) and committed under profiles/pmc/ -- the figure
     north_star asks for beside the FLOP-derived fraction.  Same validity rule as `traffic`: only for the configuration and the kernel sources
@@ -183,7 +198,10 @@ def pmc_mfma_busy(a):
     per_kernel = {r["kernel"]: (r.get("mfma_busy_frac"), r.get("launches_per_forward")) for r in d.get("kernels", []) if r.get("conv")}
     if have != want:
         return {"value": None, "stale": True, "stale_value": round(frac, 4), "measured_with_kernel_src_sha16": have, "current_kernel_src_sha16": want, "source": src}, {}
-    return {"value": round(frac, 4), "kernel_src_sha16": have, "source": src,
+    mis = _pmc_plan_mismatch(d, timed_families)
+    if mis is not None:
+        return {"value": None, "other_plan": mis, "other_plan_value": round(frac, 4), "source": src}, {}
+    return {"value": round(frac, 4), "kernel_src_sha16": have, "plan_families": d.get("plan_families"), "source": src,
             "definition": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles) over the conv launches of one forward (inside the kernels: no launch gaps)"}, per_kernel
 
 
@@ -201,7 +219,34 @@ def conv_family(cfg):
         return "y5_conv_h3_kernel"
     if 93 <= cfg < 95:
         return "y5_conv_pwk_kernel"
+    if cfg == 95:
+        return "y5_conv_g8_kernel"
+    if cfg == 96:
+        return "y5_conv_g8n_kernel"
     return "y5_conv_igemm_kernel"
+
+
+def plan_hash(plan):
+    import hashlib
+
+    return hashlib.sha256(json.dumps([[n, c] for n, c in plan]).encode()).hexdigest()[:16]
+
+
+def plan_families(plan):
+    """{kernel family: launches per forward} of a plan table ([op name, configuration] in launch order): the kernel SET a counter measurement belongs to.
+    Conv-class ops by their configuration's family (conv_family); fused heads by the kernel that carries them; everything else by its op kind."""
+    fam = {}
+    for n, c in plan:
+        if n.startswith("conv+decode:"):
+            k = "y5_conv_pw_head_kernel" if conv_family(c) == "y5_conv_pw_kernel" else "y5_conv_headk_kernel"
+        elif "(fused)" in n:
+            continue   # carried by another launch
+        elif c is not None and not (isinstance(c, int) and c < 0):
+            k = conv_family(c)
+        else:
+            k = n.split(":")[0].split("(")[0]
+        fam[k] = fam.get(k, 0) + 1
+    return dict(sorted(fam.items()))
 
 
 def usable_cores():
@@ -379,6 +424,7 @@ def gpu_state_probe(fn, dev, seconds=1.6):
             "hbm_gb": round(props.total_memory / 2 ** 30, 1)}
 
 
+REF_SUSTAINED_TFLOPS = 1950.0   # the reference box of `value_at_ref_clock` (the middle of what the pool's boxes sustain: 1900 .. 2001 measured in rounds 4 / 5)
 TRAIN_GFLOP_PER_IMG = {"yolov5s": 49.3}  # forward + data gradient + weight gradient = 3 x 16.43 GFLOP at 640^2
 
 
@@ -980,7 +1026,11 @@ def main():
             if world > 1:
                 raise  # (a rank that fails alone would leave the others in a collective)
             train = {"error": f"{type(e).__name__}: {e}"}
-    mfma_busy = pmc_mfma_busy(a) if rank == 0 else (None, {})
+    try:
+        timed_families = plan_families(eng.plan_table())
+    except Exception:
+        timed_families = None
+    mfma_busy = pmc_mfma_busy(a, timed_families) if rank == 0 else (None, {})
     dom_busy = None
     if rank == 0 and dominant and mfma_busy[1]:
         # the PMC file names kernels by their (mangled or demangled) symbol: match family + the instantiation's share of launches
@@ -1027,7 +1077,7 @@ def main():
                          "stack_kernels": "y5_conv_{front,igemm,h3,h3b,pw,k3,stem,bneck}_kernel (all conv launches of one forward)",
                          "stack_achieved": round(achieved, 2), "stack_frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                          "mfma_busy_frac": mfma_busy[0], "mfma_busy_frac_dominant_kernel": dom_busy,
-                         "traffic": pmc_traffic(a, conv_by * parts),
+                         "traffic": pmc_traffic(a, conv_by * parts, timed_families),
                          "whole_step_frac": round(a.batch * world * a.steps / dt / world * conv_fl * parts / a.batch / 1e12 / MFMA_PEAK_TFLOPS, 4),
                          "backbone_l0_9": backbone,
                          "hbm_achieved_gbytes_per_s": round(achieved_bw, 1), "hbm_peak_gbytes_per_s": HBM_PEAK_GBS, "hbm_frac": round(achieved_bw / HBM_PEAK_GBS, 4),
@@ -1055,6 +1105,19 @@ def main():
             res["configs"] = configs
         if gpu_state is not None:
             res["gpu_state"] = gpu_state
+        # Box normalisation: boxes of the pool sustain 1.90 .. 2.00 PFLOP/s of back-to-back MFMAs (a clock / power-cap property, measured
+        # by this run's own probe); `value` stays the raw throughput, `value_at_ref_clock` = value x (1950 / mfma_sustained_tflops), the factor clamped to +-10 %.
+        # Round-over-round claims quote the normalised figure; the contract's `value` is the raw one.
+        try:
+            sus = float(ceil["mfma_sustained_tflops"])
+            fac = min(1.10, max(0.90, REF_SUSTAINED_TFLOPS / sus))
+            res["value_at_ref_clock"] = round(res["value"] * fac, 1)
+            res["ref_clock"] = {"ref_mfma_sustained_tflops": REF_SUSTAINED_TFLOPS, "this_box_mfma_sustained_tflops": sus, "factor": round(fac, 4),
+                                "shader_clock_ghz_under_mfma": ceil.get("shader_clock_ghz_under_mfma")}
+            sm = [q.get("sclk_mhz") for q in (gpu_state or {}).get("samples", []) if isinstance(q, dict) and q.get("sclk_mhz")]
+            res["config"]["gpu_state"] = {"sclk_mhz": max(sm) if sm else None, "mfma_sustained_tflops": sus}
+        except Exception:
+            res["value_at_ref_clock"] = None
         if pipeline is not None:
             res["pipeline"] = pipeline
         if train is not None:

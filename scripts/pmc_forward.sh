@@ -23,7 +23,7 @@ for f in glob.glob('gpurun_out/pmcf_*/**/*counter_collection.csv', recursive=Tru
         if 'y5_' not in k: continue
         tot[k][r['Counter_Name']] += float(r['Counter_Value'])
         if r['Counter_Name'] == 'FETCH_SIZE': cnt[k] += 1
-conv = lambda k: any(s in k for s in ('conv_igemm', 'conv_h3', 'conv_pw', 'conv_k3', 'conv_stem', 'conv_bneck', 'conv_front', 'sppf_cv1_pool', 'conv_headk'))
+conv = lambda k: any(s in k for s in ('conv_igemm', 'conv_h3', 'conv_pw', 'conv_k3', 'conv_stem', 'conv_bneck', 'conv_front', 'sppf_cv1_pool', 'conv_headk', 'conv_g8'))
 def gb(keys, name, mult): return sum(tot[k][name] for k in keys) * 1024 * mult / N / 1e9   # counters are in KiB
 ck = [k for k in tot if conv(k)]; ok = [k for k in tot if not conv(k)]
 out = {"forwards": N, "conv_launches_per_forward": sum(cnt[k] for k in ck) / N,
@@ -33,6 +33,7 @@ out["conv_traffic_gb_per_forward"] = out["conv_fetch_gb_per_forward_x2_corrected
 import sys; sys.path.insert(0, '.')
 import bench
 out["kernel_src_sha16"] = bench.kernel_src_hash()   # bench.py reports this traffic only while csrc/ + engine.py still hash to it
+out.update(json.load(open('gpurun_out/forward_only_plan.json')))   # ... and only for a timed plan of the same kernel families x launches
 json.dump(out, open('gpurun_out/pmc_forward.json', 'w'), indent=1)
 print(json.dumps(out, indent=1))
 PY

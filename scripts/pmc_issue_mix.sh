@@ -35,7 +35,7 @@ for f in glob.glob('gpurun_out/pmcm_*/**/*counter_collection.csv', recursive=Tru
         if first and r['Dispatch_Id'] not in seen:
             seen.add(r['Dispatch_Id']); cnt[k] += 1
             dur[k] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-3   # us, pass 1 (the pass the busy counters come from)
-conv = lambda k: any(s in k for s in ('conv_igemm', 'conv_h3', 'conv_pw', 'conv_k3', 'conv_stem', 'conv_bneck', 'conv_front', 'conv_c3', 'sppf_cv1_pool', 'conv_headk'))
+conv = lambda k: any(s in k for s in ('conv_igemm', 'conv_h3', 'conv_pw', 'conv_k3', 'conv_stem', 'conv_bneck', 'conv_front', 'conv_c3', 'sppf_cv1_pool', 'conv_headk', 'conv_g8'))
 NSIMD = 1024.0
 MAX_GHZ = 2.4   # data-sheet shader clock of the part: no kernel can have had more cycles than duration x this
 def util(d):
@@ -87,6 +87,7 @@ res = {"forwards": N, "kernel_src_sha16": bench.kernel_src_hash(),
                  "definition": "sum over the conv launches of one forward of SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x sum of their kernel cycles); profiled passes "
                                "serialise the launches, so this is the utilisation INSIDE the kernels (no launch gaps)"},
        "kernels": out}
+res.update(json.load(open('gpurun_out/forward_only_plan.json')))   # the plan the counters belong to (bench.py compares its kernel families x launches)
 json.dump(res, open('gpurun_out/pmc_issue_mix.json', 'w'), indent=1)
 print(json.dumps(res["stack"]))
 assert all(r["effective_clock_ghz"] is None or r["effective_clock_ghz"] <= 2.45 or not r["cycle_counter_plausible"] for r in out)
