@@ -613,10 +613,10 @@ def config_probe(name, batch, imgsz, dev, steps=20):
     calibrate_head(model, x)
     masks = None
     if nm:
-        from yolov5_amd.segment import process_mask
+        from yolov5_amd.segment import process_mask_batch
 
-        def masks(protos, dets):  # segment/predict.py:161-166: per image, upsampled masks of its detections
-            return [process_mask(protos[i], d[:, 6:], d[:, :4], (imgsz, imgsz), upsample=True) for i, d in enumerate(dets) if len(d)]
+        def masks(protos, dets):  # segment/predict.py:161-172: per image, upsampled masks of its detections (float32 0/1 as the reference) -- one launch per batch
+            return process_mask_batch(protos, dets, (imgsz, imgsz), upsample=True)
 
     pipe = DetectPipeline(model, 0.25, 0.45, max_det=300 if nm else 1000, nm=nm)
     for _ in range(6):
@@ -640,7 +640,7 @@ def config_probe(name, batch, imgsz, dev, steps=20):
     eng = next(iter(model._engines.values()))
     fl = sum(f for _, f in conv_flops(eng))
     fwd_ms = _pct(fwd, 0.5)
-    out = {"workload": f"{name} inference bs={batch} 3x{imgsz}x{imgsz} fp16: forward + NMS" + (" + process_mask(upsample) per image" if nm else "") + ", DetectPipeline",
+    out = {"workload": f"{name} inference bs={batch} 3x{imgsz}x{imgsz} fp16: forward + NMS" + (" + process_mask(upsample, float32 masks as the reference) of every image, one launch" if nm else "") + ", DetectPipeline",
            "images_per_sec": round(batch * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4), "forward_ms": round(fwd_ms, 4),
            "nms_us_per_img": round(_pct(nms, 0.5) * 1e3 / batch, 2), "detections_per_img": round(ndet, 1),
            "algorithmic_gflop_per_step": round(fl / 1e9, 1), "forward_mfma_tflops": round(fl / (fwd_ms * 1e-3) / 1e12, 1),

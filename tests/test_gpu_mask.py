@@ -63,3 +63,52 @@ def test_process_mask_predict_size_on_nms_rows(dev):
     torch.cuda.synchronize()
     gpu_ms = (time.time() - t0) / 20 * 1e3
     print(f"\n[process_mask] 100 instances 160^2 -> 640^2: {gpu_ms:.3f} ms on MI355X (uint8 out, {n * 640 * 640 / gpu_ms / 1e6:.1f} GB/s written); CPU oracle {cpu_s * 1e3:.0f} ms")
+
+
+def test_process_mask_batch_equals_per_image_and_reports_write_rate(dev):
+    """BASELINE config C5 shape (yolov5s-seg bs = 32: prototypes (32, 32, 160, 160) fp16, up to 300 detections per image taken in place from the padded NMS rows,
+    640 x 640 masks): y5_process_mask_batch (ONE launch) == the per-image kernel pixel for pixel, in the reference's float32 and in uint8; image 3 has no
+    detection.  Prints the write rate."""
+    from yolov5_amd.segment import process_mask, process_mask_batch
+
+    B, c, nmax = 32, 32, 300
+    g = torch.Generator().manual_seed(3)
+    P = (torch.randn((B, c, 160, 160), generator=g) * 0.8).half().to(dev)
+    out = torch.zeros((B, nmax, 6 + c), dtype=torch.float32)
+    cxy = torch.rand((B, nmax, 2), generator=g) * 640
+    wh = torch.rand((B, nmax, 2), generator=g) ** 2 * 400 + 4
+    out[..., :2] = (cxy - wh / 2).clamp(0, 640)
+    out[..., 2:4] = (cxy + wh / 2).clamp(0, 640)
+    out[..., 6:] = torch.randn((B, nmax, c), generator=g) * 0.5
+    out = out.to(dev)
+    counts = [nmax] * B
+    counts[3], counts[7], counts[20] = 0, 1, 37
+    dets = [out[i, :n] for i, n in enumerate(counts)]
+    for dt in (torch.float32, torch.uint8):
+        got = process_mask_batch(P, dets, (640, 640), upsample=True, out_dtype=dt)
+        assert [tuple(m.shape) for m in got] == [(n, 640, 640) for n in counts]
+        for i in (0, 3, 7, 20, 31):
+            exp = process_mask(P[i], dets[i][:, 6:], dets[i][:, :4], (640, 640), upsample=True, out_dtype=dt)
+            assert torch.equal(got[i], exp), i
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            process_mask_batch(P, dets, (640, 640), upsample=True, out_dtype=dt)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        e0.record()
+        for _ in range(2):
+            [process_mask(P[i], d[:, 6:], d[:, :4], (640, 640), upsample=True, out_dtype=dt) for i, d in enumerate(dets) if len(d)]
+        e1.record()
+        torch.cuda.synchronize()
+        ms_old = e0.elapsed_time(e1) / 2
+        nbytes = sum(counts) * 640 * 640 * (4 if dt == torch.float32 else 1)
+        print(f"\n[process_mask_batch] {sum(counts)} instances of 32 images, {dt}: one launch {ms:.3f} ms = {nbytes / ms / 1e9:.2f} TB/s written; "
+              f"per-image launches {ms_old:.3f} ms = {nbytes / ms_old / 1e9:.2f} TB/s")
+    # no-upsample form and the fallback for widths the batched kernel does not take
+    got = process_mask_batch(P, dets, (640, 640), upsample=False)
+    assert torch.equal(got[0], process_mask(P[0], dets[0][:, 6:], dets[0][:, :4], (640, 640), upsample=False))
+    got = process_mask_batch(P[:2], dets[:2], (322, 322), upsample=True, out_dtype=torch.uint8)
+    assert torch.equal(got[1], process_mask(P[1], dets[1][:, 6:], dets[1][:, :4], (322, 322), upsample=True, out_dtype=torch.uint8))

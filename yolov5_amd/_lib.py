@@ -16,6 +16,12 @@ Y5_OK, Y5_ERR_BAD_ARG, Y5_ERR_UNSUPPORTED, Y5_ERR_RUNTIME, Y5_ERR_WORKSPACE = 0,
 NMS_MULTI_LABEL, NMS_AGNOSTIC = 1, 2
 
 
+class MaskImg(C.Structure):
+    """y5_mask_img (include/yolov5_hip.h): one image of y5_process_mask_batch."""
+
+    _fields_ = [("masks_in", C.c_void_p), ("boxes", C.c_void_p), ("ld_m", C.c_int), ("ld_b", C.c_int), ("n", C.c_int)]
+
+
 class ConvDesc(C.Structure):
     """y5_conv_desc (include/yolov5_hip.h)."""
 
@@ -154,6 +160,8 @@ EXPORTS = {
     "y5_loss_targets_layout": (C.c_int, [C.POINTER(LossDesc), C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_longlong)]),
     "y5_process_mask": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "y5_process_mask_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(MaskImg), C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_int, C.c_void_p]),
     "y5_mosaic_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "y5_letterbox_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "y5_val_match": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

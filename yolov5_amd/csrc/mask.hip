@@ -119,6 +119,191 @@ void y5_process_mask_kernel(const MaskParams p) {
   }
 }
 
+
+// ---- the whole batch in ONE launch (round 6) -----------------------------------------------------------------------------------------------------------
+// segment/predict.py:161-172 calls process_mask once per image; at bs = 32 with 300 instances each that was 32 launches of 30 000 workgroups writing
+// 16 KB apiece (0.8-2 TB/s of a ~5 TB/s write rate).  Here a persistent grid walks (instance, strip) items of the WHOLE batch: a strip = SH output rows x the
+// full width = one CONTIGUOUS run of the output (80 KB fp32 / 20 KB uint8), stored 16 bytes per lane.  Most strips lie wholly outside their instance's box
+// (crop_mask zeroes everything outside): those are pure zero stores -- no LDS, no barrier, no prototype read; inside a strip the columns beyond the box (+ the
+// bilinear reach) are zero stores as well.  Only the low-resolution window rows x the box's columns evaluate the c-term dot product.  Arithmetic of a non-zero
+// pixel is y5_process_mask_kernel's, expression for expression.
+struct MaskImg { const float* coef; const float* boxes; int ld_m, ld_b, n, out_off; };
+static constexpr int MB_MAX_IMG = 64;
+struct MaskBatchParams {
+  const void* protos;   // (B, c, mh, mw)
+  void* out;            // (sum n, oh, ow)
+  MaskImg img[MB_MAX_IMG];
+  int B, c, mh, mw, ih, iw, oh, ow, upsample, total, nstrip;
+  float sx, sy, rw, rh, inv_rw;
+};
+static constexpr int MB_SH = 32;   // output rows per strip
+
+template <typename TP, typename TO>
+__global__ __launch_bounds__(256)
+void y5_process_mask_batch_kernel(const MaskBatchParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* s_m = reinterpret_cast<float*>(smem);                 // [wh][mw] cropped sigmoid masks of the strip's window rows
+  constexpr int VEC = 16 / (int)sizeof(TO);
+  const int tid = threadIdx.x;
+  const int wmax = (int)((float)MB_SH * p.rh) + 3;
+  float* s_coef = s_m + wmax * p.mw;                           // [c]
+  const int vpr = p.ow / VEC;                                  // 16-byte vectors per output row
+  const long long items = (long long)p.total * p.nstrip;
+  for (long long item = blockIdx.x; item < items; item += gridDim.x) {
+    const int g = (int)(item / p.nstrip), si = (int)(item - (long long)g * p.nstrip);
+    int b = 0;
+    while (b + 1 < p.B && g >= p.img[b + 1].out_off) ++b;      // (wave-uniform: scalar loads of the descriptor table)
+    const MaskImg im = p.img[b];
+    const int inst = g - im.out_off;
+    const int Y0 = si * MB_SH, rows = p.oh - Y0 < MB_SH ? p.oh - Y0 : MB_SH;
+    // low-resolution rows the strip's bilinear taps can touch (y5_process_mask_kernel's window)
+    int wy0, wy1;
+    if (p.upsample) {
+      const float fy0 = fmaxf(p.rh * ((float)Y0 + 0.5f) - 0.5f, 0.f), fy1 = fmaxf(p.rh * ((float)(Y0 + rows - 1) + 0.5f) - 0.5f, 0.f);
+      wy0 = (int)fy0;
+      wy1 = (int)fy1 + 1;
+      wy1 = wy1 > p.mh - 1 ? p.mh - 1 : wy1;
+    } else {
+      wy0 = Y0; wy1 = Y0 + rows - 1;
+    }
+    const int wh = wy1 - wy0 + 1;
+    const float* bx = im.boxes + (long long)inst * im.ld_b;
+    const float x1 = bx[0] * p.sx, y1 = bx[1] * p.sy, x2 = bx[2] * p.sx, y2 = bx[3] * p.sy;  // general.py:42-46
+    // low-resolution pixels inside the crop: integer gx with x1 <= gx < x2 (general.py:22), likewise gy
+    const int gx_lo = (int)fmaxf(ceilf(x1), 0.f), gx_hi = (int)fminf(ceilf(x2) - 1.f, (float)(p.mw - 1));
+    const int gy_lo = (int)fmaxf(ceilf(y1), 0.f), gy_hi = (int)fminf(ceilf(y2) - 1.f, (float)(p.mh - 1));
+    TO* out = static_cast<TO*>(p.out) + ((long long)g * p.oh + Y0) * p.ow;
+    const int nvec = rows * vpr;
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const bool nan_box = !(x1 == x1 && x2 == x2 && y1 == y1 && y2 == y2);
+    if (nan_box || gx_lo > gx_hi || gy_lo > gy_hi || wy1 < gy_lo || wy0 > gy_hi) {   // nothing of the box in this strip: zeros
+      const u4 z = {0u, 0u, 0u, 0u};
+      for (int i = tid; i < nvec; i += 256) reinterpret_cast<u4*>(out)[i] = z;
+      continue;
+    }
+    // output columns a box pixel can reach (conservative): taps of column X are floor(rw (X + .5) - .5) and the next one
+    int X_lo = 0, X_hi = p.ow - 1;
+    if (p.upsample) {
+      X_lo = (int)((float)(gx_lo - 1) * p.inv_rw) - 2;
+      X_hi = (int)((float)(gx_hi + 2) * p.inv_rw) + 2;
+    } else {
+      X_lo = gx_lo; X_hi = gx_hi;
+    }
+    __syncthreads();   // the previous item's readers are done with s_m / s_coef
+    for (int i = tid; i < p.c; i += 256) s_coef[i] = im.coef[(long long)inst * im.ld_m + i];
+    __syncthreads();
+    const TP* P = static_cast<const TP*>(p.protos) + (long long)b * p.c * p.mh * p.mw;
+    const long long plane = (long long)p.mh * p.mw;
+    for (int i = tid; i < wh * p.mw; i += 256) {
+      const int ly = i / p.mw, gx = i - ly * p.mw;
+      const int gy = wy0 + ly;
+      const float r = (float)gx, cc = (float)gy;
+      float v = 0.f;
+      if (r >= x1 && r < x2 && cc >= y1 && cc < y2) {  // crop_mask, general.py:22
+        float s = 0.f;
+        const TP* q = P + (long long)gy * p.mw + gx;
+        for (int k = 0; k < p.c; ++k) s += s_coef[k] * (float)q[k * plane];
+        v = 1.0f / (1.0f + expf(-s));
+      }
+      s_m[i] = v;
+    }
+    __syncthreads();
+    const int ww = p.mw;
+    for (int i = tid; i < nvec; i += 256) {
+      const int oy = i / vpr, X = (i - oy * vpr) * VEC;
+      TO r[VEC];
+      if (X + VEC - 1 < X_lo || X > X_hi) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) r[e] = (TO)0;
+      } else {
+        const int Y = Y0 + oy;
+        float hl1 = 0.f;
+        int h1 = Y - wy0, h1p = 0;
+        if (p.upsample) {  // upsample_bilinear2d, align_corners=False (F.interpolate, general.py:50)
+          const float h1r = fmaxf(p.rh * ((float)Y + 0.5f) - 0.5f, 0.f);
+          const int hh = (int)h1r;
+          h1p = hh < p.mh - 1 ? 1 : 0;
+          hl1 = h1r - (float)hh;
+          h1 = hh - wy0;
+        }
+        const float hl0 = 1.0f - hl1;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const int Xe = X + e;
+          float val;
+          if (p.upsample) {
+            const float w1r = fmaxf(p.rw * ((float)Xe + 0.5f) - 0.5f, 0.f);
+            const int w1i = (int)w1r;
+            const int w1p = w1i < p.mw - 1 ? 1 : 0;
+            const float wl1 = w1r - (float)w1i, wl0 = 1.0f - wl1;
+            const float v00 = s_m[h1 * ww + w1i], v01 = s_m[h1 * ww + w1i + w1p];
+            const float v10 = s_m[(h1 + h1p) * ww + w1i], v11 = s_m[(h1 + h1p) * ww + w1i + w1p];
+            val = hl0 * (wl0 * v00 + wl1 * v01) + hl1 * (wl0 * v10 + wl1 * v11);
+          } else {
+            val = s_m[h1 * ww + Xe];
+          }
+          r[e] = (TO)(val > 0.5f ? 1 : 0);  // general.py:51 gt_(0.5)
+        }
+      }
+      u4 v4;
+      __builtin_memcpy(&v4, r, 16);
+      reinterpret_cast<u4*>(out)[i] = v4;
+    }
+  }
+}
+
+extern "C" int y5_process_mask_batch(const void* protos, int proto_dtype, int B, int c, int mh, int mw, const y5_mask_img* imgs, int ih, int iw,
+                                     int upsample, void* out, int out_dtype, void* stream_) {
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  if (!protos || !imgs || B < 1 || c < 1 || c > 256 || mh < 1 || mw < 1 || ih < 1 || iw < 1) return y5_fail(Y5_ERR_BAD_ARG, "process_mask_batch: bad args");
+  if (proto_dtype != Y5_F16 && proto_dtype != Y5_F32) return y5_fail(Y5_ERR_BAD_ARG, "process_mask_batch: protos must be f16 or f32");
+  if (out_dtype != Y5_F32 && out_dtype != Y5_U8) return y5_fail(Y5_ERR_BAD_ARG, "process_mask_batch: out dtype must be Y5_F32 or Y5_U8");
+  const int oh = upsample ? ih : mh, ow = upsample ? iw : mw;
+  const int vec = out_dtype == Y5_F32 ? 4 : 16;
+  const float rw = (float)mw / (float)ow, rh = (float)mh / (float)oh;
+  if (upsample && (rw > 1.0f || rh > 1.0f)) return y5_fail(Y5_ERR_UNSUPPORTED, "process_mask_batch: only upsampling (ih >= mh, iw >= mw) is supported");
+  const int wmax = (int)((float)MB_SH * rh) + 3;
+  const size_t lds = ((size_t)wmax * mw + 256) * 4;
+  if (ow % vec || ((uintptr_t)out & 15) || lds > 64 * 1024) return y5_fail(Y5_ERR_UNSUPPORTED, "process_mask_batch: needs ow % (16 bytes) == 0, a 16-byte aligned output and mw <= ~450 (use y5_process_mask)");
+  long long done = 0;   // instances of the images of earlier chunks
+  const size_t esz = out_dtype == Y5_F32 ? 4 : 1;
+  for (int b0 = 0; b0 < B; b0 += MB_MAX_IMG) {
+    MaskBatchParams p{};
+    const int nb = B - b0 < MB_MAX_IMG ? B - b0 : MB_MAX_IMG;
+    int total = 0;
+    for (int i = 0; i < nb; ++i) {
+      const y5_mask_img& s = imgs[b0 + i];
+      if (s.n < 0 || (s.n > 0 && (!s.masks_in || !s.boxes || s.ld_m < c || s.ld_b < 4))) return y5_fail(Y5_ERR_BAD_ARG, "process_mask_batch: bad image descriptor");
+      p.img[i] = MaskImg{s.masks_in, s.boxes, s.ld_m, s.ld_b, s.n, total};
+      total += s.n;
+    }
+    if (total > 0) {
+      if (!out) return y5_fail(Y5_ERR_BAD_ARG, "process_mask_batch: null output");
+      p.protos = static_cast<const char*>(protos) + (size_t)b0 * c * mh * mw * (proto_dtype == Y5_F16 ? 2 : 4);
+      p.out = static_cast<char*>(out) + (size_t)done * oh * ow * esz;
+      p.B = nb; p.c = c; p.mh = mh; p.mw = mw; p.ih = ih; p.iw = iw; p.oh = oh; p.ow = ow; p.upsample = upsample ? 1 : 0;
+      p.total = total; p.nstrip = (oh + MB_SH - 1) / MB_SH;
+      p.sx = (float)((double)mw / (double)iw); p.sy = (float)((double)mh / (double)ih);
+      p.rw = rw; p.rh = rh; p.inv_rw = (float)ow / (float)mw;
+      const long long items = (long long)total * p.nstrip;
+      long long G = (long long)y5_num_cu() * 8;
+      if (G > items) G = items;
+      const dim3 grid((unsigned)G), block(256);
+      if (proto_dtype == Y5_F16) {
+        if (out_dtype == Y5_F32) hipLaunchKernelGGL((y5_process_mask_batch_kernel<half_t, float>), grid, block, lds, st, p);
+        else hipLaunchKernelGGL((y5_process_mask_batch_kernel<half_t, unsigned char>), grid, block, lds, st, p);
+      } else {
+        if (out_dtype == Y5_F32) hipLaunchKernelGGL((y5_process_mask_batch_kernel<float, float>), grid, block, lds, st, p);
+        else hipLaunchKernelGGL((y5_process_mask_batch_kernel<float, unsigned char>), grid, block, lds, st, p);
+      }
+      const int rc = y5_check_launch("y5_process_mask_batch");
+      if (rc) return rc;
+    }
+    done += total;
+  }
+  return Y5_OK;
+}
+
 extern "C" int y5_process_mask(const void* protos, int proto_dtype, int c, int mh, int mw, const float* masks_in, int ld_m,
                                const float* boxes, int ld_b, int n, int ih, int iw, int upsample, void* out, int out_dtype,
                                void* stream_) {
