@@ -121,82 +121,85 @@ void y5_process_mask_kernel(const MaskParams p) {
 
 
 // ---- the whole batch in ONE launch (round 6) -----------------------------------------------------------------------------------------------------------
-// segment/predict.py:161-172 calls process_mask once per image; at bs = 32 with 300 instances each that was 32 launches of 30 000 workgroups writing
-// 16 KB apiece (0.8-2 TB/s of a ~5 TB/s write rate).  Here a persistent grid walks (instance, strip) items of the WHOLE batch: a strip = SH output rows x the
-// full width = one CONTIGUOUS run of the output (80 KB fp32 / 20 KB uint8), stored 16 bytes per lane.  Most strips lie wholly outside their instance's box
-// (crop_mask zeroes everything outside): those are pure zero stores -- no LDS, no barrier, no prototype read; inside a strip the columns beyond the box (+ the
-// bilinear reach) are zero stores as well.  Only the low-resolution window rows x the box's columns evaluate the c-term dot product.  Arithmetic of a non-zero
-// pixel is y5_process_mask_kernel's, expression for expression.
+// segment/predict.py:161-172 calls process_mask once per image; at bs = 32 with 300 instances each that is 32 launches of 30 000 workgroups apiece.  Here a
+// persistent grid walks (instance, tile) items of the WHOLE batch; a tile is 64 output rows x 256 BYTES of a row (64 float32 / 256 uint8 pixels: every row
+// segment is 16 lanes x 16 bytes).  Most tiles lie wholly outside their instance's box (crop_mask zeroes everything outside): those are pure zero stores -- no
+// LDS, no barrier, no prototype read.  Arithmetic of a non-zero tile is y5_process_mask_kernel's, expression for expression.
+// (A first version walked full-width 32-row strips -- one contiguous 80 KB run per workgroup: 0.27 TB/s in float32, because concurrent workgroups then write
+// at a 20 x 4 KB stride and camp on a quarter of the memory channels; the same kernel wrote uint8 (stride 5 x 4 KB) at 1.5 TB/s.  profiles/r06/r06_mask_batch.log)
 struct MaskImg { const float* coef; const float* boxes; int ld_m, ld_b, n, out_off; };
 static constexpr int MB_MAX_IMG = 64;
 struct MaskBatchParams {
   const void* protos;   // (B, c, mh, mw)
   void* out;            // (sum n, oh, ow)
   MaskImg img[MB_MAX_IMG];
-  int B, c, mh, mw, ih, iw, oh, ow, upsample, total, nstrip;
-  float sx, sy, rw, rh, inv_rw;
+  int B, c, mh, mw, ih, iw, oh, ow, upsample, total, tiles_x, tiles_y;
+  float sx, sy, rw, rh;
 };
-static constexpr int MB_SH = 32;   // output rows per strip
+static constexpr int MB_TH = 64;   // output rows per tile
 
 template <typename TP, typename TO>
 __global__ __launch_bounds__(256)
 void y5_process_mask_batch_kernel(const MaskBatchParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* s_m = reinterpret_cast<float*>(smem);                 // [wh][mw] cropped sigmoid masks of the strip's window rows
   constexpr int VEC = 16 / (int)sizeof(TO);
+  constexpr int TW = 16 * VEC;                                  // output columns per tile: 256 bytes of a row
+  constexpr int WMAX_X = TW + 4, WMAX_Y = MB_TH + 4;            // low-resolution window bounds (scale 1 = no upsampling)
+  float* s_m = reinterpret_cast<float*>(smem);                  // [wh][ww] cropped sigmoid masks
+  float* s_coef = s_m + WMAX_X * WMAX_Y;                        // [c]
   const int tid = threadIdx.x;
-  const int wmax = (int)((float)MB_SH * p.rh) + 3;
-  float* s_coef = s_m + wmax * p.mw;                           // [c]
-  const int vpr = p.ow / VEC;                                  // 16-byte vectors per output row
-  const long long items = (long long)p.total * p.nstrip;
+  const int per_inst = p.tiles_x * p.tiles_y;
+  const long long items = (long long)p.total * per_inst;
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  const int vy = tid >> 4, vx = (tid & 15) * VEC;               // this lane's vector inside a 16-row slab of the tile
   for (long long item = blockIdx.x; item < items; item += gridDim.x) {
-    const int g = (int)(item / p.nstrip), si = (int)(item - (long long)g * p.nstrip);
+    const int g = (int)(item / per_inst), ti = (int)(item - (long long)g * per_inst);
+    const int ty = ti / p.tiles_x, tx = ti - ty * p.tiles_x;
     int b = 0;
-    while (b + 1 < p.B && g >= p.img[b + 1].out_off) ++b;      // (wave-uniform: scalar loads of the descriptor table)
+    while (b + 1 < p.B && g >= p.img[b + 1].out_off) ++b;       // (wave-uniform: scalar loads of the descriptor table)
     const MaskImg im = p.img[b];
     const int inst = g - im.out_off;
-    const int Y0 = si * MB_SH, rows = p.oh - Y0 < MB_SH ? p.oh - Y0 : MB_SH;
-    // low-resolution rows the strip's bilinear taps can touch (y5_process_mask_kernel's window)
-    int wy0, wy1;
+    const int X0 = tx * TW, Y0 = ty * MB_TH;
+    // low-resolution window covering the bilinear taps of output rows [Y0, Y0 + TH) / columns [X0, X0 + TW): y5_process_mask_kernel's
+    int wx0, wy0, ww, wh;
     if (p.upsample) {
-      const float fy0 = fmaxf(p.rh * ((float)Y0 + 0.5f) - 0.5f, 0.f), fy1 = fmaxf(p.rh * ((float)(Y0 + rows - 1) + 0.5f) - 0.5f, 0.f);
-      wy0 = (int)fy0;
-      wy1 = (int)fy1 + 1;
+      const float fx0 = fmaxf(p.rw * ((float)X0 + 0.5f) - 0.5f, 0.f), fy0 = fmaxf(p.rh * ((float)Y0 + 0.5f) - 0.5f, 0.f);
+      const int Xl = (X0 + TW < p.ow ? X0 + TW : p.ow) - 1, Yl = (Y0 + MB_TH < p.oh ? Y0 + MB_TH : p.oh) - 1;
+      const float fx1 = fmaxf(p.rw * ((float)Xl + 0.5f) - 0.5f, 0.f), fy1 = fmaxf(p.rh * ((float)Yl + 0.5f) - 0.5f, 0.f);
+      wx0 = (int)fx0; wy0 = (int)fy0;
+      int wx1 = (int)fx1 + 1, wy1 = (int)fy1 + 1;
+      wx1 = wx1 > p.mw - 1 ? p.mw - 1 : wx1;
       wy1 = wy1 > p.mh - 1 ? p.mh - 1 : wy1;
+      ww = wx1 - wx0 + 1; wh = wy1 - wy0 + 1;
     } else {
-      wy0 = Y0; wy1 = Y0 + rows - 1;
+      wx0 = X0; wy0 = Y0;
+      ww = p.mw - X0 < TW ? p.mw - X0 : TW;
+      wh = p.mh - Y0 < MB_TH ? p.mh - Y0 : MB_TH;
     }
-    const int wh = wy1 - wy0 + 1;
     const float* bx = im.boxes + (long long)inst * im.ld_b;
     const float x1 = bx[0] * p.sx, y1 = bx[1] * p.sy, x2 = bx[2] * p.sx, y2 = bx[3] * p.sy;  // general.py:42-46
-    // low-resolution pixels inside the crop: integer gx with x1 <= gx < x2 (general.py:22), likewise gy
-    const int gx_lo = (int)fmaxf(ceilf(x1), 0.f), gx_hi = (int)fminf(ceilf(x2) - 1.f, (float)(p.mw - 1));
-    const int gy_lo = (int)fmaxf(ceilf(y1), 0.f), gy_hi = (int)fminf(ceilf(y2) - 1.f, (float)(p.mh - 1));
-    TO* out = static_cast<TO*>(p.out) + ((long long)g * p.oh + Y0) * p.ow;
-    const int nvec = rows * vpr;
-    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    const bool nan_box = !(x1 == x1 && x2 == x2 && y1 == y1 && y2 == y2);
-    if (nan_box || gx_lo > gx_hi || gy_lo > gy_hi || wy1 < gy_lo || wy0 > gy_hi) {   // nothing of the box in this strip: zeros
+    // does any low-resolution pixel of the window lie inside the crop (x1 <= gx < x2, y1 <= gy < y2; general.py:22)?  Evaluated with the SAME float
+    // comparisons on the window's corner pixels as the per-pixel test below (monotone in gx / gy), so an all-zero window is exactly an all-zero tile.
+    const float gxa = (float)wx0, gxb = (float)(wx0 + ww - 1), gya = (float)wy0, gyb = (float)(wy0 + wh - 1);
+    const bool hit = gxb >= x1 && gxa < x2 && gyb >= y1 && gya < y2 && x1 < x2 && y1 < y2;
+    TO* out = static_cast<TO*>(p.out) + (long long)g * p.oh * p.ow;
+    if (!hit) {
       const u4 z = {0u, 0u, 0u, 0u};
-      for (int i = tid; i < nvec; i += 256) reinterpret_cast<u4*>(out)[i] = z;
+#pragma unroll
+      for (int k = 0; k < MB_TH / 16; ++k) {
+        const int Y = Y0 + k * 16 + vy, X = X0 + vx;
+        if (Y < p.oh && X < p.ow) *reinterpret_cast<u4*>(out + (long long)Y * p.ow + X) = z;
+      }
       continue;
-    }
-    // output columns a box pixel can reach (conservative): taps of column X are floor(rw (X + .5) - .5) and the next one
-    int X_lo = 0, X_hi = p.ow - 1;
-    if (p.upsample) {
-      X_lo = (int)((float)(gx_lo - 1) * p.inv_rw) - 2;
-      X_hi = (int)((float)(gx_hi + 2) * p.inv_rw) + 2;
-    } else {
-      X_lo = gx_lo; X_hi = gx_hi;
     }
     __syncthreads();   // the previous item's readers are done with s_m / s_coef
     for (int i = tid; i < p.c; i += 256) s_coef[i] = im.coef[(long long)inst * im.ld_m + i];
     __syncthreads();
     const TP* P = static_cast<const TP*>(p.protos) + (long long)b * p.c * p.mh * p.mw;
     const long long plane = (long long)p.mh * p.mw;
-    for (int i = tid; i < wh * p.mw; i += 256) {
-      const int ly = i / p.mw, gx = i - ly * p.mw;
-      const int gy = wy0 + ly;
+    for (int i = tid; i < ww * wh; i += 256) {
+      const int ly = i / ww, lx = i - ly * ww;
+      const int gy = wy0 + ly, gx = wx0 + lx;
       const float r = (float)gx, cc = (float)gy;
       float v = 0.f;
       if (r >= x1 && r < x2 && cc >= y1 && cc < y2) {  // crop_mask, general.py:22
@@ -208,46 +211,42 @@ void y5_process_mask_batch_kernel(const MaskBatchParams p) {
       s_m[i] = v;
     }
     __syncthreads();
-    const int ww = p.mw;
-    for (int i = tid; i < nvec; i += 256) {
-      const int oy = i / vpr, X = (i - oy * vpr) * VEC;
+#pragma unroll 1
+    for (int k = 0; k < MB_TH / 16; ++k) {
+      const int Y = Y0 + k * 16 + vy, X = X0 + vx;
+      if (Y >= p.oh || X >= p.ow) continue;
       TO r[VEC];
-      if (X + VEC - 1 < X_lo || X > X_hi) {
+      float hl1 = 0.f;
+      int h1 = Y - wy0, h1p = 0;
+      if (p.upsample) {  // upsample_bilinear2d, align_corners=False (F.interpolate, general.py:50)
+        const float h1r = fmaxf(p.rh * ((float)Y + 0.5f) - 0.5f, 0.f);
+        const int hh = (int)h1r;
+        h1p = hh < p.mh - 1 ? 1 : 0;
+        hl1 = h1r - (float)hh;
+        h1 = hh - wy0;
+      }
+      const float hl0 = 1.0f - hl1;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) r[e] = (TO)0;
-      } else {
-        const int Y = Y0 + oy;
-        float hl1 = 0.f;
-        int h1 = Y - wy0, h1p = 0;
-        if (p.upsample) {  // upsample_bilinear2d, align_corners=False (F.interpolate, general.py:50)
-          const float h1r = fmaxf(p.rh * ((float)Y + 0.5f) - 0.5f, 0.f);
-          const int hh = (int)h1r;
-          h1p = hh < p.mh - 1 ? 1 : 0;
-          hl1 = h1r - (float)hh;
-          h1 = hh - wy0;
+      for (int e = 0; e < VEC; ++e) {
+        const int Xe = X + e;   // (ow % VEC == 0: a vector never straddles the row end)
+        float val;
+        if (p.upsample) {
+          const float w1r = fmaxf(p.rw * ((float)Xe + 0.5f) - 0.5f, 0.f);
+          const int w1i = (int)w1r;
+          const int w1p = w1i < p.mw - 1 ? 1 : 0;
+          const float wl1 = w1r - (float)w1i, wl0 = 1.0f - wl1;
+          const int w1 = w1i - wx0;
+          const float v00 = s_m[h1 * ww + w1], v01 = s_m[h1 * ww + w1 + w1p];
+          const float v10 = s_m[(h1 + h1p) * ww + w1], v11 = s_m[(h1 + h1p) * ww + w1 + w1p];
+          val = hl0 * (wl0 * v00 + wl1 * v01) + hl1 * (wl0 * v10 + wl1 * v11);
+        } else {
+          val = s_m[h1 * ww + (Xe - wx0)];
         }
-        const float hl0 = 1.0f - hl1;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          const int Xe = X + e;
-          float val;
-          if (p.upsample) {
-            const float w1r = fmaxf(p.rw * ((float)Xe + 0.5f) - 0.5f, 0.f);
-            const int w1i = (int)w1r;
-            const int w1p = w1i < p.mw - 1 ? 1 : 0;
-            const float wl1 = w1r - (float)w1i, wl0 = 1.0f - wl1;
-            const float v00 = s_m[h1 * ww + w1i], v01 = s_m[h1 * ww + w1i + w1p];
-            const float v10 = s_m[(h1 + h1p) * ww + w1i], v11 = s_m[(h1 + h1p) * ww + w1i + w1p];
-            val = hl0 * (wl0 * v00 + wl1 * v01) + hl1 * (wl0 * v10 + wl1 * v11);
-          } else {
-            val = s_m[h1 * ww + Xe];
-          }
-          r[e] = (TO)(val > 0.5f ? 1 : 0);  // general.py:51 gt_(0.5)
-        }
+        r[e] = (TO)(val > 0.5f ? 1 : 0);  // general.py:51 gt_(0.5)
       }
       u4 v4;
       __builtin_memcpy(&v4, r, 16);
-      reinterpret_cast<u4*>(out)[i] = v4;
+      *reinterpret_cast<u4*>(out + (long long)Y * p.ow + X) = v4;
     }
   }
 }
@@ -262,9 +261,9 @@ extern "C" int y5_process_mask_batch(const void* protos, int proto_dtype, int B,
   const int vec = out_dtype == Y5_F32 ? 4 : 16;
   const float rw = (float)mw / (float)ow, rh = (float)mh / (float)oh;
   if (upsample && (rw > 1.0f || rh > 1.0f)) return y5_fail(Y5_ERR_UNSUPPORTED, "process_mask_batch: only upsampling (ih >= mh, iw >= mw) is supported");
-  const int wmax = (int)((float)MB_SH * rh) + 3;
-  const size_t lds = ((size_t)wmax * mw + 256) * 4;
-  if (ow % vec || ((uintptr_t)out & 15) || lds > 64 * 1024) return y5_fail(Y5_ERR_UNSUPPORTED, "process_mask_batch: needs ow % (16 bytes) == 0, a 16-byte aligned output and mw <= ~450 (use y5_process_mask)");
+  const int tw = 16 * vec;
+  const size_t lds = ((size_t)(tw + 4) * (MB_TH + 4) + 256) * 4;
+  if (ow % vec || ((uintptr_t)out & 15)) return y5_fail(Y5_ERR_UNSUPPORTED, "process_mask_batch: needs ow % (16 bytes) == 0 and a 16-byte aligned output (use y5_process_mask)");
   long long done = 0;   // instances of the images of earlier chunks
   const size_t esz = out_dtype == Y5_F32 ? 4 : 1;
   for (int b0 = 0; b0 < B; b0 += MB_MAX_IMG) {
@@ -282,10 +281,10 @@ extern "C" int y5_process_mask_batch(const void* protos, int proto_dtype, int B,
       p.protos = static_cast<const char*>(protos) + (size_t)b0 * c * mh * mw * (proto_dtype == Y5_F16 ? 2 : 4);
       p.out = static_cast<char*>(out) + (size_t)done * oh * ow * esz;
       p.B = nb; p.c = c; p.mh = mh; p.mw = mw; p.ih = ih; p.iw = iw; p.oh = oh; p.ow = ow; p.upsample = upsample ? 1 : 0;
-      p.total = total; p.nstrip = (oh + MB_SH - 1) / MB_SH;
+      p.total = total; p.tiles_x = (ow + tw - 1) / tw; p.tiles_y = (oh + MB_TH - 1) / MB_TH;
       p.sx = (float)((double)mw / (double)iw); p.sy = (float)((double)mh / (double)ih);
-      p.rw = rw; p.rh = rh; p.inv_rw = (float)ow / (float)mw;
-      const long long items = (long long)total * p.nstrip;
+      p.rw = rw; p.rh = rh;
+      const long long items = (long long)total * p.tiles_x * p.tiles_y;
       long long G = (long long)y5_num_cu() * 8;
       if (G > items) G = items;
       const dim3 grid((unsigned)G), block(256);
