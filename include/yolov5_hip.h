@@ -369,8 +369,8 @@ int y5_process_mask(const void* protos, int proto_dtype, int c, int mh, int mw, 
                     void* stream);
 /* The same for a whole BATCH in one launch (segment/predict.py:161-172 calls process_mask per image): protos (B, c, mh, mw); image b has imgs[b].n instances,
  * coefficient rows at masks_in + i*ld_m and boxes at boxes + i*ld_b (device pointers, typically into the rows of the padded NMS output; `imgs` itself is a HOST
- * array, copied into the kernel arguments -- no device table, no host sync).  out: (sum of n, oh, ow), the instances of image 0 first; a persistent grid walks
- * (instance, 64-row x 256-byte tile) items, tiles outside the instance's box are plain zero stores.  Needs ow % 4 == 0 (Y5_F32) / ow % 16 == 0 (Y5_U8) and a
+ * array, copied into the kernel arguments -- no device table, no host sync).  out: (sum of n, oh, ow), the instances of image 0 first; one grid over
+ * (image, instance, 64-row x 256-byte tile) items, tiles outside the instance's box are plain zero stores.  Needs ow % 4 == 0 (Y5_F32) / ow % 16 == 0 (Y5_U8) and a
  * 16-byte aligned `out`; otherwise Y5_ERR_UNSUPPORTED (call y5_process_mask per image). */
 typedef struct y5_mask_img { const float* masks_in; const float* boxes; int ld_m, ld_b, n; } y5_mask_img;
 int y5_process_mask_batch(const void* protos, int proto_dtype, int B, int c, int mh, int mw, const y5_mask_img* imgs, int ih, int iw, int upsample,
