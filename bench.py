@@ -615,8 +615,10 @@ def config_probe(name, batch, imgsz, dev, steps=20):
     if nm:
         from yolov5_amd.segment import process_mask_batch
 
+        mask_dtype = [torch.float32]
+
         def masks(protos, dets):  # segment/predict.py:161-172: per image, upsampled masks of its detections (float32 0/1 as the reference) -- one launch per batch
-            return process_mask_batch(protos, dets, (imgsz, imgsz), upsample=True)
+            return process_mask_batch(protos, dets, (imgsz, imgsz), upsample=True, out_dtype=mask_dtype[0])
 
     pipe = DetectPipeline(model, 0.25, 0.45, max_det=300 if nm else 1000, nm=nm)
     for _ in range(6):
@@ -634,6 +636,22 @@ def config_probe(name, batch, imgsz, dev, steps=20):
         masks(pipe.protos, r)
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    dt_u8 = None
+    if nm:   # the same step with uint8 masks (4x fewer bytes than the reference's float32 0/1 tensors): reported beside, never as the config's figure
+        mask_dtype[0] = torch.uint8
+        for _ in range(2):
+            r = pipe.submit(x)
+        r = pipe.flush()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            r = pipe.submit(x)
+            if r is not None:
+                masks(pipe.protos, r)
+        masks(pipe.protos, pipe.flush())
+        torch.cuda.synchronize(dev)
+        dt_u8 = time.perf_counter() - t0
+        mask_dtype[0] = torch.float32
     fwd = event_times(lambda: model(x), 30, dev)
     z = model(x)[0]
     nms = event_times(lambda: non_max_suppression(z, 0.25, 0.45, max_det=300 if nm else 1000, nm=nm), 30, dev)
@@ -645,6 +663,9 @@ def config_probe(name, batch, imgsz, dev, steps=20):
            "nms_us_per_img": round(_pct(nms, 0.5) * 1e3 / batch, 2), "detections_per_img": round(ndet, 1),
            "algorithmic_gflop_per_step": round(fl / 1e9, 1), "forward_mfma_tflops": round(fl / (fwd_ms * 1e-3) / 1e12, 1),
            "forward_mfma_frac": round(fl / (fwd_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+    if dt_u8 is not None:
+        out["mask_gbytes_per_step_float32"] = round(ndet * batch * imgsz * imgsz * 4 / 1e9, 2)
+        out["uint8_masks"] = {"images_per_sec": round(batch * steps / dt_u8, 1), "ms_per_step": round(dt_u8 / steps * 1e3, 4)}
     del model, pipe, eng
     torch.cuda.empty_cache()
     return out
