@@ -256,6 +256,11 @@ def test_conv_stem_raw_and_device_filter_pack(B, H, W, C2):
     (1, 10, 6, 128, 64, 96, 88, 2),     # 4 low-resolution chunks + 2 plain ones, N tail, several tiles per workgroup
     (2, 6, 10, 64, 128, 160, 89, 0),    # 2-stage BK64 tile, two N tiles
     (3, 4, 4, 128, 128, 64, -1, 1),     # cfg -1 resolves to 89 for up_c > 0; one workgroup walks every tile
+    # the 8-phase family's loader (conv_g8.h UP2, ids 95 / 96): source switch after one / two K tiles, N tails, several tiles per workgroup
+    (2, 8, 12, 64, 64, 128, 95, 0),
+    (2, 12, 12, 128, 128, 264, 95, 2),
+    (1, 10, 6, 128, 64, 96, 96, 2),
+    (2, 6, 10, 64, 128, 320, 96, 1),
 ])
 def test_conv_virtual_upsample_concat(B, H, W, c_up, c_hi, C2, cfg, max_blocks):
     """Configurations 88 / 89 (conv_igemm.h UP2): the 1x1 convolution behind `nn.Upsample(2, 'nearest')` + `Concat` (models/yolov5s.yaml:36-38,41-43)

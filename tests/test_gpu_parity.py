@@ -211,6 +211,10 @@ def test_conv_matches_torch_fp32_reference(case, dev):
     (8, 80, 80, 128, 128, 128, 89, 0),     # 2-stage BK64 tile
     (4, 38, 42, 64, 192, 96, 88, 16),      # odd tile counts, N tail, source switch after one chunk
     (4, 38, 42, 320, 64, 160, 89, 24),
+    (16, 40, 40, 256, 256, 256, 95, 0),    # the 8-phase family's loader (ids 95 / 96) at the same layers
+    (8, 80, 80, 128, 128, 128, 96, 0),
+    (4, 38, 42, 64, 192, 96, 96, 16),
+    (4, 38, 42, 320, 64, 328, 95, 24),
 ])
 def test_conv_virtual_upsample_concat_matches_torch(B, H, W, c_up, c_hi, C2, cfg, max_blocks, dev):
     """Configurations 88 / 89 (conv_igemm.h UP2): the 1x1 convolution behind `nn.Upsample(2, 'nearest')` + `Concat` (models/yolov5s.yaml:36-38,41-43,

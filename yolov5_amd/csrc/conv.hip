@@ -510,9 +510,10 @@ static int conv2d_fwd_impl(const y5_conv_desc* d, const void* x, const void* w_p
   const bool pwk = cfg >= kPwk0 && !g8;   // K-streamed pointwise kernel (ids 93, 94)
   const bool h3s = cfg >= kH3S_0 && !pwk && !g8; // halo-resident 3x3 configurations added in round 5 (ids 90..92)
   const bool up2 = cfg >= kUp0 && !h3s && !pwk && !g8;   // virtual upsample + concat loader (ids 88, 89)
-  if (up2 != (d->up_c > 0)) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: configurations 88 / 89 serve exactly the layers with up_c > 0 (virtual upsample + concat)");
-  if (up2) {
-    const int bkb = kUpCfgs[cfg - kUp0].rb / 2;
+  const bool up8 = g8 && d->up_c > 0;     // ... which the 8-phase family's loader reads as well (round 6)
+  if (up2 != (d->up_c > 0) && !up8) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: only configurations 88 / 89 / 95 / 96 serve the layers with up_c > 0 (virtual upsample + concat), 88 / 89 no others");
+  if (up2 || up8) {
+    const int bkb = up8 ? 64 : kUpCfgs[cfg - kUp0].rb / 2;
     if (d->dtype != Y5_F16 || d->KH != 1 || d->KW != 1 || d->SH != 1 || d->SW != 1 || d->PH || d->PW || !residual || !y || (y_up2 != nullptr) != (d->split_n > 0) ||
         d->out_mul_h || (d->H & 1) || (d->W & 1) || d->up_c % bkb || d->up_c >= d->C1 || d->C1 % bkb || d->ld_up < d->up_c || (d->ld_up & 7))
       return y5_fail(Y5_ERR_UNSUPPORTED, "conv: virtual upsample + concat needs a 1x1 s1 fp16 layer on an even H x W grid, up_c and C1 multiples of the K chunk, "
@@ -548,8 +549,8 @@ static int conv2d_fwd_impl(const y5_conv_desc* d, const void* x, const void* w_p
     return y5_fail(Y5_ERR_UNSUPPORTED, "conv: tensor exceeds 2^31 bytes (32-bit buffer offsets)");
 
   Y5ConvParams p{};
-  p.x = x; p.w = w_packed; p.bias = bias; p.res = up2 ? nullptr : residual; p.y = y; p.y2 = y_up2;
-  if (up2) {   // (the low-resolution source travels in the `residual` argument: a layer of this kind has no residual)
+  p.x = x; p.w = w_packed; p.bias = bias; p.res = (up2 || up8) ? nullptr : residual; p.y = y; p.y2 = y_up2;
+  if (up2 || up8) {   // (the low-resolution source travels in the `residual` argument: a layer of this kind has no residual)
     p.x2 = residual; p.ldx2 = d->ld_up; p.up_c = d->up_c;
     const long long b2 = (((long long)d->B * (d->H / 2) * (d->W / 2) - 1) * d->ld_up + d->up_c) * 2;
     if (b2 >= 0x7fffffffLL) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: low-resolution tensor exceeds 2^31 bytes");
@@ -565,7 +566,7 @@ static int conv2d_fwd_impl(const y5_conv_desc* d, const void* x, const void* w_p
   p.split_n = d->split_n;
   if (d->split_n) {
     if (d->split_n < 0 || d->split_n % epp || d->split_n >= d->C2 || !y || !y_up2 || d->ld2 % epp || d->ld2 < d->C2 - d->split_n || d->ldy < d->split_n ||
-        placed || (residual && !up2))
+        placed || (residual && !up2 && !up8))
       return y5_fail(Y5_ERR_BAD_ARG, "conv: bad split store (split_n multiple of 16 bytes inside C2, both destinations, no residual / placement)");
     if (k3 || h3) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: split store needs a pointwise / implicit-GEMM configuration");
   }

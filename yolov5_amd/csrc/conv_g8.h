@@ -59,7 +59,8 @@ struct Y5G8Geom {
 
 // One staged activation row of the im2col loader: output pixel m -> byte offset of its (b, ih0, iw0) origin + the lane's source slot, and the tap mask (bit
 // kh * KW + kw SET <=> that tap lies outside the image, or the pixel is past M): conv_igemm.h's scheme (exact multiply-high division, two bit ranges)
-__device__ __forceinline__ void y5_g8_act_row(const Y5ConvParams& p, int m, int sslot, int& base, unsigned& mask) {
+template <bool UP2 = false>
+__device__ __forceinline__ void y5_g8_act_row(const Y5ConvParams& p, int m, int sslot, int& base, unsigned& mask, int* base2 = nullptr) {
   const int ohw = p.OH * p.OW;
   const int mm = m < p.M ? m : 0;
   const int b = (int)y5_fastdiv((unsigned)mm, p.dv_ohw_m, p.dv_ohw_s);
@@ -67,6 +68,9 @@ __device__ __forceinline__ void y5_g8_act_row(const Y5ConvParams& p, int m, int 
   const int oh = (int)y5_fastdiv((unsigned)r, p.dv_ow_m, p.dv_ow_s), ow = r - oh * p.OW;
   const int ih0 = oh * p.SH - p.PH, iw0 = ow * p.SW - p.PW;
   base = (((b * p.H + ih0) * p.W + iw0) * p.ldx + sslot * 8) * 2;
+  // UP2 (1x1 s1 layers behind `nn.Upsample(2)` + `Concat`, conv_igemm.h): the pixel (b, oh >> 1, ow >> 1) of the low-resolution tensor that supplies the
+  // input channels [0, up_c)
+  if constexpr (UP2) *base2 = (((b * (p.H >> 1) + (oh >> 1)) * (p.W >> 1) + (ow >> 1)) * p.ldx2 + sslot * 8) * 2;
   unsigned mk = 0;
   if (m < p.M) {
     auto range_bits = [](int lo, int hi) __attribute__((always_inline)) -> unsigned {   // bits [lo, hi), 0 <= lo, hi <= 32
@@ -92,6 +96,7 @@ __device__ unsigned long long y5_g8_dbg[512 * 2 * 8];
 #define Y5_G8_STAMP(i) ((void)0)
 #endif
 
+template <bool UP2>
 __global__ __launch_bounds__(512, 2)
 void y5_conv_g8_kernel(const Y5ConvParams p) {
   typedef half_t T;
@@ -117,6 +122,7 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
 
   const y5_rsrc_t xrs = y5_make_rsrc(p.x, p.x_bytes);
   const y5_rsrc_t wrs = y5_make_rsrc(p.w, p.w_bytes);
+  const y5_rsrc_t xrs2 = UP2 ? y5_make_rsrc(p.x2, p.x2_bytes) : xrs;
 
   float bv[Gm::MAXN / 512];   // the bias loads are issued ahead of the prologue's LDS-DMA and written to LDS behind it (older loads retire first)
 #pragma unroll
@@ -126,6 +132,8 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
   // ---- loader: the K tile being staged is (output tile s_t of this workgroup, chunk s_kc); per lane TWO rows (one per LDS-DMA instruction) of each half-tile ----
   const int lrow = lane >> 3, lslot = lane & 7;
   int a_base[2][2];        // [half][instruction]: byte offset of the pixel's (b, ih0, iw0) + source slot
+  int a_base2[UP2 ? 2 : 1][2];   // UP2: the same for the low-resolution pixel
+  bool st_up = false;
   unsigned a_mask[2][2];   // bit (kh * KW + kw) SET <=> that tap of this pixel lies outside the image (or the pixel is past M)
   unsigned w_off[2][2];    // byte offset of the filter row + source slot; bit 31 for rows past Npad
   int u_kh = 0, u_kw = 0, u_c0 = 0, s_t = 0, s_kc = 0;
@@ -150,7 +158,7 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
       const int sslot = lslot ^ ((rr >> 1) & 7);
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        y5_g8_act_row(p, m0 + (rr >> 6) * 128 + s * 64 + (rr & 63), sslot, a_base[s][jj], a_mask[s][jj]);
+        y5_g8_act_row<UP2>(p, m0 + (rr >> 6) * 128 + s * 64 + (rr & 63), sslot, a_base[s][jj], a_mask[s][jj], UP2 ? &a_base2[s][jj] : nullptr);
         const int n = n0 + (rr >> 5) * 64 + s * 32 + Gm::chan_of_row(rr & 31);
         w_off[s][jj] = n < p.Npad ? (unsigned)((n * p.Kpad + sslot * 8) * 2) : 0x80000000u;
       }
@@ -166,6 +174,7 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
     st_tap_off = ((u_kh * p.W + u_kw) * p.ldx + u_c0) * 2;
     st_tap_bit = u_kh * p.KW + u_kw;
     st_kcb = (unsigned)(s_kc * 128);
+    if constexpr (UP2) st_up = u_c0 < p.up_c;   // (1x1 layer: st_tap_off is the chunk's channel offset; up_c % 64 == 0, a chunk never straddles the boundary)
   };
   auto advance = [&]() __attribute__((always_inline)) {   // next K tile of this workgroup's sequence
     u_c0 += 64;
@@ -187,6 +196,12 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
 #endif
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
+      if constexpr (UP2) {
+        if (st_up) {   // wave-uniform
+          y5_bglds16(xrs2, (unsigned)(a_base2[s][jj] + st_tap_off) | (a_mask[s][jj] << 31), buf + s * HT + (wave * 2 + jj) * 1024);
+          continue;
+        }
+      }
       const unsigned voff = (unsigned)(a_base[s][jj] + st_tap_off) | ((a_mask[s][jj] >> st_tap_bit) << 31);
       y5_bglds16(xrs, voff, buf + s * HT + (wave * 2 + jj) * 1024);
     }
@@ -416,6 +431,7 @@ struct Y5G8nGeom {
   static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
+template <bool UP2>
 __global__ __launch_bounds__(512, 2)
 void y5_conv_g8n_kernel(const Y5ConvParams p) {
   typedef half_t T;
@@ -435,6 +451,7 @@ void y5_conv_g8n_kernel(const Y5ConvParams p) {
 
   const y5_rsrc_t xrs = y5_make_rsrc(p.x, p.x_bytes);
   const y5_rsrc_t wrs = y5_make_rsrc(p.w, p.w_bytes);
+  const y5_rsrc_t xrs2 = UP2 ? y5_make_rsrc(p.x2, p.x2_bytes) : xrs;
 
   float bv[Gm::MAXN / 512];
 #pragma unroll
@@ -443,6 +460,8 @@ void y5_conv_g8n_kernel(const Y5ConvParams p) {
   // ---- loaders: the activation walker (output tile a_t, chunk a_kc) and the filter walker (w_t, w_kc), the latter one K tile ahead ----
   const int lrow = lane >> 3, lslot = lane & 7;
   int a_base[2][2];
+  int a_base2[UP2 ? 2 : 1][2];
+  bool st_up = false;
   unsigned a_mask[2][2];
   unsigned w_off[2];
   int u_kh = 0, u_kw = 0, u_c0 = 0, a_t = 0, a_kc = 0, w_t = 0, w_kc = 0;
@@ -462,7 +481,8 @@ void y5_conv_g8n_kernel(const Y5ConvParams p) {
       const int rr = (wave * 2 + jj) * 8 + lrow;
       const int sslot = lslot ^ ((rr >> 1) & 7);
 #pragma unroll
-      for (int s = 0; s < 2; ++s) y5_g8_act_row(p, m0 + (rr >> 6) * 128 + s * 64 + (rr & 63), sslot, a_base[s][jj], a_mask[s][jj]);
+      for (int s = 0; s < 2; ++s)
+        y5_g8_act_row<UP2>(p, m0 + (rr >> 6) * 128 + s * 64 + (rr & 63), sslot, a_base[s][jj], a_mask[s][jj], UP2 ? &a_base2[s][jj] : nullptr);
     }
   };
   auto wgt_setup = [&](int j) __attribute__((always_inline)) {
@@ -479,6 +499,7 @@ void y5_conv_g8n_kernel(const Y5ConvParams p) {
   auto tap_update = [&]() {
     st_tap_off = ((u_kh * p.W + u_kw) * p.ldx + u_c0) * 2;
     st_tap_bit = u_kh * p.KW + u_kw;
+    if constexpr (UP2) st_up = u_c0 < p.up_c;
   };
   auto adv_act = [&]() __attribute__((always_inline)) {
     u_c0 += 64;
@@ -509,6 +530,12 @@ void y5_conv_g8n_kernel(const Y5ConvParams p) {
     constexpr int s = decltype(sc)::value;
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
+      if constexpr (UP2) {
+        if (st_up) {
+          y5_bglds16(xrs2, (unsigned)(a_base2[s][jj] + st_tap_off) | (a_mask[s][jj] << 31), buf + s * HT + (wave * 2 + jj) * 1024);
+          continue;
+        }
+      }
       const unsigned voff = (unsigned)(a_base[s][jj] + st_tap_off) | ((a_mask[s][jj] >> st_tap_bit) << 31);
       y5_bglds16(xrs, voff, buf + s * HT + (wave * 2 + jj) * 1024);
     }

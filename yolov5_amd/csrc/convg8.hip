@@ -13,10 +13,10 @@ static int launch_g8(K kern, const Y5ConvParams& p0, int max_blocks, hipStream_t
   p.tilesN = (p.Npad + Gm::BN - 1) / Gm::BN;
   p.nk = p.K / Gm::BK;
   y5_conv_set_fastdiv(p);
-  static bool attr_done = false;   // per instantiation
-  if (!attr_done) {
+  static const void* attr_done[2] = {nullptr, nullptr};   // (the <true> / <false> instantiations share this function: same pointer type)
+  if (attr_done[0] != reinterpret_cast<const void*>(kern) && attr_done[1] != reinterpret_cast<const void*>(kern)) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
+    attr_done[attr_done[0] ? 1 : 0] = reinterpret_cast<const void*>(kern);
   }
   const long long ntiles = (long long)p.tilesM * p.tilesN;
   if (ntiles <= 0 || ntiles > 0x7fffffffLL) return y5_fail(Y5_ERR_BAD_ARG, "conv: grid out of range");
@@ -30,9 +30,10 @@ static int launch_g8(K kern, const Y5ConvParams& p0, int max_blocks, hipStream_t
 int y5_launch_g8_by_cfg(const Y5ConvParams& p, int idx, int max_blocks, hipStream_t stream) {
   if (p.C1 % 64 || p.KH * p.KW > 32 || p.Kpad % 64 || p.Npad > Y5G8Geom::MAXN)
     return y5_fail(Y5_ERR_UNSUPPORTED, "conv: the 8-phase configurations need C1 % 64 == 0, Kpad % 64 == 0, KH * KW <= 32 and Npad <= 2048");
+  const bool up = p.up_c > 0;   // virtual Upsample + Concat loader (1x1 s1 layers; validated by the caller)
   switch (idx) {
-    case 0: return launch_g8<Y5G8Geom>(y5_conv_g8_kernel, p, max_blocks, stream);
-    case 1: return launch_g8<Y5G8nGeom>(y5_conv_g8n_kernel, p, max_blocks, stream);
+    case 0: return up ? launch_g8<Y5G8Geom>(y5_conv_g8_kernel<true>, p, max_blocks, stream) : launch_g8<Y5G8Geom>(y5_conv_g8_kernel<false>, p, max_blocks, stream);
+    case 1: return up ? launch_g8<Y5G8nGeom>(y5_conv_g8n_kernel<true>, p, max_blocks, stream) : launch_g8<Y5G8nGeom>(y5_conv_g8n_kernel<false>, p, max_blocks, stream);
   }
   return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown 8-phase config");
 }
