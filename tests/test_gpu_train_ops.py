@@ -307,3 +307,75 @@ def test_sppf_pool_bwd_matches_autograd_and_repeats(B, H, W, Cc, dev):
     torch.cuda.synchronize()
     assert not bool(torch.isfinite(grad[0, ..., :Cc].float()).all())
     assert bool(torch.isfinite(grad[1:, ..., :Cc].float()).all())
+
+
+@pytest.mark.parametrize("B,H,W,C1,C2,k,s,cfgs", [
+    (64, 320, 320, 32, 64, 3, 2, (31, 34, 81)),      # 1.Conv
+    (64, 160, 160, 64, 64, 1, 1, (16, 17, 85)),      # 2.C3.cv1+cv2 / cv3
+    (64, 160, 160, 32, 32, 1, 1, (14,)),             # 2.C3.m.0.cv1
+    (64, 160, 160, 32, 32, 3, 1, (30, 33, 82, 83)),  # 2.C3.m.0.cv2
+    (64, 80, 80, 128, 128, 1, 1, (19, 20, 84)),      # 4.C3.cv1+cv2 / cv3
+    (64, 80, 80, 64, 64, 3, 1, (32, 78, 79, 80)),    # 4.C3.m.*.cv2
+    (64, 80, 80, 128, 64, 1, 1, (18, 21, 86)),       # 17.C3.cv1 ...
+])
+def test_conv_fwd_stats_at_benchmarked_shapes(B, H, W, C1, C2, k, s, cfgs, dev):
+    """the BatchNorm statistics fused into the convolution epilogue (y5_conv2d_fwd_stats, Y5_BN_FUSED_STATS) had GPU coverage only
+    through the wide whole-plan bound.  Here, at the shapes and on every streaming configuration the training plan of yolov5s bs 64 uses it with: z is
+    BIT-IDENTICAL to y5_conv2d_fwd's, the per-workgroup partial rows add up to the float64 sums of that z (rtol 1e-5), and y5_bn_silu_fwd_from_partials gives
+    the mean / invstd / running statistics of the separate pass (y5_bn_silu_fwd) to 1e-5 and its y to one fp16 ulp (models/common.py:82-88 train mode)."""
+    from yolov5_amd import _lib
+    from yolov5_amd.packing import pack_conv_weight
+
+    lib = _lib.lib()
+    st = _lib.stream(dev)
+    vp = lambda t_: C.c_void_p(t_.data_ptr())
+    g = torch.Generator().manual_seed(C1 + C2 + k)
+    x = torch.randn((B, H, W, C1), generator=g).half().to(dev)
+    w = (torch.randn((C2, C1, k, k), generator=g) * (2.0 / (C1 * k * k)) ** 0.5)
+    wp, bp, K, Kpad, Npad = pack_conv_weight(w, torch.zeros(C2), torch.float16)
+    wp, bp = wp.to(dev), bp.to(dev)
+    p = k // 2
+    OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    npix = B * OH * OW
+    gamma = (torch.rand(C2, generator=g) + 0.5).to(dev)
+    beta = (torch.rand(C2, generator=g) - 0.5).to(dev)
+    ran = 0
+    for cfg in cfgs:
+        d = _lib.ConvDesc(dtype=_lib.Y5_F16, B=B, H=H, W=W, C1=C1, ldx=C1, OH=OH, OW=OW, C2=C2, ldy=C2, KH=k, KW=k, SH=s, SW=s, PH=p, PW=p, act=0,
+                          Kpad=Kpad, Npad=Npad, ldr=0, ld2=0, cfg=cfg, max_blocks=0)
+        z0 = torch.full((npix, C2), 5.0, dtype=torch.float16, device=dev)
+        if lib.y5_conv2d_fwd(C.byref(d), vp(x), vp(wp), vp(bp), None, vp(z0), None, st) != 0:
+            continue                                # configuration not built for this shape
+        z1 = torch.full((npix, C2), 5.0, dtype=torch.float16, device=dev)
+        part = torch.full((8 * 256 * 2 * C2,), float("nan"), dtype=torch.float32, device=dev)
+        rows = C.c_int(0)
+        rc = lib.y5_conv2d_fwd_stats(C.byref(d), vp(x), vp(wp), vp(bp), vp(z1), vp(part), part.numel() * 4, C.byref(rows), st)
+        assert rc == 0, lib.y5_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(z0, z1), cfg
+        pr = part[: rows.value * 2 * C2].view(rows.value, 2, C2).double()
+        zf = z1.double()
+        torch.testing.assert_close(pr[:, 0].sum(0), zf.sum(0), rtol=1e-5, atol=1e-2)
+        torch.testing.assert_close(pr[:, 1].sum(0), (zf * zf).sum(0), rtol=1e-5, atol=1e-2)
+        outs = []
+        for fused in (False, True):
+            rm, rv = torch.zeros(C2, device=dev), torch.ones(C2, device=dev)
+            sm, si = torch.empty(C2, device=dev), torch.empty(C2, device=dev)
+            y = torch.full((npix, C2), -7.0, dtype=torch.float16, device=dev)
+            if fused:
+                rc = lib.y5_bn_silu_fwd_from_partials(vp(z1), _lib.Y5_F16, npix, C2, C2, vp(gamma), vp(beta), 1e-3, 0.03, vp(rm), vp(rv), vp(sm), vp(si),
+                                                      vp(part), rows.value, None, 0, vp(y), C2, st)
+            else:
+                nws = lib.y5_bn_workspace_bytes(C2, npix)
+                ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+                rc = lib.y5_bn_silu_fwd(vp(z1), _lib.Y5_F16, npix, C2, C2, vp(gamma), vp(beta), 1e-3, 0.03, vp(rm), vp(rv), vp(sm), vp(si), None, 0,
+                                        vp(y), C2, vp(ws), nws, st)
+            assert rc == 0, lib.y5_last_error()
+            torch.cuda.synchronize()
+            outs.append((sm, si, rm, rv, y.float()))
+        for u, v in zip(outs[0][:4], outs[1][:4]):
+            torch.testing.assert_close(u, v, rtol=1e-5, atol=1e-6)
+        dy = (outs[0][4] - outs[1][4]).abs()
+        assert float((dy / (outs[0][4].abs() * 2.0 ** -10 + 2.0 ** -14)).max()) <= 1.0, cfg   # one fp16 ulp where the statistics differ in their last bit
+        ran += 1
+    assert ran >= 1

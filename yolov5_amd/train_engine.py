@@ -89,6 +89,7 @@ class TrainEngine:
         self._dw_total = 0
         self._keep = []
         self.grad_sink = None   # HipDDP (torch_utils.py): receives every parameter gradient as soon as it is queued
+        self.debug_hook = None  # tests only: hook(kind, st, info) behind every weight- / data-gradient launch of the backward plan (tests/test_gpu_train.py)
         max_z, max_ws = 0, 0
         for op in self.spec.ops:
             if op["op"] == "conv":
@@ -636,6 +637,8 @@ class TrainEngine:
         d.cfg, d.max_blocks = st["wg_choice"]
         # (deterministic: fixed-order reduction of the pixel-range splits through a workspace, csrc/wgrad.hip DET -- bit-identical gradients run to run)
         _lib.check(self._wgrad_launch(d, self._ptr(x), dz_ptr, ld_dz, dw_ptr, stm), lib)
+        if self.debug_hook is not None:
+            self.debug_hook("wgrad", st, dict(dz_ptr=dz_ptr, ld_dz=ld_dz, geom=g, choice=st["wg_choice"]))
         if self.grad_sink is not None:
             # a gradient sink (HipDDP) wants every gradient as early as possible -- but one unpack launch per LAYER was 56 extra launches per step
             # (most of the "exposed exchange" of a one-rank group, profiles/r05/r05_ddp_exchange_trace.log): the packed gradients of the layers whose
@@ -653,6 +656,8 @@ class TrainEngine:
             return
         acc = is_written(x)
         dense = tuple(op["s"]) == (1, 1)
+        if self.debug_hook is not None:
+            self.debug_hook("pre_dgrad", st, dict(dz_ptr=dz_ptr, ld_dz=ld_dz, acc=acc))
         for sub in st["subs"]:
             dd = _lib.ConvDesc(dtype=self.dt, B=B, H=y.H, W=y.W, C1=c2s, ldx=ld_dz, OH=sub["nh"], OW=sub["nw"], C2=x.C, ldy=self._ld(x),
                                KH=sub["nth"], KW=sub["ntw"], SH=1, SW=1, PH=sub["pad"][0], PW=sub["pad"][1], act=0, Kpad=sub["Kpad"],
@@ -665,6 +670,8 @@ class TrainEngine:
                 # (timing replays the launch: only safe when it does not accumulate into its own output)
                 sub["cfg"][acc] = dd.cfg = autotune_conv(lib, dd, ptrs, stm)
             _lib.check(lib.y5_conv2d_fwd(C.byref(dd), *ptrs, stm), lib)
+        if self.debug_hook is not None:
+            self.debug_hook("dgrad", st, dict(dz_ptr=dz_ptr, ld_dz=ld_dz, acc=acc, cfgs=[sub["cfg"].get(acc) for sub in st["subs"]]))
         mark(x)
 
 
