@@ -287,6 +287,11 @@ int y5_bn_silu_bwd_from_sums(const void* dy, int ld_dy, const void* z, int ldz, 
  * y5_sppf_pool_bwd   -- backward of SPPF's three chained max-pools (common.py:338-340) in the [x|y1|y2|y3] buffers:
  *   on entry grad holds the per-slice gradients left by cv2's data-gradient, on return grad[..., 0:C] = d/dx.  Bit-reproducible: the scatter to the
  *   window maxima accumulates on an exact 2^-24 fixed-point grid (integer LDS atomics), k <= 15, H*W <= ~1700 (LDS).
+ *   The gradients are fp16 (their magnitude is bounded by 65504: the grid holds every fp16 value exactly).  Non-finite incoming gradients (the fp16
+ *   overflow a loss scaler must see): the fixed-point form (planes <= 1371 pixels) has no Inf / NaN on its integer grid and therefore writes NaN to the WHOLE
+ *   output of the (image, channel-group) workgroup that met one; the gather form (larger planes, Y5_SPPF_BWD_GATHER) propagates Inf / NaN element by element
+ *   as fp32 addition does.  Both leave a non-finite value in d/dx, which is all `GradScaler` asks for; code that inspects WHERE must not rely on either.
+ *   Returns Y5_ERR_UNSUPPORTED when the plane does not fit the device's LDS.
  * ------------------------------------------------------------------------------------------------------- */
 int y5_nhwc_to_raw(const void* logits, void* raw, int B, int npix, int na, int no, int ld, void* stream);
 int y5_raw_to_nhwc(const void* draw, void* dlogits, int B, int npix, int na, int no, int ld, void* stream);

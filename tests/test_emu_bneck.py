@@ -270,6 +270,7 @@ def test_plan_fuses_cv3_into_the_last_128_channel_bottleneck(monkeypatch):
     monkeypatch.setenv("Y5_FUSED_CV3", "0")
     for mode in ("0", "1"):
         monkeypatch.setenv("Y5_FUSED_CV3_128", mode)
+        monkeypatch.setenv("Y5_FUSED_BNECK128", "force")   # (below the planner's workgroup-count gate at this batch)
         eng = Engine(m, (1, 3, 64, 96), torch.float16, "cpu", want_raw=False, backend=EmuBackend())
         outs[mode] = np.asarray(eng(x)["z"]).astype(np.float32).copy()
         fused = [n for n in eng.op_names if n.startswith("bneck128+cv3:")]
@@ -290,7 +291,7 @@ def test_plan_fuses_the_128_channel_bottlenecks(monkeypatch):
     x = torch.from_numpy(detgen.uniform((1, 3, 64, 96), 0.0, 1.0, name="img", seed=0)).half()
     outs, names = {}, {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("Y5_FUSED_BNECK128", mode)
+        monkeypatch.setenv("Y5_FUSED_BNECK128", "force" if mode == "1" else mode)   # (force: below the planner's workgroup-count gate at this batch)
         eng = Engine(m, (1, 3, 64, 96), torch.float16, "cpu", want_raw=False, backend=EmuBackend())
         outs[mode] = np.asarray(eng(x)["z"]).astype(np.float32).copy()
         names[mode] = list(eng.op_names)

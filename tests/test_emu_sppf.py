@@ -80,7 +80,7 @@ def test_plan_runs_sppf_front_as_one_launch(monkeypatch):
     x = torch.from_numpy(detgen.uniform((2, 3, 64, 96), 0.0, 1.0, name="img", seed=0)).half()
     outs, names = {}, {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("Y5_FUSED_SPPF", mode)
+        monkeypatch.setenv("Y5_FUSED_SPPF", "force" if mode == "1" else mode)   # (force: below the planner's workgroup-count gate at this batch)
         eng = Engine(m, (2, 3, 64, 96), torch.float16, "cpu", want_raw=False, backend=EmuBackend())
         outs[mode] = np.asarray(eng(x)["z"]).astype(np.float32).copy()
         names[mode] = list(eng.op_names)

@@ -717,7 +717,7 @@ def test_plan_bneck128_fused_equals_unfused_on_gpu(dev, monkeypatch):
     x = torch.from_numpy(detgen.uniform((8, 3, 640, 640), 0.0, 1.0, name="img", seed=1)).half().to(dev)
     outs = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("Y5_FUSED_BNECK128", mode)
+        monkeypatch.setenv("Y5_FUSED_BNECK128", "force" if mode == "1" else mode)   # (force: below the planner's workgroup-count gate at this batch)
         m = DetectionModel("yolov5s.yaml")
         m.load_state_dict(sd)
         m = m.eval().fuse().half().to(dev)
@@ -792,6 +792,7 @@ def test_plan_bneck128_cv3_fused_equals_unfused_on_gpu(dev, monkeypatch):
     outs = {}
     for mode in ("0", "1"):
         monkeypatch.setenv("Y5_FUSED_CV3_128", mode)
+        monkeypatch.setenv("Y5_FUSED_BNECK128", "force")   # (below the planner's workgroup-count gate at this batch)
         m = DetectionModel("yolov5s.yaml")
         m.load_state_dict(sd)
         m = m.eval().fuse().half().to(dev)
@@ -845,7 +846,7 @@ def test_plan_sppf_front_fused_equals_unfused_on_gpu(dev, monkeypatch):
     x = torch.from_numpy(detgen.uniform((8, 3, 640, 640), 0.0, 1.0, name="img", seed=1)).half().to(dev)
     outs = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("Y5_FUSED_SPPF", mode)
+        monkeypatch.setenv("Y5_FUSED_SPPF", "force" if mode == "1" else mode)   # (force: below the planner's workgroup-count gate at this batch)
         m = DetectionModel("yolov5s.yaml")
         m.load_state_dict(sd)
         m = m.eval().fuse().half().to(dev)

@@ -49,20 +49,23 @@ extern "C" const char* y5_last_error(void) { return g_err.c_str(); }
 // on the process group's stream) runs BESIDE the backward plan; with every CU held by a persistent workgroup for the whole life of each launch the
 // collective's workgroups only get in at kernel boundaries (measured through a one-rank group: 28.9 MB exposed for 0.73 ms, profiles/r04).  A budget
 // of CUs - r leaves r CUs' worth of workgroup slots to the collective (utils/torch_utils.py:61-70 smart_DDP; yolov5_amd.torch_utils.HipDDP sets it).
-namespace { int g_cu_budget = 0, g_cu_dev = 0; }
+namespace { int g_cu_budget = 0; }
 extern "C" int y5_set_cu_budget(int n_cus) {
   if (n_cus < 0) return y5_fail(Y5_ERR_BAD_ARG, "set_cu_budget: negative");
   g_cu_budget = n_cus;   // 0 = every CU of the device
   return Y5_OK;
 }
 int y5_num_cu() {
-  if (!g_cu_dev) {
-    int dev = 0, n = 0;
-    hipGetDevice(&dev);
+  static int cu_of_dev[64] = {};   // per device (the count of the first device queried was served for all)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!cu_of_dev[dev]) {
+    int n = 0;
     hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    g_cu_dev = n > 0 ? n : 256;
+    cu_of_dev[dev] = n > 0 ? n : 256;
   }
-  return g_cu_budget > 0 && g_cu_budget < g_cu_dev ? g_cu_budget : g_cu_dev;
+  const int n = cu_of_dev[dev];
+  return g_cu_budget > 0 && g_cu_budget < n ? g_cu_budget : n;
 }
 
 // ---------------------------------------------------------------------------------------------------

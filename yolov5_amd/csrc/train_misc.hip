@@ -434,6 +434,13 @@ extern "C" int y5_sppf_pool_bwd(const void* act, void* grad, int B, int H, int W
   if ((force_gv == 2 || force_gv == 4) && C % (8 * force_gv) == 0 && hw * force_gv * per <= kMax) gv = force_gv;
   if (force_gv == 1) gv = 1;
   const size_t lds = hw * gv * per;
+#ifndef Y5_EMU
+  {   //  the plane sizes above assume the 160 KiB LDS of gfx950: ask the device instead of launching what cannot start
+    int dev = 0, cap = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cap, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && cap > 0 && lds > (size_t)cap)
+      return y5_fail(Y5_ERR_UNSUPPORTED, "sppf_pool_bwd: H*W plane does not fit in this device's LDS");
+  }
+#endif
   static bool a = false;
   if (!a) {
     hipFuncSetAttribute((const void*)y5_sppf_pool_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);

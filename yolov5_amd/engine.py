@@ -133,6 +133,10 @@ class _Planner:
                 or (c_ == 128 and os.environ.get("Y5_FUSED_BNECK128", "1") != "0"))
         if not self.fuse_bneck or not ok_c or (c_ != 128 and (x.H % 4 or x.W % 8)) or not len(m.m):
             return False
+        #  conv_h3b.h runs ONE workgroup per CU on 10 x 20 output tiles and was measured at bs 64 only: with fewer tiles than half the CUs of an
+        # MI355X (small batches) the two-launch form, whose kernels the tuner picks per shape, is kept -- Y5_FUSED_BNECK128 = force overrides
+        if c_ == 128 and os.environ.get("Y5_FUSED_BNECK128", "1") != "force" and self.spec.B * (-(-x.H // 10)) * (-(-x.W // 20)) < 128:
+            return False
         for b in m.m:
             c1, c2 = b.cv1.conv, b.cv2.conv
             if not (c1.in_channels == c1.out_channels == c2.in_channels == c2.out_channels == c_ and _pair(c1.kernel_size) == (1, 1)
@@ -173,7 +177,9 @@ class _Planner:
         cv1 = m.cv1.conv
         # fp16 inference plans (round 5): cv1 + the three pools as ONE launch (csrc/conv_sppf.h: a workgroup owns an image's H x W pixels for 64 output
         # channels and pools its own GEMM result in LDS) -- Y5_FUSED_SPPF = 0 keeps cv1 and y5_sppf_pool apart
-        if (self.fuse_bneck and os.environ.get("Y5_FUSED_SPPF", "1") != "0" and x.H * x.W <= 416 and c_ % 64 == 0 and cv1.in_channels % 32 == 0
+        #  the fused launch has B x c_ / 64 workgroups (4 at batch 1 for yolov5s): below 64 the two-launch form is kept -- Y5_FUSED_SPPF = force overrides
+        enough = self.spec.B * (c_ // 64) >= 64 or os.environ.get("Y5_FUSED_SPPF", "1") == "force"
+        if (self.fuse_bneck and os.environ.get("Y5_FUSED_SPPF", "1") != "0" and enough and x.H * x.W <= 416 and c_ % 64 == 0 and cv1.in_channels % 32 == 0
                 and _pair(cv1.kernel_size) == (1, 1) and _pair(cv1.stride) == (1, 1) and _pair(cv1.padding) == (0, 0) and k % 2 == 1):
             self.spec.ops.append(dict(op="sppf_front", x=x, y=_slice(cat, 0, c_), buf=cat, C=c_, k=k, name=name + ".cv1+pool",
                                       cv1=self.conv([m.cv1], x, _slice(cat, 0, c_), name=name + ".cv1", emit=False)))

@@ -120,8 +120,6 @@ class HipDDP(nn.Module):
             sync = self.avg_in_collective and (mode == "all" or (mode == "last" and b is self.buckets[-1]))
             w = dist.all_reduce(self._flat[b.lo:b.hi], op=op, group=self.pg, async_op=not sync)
             b.work = None if sync else w
-            if sync and not self.avg_in_collective:
-                self._flat[b.lo:b.hi].div_(self.world)
         b.pending = -1
 
     def bucket_of(self, idx):
@@ -135,6 +133,11 @@ class HipDDP(nn.Module):
         b.pending -= 1
         if b.pending == 0:
             self._launch(b)
+
+    def abort(self):
+        """The backward plan raised (out of memory, kernel error, skipped step): give the reserved CUs back -- the budget is process-global."""
+        if self.reserve_cus > 0 and self._eng is not None:
+            _state.set_cu_budget(self._eng.lib, 0)
 
     def finish(self, grads):
         """All kernels of the backward plan are queued: launch stragglers, wait for the wire, average."""

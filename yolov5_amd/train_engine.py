@@ -123,7 +123,10 @@ class TrainEngine:
         # BatchNorm statistics from the convolution's epilogue (y5_conv2d_fwd_stats: one partial row per workgroup, <= 8 workgroups per CU x 256 channels);
         # Y5_BN_FUSED_STATS=0 keeps the separate statistics pass everywhere
         self.fused_stats = self.dtype == torch.float16 and os.environ.get("Y5_BN_FUSED_STATS", "1") != "0"
-        self.stats_ws_bytes = 8 * 256 * 8 * 2 * 256 * 4 // 8
+        ncu = 256
+        if getattr(self.be, "device", None) is not None and torch.cuda.is_available():
+            ncu = max(256, torch.cuda.get_device_properties(self.be.device).multi_processor_count)
+        self.stats_ws_bytes = ncu * 8 * 2 * 256 * 4   # one [2][<= 256 channels] fp32 row per workgroup, <= 8 workgroups per CU
         self.stats_ws = self.be.empty((self.stats_ws_bytes,), torch.uint8) if self.fused_stats else None
 
     # ---- helpers ---------------------------------------------------------------------------------------------------
@@ -357,8 +360,10 @@ class TrainEngine:
                 rc = lib.y5_conv2d_fwd_stats(C.byref(d), ptrs[0], ptrs[1], ptrs[2], ptrs[4], _vp(be.ptr(self.stats_ws)), self.stats_ws_bytes, C.byref(rows), stm)
                 if os.environ.get("Y5_STATS_DEBUG") == "1" and "stats_ok" not in st:
                     print(f"[stats] {op['name']:16s} cfg {d.cfg:3d} {'fused' if rc == 0 else 'separate pass'}  z {B * y.H * y.W * c2 * 2 / 1e6:.0f} MB", flush=True)
-                if rc == _lib.Y5_ERR_UNSUPPORTED:
-                    st["stats_ok"] = False   # this layer's configuration is not a streaming kernel: separate pass, decided once
+                if rc in (_lib.Y5_ERR_UNSUPPORTED, _lib.Y5_ERR_WORKSPACE):
+                    # this layer's configuration is not a streaming kernel -- or its grid leaves more partial rows than the workspace holds (a part with
+                    # more CUs / occupancy than it was sized for): separate pass, decided once
+                    st["stats_ok"] = False
                 else:
                     _lib.check(rc, lib)
                     st["stats_ok"], stats_rows = True, rows.value
@@ -467,6 +472,15 @@ class TrainEngine:
         sink = self.grad_sink
         if sink is not None:
             sink.begin(self)
+        try:
+            return self._backward_plan(dps, stm, is_written, mark, sink)
+        except BaseException:
+            if sink is not None:
+                sink.abort()   # (a reserved CU budget must not outlive a failed backward: ADVICE r5)
+            raise
+
+    def _backward_plan(self, dps, stm, is_written, mark, sink):
+        lib, be, B = self.lib, self.be, self.spec.B
         params = self.params
         _lib.check(lib.y5_memset_zero(_vp(be.ptr(self.dwflat)), self._dw_total * 4, stm), lib)  # every conv's dW accumulator at once
         self._run_jobs(1, stm)  # every data-gradient sub-filter, one launch
@@ -666,9 +680,20 @@ class TrainEngine:
                                out_off_w=sub["rw"], out_H=0 if dense else x.H, out_W=0 if dense else x.W)
             gx = _vp(self._ptr(x, True))
             ptrs = (_vp(dz_ptr), _vp(be.ptr(sub["w"])), _vp(be.ptr(st["zb"])), gx if acc else None, gx, None)
-            if acc not in sub["cfg"] and getattr(be, "autotune", False) and not acc:
-                # (timing replays the launch: only safe when it does not accumulate into its own output)
-                sub["cfg"][acc] = dd.cfg = autotune_conv(lib, dd, ptrs, stm)
+            if acc not in sub["cfg"] and getattr(be, "autotune", False):
+                if not acc:
+                    sub["cfg"][acc] = dd.cfg = autotune_conv(lib, dd, ptrs, stm)
+                else:
+                    # Timing replays the launch, and this one ACCUMULATES into its output: until round 6 such launches (every input with a second reader:
+                    # C3's shared input, the stride-2 parity classes after the first ...) ran the untuned default tile.  The race is run on the
+                    # non-accumulating form of the same launch (no residual read) with the gradient buffer saved and restored around it -- once per plan.
+                    gt = be.view_torch(self.gbufs[x.buf])
+                    keep = gt.clone()
+                    dn = _lib.ConvDesc.from_buffer_copy(dd)
+                    dn.ldr, dn.cfg = 0, -1
+                    sub["cfg"][acc] = dd.cfg = autotune_conv(lib, dn, (ptrs[0], ptrs[1], ptrs[2], None, ptrs[4], None), stm)
+                    gt.copy_(keep)
+                    del keep
             _lib.check(lib.y5_conv2d_fwd(C.byref(dd), *ptrs, stm), lib)
         if self.debug_hook is not None:
             self.debug_hook("dgrad", st, dict(dz_ptr=dz_ptr, ld_dz=ld_dz, acc=acc, cfgs=[sub["cfg"].get(acc) for sub in st["subs"]]))
