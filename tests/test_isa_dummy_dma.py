@@ -56,3 +56,26 @@ def test_sppf_front_ring_keeps_its_dummy_loads(tmp_path):
 def test_headk_ring_keeps_its_dummy_loads(tmp_path):
     counts = _lds_dma_counts(tmp_path, "head.hip", r"^(_Z\w*y5_conv_headk_kernel\w*):")
     assert len(counts) == 2 and all(v == 32 for v in counts.values()), counts
+
+
+@pytest.mark.parametrize("unit", ["convg8.hip", "convh3.hip", "bneck.hip", "head.hip", "sppf.hip"])
+def test_lds_dma_counts_of_the_counted_wait_kernels_are_pinned(unit):
+    """every kernel family that retires LDS-DMA with counted waits -- the 8-phase implicit GEMM (conv_g8.h: prologue 14 + loop 8 = 22 per
+    instantiation without the virtual-upsample loader), the halo-resident 3x3 and the K-streamed pointwise kernel (conv_h3.h, conv_pwk.h), the fused Bottlenecks
+    (conv_h3b.h with its 9-stage ring, W1 streamed into ring stages and the next tile's halo into dead planes; conv_bneck.h), the fused heads and the SPPF front --
+    has the LDS-DMA instruction count of EACH instantiation pinned in tests/golden/isa_lds_dma_counts.json (scripts/isa_counts.py --write regenerates it, for a
+    deliberate change of a kernel's staging only).  A merged dummy load, a dropped stage or a duplicated one changes a count.  (conv_igemm.h's hundred
+    instantiations take minutes to compile and are covered by the source scan above and the emulator's worst-case landing model.)"""
+    import json
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import isa_counts
+
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    want = json.load(open(isa_counts.GOLDEN))[unit]
+    got = isa_counts.counts_of(unit)
+    assert got == want, {k: (got.get(k), want.get(k)) for k in set(got) | set(want) if got.get(k) != want.get(k)}
+    if unit == "convg8.hip":
+        assert got["_Z17y5_conv_g8_kernelILb0EEv12Y5ConvParams"] == 22 and got["_Z18y5_conv_g8n_kernelILb0EEv12Y5ConvParams"] == 20
