@@ -176,19 +176,38 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
     st_kcb = (unsigned)(s_kc * 128);
     if constexpr (UP2) st_up = u_c0 < p.up_c;   // (1x1 layer: st_tap_off is the chunk's channel offset; up_c % 64 == 0, a chunk never straddles the boundary)
   };
-  auto advance = [&]() __attribute__((always_inline)) {   // next K tile of this workgroup's sequence
+  // The loader's step to the next K tile in two halves (round 6, after the phase stamps): the SCALAR walker runs in q4, the phase with the shortest load segment
+  // (two LDS-DMA instructions and the counted wait), and leaves the next K tile's offsets in nx_*; q1 -- the longest segment: twelve fragment reads -- only
+  // commits them behind its own staging (and re-derives the per-lane rows when the sequence enters the next output tile).
+  int nx_tap_off = 0, nx_tap_bit = 0;
+  unsigned nx_kcb = 0;
+  bool nx_up = false, nx_new = false;
+  auto advance_scalar = [&]() __attribute__((always_inline)) {
     u_c0 += 64;
     if (u_c0 >= p.C1) {
       u_c0 = 0;
       if (++u_kw == p.KW) { u_kw = 0; ++u_kh; }
     }
+    nx_new = false;
     if (++s_kc == nk) {
       s_kc = 0; u_kh = 0; u_kw = 0; u_c0 = 0;
-      if (++s_t < nmine) loader_setup(s_t);
+      ++s_t;
+      nx_new = true;
+    }
+    nx_tap_off = ((u_kh * p.W + u_kw) * p.ldx + u_c0) * 2;
+    nx_tap_bit = u_kh * p.KW + u_kw;
+    nx_kcb = (unsigned)(s_kc * 128);
+    if constexpr (UP2) nx_up = u_c0 < p.up_c;
+  };
+  auto advance_commit = [&]() __attribute__((always_inline)) {
+    if (nx_new) {
+      if (s_t < nmine) loader_setup(s_t);
       else loader_kill();
     }
-    tap_update();
+    st_tap_off = nx_tap_off; st_tap_bit = nx_tap_bit; st_kcb = nx_kcb;
+    if constexpr (UP2) st_up = nx_up;
   };
+  auto advance = [&]() __attribute__((always_inline)) { advance_scalar(); advance_commit(); };   // (prologue)
   auto stage_act = [&](auto sc, char* buf) __attribute__((always_inline)) {
     constexpr int s = decltype(sc)::value;
 #ifdef Y5_G8_ABL_NODMA
@@ -280,7 +299,8 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
   T* yg = static_cast<T*>(p.y);   // may alias p.res
   const T* rg = static_cast<const T*>(p.res);
   T* y2g = static_cast<T*>(p.y2);
-  auto epilogue = [&](int j) __attribute__((always_inline)) {
+  auto epilogue = [&](int j, auto actc) __attribute__((always_inline)) {
+    constexpr bool ACT = decltype(actc)::value;   // (a per-element select on the runtime flag cost one more VALU per element)
     int m0, n0;
     tile_coords(j, m0, n0);
 #pragma unroll
@@ -297,7 +317,7 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const float t = acc[f][c][h * 8 + e] + (e < 4 ? b0[e] : b1[e - 4]);
-            v[e] = p.act ? y5_silu(t) : t;
+            v[e] = ACT ? y5_silu(t) : t;
           }
           uint4_t raw;
 #pragma unroll
@@ -326,6 +346,7 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
   stage_wgt(I0{}, smem + BUF); stage_act(I0{}, smem + BUF); stage_wgt(I1{}, smem + BUF);
 #pragma unroll
   for (int q = 0; q < Gm::MAXN / 512; ++q) blds[tid + q * 512] = bv[q];
+  advance_scalar();                            // K tile 2's offsets: the first q1 commits them
   y5_wait_vm<3 * Gm::LPH>();
   __builtin_amdgcn_s_waitcnt(0xC07F);          // the bias table is written before the barrier that publishes it
   __builtin_amdgcn_s_barrier();
@@ -356,7 +377,7 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
 #endif
       rd_act(I0{}, cur);
       stage_act(I1{}, oth);          // Act-h1 of K tile t+1
-      advance();                     // the loader moves on to K tile t+2
+      advance_commit();              // the loader moves on to K tile t+2 (its scalars were computed in the previous q4)
       __builtin_amdgcn_s_waitcnt(0xC87F);   // lgkmcnt(8): the four filter reads have returned -- q2 restages Wgt-h0
       __builtin_amdgcn_s_barrier();
       lgkm0();
@@ -381,6 +402,7 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
 #endif
       // q4
       stage_wgt(I1{}, cur);          // Wgt-h1 of K tile t+2
+      advance_scalar();              // K tile t+3's offsets, committed in the next q1
       y5_wait_vm<3 * Gm::LPH>();     // everything but the three youngest half-tiles has landed: K tile t+1 is complete
       __builtin_amdgcn_s_barrier();
       mma(I1{}, I0{});
@@ -397,7 +419,8 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
 #ifndef Y5_G8_SERIAL_EPILOGUE
     if (wr == 0) __builtin_amdgcn_s_barrier();
 #endif
-    epilogue(ti);
+    if (p.act) epilogue(ti, std::true_type{});
+    else epilogue(ti, std::false_type{});
 #ifndef Y5_G8_SERIAL_EPILOGUE
     if (wr == 1 && ti + 1 < nmine) __builtin_amdgcn_s_barrier();
 #endif
@@ -584,7 +607,8 @@ void y5_conv_g8n_kernel(const Y5ConvParams p) {
   T* yg = static_cast<T*>(p.y);
   const T* rg = static_cast<const T*>(p.res);
   T* y2g = static_cast<T*>(p.y2);
-  auto epilogue = [&](int j) __attribute__((always_inline)) {
+  auto epilogue = [&](int j, auto actc) __attribute__((always_inline)) {
+    constexpr bool ACT = decltype(actc)::value;
     int m0, n0;
     tile_coords(j, m0, n0);
 #pragma unroll
@@ -599,7 +623,7 @@ void y5_conv_g8n_kernel(const Y5ConvParams p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float t = acc[f][h * 8 + e] + (e < 4 ? b0[e] : b1[e - 4]);
-          v[e] = p.act ? y5_silu(t) : t;
+          v[e] = ACT ? y5_silu(t) : t;
         }
         uint4_t raw;
 #pragma unroll
@@ -668,7 +692,8 @@ void y5_conv_g8n_kernel(const Y5ConvParams p) {
       char* const b = b_cur; b_cur = b_nx1; b_nx1 = b_nx2; b_nx2 = b;
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();   // (tile boundary: see y5_conv_g8_kernel)
-    epilogue(ti);
+    if (p.act) epilogue(ti, std::true_type{});
+    else epilogue(ti, std::false_type{});
     if (wr == 1 && ti + 1 < nmine) __builtin_amdgcn_s_barrier();
   }
   Y5_DRAIN_VM();
