@@ -41,6 +41,9 @@ class _TrainPlanner(_Planner):
         return self.conv([m.cv3], cat, dest, up2=up2, name=name + ".cv3")
 
 
+NO_RESIDUAL_CFGS = frozenset(list(range(14, 22)) + [56] + list(range(84, 88)) + [93, 94])   # conv.hip: configurations without a residual / accumulate path
+
+
 def _vp(v):
     return C.c_void_p(v)
 
@@ -691,10 +694,15 @@ class TrainEngine:
                     keep = gt.clone()
                     dn = _lib.ConvDesc.from_buffer_copy(dd)
                     dn.ldr, dn.cfg = 0, -1
-                    sub["cfg"][acc] = dd.cfg = autotune_conv(lib, dn, (ptrs[0], ptrs[1], ptrs[2], None, ptrs[4], None), stm)
+                    # (the streaming pointwise families 14-21 / 56 / 84-87 and the K-streamed 93 / 94 have no residual path: out of this race)
+                    sub["cfg"][acc] = dd.cfg = autotune_conv(lib, dn, (ptrs[0], ptrs[1], ptrs[2], None, ptrs[4], None), stm, exclude=NO_RESIDUAL_CFGS)
                     gt.copy_(keep)
                     del keep
-            _lib.check(lib.y5_conv2d_fwd(C.byref(dd), *ptrs, stm), lib)
+            rc = lib.y5_conv2d_fwd(C.byref(dd), *ptrs, stm)
+            if rc == _lib.Y5_ERR_UNSUPPORTED and acc and dd.cfg >= 0:   # a configuration chosen on the non-accumulating form that refuses the residual: default tile
+                sub["cfg"][acc] = dd.cfg = -1
+                rc = lib.y5_conv2d_fwd(C.byref(dd), *ptrs, stm)
+            _lib.check(rc, lib)
         if self.debug_hook is not None:
             self.debug_hook("dgrad", st, dict(dz_ptr=dz_ptr, ld_dz=ld_dz, acc=acc, cfgs=[sub["cfg"].get(acc) for sub in st["subs"]]))
         mark(x)
