@@ -829,10 +829,6 @@ def main():
 
     from yolov5_amd.general import non_max_suppression
 
-    if not emu and os.environ.get("Y5_BENCH_RESERVE_CUS", "0") not in ("", "0"):
-        # experiment switch (round 6): the plan's persistent grids leave this many CUs free for the NMS chain on the pipeline's side stream
-        from yolov5_amd import _lib as _l, _state as _st
-        _st.set_cu_budget(_l.lib(), torch.cuda.get_device_properties(dev).multi_processor_count - int(os.environ["Y5_BENCH_RESERVE_CUS"]))
     model = build_model(a.model, dev)
     model._bench_name = a.model
     model.model[-1].export = True  # AutoShape mode: return (z,) only (models/common.py:866)

@@ -18,9 +18,9 @@ os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 for r in (sys.argv[1:] or ["0", "8", "16", "32", "64", "0", "16"]):
     if r.startswith("dry"):      # bookkeeping without the collective calls
-        os.environ["Y5_DDP_DRY"], r = "1", r[3:] or "0"
+        os.environ["Y5_EXPERIMENTAL"], r = "ddp_dry", r[3:] or "0"
     else:
-        os.environ["Y5_DDP_DRY"] = "0"
+        os.environ["Y5_EXPERIMENTAL"] = ""
     os.environ["Y5_DDP_SYNC"] = "last"
     for m in ("all", "none", "last"):
         if r.startswith(m):
@@ -31,5 +31,5 @@ for r in (sys.argv[1:] or ["0", "8", "16", "32", "64", "0", "16"]):
         os.environ["Y5_DDP_BUCKET_MB"] = "6"
     os.environ["Y5_DDP_RESERVE_CUS"] = r
     ex = bench.train_probe("yolov5s", 64, 640, dev, 1, steps=20, warmup=5, exchange_group=True)
-    print(f"dry={os.environ['Y5_DDP_DRY']} sync={os.environ['Y5_DDP_SYNC']} reserve {r} CUs: buckets {ex['allreduce_buckets']}  step {ex['step_ms']['median']:.3f} ms  exposed {1e3 * (ex['step_ms']['median'] - plain['step_ms']['median']):.0f} us", flush=True)
+    print(f"dry={os.environ['Y5_EXPERIMENTAL']} sync={os.environ['Y5_DDP_SYNC']} reserve {r} CUs: buckets {ex['allreduce_buckets']}  step {ex['step_ms']['median']:.3f} ms  exposed {1e3 * (ex['step_ms']['median'] - plain['step_ms']['median']):.0f} us", flush=True)
 dist.destroy_process_group()

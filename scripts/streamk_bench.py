@@ -1,7 +1,7 @@
 """Stream-K configurations (57..60) vs the best plain configuration on the deep-layer shapes of yolov5s bs=64: correctness (vs the plain
 result) and time per launch."""
 import ctypes as C, os, sys
-os.environ["Y5_STREAMK"] = "1"
+os.environ["Y5_EXPERIMENTAL"] = "streamk"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from yolov5_amd import _lib

@@ -257,7 +257,7 @@ def test_plan_fuses_cv3_into_the_last_bottleneck(monkeypatch):
 
 
 def test_plan_fuses_cv3_into_the_last_128_channel_bottleneck(monkeypatch):
-    """yolov5s 6 / 13 / 20.C3 (c_ = 128): the C3 tail (last Bottleneck + cv3) as one conv_h3b.h launch (Y5_FUSED_CV3_128=1) against the plan with cv3 as
+    """yolov5s 6 / 13 / 20.C3 (c_ = 128): the C3 tail (last Bottleneck + cv3) as one conv_h3b.h launch (Y5_EXPERIMENTAL=cv3_128) against the plan with cv3 as
     its own launch, on the emulator (1 x 3 x 64 x 96: 8 x 12, 4 x 6 and 2 x 3 images)."""
     from oracle import detgen
     from tests.hipemu.backend import EmuBackend
@@ -269,7 +269,7 @@ def test_plan_fuses_cv3_into_the_last_128_channel_bottleneck(monkeypatch):
     outs = {}
     monkeypatch.setenv("Y5_FUSED_CV3", "0")
     for mode in ("0", "1"):
-        monkeypatch.setenv("Y5_FUSED_CV3_128", mode)
+        monkeypatch.setenv("Y5_EXPERIMENTAL", "cv3_128" if mode == "1" else "")
         monkeypatch.setenv("Y5_FUSED_BNECK128", "force")   # (below the planner's workgroup-count gate at this batch)
         eng = Engine(m, (1, 3, 64, 96), torch.float16, "cpu", want_raw=False, backend=EmuBackend())
         outs[mode] = np.asarray(eng(x)["z"]).astype(np.float32).copy()

@@ -76,9 +76,9 @@ def test_head_side_branch_schedule(monkeypatch):
     the op that completes their input and are marked for the plan's side stream; same ops, same results as the single-stream order."""
     for name, M in (("yolov5n", DetectionModel), ("yolov5n-seg", SegmentationModel)):
         m = det_model(name, 0, True)
-        monkeypatch.setenv("Y5_HEAD_BRANCH", "0")
+        monkeypatch.setenv("Y5_EXPERIMENTAL", "")
         flat = build_plan_spec(m, 2, 3, 64, 64)
-        monkeypatch.setenv("Y5_HEAD_BRANCH", "1")
+        monkeypatch.setenv("Y5_EXPERIMENTAL", "head_branch")
         br = build_plan_spec(m, 2, 3, 64, 64)
         key = lambda o: (o["op"], o.get("name"), o.get("level"))  # noqa: E731
         assert sorted(map(key, flat.ops), key=str) == sorted(map(key, br.ops), key=str)
@@ -105,6 +105,7 @@ def test_fused_bottleneck_plan_same_outputs(monkeypatch):
     monkeypatch.setenv("Y5_FUSED_BNECK", "0")
     plain = Engine(m, (2, 3, 64, 64), torch.float16, "cpu", want_raw=True, backend=EmuBackend())
     monkeypatch.setenv("Y5_FUSED_BNECK", "1")
+    monkeypatch.setenv("Y5_FUSED_BNECK128", "force")   # (the c_ = 128 form is gated on its workgroup count: below the gate at this batch)
     fused = Engine(m, (2, 3, 64, 64), torch.float16, "cpu", want_raw=True, backend=EmuBackend())
     kinds = [o["op"] for o in fused.spec.ops]
     # 4.C3.m0 / m1, 17.C3.m0 (c_ = 32) and -- round 5 -- 8.C3.m0, 23.C3.m0 (c_ = 128: conv_h3b.h, here on 2 x 2 images)
@@ -123,9 +124,9 @@ def test_virtual_upsample_concat_plan_same_outputs(monkeypatch):
     materialises the replica (another tile configuration, hence another fp32 summation order: a few fp16 ulps), and one replicated store less."""
     m = det_model("yolov5s", 0, True).half()
     x = torch.from_numpy(detgen.uniform((2, 3, 64, 64), 0.0, 1.0, name="img", seed=0)).half()
-    monkeypatch.setenv("Y5_VIRTUAL_UP", "0")
+    monkeypatch.setenv("Y5_DISABLE", "virtual_up")
     plain = Engine(m, (2, 3, 64, 64), torch.float16, "cpu", want_raw=True, backend=EmuBackend())
-    monkeypatch.setenv("Y5_VIRTUAL_UP", "1")
+    monkeypatch.setenv("Y5_DISABLE", "")
     virt = Engine(m, (2, 3, 64, 64), torch.float16, "cpu", want_raw=True, backend=EmuBackend())
     ups = [o["name"] for o in virt.spec.ops if o.get("op") == "conv" and o.get("x_up") is not None]
     assert ups == ["13.C3.cv1+cv2", "17.C3.cv1+cv2"] and not any(o.get("x_up") for o in plain.spec.ops if o.get("op") == "conv")

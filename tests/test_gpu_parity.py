@@ -495,7 +495,7 @@ def test_autoshape_pipeline(dev):
 
 
 def test_split_engine_matches_single_plan(dev):
-    """engine.SplitEngine (two sub-batch plans on two streams, opt-in Y5_SPLIT=2): same function of the input as one plan."""
+    """engine.SplitEngine (two sub-batch plans on two streams, opt-in Y5_EXPERIMENTAL=split2): same function of the input as one plan."""
     from yolov5_amd.engine import Engine, SplitEngine
 
     m = _det_model("yolov5n", 2).fuse().half().to(dev)
@@ -782,7 +782,7 @@ def test_fused_bottleneck_cv3_c128_matches_torch(B, H, W, add, c3, ldx, ld2, ldo
 
 
 def test_plan_bneck128_cv3_fused_equals_unfused_on_gpu(dev, monkeypatch):
-    """yolov5s 8 x 3 x 640 x 640 fp16: the C3 tails of layers 6 / 13 / 20 (last Bottleneck + cv3) as one conv_h3b.h launch each (Y5_FUSED_CV3_128=1) against
+    """yolov5s 8 x 3 x 640 x 640 fp16: the C3 tails of layers 6 / 13 / 20 (last Bottleneck + cv3) as one conv_h3b.h launch each (Y5_EXPERIMENTAL=cv3_128) against
     the plan that keeps cv3 its own launch."""
     from yolov5_amd.yolo import DetectionModel
 
@@ -791,7 +791,7 @@ def test_plan_bneck128_cv3_fused_equals_unfused_on_gpu(dev, monkeypatch):
     x = torch.from_numpy(detgen.uniform((8, 3, 640, 640), 0.0, 1.0, name="img", seed=1)).half().to(dev)
     outs = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("Y5_FUSED_CV3_128", mode)
+        monkeypatch.setenv("Y5_EXPERIMENTAL", "cv3_128" if mode == "1" else "")
         monkeypatch.setenv("Y5_FUSED_BNECK128", "force")   # (below the planner's workgroup-count gate at this batch)
         m = DetectionModel("yolov5s.yaml")
         m.load_state_dict(sd)

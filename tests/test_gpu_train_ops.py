@@ -319,7 +319,7 @@ def test_sppf_pool_bwd_matches_autograd_and_repeats(B, H, W, Cc, dev):
     (64, 80, 80, 128, 64, 1, 1, (18, 21, 86)),       # 17.C3.cv1 ...
 ])
 def test_conv_fwd_stats_at_benchmarked_shapes(B, H, W, C1, C2, k, s, cfgs, dev):
-    """the BatchNorm statistics fused into the convolution epilogue (y5_conv2d_fwd_stats, Y5_BN_FUSED_STATS) had GPU coverage only
+    """the BatchNorm statistics fused into the convolution epilogue (y5_conv2d_fwd_stats; off-switch Y5_DISABLE=bn_fused_stats) had GPU coverage only
     through the wide whole-plan bound.  Here, at the shapes and on every streaming configuration the training plan of yolov5s bs 64 uses it with: z is
     BIT-IDENTICAL to y5_conv2d_fwd's, the per-workgroup partial rows add up to the float64 sums of that z (rtol 1e-5), and y5_bn_silu_fwd_from_partials gives
     the mean / invstd / running statistics of the separate pass (y5_bn_silu_fwd) to 1e-5 and its y to one fp16 ulp (models/common.py:82-88 train mode)."""

@@ -9,6 +9,22 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+def _tokens(var):
+    return {t.strip() for t in os.environ.get(var, "").split(",") if t.strip()}
+
+
+def experimental(name):
+    """Opt-in forms that were built, are parity-tested and LOST their A/B (or are measurement aids): `Y5_EXPERIMENTAL=<comma list>` -- streamk, cv3_128,
+    head_branch, split2, h3_s2 (tuner candidates: the stride-2 halo ids), ddp_dry, stats_debug.  Read at call time."""
+    return name in _tokens("Y5_EXPERIMENTAL")
+
+
+def disabled(name):
+    """Off-switches of shipped features, for A/B runs: `Y5_DISABLE=<comma list>` -- raw_view, train_stem, stem, fresh_outputs, obj_hint, virtual_up,
+    head_deep, pipe_overlap, bn_fused_stats.  Read at call time."""
+    return name in _tokens("Y5_DISABLE")
+
+
 LIB_PATH = os.environ.get("Y5_LIB_PATH") or os.path.join(_HERE, "libyolov5_hip.so")  # override: kernel experiments only
 
 Y5_F16, Y5_F32, Y5_U8 = 0, 1, 2

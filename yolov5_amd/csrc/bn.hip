@@ -18,15 +18,12 @@ int check(int dt, long long npix, int C, const void* ws, size_t ws_bytes) {
   if (!ws || ws_bytes < y5_bn_workspace_bytes(C, npix) || ((uintptr_t)ws & 15)) return y5_fail(Y5_ERR_WORKSPACE, "bn: workspace too small or misaligned");
   return Y5_OK;
 }
-int bn_rev() {   // Y5_BN_REV=1: statistics passes walk the tensor from its end (bn_kernels.h); measured neutral (profiles/experiments/r05_bn_reverse_pass.log), default 0
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("Y5_BN_REV"); v = e && e[0] == '1' ? 1 : 0; }
-  return v;
-}
+// (the reversed-walk statistics pass of round 5, Y5_BN_REV, measured neutral -- profiles/experiments/r05_bn_reverse_pass.log -- and lost its switch in round 6;
+// Y5BnParams.rev stays 0)
 template <int MODE>
 void reduce(const Y5BnParams& p0, int dt, hipStream_t st) {
   Y5BnParams p = p0;
-  p.rev = bn_rev();
+  p.rev = 0;
   const int vec = dt == Y5_F16 ? 8 : 4;
   const size_t lds = (size_t)256 * 2 * vec * 4;
   if (dt == Y5_F16) hipLaunchKernelGGL((y5_chan_reduce_kernel<half_t, MODE>), dim3((unsigned)p.nblk), dim3(256), lds, st, p);

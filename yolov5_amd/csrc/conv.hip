@@ -596,9 +596,6 @@ static int conv2d_fwd_impl(const y5_conv_desc* d, const void* x, const void* w_p
     if (d->dtype != Y5_F16 || d->KH != 3 || d->KW != 3 || d->SH != d->SW || (d->SH != 1 && d->SH != 2) || d->PH != 1 || d->PW != 1 || !y || y_up2 || d->C1 % 32 ||
         d->Kpad < 9 * d->C1 || placed)
       return y5_fail(Y5_ERR_UNSUPPORTED, "conv: halo 3x3 configuration needs a 3x3 s1 / s2 p1 fp16 layer with C1 % 32 == 0 and a single destination");
-    static int s2_ok = -1;   // Y5_H3_S2=0: the stride-2 form off (A/B switch of profiles/r05/r05_ab_h3_stride2.log)
-    if (s2_ok < 0) { const char* e = getenv("Y5_H3_S2"); s2_ok = e && e[0] == '0' ? 0 : 1; }
-    if (d->SH == 2 && !s2_ok) return y5_fail(Y5_ERR_UNSUPPORTED, "conv: halo 3x3 at stride 2 switched off (Y5_H3_S2=0)");
     return y5_launch_h3_by_cfg(p, h3s ? kNumH3a + cfg - kH3S_0 : cfg - kH3_0, d->max_blocks, stream);
   }
   if (k3) {

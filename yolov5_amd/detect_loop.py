@@ -78,7 +78,8 @@ class DetectPipeline:
     def __init__(self, model, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, max_det=1000, nm=0, overlap=None):
         import os
         if overlap is None:
-            overlap = os.environ.get("Y5_PIPE_OVERLAP", "1") != "0"   # A/B switch: 0 = the NMS chain stays on the caller's stream
+            from . import _lib
+            overlap = not _lib.disabled("pipe_overlap")   # A/B switch (Y5_DISABLE=pipe_overlap): the NMS chain stays on the caller's stream
         self.model = model
         self.kw = dict(conf_thres=conf_thres, iou_thres=iou_thres, classes=classes, agnostic=agnostic, max_det=max_det, nm=nm)
         self.overlap = overlap

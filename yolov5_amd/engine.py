@@ -330,7 +330,7 @@ class _Planner:
                 self.detect(m, ins)
         # opt-in since round 2: the A/B on MI355X (scripts/ab_head_branch.sh) shows no gain any more, and without overlapping launches the
         # per-kernel durations of a rocprofv3 trace add up to the forward
-        if os.environ.get("Y5_HEAD_BRANCH", "0") != "0":
+        if _lib.experimental("head_branch"):
             self._schedule_heads()
         return spec
 
@@ -462,6 +462,12 @@ def autotune_conv(lib, d, ptrs, st, exclude=()):
         if part:
             lo, _, hi = part.partition("-")
             skip.update(range(int(lo), int(hi or lo) + 1))
+    if not _lib.experimental("h3_s2"):
+        # the halo-resident 3x3 at STRIDE 2 (ids 61-77 on stride-2 layers, the small-tile ids 90-92) lost every race of round 5
+        # (profiles/r05/r05_ab_h3_stride2.log): at parity, reachable by id, no longer timed at every plan build
+        skip.update(range(90, 93))
+        if d.SH == 2 and d.KH == 3:
+            skip.update(range(61, 78))
     timed = []
     for cfg in range(ncfg):
         if cfg in skip or cfg in exclude:
@@ -583,7 +589,7 @@ _SK_WS = {}  # device -> workspace tensor registered with the library (kept aliv
 def _ensure_sk_workspace(be, lib, st):
     """Register the stream-K scratch (64 MiB of the 288 GB) for this device once; every plan of the process shares it."""
     dev = str(getattr(be, "device", "cpu"))
-    if dev in _SK_WS or os.environ.get("Y5_STREAMK", "0") != "1":
+    if dev in _SK_WS or not _lib.experimental("streamk"):
         return
     nbytes = int(lib.y5_conv_sk_workspace_bytes())
     ws = be.empty((nbytes + 256,), torch.uint8)
@@ -664,7 +670,7 @@ class Engine:
         self.x_shape = tuple(x_shape)
         self.spec = spec if spec is not None else build_plan_spec(
             model, B, ch, H, W, want_raw, fuse_bneck=dtype == torch.float16 and os.environ.get("Y5_FUSED_BNECK", "1") != "0",
-            virtual_up=dtype == torch.float16 and os.environ.get("Y5_VIRTUAL_UP", "1") != "0")
+            virtual_up=dtype == torch.float16 and not _lib.disabled("virtual_up"))
         det = getattr(model, "model", [None])[-1] if model is not None else None
         self._det = det if det is not None and hasattr(det, "anchors") else None
         self._anchor_ops = []  # (plan op index, pyramid level) of every op that holds anchor sizes
@@ -678,7 +684,7 @@ class Engine:
         # through another index order: on the GPU they are returned as strided VIEWS of those plan buffers instead of being
         # written a second time by the decode kernel (274 MB per 64 images at 640^2).  Same shape and values; not contiguous;
         # valid until the next forward like every other output.
-        self.raw_views = (getattr(self.be, "direct", False) and outputs is None and os.environ.get("Y5_RAW_VIEW", "1") != "0") \
+        self.raw_views = (getattr(self.be, "direct", False) and outputs is None and not _lib.disabled("raw_view")) \
             if raw_views is None else raw_views
         self.outputs = {}
         for name, o in self.spec.outputs.items():
@@ -693,8 +699,8 @@ class Engine:
                 self.outputs[name] = self.be.empty(o["shape"], dtype)
         # Objectness plane beside z (one value per prediction row, written by the Detect decode / fused head): the NMS filter reads it instead
         # of the 85-value rows and fetches only the rows it cannot exclude (general.non_max_suppression picks it up from the z tensor it is
-        # attached to).  Engine-owned outputs on the device only; Y5_OBJ_HINT=0 switches it off.
-        self._hint = ("z" in self.outputs and outputs is None and getattr(self.be, "direct", False) and os.environ.get("Y5_OBJ_HINT", "1") != "0")
+        # attached to).  Engine-owned outputs on the device only; Y5_DISABLE=obj_hint switches it off.
+        self._hint = ("z" in self.outputs and outputs is None and getattr(self.be, "direct", False) and not _lib.disabled("obj_hint"))
         if self._hint:
             zs = self.spec.outputs["z"]["shape"]
             self._hint_shape = (zs[0], zs[1])  # (neither a spec output nor a key of self.outputs: it travels on the z tensor)
@@ -727,7 +733,7 @@ class Engine:
         # the plan's output pointers are re-pointed at newly allocated tensors (no copy) and captured graphs are cached per
         # binding -- in a steady loop the caching allocator hands the same blocks back and the same graph replays.  The strided
         # raw VIEWS of eval mode stay views of plan buffers (valid until the next forward; see DetectionModel.forward).
-        self.fresh_outputs = outputs is None and os.environ.get("Y5_FRESH_OUTPUTS", "1") != "0"
+        self.fresh_outputs = outputs is None and not _lib.disabled("fresh_outputs")
         self._bound = {k: self.be.ptr(v) for k, v in self.outputs.items() if not (self.raw_views and k.startswith("raw"))}
         # The objectness plane is NOT re-allocated per call: it is an engine-owned side channel guarded by a forward counter (the tag on z names the
         # forward it belongs to; general.non_max_suppression drops a hint whose forward is no longer the engine's latest).  Re-pointing it per call
@@ -829,7 +835,7 @@ class Engine:
             cin = w.shape[1]
             if (self.dtype == torch.float16 and cin == 3 and (kh, kw, sh, sw, ph, pw) == (6, 6, 2, 2, 2, 2) and op["act"] and res is None
                     and y2 is None and W % 64 == 0 and H % 2 == 0 and w.shape[0] <= 64 and w.shape[0] % 8 == 0
-                    and os.environ.get("Y5_STEM", "1") != "0"):
+                    and not _lib.disabled("stem")):
                 stem = pack_stem_weight(w, b) + (int(w.shape[0]),)
             wfull = torch.zeros((w.shape[0], C1, kh, kw), device=w.device)
             wfull[:, :cin] = w
@@ -906,7 +912,7 @@ class Engine:
         if x.C == 128:   # c_ = 128 (conv_h3b.h, CV3 form): its own switch, same meaning.  Default OFF: measured slower than the two-launch form on every box
             # (97-100 us against 54 + 36, profiles/r05/r05_ab_cv3_128.log), and under a profiler's serialised launches the plan-build race picked
             # it anyway -- a PMC pass must measure the plan the bench runs
-            mode = os.environ.get("Y5_FUSED_CV3_128", "0")
+            mode = "1" if _lib.experimental("cv3_128") else "0"
         if mode == "0" or self.dt != _lib.Y5_F16 or x.C not in (32, 128) or nxt_i >= len(self.spec.ops):
             return None
         nxt = self.spec.ops[nxt_i]
@@ -993,8 +999,8 @@ class Engine:
         if getattr(self.be, "autotune", False):
             # stream-K kernels combine split tiles through ONE registered workspace: not for ops that run beside others (side stream)
             # (measured, scripts/streamk_bench.py: at yolov5s bs=64 sizes the slab round trip costs more than the tail it removes --
-            # 60-119 us against 42-69 us for the plain tiles -- so they only enter the race when asked for: Y5_STREAMK=1)
-            d.cfg = self._autotune_conv(d, ptrs, exclude=SK_CFGS if (op.get("side") or os.environ.get("Y5_STREAMK", "0") != "1") else ())
+            # 60-119 us against 42-69 us for the plain tiles -- so they only enter the race when asked for: Y5_EXPERIMENTAL=streamk)
+            d.cfg = self._autotune_conv(d, ptrs, exclude=SK_CFGS if (op.get("side") or not _lib.experimental("streamk")) else ())
         k3pw = self._fused_k3pw_args(op, d, ptrs)
         if k3pw is not None:
             self._k3pw_skip = self._cur + 1
@@ -1149,7 +1155,7 @@ class Engine:
             return None
         if mode != "1" and not getattr(self.be, "autotune", False):
             return None
-        if d.C1 > 128 and os.environ.get("Y5_FUSED_HEAD_DEEP", "1") == "0":
+        if d.C1 > 128 and _lib.disabled("head_deep"):
             return None   # A/B switch: the K-streamed fused head of the deep levels (csrc/conv_headk.h) off
         lvl = dec["level"]
         apx = (self.anchors[lvl] * self.stride_t[lvl]).reshape(-1).tolist()
@@ -1372,7 +1378,7 @@ class SplitEngine:
         if tuple(x.shape) != self.x_shape:
             raise ValueError(f"engine built for input {self.x_shape}, got {tuple(x.shape)}")
         cur = torch.cuda.current_stream(self.device)
-        if os.environ.get("Y5_FRESH_OUTPUTS", "1") != "0":  # new result tensors per call (see Engine.fresh_outputs)
+        if not _lib.disabled("fresh_outputs"):  # new result tensors per call (see Engine.fresh_outputs)
             self.outputs = {name: torch.empty(shp, dtype=self.dtype, device=self.device) for name, shp in self._out_shapes.items()}
         for i, (eng, s) in enumerate(zip(self.engines, self.streams)):
             s.wait_stream(cur)

@@ -21,7 +21,7 @@ import torch
 import torch.distributed as dist
 from torch import nn
 
-from . import _state
+from . import _lib as _libm, _state
 
 
 def is_parallel(model):
@@ -105,7 +105,7 @@ class HipDDP(nn.Module):
             b.work = None
 
     def _launch(self, b):
-        if os.environ.get("Y5_DDP_DRY") == "1":   # measurement aid (scripts/r5_ddp_reserve.py): bookkeeping only, no collective
+        if _libm.experimental("ddp_dry"):   # measurement aid (scripts/r5_ddp_reserve.py): bookkeeping only, no collective
             b.pending = -1
             return
         if self.world > 1 or self.avg_in_collective:  # (a 1-rank RCCL group still runs the collective: exercises the launch / wait path)

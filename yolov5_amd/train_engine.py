@@ -124,8 +124,8 @@ class TrainEngine:
         self.ws = self.be.empty((max(max_ws, 256),), torch.uint8)
         self.ws_bytes = max(max_ws, 256)
         # BatchNorm statistics from the convolution's epilogue (y5_conv2d_fwd_stats: one partial row per workgroup, <= 8 workgroups per CU x 256 channels);
-        # Y5_BN_FUSED_STATS=0 keeps the separate statistics pass everywhere
-        self.fused_stats = self.dtype == torch.float16 and os.environ.get("Y5_BN_FUSED_STATS", "1") != "0"
+        # Y5_DISABLE=bn_fused_stats keeps the separate statistics pass everywhere
+        self.fused_stats = self.dtype == torch.float16 and not _lib.disabled("bn_fused_stats")
         ncu = 256
         if getattr(self.be, "device", None) is not None and torch.cuda.is_available():
             ncu = max(256, torch.cuda.get_device_properties(self.be.device).multi_processor_count)
@@ -183,10 +183,10 @@ class TrainEngine:
         st["fcfg"] = -1
         # 0.Conv (k6 s2 p2 on the 3-channel image): the forward runs in the NCHW stem kernel without bias / activation (y5_conv_stem_fwd_raw) instead of
         # a table-gather launch of the general kernel on the NHWC copy (369 -> ~185 us at bs 64); the NHWC copy stays for the weight gradient.
-        # Y5_TRAIN_STEM=0 keeps the general kernel.  (fp16 plan, fp16 NCHW input, even H, W % 64 == 0, <= 64 output channels.)
+        # Y5_DISABLE=train_stem keeps the general kernel.  (fp16 plan, fp16 NCHW input, even H, W % 64 == 0, <= 64 output channels.)
         _, _, Hi, Wi = self.x_shape
         st["stem_w"] = None
-        if (op["view"] == "first" and self.dtype == torch.float16 and os.environ.get("Y5_TRAIN_STEM", "1") != "0" and st["has_bn"]
+        if (op["view"] == "first" and self.dtype == torch.float16 and not _lib.disabled("train_stem") and st["has_bn"]
                 and (c1, kh, kw) == (3, 6, 6) and tuple(op["s"]) == (2, 2) and tuple(op["p"]) == (2, 2) and c2 % 8 == 0 and c2 <= 64
                 and Hi % 2 == 0 and Wi % 64 == 0):
             st["stem_np"] = round_up(c2, 32)
@@ -361,7 +361,7 @@ class TrainEngine:
                 # the streaming kernels of P1-P3 leave sum z / sum z^2 per workgroup beside z: no statistics pass over z (models/common.py:82-88)
                 rows = C.c_int(0)
                 rc = lib.y5_conv2d_fwd_stats(C.byref(d), ptrs[0], ptrs[1], ptrs[2], ptrs[4], _vp(be.ptr(self.stats_ws)), self.stats_ws_bytes, C.byref(rows), stm)
-                if os.environ.get("Y5_STATS_DEBUG") == "1" and "stats_ok" not in st:
+                if _lib.experimental("stats_debug") and "stats_ok" not in st:
                     print(f"[stats] {op['name']:16s} cfg {d.cfg:3d} {'fused' if rc == 0 else 'separate pass'}  z {B * y.H * y.W * c2 * 2 / 1e6:.0f} MB", flush=True)
                 if rc in (_lib.Y5_ERR_UNSUPPORTED, _lib.Y5_ERR_WORKSPACE):
                     # this layer's configuration is not a streaming kernel -- or its grid leaves more partial rows than the workspace holds (a part with

@@ -17,7 +17,7 @@ from pathlib import Path
 import torch
 from torch import nn
 
-from . import _state
+from . import _lib, _state
 from .cfg import load_cfg
 from .common import C3, SPPF, Bottleneck, Concat, Conv, Proto
 from .general import LOGGER, make_divisible
@@ -91,9 +91,9 @@ class BaseModel(nn.Module):
         if eng is None:
             from .engine import Engine, SplitEngine
 
-            parts = int(os.environ.get("Y5_SPLIT", "1"))
+            parts = 2 if _lib.experimental("split2") else 1
             if x.is_cuda and parts > 1 and x.shape[0] >= 16 * parts and x.shape[0] % parts == 0:
-                # opt-in (Y5_SPLIT=2): sub-batch plans on separate streams fill each other's kernel tails (engine.SplitEngine;
+                # opt-in (Y5_EXPERIMENTAL=split2): sub-batch plans on separate streams fill each other's kernel tails (engine.SplitEngine;
                 # +3 % images/s on yolov5s bs=64, but per-kernel figures then describe overlapped launches)
                 eng = SplitEngine(self, tuple(x.shape), key[1], x.device, want_raw=want_raw, parts=parts)
             else:
