@@ -1135,6 +1135,10 @@ def main():
             res["value_at_ref_clock"] = round(res["value"] * fac, 1)
             res["ref_clock"] = {"ref_mfma_sustained_tflops": REF_SUSTAINED_TFLOPS, "this_box_mfma_sustained_tflops": sus, "factor": round(fac, 4),
                                 "shader_clock_ghz_under_mfma": ceil.get("shader_clock_ghz_under_mfma")}
+            # the same FLOPs against what THIS box sustains on back-to-back MFMAs (MFMA-dense code clocks the part to 0.65-0.75 of the
+            # 2.4 GHz the 2.5 PFLOP/s peak assumes); `frac` / `stack_frac` keep the contract's 2.5 PFLOP/s denominator
+            res["roofline"]["frac_of_sustained"] = round(float(res["roofline"]["achieved"]) / sus, 4)
+            res["roofline"]["stack_frac_of_sustained"] = round(float(res["roofline"]["stack_achieved"]) / sus, 4)
             sm = [q.get("sclk_mhz") for q in (gpu_state or {}).get("samples", []) if isinstance(q, dict) and q.get("sclk_mhz")]
             res["config"]["gpu_state"] = {"sclk_mhz": max(sm) if sm else None, "mfma_sustained_tflops": sus}
         except Exception:
