@@ -99,6 +99,15 @@ void y5_conv_bneck_kernel(const Y5BneckParams p) {
   T* __restrict__ yg = static_cast<T*>(p.y);
 
   auto fsw = [](int q) { return C == 32 ? ((q >> 2) & 3) : ((q >> 1) & 7); };  // pixel-row swizzle (64 / 128-byte rows)
+  // The t buffer has its own swizzle (round 6).  GEMM 2's fragment rows are NOT consecutive -- lane pl reads pixel (pl >> 3) * 10 + (pl & 7) + tap -- and under
+  // fsw every one of its ds_read_b128 was 3-way bank-conflicted (the "36-43 % of LDS-active cycles" of the round-5 counters; modelled lane group by lane group
+  // in DESIGN.md section 4.8).  No function of the pixel row is conflict-free for all nine taps at row pitch 10 (pitch 16 is, and does not fit the LDS at C = 64);
+  // these two bring the reads from 3.0 to 1.9 LDS cycles per lane group and leave the t stores at their 2.0.
+#ifdef Y5_BNECK_OLD_TSW   // (A/B build of profiles/r06/r06_ab_bneck_tsw.log)
+  auto tsw = fsw;
+#else
+  auto tsw = [](int q) { return C == 32 ? (((q >> 2) + 3 * (q >> 4)) & 3) : (((q >> 1) + 6 * (q >> 4)) & 7); };
+#endif
 
   // ---- prologue: both filters (rows swizzled like the activation rows) + biases into LDS -----------------------------
   {
@@ -153,7 +162,7 @@ void y5_conv_bneck_kernel(const Y5BneckParams p) {
   for (int t = 0; t < 9; ++t) {
     const int q = q0 + (t / 3) * RW + (t % 3);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) rd[t][ks] = q * ROWB + (((ks * 2 + g) ^ fsw(q)) * 16);
+    for (int ks = 0; ks < KS; ++ks) rd[t][ks] = q * ROWB + (((ks * 2 + g) ^ tsw(q)) * 16);
   }
   int w2sl[KS];
 #pragma unroll
@@ -277,7 +286,7 @@ void y5_conv_bneck_kernel(const Y5BneckParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = in_img ? (half_t)y5_bneck_act(acc1[f][j][qq * 4 + e] + bv[e]) : (half_t)0.f;
             const int slot = j * 4 + qq;  // 16-byte slot = channel / 8
-            *reinterpret_cast<half4_t*>(ts + q * ROWB + ((slot ^ fsw(q)) * 16) + g * 8) = o;
+            *reinterpret_cast<half4_t*>(ts + q * ROWB + ((slot ^ tsw(q)) * 16) + g * 8) = o;
           }
       }
     }
