@@ -143,7 +143,14 @@ def _pmc_plan_mismatch(d, timed_families):
     if timed_families is None or have == timed_families:
         return None
     keys = sorted(set(have) | set(timed_families))
-    return {"reason": "the counters were collected on another plan", "family: [profiled, timed] launches": {k: [have.get(k, 0), timed_families.get(k, 0)] for k in keys if have.get(k, 0) != timed_families.get(k, 0)}}
+    delta = {k: [have.get(k, 0), timed_families.get(k, 0)] for k in keys if have.get(k, 0) != timed_families.get(k, 0)}
+    # One near-tie layer that the tuner gives to another family on another box (boxes differ by 5 % in clocks: one plan hash across boxes is not achievable)
+    # moves one launch from one family to another and < 1 % of the traffic; that much is tolerated and REPORTED (`plan_delta`).  Anything more -- a family
+    # that exists on one side only, more than one swapped layer -- is another plan: the counter figures are withheld.
+    if set(have) == set(timed_families) and sum(abs(a - b) for a, b in delta.values()) <= 2:
+        d["_plan_delta"] = delta
+        return None
+    return {"reason": "the counters were collected on another plan", "family: [profiled, timed] launches": delta}
 
 
 def pmc_traffic(a, conv_by, timed_families=None):
@@ -173,7 +180,7 @@ def pmc_traffic(a, conv_by, timed_families=None):
     if mis is not None:
         return {"gbytes_per_step": None, "vs_algorithmic": None, "other_plan": mis, "other_plan_gbytes_per_step": round(gb, 3), "source": src}
     return {"gbytes_per_step": round(gb, 3), "vs_algorithmic": round(gb * 1e9 / conv_by, 3) if conv_by else None, "kernel_src_sha16": have,
-            "plan_families": d.get("plan_families"), "source": src}
+            "plan_families": d.get("plan_families"), "plan_delta": d.get("_plan_delta"), "source": src}
 
 
 def pmc_mfma_busy(a, timed_families=None):
@@ -201,7 +208,7 @@ def pmc_mfma_busy(a, timed_families=None):
     mis = _pmc_plan_mismatch(d, timed_families)
     if mis is not None:
         return {"value": None, "other_plan": mis, "other_plan_value": round(frac, 4), "source": src}, {}
-    return {"value": round(frac, 4), "kernel_src_sha16": have, "plan_families": d.get("plan_families"), "source": src,
+    return {"value": round(frac, 4), "kernel_src_sha16": have, "plan_families": d.get("plan_families"), "plan_delta": d.get("_plan_delta"), "source": src,
             "definition": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles) over the conv launches of one forward (inside the kernels: no launch gaps)"}, per_kernel
 
 
@@ -969,7 +976,11 @@ def main():
         dominant = {"name": f"{fam} (configuration {cid}{tile})", "family": fam, "cfg": cid, "launches_per_step": gn * parts, "ms_per_step": round(gms * parts, 4),
                     "share_of_conv_time": round(gms / conv_ms_in_situ, 3) if conv_ms_in_situ > 0 else None,
                     "achieved_tflops": round(gfl / (gms * 1e-3) / 1e12, 1), "frac": round(gfl / (gms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
-                    "hbm_gbytes_per_s": round(gby / (gms * 1e-3) / 1e9, 1)}
+                    "hbm_gbytes_per_s": round(gby / (gms * 1e-3) / 1e9, 1), "hbm_frac": round(gby / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    # which roof bounds THIS group: its algorithmic bytes at 8 TB/s against its FLOPs at 2.5 PFLOP/s (round 6: the dominant group is no longer
+                    # an implicit-GEMM configuration -- the 8-phase family split that group up -- but the fused Bottlenecks of P2 / P3, 160 flop/B: HBM-bound)
+                    "bound": "hbm" if gby / (HBM_PEAK_GBS * 1e9) >= gfl / (MFMA_PEAK_TFLOPS * 1e12) else "mfma",
+                    "arithmetic_intensity_flop_per_byte": round(gfl / gby, 1) if gby else None}
     try:  # which plan the tuner built on this box: two lines are comparable only when this hash agrees
         import hashlib
         plan_sha16 = hashlib.sha256(json.dumps([[n, c] for n, c in eng.plan_table()]).encode()).hexdigest()[:16]
@@ -1089,11 +1100,15 @@ def main():
             # per-layer it is the HBM figure that says how close each launch is to ITS bound -- but the contract prices the stack against MFMA.
             # roofline.kernel / achieved / frac: the DOMINANT kernel instantiation (largest time per forward) with its own figure; stack_* : all conv
             # launches of one forward (the number rounds 1-3 reported as `frac`); mfma_busy_frac: the counter-based utilisation of the same launches
-            "roofline": {"bound": "mfma", "kernel": dominant["name"] if dominant else "y5_conv_*_kernel (all conv launches of one forward)",
-                         "achieved": dominant["achieved_tflops"] if dominant else round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": dominant["frac"] if dominant else round(achieved / MFMA_PEAK_TFLOPS, 4),
-                         "frac_definition": "conv FLOPs of the dominant kernel's launches / their in-situ time / 2500 TFLOP/s; stack_frac = the same over ALL conv "
-                                            "launches of one forward (rounds 1-3 reported that one as frac)",
+            "roofline": {"bound": dominant["bound"] if dominant else "mfma", "kernel": dominant["name"] if dominant else "y5_conv_*_kernel (all conv launches of one forward)",
+                         "achieved": (dominant["hbm_gbytes_per_s"] if dominant["bound"] == "hbm" else dominant["achieved_tflops"]) if dominant else round(achieved, 2),
+                         "peak": (HBM_PEAK_GBS if dominant["bound"] == "hbm" else MFMA_PEAK_TFLOPS) if dominant else MFMA_PEAK_TFLOPS,
+                         "unit": ("GB/s" if dominant["bound"] == "hbm" else "TFLOP/s") if dominant else "TFLOP/s",
+                         "frac": (dominant["hbm_frac"] if dominant["bound"] == "hbm" else dominant["frac"]) if dominant else round(achieved / MFMA_PEAK_TFLOPS, 4),
+                         "frac_definition": "the dominant kernel group (largest in-situ time per forward) against the roof that bounds IT: algorithmic bytes of its launches / their "
+                                            "in-situ time / 8000 GB/s when its arithmetic intensity is below the ridge (312 flop/B), else its conv FLOPs / time / 2500 TFLOP/s "
+                                            "(dominant_kernel carries both views); stack_frac = conv FLOPs of ALL conv launches of one forward / their time / 2500 TFLOP/s "
+                                            "(rounds 1-3 reported that one as frac; rounds 4-5 the MFMA view of an implicit-GEMM group)",
                          "dominant_kernel": dominant,
                          "stack_kernels": "y5_conv_{front,igemm,h3,h3b,pw,k3,stem,bneck}_kernel (all conv launches of one forward)",
                          "stack_achieved": round(achieved, 2), "stack_frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
@@ -1137,7 +1152,8 @@ def main():
                                 "shader_clock_ghz_under_mfma": ceil.get("shader_clock_ghz_under_mfma")}
             # the same FLOPs against what THIS box sustains on back-to-back MFMAs (MFMA-dense code clocks the part to 0.65-0.75 of the
             # 2.4 GHz the 2.5 PFLOP/s peak assumes); `frac` / `stack_frac` keep the contract's 2.5 PFLOP/s denominator
-            res["roofline"]["frac_of_sustained"] = round(float(res["roofline"]["achieved"]) / sus, 4)
+            if dominant:
+                res["roofline"]["frac_of_sustained"] = round(float(dominant["achieved_tflops"]) / sus, 4)   # (MFMA view of the dominant group)
             res["roofline"]["stack_frac_of_sustained"] = round(float(res["roofline"]["stack_achieved"]) / sus, 4)
             sm = [q.get("sclk_mhz") for q in (gpu_state or {}).get("samples", []) if isinstance(q, dict) and q.get("sclk_mhz")]
             res["config"]["gpu_state"] = {"sclk_mhz": max(sm) if sm else None, "mfma_sustained_tflops": sus}

@@ -12,7 +12,7 @@ hbm frac = algorithmic GB (bench.py's `algorithmic_gbytes_per_step`) / median su
 """
 import argparse, collections, csv, json, statistics, sys
 
-CONV = ("conv_igemm", "conv_h3", "conv_pw", "conv_k3", "conv_pwk", "conv_stem", "conv_bneck", "conv_front", "sppf_cv1_pool", "conv_headk")
+CONV = ("conv_igemm", "conv_g8", "conv_h3", "conv_pw", "conv_k3", "conv_pwk", "conv_stem", "conv_bneck", "conv_front", "sppf_cv1_pool", "conv_headk")
 
 
 def main():
