@@ -855,3 +855,43 @@ def test_plan_sppf_front_fused_equals_unfused_on_gpu(dev, monkeypatch):
         assert any(n.startswith("sppf_front:") for n in eng.op_names) == (mode == "1") and ("sppf_pool" in eng.op_names) == (mode == "0"), eng.op_names
     u, v = outs["0"], outs["1"]
     assert float((u - v).abs().max()) <= 4e-3 * max(1.0, float(u.abs().max()))
+
+
+@pytest.mark.parametrize("cfg,B,H,C1,C2,k,s", [(95, 64, 40, 256, 512, 3, 2), (96, 64, 40, 256, 256, 3, 2), (95, 64, 40, 256, 256, 1, 1), (96, 64, 80, 128, 128, 3, 2)])
+def test_8phase_kernels_are_repeatable_under_load(cfg, B, H, C1, C2, k, s, dev):
+    """conv_g8.h hands LDS half-tiles between two wave rows that run one barrier apart; the restage-after-read distances are argued in its header, and a
+    violation would show as RARE wrong tiles that depend on timing -- something neither a single parity run nor the host emulator (which runs the rows of a
+    workgroup one after the other) can see.  Here the benchmarked shapes run 40 times each, alternating with a bandwidth-heavy copy on a second stream that
+    perturbs the memory system's timing, and every output must be BIT-IDENTICAL to the first (the kernel has no atomics: any difference is a race)."""
+    from yolov5_amd import _lib
+    from yolov5_amd.packing import pack_conv_weight
+
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(cfg + C2)
+    x = torch.randn((B, H, H, C1), generator=g).half().to(dev)
+    w = torch.randn((C2, C1, k, k), generator=g) * (2.0 / (C1 * k * k)) ** 0.5
+    wp, bp, K, Kpad, Npad = pack_conv_weight(w, torch.randn(C2, generator=g) * 0.2, torch.float16)
+    wp, bp = wp.to(dev), bp.to(dev)
+    p = k // 2
+    OH = (H + 2 * p - k) // s + 1
+    d = _lib.ConvDesc(dtype=_lib.Y5_F16, B=B, H=H, W=H, C1=C1, ldx=C1, OH=OH, OW=OH, C2=C2, ldy=C2, KH=k, KW=k, SH=s, SW=s, PH=p, PW=p, act=1,
+                      Kpad=Kpad, Npad=Npad, ldr=0, ld2=0, cfg=cfg, max_blocks=0)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    side = torch.cuda.Stream(dev)
+    junk_a = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    junk_b = torch.empty_like(junk_a)
+    first = None
+    for it in range(40):
+        y = torch.full((B, OH, OH, C2), -3.0, dtype=torch.float16, device=dev)
+        if it % 2:
+            with torch.cuda.stream(side):
+                junk_b.copy_(junk_a)
+        rc = lib.y5_conv2d_fwd(C.byref(d), C.c_void_p(x.data_ptr()), C.c_void_p(wp.data_ptr()), C.c_void_p(bp.data_ptr()), None, C.c_void_p(y.data_ptr()), None, st)
+        assert rc == 0, lib.y5_last_error()
+        torch.cuda.synchronize()
+        if first is None:
+            first = y
+            ref = F.silu(F.conv2d(x.permute(0, 3, 1, 2).float(), w.half().float().to(dev), bp[:C2], s, p)).permute(0, 2, 3, 1)
+            torch.testing.assert_close(y.float(), ref, rtol=2e-2, atol=2e-2)
+        else:
+            assert torch.equal(y, first), f"run {it} differs from run 0 in {int((y != first).sum())} elements"
