@@ -347,10 +347,7 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
 #pragma unroll
   for (int q = 0; q < Gm::MAXN / 512; ++q) blds[tid + q * 512] = bv[q];
   advance_scalar();                            // K tile 2's offsets: the first q1 commits them
-  // Only the FIRST TWO half-tiles (Wgt-h0, Act-h0 of K tile 0: the four oldest of the fourteen loads) are waited for here: q1 reads nothing else.  Wgt-h1 and
-  // Act-h1 of K tile 0 are retired by the vmcnt(10) at the end of q1 / q2 -- waits that are no-ops in steady state (at most 8 / 10 loads are outstanding there)
-  // and matter only behind this prologue, where every CU's first 64 KB arrive at the memory system's burst rate (1.7 us per 32 KB, section 4.2).
-  y5_wait_vm<10>();
+  y5_wait_vm<3 * Gm::LPH>();
   __builtin_amdgcn_s_waitcnt(0xC07F);          // the bias table is written before the barrier that publishes it
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();   // the stagger: wave row 1 runs one barrier interval behind wave row 0
@@ -381,7 +378,6 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
       rd_act(I0{}, cur);
       stage_act(I1{}, oth);          // Act-h1 of K tile t+1
       advance_commit();              // the loader moves on to K tile t+2 (its scalars were computed in the previous q4)
-      y5_wait_vm<10>();              // (first K tile behind the prologue: Wgt-h1 of K tile 0 has landed -- q2 reads it; a no-op in steady state)
       __builtin_amdgcn_s_waitcnt(0xC87F);   // lgkmcnt(8): the four filter reads have returned -- q2 restages Wgt-h0
       __builtin_amdgcn_s_barrier();
       lgkm0();
@@ -390,7 +386,6 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
       // q2
       rd_wgt(I1{}, cur);
       stage_wgt(I0{}, cur);          // Wgt-h0 of K tile t+2
-      y5_wait_vm<10>();              // (first K tile behind the prologue: Act-h1 of K tile 0 has landed -- q3 reads it; a no-op in steady state)
       __builtin_amdgcn_s_barrier();
       lgkm0();
       mma(I0{}, I1{});
@@ -657,7 +652,7 @@ void y5_conv_g8n_kernel(const Y5ConvParams p) {
   stage_wgt(smem + 2 * BUF); adv_wgt();
 #pragma unroll
   for (int q = 0; q < Gm::MAXN / 512; ++q) blds[tid + q * 512] = bv[q];
-  y5_wait_vm<10>();  // Wgt and Act-h0 of K tile 0 (the four oldest loads) have landed: p1 reads nothing else; Act-h1 is retired by p1's vmcnt(10) (a no-op in steady state)
+  y5_wait_vm<8>();   // K tile 0 (the six oldest loads) has landed
   __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();
@@ -678,7 +673,6 @@ void y5_conv_g8n_kernel(const Y5ConvParams p) {
 #endif
       rd_act(I0{}, b_cur);
       stage_act(I0{}, b_nx2);        // Act-h0 of K tile t+2
-      y5_wait_vm<10>();              // (first K tile behind the prologue: Act-h1 of K tile 0 has landed -- p2 reads it)
       __builtin_amdgcn_s_waitcnt(0xC87F);   // lgkmcnt(8): the four filter reads have returned -- p2 restages Wgt
       __builtin_amdgcn_s_barrier();
       lgkm0();
