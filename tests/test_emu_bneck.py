@@ -118,7 +118,7 @@ def test_fused_bottleneck_rejects_overlap_and_bad_shapes():
     assert lib.y5_bottleneck_fwd(*args(ptr(buf), C.c_void_p(buf.ctypes.data + 64), H=6)) != 0
 
 
-@pytest.mark.parametrize("cfg", [-1, 2, 17, 93])
+@pytest.mark.parametrize("cfg", [-1, 2, 17, 93, 95, 96])
 def test_conv_split_store(cfg):
     """1x1 64 -> 64 conv whose channels [0, 32) go to one buffer and [32, 64) to a slice of another (desc.split_n)."""
     lib = emu()

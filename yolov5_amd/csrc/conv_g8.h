@@ -299,20 +299,32 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
   T* yg = static_cast<T*>(p.y);   // may alias p.res
   const T* rg = static_cast<const T*>(p.res);
   T* y2g = static_cast<T*>(p.y2);
-  auto epilogue = [&](int j, auto actc) __attribute__((always_inline)) {
+  // Stores (and residual loads) go through BUFFER addressing against per-tile resource descriptors (base = row m0 of the destination): a lane outside the layer
+  // (m >= M, n >= C2) carries bit 31 in its offset and the hardware's range check drops it.  The pointer form spent ~20 of its 77 instructions per store on an
+  // exec-mask branch and 64-bit address arithmetic -- the epilogue is instruction-issue bound (two waves per SIMD, 2 474 instructions each, section 4.2).
+  const int e_rb = (wr * 128 + l31) * p.ldy * 2, e_rb2 = (wr * 128 + l31) * p.ld2 * 2, e_rbr = (wr * 128 + l31) * p.ldr * 2;
+  auto epilogue = [&](int j, auto actc, auto modec) __attribute__((always_inline)) {
     constexpr bool ACT = decltype(actc)::value;   // (a per-element select on the runtime flag cost one more VALU per element)
+    constexpr int MODE = decltype(modec)::value;  // 0: one destination; 1: + residual; 2: split store (C3's cv1 / cv2 halves) -- chosen once per launch
     int m0, n0;
     tile_coords(j, m0, n0);
+    const y5_rsrc_t yrs = y5_make_rsrc(yg + (size_t)m0 * p.ldy, 0x7fffffffu);
+    const y5_rsrc_t y2rs = MODE == 2 ? y5_make_rsrc(y2g + (size_t)m0 * p.ld2, 0x7fffffffu) : yrs;
+    const y5_rsrc_t rrs = MODE == 1 ? y5_make_rsrc(rg + (size_t)m0 * p.ldr, 0x7fffffffu) : yrs;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int n = n0 + wc * 64 + c * 32 + h * 16 + g * 8;
+        const int nbase = n0 + wc * 64 + c * 32 + h * 16;   // wave-uniform
+        const int n = nbase + g * 8;
         const int nb = n < p.Npad ? n : 0;
         const float4_t b0 = *reinterpret_cast<const float4_t*>(blds + nb), b1 = *reinterpret_cast<const float4_t*>(blds + nb + 4);
+        const bool to2 = MODE == 2 && n >= p.split_n;
+        (void)nbase;
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-          const int m = m0 + wr * 128 + (f >> 1) * 64 + (f & 1) * 32 + l31;
+          const int fr = (f >> 1) * 64 + (f & 1) * 32;
+          const bool ok = m0 + wr * 128 + fr + l31 < p.M && n < p.C2;
           float v[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -322,20 +334,23 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
           uint4_t raw;
 #pragma unroll
           for (int e = 0; e < 4; ++e) raw[e] = y5_pack_h2(v[2 * e], v[2 * e + 1]);
-          if (m < p.M && n < p.C2) {
-            if (rg) {
-              const uint4_t rr = *reinterpret_cast<const uint4_t*>(rg + (size_t)m * p.ldr + n);
-              half8_t a = __builtin_bit_cast(half8_t, raw), b = __builtin_bit_cast(half8_t, rr), o;
+          if constexpr (MODE == 1) {   // (a layer with a residual has no split store)
+            const uint4_t rr = y5_buffer_load16(rrs, ok ? e_rbr + fr * p.ldr * 2 + n * 2 : (int)0x80000000u, 0);
+            half8_t a = __builtin_bit_cast(half8_t, raw), b = __builtin_bit_cast(half8_t, rr), o;
 #pragma unroll
-              for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)a[e] + (float)b[e]);
-              raw = __builtin_bit_cast(uint4_t, o);
-            }
-            T* d = (p.split_n && n >= p.split_n) ? y2g + (size_t)m * p.ld2 + (n - p.split_n) : yg + (size_t)m * p.ldy + n;
-            *reinterpret_cast<uint4_t*>(d) = raw;
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)a[e] + (float)b[e]);
+            raw = __builtin_bit_cast(uint4_t, o);
           }
+          y5_buffer_store16(raw, yrs, ok && !to2 ? e_rb + fr * p.ldy * 2 + n * 2 : (int)0x80000000u, 0);
+          if constexpr (MODE == 2) y5_buffer_store16(raw, y2rs, ok && to2 ? e_rb2 + fr * p.ld2 * 2 + (n - p.split_n) * 2 : (int)0x80000000u, 0);
         }
       }
     }
+  };
+  auto run_epilogue = [&](int j) __attribute__((always_inline)) {   // the launch's variant (wave-uniform launch parameters)
+    using M0 = std::integral_constant<int, 0>; using M1 = std::integral_constant<int, 1>; using M2 = std::integral_constant<int, 2>;
+    if (p.act) { if (p.split_n) epilogue(j, std::true_type{}, M2{}); else if (rg) epilogue(j, std::true_type{}, M1{}); else epilogue(j, std::true_type{}, M0{}); }
+    else { if (p.split_n) epilogue(j, std::false_type{}, M2{}); else if (rg) epilogue(j, std::false_type{}, M1{}); else epilogue(j, std::false_type{}, M0{}); }
   };
 
   // ---- prologue: all of K tile 0, three half-tiles of K tile 1 ----
@@ -419,8 +434,7 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
 #ifndef Y5_G8_SERIAL_EPILOGUE
     if (wr == 0) __builtin_amdgcn_s_barrier();
 #endif
-    if (p.act) epilogue(ti, std::true_type{});
-    else epilogue(ti, std::false_type{});
+    run_epilogue(ti);
 #ifndef Y5_G8_SERIAL_EPILOGUE
     if (wr == 1 && ti + 1 < nmine) __builtin_amdgcn_s_barrier();
 #endif
@@ -607,18 +621,27 @@ void y5_conv_g8n_kernel(const Y5ConvParams p) {
   T* yg = static_cast<T*>(p.y);
   const T* rg = static_cast<const T*>(p.res);
   T* y2g = static_cast<T*>(p.y2);
-  auto epilogue = [&](int j, auto actc) __attribute__((always_inline)) {
+  const int e_rb = (wr * 128 + l31) * p.ldy * 2, e_rb2 = (wr * 128 + l31) * p.ld2 * 2, e_rbr = (wr * 128 + l31) * p.ldr * 2;   // (buffer-addressed stores: see y5_conv_g8_kernel)
+  auto epilogue = [&](int j, auto actc, auto modec) __attribute__((always_inline)) {
     constexpr bool ACT = decltype(actc)::value;
+    constexpr int MODE = decltype(modec)::value;
     int m0, n0;
     tile_coords(j, m0, n0);
+    const y5_rsrc_t yrs = y5_make_rsrc(yg + (size_t)m0 * p.ldy, 0x7fffffffu);
+    const y5_rsrc_t y2rs = MODE == 2 ? y5_make_rsrc(y2g + (size_t)m0 * p.ld2, 0x7fffffffu) : yrs;
+    const y5_rsrc_t rrs = MODE == 1 ? y5_make_rsrc(rg + (size_t)m0 * p.ldr, 0x7fffffffu) : yrs;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int n = n0 + wc * 32 + h * 16 + g * 8;
+      const int nbase = n0 + wc * 32 + h * 16;
+      const int n = nbase + g * 8;
       const int nb = n < p.Npad ? n : 0;
       const float4_t b0 = *reinterpret_cast<const float4_t*>(blds + nb), b1 = *reinterpret_cast<const float4_t*>(blds + nb + 4);
+      const bool to2 = MODE == 2 && n >= p.split_n;
+      (void)nbase;
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        const int m = m0 + wr * 128 + (f >> 1) * 64 + (f & 1) * 32 + l31;
+        const int fr = (f >> 1) * 64 + (f & 1) * 32;
+        const bool ok = m0 + wr * 128 + fr + l31 < p.M && n < p.C2;
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -628,19 +651,22 @@ void y5_conv_g8n_kernel(const Y5ConvParams p) {
         uint4_t raw;
 #pragma unroll
         for (int e = 0; e < 4; ++e) raw[e] = y5_pack_h2(v[2 * e], v[2 * e + 1]);
-        if (m < p.M && n < p.C2) {
-          if (rg) {
-            const uint4_t rr = *reinterpret_cast<const uint4_t*>(rg + (size_t)m * p.ldr + n);
-            half8_t a = __builtin_bit_cast(half8_t, raw), b = __builtin_bit_cast(half8_t, rr), o;
+        if constexpr (MODE == 1) {
+          const uint4_t rr = y5_buffer_load16(rrs, ok ? e_rbr + fr * p.ldr * 2 + n * 2 : (int)0x80000000u, 0);
+          half8_t a = __builtin_bit_cast(half8_t, raw), b = __builtin_bit_cast(half8_t, rr), o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)a[e] + (float)b[e]);
-            raw = __builtin_bit_cast(uint4_t, o);
-          }
-          T* d = (p.split_n && n >= p.split_n) ? y2g + (size_t)m * p.ld2 + (n - p.split_n) : yg + (size_t)m * p.ldy + n;
-          *reinterpret_cast<uint4_t*>(d) = raw;
+          for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)a[e] + (float)b[e]);
+          raw = __builtin_bit_cast(uint4_t, o);
         }
+        y5_buffer_store16(raw, yrs, ok && !to2 ? e_rb + fr * p.ldy * 2 + n * 2 : (int)0x80000000u, 0);
+        if constexpr (MODE == 2) y5_buffer_store16(raw, y2rs, ok && to2 ? e_rb2 + fr * p.ld2 * 2 + (n - p.split_n) * 2 : (int)0x80000000u, 0);
       }
     }
+  };
+  auto run_epilogue = [&](int j) __attribute__((always_inline)) {
+    using M0 = std::integral_constant<int, 0>; using M1 = std::integral_constant<int, 1>; using M2 = std::integral_constant<int, 2>;
+    if (p.act) { if (p.split_n) epilogue(j, std::true_type{}, M2{}); else if (rg) epilogue(j, std::true_type{}, M1{}); else epilogue(j, std::true_type{}, M0{}); }
+    else { if (p.split_n) epilogue(j, std::false_type{}, M2{}); else if (rg) epilogue(j, std::false_type{}, M1{}); else epilogue(j, std::false_type{}, M0{}); }
   };
 
   // ---- prologue: K tiles 0 and 1 complete, the filter half-tile of K tile 2 ----
@@ -692,8 +718,7 @@ void y5_conv_g8n_kernel(const Y5ConvParams p) {
       char* const b = b_cur; b_cur = b_nx1; b_nx1 = b_nx2; b_nx2 = b;
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();   // (tile boundary: see y5_conv_g8_kernel)
-    if (p.act) epilogue(ti, std::true_type{});
-    else epilogue(ti, std::false_type{});
+    run_epilogue(ti);
     if (wr == 1 && ti + 1 < nmine) __builtin_amdgcn_s_barrier();
   }
   Y5_DRAIN_VM();

@@ -49,7 +49,7 @@ __device__ __forceinline__ void y5_bglds16_dummy(y5_rsrc_t r, void* dummy_lds) {
 // transport of data that another workgroup -- possibly on another XCD -- reads within the same launch (stream-K slabs)
 __device__ __forceinline__ void y5_buffer_store16(uint4_t v, y5_rsrc_t r, int voff, int aux) {
 #ifdef Y5_EMU
-  memcpy(const_cast<char*>(r.base) + voff, &v, 16);
+  if ((unsigned long long)(unsigned)voff + 16 <= r.num_records) memcpy(const_cast<char*>(r.base) + (unsigned)voff, &v, 16);   // (out of range: dropped, as the hardware does)
 #else
   if (aux == 16) __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 16);
   else __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 0);
@@ -57,8 +57,8 @@ __device__ __forceinline__ void y5_buffer_store16(uint4_t v, y5_rsrc_t r, int vo
 }
 __device__ __forceinline__ uint4_t y5_buffer_load16(y5_rsrc_t r, int voff, int aux) {
 #ifdef Y5_EMU
-  uint4_t v;
-  memcpy(&v, r.base + voff, 16);
+  uint4_t v = {0u, 0u, 0u, 0u};
+  if ((unsigned long long)(unsigned)voff + 16 <= r.num_records) memcpy(&v, r.base + (unsigned)voff, 16);   // (out of range: zeros)
   return v;
 #else
   return aux == 16 ? __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 16) : __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
