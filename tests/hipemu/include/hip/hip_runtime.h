@@ -41,6 +41,7 @@ void wave_exchange(const void* payload, int bytes, const void* out[64]);
 // end) -- the LATEST moment the hardware allows, so a wait that is one piece too loose reads poison instead of passing by luck.  Default (0): lands
 // at issue, the EARLIEST moment (write-after-read hazards of a ring show up in this mode).  Tests of the counted-vmcnt kernels run both.
 void dma_issue(void* dst, const void* src, int size);   // src == nullptr: zero fill
+void vm_op_note();                                   // Y5_EMU_VM_OP (y5_common.h): a global store takes a slot of the same in-order queue
 void dma_wait(int keep);                                // retire all but the `keep` youngest pieces of the calling lane
 }  // namespace emu
 

@@ -298,11 +298,10 @@ def test_conv_virtual_upsample_concat(B, H, W, c_up, c_hi, C2, cfg, max_blocks):
 
 
 # ---- worst-case LDS-DMA landing model (tests/hipemu: Y5_EMU_ASYNC=1, latched per process -> child processes) -----------------------------------------
-# In this mode an LDS-DMA load only lands when an `s_waitcnt vmcnt(N)` of its wave (or the end of the kernel) covers it: a counted wait that is one load
-# too lenient reads stale LDS.  Every convolution family is run through it EXCEPT the four-wave streaming pointwise ids 14..21 / 56, whose counted waits also
-# count their global STORES (which this model does not queue; on the hardware loads and stores retire in issue order on one counter).
-_ASYNC_SKIP = set(range(14, 22)) | {56}
-_ASYNC_CASES = [i for i, c in enumerate(CASES) if c[11] not in _ASYNC_SKIP]
+# In this mode an LDS-DMA load only lands when an `s_waitcnt vmcnt(N)` of its wave (or the end of the kernel) covers it: a counted wait that is one operation
+# too lenient reads stale LDS.  EVERY convolution family is run through it, the four-wave streaming pointwise ids 14..21 / 56 included: their counted waits also
+# count their global stores, which the kernels mark with Y5_EMU_VM_OP (csrc/y5_common.h) so that the model queues them as the hardware's counter does.
+_ASYNC_CASES = list(range(len(CASES)))
 
 
 def _run_cases(idx):

@@ -395,6 +395,7 @@ void y5_conv_bneck_kernel(const Y5BneckParams p) {
         const size_t m = ((size_t)b * p.H + oh0 + (row >> 3)) * p.W + ow0 + (row & 7);
         const int n = oslot3 * 8;
         if (n < p.C3) *reinterpret_cast<uint4_t*>(yg + m * p.ldy + n) = raw;
+        Y5_EMU_VM_OP(true);   // (lane slot 0 holds channel 0: the wave always issues it)
       }
     } else {
 #pragma unroll
@@ -410,6 +411,7 @@ void y5_conv_bneck_kernel(const Y5BneckParams p) {
         const size_t m = ((size_t)b * p.H + oh0 + (row >> 3)) * p.W + ow0 + (row & 7);
         if (!(Y5_BNECK_ABL & 8)) *reinterpret_cast<uint4_t*>(yg + m * p.ldy + oslot * 8) = raw;
         else asm volatile("" ::"v"(raw));
+        Y5_EMU_VM_OP(true);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

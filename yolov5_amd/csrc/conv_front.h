@@ -447,6 +447,7 @@ void y5_conv_front_kernel(const Y5FrontParams p) {
           const int n = n0 + g * 8;
           T* d = n < p.split ? yg + m * p.ldy + n : y2g + m * p.ld2 + (n - p.split);
           *reinterpret_cast<uint4_t*>(d) = __builtin_bit_cast(uint4_t, of[ks]);
+          Y5_EMU_VM_OP(true);
         }
       }
     }

@@ -220,6 +220,7 @@ void y5_conv_k3_kernel(const Y5ConvParams p) {
         const int row = ps * RPP + orow;
         const size_t m = ((size_t)b * p.OH + oh0 + (row >> 3)) * p.OW + ow0 + (row & 7);
         resv[ps] = *reinterpret_cast<const uint4_t*>(rg + m * p.ldr + oslot * 8);
+        Y5_EMU_VM_OP(true);   // (a register load: one of the RP operations the counted waits skip)
       }
     }
 #ifdef Y5_K3_TIMING
@@ -305,6 +306,7 @@ void y5_conv_k3_kernel(const Y5ConvParams p) {
           T* d = n < p.pw2_split ? yg + m * p.ldy + n : y2g + m * p.ld2 + (n - p.pw2_split);  // ONE store instruction either way (counted vmcnt)
           *reinterpret_cast<uint4_t*>(d) = raw;
         }
+        Y5_EMU_VM_OP(true);   // (lane slot 0 holds channel 0: the wave always issues it)
       }
     } else {
 #pragma unroll
@@ -323,6 +325,7 @@ void y5_conv_k3_kernel(const Y5ConvParams p) {
         if (p.bn_partial) stat[0].add(raw);   // (a wave tile is 4 x 8 real pixels: H % 4 == 0, W % 8 == 0)
       }
       if (n < p.C2) *reinterpret_cast<uint4_t*>(yg + m * p.ldy + n) = raw;
+      Y5_EMU_VM_OP(true);
     }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -220,10 +220,12 @@ __device__ __forceinline__ void y5_conv_pw_body(const Y5ConvParams& p, const Y5H
         for (int it = 0; it < (NV + 63) / 64; ++it) {
           const int v = it * 64 + lane;
           if (v < NV) *reinterpret_cast<uint4_t*>(zrow + v * 8) = *reinterpret_cast<const uint4_t*>(sc + v * 8);
+          Y5_EMU_VM_OP(true);   // (it * 64 < NV: lane 0 always stores)
         }
         if constexpr (HINT) {  // the rows' objectness, bit for bit what z holds (one more store per anchor block: counted in SP)
           if (lane < 32)
             static_cast<half_t*>(hd.obj_hint)[(long long)bimg * hd.nrows_total + hd.row_off + (long long)a * hd.npix + pix0 + lane] = sc[lane * NO + 4];
+          Y5_EMU_VM_OP(true);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();  // the scratch is rewritten by the next anchor / refilled by the next tile's loads
@@ -275,6 +277,8 @@ __device__ __forceinline__ void y5_conv_pw_body(const Y5ConvParams& p, const Y5H
             *reinterpret_cast<uint4_t*>(d1 + p.ld2) = raw;
           }
         }
+#pragma unroll
+        for (int st_i = 0; st_i < (UP2 ? 5 : 1); ++st_i) Y5_EMU_VM_OP(h * NPH < p.C2);   // (lane slot 0 holds the group's first channel)
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       __builtin_amdgcn_wave_barrier();  // the scratch is rewritten by the next group / refilled by the next tile's loads

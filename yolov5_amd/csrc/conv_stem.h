@@ -172,6 +172,7 @@ void y5_conv_stem_kernel(const Y5StemParams p) {
       const uint4_t raw = *reinterpret_cast<const uint4_t*>(st + row * (NPAD * 2) + ((oslot ^ (row & SWM)) * 16));
       const int n = oslot * 8;
       if (n < p.C2) *reinterpret_cast<uint4_t*>(yg + (size_t)(m0 + row) * p.ldy + n) = raw;
+      Y5_EMU_VM_OP(true);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();

@@ -116,6 +116,16 @@ template <int N> __device__ __forceinline__ void y5_wait_vm() {
 #define Y5_DRAIN_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
 
+// Kernels whose counted waits also count their global STORES and register loads (conv_front.h, conv_bneck.h, conv_pw.h, conv_k3.h, conv_stem.h: every
+// vector-memory operation retires in issue order on ONE counter) mark each such instruction for the host emulator's worst-case landing model
+// (tests/hipemu, Y5_EMU_ASYNC=1), which can intercept the LDS-DMA builtin but not a plain load or store.  `wave_issues` restates when the WAVE issues the instruction (some lane's predicate holds): that, not the lane's own
+// predicate, is what the hardware counts.  Compiles to nothing on the GPU.
+#ifdef Y5_EMU
+#define Y5_EMU_VM_OP(wave_issues) do { if (wave_issues) emu::vm_op_note(); } while (0)
+#else
+#define Y5_EMU_VM_OP(wave_issues) ((void)0)
+#endif
+
 // compile-time loop: f(std::integral_constant<int, I>{}) for I in [B, E)
 template <int B, int E, typename F>
 __device__ __forceinline__ void y5_static_for(F&& f) {
