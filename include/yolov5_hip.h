@@ -552,6 +552,9 @@ int y5_plan_set_input(y5_plan*, int op_index, const void* src);  /* re-point a s
  * complete at the fork point and that no later op of the range reads their outputs (the Detect heads of the lower pyramid levels,
  * models/yolo.py:83-108, which only the final output depends on). */
 int y5_plan_set_branch(y5_plan*, int op_index, int branch);
+/* Tile configuration of a recorded y5_plan_add_conv op (the host's in-situ refinement of the tuner's isolated race: engine.py _refine_in_situ times the
+ * runner-up of every layer inside the running plan).  Only before the first graph capture; Y5_ERR_BAD_ARG for any other op kind. */
+int y5_plan_set_conv_cfg(y5_plan*, int op_index, int cfg);
 int y5_plan_set_anchors(y5_plan*, int op_index, const float* anchors_px, int n);  /* decode / fused-head op: new anchor sizes (px) */
 int y5_plan_add_nchw_to_nhwc(y5_plan*, const void* src, int src_dtype, void* dst, int dst_dtype, int B, int C, int H,
                              int W, int ld, float scale);

@@ -19,7 +19,8 @@ lib.y5_g8_dbg_read.restype = C.c_int
 lib.y5_g8_dbg_read.argtypes = [C.c_void_p]
 dev = torch.device("cuda:0")
 st = _lib.stream(dev)
-SHAPES = {"7": (64, 40, 256, 512, 3, 2), "5": (64, 80, 128, 256, 3, 2), "sppf": (64, 20, 1024, 512, 1, 1), "21": (64, 40, 256, 256, 3, 2), "x640": (16, 40, 640, 640, 3, 1)}
+SHAPES = {"7": (64, 40, 256, 512, 3, 2), "5": (64, 80, 128, 256, 3, 2), "sppf": (64, 20, 1024, 512, 1, 1), "21": (64, 40, 256, 256, 3, 2), "x640": (16, 40, 640, 640, 3, 1),
+          "3": (64, 160, 64, 128, 3, 2), "18": (64, 80, 128, 128, 3, 2), "6cv3": (64, 40, 256, 256, 1, 1)}
 for key in (sys.argv[1:] or ["7", "5"]):
     B, H, C1, C2, k, s = SHAPES[key]
     p = k // 2

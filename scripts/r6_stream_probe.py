@@ -20,6 +20,8 @@ LAYERS = [
     ("3.Conv 3x3s2 64->128 @160", 64, 160, 64, 128, 3, 2),
     ("18.Conv 3x3s2 128->128 @80", 64, 80, 128, 128, 3, 2),
     ("5.Conv 3x3s2 128->256 @80", 64, 80, 128, 256, 3, 2),
+    ("7.Conv 3x3s2 256->512 @40", 64, 40, 256, 512, 3, 2),
+    ("21.Conv 3x3s2 256->256 @40", 64, 40, 256, 256, 3, 2),
     ("4.cv3 1x1 128->128 @80", 64, 80, 128, 128, 1, 1),
 ]
 

@@ -110,6 +110,9 @@ CASES = [
     (2, 13, 11, 64, 256, 3, 1, 1, 1, True, False, 96, 1, "f16"),
     (2, 16, 16, 192, 320, 1, 1, 0, 1, False, False, 96, 3, "f16"),
     (3, 10, 10, 64, 384, 1, 1, 0, 1, True, False, 96, 1, "f16"),
+    # stride-2 3x3 walks the taps in the class order of Y5ConvParams::tap_seq: two chunks per tap (C1 = 128), odd image sizes, several tiles per workgroup
+    (3, 19, 21, 128, 96, 3, 2, 1, 1, False, False, 95, 1, "f16"),
+    (3, 19, 21, 128, 96, 3, 2, 1, 1, False, False, 96, 1, "f16"),
 ] + [
     # every fp16 tile configuration on one shape with M, N tails and K = 9*64 (uniform) / 9*48 (table for BK64)
     (2, 9, 9, c1, 160, 3, 1, 1, 1, True, False, cfg, 2, "f16") for cfg in list(range(14)) + list(range(22, 30)) + list(range(35, 56)) for c1 in (64, 48)

@@ -198,3 +198,56 @@ def test_benchmarked_plan_parity(case, rank, dev, monkeypatch, tmp_path):
           f"oracle rows img {pick}: box {ob.mean():.3g} score {oc.mean():.3g}; NMS bit-exact on {bs} images ({ndet} detections); "
           f"unpaired vs reference fp32 {un_h}/{st_h} (reference fp16: {un_r}/{st_r}); pipeline == sequential; "
           f"this host's oracle-fp16 vs the fixture's reference-fp16 rows (box, score mean): {track}")
+
+
+def test_in_situ_refinement_of_the_tuned_plan(dev, monkeypatch, tmp_path):
+    """Engine._refine_in_situ (round 6): on the first forward the runner-up of every plain convolution is timed inside the running plan and replaces the
+    isolated race's winner where it is faster in place.  Whatever it decides, (a) the refined plan's z agrees with the unrefined plan's to fp16 accumulation
+    noise, (b) the decisions persist -- a second engine of the same shape applies them WITHOUT a single timing launch -- and (c) a swapped launch really runs the
+    runner-up's configuration id (plan table)."""
+    import yolov5_amd.engine as eng_mod
+
+    name, bs = "yolov5s_640", 16
+    monkeypatch.setenv("Y5_TUNE_CACHE", str(tmp_path / "tune.json"))
+    eng_mod._TUNE_CACHE.clear()
+    eng_mod._TUNE_FILE_STATE["loaded"] = False
+    g, cfg, X, seg = _batch(name, bs)
+    xd = X.half().to(dev)
+
+    def run(disable):
+        if disable:
+            monkeypatch.setenv("Y5_DISABLE", "insitu_tune")
+        else:
+            monkeypatch.delenv("Y5_DISABLE", raising=False)
+        m = _build(name, g, dev, seg)
+        z = m(xd)[0].float().cpu().numpy()
+        eng = next(iter(m._engines.values()))
+        return z, eng
+
+    z0, e0 = run(True)
+    assert not hasattr(e0, "insitu_swaps")
+    z1, e1 = run(False)
+    swaps = getattr(e1, "insitu_swaps", None)
+    assert swaps is not None, "the refinement did not run (no convolution with a runner-up?)"
+    print(f"\n[in-situ refinement] {len(swaps)} swap(s): {swaps}")
+    t0, t1 = dict(e0.plan_table()), dict(e1.plan_table())
+    for op, best, second in swaps:
+        assert t0[op] == best and t1[op] == second, (op, t0[op], t1[op], best, second)
+    assert {k for k in t0 if t0[k] != t1[k]} == {op for op, _, _ in swaps}
+    assert any(k[-2] == eng_mod._INSITU_MARK for k in eng_mod._TUNE_CACHE if len(k) >= 2), "decisions were not written to the tile-choice cache"
+    np.testing.assert_allclose(z1, z0, rtol=2e-2, atol=2e-2 * max(1.0, np.abs(z0).max() / 64))
+    # a later engine (same process or another one reading the cache file): the stored decisions, no profile pass
+    calls = []
+    real = eng_mod.Engine._refine_in_situ
+
+    def spy(self, lo, hi):
+        try:
+            real(self, lo, hi)
+        finally:
+            calls.append(getattr(self, "insitu_swaps", "from-cache"))
+
+    monkeypatch.setattr(eng_mod.Engine, "_refine_in_situ", spy)
+    z2, e2 = run(False)
+    assert calls == ["from-cache"], calls
+    assert dict(e2.plan_table()) == t1
+    np.testing.assert_array_equal(z2, z1)

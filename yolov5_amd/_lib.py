@@ -214,6 +214,7 @@ EXPORTS = {
                                              C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "y5_plan_set_input": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "y5_plan_set_branch": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "y5_plan_set_conv_cfg": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "y5_plan_set_anchors": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int]),
     "y5_plan_add_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.c_int, C.c_int, C.c_float]),

@@ -87,6 +87,11 @@ __device__ __forceinline__ void y5_g8_act_row(const Y5ConvParams& p, int m, int 
   mask = ~mk;
 }
 
+#ifndef Y5_G8_ST_AUX
+#define Y5_G8_ST_AUX 0   // cache policy of the epilogue stores.  Kernel experiments: 2 = nt measured 1.2-2.9x SLOWER (profiles/r06/r06_stream_probe_v2_taps_nt.log:
+                         // the 32-byte pieces of a cache line arrive from four waves and are no longer merged in L2)
+#endif
+
 #ifdef Y5_G8_TIMING
 // kernel-experiment builds only: per workgroup (< 512) and wave row, stamps of the FIRST output tile -- s_memrealtime (100 MHz) at kernel entry / bias staged /
 // K tile 0 landed / K loop done / epilogue done, and the shader-clock length of the K loop (s_memtime)
@@ -96,7 +101,10 @@ __device__ unsigned long long y5_g8_dbg[512 * 2 * 8];
 #define Y5_G8_STAMP(i) ((void)0)
 #endif
 
-template <bool UP2>
+// SEQ: the K loop walks the taps in the order of Y5ConvParams::tap_seq (stride-2 3x3 launches) instead of the natural (kh, kw) order.  A separate instantiation:
+// the look-up walker costs a few scalar instructions per K tile inside the phase that holds the counted wait, and with it compiled into every launch the forward
+// lost 2.6 % (profiles/r06/r06_ab_tapseq_runtime_walker.log) -- the other layers keep the incremental walker untouched.
+template <bool UP2, bool SEQ = false>
 __global__ __launch_bounds__(512, 2)
 void y5_conv_g8_kernel(const Y5ConvParams p) {
   typedef half_t T;
@@ -136,9 +144,15 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
   bool st_up = false;
   unsigned a_mask[2][2];   // bit (kh * KW + kw) SET <=> that tap of this pixel lies outside the image (or the pixel is past M)
   unsigned w_off[2][2];    // byte offset of the filter row + source slot; bit 31 for rows past Npad
-  int u_kh = 0, u_kw = 0, u_c0 = 0, s_t = 0, s_kc = 0;
+  int u_kh = 0, u_kw = 0, u_c0 = 0, u_ts = 0, s_t = 0, s_kc = 0;
   int st_tap_off = 0, st_tap_bit = 0;
   unsigned st_kcb = 0;
+  const int kw_r = (256 + p.KW - 1) / p.KW;   // t / KW == (t * kw_r) >> 8 for t < 32, KW <= 7 (the tap-sequence walk)
+  auto tap_at = [&](int ts) __attribute__((always_inline)) {   // position ts of the launch's tap sequence -> (u_kh, u_kw)
+    const int t = (int)((unsigned)(p.tap_seq >> (ts * 4)) & 15u);
+    u_kh = (t * kw_r) >> 8;
+    u_kw = t - u_kh * p.KW;
+  };
 #ifdef Y5_G8_ABL_NODMA
   bool t_loop = false;   // ablation build: no LDS-DMA inside the K loop (the prologue's tiles are multiplied over and over)
 #endif
@@ -171,9 +185,10 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
       for (int jj = 0; jj < 2; ++jj) { a_mask[s][jj] = ~0u; w_off[s][jj] = 0x80000000u; }
   };
   auto tap_update = [&]() {
+    if constexpr (SEQ) tap_at(0);
     st_tap_off = ((u_kh * p.W + u_kw) * p.ldx + u_c0) * 2;
     st_tap_bit = u_kh * p.KW + u_kw;
-    st_kcb = (unsigned)(s_kc * 128);
+    st_kcb = SEQ ? (unsigned)((st_tap_bit * p.C1 + u_c0) * 2) : (unsigned)(s_kc * 128);
     if constexpr (UP2) st_up = u_c0 < p.up_c;   // (1x1 layer: st_tap_off is the chunk's channel offset; up_c % 64 == 0, a chunk never straddles the boundary)
   };
   // The loader's step to the next K tile in two halves (round 6, after the phase stamps): the SCALAR walker runs in q4, the phase with the shortest load segment
@@ -184,19 +199,32 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
   bool nx_up = false, nx_new = false;
   auto advance_scalar = [&]() __attribute__((always_inline)) {
     u_c0 += 64;
-    if (u_c0 >= p.C1) {
-      u_c0 = 0;
-      if (++u_kw == p.KW) { u_kw = 0; ++u_kh; }
-    }
-    nx_new = false;
-    if (++s_kc == nk) {
-      s_kc = 0; u_kh = 0; u_kw = 0; u_c0 = 0;
-      ++s_t;
-      nx_new = true;
+    if constexpr (SEQ) {
+      nx_new = false;
+      if (++s_kc == nk) {
+        s_kc = 0; u_c0 = 0; u_ts = 0;
+        ++s_t;
+        nx_new = true;
+        tap_at(0);
+      } else if (u_c0 >= p.C1) {
+        u_c0 = 0;
+        tap_at(++u_ts);
+      }
+    } else {
+      if (u_c0 >= p.C1) {
+        u_c0 = 0;
+        if (++u_kw == p.KW) { u_kw = 0; ++u_kh; }
+      }
+      nx_new = false;
+      if (++s_kc == nk) {
+        s_kc = 0; u_kh = 0; u_kw = 0; u_c0 = 0;
+        ++s_t;
+        nx_new = true;
+      }
     }
     nx_tap_off = ((u_kh * p.W + u_kw) * p.ldx + u_c0) * 2;
     nx_tap_bit = u_kh * p.KW + u_kw;
-    nx_kcb = (unsigned)(s_kc * 128);
+    nx_kcb = SEQ ? (unsigned)((nx_tap_bit * p.C1 + u_c0) * 2) : (unsigned)(s_kc * 128);
     if constexpr (UP2) nx_up = u_c0 < p.up_c;
   };
   auto advance_commit = [&]() __attribute__((always_inline)) {
@@ -341,8 +369,8 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
             for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)a[e] + (float)b[e]);
             raw = __builtin_bit_cast(uint4_t, o);
           }
-          y5_buffer_store16(raw, yrs, ok && !to2 ? e_rb + fr * p.ldy * 2 + n * 2 : (int)0x80000000u, 0);
-          if constexpr (MODE == 2) y5_buffer_store16(raw, y2rs, ok && to2 ? e_rb2 + fr * p.ld2 * 2 + (n - p.split_n) * 2 : (int)0x80000000u, 0);
+          y5_buffer_store16(raw, yrs, ok && !to2 ? e_rb + fr * p.ldy * 2 + n * 2 : (int)0x80000000u, Y5_G8_ST_AUX);
+          if constexpr (MODE == 2) y5_buffer_store16(raw, y2rs, ok && to2 ? e_rb2 + fr * p.ld2 * 2 + (n - p.split_n) * 2 : (int)0x80000000u, Y5_G8_ST_AUX);
         }
       }
     }
@@ -468,7 +496,7 @@ struct Y5G8nGeom {
   static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
-template <bool UP2>
+template <bool UP2, bool SEQ = false>
 __global__ __launch_bounds__(512, 2)
 void y5_conv_g8n_kernel(const Y5ConvParams p) {
   typedef half_t T;
@@ -501,8 +529,19 @@ void y5_conv_g8n_kernel(const Y5ConvParams p) {
   bool st_up = false;
   unsigned a_mask[2][2];
   unsigned w_off[2];
-  int u_kh = 0, u_kw = 0, u_c0 = 0, a_t = 0, a_kc = 0, w_t = 0, w_kc = 0;
+  int u_kh = 0, u_kw = 0, u_c0 = 0, u_ts = 0, a_t = 0, a_kc = 0, w_t = 0, w_kc = 0, w_ts = 0, w_c0 = 0;
   int st_tap_off = 0, st_tap_bit = 0;
+  unsigned w_kcb = 0;   // byte offset of the filter walker's K tile inside a filter row
+  const int kw_r = (256 + p.KW - 1) / p.KW;   // (see y5_conv_g8_kernel)
+  auto tap_at = [&](int ts) __attribute__((always_inline)) {
+    const int t = (int)((unsigned)(p.tap_seq >> (ts * 4)) & 15u);
+    u_kh = (t * kw_r) >> 8;
+    u_kw = t - u_kh * p.KW;
+  };
+  auto wgt_kcb = [&]() __attribute__((always_inline)) {
+    const int t = (int)((unsigned)(p.tap_seq >> (w_ts * 4)) & 15u);
+    w_kcb = (unsigned)((t * p.C1 + w_c0) * 2);
+  };
 
   auto tile_coords = [&](int j, int& m0, int& n0) {
     const int t = y5_xcd_remap(bid + j * G, ntiles);
@@ -540,12 +579,17 @@ void y5_conv_g8n_kernel(const Y5ConvParams p) {
   };
   auto adv_act = [&]() __attribute__((always_inline)) {
     u_c0 += 64;
-    if (u_c0 >= p.C1) {
-      u_c0 = 0;
-      if (++u_kw == p.KW) { u_kw = 0; ++u_kh; }
+    if constexpr (SEQ) {
+      if (u_c0 >= p.C1 && a_kc + 1 < nk) { u_c0 = 0; tap_at(++u_ts); }
+    } else {
+      if (u_c0 >= p.C1) {
+        u_c0 = 0;
+        if (++u_kw == p.KW) { u_kw = 0; ++u_kh; }
+      }
     }
     if (++a_kc == nk) {
-      a_kc = 0; u_kh = 0; u_kw = 0; u_c0 = 0;
+      a_kc = 0; u_kh = 0; u_kw = 0; u_c0 = 0; u_ts = 0;
+      if constexpr (SEQ) tap_at(0);
       if (++a_t < nmine) act_setup(a_t);
       else {
 #pragma unroll
@@ -557,11 +601,16 @@ void y5_conv_g8n_kernel(const Y5ConvParams p) {
     tap_update();
   };
   auto adv_wgt = [&]() __attribute__((always_inline)) {
+    if constexpr (SEQ) {
+      w_c0 += 64;
+      if (w_c0 >= p.C1) { w_c0 = 0; ++w_ts; }
+    }
     if (++w_kc == nk) {
-      w_kc = 0;
+      w_kc = 0; w_ts = 0; w_c0 = 0;
       if (++w_t < nmine) wgt_setup(w_t);
       else { w_off[0] = 0x80000000u; w_off[1] = 0x80000000u; }
     }
+    if constexpr (SEQ) wgt_kcb();
   };
   auto stage_act = [&](auto sc, char* buf) __attribute__((always_inline)) {
     constexpr int s = decltype(sc)::value;
@@ -579,7 +628,7 @@ void y5_conv_g8n_kernel(const Y5ConvParams p) {
   };
   auto stage_wgt = [&](char* buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) y5_bglds16(wrs, w_off[jj] + (unsigned)(w_kc * 128), buf + 2 * HT + (wave * 2 + jj) * 1024);
+    for (int jj = 0; jj < 2; ++jj) y5_bglds16(wrs, w_off[jj] + (SEQ ? w_kcb : (unsigned)(w_kc * 128)), buf + 2 * HT + (wave * 2 + jj) * 1024);
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -658,8 +707,8 @@ void y5_conv_g8n_kernel(const Y5ConvParams p) {
           for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)a[e] + (float)b[e]);
           raw = __builtin_bit_cast(uint4_t, o);
         }
-        y5_buffer_store16(raw, yrs, ok && !to2 ? e_rb + fr * p.ldy * 2 + n * 2 : (int)0x80000000u, 0);
-        if constexpr (MODE == 2) y5_buffer_store16(raw, y2rs, ok && to2 ? e_rb2 + fr * p.ld2 * 2 + (n - p.split_n) * 2 : (int)0x80000000u, 0);
+        y5_buffer_store16(raw, yrs, ok && !to2 ? e_rb + fr * p.ldy * 2 + n * 2 : (int)0x80000000u, Y5_G8_ST_AUX);
+        if constexpr (MODE == 2) y5_buffer_store16(raw, y2rs, ok && to2 ? e_rb2 + fr * p.ld2 * 2 + (n - p.split_n) * 2 : (int)0x80000000u, Y5_G8_ST_AUX);
       }
     }
   };
@@ -672,7 +721,9 @@ void y5_conv_g8n_kernel(const Y5ConvParams p) {
   // ---- prologue: K tiles 0 and 1 complete, the filter half-tile of K tile 2 ----
   act_setup(0);
   wgt_setup(0);
+  if constexpr (SEQ) tap_at(0);
   tap_update();
+  if constexpr (SEQ) wgt_kcb();
   stage_wgt(smem); adv_wgt(); stage_act(I0{}, smem); stage_act(I1{}, smem); adv_act();
   stage_wgt(smem + BUF); adv_wgt(); stage_act(I0{}, smem + BUF); stage_act(I1{}, smem + BUF); adv_act();
   stage_wgt(smem + 2 * BUF); adv_wgt();

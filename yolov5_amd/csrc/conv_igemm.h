@@ -73,6 +73,11 @@ struct Y5ConvParams {
   float* bn_partial;
   size_t bn_bytes;         // host side: capacity of bn_partial
   int* bn_rows;            // host side: receives the number of rows (= grid size) of this launch
+  // conv_g8.h: the ORDER in which the K loop walks the filter taps -- 4 bits per position, position i holds the tap kh * KW + kw staged i-th; 0 = natural
+  // order.  Stride-2 3x3 layers walk the taps grouped by the input-pixel class they touch ((odd row, odd column): four taps, ...), so that a cache line is
+  // re-requested in the NEXT K tiles instead of six K tiles later (set by the host launcher, convg8.hip; needs KH * KW <= 16, KW <= 7; LAST member: the
+  // other kernels' argument offsets stay as they were)
+  unsigned long long tap_seq;
 };
 
 __host__ __device__ inline void y5_fastdiv_make(unsigned d, unsigned* m, int* s) {

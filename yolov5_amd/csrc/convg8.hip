@@ -7,16 +7,23 @@
 
 // idx 0 (id 95): 256 pixels x 256 channels; idx 1 (id 96): 256 pixels x 128 channels; K tile 64, mfma_f32_32x32x16_f16
 template <typename Gm, typename K>
-static int launch_g8(K kern, const Y5ConvParams& p0, int max_blocks, hipStream_t stream) {
+static int launch_g8(K kern, const Y5ConvParams& p0, int max_blocks, hipStream_t stream, bool seq_kernel = false) {
   Y5ConvParams p = p0;
   p.tilesM = (p.M + Gm::BM - 1) / Gm::BM;
   p.tilesN = (p.Npad + Gm::BN - 1) / Gm::BN;
   p.nk = p.K / Gm::BK;
   y5_conv_set_fastdiv(p);
-  static const void* attr_done[2] = {nullptr, nullptr};   // (the <true> / <false> instantiations share this function: same pointer type)
-  if (attr_done[0] != reinterpret_cast<const void*>(kern) && attr_done[1] != reinterpret_cast<const void*>(kern)) {
+  // Stride-2 3x3: taps grouped by the class of input pixel they touch -- (odd row, odd column): the four corner taps; (odd, even): (0,1), (2,1); (even, odd):
+  // (1,0), (1,2); (even, even): the centre -- so every re-request of a cache line follows within the next three K tiles (Y5ConvParams::tap_seq)
+  p.tap_seq = 0;
+  if (seq_kernel) {
+    static const int seq[9] = {0, 2, 6, 8, 1, 7, 3, 5, 4};
+    for (int i = 0; i < 9; ++i) p.tap_seq |= (unsigned long long)seq[i] << (4 * i);
+  }
+  static const void* attr_done[3] = {nullptr, nullptr, nullptr};   // (the instantiations of one geometry share this function: same pointer type)
+  if (attr_done[0] != reinterpret_cast<const void*>(kern) && attr_done[1] != reinterpret_cast<const void*>(kern) && attr_done[2] != reinterpret_cast<const void*>(kern)) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done[attr_done[0] ? 1 : 0] = reinterpret_cast<const void*>(kern);
+    attr_done[!attr_done[0] ? 0 : !attr_done[1] ? 1 : 2] = reinterpret_cast<const void*>(kern);
   }
   const long long ntiles = (long long)p.tilesM * p.tilesN;
   if (ntiles <= 0 || ntiles > 0x7fffffffLL) return y5_fail(Y5_ERR_BAD_ARG, "conv: grid out of range");
@@ -31,9 +38,14 @@ int y5_launch_g8_by_cfg(const Y5ConvParams& p, int idx, int max_blocks, hipStrea
   if (p.C1 % 64 || p.KH * p.KW > 32 || p.Kpad % 64 || p.Npad > Y5G8Geom::MAXN)
     return y5_fail(Y5_ERR_UNSUPPORTED, "conv: the 8-phase configurations need C1 % 64 == 0, Kpad % 64 == 0, KH * KW <= 32 and Npad <= 2048");
   const bool up = p.up_c > 0;   // virtual Upsample + Concat loader (1x1 s1 layers; validated by the caller)
+  const bool seq = !up && p.KH == 3 && p.KW == 3 && p.SH == 2 && p.SW == 2;   // class-ordered taps (launch_g8 fills Y5ConvParams::tap_seq)
   switch (idx) {
-    case 0: return up ? launch_g8<Y5G8Geom>(y5_conv_g8_kernel<true>, p, max_blocks, stream) : launch_g8<Y5G8Geom>(y5_conv_g8_kernel<false>, p, max_blocks, stream);
-    case 1: return up ? launch_g8<Y5G8nGeom>(y5_conv_g8n_kernel<true>, p, max_blocks, stream) : launch_g8<Y5G8nGeom>(y5_conv_g8n_kernel<false>, p, max_blocks, stream);
+    case 0:
+      if (seq) return launch_g8<Y5G8Geom>(y5_conv_g8_kernel<false, true>, p, max_blocks, stream, true);
+      return up ? launch_g8<Y5G8Geom>(y5_conv_g8_kernel<true>, p, max_blocks, stream) : launch_g8<Y5G8Geom>(y5_conv_g8_kernel<false>, p, max_blocks, stream);
+    case 1:
+      if (seq) return launch_g8<Y5G8nGeom>(y5_conv_g8n_kernel<false, true>, p, max_blocks, stream, true);
+      return up ? launch_g8<Y5G8nGeom>(y5_conv_g8n_kernel<true>, p, max_blocks, stream) : launch_g8<Y5G8nGeom>(y5_conv_g8n_kernel<false>, p, max_blocks, stream);
   }
   return y5_fail(Y5_ERR_BAD_ARG, "conv: unknown 8-phase config");
 }

@@ -333,6 +333,13 @@ extern "C" int y5_plan_set_branch(y5_plan* pl, int op, int branch) {
   return Y5_OK;
 }
 
+extern "C" int y5_plan_set_conv_cfg(y5_plan* pl, int op, int cfg) {
+  if (!pl || op < 0 || op >= (int)pl->ops.size() || pl->ops[op].kind != OP_CONV) return y5_fail(Y5_ERR_BAD_ARG, "plan_set_conv_cfg: not a convolution op");
+  if (pl->graph || !pl->cache.empty()) return y5_fail(Y5_ERR_BAD_ARG, "plan_set_conv_cfg: the plan has captured graphs");
+  pl->ops[op].conv.cfg = cfg;
+  return Y5_OK;
+}
+
 static hipEvent_t plan_event(y5_plan* pl, size_t idx) {
   while (pl->events.size() <= idx) {
     hipEvent_t e = nullptr;

@@ -52,6 +52,7 @@ __device__ __forceinline__ void y5_buffer_store16(uint4_t v, y5_rsrc_t r, int vo
   if ((unsigned long long)(unsigned)voff + 16 <= r.num_records) memcpy(const_cast<char*>(r.base) + (unsigned)voff, &v, 16);   // (out of range: dropped, as the hardware does)
 #else
   if (aux == 16) __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 16);
+  else if (aux == 2) __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 2);   // nt: streaming data (kernel experiments)
   else __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 0);
 #endif
 }

@@ -436,6 +436,8 @@ def folded_weights(mods):
 
 
 _TUNE_CACHE = {}  # conv descriptor (shape/dtype/strides) -> fastest tile configuration id, per process
+_LAST_RACE = [None, None]  # key and (best, runner-up) of the latest autotune_conv call (Engine._refine_in_situ)
+_INSITU_MARK = -777        # key suffix (_INSITU_MARK, plan index): the configuration the in-situ refinement settled on for that op of that plan
 
 
 SK_CFGS = frozenset(range(57, 61))  # stream-K configurations: they share one registered workspace (include/yolov5_hip.h)
@@ -450,6 +452,7 @@ def autotune_conv(lib, d, ptrs, st, exclude=()):
     _load_tune_cache()
     rank = int(os.environ.get("Y5_TUNE_RANK", "0"))  # 1: the RUNNER-UP of every race (parity tests cover the plans a near-tie could select)
     hit = _TUNE_CACHE.get(key)
+    _LAST_RACE[:] = [key, hit]
     if hit is not None and (rank == 0 or hit[1] >= 0):
         return hit[1] if rank else hit[0]
     ncfg = lib.y5_conv_num_cfgs() if d.dtype == _lib.Y5_F16 else 4
@@ -505,6 +508,7 @@ def autotune_conv(lib, d, ptrs, st, exclude=()):
     if second < 0:
         second = best  # a single applicable configuration: the runner-up plan keeps it
     _TUNE_CACHE[key] = (best, second)
+    _LAST_RACE[:] = [key, (best, second)]
     _save_tune_cache()
     return second if rank else best
 
@@ -708,6 +712,7 @@ class Engine:
         self.plan = C.c_void_p(self.lib.y5_plan_create())
         self.op_names = []
         self.conv_cfgs = []
+        self._insitu = []      # plain convolution ops with a runner-up configuration: candidates of _refine_in_situ (first forward)
         self._first_op = None
         self._stem = None      # plan index of the fused NCHW stem op (conv_stem.h), appended after the regular ops
         self._stem_args = None
@@ -1001,6 +1006,9 @@ class Engine:
             # (measured, scripts/streamk_bench.py: at yolov5s bs=64 sizes the slab round trip costs more than the tail it removes --
             # 60-119 us against 42-69 us for the plain tiles -- so they only enter the race when asked for: Y5_EXPERIMENTAL=streamk)
             d.cfg = self._autotune_conv(d, ptrs, exclude=SK_CFGS if (op.get("side") or not _lib.experimental("streamk")) else ())
+            race = tuple(_LAST_RACE)   # (key, (winner, runner-up)) of THIS op's race: the fusion checks below may run further races
+        else:
+            race = (None, None)
         k3pw = self._fused_k3pw_args(op, d, ptrs)
         if k3pw is not None:
             self._k3pw_skip = self._cur + 1
@@ -1017,6 +1025,8 @@ class Engine:
             if rc == 0 and self._hint:
                 rc = self.lib.y5_plan_set_obj_hint(self.plan, self.lib.y5_plan_size(self.plan) - 1, C.c_void_p(self.be.ptr(self._hint_t)))
             return rc
+        if race[1] is not None and int(d.cfg) == race[1][0] and not op.get("side"):
+            self._insitu.append(dict(idx=self.lib.y5_plan_size(self.plan), slot=len(self.conv_cfgs), key=race[0], best=race[1][0], second=race[1][1]))
         self.conv_cfgs.append(int(d.cfg))
         self.op_names.append("conv:" + op["name"])
         return self.lib.y5_plan_add_conv(self.plan, C.byref(d), self._ptr(x), C.c_void_p(self.be.ptr(wp)), C.c_void_p(self.be.ptr(bp)),
@@ -1223,6 +1233,8 @@ class Engine:
             body0 = 4 if self._front is not None else 2
             _lib.check(self.lib.y5_plan_set_input(self.plan, head, C.c_void_p(xptr)), self.lib)
             _lib.check(self.lib.y5_plan_run_range(self.plan, head, head + 1, st), self.lib)
+            if self._insitu and not self._graph:
+                self._refine_in_situ(body0, self._stem)
             if self._use_graph:
                 # the body only touches plan-owned buffers and the bound outputs: replayed as ONE hipGraph launch (captured on first
                 # use of every output binding)
@@ -1240,6 +1252,8 @@ class Engine:
         scale = 1.0 / 255.0 if src_dt == _lib.Y5_U8 else 1.0  # train.py:379 / detect.py:209: uint8 images -> 0..1
         _lib.check(self.lib.y5_nchw_to_nhwc(C.c_void_p(xptr), src_dt, self._ptr(d), self.dt, B, cin, d.H, d.W, self._ld(d),
                                             scale, st), self.lib)
+        if self._insitu:
+            self._refine_in_situ(1, n if self._stem is None else self._stem)
         _lib.check(self.lib.y5_plan_run_range(self.plan, 1, n if self._stem is None else self._stem, st), self.lib)
         return self._tag_hint()
 
@@ -1283,6 +1297,61 @@ class Engine:
         if changed or not self._graph:
             key = hash((getattr(self, "_graph_gen", 0),) + tuple(sorted(self._bound.items()))) & 0xFFFFFFFFFFFFFFFF
             self._graph = self.lib.y5_plan_select_graph(self.plan, key) == 1
+
+    def _refine_in_situ(self, lo, hi):
+        """The tuner races configurations on ISOLATED back-to-back launches (warm caches, no neighbours); inside the forward a launch starts behind another
+        kernel's tail with cold caches, and configurations differ in how much that costs them -- a near tie flipped 21.Conv from id 96 (38.6 us in situ) to id 40
+        (49.2 us in situ; 38.7 vs 39.3 isolated: profiles/r06/r06_ab_tapseq_runtime_walker.log).  So, once per plan and before its graph is captured, the
+        runner-up of every plain convolution is timed IN its place: one in-situ profile of ops [lo, hi) with every winner, one with every runner-up, a
+        runner-up replaces a winner when it is more than 3 % faster where it runs, and a last profile keeps the mix only if the whole range did not get slower.
+        Decisions persist in the tile-choice cache (key + (_INSITU_MARK, plan index)): later processes -- clean rocprof traces, production -- apply them without
+        timing.  Y5_DISABLE=insitu_tune switches it off; runner-up plans (Y5_TUNE_RANK=1) are left alone."""
+        cands = [c for c in self._insitu if lo <= c["idx"] < hi and c["second"] >= 0 and c["second"] != c["best"]]
+        self._insitu = []
+        if not cands or _lib.disabled("insitu_tune") or int(os.environ.get("Y5_TUNE_RANK", "0")):
+            return
+        lib, st = self.lib, self._stream()
+
+        def apply(c, cfg):
+            _lib.check(lib.y5_plan_set_conv_cfg(self.plan, c["idx"], cfg), lib)
+            self.conv_cfgs[c["slot"]] = cfg
+
+        stored = [_TUNE_CACHE.get(c["key"] + (_INSITU_MARK, c["idx"])) for c in cands]
+        if all(s is not None for s in stored):
+            for c, s in zip(cands, stored):
+                if s[0] != c["best"]:
+                    apply(c, s[0])
+            return
+
+        def profile():
+            buf = (C.c_float * (hi - lo))()
+            _lib.check(lib.y5_plan_profile_range(self.plan, lo, hi, 9, st, buf), lib)
+            return [float(v) for v in buf]
+
+        t_best = profile()
+        for c in cands:
+            apply(c, c["second"])
+        try:
+            t_second = profile()
+        except RuntimeError:   # a runner-up the plan cannot launch in place: the winners stay
+            for c in cands:
+                apply(c, c["best"])
+            return
+        swapped = []
+        for c in cands:
+            k = c["idx"] - lo
+            if t_second[k] < 0.97 * t_best[k]:
+                swapped.append(c)
+            else:
+                apply(c, c["best"])
+        if swapped and sum(profile()) > sum(t_best):
+            for c in swapped:
+                apply(c, c["best"])
+            swapped = []
+        for c in cands:
+            _TUNE_CACHE[c["key"] + (_INSITU_MARK, c["idx"])] = (c["second"] if c in swapped else c["best"], -1)
+        self.insitu_swaps = [(self.op_names[c["idx"]], c["best"], c["second"]) for c in swapped]
+        _save_tune_cache()
 
     def plan_table(self):
         """[(op name, tile configuration id | "stem" | "bneck" | None)] in launch order: what the autotuner / the fusion races chose for this
