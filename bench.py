@@ -1159,6 +1159,13 @@ def main():
             res["config"]["gpu_state"] = {"sclk_mhz": max(sm) if sm else None, "mfma_sustained_tflops": sus}
         except Exception:
             res["value_at_ref_clock"] = None
+        try:   # where the plan's tile choices came from: the database shipped with the kernels (yolov5_amd/tune_db.json, engine._load_tune_cache) or races run here
+            from yolov5_amd import engine as _eng
+
+            res["config"]["tile_choices"] = {"from_shipped_db": _eng.TUNE_STATS["db_entries"], "races_run_here": _eng.TUNE_STATS["races"],
+                                             "in_situ_swaps": [list(s) for e in getattr(model, "_engines", {}).values() for s in getattr(e, "insitu_swaps", [])]}
+        except Exception:
+            pass
         if pipeline is not None:
             res["pipeline"] = pipeline
         if train is not None:

@@ -20,6 +20,7 @@ if [ "$WHAT" = "all" ] || [ "$WHAT" = "prof" ]; then
   rm -rf gpurun_out/prof
   # tile choices cached by a first plain run: the profiled run launches no autotune timing kernels
   export Y5_TUNE_CACHE=/tmp/y5_tune_prof.json
+  [ -n "$Y5_SEED_TUNE_CACHE" ] && [ -f "$Y5_SEED_TUNE_CACHE" ] && cp "$Y5_SEED_TUNE_CACHE" "$Y5_TUNE_CACHE"   # (scripts/r6_final.sh: the timed run's choices)
   timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train --no-configs --no-selfcheck > /dev/null 2>&1
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o r -- python "$OLDPWD/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-train --no-configs --no-selfcheck > "$OLDPWD/gpurun_out/prof.log" 2>&1); echo "prof rc=$?"
   find gpurun_out/prof -name "*stats*" | head; 
@@ -35,6 +36,7 @@ fi
 if [ "$WHAT" = "all" ] || [ "$WHAT" = "train" ]; then
   # training step: per-kernel summary with warm tile / split choices (the first plain run fills the cache)
   export Y5_TUNE_CACHE=/tmp/y5_tune_train.json
+  [ -n "$Y5_SEED_TUNE_CACHE" ] && [ -f "$Y5_SEED_TUNE_CACHE" ] && cp "$Y5_SEED_TUNE_CACHE" "$Y5_TUNE_CACHE"
   timeout 300 python scripts/train_bench.py --steps 5 --warmup 3 > gpurun_out/train_bench.log 2>&1; tail -1 gpurun_out/train_bench.log
   rm -rf gpurun_out/trainprof
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/trainprof" -o t -- python "$OLDPWD/scripts/train_bench.py" --steps 10 --warmup 3 > "$OLDPWD/gpurun_out/train_prof.log" 2>&1); echo "train prof rc=$?"

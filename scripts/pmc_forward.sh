@@ -4,6 +4,8 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp Y5_TUNE_CACHE=/tmp/tc_fwd.json Y5_GRAPH=0
+# the timed bench run's tile choices and in-situ decisions (scripts/r6_final.sh exports the file): the profiled plan is the timed plan
+[ -n "$Y5_SEED_TUNE_CACHE" ] && [ -f "$Y5_SEED_TUNE_CACHE" ] && cp "$Y5_SEED_TUNE_CACHE" "$Y5_TUNE_CACHE"
 # fusion decisions forced on (what the timing at plan build picks on this part): the profiled process launches no fused-vs-unfused timing kernels
 export Y5_FUSED_K3PW=1 Y5_FUSED_CV3=1 Y5_FUSED_HEAD=1 Y5_FUSED_FRONT=1
 N=10

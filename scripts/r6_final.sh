@@ -10,6 +10,8 @@ export Y5_TUNE_CACHE=/tmp/tc_final.json
 timeout 900 python bench.py --op-table $O/op_table.json > $O/bench.log 2>&1; echo "bench rc=$?"; grep '^{' $O/bench.log | tail -1 > $O/bench.json
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.log 2>&1; grep '^{' $O/bench_driver_cmd.log | tail -1 > $O/bench_driver_cmd.json
 timeout 600 python bench.py --model yolov5x --batch 16 --imgsz 1280 --no-train --no-pipeline --no-configs --no-cpu-baseline --no-selfcheck --steps 20 --warmup 5 --op-table $O/op_table_yolov5x.json > $O/bench_yolov5x.log 2>&1; grep '^{' $O/bench_yolov5x.log | tail -1 > $O/bench_yolov5x.json
+cp /tmp/tc_final.json $O/tune_db.json   # -> yolov5_amd/tune_db.json (engine._load_tune_cache): the choices of the plans timed above, bound to this library build
+export Y5_SEED_TUNE_CACHE=/tmp/tc_final.json
 unset Y5_TUNE_CACHE
 bash scripts/pmc_forward.sh > $O/pmc_forward.log 2>&1; cp gpurun_out/pmc_forward.json $O/ 2>/dev/null; tail -14 $O/pmc_forward.log
 bash scripts/pmc_issue_mix.sh > $O/pmc_issue_mix.log 2>&1; cp gpurun_out/pmc_issue_mix.json $O/ 2>/dev/null; grep mfma_busy_frac $O/pmc_issue_mix.log | head -2 | cut -c1-300

@@ -289,3 +289,52 @@ def test_tune_cache_is_bound_to_the_kernel_library(tmp_path, monkeypatch):
     finally:
         eng._TUNE_CACHE.clear(); eng._TUNE_CACHE.update(saved)
         eng._TUNE_FILE_STATE.clear(); eng._TUNE_FILE_STATE.update(state)
+
+
+def test_shipped_tune_database_seeds_the_choices(tmp_path, monkeypatch):
+    """yolov5_amd/tune_db.json (engine._load_tune_cache): taken when it was written for THIS build of the library and no cache file was named explicitly;
+    ignored for another build, with Y5_TUNE_CACHE set (tests and profiling scripts keep their own races) and with Y5_TUNE_DB=0; the user's cache wins."""
+    import json
+
+    from yolov5_amd import engine as eng
+
+    db = tmp_path / "tune_db.json"
+    monkeypatch.setattr(eng, "TUNE_DB_PATH", str(db))
+    monkeypatch.setenv("HOME", str(tmp_path))   # the default cache path lives under ~/.cache
+    saved, state, stats = dict(eng._TUNE_CACHE), dict(eng._TUNE_FILE_STATE), dict(eng.TUNE_STATS)
+
+    def load(**env):
+        for k in ("Y5_TUNE_CACHE", "Y5_TUNE_DB"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng._TUNE_CACHE.clear()
+        eng._TUNE_FILE_STATE["loaded"] = False
+        eng.TUNE_STATS["db_entries"] = 0
+        eng._load_tune_cache()
+        return dict(eng._TUNE_CACHE)
+
+    try:
+        eng._TUNE_FILE_STATE.pop("stamp", None)
+        json.dump({"__lib_sha16__": eng._lib_stamp(), "1,2,True": [96, 40], "1,2,True,-777,33": [40, -1]}, open(db, "w"))
+        want = {(1, 2, True): (96, 40), (1, 2, True, eng._INSITU_MARK, 33): (40, -1)}
+        assert load() == want and eng.TUNE_STATS["db_entries"] == 2
+        assert load(Y5_TUNE_DB="0") == {}
+        assert load(Y5_TUNE_CACHE=str(tmp_path / "own.json")) == {}
+        assert load(Y5_TUNE_CACHE="off") == {}
+        # the user's cache (default path; None where the HIP library cannot be loaded, as on a CPU-only host) overrides an entry of the database
+        path = eng._tune_cache_path()
+        if path:
+            import os
+
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            json.dump({"__lib_sha16__": eng._lib_stamp(), "1,2,True": [43, 96]}, open(path, "w"))
+            got = load()
+            assert got[(1, 2, True)] == (43, 96) and got[(1, 2, True, eng._INSITU_MARK, 33)] == (40, -1)
+            os.remove(path)
+        json.dump({"__lib_sha16__": "0123456789abcdef", "1,2,True": [96, 40]}, open(db, "w"))   # written for another build of the kernels
+        assert load() == {} and eng.TUNE_STATS["db_entries"] == 0
+    finally:
+        eng._TUNE_CACHE.clear(); eng._TUNE_CACHE.update(saved)
+        eng._TUNE_FILE_STATE.clear(); eng._TUNE_FILE_STATE.update(state)
+        eng.TUNE_STATS.update(stats)

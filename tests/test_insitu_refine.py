@@ -87,6 +87,15 @@ def test_refinement_decisions(monkeypatch, tmp_path, clean_cache):
     assert lib2.calls == 0 and eng2.conv_cfgs[slot[a]] == 0 and not hasattr(eng2, "insitu_swaps")
     np.testing.assert_array_equal(np.asarray(eng2(x)["z"]).astype(np.float32), z_swapped)
 
+    # (2b) faster in the runner-up profile, not confirmed by the closing profile: goes back
+    eng_mod._TUNE_CACHE.clear()
+    eng2b = _engine(monkeypatch, tmp_path)
+    lib2b = _Lib(eng2b.lib, [{a: 1.0, b: 1.0}, {a: 0.9, b: 0.9}, {a: 0.9, b: 0.99}])
+    eng2b.lib = lib2b
+    eng2b._insitu = cands(eng2b)
+    eng2b._refine_in_situ(1, hi)
+    assert lib2b.calls == 3 and eng2b.insitu_swaps == [(names[a], best_a, 0)] and eng2b.conv_cfgs[slot[b]] == best_b
+
     # (3) a faster launch but a slower range (the closing profile): everything goes back
     eng_mod._TUNE_CACHE.clear()
     eng3 = _engine(monkeypatch, tmp_path)

@@ -472,6 +472,7 @@ def autotune_conv(lib, d, ptrs, st, exclude=()):
         if d.SH == 2 and d.KH == 3:
             skip.update(range(61, 78))
     timed = []
+    TUNE_STATS["races"] += 1
     for cfg in range(ncfg):
         if cfg in skip or cfg in exclude:
             continue
@@ -545,23 +546,46 @@ def _lib_stamp():
     return _TUNE_FILE_STATE["stamp"]
 
 
-def _load_tune_cache():
-    path = _tune_cache_path()
-    if not path or _TUNE_FILE_STATE["loaded"]:
-        return
-    _TUNE_FILE_STATE["loaded"] = True
+TUNE_DB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tune_db.json")
+TUNE_STATS = {"db_entries": 0, "races": 0}   # entries taken from the shipped database / races run by this process (bench.py reports both)
+
+
+def _read_tune_file(path):
+    """{key tuple: (best, runner-up)} of a tile-choice file written for THIS build of the kernel library, else {}."""
     try:
         import json
 
         with open(path) as f:
             d = json.load(f)
-            if d.pop("__lib_sha16__", None) != _lib_stamp():
-                return
-            for k, v in d.items():
-                v = (int(v), -1) if not isinstance(v, (list, tuple)) else (int(v[0]), int(v[1]))  # (best, runner-up); older files: best only
-                _TUNE_CACHE[tuple(int(x) if x not in ("True", "False") else x == "True" for x in k.split(","))] = v
+        if d.pop("__lib_sha16__", None) != _lib_stamp():
+            return {}
+        out = {}
+        for k, v in d.items():
+            v = (int(v), -1) if not isinstance(v, (list, tuple)) else (int(v[0]), int(v[1]))  # (best, runner-up); older files: best only
+            out[tuple(int(x) if x not in ("True", "False") else x == "True" for x in k.split(","))] = v
+        return out
     except (OSError, ValueError):
-        pass
+        return {}
+
+
+def _load_tune_cache():
+    """Tile choices known before any race: the user's cache file (_tune_cache_path) and -- only when no cache was named explicitly with Y5_TUNE_CACHE --
+    the database shipped beside the library (yolov5_amd/tune_db.json: the races and in-situ decisions of the benchmarked plans, written on an MI355X by
+    scripts/r6_final.sh with the committed kernels).  Like the cache it is bound to the library's hash: after any kernel change it is ignored and every
+    choice is raced again on the spot.  With it, a bench run executes exactly the plan whose counter files are committed under profiles/pmc/.
+    Y5_TUNE_DB=0 ignores it."""
+    if _TUNE_FILE_STATE["loaded"]:
+        return
+    path = _tune_cache_path()
+    if os.environ.get("Y5_TUNE_CACHE") is None and os.environ.get("Y5_TUNE_DB", "1") != "0":
+        _TUNE_FILE_STATE["loaded"] = True
+        db = _read_tune_file(TUNE_DB_PATH)
+        TUNE_STATS["db_entries"] = len(db)
+        _TUNE_CACHE.update(db)
+    if not path:
+        return
+    _TUNE_FILE_STATE["loaded"] = True
+    _TUNE_CACHE.update(_read_tune_file(path))
 
 
 def _save_tune_cache():
@@ -1303,7 +1327,8 @@ class Engine:
         kernel's tail with cold caches, and configurations differ in how much that costs them -- a near tie flipped 21.Conv from id 96 (38.6 us in situ) to id 40
         (49.2 us in situ; 38.7 vs 39.3 isolated: profiles/r06/r06_ab_tapseq_runtime_walker.log).  So, once per plan and before its graph is captured, the
         runner-up of every plain convolution is timed IN its place: one in-situ profile of ops [lo, hi) with every winner, one with every runner-up, a
-        runner-up replaces a winner when it is more than 3 % faster where it runs, and a last profile keeps the mix only if the whole range did not get slower.
+        runner-up replaces a winner when it is more than 3 % faster where it runs -- in that profile AND in a closing profile of the mix, which also has to be no
+        slower as a whole.
         Decisions persist in the tile-choice cache (key + (_INSITU_MARK, plan index)): later processes -- clean rocprof traces, production -- apply them without
         timing.  Y5_DISABLE=insitu_tune switches it off; runner-up plans (Y5_TUNE_RANK=1) are left alone."""
         cands = [c for c in self._insitu if lo <= c["idx"] < hi and c["second"] >= 0 and c["second"] != c["best"]]
@@ -1344,10 +1369,15 @@ class Engine:
                 swapped.append(c)
             else:
                 apply(c, c["best"])
-        if swapped and sum(profile()) > sum(t_best):
-            for c in swapped:
-                apply(c, c["best"])
-            swapped = []
+        if swapped:
+            # second opinion: the mix profiled as a whole -- a swap stays only if it is faster in THIS measurement too (two independent medians: launch noise
+            # alone passes the 3 % bar once in a while, not twice), and nothing stays if the range as a whole got slower
+            t_mix = profile()
+            whole = sum(t_mix) <= sum(t_best)
+            for c in list(swapped):
+                if not whole or t_mix[c["idx"] - lo] >= 0.97 * t_best[c["idx"] - lo]:
+                    apply(c, c["best"])
+                    swapped.remove(c)
         for c in cands:
             _TUNE_CACHE[c["key"] + (_INSITU_MARK, c["idx"])] = (c["second"] if c in swapped else c["best"], -1)
         self.insitu_swaps = [(self.op_names[c["idx"]], c["best"], c["second"]) for c in swapped]
