@@ -1045,6 +1045,10 @@ def main():
             except Exception as e:  # the headline metric must not depend on a secondary probe
                 configs[key] = {"error": f"{type(e).__name__}: {e}"}
 
+    try:   # (the model is released below: what its engines' in-situ refinement swapped is read here)
+        insitu_swaps = [list(s) for e in getattr(model, "_engines", {}).values() for s in getattr(e, "insitu_swaps", [])]
+    except Exception:
+        insitu_swaps = None
     train = None
     if not a.no_train:
         try:
@@ -1163,7 +1167,7 @@ def main():
             from yolov5_amd import engine as _eng
 
             res["config"]["tile_choices"] = {"from_shipped_db": _eng.TUNE_STATS["db_entries"], "races_run_here": _eng.TUNE_STATS["races"],
-                                             "in_situ_swaps": [list(s) for e in getattr(model, "_engines", {}).values() for s in getattr(e, "insitu_swaps", [])]}
+                                             "in_situ_swaps": insitu_swaps}
         except Exception:
             pass
         if pipeline is not None:

@@ -437,6 +437,7 @@ def folded_weights(mods):
 
 _TUNE_CACHE = {}  # conv descriptor (shape/dtype/strides) -> fastest tile configuration id, per process
 _LAST_RACE = [None, None]  # key and (best, runner-up) of the latest autotune_conv call (Engine._refine_in_situ)
+_HEAD_MARK = -778          # key prefix: which build of the fused Detect head (configuration 56 / 87) won the race for that shape
 _INSITU_MARK = -777        # key suffix (_INSITU_MARK, plan index): the configuration the in-situ refinement settled on for that op of that plan
 
 
@@ -1198,14 +1199,18 @@ class Engine:
         args = (dec["ny"], dec["nx"], self.stride_t[lvl], arr, zp, dec["nrows"], dec["row_off"])
         lib, st = self.lib, self._stream()
         # two builds of the fused kernel: four waves x two stages (cfg 56) and eight waves x one stage (cfg 87); timed, faster kept
+        # (the choice between the two is kept in the tile-choice cache like any other race: timed once per shape, the same in every later plan)
         best, tuned = None, int(d.cfg)
-        for hc in (56, 87):
+        hkey = (_HEAD_MARK, int(d.dtype), int(d.B), int(d.H), int(d.W), int(d.C1), int(d.C2), int(d.ldx))
+        _load_tune_cache()
+        known = _TUNE_CACHE.get(hkey)
+        for hc in ((known[0],) if known is not None and known[0] in (56, 87) else (56, 87)):
             d.cfg = hc
             one = C.c_void_p(lib.y5_plan_create())
             try:
                 ms_h = C.c_float(0)
                 if (lib.y5_plan_add_detect_head(one, C.byref(d), ptrs[0], ptrs[1], ptrs[2], *args) == 0
-                        and lib.y5_plan_time_range(one, 0, 1, 1 if mode == "1" else 10, st, C.byref(ms_h)) == 0
+                        and lib.y5_plan_time_range(one, 0, 1, 1 if (mode == "1" and known is not None) else 10, st, C.byref(ms_h)) == 0
                         and (best is None or ms_h.value < best[0])):
                     best = (ms_h.value, hc)
             finally:
@@ -1213,6 +1218,9 @@ class Engine:
         d.cfg = tuned
         if best is None:
             return None  # shape not supported by the fused kernel
+        if known is None:
+            _TUNE_CACHE[hkey] = (best[1], -1)
+            _save_tune_cache()
         if mode != "1":
             two = C.c_void_p(lib.y5_plan_create())
             try:
