@@ -228,7 +228,7 @@ def test_in_situ_refinement_of_the_tuned_plan(dev, monkeypatch, tmp_path):
     assert not hasattr(e0, "insitu_swaps")
     z1, e1 = run(False)
     swaps = getattr(e1, "insitu_swaps", None)
-    assert swaps is not None, "the refinement did not run (no convolution with a runner-up?)"
+    assert swaps is not None and e1.insitu_timed, "the refinement did not run (no convolution with a runner-up?)"
     print(f"\n[in-situ refinement] {len(swaps)} swap(s): {swaps}")
     t0, t1 = dict(e0.plan_table()), dict(e1.plan_table())
     for op, best, second in swaps:
@@ -244,7 +244,7 @@ def test_in_situ_refinement_of_the_tuned_plan(dev, monkeypatch, tmp_path):
         try:
             real(self, lo, hi)
         finally:
-            calls.append(getattr(self, "insitu_swaps", "from-cache"))
+            calls.append("timed" if self.insitu_timed else "from-cache")
 
     monkeypatch.setattr(eng_mod.Engine, "_refine_in_situ", spy)
     z2, e2 = run(False)

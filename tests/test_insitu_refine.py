@@ -72,7 +72,7 @@ def test_refinement_decisions(monkeypatch, tmp_path, clean_cache):
     assert best_a != 0
     eng._insitu = cands(eng)
     eng._refine_in_situ(1, hi)
-    assert lib.calls == 3 and eng.insitu_swaps == [(names[a], best_a, 0)]
+    assert lib.calls == 3 and eng.insitu_timed and eng.insitu_swaps == [(names[a], best_a, 0)]
     assert eng.conv_cfgs[slot[a]] == 0 and eng.conv_cfgs[slot[b]] == best_b
     assert eng_mod._TUNE_CACHE[("t", a, eng_mod._INSITU_MARK, a)] == (0, -1) and eng_mod._TUNE_CACHE[("t", b, eng_mod._INSITU_MARK, b)] == (best_b, -1)
     z_swapped = np.asarray(eng(x)["z"]).astype(np.float32)
@@ -84,7 +84,7 @@ def test_refinement_decisions(monkeypatch, tmp_path, clean_cache):
     eng2.lib = lib2
     eng2._insitu = cands(eng2)
     eng2._refine_in_situ(1, hi)
-    assert lib2.calls == 0 and eng2.conv_cfgs[slot[a]] == 0 and not hasattr(eng2, "insitu_swaps")
+    assert lib2.calls == 0 and eng2.conv_cfgs[slot[a]] == 0 and eng2.insitu_swaps == [(names[a], best_a, 0)] and not eng2.insitu_timed
     np.testing.assert_array_equal(np.asarray(eng2(x)["z"]).astype(np.float32), z_swapped)
 
     # (2b) faster in the runner-up profile, not confirmed by the closing profile: goes back

@@ -437,6 +437,7 @@ def folded_weights(mods):
 
 _TUNE_CACHE = {}  # conv descriptor (shape/dtype/strides) -> fastest tile configuration id, per process
 _LAST_RACE = [None, None]  # key and (best, runner-up) of the latest autotune_conv call (Engine._refine_in_situ)
+_K3PW_MARK = -779          # key prefix: which build of the 3x3 + pointwise fusion (configuration 34 / 81) won the race for that shape
 _HEAD_MARK = -778          # key prefix: which build of the fused Detect head (configuration 56 / 87) won the race for that shape
 _INSITU_MARK = -777        # key suffix (_INSITU_MARK, plan index): the configuration the in-situ refinement settled on for that op of that plan
 
@@ -1095,23 +1096,27 @@ class Engine:
         lib, st = self.lib, self._stream()
         d3 = _lib.ConvDesc.from_buffer_copy(d)
         best_cfg, ms_f = None, C.c_float(0)
-        for cand in (34, 81):  # four waves with two stages each / eight waves with one stage each
+        kkey = (_K3PW_MARK, int(d.dtype), int(d.B), int(d.H), int(d.W), int(d.ldx), int(c3))   # (the race between the two builds is kept like any other)
+        _load_tune_cache()
+        known = _TUNE_CACHE.get(kkey)
+        for cand in ((known[0],) if known is not None and known[0] in (34, 81) else (34, 81)):  # four waves with two stages each / eight waves with one stage each
             d3.cfg = cand
             fused = C.c_void_p(lib.y5_plan_create())
             try:
                 if lib.y5_plan_add_conv_k3pw(fused, C.byref(d3), ptrs[0], ptrs[1], ptrs[2], *args) != 0:
                     continue
                 ms = C.c_float(0)
-                if lib.y5_plan_time_range(fused, 0, 1, 1 if mode == "1" else 10, st, C.byref(ms)) != 0:
+                if lib.y5_plan_time_range(fused, 0, 1, 1 if (mode == "1" and known is not None) else 10, st, C.byref(ms)) != 0:
                     continue
                 if best_cfg is None or ms.value < ms_f.value:
                     best_cfg, ms_f = cand, C.c_float(ms.value)
             finally:
                 lib.y5_plan_destroy(fused)
-            if mode == "1":
-                break
         if best_cfg is None:
             return None
+        if known is None:
+            _TUNE_CACHE[kkey] = (best_cfg, -1)
+            _save_tune_cache()
         d3.cfg = best_cfg
         if mode != "1":
             (H2, W2, C12, ldx2, *_r) = _g
@@ -1350,11 +1355,14 @@ class Engine:
             self.conv_cfgs[c["slot"]] = cfg
 
         stored = [_TUNE_CACHE.get(c["key"] + (_INSITU_MARK, c["idx"])) for c in cands]
+        self.insitu_timed = False
         if all(s is not None for s in stored):
             for c, s in zip(cands, stored):
                 if s[0] != c["best"]:
                     apply(c, s[0])
+            self.insitu_swaps = [(self.op_names[c["idx"]], c["best"], s[0]) for c, s in zip(cands, stored) if s[0] != c["best"]]
             return
+        self.insitu_timed = True
 
         def profile():
             buf = (C.c_float * (hi - lo))()
