@@ -85,7 +85,8 @@ typedef struct {
                                 9 x 33 input halo),
                                 93..94 pointwise (1x1 s1, fp16, C1 % 32 == 0) with K streamed through an LDS ring and the whole 256- / 128-channel N tile
                                 owned by one workgroup of eight waves (256 pixels): the deep 1x1 layers of P4 / P5,
-                                95..96 implicit GEMM on the 256-row / 8-phase ping-pong structure (conv_g8.h; fp16, C1 % 64 == 0, <= 32 taps, Npad <= 2048):
+                                95..96 implicit GEMM on the 256-row / 8-phase ping-pong structure (conv_g8.h; fp16, C1 % 8 == 0 and C1 >= 64 -- a K tile of a layer
+                                with C1 % 64 != 0 spans two taps --, <= 32 taps, Npad <= 2048):
                                 256 pixels x 256 channels per workgroup, K tile 64 in four half-tiles, two wave rows staggered by one barrier, counted
                                 vmcnt(6) once per K tile -- the MFMA-bound 3x3 / deep 1x1 layers; 96: 256 pixels x 128 channels (three half-tiles per K
                                 tile, three K tiles resident) */

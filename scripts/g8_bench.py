@@ -27,6 +27,11 @@ LAYERS = [
     ("18.Conv 3x3s2 128->128 @80", 64, 80, 128, 128, 3, 2, False),
     ("3.Conv 3x3s2 64->128 @160", 64, 160, 64, 128, 3, 2, False),
     ("6.b.cv2 3x3 128->128 @40 +res", 64, 40, 128, 128, 3, 1, True),
+    ("x:3x3 80->80 @320 +res", 16, 320, 80, 80, 3, 1, True),
+    ("x:3x3s2 80->160 @640", 16, 640, 80, 160, 3, 2, False),
+    ("x:3x3 160->160 @160 +res", 16, 160, 160, 160, 3, 1, True),
+    ("x:3x3s2 160->320 @320", 16, 320, 160, 320, 3, 2, False),
+    ("x:1x1 160->160 @320", 16, 320, 160, 160, 1, 1, False),
     ("x:3x3 320->320 @80 +res", 16, 80, 320, 320, 3, 1, True),
     ("x:3x3s2 320->640 @80", 16, 80, 320, 640, 3, 2, False),
     ("x:3x3 640->640 @40 +res", 16, 40, 640, 640, 3, 1, True),
@@ -41,7 +46,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--only", default="")
     ap.add_argument("--cfgs", default="95,96", help="the new ids to race")
-    ap.add_argument("--base", default="8,12,37,38,39,40,41,42,43,44,64,69,70,73,76,93,94", help="ids of the round-5 library to race against")
+    ap.add_argument("--base", default="8,12,37,38,39,40,41,42,43,44,46,50,52,64,69,70,73,74,76,77,93,94", help="ids of the round-5 library to race against")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     lib = _lib.lib()

@@ -113,6 +113,14 @@ CASES = [
     # stride-2 3x3 walks the taps in the class order of Y5ConvParams::tap_seq: two chunks per tap (C1 = 128), odd image sizes, several tiles per workgroup
     (3, 19, 21, 128, 96, 3, 2, 1, 1, False, False, 95, 1, "f16"),
     (3, 19, 21, 128, 96, 3, 2, 1, 1, False, False, 96, 1, "f16"),
+    # C1 % 64 != 0 (the GEN loader: a K tile spans two taps): yolov5x's 80 / 160 and yolov5m's 96 channels; 3x3 s1 with residual, 3x3 s2, 1x1 (K tiles past the only tap)
+    (2, 9, 10, 80, 80, 3, 1, 1, 1, True, False, 95, 1, "f16"),
+    (2, 9, 10, 80, 80, 3, 1, 1, 1, True, False, 96, 1, "f16"),
+    (2, 15, 13, 160, 96, 3, 2, 1, 1, False, False, 95, 0, "f16"),
+    (2, 15, 13, 160, 96, 3, 2, 1, 1, False, False, 96, 0, "f16"),
+    (3, 8, 9, 96, 136, 1, 1, 0, 1, False, False, 95, 1, "f16"),
+    (3, 8, 9, 96, 136, 1, 1, 0, 0, False, False, 96, 1, "f16"),
+    (1, 10, 10, 72, 64, 3, 1, 1, 1, False, False, 96, 0, "f16"),
 ] + [
     # every fp16 tile configuration on one shape with M, N tails and K = 9*64 (uniform) / 9*48 (table for BK64)
     (2, 9, 9, c1, 160, 3, 1, 1, 1, True, False, cfg, 2, "f16") for cfg in list(range(14)) + list(range(22, 30)) + list(range(35, 56)) for c1 in (64, 48)

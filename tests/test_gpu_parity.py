@@ -152,6 +152,17 @@ CONV_CASES = [
     (3, 41, 37, 192, 328, 3, 1, 1, 0, False, False, 96, 24, "f16"),
     (4, 40, 40, 64, 384, 1, 1, 0, 1, False, False, 96, 8, "f16"),
     (8, 20, 20, 128, 136, 1, 1, 0, 1, False, False, 96, 1, "f16"),
+    # ... C1 % 64 != 0 (GEN loader: K tiles that span two taps): yolov5x's 80- / 160-channel layers (Bottleneck.cv2 at 320^2 / 160^2 with residual, 1.Conv / 3.Conv
+    # at stride 2), yolov5m's 96 / 192, a 1x1 whose last K tile runs past the only tap, several tiles per workgroup, tails
+    (2, 160, 160, 80, 80, 3, 1, 1, 1, True, False, 96, 0, "f16"),
+    (2, 160, 160, 80, 80, 3, 1, 1, 1, True, False, 95, 0, "f16"),
+    (2, 160, 160, 80, 160, 3, 2, 1, 1, False, False, 96, 0, "f16"),
+    (4, 80, 80, 160, 160, 3, 1, 1, 1, True, False, 96, 0, "f16"),
+    (4, 80, 80, 160, 320, 3, 2, 1, 1, False, False, 95, 0, "f16"),
+    (3, 41, 37, 96, 200, 3, 1, 1, 0, False, False, 96, 24, "f16"),
+    (3, 41, 37, 96, 200, 3, 1, 1, 0, False, False, 95, 24, "f16"),
+    (4, 40, 40, 160, 320, 1, 1, 0, 1, False, False, 96, 8, "f16"),
+    (4, 40, 40, 192, 96, 1, 1, 0, 1, False, False, 95, 0, "f16"),
 ]
 
 

@@ -78,5 +78,6 @@ def test_lds_dma_counts_of_the_counted_wait_kernels_are_pinned(unit):
     got = isa_counts.counts_of(unit)
     assert got == want, {k: (got.get(k), want.get(k)) for k in set(got) | set(want) if got.get(k) != want.get(k)}
     if unit == "convg8.hip":
-        assert got["_Z17y5_conv_g8_kernelILb0ELb0EEv12Y5ConvParams"] == 22 and got["_Z18y5_conv_g8n_kernelILb0ELb0EEv12Y5ConvParams"] == 20
-        assert got["_Z17y5_conv_g8_kernelILb0ELb1EEv12Y5ConvParams"] == 22 and got["_Z18y5_conv_g8n_kernelILb0ELb1EEv12Y5ConvParams"] == 20   # (class-ordered taps)
+        assert got["_Z17y5_conv_g8_kernelILb0ELb0ELb0EEv12Y5ConvParams"] == 22 and got["_Z18y5_conv_g8n_kernelILb0ELb0ELb0EEv12Y5ConvParams"] == 20
+        assert got["_Z17y5_conv_g8_kernelILb0ELb1ELb0EEv12Y5ConvParams"] == 22 and got["_Z18y5_conv_g8n_kernelILb0ELb1ELb0EEv12Y5ConvParams"] == 20   # (class-ordered taps)
+        assert got["_Z17y5_conv_g8_kernelILb0ELb0ELb1EEv12Y5ConvParams"] == 22 and got["_Z18y5_conv_g8n_kernelILb0ELb0ELb1EEv12Y5ConvParams"] == 20   # (general-C1 loader)

@@ -582,8 +582,8 @@ static int conv2d_fwd_impl(const y5_conv_desc* d, const void* x, const void* w_p
   }
 
   if (g8) {
-    if (d->dtype != Y5_F16 || !y || (y_up2 && !d->split_n) || placed || (d->C1 & 63) || (d->Kpad & 63) || d->KH * d->KW > 32 || d->Npad > 2048)
-      return y5_fail(Y5_ERR_UNSUPPORTED, "conv: the 8-phase configurations need an fp16 layer with C1 % 64 == 0, Kpad % 64 == 0, at most 32 taps, Npad <= 2048, no replica / placement");
+    if (d->dtype != Y5_F16 || !y || (y_up2 && !d->split_n) || placed || (d->C1 & 7) || d->C1 < 64 || (d->Kpad & 63) || d->KH * d->KW > 32 || d->Npad > 2048)
+      return y5_fail(Y5_ERR_UNSUPPORTED, "conv: the 8-phase configurations need an fp16 layer with C1 % 8 == 0, C1 >= 64, Kpad % 64 == 0, at most 32 taps, Npad <= 2048, no replica / placement");
     return y5_launch_g8_by_cfg(p, cfg - kG8_0, d->max_blocks, stream);
   }
   if (pwk) {

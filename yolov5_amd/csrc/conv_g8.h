@@ -104,9 +104,15 @@ __device__ unsigned long long y5_g8_dbg[512 * 2 * 8];
 // SEQ: the K loop walks the taps in the order of Y5ConvParams::tap_seq (stride-2 3x3 launches) instead of the natural (kh, kw) order.  A separate instantiation:
 // the look-up walker costs a few scalar instructions per K tile inside the phase that holds the counted wait, and with it compiled into every launch the forward
 // lost 2.6 % (profiles/r06/r06_ab_tapseq_runtime_walker.log) -- the other layers keep the incremental walker untouched.
-template <bool UP2, bool SEQ = false>
+// GEN: input channel counts that are not multiples of the 64-channel K tile (C1 % 8 == 0, C1 >= 64: yolov5x's 80 / 160, yolov5m's 96 / 192).  K stays the
+// contiguous (kh, kw, c) axis of the packed filter, so a K tile may begin inside one tap and end inside the next: the first n_lo 16-byte slots of a staged row
+// come from tap t at channel c_start + 8 s, the others from tap t + 1 at channel 8 (s - n_lo).  A slot never straddles a tap (C1 % 8 == 0) and a tile never spans
+// three (C1 >= 64).  Two scalar (offset, mask bit) pairs per K tile, one per-lane select per load; K tiles past the last tap (Kpad > K) name tap KH * KW, whose
+// mask bit is always set (zero fill) -- the filter is zero there as well.  Again a separate instantiation: the C1 % 64 == 0 layers run the code they ran before.
+template <bool UP2, bool SEQ = false, bool GEN = false>
 __global__ __launch_bounds__(512, 2)
 void y5_conv_g8_kernel(const Y5ConvParams p) {
+  static_assert(!GEN || (!UP2 && !SEQ), "the general-C1 loader serves plain layers in natural tap order");
   typedef half_t T;
   using Gm = Y5G8Geom;
   constexpr int HT = Gm::HT, BUF = Gm::BUF;
@@ -147,6 +153,15 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
   int u_kh = 0, u_kw = 0, u_c0 = 0, u_ts = 0, s_t = 0, s_kc = 0;
   int st_tap_off = 0, st_tap_bit = 0;
   unsigned st_kcb = 0;
+  int st_off_hi = 0, st_nlo = 8, nx_off_hi = 0, nx_nlo = 8;   // GEN: the K tile's second tap (offset already minus n_lo slots) and its first slot
+  const int g_sl0 = lslot ^ ((((wave * 2 + 0) * 8 + lrow) >> 1) & 7), g_sl1 = lslot ^ ((((wave * 2 + 1) * 8 + lrow) >> 1) & 7);   // GEN: this lane's source slot per instruction
+  auto gen_hi = [&](int& off_hi, int& nlo) __attribute__((always_inline)) {   // from (u_kh, u_kw, u_c0)
+    nlo = (p.C1 - u_c0) >> 3;
+    nlo = nlo < 8 ? nlo : 8;
+    int kh1 = u_kh, kw1 = u_kw + 1;
+    if (kw1 == p.KW) { kw1 = 0; ++kh1; }
+    off_hi = ((kh1 * p.W + kw1) * p.ldx) * 2 - nlo * 16;
+  };
   const int kw_r = (256 + p.KW - 1) / p.KW;   // t / KW == (t * kw_r) >> 8 for t < 32, KW <= 7 (the tap-sequence walk)
   auto tap_at = [&](int ts) __attribute__((always_inline)) {   // position ts of the launch's tap sequence -> (u_kh, u_kw)
     const int t = (int)((unsigned)(p.tap_seq >> (ts * 4)) & 15u);
@@ -189,6 +204,7 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
     st_tap_off = ((u_kh * p.W + u_kw) * p.ldx + u_c0) * 2;
     st_tap_bit = u_kh * p.KW + u_kw;
     st_kcb = SEQ ? (unsigned)((st_tap_bit * p.C1 + u_c0) * 2) : (unsigned)(s_kc * 128);
+    if constexpr (GEN) gen_hi(st_off_hi, st_nlo);
     if constexpr (UP2) st_up = u_c0 < p.up_c;   // (1x1 layer: st_tap_off is the chunk's channel offset; up_c % 64 == 0, a chunk never straddles the boundary)
   };
   // The loader's step to the next K tile in two halves (round 6, after the phase stamps): the SCALAR walker runs in q4, the phase with the shortest load segment
@@ -212,7 +228,7 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
       }
     } else {
       if (u_c0 >= p.C1) {
-        u_c0 = 0;
+        u_c0 = GEN ? u_c0 - p.C1 : 0;
         if (++u_kw == p.KW) { u_kw = 0; ++u_kh; }
       }
       nx_new = false;
@@ -225,6 +241,7 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
     nx_tap_off = ((u_kh * p.W + u_kw) * p.ldx + u_c0) * 2;
     nx_tap_bit = u_kh * p.KW + u_kw;
     nx_kcb = SEQ ? (unsigned)((nx_tap_bit * p.C1 + u_c0) * 2) : (unsigned)(s_kc * 128);
+    if constexpr (GEN) gen_hi(nx_off_hi, nx_nlo);
     if constexpr (UP2) nx_up = u_c0 < p.up_c;
   };
   auto advance_commit = [&]() __attribute__((always_inline)) {
@@ -233,6 +250,7 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
       else loader_kill();
     }
     st_tap_off = nx_tap_off; st_tap_bit = nx_tap_bit; st_kcb = nx_kcb;
+    if constexpr (GEN) { st_off_hi = nx_off_hi; st_nlo = nx_nlo; }
     if constexpr (UP2) st_up = nx_up;
   };
   auto advance = [&]() __attribute__((always_inline)) { advance_scalar(); advance_commit(); };   // (prologue)
@@ -249,7 +267,13 @@ void y5_conv_g8_kernel(const Y5ConvParams p) {
           continue;
         }
       }
-      const unsigned voff = (unsigned)(a_base[s][jj] + st_tap_off) | ((a_mask[s][jj] >> st_tap_bit) << 31);
+      unsigned voff;
+      if constexpr (GEN) {
+        const bool hi = (jj ? g_sl1 : g_sl0) >= st_nlo;
+        voff = (unsigned)(a_base[s][jj] + (hi ? st_off_hi : st_tap_off)) | ((a_mask[s][jj] >> (hi ? st_tap_bit + 1 : st_tap_bit)) << 31);
+      } else {
+        voff = (unsigned)(a_base[s][jj] + st_tap_off) | ((a_mask[s][jj] >> st_tap_bit) << 31);
+      }
       y5_bglds16(xrs, voff, buf + s * HT + (wave * 2 + jj) * 1024);
     }
   };
@@ -496,9 +520,10 @@ struct Y5G8nGeom {
   static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
-template <bool UP2, bool SEQ = false>
+template <bool UP2, bool SEQ = false, bool GEN = false>
 __global__ __launch_bounds__(512, 2)
 void y5_conv_g8n_kernel(const Y5ConvParams p) {
+  static_assert(!GEN || (!UP2 && !SEQ), "the general-C1 loader serves plain layers in natural tap order");
   typedef half_t T;
   using Gm = Y5G8nGeom;
   constexpr int HT = Gm::HT, BUF = Gm::BUF;
@@ -531,6 +556,8 @@ void y5_conv_g8n_kernel(const Y5ConvParams p) {
   unsigned w_off[2];
   int u_kh = 0, u_kw = 0, u_c0 = 0, u_ts = 0, a_t = 0, a_kc = 0, w_t = 0, w_kc = 0, w_ts = 0, w_c0 = 0;
   int st_tap_off = 0, st_tap_bit = 0;
+  int st_off_hi = 0, st_nlo = 8;   // GEN (see y5_conv_g8_kernel)
+  const int g_sl0 = lslot ^ ((((wave * 2 + 0) * 8 + lrow) >> 1) & 7), g_sl1 = lslot ^ ((((wave * 2 + 1) * 8 + lrow) >> 1) & 7);
   unsigned w_kcb = 0;   // byte offset of the filter walker's K tile inside a filter row
   const int kw_r = (256 + p.KW - 1) / p.KW;   // (see y5_conv_g8_kernel)
   auto tap_at = [&](int ts) __attribute__((always_inline)) {
@@ -575,6 +602,13 @@ void y5_conv_g8n_kernel(const Y5ConvParams p) {
   auto tap_update = [&]() {
     st_tap_off = ((u_kh * p.W + u_kw) * p.ldx + u_c0) * 2;
     st_tap_bit = u_kh * p.KW + u_kw;
+    if constexpr (GEN) {
+      st_nlo = (p.C1 - u_c0) >> 3;
+      st_nlo = st_nlo < 8 ? st_nlo : 8;
+      int kh1 = u_kh, kw1 = u_kw + 1;
+      if (kw1 == p.KW) { kw1 = 0; ++kh1; }
+      st_off_hi = ((kh1 * p.W + kw1) * p.ldx) * 2 - st_nlo * 16;
+    }
     if constexpr (UP2) st_up = u_c0 < p.up_c;
   };
   auto adv_act = [&]() __attribute__((always_inline)) {
@@ -583,7 +617,7 @@ void y5_conv_g8n_kernel(const Y5ConvParams p) {
       if (u_c0 >= p.C1 && a_kc + 1 < nk) { u_c0 = 0; tap_at(++u_ts); }
     } else {
       if (u_c0 >= p.C1) {
-        u_c0 = 0;
+        u_c0 = GEN ? u_c0 - p.C1 : 0;
         if (++u_kw == p.KW) { u_kw = 0; ++u_kh; }
       }
     }
@@ -622,7 +656,13 @@ void y5_conv_g8n_kernel(const Y5ConvParams p) {
           continue;
         }
       }
-      const unsigned voff = (unsigned)(a_base[s][jj] + st_tap_off) | ((a_mask[s][jj] >> st_tap_bit) << 31);
+      unsigned voff;
+      if constexpr (GEN) {
+        const bool hi = (jj ? g_sl1 : g_sl0) >= st_nlo;
+        voff = (unsigned)(a_base[s][jj] + (hi ? st_off_hi : st_tap_off)) | ((a_mask[s][jj] >> (hi ? st_tap_bit + 1 : st_tap_bit)) << 31);
+      } else {
+        voff = (unsigned)(a_base[s][jj] + st_tap_off) | ((a_mask[s][jj] >> st_tap_bit) << 31);
+      }
       y5_bglds16(xrs, voff, buf + s * HT + (wave * 2 + jj) * 1024);
     }
   };

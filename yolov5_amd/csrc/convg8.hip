@@ -11,7 +11,7 @@ static int launch_g8(K kern, const Y5ConvParams& p0, int max_blocks, hipStream_t
   Y5ConvParams p = p0;
   p.tilesM = (p.M + Gm::BM - 1) / Gm::BM;
   p.tilesN = (p.Npad + Gm::BN - 1) / Gm::BN;
-  p.nk = p.K / Gm::BK;
+  p.nk = (p.K + Gm::BK - 1) / Gm::BK;   // (C1 % 64 != 0: the last K tile runs into the zero padding of the filter rows, Kpad % 64 == 0)
   y5_conv_set_fastdiv(p);
   // Stride-2 3x3: taps grouped by the class of input pixel they touch -- (odd row, odd column): the four corner taps; (odd, even): (0,1), (2,1); (even, odd):
   // (1,0), (1,2); (even, even): the centre -- so every re-request of a cache line follows within the next three K tiles (Y5ConvParams::tap_seq)
@@ -20,10 +20,13 @@ static int launch_g8(K kern, const Y5ConvParams& p0, int max_blocks, hipStream_t
     static const int seq[9] = {0, 2, 6, 8, 1, 7, 3, 5, 4};
     for (int i = 0; i < 9; ++i) p.tap_seq |= (unsigned long long)seq[i] << (4 * i);
   }
-  static const void* attr_done[3] = {nullptr, nullptr, nullptr};   // (the instantiations of one geometry share this function: same pointer type)
-  if (attr_done[0] != reinterpret_cast<const void*>(kern) && attr_done[1] != reinterpret_cast<const void*>(kern) && attr_done[2] != reinterpret_cast<const void*>(kern)) {
+  static const void* attr_done[4] = {nullptr, nullptr, nullptr, nullptr};   // (the instantiations of one geometry share this function: same pointer type)
+  bool seen = false;
+  for (const void* a : attr_done) seen = seen || a == reinterpret_cast<const void*>(kern);
+  if (!seen) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done[!attr_done[0] ? 0 : !attr_done[1] ? 1 : 2] = reinterpret_cast<const void*>(kern);
+    for (const void*& a : attr_done)
+      if (!a) { a = reinterpret_cast<const void*>(kern); break; }
   }
   const long long ntiles = (long long)p.tilesM * p.tilesN;
   if (ntiles <= 0 || ntiles > 0x7fffffffLL) return y5_fail(Y5_ERR_BAD_ARG, "conv: grid out of range");
@@ -35,15 +38,18 @@ static int launch_g8(K kern, const Y5ConvParams& p0, int max_blocks, hipStream_t
 }
 
 int y5_launch_g8_by_cfg(const Y5ConvParams& p, int idx, int max_blocks, hipStream_t stream) {
-  if (p.C1 % 64 || p.KH * p.KW > 32 || p.Kpad % 64 || p.Npad > Y5G8Geom::MAXN)
-    return y5_fail(Y5_ERR_UNSUPPORTED, "conv: the 8-phase configurations need C1 % 64 == 0, Kpad % 64 == 0, KH * KW <= 32 and Npad <= 2048");
   const bool up = p.up_c > 0;   // virtual Upsample + Concat loader (1x1 s1 layers; validated by the caller)
-  const bool seq = !up && p.KH == 3 && p.KW == 3 && p.SH == 2 && p.SW == 2;   // class-ordered taps (launch_g8 fills Y5ConvParams::tap_seq)
+  const bool gen = (p.C1 % 64) != 0;   // general-C1 loader (conv_g8.h GEN): a K tile may span two taps
+  if (p.C1 % 8 || p.C1 < 64 || p.KH * p.KW > (gen ? 31 : 32) || p.Kpad % 64 || p.Kpad < p.K || p.Npad > Y5G8Geom::MAXN || (gen && up))
+    return y5_fail(Y5_ERR_UNSUPPORTED, "conv: the 8-phase configurations need C1 % 8 == 0, C1 >= 64 (C1 % 64 == 0 with up_c > 0), Kpad % 64 == 0, KH * KW <= 32 (31 unless C1 % 64 == 0) and Npad <= 2048");
+  const bool seq = !up && !gen && p.KH == 3 && p.KW == 3 && p.SH == 2 && p.SW == 2;   // class-ordered taps (launch_g8 fills Y5ConvParams::tap_seq)
   switch (idx) {
     case 0:
+      if (gen) return launch_g8<Y5G8Geom>(y5_conv_g8_kernel<false, false, true>, p, max_blocks, stream);
       if (seq) return launch_g8<Y5G8Geom>(y5_conv_g8_kernel<false, true>, p, max_blocks, stream, true);
       return up ? launch_g8<Y5G8Geom>(y5_conv_g8_kernel<true>, p, max_blocks, stream) : launch_g8<Y5G8Geom>(y5_conv_g8_kernel<false>, p, max_blocks, stream);
     case 1:
+      if (gen) return launch_g8<Y5G8nGeom>(y5_conv_g8n_kernel<false, false, true>, p, max_blocks, stream);
       if (seq) return launch_g8<Y5G8nGeom>(y5_conv_g8n_kernel<false, true>, p, max_blocks, stream, true);
       return up ? launch_g8<Y5G8nGeom>(y5_conv_g8n_kernel<true>, p, max_blocks, stream) : launch_g8<Y5G8nGeom>(y5_conv_g8n_kernel<false>, p, max_blocks, stream);
   }
