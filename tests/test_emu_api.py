@@ -338,3 +338,43 @@ def test_shipped_tune_database_seeds_the_choices(tmp_path, monkeypatch):
         eng._TUNE_CACHE.clear(); eng._TUNE_CACHE.update(saved)
         eng._TUNE_FILE_STATE.clear(); eng._TUNE_FILE_STATE.update(state)
         eng.TUNE_STATS.update(stats)
+
+
+def test_committed_tune_database_is_well_formed():
+    """yolov5_amd/tune_db.json as committed: valid JSON, every key parses into the integer / boolean tuple the cache uses, every value is a pair of integers ((best, runner-up) configuration ids for
+    the forward races), the in-situ decisions name one of their race's two candidates.  Whether it is USED is decided at run time by the library hash it carries (a
+    database written for other kernels is ignored, test_shipped_tune_database_seeds_the_choices); when the hash matches the library built here that is asserted too."""
+    import hashlib
+    import json
+    import os
+
+    from yolov5_amd import _lib, engine as eng
+
+    if not os.path.isfile(eng.TUNE_DB_PATH):
+        pytest.skip("no shipped database")
+    d = json.load(open(eng.TUNE_DB_PATH))
+    sha = d.pop("__lib_sha16__")
+    assert isinstance(sha, str) and len(sha) == 16
+    assert len(d) >= 100
+    parsed = {}
+    for k, v in d.items():
+        key = tuple(int(x) if x not in ("True", "False") else x == "True" for x in k.split(","))
+        assert isinstance(v, list) and len(v) == 2 and all(isinstance(c, int) for c in v), (k, v)   # (the training plan's entries pack a configuration and a grid size)
+        if key[0] >= 0:
+            assert all(-1 <= c < 200 for c in v), (k, v)   # forward races: configuration ids
+        parsed[key] = tuple(v)
+    marks = 0
+    for key, v in parsed.items():
+        if len(key) > 2 and key[-2] == eng._INSITU_MARK:
+            marks += 1
+            race = parsed.get(key[:-2])
+            assert race is not None and v[0] in race, (key, v, race)
+    assert marks >= 20
+    if os.path.isfile(_lib.LIB_PATH) and hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16] == sha:
+        saved, state = dict(eng._TUNE_CACHE), dict(eng._TUNE_FILE_STATE)
+        try:
+            eng._TUNE_FILE_STATE.pop("stamp", None)
+            assert eng._read_tune_file(eng.TUNE_DB_PATH) == parsed
+        finally:
+            eng._TUNE_CACHE.clear(); eng._TUNE_CACHE.update(saved)
+            eng._TUNE_FILE_STATE.clear(); eng._TUNE_FILE_STATE.update(state)
